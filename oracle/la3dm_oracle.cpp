@@ -1,0 +1,790 @@
+// la3dm_oracle.cpp — CPU restatement of la3dm's per-scan BGK occupancy-inference path.
+//
+// *** TEST INFRASTRUCTURE ONLY. ***  This file is the parity oracle for the HIP
+// implementation in la3dm_amd/csrc.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load it.  Nothing in the product path links,
+// imports or calls it.
+//
+// It restates, in strict fp32 (build with -ffp-contract=off, no -ffast-math), the
+// reference algorithm of RobustFieldAutonomyLab/la3dm.  Every function cites the
+// reference file:line it follows (paths relative to the reference checkout).
+//
+// PARITY PINNING STATUS
+//  * Block hashing, voxel LUT, leaf enumeration order, Occupancy::update, prune and
+//    the R-tree closed-box inclusion rule are PINNED: tests compare this file with
+//    the reference's own std-only sources compiled in place (oracle/_ref, built by
+//    oracle/Makefile) and with golden vectors captured from them (tests/golden).
+//  * The kernel arithmetic (include/bgkoctomap/bgkinference.h) runs on Eigen and the
+//    front-end filter on pcl::VoxelGrid.  Neither library is vendored by the
+//    reference (Eigen arrives through PCL; both unpinned, README targets ROS
+//    Noetic => Eigen 3.3.7 / PCL 1.10) and neither is installed here, and the
+//    reference ships no tests or golden vectors.  For those two boundaries this
+//    oracle restates the published algorithms and is  **parity unpinned**.
+//
+// Conventions: all arithmetic that the reference does in float is done in float
+// here, every float->double promotion the reference performs is reproduced.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <queue>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// include/bgkoctomap/bgkoctree_node.h:10-12
+enum : uint8_t { ST_FREE = 0, ST_OCCUPIED = 1, ST_UNKNOWN = 2, ST_PRUNED = 3 };
+
+struct Params {
+    float resolution;
+    int block_depth;
+    float sf2, ell;
+    float free_thresh, occupied_thresh, var_thresh;
+    float prior_A, prior_B;
+    float block_size;  // src/bgkoctomap/bgkoctomap.cpp:41
+};
+
+// include/bgkoctomap/bgkoctree_node.h:76-81 (classified, m_A, m_B, state)
+struct Node {
+    uint8_t classified;
+    float A, B;
+    uint8_t state;
+};
+
+struct V3 {
+    float x, y, z;
+};
+
+// ---------------------------------------------------------------------------
+// Node: src/bgkoctomap/bgkoctree_node.cpp:27-44, include/.../bgkoctree_node.h:60
+// ---------------------------------------------------------------------------
+inline float node_var(const Node &n) {
+    // (m_A * m_B) / ((m_A + m_B) * (m_A + m_B) * (m_A + m_B + 1.0f))
+    float s = n.A + n.B;
+    float num = n.A * n.B;
+    float den = (s * s) * (s + 1.0f);
+    return num / den;
+}
+inline float node_prob(const Node &n) { return n.A / (n.A + n.B); }
+
+inline void node_update(const Params &p, Node &n, float ybar, float kbar) {
+    n.classified = 1;
+    n.A += ybar;
+    n.B += kbar - ybar;
+    float var = node_var(n);
+    if (var > p.var_thresh)
+        n.state = ST_UNKNOWN;
+    else {
+        float pr = node_prob(n);
+        n.state = pr > p.occupied_thresh ? ST_OCCUPIED : (pr < p.free_thresh ? ST_FREE : ST_UNKNOWN);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Block hashing: src/bgkoctomap/bgkblock.cpp:73-101
+// ---------------------------------------------------------------------------
+inline int64_t block_to_hash_key(const Params &p, float x, float y, float z) {
+    double s = (double)p.block_size;
+    return (int64_t(x / s + 524288.5) << 40) | (int64_t(y / s + 524288.5) << 20) | (int64_t(z / s + 524288.5));
+}
+inline V3 hash_key_to_block(const Params &p, int64_t key) {
+    V3 c;
+    c.x = ((key >> 40) - 524288) * p.block_size;  // int64 -> float, float multiply
+    c.y = (((key >> 20) & 0xFFFFF) - 524288) * p.block_size;
+    c.z = ((key & 0xFFFFF) - 524288) * p.block_size;
+    return c;
+}
+// order: self,+x,-x,+y,-y,+z,-z  (bgkblock.cpp:85-101 and 114-130)
+inline void extended_block_from_center(const Params &p, V3 c, int64_t key0, int64_t out[7]) {
+    out[0] = key0;
+    for (int i = 0; i < 6; ++i) {
+        float ex = (i / 2 == 0) ? (i % 2 == 0 ? p.block_size : -p.block_size) : 0;
+        float ey = (i / 2 == 1) ? (i % 2 == 0 ? p.block_size : -p.block_size) : 0;
+        float ez = (i / 2 == 2) ? (i % 2 == 0 ? p.block_size : -p.block_size) : 0;
+        out[i + 1] = block_to_hash_key(p, ex + c.x, ey + c.y, ez + c.z);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Voxel LUT: src/bgkoctomap/bgkblock.cpp:7-32 (BFS, f64 intermediates)
+// lut[depth][index]
+// ---------------------------------------------------------------------------
+std::vector<std::vector<V3>> build_lut(float resolution, int max_depth) {
+    std::vector<std::vector<V3>> lut(max_depth);
+    std::queue<V3> q;
+    q.push(V3{0.0f, 0.0f, 0.0f});
+    for (int depth = 0; depth < max_depth; ++depth) {
+        size_t q_size = q.size();
+        float half_size = (float)(resolution * pow(2, max_depth - depth - 1) * 0.5f);
+        for (size_t index = 0; index < q_size; ++index) {
+            V3 center = q.front();
+            q.pop();
+            lut[depth].push_back(center);
+            if (depth == max_depth - 1) continue;
+            for (int i = 0; i < 8; ++i) {
+                float x = (float)(center.x + half_size * (i & 4 ? 0.5 : -0.5));
+                float y = (float)(center.y + half_size * (i & 2 ? 0.5 : -0.5));
+                float z = (float)(center.z + half_size * (i & 1 ? 0.5 : -0.5));
+                q.push(V3{x, y, z});
+            }
+        }
+    }
+    return lut;
+}
+
+// ---------------------------------------------------------------------------
+// OcTree / Block: src/bgkoctomap/bgkoctree.cpp:18-27,72-82,101-148,
+//                 include/bgkoctomap/bgkoctree.h:62-147
+// ---------------------------------------------------------------------------
+struct Block {
+    V3 center;
+    std::vector<std::vector<Node>> layer;  // empty vector == deleted layer
+    std::vector<char> alive;
+};
+
+Block *block_new(const Params &p, V3 center) {
+    Block *b = new Block;
+    b->center = center;
+    b->layer.resize(p.block_depth);
+    b->alive.assign(p.block_depth, 1);
+    size_t n = 1;
+    for (int d = 0; d < p.block_depth; ++d, n *= 8) {
+        Node def{0, p.prior_A, p.prior_B, ST_UNKNOWN};  // bgkoctree_node.h:34
+        b->layer[d].assign(n, def);
+    }
+    return b;
+}
+
+inline bool is_leaf(const Params &p, const Block &b, int depth, int index) {
+    if (b.alive[depth] && b.layer[depth][index].state != ST_PRUNED) {
+        if (depth + 1 < p.block_depth) {
+            if (!b.alive[depth + 1] || b.layer[depth + 1][index * 8].state == ST_PRUNED) return true;
+        } else
+            return true;
+    }
+    return false;
+}
+
+// Leaf order of OcTree::LeafIterator: explicit stack, children pushed 0..7, popped 7..0.
+void enumerate_leaves(const Params &p, const Block &b, std::vector<int> &keys) {
+    keys.clear();
+    std::vector<std::pair<int, int>> st;
+    st.emplace_back(0, 0);
+    while (!st.empty()) {
+        auto top = st.back();
+        if (is_leaf(p, b, top.first, top.second)) {
+            keys.push_back((top.first << 16) + top.second);
+            st.pop_back();
+        } else {
+            st.pop_back();
+            // single_inc(): expands unconditionally; guard the array bound the
+            // reference never reaches (a non-leaf at the last depth is PRUNED and
+            // is only reachable below a collapsed parent, which is a leaf).
+            if (top.first + 1 < p.block_depth)
+                for (int i = 0; i < 8; ++i) st.emplace_back(top.first + 1, top.second * 8 + i);
+        }
+    }
+}
+
+bool block_prune(const Params &p, Block &b) {
+    bool pruned = false;
+    for (int depth = p.block_depth - 1; depth > 0; --depth) {
+        if (!b.alive[depth]) continue;
+        std::vector<Node> &layer = b.layer[depth];
+        std::vector<Node> &parent = b.layer[depth - 1];
+        bool empty_layer = true;
+        size_t n = layer.size();
+        for (size_t index = 0; index < n; index += 8) {
+            uint8_t state = layer[index].state;
+            if (state == ST_UNKNOWN) {
+                empty_layer = false;
+                continue;
+            }
+            if (state == ST_PRUNED) continue;
+            bool collapsible = true;
+            for (int i = 1; i < 8; ++i)
+                if (layer[index + i].state != state) collapsible = false;
+            if (collapsible) {
+                // Occupancy::operator= copies m_A, m_B, state but NOT classified
+                // (bgkoctree_node.h:40-45)
+                Node &par = parent[index / 8];
+                par.A = layer[index].A;
+                par.B = layer[index].B;
+                par.state = layer[index].state;
+                for (int i = 0; i < 8; ++i) layer[index + i].state = ST_PRUNED;
+                pruned = true;
+            } else
+                empty_layer = false;
+        }
+        if (empty_layer) {
+            b.alive[depth] = 0;
+            std::vector<Node>().swap(b.layer[depth]);
+        }
+    }
+    return pruned;
+}
+
+// ---------------------------------------------------------------------------
+// Sparse kernel: include/bgkoctomap/bgkinference.h:113-126 (elementwise, fp32)
+// r is the distance of the ell-prescaled coordinates.
+// ---------------------------------------------------------------------------
+inline float cov_sparse_elem(float r, float sf2) {
+    float t = (r * 2.0f) * 3.1415926f;
+    float a = ((2.0f + cosf(t)) * (1.0f - r)) / 3.0f;
+    float b = sinf(t) / (2.0f * 3.1415926f);
+    float k = (a + b) * sf2;
+    if (k < 0.0) k = 0.0f;
+    return k;
+}
+
+// BGKInference::predict, bgkinference.h:73-79 with dist :88-93.
+// xs: M test points, x: N training points (both un-scaled); division by ell per
+// coordinate first (:114), difference, dx^2 + (dy^2 + dz^2), sqrt.
+void bgk_predict(float sf2, float ell, const float *xs, int M, const float *x, const float *y, int N, float *ybar,
+                 float *kbar) {
+    std::vector<float> xsn((size_t)M * 3), xn((size_t)N * 3);
+    for (int i = 0; i < M * 3; ++i) xsn[i] = xs[i] / ell;
+    for (int i = 0; i < N * 3; ++i) xn[i] = x[i] / ell;
+    for (int i = 0; i < M; ++i) {
+        float yb = 0.0f, kb = 0.0f;
+        for (int j = 0; j < N; ++j) {
+            float dx = xn[3 * j + 0] - xsn[3 * i + 0];
+            float dy = xn[3 * j + 1] - xsn[3 * i + 1];
+            float dz = xn[3 * j + 2] - xsn[3 * i + 2];
+            float d2 = dx * dx + (dy * dy + dz * dz);
+            float r = sqrtf(d2);
+            float k = cov_sparse_elem(r, sf2);
+            yb += k * y[j];  // Ks * y
+            kb += k;         // Ks.rowwise().sum()
+        }
+        ybar[i] = yb;
+        kbar[i] = kb;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pcl::VoxelGrid<PointXYZ>::applyFilter restated (PCL 1.10 filters/impl/voxel_grid.hpp;
+// third-party, absent from /root/reference, version unpinned => parity unpinned).
+// downsample_all_data_=true, min_points_per_voxel_=0, no field filter.
+// Call site: src/bgkoctomap/bgkoctomap.cpp:419-431.
+// ---------------------------------------------------------------------------
+void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
+    out.clear();
+    if (in.empty()) return;
+    float inv = 1.0f / leaf;  // inverse_leaf_size_ = Ones / leaf_size_
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(),
+                   std::numeric_limits<float>::max()};
+    float mx[3] = {-mn[0], -mn[0], -mn[0]};
+    for (const V3 &p : in) {
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
+        mx[0] = std::max(mx[0], p.x); mx[1] = std::max(mx[1], p.y); mx[2] = std::max(mx[2], p.z);
+    }
+    int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1;
+    int64_t dy = (int64_t)((mx[1] - mn[1]) * inv) + 1;
+    int64_t dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)std::numeric_limits<int32_t>::max()) {
+        out = in;  // "Leaf size is too small ... Integer indices would overflow."
+        return;
+    }
+    int min_b[3], max_b[3], div_b[3], mul[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = (int)std::floor(mn[a] * inv);
+        max_b[a] = (int)std::floor(mx[a] * inv);
+        div_b[a] = max_b[a] - min_b[a] + 1;
+    }
+    mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1];
+    std::vector<std::pair<unsigned, unsigned>> iv;
+    iv.reserve(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+        const V3 &p = in[i];
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        int i0 = (int)(std::floor(p.x * inv) - (float)min_b[0]);
+        int i1 = (int)(std::floor(p.y * inv) - (float)min_b[1]);
+        int i2 = (int)(std::floor(p.z * inv) - (float)min_b[2]);
+        int idx = i0 * mul[0] + i1 * mul[1] + i2 * mul[2];
+        iv.emplace_back((unsigned)idx, (unsigned)i);
+    }
+    // std::sort in PCL is not stable; equal-cell order is implementation defined.
+    // Restated as ascending cloud index inside a cell.
+    std::sort(iv.begin(), iv.end());
+    size_t i = 0;
+    while (i < iv.size()) {
+        size_t j = i + 1;
+        while (j < iv.size() && iv[j].first == iv[i].first) ++j;
+        // CentroidPoint / AccumulatorXYZ: float sums, divide by (float)n
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (size_t k = i; k < j; ++k) {
+            const V3 &p = in[iv[k].second];
+            sx += p.x; sy += p.y; sz += p.z;
+        }
+        float n = (float)(j - i);
+        out.push_back(V3{sx / n, sy / n, sz / n});
+        i = j;
+    }
+}
+
+// src/bgkoctomap/bgkoctomap.cpp:433-458
+void beam_sample(V3 hit, V3 origin, float free_resolution, std::vector<V3> &frees) {
+    frees.clear();
+    float x0 = origin.x, y0 = origin.y, z0 = origin.z;
+    float x = hit.x, y = hit.y, z = hit.z;
+    float l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
+    float nx = (x - x0) / l, ny = (y - y0) / l, nz = (z - z0) / l;
+    float d = free_resolution;
+    while (d < l) {
+        frees.push_back(V3{x0 + nx * d, y0 + ny * d, z0 + nz * d});
+        d += free_resolution;
+    }
+    if (l > free_resolution)
+        frees.push_back(V3{x0 + nx * (l - free_resolution), y0 + ny * (l - free_resolution),
+                           z0 + nz * (l - free_resolution)});
+}
+
+struct XY {
+    V3 p;
+    float y;
+};
+
+// src/bgkoctomap/bgkoctomap.cpp:383-417
+void get_training_data(const std::vector<V3> &cloud, V3 origin, float ds_resolution, float free_resolution,
+                       float max_range, std::vector<XY> &xy, size_t *n_hits, size_t *n_frees) {
+    std::vector<V3> sampled_hits;
+    if (ds_resolution < 0) sampled_hits = cloud; else voxel_grid(cloud, ds_resolution, sampled_hits);
+    std::vector<V3> frees, frees_n;
+    xy.clear();
+    for (const V3 &p : sampled_hits) {
+        if (max_range > 0) {
+            float ddx = p.x - origin.x, ddy = p.y - origin.y, ddz = p.z - origin.z;
+            // point3f::norm(): double sqrt of a float sum (point3f.h:207-214)
+            double l = sqrt((double)(ddx * ddx + ddy * ddy + ddz * ddz));
+            if (l > max_range) continue;
+        }
+        xy.push_back(XY{p, 1.0f});
+        beam_sample(p, origin, free_resolution, frees_n);
+        frees.push_back(origin);
+        for (const V3 &f : frees_n) frees.push_back(f);
+    }
+    if (n_hits) *n_hits = xy.size();
+    std::vector<V3> sampled_frees;
+    if (ds_resolution < 0) sampled_frees = frees; else voxel_grid(frees, ds_resolution, sampled_frees);
+    for (const V3 &f : sampled_frees) xy.push_back(XY{f, 0.0f});
+    if (n_frees) *n_frees = sampled_frees.size();
+}
+
+// ---------------------------------------------------------------------------
+// Map
+// ---------------------------------------------------------------------------
+struct Stats {
+    double n_hits, n_frees, n_bbox_blocks, n_train_blocks, n_test_blocks;
+    double voxel_updates;   // U: sum over test blocks of leaf count
+    double update_calls;    // node.update invocations
+    double pair_evals;      // P
+    double train_reads;     // sum_t sum_{b in E(t)} N_b
+    double t_frontend, t_partition, t_predict, t_prune, t_total;
+};
+
+struct Map {
+    Params p;
+    std::vector<std::vector<V3>> lut;
+    std::unordered_map<int64_t, Block *> blocks;
+    Stats st;
+    ~Map() {
+        for (auto &kv : blocks) delete kv.second;
+    }
+};
+
+// Closed-box membership (src/bgkoctomap/bgkoctomap.cpp:497-503 + rtree.h:1519-1532):
+// p in block iff  c-h <= p <= c+h  per axis, all in fp32.
+inline bool in_closed_box(const Params &p, V3 c, V3 q) {
+    float h = p.block_size / 2.0f;
+    float lo, hi;
+    lo = c.x - h; hi = c.x + h; if (lo > q.x || q.x > hi) return false;
+    lo = c.y - h; hi = c.y + h; if (lo > q.y || q.y > hi) return false;
+    lo = c.z - h; hi = c.z + h; if (lo > q.z || q.z > hi) return false;
+    return true;
+}
+
+// Spatial index standing in for the reference's per-scan R-tree
+// (include/common/rtree.h): same query results (closed boxes), returned in
+// ascending training-point index (the R-tree's traversal order is not restated —
+// it only permutes fp32 sums).
+struct PointIndex {
+    const Params *p;
+    const std::vector<XY> *xy;
+    std::unordered_map<int64_t, std::vector<int>> cell;  // primary cell -> point ids
+    static int64_t ckey(int64_t ix, int64_t iy, int64_t iz) { return (ix << 40) | (iy << 20) | iz; }
+    void build(const Params &pp, const std::vector<XY> &pts) {
+        p = &pp; xy = &pts;
+        for (size_t i = 0; i < pts.size(); ++i) {
+            int64_t k = block_to_hash_key(pp, pts[i].p.x, pts[i].p.y, pts[i].p.z);
+            cell[k].push_back((int)i);
+        }
+    }
+    // gather ids inside the closed box of block `key`; if first_only, stop at one.
+    int query(int64_t key, std::vector<int> *out, bool first_only) const {
+        V3 c = hash_key_to_block(*p, key);
+        int64_t ix = key >> 40, iy = (key >> 20) & 0xFFFFF, iz = key & 0xFFFFF;
+        int found = 0;
+        for (int64_t a = -1; a <= 1; ++a)
+            for (int64_t b = -1; b <= 1; ++b)
+                for (int64_t d = -1; d <= 1; ++d) {
+                    auto it = cell.find(ckey(ix + a, iy + b, iz + d));
+                    if (it == cell.end()) continue;
+                    for (int id : it->second)
+                        if (in_closed_box(*p, c, (*xy)[id].p)) {
+                            ++found;
+                            if (out) out->push_back(id);
+                            if (first_only) return found;
+                        }
+                }
+        if (out) std::sort(out->begin(), out->end());
+        return found;
+    }
+};
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Stages B..G of BGKOctoMap::insert_pointcloud, src/bgkoctomap/bgkoctomap.cpp:229-366
+void insert_xy(Map &m, const std::vector<XY> &xy) {
+    const Params &p = m.p;
+    Stats &st = m.st;
+    if (xy.empty()) return;  // :230-232
+    double t0 = now_s();
+
+    // bbox(): :464-484
+    V3 lo = xy[0].p, hi = xy[0].p;
+    for (const XY &q : xy) {
+        lo.x = std::min(lo.x, q.p.x); lo.y = std::min(lo.y, q.p.y); lo.z = std::min(lo.z, q.p.z);
+        hi.x = std::max(hi.x, q.p.x); hi.y = std::max(hi.y, q.p.y); hi.z = std::max(hi.z, q.p.z);
+    }
+    // get_blocks_in_bbox(): :486-495 — float-stepped triple loop, duplicates kept.
+    std::vector<int64_t> blocks;
+    const float bs = p.block_size;
+    for (float x = lo.x - bs; x <= hi.x + 2 * bs; x += bs)
+        for (float y = lo.y - bs; y <= hi.y + 2 * bs; y += bs)
+            for (float z = lo.z - bs; z <= hi.z + 2 * bs; z += bs) blocks.push_back(block_to_hash_key(p, x, y, z));
+    st.n_bbox_blocks = (double)blocks.size();
+
+    PointIndex index;  // :240-243 rtree.Insert
+    index.build(p, xy);
+
+    // TRAIN :250-284 (serial order; `test_blocks` keeps duplicates of `blocks`)
+    std::vector<int64_t> test_blocks;
+    std::unordered_map<int64_t, std::vector<int>> bgk_arr;  // key -> training point ids
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        int64_t key = blocks[i];
+        int64_t eb[7];
+        extended_block_from_center(p, hash_key_to_block(p, key), key, eb);  // get_extended_block(key)
+        bool has = false;
+        for (int k = 0; k < 7 && !has; ++k) has = index.query(eb[k], nullptr, true) > 0;
+        if (has) test_blocks.push_back(key);
+        std::vector<int> ids;
+        index.query(key, &ids, false);
+        if (ids.empty()) continue;
+        bgk_arr.emplace(key, std::move(ids));  // emplace: first insertion wins
+    }
+    st.n_train_blocks = (double)bgk_arr.size();
+    st.n_test_blocks = (double)test_blocks.size();
+    double t1 = now_s();
+    st.t_partition = t1 - t0;
+
+    // Blocks are created serially first (the reference does it inside an omp
+    // critical; creation order does not affect results).
+    for (int64_t key : test_blocks)
+        if (m.blocks.find(key) == m.blocks.end()) m.blocks.emplace(key, block_new(p, hash_key_to_block(p, key)));
+
+    // PREDICT :293-336
+    double U = 0, calls = 0, pairs = 0, reads = 0;
+    // duplicates in test_blocks must be processed one after the other; group them.
+    // (With OpenMP the reference would race on them; serial semantics are kept.)
+    std::vector<char> is_dup(test_blocks.size(), 0);
+    {
+        std::unordered_map<int64_t, int> seen;
+        for (size_t i = 0; i < test_blocks.size(); ++i) is_dup[i] = seen[test_blocks[i]]++ > 0;
+    }
+    auto predict_one = [&](long ti, double &U_, double &calls_, double &pairs_, double &reads_) {
+        int64_t key = test_blocks[ti];
+        Block *block = m.blocks.find(key)->second;
+        std::vector<int> leaf_keys;
+        enumerate_leaves(p, *block, leaf_keys);
+        int M = (int)leaf_keys.size();
+        std::vector<float> xs((size_t)M * 3);
+        for (int j = 0; j < M; ++j) {
+            const V3 &o = m.lut[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF];
+            xs[3 * j + 0] = o.x + block->center.x;  // Block::get_loc, bgkblock.h:64-66
+            xs[3 * j + 1] = o.y + block->center.y;
+            xs[3 * j + 2] = o.z + block->center.z;
+        }
+        U_ += M;
+        int64_t eb[7];
+        extended_block_from_center(p, block->center,
+                                   block_to_hash_key(p, block->center.x, block->center.y, block->center.z), eb);
+        std::vector<float> bx, by, ybar(M), kbar(M);
+        for (int k = 0; k < 7; ++k) {
+            auto it = bgk_arr.find(eb[k]);
+            if (it == bgk_arr.end()) continue;
+            const std::vector<int> &ids = it->second;
+            int N = (int)ids.size();
+            bx.resize((size_t)N * 3); by.resize(N);
+            for (int n = 0; n < N; ++n) {
+                bx[3 * n] = xy[ids[n]].p.x; bx[3 * n + 1] = xy[ids[n]].p.y; bx[3 * n + 2] = xy[ids[n]].p.z;
+                by[n] = xy[ids[n]].y;
+            }
+            bgk_predict(p.sf2, p.ell, xs.data(), M, bx.data(), by.data(), N, ybar.data(), kbar.data());
+            pairs_ += (double)M * N;
+            reads_ += N;
+            for (int j = 0; j < M; ++j) {
+                Node &node = block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF];
+                if (kbar[j] > 0.0) {  // :331-333
+                    node_update(p, node, ybar[j], kbar[j]);
+                    calls_ += 1;
+                }
+            }
+        }
+    };
+    // first occurrences: independent blocks, parallel like the reference's omp loop
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) reduction(+ : U, calls, pairs, reads)
+#endif
+    for (long ti = 0; ti < (long)test_blocks.size(); ++ti)
+        if (!is_dup[ti]) predict_one(ti, U, calls, pairs, reads);
+    // repeated keys (float-stepping artefact of get_blocks_in_bbox): serial, in list order
+    for (long ti = 0; ti < (long)test_blocks.size(); ++ti)
+        if (is_dup[ti]) predict_one(ti, U, calls, pairs, reads);
+    st.voxel_updates = U; st.update_calls = calls; st.pair_evals = pairs; st.train_reads = reads;
+    double t2 = now_s();
+    st.t_predict = t2 - t1;
+
+    // PRUNE :344-353
+    for (int64_t key : test_blocks) {
+        auto it = m.blocks.find(key);
+        if (it == m.blocks.end()) continue;
+        block_prune(p, *it->second);
+    }
+    st.t_prune = now_s() - t2;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C interface (ctypes)
+// ===========================================================================
+extern "C" {
+
+void *orc_map_create(float resolution, int block_depth, float sf2, float ell, float free_thresh, float occupied_thresh,
+                     float var_thresh, float prior_A, float prior_B) {
+    Map *m = new Map;
+    m->p = Params{resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B,
+                  (float)pow(2, block_depth - 1) * resolution};  // bgkoctomap.cpp:41
+    m->lut = build_lut(resolution, block_depth);
+    std::memset(&m->st, 0, sizeof(Stats));
+    return m;
+}
+void orc_map_destroy(void *h) { delete (Map *)h; }
+float orc_block_size(void *h) { return ((Map *)h)->p.block_size; }
+
+int64_t orc_block_to_hash_key(void *h, float x, float y, float z) { return block_to_hash_key(((Map *)h)->p, x, y, z); }
+void orc_hash_key_to_block(void *h, int64_t key, float *out3) {
+    V3 c = hash_key_to_block(((Map *)h)->p, key);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+void orc_get_extended_block(void *h, int64_t key, int64_t *out7) {
+    Map *m = (Map *)h;
+    extended_block_from_center(m->p, hash_key_to_block(m->p, key), key, out7);
+}
+int orc_lut_count(void *h, int depth) { return (int)((Map *)h)->lut[depth].size(); }
+void orc_lut(void *h, int depth, int index, float *out3) {
+    const V3 &v = ((Map *)h)->lut[depth][index];
+    out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
+}
+
+float orc_kernel(float r, float sf2) { return cov_sparse_elem(r, sf2); }
+// k(r) without the <0 clamp (for the support-radius test)
+float orc_kernel_raw(float r, float sf2) {
+    float t = (r * 2.0f) * 3.1415926f;
+    float a = ((2.0f + cosf(t)) * (1.0f - r)) / 3.0f;
+    float b = sinf(t) / (2.0f * 3.1415926f);
+    return (a + b) * sf2;
+}
+// exhaustive scan of fp32 r in [r0, r1]: returns max raw kernel value (must be <= 0 for r >= 1)
+float orc_kernel_max_over(float r0, float r1, float sf2) {
+    float mx = -std::numeric_limits<float>::infinity();
+    for (float r = r0; r <= r1; r = std::nextafter(r, std::numeric_limits<float>::infinity())) {
+        float k = orc_kernel_raw(r, sf2);
+        if (k > mx) mx = k;
+    }
+    return mx;
+}
+void orc_bgk_predict(float sf2, float ell, const float *xs, int M, const float *x, const float *y, int N, float *ybar,
+                     float *kbar) {
+    bgk_predict(sf2, ell, xs, M, x, y, N, ybar, kbar);
+}
+// node update on a bare (A,B,state) triple
+void orc_node_update(void *h, float *A, float *B, uint8_t *state, float ybar, float kbar) {
+    Node n{0, *A, *B, *state};
+    node_update(((Map *)h)->p, n, ybar, kbar);
+    *A = n.A; *B = n.B; *state = n.state;
+}
+float orc_node_var(float A, float B) { return node_var(Node{0, A, B, 0}); }
+float orc_node_prob(float A, float B) { return node_prob(Node{0, A, B, 0}); }
+
+int orc_voxel_grid(const float *xyz, int n, float leaf, float *out_xyz) {
+    std::vector<V3> in(n), out;
+    for (int i = 0; i < n; ++i) in[i] = V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    voxel_grid(in, leaf, out);
+    for (size_t i = 0; i < out.size(); ++i) {
+        out_xyz[3 * i] = out[i].x; out_xyz[3 * i + 1] = out[i].y; out_xyz[3 * i + 2] = out[i].z;
+    }
+    return (int)out.size();
+}
+int orc_beam_sample(const float *hit, const float *origin, float free_res, float *out_xyz, int cap) {
+    std::vector<V3> f;
+    beam_sample(V3{hit[0], hit[1], hit[2]}, V3{origin[0], origin[1], origin[2]}, free_res, f);
+    int n = (int)std::min<size_t>(f.size(), cap);
+    for (int i = 0; i < n; ++i) { out_xyz[3 * i] = f[i].x; out_xyz[3 * i + 1] = f[i].y; out_xyz[3 * i + 2] = f[i].z; }
+    return (int)f.size();
+}
+
+// returns number of training points; out may be null to query the size (call twice)
+static std::vector<XY> g_xy;
+int64_t orc_get_training_data(const float *xyz, int64_t n, const float *origin, float ds, float free_res,
+                              float max_range, float *out_xyzy, int64_t cap) {
+    std::vector<V3> cloud(n);
+    for (int64_t i = 0; i < n; ++i) cloud[i] = V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    get_training_data(cloud, V3{origin[0], origin[1], origin[2]}, ds, free_res, max_range, g_xy, nullptr, nullptr);
+    if (out_xyzy) {
+        int64_t m = std::min<int64_t>(cap, (int64_t)g_xy.size());
+        for (int64_t i = 0; i < m; ++i) {
+            out_xyzy[4 * i] = g_xy[i].p.x; out_xyzy[4 * i + 1] = g_xy[i].p.y; out_xyzy[4 * i + 2] = g_xy[i].p.z;
+            out_xyzy[4 * i + 3] = g_xy[i].y;
+        }
+    }
+    return (int64_t)g_xy.size();
+}
+
+// BGKOctoMap::insert_pointcloud, src/bgkoctomap/bgkoctomap.cpp:214-366
+void orc_insert_pointcloud(void *h, const float *xyz, int64_t n, const float *origin, float ds_resolution,
+                           float free_res, float max_range) {
+    Map *m = (Map *)h;
+    double t0 = now_s();
+    std::vector<V3> cloud(n);
+    for (int64_t i = 0; i < n; ++i) cloud[i] = V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    std::vector<XY> xy;
+    size_t nh = 0, nf = 0;
+    get_training_data(cloud, V3{origin[0], origin[1], origin[2]}, ds_resolution, free_res, max_range, xy, &nh, &nf);
+    m->st.n_hits = (double)nh; m->st.n_frees = (double)nf;
+    m->st.t_frontend = now_s() - t0;
+    insert_xy(*m, xy);
+    m->st.t_total = now_s() - t0;
+}
+// stages B..G on a prepared training set (x,y,z,label per point)
+void orc_insert_xy(void *h, const float *xyzy, int64_t n) {
+    Map *m = (Map *)h;
+    double t0 = now_s();
+    std::vector<XY> xy(n);
+    double nh = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        xy[i] = XY{V3{xyzy[4 * i], xyzy[4 * i + 1], xyzy[4 * i + 2]}, xyzy[4 * i + 3]};
+        nh += xyzy[4 * i + 3] > 0.5f;
+    }
+    m->st.n_hits = nh; m->st.n_frees = (double)n - nh; m->st.t_frontend = 0;
+    insert_xy(*m, xy);
+    m->st.t_total = now_s() - t0;
+}
+void orc_stats(void *h, double *out15) { std::memcpy(out15, &((Map *)h)->st, sizeof(Stats)); }
+int orc_num_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int64_t orc_block_count(void *h) { return (int64_t)((Map *)h)->blocks.size(); }
+int64_t orc_leaf_count(void *h) {
+    Map *m = (Map *)h;
+    int64_t n = 0;
+    std::vector<int> keys;
+    for (auto &kv : m->blocks) { enumerate_leaves(m->p, *kv.second, keys); n += (int64_t)keys.size(); }
+    return n;
+}
+// Dump all leaves, blocks in ascending hash key, leaves in LeafIterator order.
+int64_t orc_dump_leaves(void *h, int64_t *block_key, int32_t *node_key, float *loc_xyz, float *size, float *A,
+                        float *B, uint8_t *state, uint8_t *classified, int64_t cap) {
+    Map *m = (Map *)h;
+    std::vector<int64_t> bk;
+    for (auto &kv : m->blocks) bk.push_back(kv.first);
+    std::sort(bk.begin(), bk.end());
+    int64_t n = 0;
+    std::vector<int> keys;
+    for (int64_t key : bk) {
+        Block *b = m->blocks[key];
+        enumerate_leaves(m->p, *b, keys);
+        for (int k : keys) {
+            if (n >= cap) return n;
+            const Node &nd = b->layer[k >> 16][k & 0xFFFF];
+            const V3 &o = m->lut[k >> 16][k & 0xFFFF];
+            block_key[n] = key; node_key[n] = k;
+            loc_xyz[3 * n] = o.x + b->center.x; loc_xyz[3 * n + 1] = o.y + b->center.y; loc_xyz[3 * n + 2] = o.z + b->center.z;
+            size[n] = float(m->p.block_size / pow(2, k >> 16));  // bgkblock.h:69-73
+            A[n] = nd.A; B[n] = nd.B; state[n] = nd.state; classified[n] = nd.classified;
+            ++n;
+        }
+    }
+    return n;
+}
+
+// ---- single-block access (known-answer tests against oracle/_ref) ----
+void *orc_block_new(void *h, float cx, float cy, float cz) { return block_new(((Map *)h)->p, V3{cx, cy, cz}); }
+void orc_block_free(void *b) { delete (Block *)b; }
+int orc_block_leaves(void *h, void *b, int32_t *keys, float *loc_xyz, int cap) {
+    Map *m = (Map *)h; Block *blk = (Block *)b;
+    std::vector<int> k;
+    enumerate_leaves(m->p, *blk, k);
+    int n = (int)std::min<size_t>(k.size(), cap);
+    for (int i = 0; i < n; ++i) {
+        keys[i] = k[i];
+        const V3 &o = m->lut[k[i] >> 16][k[i] & 0xFFFF];
+        loc_xyz[3 * i] = o.x + blk->center.x; loc_xyz[3 * i + 1] = o.y + blk->center.y; loc_xyz[3 * i + 2] = o.z + blk->center.z;
+    }
+    return (int)k.size();
+}
+void orc_block_update(void *h, void *b, int32_t key, float ybar, float kbar) {
+    node_update(((Map *)h)->p, ((Block *)b)->layer[key >> 16][key & 0xFFFF], ybar, kbar);
+}
+int orc_block_prune(void *h, void *b) { return block_prune(((Map *)h)->p, *(Block *)b); }
+// returns 0 if the layer was deleted
+int orc_block_node(void *b, int32_t key, float *A, float *B, uint8_t *state, uint8_t *classified) {
+    Block *blk = (Block *)b;
+    if (!blk->alive[key >> 16]) return 0;
+    const Node &n = blk->layer[key >> 16][key & 0xFFFF];
+    *A = n.A; *B = n.B; *state = n.state; *classified = n.classified;
+    return 1;
+}
+// closed-box query on an arbitrary point set (R-tree inclusion rule KAT)
+int orc_box_query(void *h, const float *xyz, int n, int64_t key, int32_t *ids, int cap) {
+    Map *m = (Map *)h;
+    V3 c = hash_key_to_block(m->p, key);
+    int f = 0;
+    for (int i = 0; i < n; ++i)
+        if (in_closed_box(m->p, c, V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]})) {
+            if (f < cap) ids[f] = i;
+            ++f;
+        }
+    return f;
+}
+
+}  // extern "C"

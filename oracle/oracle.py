@@ -1,0 +1,259 @@
+"""ctypes front end of the CPU parity oracle (oracle/la3dm_oracle.cpp) and of the
+compiled reference layer (oracle/_ref/libla3dm_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (la3dm_amd) never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+STATS_FIELDS = ["n_hits", "n_frees", "n_bbox_blocks", "n_train_blocks", "n_test_blocks", "voxel_updates",
+                "update_calls", "pair_evals", "train_reads", "t_frontend", "t_partition", "t_predict", "t_prune",
+                "t_total"]
+
+
+def build(force=False):
+    """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
+    need = force or not (os.path.exists(os.path.join(_HERE, "liboracle.so"))
+                         and os.path.exists(os.path.join(_HERE, "liboracle_omp.so")))
+    if need or os.path.getmtime(os.path.join(_HERE, "la3dm_oracle.cpp")) > os.path.getmtime(
+            os.path.join(_HERE, "liboracle.so")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so", "liboracle_omp.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(
+            os.path.join(_HERE, "_ref", "libla3dm_ref.so"))):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _load(name):
+    lib = C.CDLL(os.path.join(_HERE, name))
+    lib.orc_map_create.restype = C.c_void_p
+    lib.orc_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7
+    lib.orc_map_destroy.argtypes = [C.c_void_p]
+    lib.orc_block_size.restype = C.c_float
+    lib.orc_block_size.argtypes = [C.c_void_p]
+    lib.orc_block_to_hash_key.restype = C.c_int64
+    lib.orc_block_to_hash_key.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    lib.orc_hash_key_to_block.argtypes = [C.c_void_p, C.c_int64, f32p]
+    lib.orc_get_extended_block.argtypes = [C.c_void_p, C.c_int64, i64p]
+    lib.orc_lut_count.restype = C.c_int
+    lib.orc_lut_count.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p]
+    lib.orc_kernel.restype = C.c_float
+    lib.orc_kernel.argtypes = [C.c_float, C.c_float]
+    lib.orc_kernel_raw.restype = C.c_float
+    lib.orc_kernel_raw.argtypes = [C.c_float, C.c_float]
+    lib.orc_kernel_max_over.restype = C.c_float
+    lib.orc_kernel_max_over.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.orc_bgk_predict.argtypes = [C.c_float, C.c_float, f32p, C.c_int, f32p, f32p, C.c_int, f32p, f32p]
+    lib.orc_node_update.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                    C.c_float, C.c_float]
+    lib.orc_node_var.restype = C.c_float
+    lib.orc_node_var.argtypes = [C.c_float, C.c_float]
+    lib.orc_node_prob.restype = C.c_float
+    lib.orc_node_prob.argtypes = [C.c_float, C.c_float]
+    lib.orc_voxel_grid.restype = C.c_int
+    lib.orc_voxel_grid.argtypes = [f32p, C.c_int, C.c_float, f32p]
+    lib.orc_beam_sample.restype = C.c_int
+    lib.orc_beam_sample.argtypes = [f32p, f32p, C.c_float, f32p, C.c_int]
+    lib.orc_get_training_data.restype = C.c_int64
+    lib.orc_get_training_data.argtypes = [f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                          C.c_int64]
+    lib.orc_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float]
+    lib.orc_insert_xy.argtypes = [C.c_void_p, f32p, C.c_int64]
+    lib.orc_stats.argtypes = [C.c_void_p, f64p]
+    lib.orc_num_threads.restype = C.c_int
+    lib.orc_block_count.restype = C.c_int64
+    lib.orc_block_count.argtypes = [C.c_void_p]
+    lib.orc_leaf_count.restype = C.c_int64
+    lib.orc_leaf_count.argtypes = [C.c_void_p]
+    lib.orc_dump_leaves.restype = C.c_int64
+    lib.orc_dump_leaves.argtypes = [C.c_void_p, i64p, i32p, f32p, f32p, f32p, f32p, u8p, u8p, C.c_int64]
+    lib.orc_block_new.restype = C.c_void_p
+    lib.orc_block_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    lib.orc_block_free.argtypes = [C.c_void_p]
+    lib.orc_block_leaves.restype = C.c_int
+    lib.orc_block_leaves.argtypes = [C.c_void_p, C.c_void_p, i32p, f32p, C.c_int]
+    lib.orc_block_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float]
+    lib.orc_block_prune.restype = C.c_int
+    lib.orc_block_prune.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_block_node.restype = C.c_int
+    lib.orc_block_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    lib.orc_box_query.restype = C.c_int
+    lib.orc_box_query.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int64, i32p, C.c_int]
+    return lib
+
+
+_libs = {}
+
+
+def lib(omp=False):
+    name = "liboracle_omp.so" if omp else "liboracle.so"
+    if name not in _libs:
+        build()
+        _libs[name] = _load(name)
+    return _libs[name]
+
+
+BGK_YAML = dict(resolution=0.1, block_depth=3, sf2=1.0, ell=0.2, free_thresh=0.3, occupied_thresh=0.7,
+                var_thresh=100.0, prior_A=0.001, prior_B=0.001)
+
+
+class OracleMap:
+    """CPU BGKOctoMap restatement (same constructor argument order as the reference's
+    BGKOctoMap, include/bgkoctomap/bgkoctomap.h:50-58)."""
+
+    def __init__(self, resolution=0.1, block_depth=3, sf2=1.0, ell=0.2, free_thresh=0.3, occupied_thresh=0.7,
+                 var_thresh=100.0, prior_A=0.001, prior_B=0.001, omp=False):
+        self.L = lib(omp)
+        self.h = self.L.orc_map_create(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+                                       prior_A, prior_B)
+        self.block_depth = block_depth
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_map_destroy(self.h)
+            self.h = None
+
+    @property
+    def block_size(self):
+        return self.L.orc_block_size(self.h)
+
+    def block_to_hash_key(self, x, y, z):
+        return self.L.orc_block_to_hash_key(self.h, x, y, z)
+
+    def hash_key_to_block(self, key):
+        o = np.zeros(3, np.float32)
+        self.L.orc_hash_key_to_block(self.h, key, o)
+        return o
+
+    def get_extended_block(self, key):
+        o = np.zeros(7, np.int64)
+        self.L.orc_get_extended_block(self.h, key, o)
+        return o
+
+    def lut(self):
+        """list over depth of (8^d, 3) float32 arrays"""
+        out = []
+        for d in range(self.block_depth):
+            n = self.L.orc_lut_count(self.h, d)
+            a = np.zeros((n, 3), np.float32)
+            t = np.zeros(3, np.float32)
+            for i in range(n):
+                self.L.orc_lut(self.h, d, i, t)
+                a[i] = t
+            out.append(a)
+        return out
+
+    def insert_pointcloud(self, xyz, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        origin = np.ascontiguousarray(origin, np.float32)
+        self.L.orc_insert_pointcloud(self.h, xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range)
+
+    def insert_xy(self, xyzy):
+        xyzy = np.ascontiguousarray(xyzy, np.float32).reshape(-1, 4)
+        self.L.orc_insert_xy(self.h, xyzy, xyzy.shape[0])
+
+    def stats(self):
+        a = np.zeros(len(STATS_FIELDS), np.float64)
+        self.L.orc_stats(self.h, a)
+        return dict(zip(STATS_FIELDS, a.tolist()))
+
+    def leaves(self):
+        n = self.L.orc_leaf_count(self.h)
+        out = dict(block_key=np.zeros(n, np.int64), node_key=np.zeros(n, np.int32), loc=np.zeros((n, 3), np.float32),
+                   size=np.zeros(n, np.float32), A=np.zeros(n, np.float32), B=np.zeros(n, np.float32),
+                   state=np.zeros(n, np.uint8), classified=np.zeros(n, np.uint8))
+        m = self.L.orc_dump_leaves(self.h, out["block_key"], out["node_key"], out["loc"], out["size"], out["A"],
+                                   out["B"], out["state"], out["classified"], n)
+        assert m == n
+        return out
+
+
+def get_training_data(xyz, origin, ds_resolution, free_res, max_range):
+    L = lib()
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    origin = np.ascontiguousarray(origin, np.float32)
+    n = L.orc_get_training_data(xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range, None, 0)
+    out = np.zeros((n, 4), np.float32)
+    L.orc_get_training_data(xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range,
+                            out.ctypes.data_as(C.c_void_p), n)
+    return out
+
+
+def voxel_grid(xyz, leaf):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros_like(xyz)
+    n = lib().orc_voxel_grid(xyz, xyz.shape[0], leaf, out)
+    return out[:n].copy()
+
+
+def bgk_predict(sf2, ell, xs, x, y):
+    xs = np.ascontiguousarray(xs, np.float32).reshape(-1, 3)
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 3)
+    y = np.ascontiguousarray(y, np.float32)
+    ybar = np.zeros(xs.shape[0], np.float32)
+    kbar = np.zeros(xs.shape[0], np.float32)
+    lib().orc_bgk_predict(sf2, ell, xs, xs.shape[0], x, y, x.shape[0], ybar, kbar)
+    return ybar, kbar
+
+
+# ---------------------------------------------------------------------------
+# compiled reference layer (oracle/_ref)
+# ---------------------------------------------------------------------------
+_ref = None
+
+
+def ref_available():
+    build()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libla3dm_ref.so"))
+
+
+def ref():
+    """ctypes handle of the reference's std-only layer, or None if not built."""
+    global _ref
+    if _ref is None:
+        if not ref_available():
+            return None
+        R = C.CDLL(os.path.join(_HERE, "_ref", "libla3dm_ref.so"))
+        R.ref_configure.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7
+        R.ref_block_size.restype = C.c_float
+        R.ref_lut.restype = C.c_int
+        R.ref_lut.argtypes = [C.c_int, C.c_int, f32p]
+        R.ref_block_to_hash_key.restype = C.c_int64
+        R.ref_block_to_hash_key.argtypes = [C.c_float] * 3
+        R.ref_hash_key_to_block.argtypes = [C.c_int64, f32p]
+        R.ref_get_extended_block.argtypes = [C.c_int64, i64p]
+        R.ref_block_new.restype = C.c_void_p
+        R.ref_block_new.argtypes = [C.c_float] * 3
+        R.ref_block_free.argtypes = [C.c_void_p]
+        R.ref_block_extended.argtypes = [C.c_void_p, i64p]
+        R.ref_block_leaves.restype = C.c_int
+        R.ref_block_leaves.argtypes = [C.c_void_p, i32p, f32p, f32p, C.c_int]
+        R.ref_block_update.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        R.ref_block_prune.restype = C.c_int
+        R.ref_block_prune.argtypes = [C.c_void_p]
+        R.ref_block_node.restype = C.c_int
+        R.ref_block_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        R.ref_node_sequence.argtypes = [f32p, f32p, C.c_int, f32p, f32p, u8p, f32p, f32p]
+        R.ref_rtree_new.restype = C.c_void_p
+        R.ref_rtree_new.argtypes = [f32p, C.c_int]
+        R.ref_rtree_free.argtypes = [C.c_void_p]
+        R.ref_rtree_block_query.restype = C.c_int
+        R.ref_rtree_block_query.argtypes = [C.c_void_p, C.c_int64, i32p, C.c_int]
+        R.ref_rtree_box_query.restype = C.c_int
+        R.ref_rtree_box_query.argtypes = [C.c_void_p, f32p, f32p, i32p, C.c_int]
+        _ref = R
+    return _ref

@@ -1,0 +1,165 @@
+// ref_harness.cpp — C entry points over the REFERENCE's own std-only sources.
+//
+// TEST INFRASTRUCTURE ONLY.  This file contains no reference code: it includes the
+// reference headers where they lie (/root/reference/include/...) and is linked with
+// the reference's own point3f.cpp, bgkoctree_node.cpp, bgkoctree.cpp, bgkblock.cpp
+// (see oracle/Makefile, target `ref`).  The result, oracle/_ref/libla3dm_ref.so,
+// pins the oracle's restatement of block hashing, the voxel LUT, leaf order,
+// Occupancy::update, OcTree::prune and the R-tree closed-box rule.
+//
+// The reference's Eigen/PCL/ROS-dependent files (bgkinference.h, bgkoctomap.cpp, the
+// nodes) are NOT buildable here (no Eigen/PCL/ROS in the image) and are not used.
+//
+// Access to the reference's private statics goes through the friendship the
+// reference itself grants to `la3dm::BGKOctoMap` (bgkblock.h:56, bgkoctree.h:30,
+// bgkoctree_node.h:28): this harness defines a class of that name.
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "bgkblock.h"
+#include "rtree.h"
+
+namespace la3dm {
+class BGKOctoMap {
+public:
+    // what BGKOctoMap::BGKOctoMap does, src/bgkoctomap/bgkoctomap.cpp:31-56
+    static void configure(float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh,
+                          float occupied_thresh, float var_thresh, float prior_A, float prior_B) {
+        Block::resolution = resolution;
+        Block::size = (float) pow(2, block_depth - 1) * resolution;
+        Block::key_loc_map = init_key_loc_map(resolution, block_depth);
+        Block::index_map = init_index_map(Block::key_loc_map, block_depth);
+        OcTree::max_depth = block_depth;
+        OcTreeNode::sf2 = sf2;
+        OcTreeNode::ell = ell;
+        OcTreeNode::free_thresh = free_thresh;
+        OcTreeNode::occupied_thresh = occupied_thresh;
+        OcTreeNode::var_thresh = var_thresh;
+        OcTreeNode::prior_A = prior_A;
+        OcTreeNode::prior_B = prior_B;
+    }
+    static float block_size() { return Block::size; }
+    static int lut_size() { return (int) Block::key_loc_map.size(); }
+    static bool lut(int key, float *out) {
+        auto it = Block::key_loc_map.find(key);
+        if (it == Block::key_loc_map.end()) return false;
+        out[0] = it->second.x(); out[1] = it->second.y(); out[2] = it->second.z();
+        return true;
+    }
+    static float A(const OcTreeNode &n) { return n.m_A; }
+    static float B(const OcTreeNode &n) { return n.m_B; }
+    static bool layer_alive(const OcTree &t, int depth) { return t.node_arr != nullptr && t.node_arr[depth] != nullptr; }
+};
+}  // namespace la3dm
+
+using namespace la3dm;
+
+extern "C" {
+
+void ref_configure(float resolution, int block_depth, float sf2, float ell, float free_thresh, float occupied_thresh,
+                   float var_thresh, float prior_A, float prior_B) {
+    BGKOctoMap::configure(resolution, (unsigned short) block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+                          prior_A, prior_B);
+}
+float ref_block_size() { return BGKOctoMap::block_size(); }
+int ref_sizeof_node() { return (int) sizeof(OcTreeNode); }
+int ref_sizeof_block() { return (int) sizeof(Block); }
+int ref_lut_size() { return BGKOctoMap::lut_size(); }
+int ref_lut(int depth, int index, float *out3) { return BGKOctoMap::lut(node_to_hash_key(depth, index), out3); }
+
+int64_t ref_block_to_hash_key(float x, float y, float z) { return block_to_hash_key(x, y, z); }
+void ref_hash_key_to_block(int64_t key, float *out3) {
+    point3f c = hash_key_to_block(key);
+    out3[0] = c.x(); out3[1] = c.y(); out3[2] = c.z();
+}
+void ref_get_extended_block(int64_t key, int64_t *out7) {
+    ExtendedBlock eb = get_extended_block(key);
+    for (int i = 0; i < 7; ++i) out7[i] = eb[i];
+}
+
+void *ref_block_new(float cx, float cy, float cz) { return new Block(point3f(cx, cy, cz)); }
+void ref_block_free(void *b) { delete (Block *) b; }
+void ref_block_extended(void *b, int64_t *out7) {
+    ExtendedBlock eb = ((Block *) b)->get_extended_block();
+    for (int i = 0; i < 7; ++i) out7[i] = eb[i];
+}
+int ref_block_leaves(void *b, int32_t *keys, float *loc_xyz, float *sizes, int cap) {
+    Block *blk = (Block *) b;
+    int n = 0;
+    for (auto it = blk->begin_leaf(); it != blk->end_leaf(); ++it, ++n) {
+        if (n < cap) {
+            keys[n] = it.get_hash_key();
+            point3f p = blk->get_loc(it);
+            loc_xyz[3 * n] = p.x(); loc_xyz[3 * n + 1] = p.y(); loc_xyz[3 * n + 2] = p.z();
+            sizes[n] = blk->get_size(it);
+        }
+    }
+    return n;
+}
+void ref_block_update(void *b, int32_t key, float ybar, float kbar) { (*(Block *) b)[key].update(ybar, kbar); }
+int ref_block_prune(void *b) { return ((Block *) b)->prune() ? 1 : 0; }
+int ref_block_node(void *b, int32_t key, float *A, float *B, uint8_t *state, float *prob, float *var) {
+    Block *blk = (Block *) b;
+    unsigned short depth, index;
+    hash_key_to_node(key, depth, index);
+    if (!BGKOctoMap::layer_alive(*blk, depth)) return 0;
+    OcTreeNode &n = (*blk)[key];
+    *A = BGKOctoMap::A(n); *B = BGKOctoMap::B(n); *state = (uint8_t) n.get_state();
+    *prob = n.get_prob(); *var = n.get_var();
+    return 1;
+}
+
+// standalone node sequence: start from a default node, apply updates, report each step
+void ref_node_sequence(const float *ybar, const float *kbar, int n, float *A, float *B, uint8_t *state, float *prob,
+                       float *var) {
+    OcTreeNode node;
+    for (int i = 0; i < n; ++i) {
+        node.update(ybar[i], kbar[i]);
+        A[i] = BGKOctoMap::A(node); B[i] = BGKOctoMap::B(node); state[i] = (uint8_t) node.get_state();
+        prob[i] = node.get_prob(); var[i] = node.get_var();
+    }
+}
+
+// R-tree with the reference's instantiation shape (bgkoctomap.h:32 uses GPPointType*; ids suffice)
+typedef RTree<int, float, 3, float> RefRTree;
+static bool collect_cb(int id, void *arg) {
+    ((std::vector<int> *) arg)->push_back(id);
+    return true;
+}
+void *ref_rtree_new(const float *xyz, int n) {
+    RefRTree *t = new RefRTree;
+    for (int i = 0; i < n; ++i) {
+        float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        t->Insert(p, p, i);
+    }
+    return t;
+}
+void ref_rtree_free(void *t) { delete (RefRTree *) t; }
+// box query as BGKOctoMap::get_gp_points_in_bbox(key, out) does it
+// (src/bgkoctomap/bgkoctomap.cpp:497-517): centre -/+ half_size in point3f arithmetic.
+int ref_rtree_block_query(void *t, int64_t key, int32_t *ids, int cap) {
+    float bs = BGKOctoMap::block_size();
+    point3f half_size(bs / 2.0f, bs / 2.0f, bs / 2.0);
+    point3f lim_min = hash_key_to_block(key) - half_size;
+    point3f lim_max = hash_key_to_block(key) + half_size;
+    float a_min[] = {lim_min.x(), lim_min.y(), lim_min.z()};
+    float a_max[] = {lim_max.x(), lim_max.y(), lim_max.z()};
+    std::vector<int> out;
+    ((RefRTree *) t)->Search(a_min, a_max, collect_cb, &out);
+    int n = (int) out.size();
+    for (int i = 0; i < n && i < cap; ++i) ids[i] = out[i];
+    return n;
+}
+int ref_rtree_box_query(void *t, const float *lo, const float *hi, int32_t *ids, int cap) {
+    float a_min[] = {lo[0], lo[1], lo[2]};
+    float a_max[] = {hi[0], hi[1], hi[2]};
+    std::vector<int> out;
+    ((RefRTree *) t)->Search(a_min, a_max, collect_cb, &out);
+    int n = (int) out.size();
+    for (int i = 0; i < n && i < cap; ++i) ids[i] = out[i];
+    return n;
+}
+
+}  // extern "C"
