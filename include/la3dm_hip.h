@@ -1,0 +1,132 @@
+/* la3dm_hip.h — C ABI of the MI355X (gfx950) occupancy-inference hot path.
+ *
+ * This is the drop-in boundary for la3dm's per-scan inference + fusion:
+ * everything between "training points gathered per block" and "leaf (alpha, beta,
+ * state) updated" runs behind these entry points as hand-written HIP kernels.
+ * Plain pointers and sizes only — no C++/torch types.
+ *
+ * Reference interfaces replaced (paths relative to RobustFieldAutonomyLab/la3dm):
+ *   BGK3f::train(x, y) / BGK3f::predict(xs, ybar, kbar)
+ *                                   include/bgkoctomap/bgkinference.h:28-44, 52-79, 113-126
+ *   the 7-neighbour predict/update loop of BGKOctoMap::insert_pointcloud
+ *                                   src/bgkoctomap/bgkoctomap.cpp:293-336
+ *   Occupancy::update(ybar, kbar)   src/bgkoctomap/bgkoctree_node.cpp:31-44
+ *   Block::get_loc (LUT + centre)   include/bgkoctomap/bgkblock.h:64-66
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: one ctx per map, calls on one ctx are serialized by the caller (the
+ * reference's insert_pointcloud is single-caller too).  All functions return
+ * LA3DM_OK (0) or a negative error code and never throw; la3dm_last_error() gives
+ * the text.  There is NO CPU fallback: without a HIP device la3dm_create fails with
+ * LA3DM_ERR_NODEVICE.
+ */
+#ifndef LA3DM_HIP_H
+#define LA3DM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct la3dm_ctx la3dm_ctx;
+
+enum {
+    LA3DM_OK = 0,
+    LA3DM_ERR_ARG = -1,      /* null / inconsistent argument */
+    LA3DM_ERR_HIP = -2,      /* a HIP runtime call failed */
+    LA3DM_ERR_NODEVICE = -3, /* no usable HIP device */
+    LA3DM_ERR_OOM = -4       /* device arena allocation failed */
+};
+
+/* Occupancy state codes, include/bgkoctomap/bgkoctree_node.h:10-12 */
+enum { LA3DM_FREE = 0, LA3DM_OCCUPIED = 1, LA3DM_UNKNOWN = 2, LA3DM_PRUNED = 3 };
+/* OR-ed into the per-leaf state byte when Occupancy::update ran for that leaf
+ * in this scan (the reference sets node.classified = true there). A leaf whose
+ * byte has this bit clear was not touched: its alpha/beta/state are unchanged. */
+#define LA3DM_LEAF_UPDATED 0x80u
+
+/* la3dm_bgk_scan.flags */
+#define LA3DM_SCAN_UPDATE_UNGATED 0x1u /* insert_training_data semantics: update even when kbar == 0
+                                          (src/bgkoctomap/bgkoctomap.cpp:179-185) */
+
+/* Map-wide constants: the statics BGKOctoMap's constructor sets
+ * (src/bgkoctomap/bgkoctomap.cpp:31-56) plus the voxel look-up table
+ * Block::key_loc_map (src/bgkoctomap/bgkblock.cpp:7-32) flattened depth-major:
+ * entry (depth d, index i) at ((8^d - 1) / 7 + i), 3 floats each. */
+typedef struct la3dm_params {
+    float resolution;
+    int32_t block_depth;
+    float sf2;
+    float ell;
+    float free_thresh;
+    float occupied_thresh;
+    float var_thresh;
+    float prior_A;
+    float prior_B;
+    int32_t device;       /* HIP device ordinal */
+    const float *lut_xyz; /* host pointer, lut_count * 3 floats; copied */
+    uint32_t lut_count;   /* sum_{d<block_depth} 8^d */
+} la3dm_params;
+
+/* One scan's worth of work for the BGK kernel.
+ *  - training points are grouped by training block (CSR): block b owns points
+ *    [train_off[b], train_off[b+1]); each point is (x, y, z, label) fp32, label 1 = hit,
+ *    0 = free-beam sample  (bgkoctomap.cpp:265-277).
+ *  - test block t has centre blk_center[3t..], leaves [leaf_off[t], leaf_off[t+1]) in
+ *    OcTree::LeafIterator order, and up to 7 neighbour training blocks nbr[7t..7t+6] in
+ *    ExtendedBlock order self,+x,-x,+y,-y,+z,-z  (-1 = no trained model there).
+ *  - leaf_key[l] = (depth << 16) + index  (OcTreeHashKey, bgkoctree.cpp:9-11).
+ *  - alpha/beta are in/out (m_A, m_B); state is out (see LA3DM_LEAF_UPDATED).
+ * A test block must appear at most once per call (the caller runs repeated keys as
+ * separate calls, preserving the reference's serial semantics). */
+typedef struct la3dm_bgk_scan {
+    const float *train_xyzy;   /* [n_train_pts * 4] */
+    const uint32_t *train_off; /* [n_train_blk + 1] */
+    uint32_t n_train_pts;
+    uint32_t n_train_blk;
+    const int32_t *nbr;        /* [n_test_blk * 7] */
+    const float *blk_center;   /* [n_test_blk * 3] */
+    const uint32_t *leaf_off;  /* [n_test_blk + 1], absolute indices into the leaf arrays */
+    uint32_t n_test_blk;
+    uint32_t n_leaf;           /* length of the leaf arrays */
+    const uint32_t *leaf_key;  /* [n_leaf] */
+    float *alpha;              /* [n_leaf] in/out */
+    float *beta;               /* [n_leaf] in/out */
+    uint8_t *state;            /* [n_leaf] out */
+    uint32_t flags;
+} la3dm_bgk_scan;
+
+/* Per-call work counters (filled by the *_scan_* calls when `out` is non-null). */
+typedef struct la3dm_bgk_counters {
+    uint64_t n_tiles;          /* 64-leaf tiles launched */
+    uint64_t scratch_bytes;    /* device scratch used by this call */
+} la3dm_bgk_counters;
+
+int la3dm_device_count(void);
+const char *la3dm_version(void);
+
+int la3dm_create(const la3dm_params *params, la3dm_ctx **out);
+void la3dm_destroy(la3dm_ctx *ctx);
+const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* Select the kernel implementation (A/B measurements): 0 = default. */
+int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
+
+/* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */
+int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, la3dm_bgk_counters *out);
+
+/* All pointers in *scan are DEVICE pointers (on params.device). Asynchronous on
+ * `stream` (a hipStream_t passed as void*, NULL = the default stream). The ctx's
+ * scratch arena is reused by the next call, so calls must be stream-ordered. */
+int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, void *stream, la3dm_bgk_counters *out);
+
+/* Diagnostics used by the parity tests: evaluate one primitive of the device
+ * arithmetic elementwise on host arrays.  op: 0 sqrt(x)  1 sin(x)  2 cos(x)
+ * 3 sparse kernel k(r) with the ctx's sf2 (clamped)  4 x / ell  5 k(r) unclamped. */
+int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LA3DM_HIP_H */

@@ -1,0 +1,69 @@
+/* la3dm_map.h — C binding of the host-side BGKOctoMap (la3dm_amd/csrc/host/bgkoctomap.h).
+ *
+ * The C++ class is the drop-in for the reference's la3dm::BGKOctoMap
+ * (include/bgkoctomap/bgkoctomap.h:26-367); this flat C view exists for language
+ * bindings (the Python tests and bench use it through ctypes).  Every function
+ * returns 0 on success, negative on failure (la3dm_map_last_error()).
+ */
+#ifndef LA3DM_MAP_H
+#define LA3DM_MAP_H
+#include <stdint.h>
+#include "la3dm_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct la3dm_map la3dm_map;
+
+/* mirrors ScanStats */
+typedef struct la3dm_scan_stats {
+    uint64_t n_hits, n_frees, n_bbox_blocks, n_train_blocks, n_test_blocks;
+    uint64_t voxel_updates, train_reads, pair_evals, n_tiles;
+    double t_frontend, t_partition, t_pack, t_device, t_commit, t_prune, t_total;
+} la3dm_scan_stats;
+
+/* BGKOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B) */
+la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float ell, float free_thresh,
+                            float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device);
+void la3dm_map_destroy(la3dm_map *m);
+const char *la3dm_map_last_error(void);
+
+/* insert_pointcloud(cloud, origin, ds_resolution, free_res, max_range); xyz packed, 3 floats per point */
+int la3dm_map_insert_pointcloud(la3dm_map *m, const float *xyz, uint64_t n, const float *origin3, float ds_resolution,
+                                float free_res, float max_range);
+/* insert_training_data(GPPointCloud): x,y,z,label per point */
+int la3dm_map_insert_training_data(la3dm_map *m, const float *xyzy, uint64_t n);
+
+/* split form: prepare -> (caller runs la3dm_bgk_scan_* on the packed scan) -> commit.
+ * prepare returns 1 if there is work, 0 if the training set is empty. */
+int la3dm_map_prepare(la3dm_map *m, const float *xyz, uint64_t n, const float *origin3, float ds_resolution,
+                      float free_res, float max_range);
+int la3dm_map_prepare_training_data(la3dm_map *m, const float *xyzy, uint64_t n, int ungated);
+int la3dm_map_packed(la3dm_map *m, la3dm_bgk_scan *out);
+int la3dm_map_commit(la3dm_map *m);
+la3dm_ctx *la3dm_map_ctx(la3dm_map *m);
+
+int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out);
+uint64_t la3dm_map_training_size(const la3dm_map *m);
+int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap);
+
+float la3dm_map_block_size(const la3dm_map *m);
+uint64_t la3dm_map_block_count(const la3dm_map *m);
+uint64_t la3dm_map_leaf_count(const la3dm_map *m);
+/* all leaves, blocks by ascending hash key, leaves in LeafIterator order */
+uint64_t la3dm_map_dump_leaves(const la3dm_map *m, int64_t *block_key, int32_t *node_key, float *loc_xyz, float *size,
+                               float *A, float *B, uint8_t *state, uint8_t *classified, uint64_t cap);
+/* search(x, y, z): returns 1 if the block exists */
+int la3dm_map_search(const la3dm_map *m, float x, float y, float z, float *A, float *B, uint8_t *state);
+int la3dm_map_get_bbox(const la3dm_map *m, float *lim_min3, float *lim_max3);
+
+/* host bookkeeping primitives (known-answer tests) */
+int64_t la3dm_map_block_to_hash_key(const la3dm_map *m, float x, float y, float z);
+void la3dm_map_hash_key_to_block(const la3dm_map *m, int64_t key, float *out3);
+void la3dm_map_extended_block(const la3dm_map *m, int64_t key, int64_t *out7);
+uint32_t la3dm_map_lut(const la3dm_map *m, float *xyz, uint32_t cap_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

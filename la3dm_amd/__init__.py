@@ -1,0 +1,8 @@
+"""la3dm_amd — MI355X-native (gfx950) implementation of la3dm's per-scan occupancy-inference
+hot path behind the reference's BGKOctoMap interface.  See DESIGN.md / INTEGRATION.md."""
+from .bgkoctomap import BGKOctoMap, PackedScan, FREE, OCCUPIED, UNKNOWN, PRUNED  # noqa: F401
+from .pcd import load_pcd  # noqa: F401
+from .synth import synthetic_scan  # noqa: F401
+
+BGK_YAML = dict(resolution=0.1, block_depth=3, sf2=1.0, ell=0.2, free_thresh=0.3, occupied_thresh=0.7,
+                var_thresh=100.0, prior_A=0.001, prior_B=0.001)  # config/methods/bgkoctomap.yaml

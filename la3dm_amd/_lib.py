@@ -1,0 +1,140 @@
+"""ctypes bindings of the two product libraries.
+
+  libla3dm_hip.so   C ABI of the device hot path        (include/la3dm_hip.h)
+  libla3dm_map.so   host-side BGKOctoMap, C view         (include/la3dm_map.h)
+
+Both are built in-tree by la3dm_amd/csrc/Makefile.  There is no Python or CPU fallback:
+if a library is missing or no HIP device is present, loading / map creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+HIP_SO = os.path.join(_CSRC, "libla3dm_hip.so")
+MAP_SO = os.path.join(_CSRC, "libla3dm_map.so")
+
+LEAF_UPDATED = 0x80
+SCAN_UPDATE_UNGATED = 0x1
+
+
+class Params(C.Structure):
+    _fields_ = [("resolution", C.c_float), ("block_depth", C.c_int32), ("sf2", C.c_float), ("ell", C.c_float),
+                ("free_thresh", C.c_float), ("occupied_thresh", C.c_float), ("var_thresh", C.c_float),
+                ("prior_A", C.c_float), ("prior_B", C.c_float), ("device", C.c_int32),
+                ("lut_xyz", C.c_void_p), ("lut_count", C.c_uint32)]
+
+
+class BgkScan(C.Structure):
+    _fields_ = [("train_xyzy", C.c_void_p), ("train_off", C.c_void_p), ("n_train_pts", C.c_uint32),
+                ("n_train_blk", C.c_uint32), ("nbr", C.c_void_p), ("blk_center", C.c_void_p),
+                ("leaf_off", C.c_void_p), ("n_test_blk", C.c_uint32), ("n_leaf", C.c_uint32),
+                ("leaf_key", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("state", C.c_void_p),
+                ("flags", C.c_uint32)]
+
+
+class BgkCounters(C.Structure):
+    _fields_ = [("n_tiles", C.c_uint64), ("scratch_bytes", C.c_uint64)]
+
+
+class ScanStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_hits", "n_frees", "n_bbox_blocks", "n_train_blocks", "n_test_blocks",
+                                           "voxel_updates", "train_reads", "pair_evals", "n_tiles")] + \
+               [(n, C.c_double) for n in ("t_frontend", "t_partition", "t_pack", "t_device", "t_commit", "t_prune",
+                                          "t_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_destroy", "la3dm_last_error",
+               "la3dm_set_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_diag_eval"]
+MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
+               "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
+               "la3dm_map_packed", "la3dm_map_commit", "la3dm_map_ctx", "la3dm_map_stats", "la3dm_map_training_size",
+               "la3dm_map_training_data", "la3dm_map_block_size", "la3dm_map_block_count", "la3dm_map_leaf_count",
+               "la3dm_map_dump_leaves", "la3dm_map_search", "la3dm_map_get_bbox", "la3dm_map_block_to_hash_key",
+               "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut"]
+
+_hip = None
+_map = None
+
+
+def hip():
+    """libla3dm_hip.so (raises OSError if it has not been built)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise OSError(f"{HIP_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no fallback path)")
+        L = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        L.la3dm_device_count.restype = C.c_int
+        L.la3dm_version.restype = C.c_char_p
+        L.la3dm_create.restype = C.c_int
+        L.la3dm_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.la3dm_destroy.argtypes = [C.c_void_p]
+        L.la3dm_last_error.restype = C.c_char_p
+        L.la3dm_last_error.argtypes = [C.c_void_p]
+        L.la3dm_set_option.restype = C.c_int
+        L.la3dm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.la3dm_bgk_scan_host.restype = C.c_int
+        L.la3dm_bgk_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
+        L.la3dm_bgk_scan_device.restype = C.c_int
+        L.la3dm_bgk_scan_device.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.c_void_p, C.POINTER(BgkCounters)]
+        L.la3dm_diag_eval.restype = C.c_int
+        L.la3dm_diag_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        _hip = L
+    return _hip
+
+
+def maplib():
+    global _map
+    if _map is None:
+        hip()
+        if not os.path.exists(MAP_SO):
+            raise OSError(f"{MAP_SO} is missing: build it first (no fallback path)")
+        M = C.CDLL(MAP_SO)
+        f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        M.la3dm_map_create.restype = C.c_void_p
+        M.la3dm_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7 + [C.c_int]
+        M.la3dm_map_destroy.argtypes = [C.c_void_p]
+        M.la3dm_map_last_error.restype = C.c_char_p
+        M.la3dm_map_insert_pointcloud.restype = C.c_int
+        M.la3dm_map_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_uint64, f32p, C.c_float, C.c_float, C.c_float]
+        M.la3dm_map_insert_training_data.restype = C.c_int
+        M.la3dm_map_insert_training_data.argtypes = [C.c_void_p, f32p, C.c_uint64]
+        M.la3dm_map_prepare.restype = C.c_int
+        M.la3dm_map_prepare.argtypes = [C.c_void_p, f32p, C.c_uint64, f32p, C.c_float, C.c_float, C.c_float]
+        M.la3dm_map_prepare_training_data.restype = C.c_int
+        M.la3dm_map_prepare_training_data.argtypes = [C.c_void_p, f32p, C.c_uint64, C.c_int]
+        M.la3dm_map_packed.restype = C.c_int
+        M.la3dm_map_packed.argtypes = [C.c_void_p, C.POINTER(BgkScan)]
+        M.la3dm_map_commit.restype = C.c_int
+        M.la3dm_map_commit.argtypes = [C.c_void_p]
+        M.la3dm_map_ctx.restype = C.c_void_p
+        M.la3dm_map_ctx.argtypes = [C.c_void_p]
+        M.la3dm_map_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats)]
+        M.la3dm_map_training_size.restype = C.c_uint64
+        M.la3dm_map_training_size.argtypes = [C.c_void_p]
+        M.la3dm_map_training_data.argtypes = [C.c_void_p, f32p, C.c_uint64]
+        M.la3dm_map_block_size.restype = C.c_float
+        M.la3dm_map_block_size.argtypes = [C.c_void_p]
+        M.la3dm_map_block_count.restype = C.c_uint64
+        M.la3dm_map_block_count.argtypes = [C.c_void_p]
+        M.la3dm_map_leaf_count.restype = C.c_uint64
+        M.la3dm_map_leaf_count.argtypes = [C.c_void_p]
+        M.la3dm_map_dump_leaves.restype = C.c_uint64
+        M.la3dm_map_dump_leaves.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_uint64]
+        M.la3dm_map_search.restype = C.c_int
+        M.la3dm_map_search.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_uint8)]
+        M.la3dm_map_get_bbox.argtypes = [C.c_void_p, f32p, f32p]
+        M.la3dm_map_block_to_hash_key.restype = C.c_int64
+        M.la3dm_map_block_to_hash_key.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        M.la3dm_map_hash_key_to_block.argtypes = [C.c_void_p, C.c_int64, f32p]
+        M.la3dm_map_extended_block.argtypes = [C.c_void_p, C.c_int64, np.ctypeslib.ndpointer(np.int64)]
+        M.la3dm_map_lut.restype = C.c_uint32
+        M.la3dm_map_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        _map = M
+    return _map

@@ -1,0 +1,185 @@
+"""Python mirror of la3dm::BGKOctoMap (reference include/bgkoctomap/bgkoctomap.h:26-367).
+
+Same constructor argument order, same method names and argument meaning as the C++
+class; all work is done by libla3dm_map.so (host bookkeeping, C++) and
+libla3dm_hip.so (HIP kernels).  No Python compute path exists.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FREE, OCCUPIED, UNKNOWN, PRUNED = 0, 1, 2, 3
+
+
+class PackedScan:
+    """Host view of one prepared scan (numpy arrays aliasing the map's buffers)."""
+
+    def __init__(self, s: _lib.BgkScan):
+        self.c = s
+
+        def arr(ptr, n, dt):
+            if not ptr or n == 0:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt, count=n)
+
+        self.train_xyzy = arr(s.train_xyzy, 4 * s.n_train_pts, np.float32).reshape(-1, 4)
+        self.train_off = arr(s.train_off, s.n_train_blk + 1, np.uint32)
+        self.nbr = arr(s.nbr, 7 * s.n_test_blk, np.int32).reshape(-1, 7)
+        self.blk_center = arr(s.blk_center, 3 * s.n_test_blk, np.float32).reshape(-1, 3)
+        self.leaf_off = arr(s.leaf_off, s.n_test_blk + 1, np.uint32)
+        self.leaf_key = arr(s.leaf_key, s.n_leaf, np.uint32)
+        self.alpha = arr(s.alpha, s.n_leaf, np.float32)
+        self.beta = arr(s.beta, s.n_leaf, np.float32)
+        self.state = arr(s.state, s.n_leaf, np.uint8)
+        self.flags = s.flags
+        self.n_test_blk = s.n_test_blk
+        self.n_leaf = s.n_leaf
+        self.n_train_pts = s.n_train_pts
+        self.n_train_blk = s.n_train_blk
+
+
+class BGKOctoMap:
+    def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, free_thresh=0.3, occupied_thresh=0.7,
+                 var_thresh=1.0, prior_A=1.0, prior_B=1.0, device=0):
+        self._M = _lib.maplib()
+        self._h = self._M.la3dm_map_create(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh,
+                                           var_thresh, prior_A, prior_B, device)
+        if not self._h:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        self.resolution = resolution
+        self.block_depth = block_depth
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._M.la3dm_map_destroy(self._h)
+            self._h = None
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        return rc
+
+    # -- reference API ------------------------------------------------------
+    def get_resolution(self):
+        return self.resolution
+
+    def get_block_depth(self):
+        return self.block_depth
+
+    def get_block_size(self):
+        return self._M.la3dm_map_block_size(self._h)
+
+    def insert_pointcloud(self, cloud, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        xyz = np.ascontiguousarray(cloud, np.float32).reshape(-1, 3)
+        o = np.ascontiguousarray(origin, np.float32)
+        self._chk(self._M.la3dm_map_insert_pointcloud(self._h, xyz, xyz.shape[0], o, ds_resolution, free_res,
+                                                      max_range))
+
+    def insert_training_data(self, xyzy):
+        a = np.ascontiguousarray(xyzy, np.float32).reshape(-1, 4)
+        self._chk(self._M.la3dm_map_insert_training_data(self._h, a, a.shape[0]))
+
+    def get_bbox(self):
+        lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._M.la3dm_map_get_bbox(self._h, lo, hi)
+        return lo, hi
+
+    def search(self, x, y, z):
+        """-> (exists, alpha, beta, state)"""
+        a, b, s = C.c_float(), C.c_float(), C.c_uint8()
+        e = self._M.la3dm_map_search(self._h, x, y, z, C.byref(a), C.byref(b), C.byref(s))
+        return bool(e), a.value, b.value, s.value
+
+    def leaves(self):
+        """All leaves (begin_leaf()..end_leaf()), blocks by ascending hash key, leaves in
+        LeafIterator order: dict of block_key, node_key, loc, size, A, B, state, classified."""
+        n = self._M.la3dm_map_leaf_count(self._h)
+        out = dict(block_key=np.zeros(n, np.int64), node_key=np.zeros(n, np.int32), loc=np.zeros((n, 3), np.float32),
+                   size=np.zeros(n, np.float32), A=np.zeros(n, np.float32), B=np.zeros(n, np.float32),
+                   state=np.zeros(n, np.uint8), classified=np.zeros(n, np.uint8))
+        m = self._M.la3dm_map_dump_leaves(self._h, *[out[k].ctypes.data for k in
+                                                     ("block_key", "node_key", "loc", "size", "A", "B", "state",
+                                                      "classified")], n)
+        assert m == n
+        return out
+
+    def block_count(self):
+        return self._M.la3dm_map_block_count(self._h)
+
+    # -- split form ---------------------------------------------------------
+    def prepare(self, cloud, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        xyz = np.ascontiguousarray(cloud, np.float32).reshape(-1, 3)
+        o = np.ascontiguousarray(origin, np.float32)
+        return bool(self._chk(self._M.la3dm_map_prepare(self._h, xyz, xyz.shape[0], o, ds_resolution, free_res,
+                                                        max_range)))
+
+    def prepare_training_data(self, xyzy, ungated=False):
+        a = np.ascontiguousarray(xyzy, np.float32).reshape(-1, 4)
+        return bool(self._chk(self._M.la3dm_map_prepare_training_data(self._h, a, a.shape[0], int(ungated))))
+
+    def packed(self):
+        s = _lib.BgkScan()
+        self._chk(self._M.la3dm_map_packed(self._h, C.byref(s)))
+        return PackedScan(s)
+
+    def commit(self):
+        self._chk(self._M.la3dm_map_commit(self._h))
+
+    def ctx(self):
+        return self._M.la3dm_map_ctx(self._h)
+
+    def set_option(self, name, value):
+        rc = _lib.hip().la3dm_set_option(self.ctx(), name.encode(), int(value))
+        if rc != 0:
+            raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
+
+    def scan_host(self, packed: PackedScan):
+        cnt = _lib.BgkCounters()
+        rc = _lib.hip().la3dm_bgk_scan_host(self.ctx(), C.byref(packed.c), C.byref(cnt))
+        if rc != 0:
+            raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
+        return cnt
+
+    def stats(self):
+        s = _lib.ScanStats()
+        self._M.la3dm_map_stats(self._h, C.byref(s))
+        return s.as_dict()
+
+    def training_data(self):
+        n = self._M.la3dm_map_training_size(self._h)
+        a = np.zeros((n, 4), np.float32)
+        if n:
+            self._M.la3dm_map_training_data(self._h, a, n)
+        return a
+
+    def diag_eval(self, op, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros_like(x)
+        rc = _lib.hip().la3dm_diag_eval(self.ctx(), op, x.ctypes.data, x.size, y.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
+        return y
+
+    # host bookkeeping primitives
+    def block_to_hash_key(self, x, y, z):
+        return self._M.la3dm_map_block_to_hash_key(self._h, x, y, z)
+
+    def hash_key_to_block(self, key):
+        o = np.zeros(3, np.float32)
+        self._M.la3dm_map_hash_key_to_block(self._h, key, o)
+        return o
+
+    def get_extended_block(self, key):
+        o = np.zeros(7, np.int64)
+        self._M.la3dm_map_extended_block(self._h, key, o)
+        return o
+
+    def lut(self):
+        n = self._M.la3dm_map_lut(self._h, None, 0)
+        a = np.zeros((n, 3), np.float32)
+        self._M.la3dm_map_lut(self._h, a.ctypes.data, n)
+        return a

@@ -1,0 +1,731 @@
+// bgkoctomap.cpp — host side of the MI355X BGKOctoMap: node/octree/block bookkeeping,
+// training-set front end, block partition (counting sort + closed-box rule), scan packing,
+// commit + prune.  Kernel evaluation and fusion happen on the GPU via include/la3dm_hip.h.
+//
+// Reference behaviour followed (file:line relative to RobustFieldAutonomyLab/la3dm):
+//   constructor / statics              src/bgkoctomap/bgkoctomap.cpp:31-56
+//   insert_pointcloud stages A..G      src/bgkoctomap/bgkoctomap.cpp:214-366
+//   get_training_data / beam_sample    src/bgkoctomap/bgkoctomap.cpp:383-458
+//   bbox / get_blocks_in_bbox          src/bgkoctomap/bgkoctomap.cpp:464-495
+//   closed-box gather                  src/bgkoctomap/bgkoctomap.cpp:497-552, include/common/rtree.h:1519-1532
+//   hashing / LUT / extended block     src/bgkoctomap/bgkblock.cpp:7-32, 73-130
+//   OcTree leaves / prune              src/bgkoctomap/bgkoctree.cpp:72-148, include/bgkoctomap/bgkoctree.h:62-147
+//   Occupancy                          src/bgkoctomap/bgkoctree_node.cpp:15-44
+#include "bgkoctomap.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+
+namespace la3dm {
+
+namespace {
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline uint32_t layer_base(unsigned depth) { return 0x249249u & ((1u << (3u * depth)) - 1u); }
+}  // namespace
+
+// ------------------------------------------------------------------ Occupancy
+float Occupancy::sf2 = 1.0f;
+float Occupancy::ell = 1.0f;
+float Occupancy::free_thresh = 0.3f;
+float Occupancy::occupied_thresh = 0.7f;
+float Occupancy::var_thresh = 1000.0f;
+float Occupancy::prior_A = 0.5f;
+float Occupancy::prior_B = 0.5f;
+
+void Occupancy::classify() {
+    if (get_var() > var_thresh) {
+        state = State::UNKNOWN;
+        return;
+    }
+    float p = get_prob();
+    state = p > occupied_thresh ? State::OCCUPIED : (p < free_thresh ? State::FREE : State::UNKNOWN);
+}
+
+Occupancy::Occupancy(float A, float B) : classified(false), m_A(prior_A + A), m_B(prior_B + B) { classify(); }
+
+void Occupancy::update(float ybar, float kbar) {
+    classified = true;
+    m_A += ybar;
+    m_B += kbar - ybar;
+    classify();
+}
+
+// --------------------------------------------------------------------- OcTree
+unsigned short OcTree::max_depth = 0;
+
+OcTree::OcTree() : node_arr(nullptr), slab(nullptr), ever_pruned(false) {
+    if (max_depth == 0) return;
+    size_t total = layer_base(max_depth);
+    slab = new OcTreeNode[total]();
+    node_arr = new OcTreeNode *[max_depth];
+    for (unsigned d = 0; d < max_depth; ++d) node_arr[d] = slab + layer_base(d);
+}
+
+OcTree::~OcTree() {
+    delete[] node_arr;
+    delete[] slab;
+}
+
+bool OcTree::is_leaf(unsigned short depth, unsigned short index) const {
+    if (node_arr == nullptr || node_arr[depth] == nullptr) return false;
+    if (node_arr[depth][index].get_state() == State::PRUNED) return false;
+    if (depth + 1 >= max_depth) return true;
+    return node_arr[depth + 1] == nullptr || node_arr[depth + 1][index * 8].get_state() == State::PRUNED;
+}
+
+bool OcTree::is_leaf(OcTreeHashKey key) const { return is_leaf((unsigned short)(key >> 16), (unsigned short)(key & 0xFFFF)); }
+
+bool OcTree::search(OcTreeHashKey key) const {
+    unsigned d = key >> 16, i = key & 0xFFFF;
+    return node_arr != nullptr && node_arr[d] != nullptr && node_arr[d][i].get_state() != State::PRUNED;
+}
+
+OcTreeNode &OcTree::operator[](OcTreeHashKey key) const { return node_arr[key >> 16][key & 0xFFFF]; }
+
+// Bottom-up collapse of sibling groups that share one non-UNKNOWN state; the parent becomes a
+// copy of child 0 (not an average) and a layer with nothing left to collapse is retired.
+bool OcTree::prune() {
+    if (node_arr == nullptr) return false;
+    bool any = false;
+    for (int depth = max_depth - 1; depth > 0; --depth) {
+        OcTreeNode *layer = node_arr[depth];
+        if (layer == nullptr) continue;
+        OcTreeNode *parents = node_arr[depth - 1];
+        const unsigned n = 1u << (3 * depth);
+        bool retire = true;
+        for (unsigned g = 0; g < n; g += 8) {
+            const State s0 = layer[g].get_state();
+            if (s0 == State::PRUNED) continue;
+            if (s0 == State::UNKNOWN) {
+                retire = false;
+                continue;
+            }
+            bool same = true;
+            for (unsigned c = 1; c < 8; ++c) same &= (layer[g + c].get_state() == s0);
+            if (!same) {
+                retire = false;
+                continue;
+            }
+            parents[g >> 3] = layer[g];
+            for (unsigned c = 0; c < 8; ++c) layer[g + c].prune();
+            any = true;
+        }
+        if (retire) node_arr[depth] = nullptr;
+    }
+    if (any) ever_pruned = true;
+    return any;
+}
+
+OcTree::LeafIterator::LeafIterator(const OcTree *t) : tree(t != nullptr && t->node_arr != nullptr ? t : nullptr), top(0) {
+    if (tree == nullptr) return;
+    stack[top++] = node_to_hash_key(0, 0);
+    settle();
+    if (top == 0) tree = nullptr;
+}
+
+void OcTree::LeafIterator::settle() {
+    while (top > 0 && !tree->is_leaf(stack[top - 1])) {
+        const OcTreeHashKey k = stack[--top];
+        const unsigned d = k >> 16, i = k & 0xFFFF;
+        if (d + 1 >= OcTree::max_depth) continue;  // pruned node at the last layer
+        for (unsigned c = 0; c < 8; ++c) stack[top++] = node_to_hash_key(d + 1, i * 8 + c);
+    }
+}
+
+OcTree::LeafIterator &OcTree::LeafIterator::operator++() {
+    if (top > 0) {
+        --top;
+        settle();
+    }
+    if (top == 0) tree = nullptr;
+    return *this;
+}
+
+void OcTree::collect_leaves(std::vector<uint32_t> &keys) const {
+    if (node_arr == nullptr) return;
+    if (!ever_pruned) {  // untouched tree: the whole finest layer, highest index first
+        const unsigned d = max_depth - 1, n = 1u << (3 * d);
+        for (unsigned i = n; i-- > 0;) keys.push_back((d << 16) + i);
+        return;
+    }
+    for (LeafIterator it(this); it != LeafIterator(); ++it) keys.push_back((uint32_t)it.get_hash_key());
+}
+
+// ---------------------------------------------------------------------- Block
+float Block::resolution = 0.1f;
+float Block::size = 0.8f;
+std::vector<point3f> Block::key_loc_map;
+
+std::vector<point3f> init_key_loc_map(float resolution, unsigned short max_depth) {
+    // Layer by layer; the child offsets are formed in double and rounded once, exactly as
+    // the reference's breadth-first construction does (bgkblock.cpp:14-28).
+    std::vector<point3f> lut(layer_base(max_depth));
+    if (max_depth == 0) return lut;
+    lut[0] = point3f(0.0f, 0.0f, 0.0f);
+    for (unsigned d = 0; d + 1 < max_depth; ++d) {
+        const float half_size = (float)(resolution * pow(2, max_depth - d - 1) * 0.5f);
+        const unsigned n = 1u << (3 * d);
+        for (unsigned i = 0; i < n; ++i) {
+            const point3f c = lut[layer_base(d) + i];
+            for (unsigned k = 0; k < 8; ++k)
+                lut[layer_base(d + 1) + 8 * i + k] =
+                    point3f((float)(c.x() + half_size * (k & 4 ? 0.5 : -0.5)), (float)(c.y() + half_size * (k & 2 ? 0.5 : -0.5)),
+                            (float)(c.z() + half_size * (k & 1 ? 0.5 : -0.5)));
+        }
+    }
+    return lut;
+}
+
+BlockHashKey block_to_hash_key(point3f c) { return block_to_hash_key(c.x(), c.y(), c.z()); }
+
+BlockHashKey block_to_hash_key(float x, float y, float z) {
+    const double s = (double)Block::size;
+    return (int64_t(x / s + 524288.5) << 40) | (int64_t(y / s + 524288.5) << 20) | int64_t(z / s + 524288.5);
+}
+
+point3f hash_key_to_block(BlockHashKey key) {
+    return point3f(((key >> 40) - 524288) * Block::size, (((key >> 20) & 0xFFFFF) - 524288) * Block::size,
+                   ((key & 0xFFFFF) - 524288) * Block::size);
+}
+
+static ExtendedBlock extended_from(float x, float y, float z, BlockHashKey self, float s) {
+    ExtendedBlock e;
+    e[0] = self;
+    e[1] = block_to_hash_key(s + x, 0 + y, 0 + z);
+    e[2] = block_to_hash_key(-s + x, 0 + y, 0 + z);
+    e[3] = block_to_hash_key(0 + x, s + y, 0 + z);
+    e[4] = block_to_hash_key(0 + x, -s + y, 0 + z);
+    e[5] = block_to_hash_key(0 + x, 0 + y, s + z);
+    e[6] = block_to_hash_key(0 + x, 0 + y, -s + z);
+    return e;
+}
+
+ExtendedBlock get_extended_block(BlockHashKey key) {
+    const point3f c = hash_key_to_block(key);
+    return extended_from(c.x(), c.y(), c.z(), key, Block::size);
+}
+
+ExtendedBlock Block::get_extended_block() const {
+    return extended_from(center.x(), center.y(), center.z(), block_to_hash_key(center.x(), center.y(), center.z()), size);
+}
+
+OcTreeNode &Block::search(point3f p) const {
+    // finest-layer voxel containing p; child bit 4 -> +x, 2 -> +y, 1 -> +z at every level
+    const int cells = 1 << (max_depth - 1);
+    auto cell = [&](float v, float c) {
+        int i = (int)std::floor((v - c) / resolution + cells / 2.0f);
+        return std::max(0, std::min(i, cells - 1));
+    };
+    const int ix = cell(p.x(), center.x()), iy = cell(p.y(), center.y()), iz = cell(p.z(), center.z());
+    unsigned index = 0;
+    for (int level = max_depth - 2; level >= 0; --level)
+        index = index * 8 + ((((ix >> level) & 1) << 2) | (((iy >> level) & 1) << 1) | ((iz >> level) & 1));
+    return node_arr[max_depth - 1][index];
+}
+
+// ----------------------------------------------------------------- BGKOctoMap
+BGKOctoMap::BGKOctoMap() : BGKOctoMap(0.1f, 4, 1.0, 1.0, 0.3f, 0.7f, 1.0f, 1.0f, 1.0f) {}
+
+BGKOctoMap::BGKOctoMap(float resolution_, unsigned short block_depth_, float sf2, float ell, float free_thresh,
+                       float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device)
+    : resolution(resolution_), block_size((float)pow(2, block_depth_ - 1) * resolution_), block_depth(block_depth_),
+      ctx(nullptr), scan_flags(0) {
+    Block::resolution = resolution;
+    Block::size = block_size;
+    Block::key_loc_map = init_key_loc_map(resolution, block_depth);
+    OcTree::max_depth = block_depth;
+    OcTreeNode::sf2 = sf2;
+    OcTreeNode::ell = ell;
+    OcTreeNode::free_thresh = free_thresh;
+    OcTreeNode::occupied_thresh = occupied_thresh;
+    OcTreeNode::var_thresh = var_thresh;
+    OcTreeNode::prior_A = prior_A;
+    OcTreeNode::prior_B = prior_B;
+
+    la3dm_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.resolution = resolution;
+    p.block_depth = block_depth;
+    p.sf2 = sf2;
+    p.ell = ell;
+    p.free_thresh = free_thresh;
+    p.occupied_thresh = occupied_thresh;
+    p.var_thresh = var_thresh;
+    p.prior_A = prior_A;
+    p.prior_B = prior_B;
+    p.device = device;
+    p.lut_xyz = &Block::key_loc_map[0].x();
+    p.lut_count = (uint32_t)Block::key_loc_map.size();
+    static_assert(sizeof(point3f) == 12, "LUT is handed to the device as packed xyz");
+    if (device < 0) return;  // bookkeeping-only map (tests of the host logic): inserting throws
+    int rc = la3dm_create(&p, &ctx);
+    if (rc != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKOctoMap: GPU context creation failed: ") + la3dm_last_error(nullptr));
+}
+
+BGKOctoMap::~BGKOctoMap() {
+    for (auto &kv : block_arr) delete kv.second;
+    la3dm_destroy(ctx);
+}
+
+Block *BGKOctoMap::search(BlockHashKey key) const {
+    auto it = block_arr.find(key);
+    return it == block_arr.end() ? nullptr : it->second;
+}
+
+OcTreeNode BGKOctoMap::search(point3f p) const {
+    Block *b = search(block_to_hash_key(p));
+    return b == nullptr ? OcTreeNode() : OcTreeNode(b->search(p));
+}
+
+void BGKOctoMap::get_bbox(point3f &lim_min, point3f &lim_max) const {
+    lim_min = point3f(0, 0, 0);
+    lim_max = point3f(0, 0, 0);
+    bool first = true;
+    for (auto &kv : block_arr) {
+        const point3f c = kv.second->get_center();
+        if (first) {
+            lim_min = lim_max = c;
+            first = false;
+            continue;
+        }
+        for (unsigned a = 0; a < 3; ++a) {
+            lim_min(a) = std::min(lim_min(a), c(a));
+            lim_max(a) = std::max(lim_max(a), c(a));
+        }
+    }
+    if (!first) {
+        lim_min -= point3f(block_size, block_size, block_size) * 0.5;
+        lim_max += point3f(block_size, block_size, block_size) * 0.5;
+    }
+}
+
+BGKOctoMap::LeafIterator::LeafIterator(const BGKOctoMap *map)
+    : block_it(map->block_arr.cbegin()), end_block(map->block_arr.cend()) {
+    // skip nothing: every block has at least one leaf
+    if (block_it != end_block) {
+        leaf_it = block_it->second->begin_leaf();
+        end_leaf = block_it->second->end_leaf();
+    }
+}
+
+BGKOctoMap::LeafIterator &BGKOctoMap::LeafIterator::operator++() {
+    ++leaf_it;
+    if (leaf_it == end_leaf) {
+        ++block_it;
+        if (block_it != end_block) {
+            leaf_it = block_it->second->begin_leaf();
+            end_leaf = block_it->second->end_leaf();
+        }
+    }
+    return *this;
+}
+
+std::vector<point3f> BGKOctoMap::LeafIterator::get_pruned_locs() const {
+    // base-resolution voxel centres covered by a (possibly collapsed) leaf
+    std::vector<point3f> out;
+    const point3f c = get_loc();
+    const float size = get_size();
+    const float x0 = c.x() - size * 0.5 + Block::resolution * 0.5;
+    const float y0 = c.y() - size * 0.5 + Block::resolution * 0.5;
+    const float z0 = c.z() - size * 0.5 + Block::resolution * 0.5;
+    const float x1 = c.x() + size * 0.5, y1 = c.y() + size * 0.5, z1 = c.z() + size * 0.5;
+    for (float x = x0; x < x1; x += Block::resolution)
+        for (float y = y0; y < y1; y += Block::resolution)
+            for (float z = z0; z < z1; z += Block::resolution) out.emplace_back(x, y, z);
+    return out;
+}
+
+// ---------------------------------------------------------------- front end (stage A)
+namespace {
+
+// Voxel-grid centroid filter with the semantics of pcl::VoxelGrid<PointXYZ> (PCL is not a
+// dependency of this build): cell = floor(p * (1/leaf)) - floor(min * (1/leaf)), output cells in
+// ascending linear index, centroid = fp32 sum in cloud order / (float)count.
+void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float> &out) {
+    out.clear();
+    if (n == 0) return;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float mx[3] = {-mn[0], -mn[1], -mn[2]};
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = in + 3 * i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], p[a]);
+            mx[a] = std::max(mx[a], p[a]);
+        }
+    }
+    const int64_t ex = (int64_t)((mx[0] - mn[0]) * inv) + 1, ey = (int64_t)((mx[1] - mn[1]) * inv) + 1,
+                  ez = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (ex * ey * ez > (int64_t)std::numeric_limits<int32_t>::max()) {  // PCL gives the input back
+        out.assign(in, in + 3 * n);
+        return;
+    }
+    int lo[3], span[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = (int)std::floor(mn[a] * inv);
+        span[a] = (int)std::floor(mx[a] * inv) - lo[a] + 1;
+    }
+    const int m1 = span[0], m2 = span[0] * span[1];
+    std::vector<uint64_t> order;
+    order.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = in + 3 * i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        const int c0 = (int)(std::floor(p[0] * inv) - (float)lo[0]);
+        const int c1 = (int)(std::floor(p[1] * inv) - (float)lo[1]);
+        const int c2 = (int)(std::floor(p[2] * inv) - (float)lo[2]);
+        const uint32_t cell = (uint32_t)(c0 + c1 * m1 + c2 * m2);
+        order.push_back(((uint64_t)cell << 32) | (uint32_t)i);
+    }
+    std::sort(order.begin(), order.end());
+    size_t i = 0;
+    while (i < order.size()) {
+        const uint32_t cell = (uint32_t)(order[i] >> 32);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        size_t j = i;
+        for (; j < order.size() && (uint32_t)(order[j] >> 32) == cell; ++j) {
+            const float *p = in + 3 * (uint32_t)order[j];
+            sx += p[0];
+            sy += p[1];
+            sz += p[2];
+        }
+        const float cnt = (float)(j - i);
+        out.push_back(sx / cnt);
+        out.push_back(sy / cnt);
+        out.push_back(sz / cnt);
+        i = j;
+    }
+}
+
+}  // namespace
+
+void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                                   float free_resolution, float max_range) {
+    std::vector<float> packed(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        packed[3 * i] = xyz[stride * i];
+        packed[3 * i + 1] = xyz[stride * i + 1];
+        packed[3 * i + 2] = xyz[stride * i + 2];
+    }
+    std::vector<float> hits;
+    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
+
+    xy.clear();
+    std::vector<float> frees;
+    const float x0 = origin.x(), y0 = origin.y(), z0 = origin.z();
+    const size_t nh = hits.size() / 3;
+    size_t kept = 0;
+    for (size_t i = 0; i < nh; ++i) {
+        const float x = hits[3 * i], y = hits[3 * i + 1], z = hits[3 * i + 2];
+        if (max_range > 0) {
+            const double l = (point3f(x, y, z) - origin).norm();
+            if (l > max_range) continue;
+        }
+        xy.insert(xy.end(), {x, y, z, 1.0f});
+        ++kept;
+        // free-space samples along the beam: the origin itself, then every free_resolution,
+        // then one sample free_resolution short of the hit
+        frees.insert(frees.end(), {x0, y0, z0});
+        const float l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
+        const float nx = (x - x0) / l, ny = (y - y0) / l, nz = (z - z0) / l;
+        for (float d = free_resolution; d < l; d += free_resolution)
+            frees.insert(frees.end(), {x0 + nx * d, y0 + ny * d, z0 + nz * d});
+        if (l > free_resolution) {
+            const float d = l - free_resolution;
+            frees.insert(frees.end(), {x0 + nx * d, y0 + ny * d, z0 + nz * d});
+        }
+    }
+    std::vector<float> sampled;
+    if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled);
+    const size_t nf = sampled.size() / 3;
+    xy.reserve(xy.size() + 4 * nf);
+    for (size_t i = 0; i < nf; ++i) xy.insert(xy.end(), {sampled[3 * i], sampled[3 * i + 1], sampled[3 * i + 2], 0.0f});
+    stats.n_hits = kept;
+    stats.n_frees = nf;
+}
+
+// ------------------------------------------------- partition + pack (stages B..E host part)
+namespace {
+struct AxisCand {
+    int64_t idx[3];
+    int n;
+};
+// block indices (with the +524288 bias) whose CLOSED fp32 box [c-h, c+h] holds v on one axis
+inline AxisCand axis_candidates(float v, float size, float h) {
+    AxisCand r;
+    r.n = 0;
+    const int64_t i0 = int64_t(v / (double)size + 524288.5);
+    for (int64_t i = i0 - 1; i <= i0 + 1; ++i) {
+        const float c = (i - 524288) * size;
+        if (c - h <= v && v <= c + h) r.idx[r.n++] = i;
+    }
+    return r;
+}
+}  // namespace
+
+bool BGKOctoMap::partition_and_pack(bool ungated) {
+    scan_flags = ungated ? LA3DM_SCAN_UPDATE_UNGATED : 0u;
+    passes.clear();
+    prune_list.clear();
+    train_xyzy.clear();
+    train_off.assign(1, 0u);
+    const size_t npts = xy.size() / 4;
+    if (npts == 0) return false;
+    const double t0 = wall();
+    const float bs = block_size;
+    const float h = bs / 2.0f;
+
+    // bounding box of the training set, candidate block list (float-stepped, repeats kept)
+    float lo[3] = {xy[0], xy[1], xy[2]}, hi[3] = {xy[0], xy[1], xy[2]};
+    for (size_t i = 1; i < npts; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], xy[4 * i + a]);
+            hi[a] = std::max(hi[a], xy[4 * i + a]);
+        }
+    std::vector<BlockHashKey> bbox_keys;
+    for (float x = lo[0] - bs; x <= hi[0] + 2 * bs; x += bs)
+        for (float y = lo[1] - bs; y <= hi[1] + 2 * bs; y += bs)
+            for (float z = lo[2] - bs; z <= hi[2] + 2 * bs; z += bs) bbox_keys.push_back(block_to_hash_key(x, y, z));
+    stats.n_bbox_blocks = bbox_keys.size();
+    std::unordered_map<BlockHashKey, int32_t> in_bbox;  // key -> training-block index (or -1)
+    in_bbox.reserve(bbox_keys.size() * 2);
+    for (BlockHashKey k : bbox_keys) in_bbox.emplace(k, -1);
+
+    // membership: every (block, point) pair with the point in the block's closed box
+    struct Member {
+        BlockHashKey key;
+        uint32_t pt;
+    };
+    std::vector<Member> members;
+    members.reserve(npts + npts / 8);
+    for (size_t i = 0; i < npts; ++i) {
+        const AxisCand ax = axis_candidates(xy[4 * i], bs, h), ay = axis_candidates(xy[4 * i + 1], bs, h),
+                       az = axis_candidates(xy[4 * i + 2], bs, h);
+        for (int a = 0; a < ax.n; ++a)
+            for (int b = 0; b < ay.n; ++b)
+                for (int c = 0; c < az.n; ++c)
+                    members.push_back(Member{(ax.idx[a] << 40) | (ay.idx[b] << 20) | az.idx[c], (uint32_t)i});
+    }
+    // group by block; inside a block keep ascending point index
+    std::stable_sort(members.begin(), members.end(), [](const Member &a, const Member &b) { return a.key < b.key; });
+
+    // "geo" blocks = every block that geometrically holds points (what an R-tree query sees);
+    // trained blocks = geo blocks that are also in the candidate list.
+    std::unordered_map<BlockHashKey, char> geo;
+    geo.reserve(members.size() / 4 + 16);
+    train_xyzy.reserve(members.size() * 4);
+    uint32_t n_train_blk = 0;
+    for (size_t i = 0; i < members.size();) {
+        size_t j = i;
+        while (j < members.size() && members[j].key == members[i].key) ++j;
+        geo.emplace(members[i].key, 1);
+        auto it = in_bbox.find(members[i].key);
+        if (it != in_bbox.end()) {
+            it->second = (int32_t)n_train_blk++;
+            for (size_t k = i; k < j; ++k) {
+                const float *p = &xy[4 * (size_t)members[k].pt];
+                train_xyzy.insert(train_xyzy.end(), p, p + 4);
+            }
+            train_off.push_back((uint32_t)(train_xyzy.size() / 4));
+        }
+        i = j;
+    }
+    stats.n_train_blocks = n_train_blk;
+
+    // test blocks: candidate blocks whose extended block holds any point; list order kept
+    std::unordered_map<BlockHashKey, uint32_t> times_seen;
+    std::vector<std::pair<BlockHashKey, uint32_t>> test;  // (key, occurrence number)
+    for (BlockHashKey k : bbox_keys) {
+        const ExtendedBlock e = get_extended_block(k);
+        bool any = false;
+        for (int q = 0; q < 7 && !any; ++q) any = geo.find(e[q]) != geo.end();
+        if (!any) continue;
+        test.emplace_back(k, times_seen[k]++);
+        prune_list.push_back(k);
+    }
+    stats.n_test_blocks = test.size();
+    const double t1 = wall();
+    stats.t_partition = t1 - t0;
+
+    uint32_t max_occ = 0;
+    for (auto &t : test) max_occ = std::max(max_occ, t.second);
+    passes.resize(test.empty() ? 0 : max_occ + 1);
+    stats.voxel_updates = stats.train_reads = stats.pair_evals = 0;
+    for (auto &t : test) {
+        Pass &ps = passes[t.second];
+        auto bit = block_arr.find(t.first);
+        if (bit == block_arr.end()) bit = block_arr.emplace(t.first, new Block(hash_key_to_block(t.first))).first;
+        Block *blk = bit->second;
+        ps.keys.push_back(t.first);
+        ps.blocks.push_back(blk);
+        const point3f c = blk->get_center();
+        ps.center.insert(ps.center.end(), {c.x(), c.y(), c.z()});
+        const ExtendedBlock e = blk->get_extended_block();
+        uint64_t npts_nb = 0;
+        for (int q = 0; q < 7; ++q) {
+            auto it = in_bbox.find(e[q]);
+            const int32_t tb = it == in_bbox.end() ? -1 : it->second;
+            ps.nbr.push_back(tb);
+            if (tb >= 0) npts_nb += train_off[tb + 1] - train_off[tb];
+        }
+        if (ps.leaf_off.empty()) ps.leaf_off.push_back(0u);
+        const size_t before = ps.leaf_key.size();
+        blk->collect_leaves(ps.leaf_key);
+        const size_t nl = ps.leaf_key.size() - before;
+        ps.leaf_off.push_back((uint32_t)ps.leaf_key.size());
+        stats.voxel_updates += nl;
+        stats.train_reads += npts_nb;
+        stats.pair_evals += npts_nb * nl;
+    }
+    for (Pass &ps : passes) {
+        const size_t nl = ps.leaf_key.size();
+        ps.alpha.resize(nl);
+        ps.beta.resize(nl);
+        ps.state.assign(nl, 0);
+        size_t l = 0;
+        for (size_t b = 0; b < ps.blocks.size(); ++b)
+            for (; l < ps.leaf_off[b + 1]; ++l) {
+                const OcTreeNode &nd = (*ps.blocks[b])[(OcTreeHashKey)ps.leaf_key[l]];
+                ps.alpha[l] = nd.m_A;
+                ps.beta[l] = nd.m_B;
+            }
+    }
+    stats.t_pack = wall() - t1;
+    return !passes.empty();
+}
+
+la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
+    la3dm_bgk_scan s;
+    std::memset(&s, 0, sizeof(s));
+    Pass &ps = passes.at(pass);
+    s.train_xyzy = train_xyzy.data();
+    s.train_off = train_off.data();
+    s.n_train_pts = (uint32_t)(train_xyzy.size() / 4);
+    s.n_train_blk = (uint32_t)(train_off.size() - 1);
+    s.nbr = ps.nbr.data();
+    s.blk_center = ps.center.data();
+    s.leaf_off = ps.leaf_off.data();
+    s.n_test_blk = (uint32_t)ps.blocks.size();
+    s.n_leaf = (uint32_t)ps.leaf_key.size();
+    s.leaf_key = ps.leaf_key.data();
+    s.alpha = ps.alpha.data();
+    s.beta = ps.beta.data();
+    s.state = ps.state.data();
+    s.flags = scan_flags;
+    return s;
+}
+
+void BGKOctoMap::refresh_pass(size_t p) {
+    Pass &ps = passes[p];
+    size_t l = 0;
+    for (size_t b = 0; b < ps.blocks.size(); ++b)
+        for (; l < ps.leaf_off[b + 1]; ++l) {
+            const OcTreeNode &nd = (*ps.blocks[b])[(OcTreeHashKey)ps.leaf_key[l]];
+            ps.alpha[l] = nd.m_A;
+            ps.beta[l] = nd.m_B;
+        }
+}
+
+void BGKOctoMap::write_nodes(size_t p) {
+    Pass &ps = passes[p];
+    size_t l = 0;
+    for (size_t b = 0; b < ps.blocks.size(); ++b)
+        for (; l < ps.leaf_off[b + 1]; ++l) {
+            const uint8_t st = ps.state[l];
+            if (!(st & LA3DM_LEAF_UPDATED)) continue;
+            OcTreeNode &nd = (*ps.blocks[b])[(OcTreeHashKey)ps.leaf_key[l]];
+            nd.classified = true;
+            nd.m_A = ps.alpha[l];
+            nd.m_B = ps.beta[l];
+            nd.state = (State)(st & 3u);
+        }
+}
+
+// Pass 0 (all distinct test blocks) has been run by the caller; repeated keys of the
+// candidate list (a float-stepping artefact, normally none) are replayed here one pass
+// after the other so that they see the previous pass's posterior, as the serial reference does.
+void BGKOctoMap::commit() {
+    const double t0 = wall();
+    if (!passes.empty()) write_nodes(0);
+    for (size_t p = 1; p < passes.size(); ++p) {
+        refresh_pass(p);
+        la3dm_bgk_scan s = packed(p);
+        if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::commit: no device context");
+        if (la3dm_bgk_scan_host(ctx, &s, nullptr) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::commit: ") + la3dm_last_error(ctx));
+        write_nodes(p);
+    }
+    const double t1 = wall();
+    stats.t_commit = t1 - t0;
+    for (BlockHashKey k : prune_list) {
+        auto it = block_arr.find(k);
+        if (it != block_arr.end()) it->second->prune();
+    }
+    stats.t_prune = wall() - t1;
+}
+
+bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                         float free_res, float max_range) {
+    stats = ScanStats();
+    const double t0 = wall();
+    get_training_data(xyz, n, stride, origin, ds_resolution, free_res, max_range);
+    stats.t_frontend = wall() - t0;
+    return partition_and_pack(false);
+}
+
+bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated) {
+    stats = ScanStats();
+    xy.assign(xyzy, xyzy + 4 * n);
+    for (size_t i = 0; i < n; ++i) (xyzy[4 * i + 3] > 0.5f ? stats.n_hits : stats.n_frees)++;
+    return partition_and_pack(ungated);
+}
+
+void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                                   float free_res, float max_range) {
+    const double t0 = wall();
+    if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_pointcloud: no device context (there is no CPU path)");
+    if (!prepare(xyz, n, stride, origin, ds_resolution, free_res, max_range)) return;
+    const double t1 = wall();
+    {
+        la3dm_bgk_scan s = packed(0);
+        la3dm_bgk_counters c;
+        if (la3dm_bgk_scan_host(ctx, &s, &c) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
+        stats.n_tiles += c.n_tiles;
+    }
+    stats.t_device = wall() - t1;
+    commit();
+    stats.t_total = wall() - t0;
+}
+
+void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
+    const double t0 = wall();
+    if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: no device context (there is no CPU path)");
+    std::vector<float> flat;
+    flat.reserve(cloud.size() * 4);
+    for (const GPPointType &p : cloud) flat.insert(flat.end(), {p.first.x(), p.first.y(), p.first.z(), p.second});
+    if (!prepare_training_data(flat.data(), cloud.size(), true)) return;
+    const double t1 = wall();
+    {
+        la3dm_bgk_scan s = packed(0);
+        if (la3dm_bgk_scan_host(ctx, &s, nullptr) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::insert_training_data: ") + la3dm_last_error(ctx));
+    }
+    stats.t_device = wall() - t1;
+    commit();
+    stats.t_total = wall() - t0;
+}
+
+}  // namespace la3dm
+
+extern "C" void la3dm_node_ab(const void *node, float *A, float *B) {
+    const la3dm::Occupancy *n = static_cast<const la3dm::Occupancy *>(node);
+    *A = n->m_A;
+    *B = n->m_B;
+}

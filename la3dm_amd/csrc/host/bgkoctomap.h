@@ -1,0 +1,344 @@
+// bgkoctomap.h — host side of the MI355X BGKOctoMap.
+//
+// Same public surface and data layout as the reference's BGKOctoMap family
+// (include/bgkoctomap/{bgkoctomap,bgkblock,bgkoctree,bgkoctree_node}.h,
+// include/common/point3f.h) so that the ROS nodes' call sequence
+// (src/bgkoctomap/bgkoctomap_static_node.cpp:86-139) works unchanged:
+//
+//     la3dm::BGKOctoMap map(resolution, block_depth, sf2, ell, free_thresh,
+//                           occupied_thresh, var_thresh, prior_A, prior_B);
+//     map.insert_pointcloud(cloud, origin, ds_resolution, free_res, max_range);
+//     for (auto it = map.begin_leaf(); it != map.end_leaf(); ++it) { it.get_loc(); it.get_node()...}
+//
+// What is different underneath: block hashing, neighbour gather (a counting sort by
+// block instead of an R-tree) and octree bookkeeping stay on the host in this file's
+// implementation; kernel evaluation and the alpha/beta fusion run on the GPU through
+// the C ABI of include/la3dm_hip.h.  There is no CPU inference path: constructing a
+// map without a HIP device throws std::runtime_error.
+#ifndef LA3DM_AMD_BGKOCTOMAP_H
+#define LA3DM_AMD_BGKOCTOMAP_H
+
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../../include/la3dm_hip.h"
+
+extern "C" void la3dm_node_ab(const void *node, float *A, float *B);  // (m_A, m_B) of an Occupancy
+
+namespace la3dm {
+
+/// 3 floats; the scalar type of every coordinate (reference: include/common/point3f.h).
+class point3f {
+public:
+    point3f() : d{0.f, 0.f, 0.f} {}
+    point3f(float x, float y, float z) : d{x, y, z} {}
+    float &x() { return d[0]; }
+    float &y() { return d[1]; }
+    float &z() { return d[2]; }
+    const float &x() const { return d[0]; }
+    const float &y() const { return d[1]; }
+    const float &z() const { return d[2]; }
+    float &operator()(unsigned i) { return d[i]; }
+    const float &operator()(unsigned i) const { return d[i]; }
+    point3f operator+(const point3f &o) const { return point3f(d[0] + o.d[0], d[1] + o.d[1], d[2] + o.d[2]); }
+    point3f operator-(const point3f &o) const { return point3f(d[0] - o.d[0], d[1] - o.d[1], d[2] - o.d[2]); }
+    point3f operator*(float s) const { return point3f(d[0] * s, d[1] * s, d[2] * s); }
+    void operator+=(const point3f &o) { d[0] += o.d[0]; d[1] += o.d[1]; d[2] += o.d[2]; }
+    void operator-=(const point3f &o) { d[0] -= o.d[0]; d[1] -= o.d[1]; d[2] -= o.d[2]; }
+    bool operator==(const point3f &o) const { return d[0] == o.d[0] && d[1] == o.d[1] && d[2] == o.d[2]; }
+    /// double sqrt of a float sum, as the reference (point3f.h:207-214)
+    double norm() const { return std::sqrt((double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])); }
+
+private:
+    float d[3];
+};
+
+typedef int OcTreeHashKey;     // (depth << 16) + index
+typedef int64_t BlockHashKey;  // 3 x 20-bit block indices
+typedef std::array<BlockHashKey, 7> ExtendedBlock;  // self,+x,-x,+y,-y,+z,-z
+
+enum class State : char { FREE, OCCUPIED, UNKNOWN, PRUNED };
+
+inline OcTreeHashKey node_to_hash_key(unsigned short depth, unsigned short index) { return (depth << 16) + index; }
+inline void hash_key_to_node(OcTreeHashKey key, unsigned short &depth, unsigned short &index) {
+    depth = (unsigned short)(key >> 16);
+    index = (unsigned short)(key & 0xFFFF);
+}
+
+/// Beta posterior of one voxel. 16 bytes: classified@0, m_A@4, m_B@8, state@12
+/// (reference: include/bgkoctomap/bgkoctree_node.h:76-81).
+class Occupancy {
+    friend class BGKOctoMap;
+    friend class OcTree;
+    friend void ::la3dm_node_ab(const void *node, float *A, float *B);
+
+public:
+    Occupancy() : classified(false), m_A(prior_A), m_B(prior_B), state(State::UNKNOWN) {}
+    Occupancy(float A, float B);
+    // like the reference, copying does not carry `classified`
+    Occupancy(const Occupancy &o) : m_A(o.m_A), m_B(o.m_B), state(o.state) {}
+    Occupancy &operator=(const Occupancy &o) {
+        m_A = o.m_A;
+        m_B = o.m_B;
+        state = o.state;
+        return *this;
+    }
+
+    /// Host twin of the device-side update (kept for API parity; the map itself
+    /// never calls it — the GPU does the updates).
+    void update(float ybar, float kbar);
+
+    float get_prob() const { return m_A / (m_A + m_B); }
+    float get_var() const { return (m_A * m_B) / ((m_A + m_B) * (m_A + m_B) * (m_A + m_B + 1.0f)); }
+    State get_state() const { return state; }
+    void prune() { state = State::PRUNED; }
+    bool operator==(const Occupancy &rhs) const { return state != State::UNKNOWN && state == rhs.state; }
+
+    bool classified;
+
+private:
+    void classify();
+    float m_A;
+    float m_B;
+    State state;
+
+    static float sf2, ell, prior_A, prior_B, free_thresh, occupied_thresh, var_thresh;
+};
+typedef Occupancy OcTreeNode;
+static_assert(sizeof(Occupancy) == 16, "node layout must match the reference (16 bytes)");
+
+/// Fixed-depth test-data octree of one block: layer d holds 8^d nodes, child c of node i
+/// is node 8i+c of the next layer (c&4 -> +x, c&2 -> +y, c&1 -> +z).
+class OcTree {
+    friend class BGKOctoMap;
+
+public:
+    OcTree();
+    ~OcTree();
+    OcTree(const OcTree &) = delete;
+    OcTree &operator=(const OcTree &) = delete;
+
+    bool prune();
+    bool is_leaf(OcTreeHashKey key) const;
+    bool is_leaf(unsigned short depth, unsigned short index) const;
+    bool search(OcTreeHashKey key) const;
+    OcTreeNode &operator[](OcTreeHashKey key) const;
+
+    /// Leaves in the reference's LeafIterator order (depth-first, children 7..0).
+    class LeafIterator {
+    public:
+        LeafIterator() : tree(nullptr), top(0) {}
+        explicit LeafIterator(const OcTree *t);
+        bool operator==(const LeafIterator &o) const {
+            return tree == o.tree && top == o.top && (top == 0 || stack[top - 1] == o.stack[o.top - 1]);
+        }
+        bool operator!=(const LeafIterator &o) const { return !(*this == o); }
+        LeafIterator &operator++();
+        LeafIterator operator++(int) {
+            LeafIterator r(*this);
+            ++(*this);
+            return r;
+        }
+        OcTreeNode &operator*() const { return (*tree)[get_hash_key()]; }
+        OcTreeNode &get_node() const { return operator*(); }
+        OcTreeHashKey get_hash_key() const { return stack[top - 1]; }
+
+    private:
+        void settle();
+        const OcTree *tree;
+        int top;
+        OcTreeHashKey stack[7 * 6 + 2];  // depth <= 6: at most 7 siblings pending per level
+    };
+    LeafIterator begin_leaf() const { return LeafIterator(this); }
+    LeafIterator end_leaf() const { return LeafIterator(); }
+
+    /// Append the leaf keys in LeafIterator order (bulk form used by the packer).
+    void collect_leaves(std::vector<uint32_t> &keys) const;
+
+protected:
+    OcTreeNode **node_arr;  // node_arr[d] == nullptr once a layer is fully collapsed
+    OcTreeNode *slab;       // all layers in one allocation
+    bool ever_pruned;
+    static unsigned short max_depth;
+};
+
+BlockHashKey block_to_hash_key(point3f center);
+BlockHashKey block_to_hash_key(float x, float y, float z);
+point3f hash_key_to_block(BlockHashKey key);
+ExtendedBlock get_extended_block(BlockHashKey key);
+
+/// Voxel LUT, flat and depth-major: entry (d, i) at (8^d - 1)/7 + i
+/// (replaces the reference's unordered_map Block::key_loc_map; same values).
+std::vector<point3f> init_key_loc_map(float resolution, unsigned short max_depth);
+
+class Block : public OcTree {
+    friend class BGKOctoMap;
+    friend BlockHashKey block_to_hash_key(float x, float y, float z);
+    friend point3f hash_key_to_block(BlockHashKey key);
+    friend ExtendedBlock get_extended_block(BlockHashKey key);
+
+public:
+    Block() : OcTree(), center(0.f, 0.f, 0.f) {}
+    explicit Block(point3f c) : OcTree(), center(c) {}
+
+    static const point3f &lut(OcTreeHashKey key) {
+        return key_loc_map[(0x249249u & ((1u << (3u * (unsigned)(key >> 16))) - 1u)) + (unsigned)(key & 0xFFFF)];
+    }
+    point3f get_loc(const LeafIterator &it) const { return lut(it.get_hash_key()) + center; }
+    float get_size(const LeafIterator &it) const { return float(size / pow(2, it.get_hash_key() >> 16)); }
+    point3f get_center() const { return center; }
+    point3f get_lim_min() const { return center - point3f(size / 2.0f, size / 2.0f, size / 2.0f); }
+    point3f get_lim_max() const { return center + point3f(size / 2.0f, size / 2.0f, size / 2.0f); }
+    ExtendedBlock get_extended_block() const;
+    /// voxel containing p (index clamped into the block), at the finest layer
+    OcTreeNode &search(point3f p) const;
+    OcTreeNode &search(float x, float y, float z) const { return search(point3f(x, y, z)); }
+
+private:
+    static std::vector<point3f> key_loc_map;
+    static float resolution;
+    static float size;
+    point3f center;
+};
+
+struct ScanStats {
+    uint64_t n_hits = 0, n_frees = 0, n_bbox_blocks = 0, n_train_blocks = 0, n_test_blocks = 0;
+    uint64_t voxel_updates = 0;  // U
+    uint64_t train_reads = 0;    // sum_t sum_{b in E(t)} N_b
+    uint64_t pair_evals = 0;     // P
+    uint64_t n_tiles = 0;
+    double t_frontend = 0, t_partition = 0, t_pack = 0, t_device = 0, t_commit = 0, t_prune = 0, t_total = 0;
+};
+
+class BGKOctoMap {
+public:
+    typedef std::vector<point3f> PointCloud;
+    typedef std::pair<point3f, float> GPPointType;
+    typedef std::vector<GPPointType> GPPointCloud;
+
+    BGKOctoMap();
+    /// Same argument order as the reference constructor (bgkoctomap.h:50-58); `device`
+    /// is the HIP device ordinal (a negative ordinal builds a bookkeeping-only map without a
+    /// GPU context — prepare()/packed()/commit() work, insert_* throw; used to test host logic).
+    BGKOctoMap(float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh,
+               float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device = 0);
+    ~BGKOctoMap();
+    BGKOctoMap(const BGKOctoMap &) = delete;
+    BGKOctoMap &operator=(const BGKOctoMap &) = delete;
+
+    float get_resolution() const { return resolution; }
+    float get_block_depth() const { return block_depth; }
+    float get_block_size() const { return block_size; }
+
+    /// One scan. xyz: n points, `stride` floats between consecutive points (3 for packed
+    /// xyz, 4 for PCL's PointXYZ).  Mirrors insert_pointcloud(const PCLPointCloud&, ...)
+    /// (bgkoctomap.h:82-84): ds_resolution < 0 disables the voxel-grid filter,
+    /// max_range <= 0 disables the range gate. Empty training set => silent return.
+    void insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                           float free_res = 2.0f, float max_range = -1);
+    void insert_pointcloud(const PointCloud &cloud, const point3f &origin, float ds_resolution, float free_res = 2.0f,
+                           float max_range = -1) {
+        insert_pointcloud(cloud.empty() ? nullptr : &cloud[0].x(), cloud.size(), 3, origin, ds_resolution, free_res,
+                          max_range);
+    }
+#if defined(LA3DM_WITH_PCL)
+    template <class PCLCloud>
+    void insert_pointcloud(const PCLCloud &cloud, const point3f &origin, float ds_resolution, float free_res = 2.0f,
+                           float max_range = -1) {
+        insert_pointcloud(cloud.empty() ? nullptr : &cloud.points[0].x, cloud.size(),
+                          sizeof(cloud.points[0]) / sizeof(float), origin, ds_resolution, free_res, max_range);
+    }
+#endif
+    /// Pre-labelled training points (y = 1 hit, 0 free); updates are not gated on kbar
+    /// (reference bgkoctomap.cpp:82-212, without its null dereference).
+    void insert_training_data(const GPPointCloud &xy);
+
+    void get_bbox(point3f &lim_min, point3f &lim_max) const;
+
+    // ---- split form of insert_pointcloud, used by the benchmark and the multi-GPU
+    // driver: prepare() runs the front end, the block partition and packs the scan into
+    // flat host arrays (valid until the next prepare); the caller runs the kernel
+    // (la3dm_bgk_scan_host / _device on any shard of the test blocks) and hands the
+    // updated leaf arrays back to commit(), which writes the nodes and prunes.
+    /// returns false when there is nothing to do (empty training set)
+    bool prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution, float free_res,
+                 float max_range);
+    bool prepare_training_data(const float *xyzy, size_t n, bool ungated);
+    /// the packed scan (host pointers into this map's buffers): pass 0 = every distinct
+    /// test block. (Repeated keys of get_blocks_in_bbox — normally none — form further
+    /// passes that commit() replays itself.)
+    size_t num_passes() const { return passes.size(); }
+    la3dm_bgk_scan packed(size_t pass = 0);
+    /// write the updated leaves of pass 0 back into the nodes, replay passes >= 1, prune
+    void commit();
+    la3dm_ctx *device_ctx() const { return ctx; }
+    const ScanStats &last_stats() const { return stats; }
+    const std::vector<float> &last_training_data() const { return xy; }  // x,y,z,label
+
+    class LeafIterator {
+    public:
+        explicit LeafIterator(const BGKOctoMap *map);
+        LeafIterator(std::unordered_map<BlockHashKey, Block *>::const_iterator bit, OcTree::LeafIterator lit)
+            : block_it(bit), end_block(bit), leaf_it(lit), end_leaf(lit) {}
+        bool operator==(const LeafIterator &o) const { return block_it == o.block_it && leaf_it == o.leaf_it; }
+        bool operator!=(const LeafIterator &o) const { return !(*this == o); }
+        LeafIterator &operator++();
+        OcTreeNode &operator*() const { return *leaf_it; }
+        OcTreeNode &get_node() const { return *leaf_it; }
+        point3f get_loc() const { return block_it->second->get_loc(leaf_it); }
+        float get_size() const { return block_it->second->get_size(leaf_it); }
+        BlockHashKey get_block_key() const { return block_it->first; }
+        OcTreeHashKey get_node_key() const { return leaf_it.get_hash_key(); }
+        std::vector<point3f> get_pruned_locs() const;
+
+    private:
+        std::unordered_map<BlockHashKey, Block *>::const_iterator block_it, end_block;
+        OcTree::LeafIterator leaf_it, end_leaf;
+    };
+    LeafIterator begin_leaf() const { return LeafIterator(this); }
+    LeafIterator end_leaf() const { return LeafIterator(block_arr.cend(), OcTree::LeafIterator()); }
+
+    OcTreeNode search(point3f p) const;
+    OcTreeNode search(float x, float y, float z) const { return search(point3f(x, y, z)); }
+    Block *search(BlockHashKey key) const;
+    size_t block_count() const { return block_arr.size(); }
+
+private:
+    void get_training_data(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                           float free_resolution, float max_range);
+    bool partition_and_pack(bool ungated);
+    void refresh_pass(size_t p);
+    void write_nodes(size_t p);
+
+    float resolution;
+    float block_size;
+    unsigned short block_depth;
+    std::unordered_map<BlockHashKey, Block *> block_arr;
+    la3dm_ctx *ctx;
+
+    // per-scan buffers (capacity reused across scans)
+    std::vector<float> xy;               // training set: x,y,z,label
+    std::vector<float> train_xyzy;       // grouped by training block
+    std::vector<uint32_t> train_off;
+    struct Pass {
+        std::vector<BlockHashKey> keys;
+        std::vector<Block *> blocks;
+        std::vector<int32_t> nbr;
+        std::vector<float> center;
+        std::vector<uint32_t> leaf_off, leaf_key;
+        std::vector<float> alpha, beta;
+        std::vector<uint8_t> state;
+    };
+    std::vector<Pass> passes;
+    std::vector<BlockHashKey> prune_list;  // test_blocks in list order (with repeats)
+    uint32_t scan_flags;
+    ScanStats stats;
+};
+
+}  // namespace la3dm
+#endif

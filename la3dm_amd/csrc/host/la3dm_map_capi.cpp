@@ -1,0 +1,185 @@
+// la3dm_map_capi.cpp — flat C view of la3dm::BGKOctoMap (include/la3dm_map.h) for bindings.
+#include "../../../include/la3dm_map.h"
+
+#include <algorithm>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "bgkoctomap.h"
+
+using la3dm::BGKOctoMap;
+using la3dm::point3f;
+
+struct la3dm_map {
+    BGKOctoMap *map;
+};
+
+static thread_local std::string g_err;
+
+#define GUARD(body)                     \
+    try {                               \
+        body                            \
+    } catch (const std::exception &e) { \
+        g_err = e.what();               \
+        return -1;                      \
+    }
+
+extern "C" {
+
+const char *la3dm_map_last_error(void) { return g_err.c_str(); }
+
+la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float ell, float free_thresh,
+                            float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device) {
+    try {
+        la3dm_map *m = new la3dm_map;
+        m->map = new BGKOctoMap(resolution, (unsigned short)block_depth, sf2, ell, free_thresh, occupied_thresh,
+                                var_thresh, prior_A, prior_B, device);
+        return m;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+void la3dm_map_destroy(la3dm_map *m) {
+    if (!m) return;
+    delete m->map;
+    delete m;
+}
+
+int la3dm_map_insert_pointcloud(la3dm_map *m, const float *xyz, uint64_t n, const float *o, float ds, float free_res,
+                                float max_range) {
+    GUARD(m->map->insert_pointcloud(xyz, (size_t)n, 3, point3f(o[0], o[1], o[2]), ds, free_res, max_range); return 0;)
+}
+
+int la3dm_map_insert_training_data(la3dm_map *m, const float *xyzy, uint64_t n) {
+    GUARD(BGKOctoMap::GPPointCloud c; c.reserve(n);
+          for (uint64_t i = 0; i < n; ++i)
+              c.emplace_back(point3f(xyzy[4 * i], xyzy[4 * i + 1], xyzy[4 * i + 2]), xyzy[4 * i + 3]);
+          m->map->insert_training_data(c); return 0;)
+}
+
+int la3dm_map_prepare(la3dm_map *m, const float *xyz, uint64_t n, const float *o, float ds, float free_res,
+                      float max_range) {
+    GUARD(return m->map->prepare(xyz, (size_t)n, 3, point3f(o[0], o[1], o[2]), ds, free_res, max_range) ? 1 : 0;)
+}
+
+int la3dm_map_prepare_training_data(la3dm_map *m, const float *xyzy, uint64_t n, int ungated) {
+    GUARD(return m->map->prepare_training_data(xyzy, (size_t)n, ungated != 0) ? 1 : 0;)
+}
+
+int la3dm_map_packed(la3dm_map *m, la3dm_bgk_scan *out) {
+    GUARD(if (m->map->num_passes() == 0) {
+        std::memset(out, 0, sizeof(*out));
+        return 0;
+    } *out = m->map->packed(0);
+          return 0;)
+}
+
+int la3dm_map_commit(la3dm_map *m) { GUARD(m->map->commit(); return 0;) }
+
+la3dm_ctx *la3dm_map_ctx(la3dm_map *m) { return m->map->device_ctx(); }
+
+int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out) {
+    const la3dm::ScanStats &s = m->map->last_stats();
+    out->n_hits = s.n_hits; out->n_frees = s.n_frees; out->n_bbox_blocks = s.n_bbox_blocks;
+    out->n_train_blocks = s.n_train_blocks; out->n_test_blocks = s.n_test_blocks;
+    out->voxel_updates = s.voxel_updates; out->train_reads = s.train_reads; out->pair_evals = s.pair_evals;
+    out->n_tiles = s.n_tiles;
+    out->t_frontend = s.t_frontend; out->t_partition = s.t_partition; out->t_pack = s.t_pack;
+    out->t_device = s.t_device; out->t_commit = s.t_commit; out->t_prune = s.t_prune; out->t_total = s.t_total;
+    return 0;
+}
+
+uint64_t la3dm_map_training_size(const la3dm_map *m) { return m->map->last_training_data().size() / 4; }
+
+int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap) {
+    const std::vector<float> &v = m->map->last_training_data();
+    std::memcpy(xyzy, v.data(), sizeof(float) * std::min<size_t>(v.size(), 4 * cap));
+    return 0;
+}
+
+float la3dm_map_block_size(const la3dm_map *m) { return m->map->get_block_size(); }
+uint64_t la3dm_map_block_count(const la3dm_map *m) { return m->map->block_count(); }
+
+uint64_t la3dm_map_leaf_count(const la3dm_map *m) {
+    uint64_t n = 0;
+    for (auto it = m->map->begin_leaf(); it != m->map->end_leaf(); ++it) ++n;
+    return n;
+}
+
+uint64_t la3dm_map_dump_leaves(const la3dm_map *m, int64_t *block_key, int32_t *node_key, float *loc, float *size,
+                               float *A, float *B, uint8_t *state, uint8_t *classified, uint64_t cap) {
+    struct Row {
+        int64_t bk;
+        uint64_t seq;
+        int32_t nk;
+        float loc[3], size, p, v;
+        uint8_t st, cl;
+    };
+    // the map iterates blocks in hash-map order; sort rows by (block key, leaf sequence)
+    std::vector<Row> rows;
+    uint64_t seq = 0;
+    for (auto it = m->map->begin_leaf(); it != m->map->end_leaf(); ++it, ++seq) {
+        Row r;
+        r.bk = it.get_block_key();
+        r.seq = seq;
+        r.nk = it.get_node_key();
+        const point3f p = it.get_loc();
+        r.loc[0] = p.x(); r.loc[1] = p.y(); r.loc[2] = p.z();
+        r.size = it.get_size();
+        const la3dm::OcTreeNode &nd = it.get_node();
+        // alpha/beta are private; recover them exactly from the public accessors is not
+        // possible, so the C view goes through the block search path below
+        r.p = 0; r.v = 0;
+        r.st = (uint8_t)nd.get_state();
+        r.cl = nd.classified ? 1 : 0;
+        rows.push_back(r);
+    }
+    std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.bk < b.bk; });
+    uint64_t n = std::min<uint64_t>(rows.size(), cap);
+    for (uint64_t i = 0; i < n; ++i) {
+        const Row &r = rows[i];
+        block_key[i] = r.bk; node_key[i] = r.nk;
+        loc[3 * i] = r.loc[0]; loc[3 * i + 1] = r.loc[1]; loc[3 * i + 2] = r.loc[2];
+        size[i] = r.size; state[i] = r.st; classified[i] = r.cl;
+        const la3dm::OcTreeNode &nd = (*m->map->search((la3dm::BlockHashKey)r.bk))[r.nk];
+        la3dm_node_ab(&nd, &A[i], &B[i]);
+    }
+    return rows.size();
+}
+
+int la3dm_map_search(const la3dm_map *m, float x, float y, float z, float *A, float *B, uint8_t *state) {
+    la3dm::Block *b = m->map->search(la3dm::block_to_hash_key(x, y, z));
+    la3dm::OcTreeNode nd = m->map->search(x, y, z);
+    la3dm_node_ab(&nd, A, B);
+    *state = (uint8_t)nd.get_state();
+    return b != nullptr;
+}
+
+int la3dm_map_get_bbox(const la3dm_map *m, float *lo, float *hi) {
+    point3f a, b;
+    m->map->get_bbox(a, b);
+    for (unsigned i = 0; i < 3; ++i) { lo[i] = a(i); hi[i] = b(i); }
+    return 0;
+}
+
+int64_t la3dm_map_block_to_hash_key(const la3dm_map *, float x, float y, float z) { return la3dm::block_to_hash_key(x, y, z); }
+void la3dm_map_hash_key_to_block(const la3dm_map *, int64_t key, float *out3) {
+    const point3f c = la3dm::hash_key_to_block(key);
+    out3[0] = c.x(); out3[1] = c.y(); out3[2] = c.z();
+}
+void la3dm_map_extended_block(const la3dm_map *, int64_t key, int64_t *out7) {
+    const la3dm::ExtendedBlock e = la3dm::get_extended_block(key);
+    for (int i = 0; i < 7; ++i) out7[i] = e[i];
+}
+uint32_t la3dm_map_lut(const la3dm_map *m, float *xyz, uint32_t cap) {
+    const std::vector<point3f> lut = la3dm::init_key_loc_map(m->map->get_resolution(), (unsigned short)m->map->get_block_depth());
+    uint32_t n = std::min<uint32_t>((uint32_t)lut.size(), cap);
+    for (uint32_t i = 0; i < n; ++i) { xyz[3 * i] = lut[i].x(); xyz[3 * i + 1] = lut[i].y(); xyz[3 * i + 2] = lut[i].z(); }
+    return (uint32_t)lut.size();
+}
+
+}  // extern "C"

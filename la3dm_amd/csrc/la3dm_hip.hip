@@ -1,0 +1,293 @@
+// la3dm_hip.hip — implementation of the C ABI in include/la3dm_hip.h.
+// Owns the device context: voxel LUT, grow-only scratch arenas, launch glue.
+// There is no CPU fallback anywhere in this file.
+#include "../../include/la3dm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bgk_kernels.h"
+
+using namespace la3dm_dev;
+
+static thread_local std::string g_create_error;
+
+struct Arena {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct la3dm_ctx {
+    la3dm_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;  // used by the host-pointer entry points
+    float4 *d_lut = nullptr;
+    uint32_t lut_count = 0;
+    std::string err;
+    int opt_variant = 0;   // 0 default
+    int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
+    // scratch (device-pointer path)
+    Arena pts_scaled;
+    // staging (host-pointer path)
+    Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,
+        h_diag_out;
+};
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+            return LA3DM_ERR_HIP;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+static int arena_reserve(la3dm_ctx *ctx, Arena &a, size_t bytes) {
+    if (bytes <= a.cap) return LA3DM_OK;
+    if (a.ptr) {
+        HIP_TRY(ctx, hipFree(a.ptr));
+        a.ptr = nullptr;
+        a.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&a.ptr, want);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+        a.ptr = nullptr;
+        return LA3DM_ERR_OOM;
+    }
+    a.cap = want;
+    return LA3DM_OK;
+}
+
+extern "C" {
+
+int la3dm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *la3dm_version(void) { return "la3dm_hip 0.1 (gfx950)"; }
+
+const char *la3dm_last_error(const la3dm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
+    if (!params || !out) {
+        g_create_error = "la3dm_create: null argument";
+        return LA3DM_ERR_ARG;
+    }
+    *out = nullptr;
+    if (params->block_depth < 1 || params->block_depth > 6 || !(params->ell > 0.0f) || !params->lut_xyz) {
+        g_create_error = "la3dm_create: bad params (block_depth must be 1..6, ell > 0, lut_xyz non-null)";
+        return LA3DM_ERR_ARG;
+    }
+    uint32_t want = 0;
+    for (int d = 0; d < params->block_depth; ++d) want += 1u << (3 * d);
+    if (params->lut_count != want) {
+        g_create_error = "la3dm_create: lut_count must be sum_{d<block_depth} 8^d";
+        return LA3DM_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "la3dm_create: no HIP device visible (this library has no CPU fallback)";
+        return LA3DM_ERR_NODEVICE;
+    }
+    if (params->device < 0 || params->device >= ndev) {
+        g_create_error = "la3dm_create: device ordinal out of range";
+        return LA3DM_ERR_ARG;
+    }
+    la3dm_ctx *ctx = new la3dm_ctx;
+    ctx->p = *params;
+    ctx->p.lut_xyz = nullptr;
+    ctx->device = params->device;
+    ctx->lut_count = params->lut_count;
+    auto fail = [&](const char *what, hipError_t e) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        delete ctx;
+        return LA3DM_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(ctx->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        return fail("hipStreamCreate", e);
+    std::vector<float4> lut4(ctx->lut_count);
+    for (uint32_t i = 0; i < ctx->lut_count; ++i)
+        lut4[i] = make_float4(params->lut_xyz[3 * i], params->lut_xyz[3 * i + 1], params->lut_xyz[3 * i + 2], 0.0f);
+    if ((e = hipMalloc((void **)&ctx->d_lut, sizeof(float4) * ctx->lut_count)) != hipSuccess)
+        return fail("hipMalloc(lut)", e);
+    if ((e = hipMemcpy(ctx->d_lut, lut4.data(), sizeof(float4) * ctx->lut_count, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail("hipMemcpy(lut)", e);
+    *out = ctx;
+    return LA3DM_OK;
+}
+
+void la3dm_destroy(la3dm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    Arena *all[] = {&ctx->pts_scaled, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
+                    &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
+    for (Arena *a : all)
+        if (a->ptr) (void)hipFree(a->ptr);
+    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
+    if (!ctx || !name) return LA3DM_ERR_ARG;
+    if (!strcmp(name, "bgk_variant")) {
+        ctx->opt_variant = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "fast_trig")) {
+        ctx->opt_fast_trig = value;
+        return LA3DM_OK;
+    }
+    ctx->err = std::string("la3dm_set_option: unknown option ") + name;
+    return LA3DM_ERR_ARG;
+}
+
+static int check_scan(la3dm_ctx *ctx, const la3dm_bgk_scan *s) {
+    if (!ctx) return LA3DM_ERR_ARG;
+    if (!s) {
+        ctx->err = "scan: null";
+        return LA3DM_ERR_ARG;
+    }
+    if (s->n_test_blk == 0) return LA3DM_OK;
+    if (!s->nbr || !s->blk_center || !s->leaf_off || !s->leaf_key || !s->alpha || !s->beta || !s->state ||
+        !s->train_off || (s->n_train_pts && !s->train_xyzy)) {
+        ctx->err = "scan: null array pointer";
+        return LA3DM_ERR_ARG;
+    }
+    return LA3DM_OK;
+}
+
+int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_, la3dm_bgk_counters *out) {
+    int rc = check_scan(ctx, s);
+    if (rc != LA3DM_OK) return rc;
+    if (out) memset(out, 0, sizeof(*out));
+    if (s->n_test_blk == 0) return LA3DM_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // 1. x / ell once per training point
+    rc = arena_reserve(ctx, ctx->pts_scaled, sizeof(float4) * (size_t)(s->n_train_pts ? s->n_train_pts : 1));
+    if (rc != LA3DM_OK) return rc;
+    if (s->n_train_pts) {
+        dim3 g((s->n_train_pts + 255) / 256), b(256);
+        hipLaunchKernelGGL(bgk_prescale_points, g, b, 0, stream, (const float4 *)s->train_xyzy,
+                           (float4 *)ctx->pts_scaled.ptr, s->n_train_pts, ctx->p.ell);
+    }
+
+    // 2. predict + fuse
+    uint32_t max_leaves = 1u << (3 * (ctx->p.block_depth - 1));
+    uint32_t tpb = (max_leaves + kWave - 1) / kWave;  // power of two
+    uint32_t tpb_shift = 0;
+    while ((1u << tpb_shift) < tpb) ++tpb_shift;
+    BgkArgs a;
+    a.pts = (const float4 *)ctx->pts_scaled.ptr;
+    a.train_off = s->train_off;
+    a.nbr = s->nbr;
+    a.blk_center = s->blk_center;
+    a.leaf_off = s->leaf_off;
+    a.leaf_key = s->leaf_key;
+    a.alpha = s->alpha;
+    a.beta = s->beta;
+    a.state = s->state;
+    a.lut = ctx->d_lut;
+    a.n_test_blk = s->n_test_blk;
+    a.tpb_shift = tpb_shift;
+    a.n_tasks = s->n_test_blk << tpb_shift;
+    a.flags = s->flags;
+    a.sf2 = ctx->p.sf2;
+    a.ell = ctx->p.ell;
+    a.free_thresh = ctx->p.free_thresh;
+    a.occupied_thresh = ctx->p.occupied_thresh;
+    a.var_thresh = ctx->p.var_thresh;
+    dim3 grid((a.n_tasks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * kWave);
+    switch (ctx->opt_fast_trig) {
+    case 1: hipLaunchKernelGGL(bgk_predict_fuse_v1<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(bgk_predict_fuse_v1<2>, grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL(bgk_predict_fuse_v1<0>, grid, block, 0, stream, a); break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (out) {
+        out->n_tiles = a.n_tasks;
+        out->scratch_bytes = sizeof(float4) * (size_t)s->n_train_pts;
+    }
+    return LA3DM_OK;
+}
+
+int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out) {
+    int rc = check_scan(ctx, s);
+    if (rc != LA3DM_OK) return rc;
+    if (out) memset(out, 0, sizeof(*out));
+    if (s->n_test_blk == 0) return LA3DM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    struct Up {
+        Arena *a;
+        const void *src;
+        size_t bytes;
+    } ups[] = {
+        {&ctx->h_train, s->train_xyzy, sizeof(float) * 4 * (size_t)s->n_train_pts},
+        {&ctx->h_train_off, s->train_off, sizeof(uint32_t) * ((size_t)s->n_train_blk + 1)},
+        {&ctx->h_nbr, s->nbr, sizeof(int32_t) * 7 * (size_t)s->n_test_blk},
+        {&ctx->h_center, s->blk_center, sizeof(float) * 3 * (size_t)s->n_test_blk},
+        {&ctx->h_leaf_off, s->leaf_off, sizeof(uint32_t) * ((size_t)s->n_test_blk + 1)},
+        {&ctx->h_leaf_key, s->leaf_key, sizeof(uint32_t) * (size_t)s->n_leaf},
+        {&ctx->h_alpha, s->alpha, sizeof(float) * (size_t)s->n_leaf},
+        {&ctx->h_beta, s->beta, sizeof(float) * (size_t)s->n_leaf},
+    };
+    for (auto &u : ups) {
+        rc = arena_reserve(ctx, *u.a, u.bytes ? u.bytes : 16);
+        if (rc != LA3DM_OK) return rc;
+        if (u.bytes) HIP_TRY(ctx, hipMemcpyAsync(u.a->ptr, u.src, u.bytes, hipMemcpyHostToDevice, st));
+    }
+    rc = arena_reserve(ctx, ctx->h_state, s->n_leaf ? s->n_leaf : 16);
+    if (rc != LA3DM_OK) return rc;
+    la3dm_bgk_scan d = *s;
+    d.train_xyzy = (const float *)ctx->h_train.ptr;
+    d.train_off = (const uint32_t *)ctx->h_train_off.ptr;
+    d.nbr = (const int32_t *)ctx->h_nbr.ptr;
+    d.blk_center = (const float *)ctx->h_center.ptr;
+    d.leaf_off = (const uint32_t *)ctx->h_leaf_off.ptr;
+    d.leaf_key = (const uint32_t *)ctx->h_leaf_key.ptr;
+    d.alpha = (float *)ctx->h_alpha.ptr;
+    d.beta = (float *)ctx->h_beta.ptr;
+    d.state = (uint8_t *)ctx->h_state.ptr;
+    rc = la3dm_bgk_scan_device(ctx, &d, st, out);
+    if (rc != LA3DM_OK) return rc;
+    if (s->n_leaf) {
+        HIP_TRY(ctx, hipMemcpyAsync(s->alpha, d.alpha, sizeof(float) * (size_t)s->n_leaf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(s->beta, d.beta, sizeof(float) * (size_t)s->n_leaf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(s->state, d.state, (size_t)s->n_leaf, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *out) {
+    if (!ctx || !in || !out) return LA3DM_ERR_ARG;
+    if (n == 0) return LA3DM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = arena_reserve(ctx, ctx->h_diag_in, sizeof(float) * (size_t)n);
+    if (rc != LA3DM_OK) return rc;
+    rc = arena_reserve(ctx, ctx->h_diag_out, sizeof(float) * (size_t)n);
+    if (rc != LA3DM_OK) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_diag_in.ptr, in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(diag_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, op, (const float *)ctx->h_diag_in.ptr,
+                       (float *)ctx->h_diag_out.ptr, n, ctx->p.sf2, ctx->p.ell);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->h_diag_out.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+}  // extern "C"

@@ -237,11 +237,21 @@ bool block_prune(const Params &p, Block &b) {
 // ---------------------------------------------------------------------------
 // Sparse kernel: include/bgkoctomap/bgkinference.h:113-126 (elementwise, fp32)
 // r is the distance of the ell-prescaled coordinates.
+//
+// cos()/sin() of a float Eigen array are third-party (Eigen packet psin/pcos for
+// full packets, libm for the tail; version and SIMD level unpinned).  They are
+// restated as the CORRECTLY ROUNDED single-precision functions: the double libm
+// value rounded once to float (differs from the exactly rounded result only when
+// the true value lies within ~1e-16 relative of a rounding tie).  This is
+// independent of which cosf/sinf variant glibc's ifunc selects on the host.
 // ---------------------------------------------------------------------------
+inline float cr_cosf(float t) { return (float)cos((double)t); }
+inline float cr_sinf(float t) { return (float)sin((double)t); }
+
 inline float cov_sparse_elem(float r, float sf2) {
     float t = (r * 2.0f) * 3.1415926f;
-    float a = ((2.0f + cosf(t)) * (1.0f - r)) / 3.0f;
-    float b = sinf(t) / (2.0f * 3.1415926f);
+    float a = ((2.0f + cr_cosf(t)) * (1.0f - r)) / 3.0f;
+    float b = cr_sinf(t) / (2.0f * 3.1415926f);
     float k = (a + b) * sf2;
     if (k < 0.0) k = 0.0f;
     return k;
@@ -612,11 +622,14 @@ void orc_lut(void *h, int depth, int index, float *out3) {
 }
 
 float orc_kernel(float r, float sf2) { return cov_sparse_elem(r, sf2); }
+void orc_kernel_array(const float *r, int n, float sf2, float *out) {
+    for (int i = 0; i < n; ++i) out[i] = cov_sparse_elem(r[i], sf2);
+}
 // k(r) without the <0 clamp (for the support-radius test)
 float orc_kernel_raw(float r, float sf2) {
     float t = (r * 2.0f) * 3.1415926f;
-    float a = ((2.0f + cosf(t)) * (1.0f - r)) / 3.0f;
-    float b = sinf(t) / (2.0f * 3.1415926f);
+    float a = ((2.0f + cr_cosf(t)) * (1.0f - r)) / 3.0f;
+    float b = cr_sinf(t) / (2.0f * 3.1415926f);
     return (a + b) * sf2;
 }
 // exhaustive scan of fp32 r in [r0, r1]: returns max raw kernel value (must be <= 0 for r >= 1)

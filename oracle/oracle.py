@@ -51,6 +51,7 @@ def _load(name):
     lib.orc_lut.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p]
     lib.orc_kernel.restype = C.c_float
     lib.orc_kernel.argtypes = [C.c_float, C.c_float]
+    lib.orc_kernel_array.argtypes = [f32p, C.c_int, C.c_float, f32p]
     lib.orc_kernel_raw.restype = C.c_float
     lib.orc_kernel_raw.argtypes = [C.c_float, C.c_float]
     lib.orc_kernel_max_over.restype = C.c_float
@@ -197,6 +198,13 @@ def voxel_grid(xyz, leaf):
     out = np.zeros_like(xyz)
     n = lib().orc_voxel_grid(xyz, xyz.shape[0], leaf, out)
     return out[:n].copy()
+
+
+def kernel(r, sf2=1.0):
+    r = np.ascontiguousarray(r, np.float32)
+    out = np.zeros_like(r)
+    lib().orc_kernel_array(r, r.size, sf2, out)
+    return out
 
 
 def bgk_predict(sf2, ell, xs, x, y):
