@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py — voxel-updates/s of the BGK predict+fuse hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): BGKOctoMap, synthetic 200k-ray scan, 0.1 m resolution,
+config/methods/bgkoctomap.yaml parameters (block_depth 3, sf2 1, ell 0.2, free_res 0.5,
+ds_resolution = resolution, priors 0.001).  A "step" is one pass of the hot path over the
+scan: la3dm_bgk_scan_device() on the packed scan already resident in HBM (x/ell prescale
+kernel + bgk_predict_fuse kernel), i.e. every leaf of every test block receives its fused
+(ybar, kbar) from its <= 7 neighbour models and its alpha/beta/state update.
+value = voxel-updates (leaves of test blocks) per second, whole job.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling — every rank
+owns one scan of the same size (different seed), runs the kernel on its blocks, and one RCCL
+all-gather reassembles the updated (alpha, beta, state) grid of all ranks on every rank.
+
+Adds to the JSON line: "roofline" (algorithmic bytes / HIP-event kernel time vs 8 TB/s) and,
+at N=1, "cpu_baseline" (the CPU oracle timed on the host cores on the same scan).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=200000)
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--resolution", type=float, default=0.1)
+    ap.add_argument("--fast-trig", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (kernel variant 3); 0 = library default")
+    ap.add_argument("--remap", type=int, default=-1, help="workgroup->tile remap mode; -1 = library default")
+    ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): 1 skip k(r) evaluation, 2 skip tests")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-omp", action="store_true", help="also time the OpenMP oracle on all cores")
+    args = ap.parse_args()
+
+    import torch
+    import la3dm_amd
+    from la3dm_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- build the workload (host side, untimed) -------------------------------------
+    params = dict(la3dm_amd.BGK_YAML, resolution=args.resolution, block_depth=args.depth)
+    xyz, origin = la3dm_amd.synthetic_scan(args.rays, seed=1234 + rank)
+    m = la3dm_amd.BGKOctoMap(**params, device=local_rank)
+    t0 = time.perf_counter()
+    ok = m.prepare(xyz, origin, args.resolution, 0.5, -1.0)
+    t_prepare = time.perf_counter() - t0
+    assert ok
+    st = m.stats()
+    pk = m.packed()
+    U = int(st["voxel_updates"])
+    b_alg = 16 * int(st["train_reads"]) + 17 * U
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    d = dict(train=up(pk.train_xyzy), train_off=up(pk.train_off.view(np.int32)), nbr=up(pk.nbr), center=up(pk.blk_center),
+             leaf_off=up(pk.leaf_off.view(np.int32)), leaf_key=up(pk.leaf_key.view(np.int32)), alpha=up(pk.alpha),
+             beta=up(pk.beta), state=torch.zeros(pk.n_leaf, dtype=torch.uint8, device=dev))
+    scan = _lib.BgkScan()
+    scan.train_xyzy = d["train"].data_ptr()
+    scan.train_off = d["train_off"].data_ptr()
+    scan.n_train_pts = pk.n_train_pts
+    scan.n_train_blk = pk.n_train_blk
+    scan.nbr = d["nbr"].data_ptr()
+    scan.blk_center = d["center"].data_ptr()
+    scan.leaf_off = d["leaf_off"].data_ptr()
+    scan.n_test_blk = pk.n_test_blk
+    scan.n_leaf = pk.n_leaf
+    scan.leaf_key = d["leaf_key"].data_ptr()
+    scan.alpha = d["alpha"].data_ptr()
+    scan.beta = d["beta"].data_ptr()
+    scan.state = d["state"].data_ptr()
+    scan.flags = 0
+
+    H = _lib.hip()
+    ctx = m.ctx()
+    if args.fast_trig:
+        m.set_option("fast_trig", args.fast_trig)
+    if args.variant:
+        m.set_option("bgk_variant", args.variant)
+    if args.waves:
+        m.set_option("waves_per_wg", args.waves)
+    if args.remap >= 0:
+        m.set_option("remap", args.remap)
+    if args.ablate:
+        m.set_option("ablate", args.ablate)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # all-gather buffers (N > 1): every rank contributes alpha|beta|state of its leaves, padded
+    gather_in = gather_out = None
+    if world > 1:
+        n_leaf_max = torch.tensor([pk.n_leaf], device=dev)
+        dist.all_reduce(n_leaf_max, op=dist.ReduceOp.MAX)
+        cap = int(n_leaf_max.item())
+        gather_in = torch.zeros(cap * 9, dtype=torch.uint8, device=dev)
+        gather_out = torch.zeros(world * cap * 9, dtype=torch.uint8, device=dev)
+
+    def step():
+        rc = H.la3dm_bgk_scan_device(ctx, C.byref(scan), stream, None)
+        if rc != 0:
+            raise RuntimeError(H.la3dm_last_error(ctx).decode())
+        if world > 1:
+            n = pk.n_leaf
+            gather_in[0:4 * n].copy_(d["alpha"].view(torch.uint8))
+            gather_in[4 * cap:4 * cap + 4 * n].copy_(d["beta"].view(torch.uint8))
+            gather_in[8 * cap:8 * cap + n].copy_(d["state"])
+            dist.all_gather_into_tensor(gather_out, gather_in)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    m.set_option("time_kernel", 1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    kt = np.zeros(args.steps + 8, np.float32)
+    nk = C.c_uint32()
+    H.la3dm_kernel_times(ctx, kt.ctypes.data, kt.size, C.byref(nk))
+    m.set_option("time_kernel", 0)
+    k_ms = float(kt[:nk.value].mean()) if nk.value else float("nan")
+
+    total_U = U
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        uu = torch.tensor([U], dtype=torch.float64, device=dev)
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        total_U = int(uu.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_U / (dt / args.steps)
+        achieved = b_alg / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "bgk_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                key = f"rays{args.rays}_d{args.depth}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "voxel-updates/sec per scan (200k pts, 0.1 m res); HBM GB/s vs roofline",
+            "value": value, "unit": "voxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BGKOctoMap synthetic {args.rays}-ray scan, {args.resolution} m res, "
+                                   f"block_depth {args.depth}, bgkoctomap.yaml kernel params (configs[1])",
+                       "rays": args.rays, "resolution": args.resolution, "block_depth": args.depth,
+                       "ds_resolution": args.resolution, "free_resolution": 0.5,
+                       "hits": int(st["n_hits"]), "frees": int(st["n_frees"]),
+                       "test_blocks": int(st["n_test_blocks"]), "train_blocks": int(st["n_train_blocks"]),
+                       "voxel_updates_per_scan": U, "pair_evals_per_scan": int(st["pair_evals"]),
+                       "parallelism": "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)" if world > 1
+                       else "single GPU", "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
+                       "kernel_variant": args.variant, "waves_per_wg": args.waves, "remap": args.remap},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "bgk_predict_fuse", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
+                         "pair_evals_per_s": int(st["pair_evals"]) / (k_ms * 1e-3)},
+            "host": {"prepare_s": t_prepare, "frontend_s": st["t_frontend"], "partition_s": st["t_partition"],
+                     "pack_s": st["t_pack"]},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(params, xyz, origin, args, U)
+            if args.cpu_omp:
+                out["cpu_baseline_omp"] = cpu_baseline(params, xyz, origin, args, U, omp=True)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(params, xyz, origin, args, U, omp=False):
+    """The CPU oracle (strict-fp32 restatement of the reference's insert_pointcloud) on the same
+    scan, on this box's host cores.  Bounded: for the default 200k-ray scan one full
+    insert_pointcloud takes ~10-20 s on one core; larger workloads are subsampled by rays."""
+    from oracle import oracle as O
+    rays = xyz.shape[0]
+    sample = xyz
+    desc = f"full {rays}-ray scan, 1 insert_pointcloud"
+    if rays > 250000 and not omp:
+        sample = xyz[:: int(np.ceil(rays / 250000))]
+        desc = f"every {int(np.ceil(rays / 250000))}th ray of the scan ({sample.shape[0]} rays), 1 insert_pointcloud"
+    o = O.OracleMap(**params, omp=omp)
+    t0 = time.perf_counter()
+    o.insert_pointcloud(sample, origin, args.resolution, 0.5, -1.0)
+    t = time.perf_counter() - t0
+    s = o.stats()
+    cores = O.lib(omp).orc_num_threads() if omp else 1
+    return {"value": s["voxel_updates"] / s["t_predict"], "unit": "voxel-updates/s", "cores": cores, "kind": "port",
+            "sample": desc + "; value = leaves of test blocks / predict+fuse stage time",
+            "stage_s": {"frontend": s["t_frontend"], "partition": s["t_partition"], "predict_fuse": s["t_predict"],
+                        "prune": s["t_prune"], "insert_pointcloud": t},
+            "voxel_updates": s["voxel_updates"], "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

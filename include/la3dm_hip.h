@@ -110,7 +110,9 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out);
 void la3dm_destroy(la3dm_ctx *ctx);
 const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last create error */
 
-/* Select the kernel implementation (A/B measurements): 0 = default. */
+/* Options: "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial,
+ * 2 = OCML; "bgk_variant" selects the kernel implementation (A/B measurements);
+ * "time_kernel" see la3dm_kernel_times. */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */
@@ -121,10 +123,23 @@ int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, la3dm_bgk_co
  * scratch arena is reused by the next call, so calls must be stream-ordered. */
 int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, void *stream, la3dm_bgk_counters *out);
 
+/* Kernel timing.  After la3dm_set_option(ctx, "time_kernel", 1) every *_scan_device call
+ * brackets its dominant kernel (bgk_predict_fuse) with HIP events on the launch stream.
+ * This call waits for them, writes the elapsed milliseconds of each launch since the
+ * last call (oldest first, at most cap) and resets the list. */
+int la3dm_kernel_times(la3dm_ctx *ctx, float *ms, uint32_t cap, uint32_t *n_out);
+
 /* Diagnostics used by the parity tests: evaluate one primitive of the device
  * arithmetic elementwise on host arrays.  op: 0 sqrt(x)  1 sin(x)  2 cos(x)
  * 3 sparse kernel k(r) with the ctx's sf2 (clamped)  4 x / ell  5 k(r) unclamped. */
 int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *out);
+
+
+/* Exhaustive device-side sweep over every fp32 bit pattern in [lo_bits, hi_bits]: counts the
+ * inputs where a shortcut of the kernel differs from the IEEE result.  what: 0  x/3 by
+ * reciprocal+FMA correction, 1  x/(2*pi') likewise, 2  lean sqrt vs correctly rounded sqrt,
+ * 3  sin/cos (f64 kernels rounded to f32) vs the f64 library functions rounded to f32. */
+int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ class ScanStats(C.Structure):
 
 
 HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_destroy", "la3dm_last_error",
-               "la3dm_set_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_diag_eval"]
+               "la3dm_set_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
                "la3dm_map_packed", "la3dm_map_commit", "la3dm_map_ctx", "la3dm_map_stats", "la3dm_map_training_size",
@@ -82,6 +82,10 @@ def hip():
         L.la3dm_bgk_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_bgk_scan_device.restype = C.c_int
         L.la3dm_bgk_scan_device.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.c_void_p, C.POINTER(BgkCounters)]
+        L.la3dm_kernel_times.restype = C.c_int
+        L.la3dm_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.la3dm_diag_sweep.restype = C.c_int
+        L.la3dm_diag_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.la3dm_diag_eval.restype = C.c_int
         L.la3dm_diag_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
         _hip = L

@@ -164,6 +164,18 @@ class BGKOctoMap:
             raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
         return y
 
+    def diag_sweep(self, what, lo, hi):
+        """count fp32 inputs in [lo, hi] (floats, same sign) where a kernel shortcut differs from IEEE"""
+        lo_b = int(np.float32(lo).view(np.uint32))
+        hi_b = int(np.float32(hi).view(np.uint32))
+        if lo_b > hi_b:
+            lo_b, hi_b = hi_b, lo_b
+        out = C.c_uint64()
+        rc = _lib.hip().la3dm_diag_sweep(self.ctx(), what, lo_b, hi_b, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
+        return out.value
+
     # host bookkeeping primitives
     def block_to_hash_key(self, x, y, z):
         return self._M.la3dm_map_block_to_hash_key(self._h, x, y, z)

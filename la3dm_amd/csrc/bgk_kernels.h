@@ -46,6 +46,7 @@ struct BgkArgs {
     uint32_t tpb_shift;         // log2(tiles per test block)
     uint32_t n_tasks;           // n_test_blk << tpb_shift
     uint32_t flags;
+    uint32_t remap;             // 0 contiguous range per XCD, 1 identity, 2 chunks of 8
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
 };
 
@@ -139,6 +140,13 @@ __device__ __forceinline__ float div_const(float x, float d, float inv_d) {
     const float q = x * inv_d;
     const float rem = __builtin_fmaf(-q, d, x);
     return __builtin_fmaf(rem, inv_d, q);
+}
+// two correction steps (the refinement core of the hardware division sequence with the
+// reciprocal folded into a constant)
+__device__ __forceinline__ float div_const2(float x, float d, float inv_d) {
+    const float q0 = x * inv_d;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, x), inv_d, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, x), inv_d, q1);
 }
 
 // trig flavours: 0 = correctly rounded (default, parity), 1 = f32 polynomial (<= 1.5 ulp),
@@ -279,6 +287,487 @@ __global__ __launch_bounds__(kWavesPerWG *kWave) void bgk_predict_fuse_v1(BgkArg
             a.state[li] = 0;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Variant 2 (default): pair compaction.
+//   A. stage: lane = training point; all <=7 neighbour chunks are loaded up front
+//      (independent 16-byte loads in flight together), culled against the tile's box,
+//      ballot/mbcnt-compacted into the wave's LDS candidate list.
+//   B. test: lane = leaf; for each candidate (LDS broadcast) d2 = dx^2 + (dy^2 + dz^2);
+//      lanes with d2 < 1 append {d2, leaf | nb | candidate} to an LDS ring queue.
+//   C. evaluate: whenever 64 pairs are queued every lane takes one pair — sqrt, the
+//      sparse kernel (correctly rounded sin/cos) at full lane utilisation — and adds
+//      k and k*y to the (neighbour, leaf) accumulators with LDS float atomics.
+//   D. fuse: lane = leaf; the 7 (ybar, kbar) pairs are applied in ExtendedBlock order
+//      exactly like the reference's update loop; alpha/beta/state are written once.
+// Only ~7.5 % of the (leaf, point) pairs lie inside the kernel support, so moving the
+// ~75-instruction kernel evaluation off the sparse lane mask is the main lever.
+// ---------------------------------------------------------------------------
+constexpr int kCand = 128;   // candidate list capacity per wave
+constexpr int kQueue = 256;  // pair ring capacity per wave (power of two)
+
+struct __attribute__((aligned(16))) WaveLds {
+    float4 cand[kCand];      // x/ell, y/ell, z/ell, label
+    uint32_t cand_nb[kCand]; // neighbour slot << 6
+    uint2 queue[kQueue];     // d2 bits, leaf | nb << 6 | cand << 9
+    float acc[14][kWave];    // [2*nb] = kbar, [2*nb+1] = ybar
+};
+
+template <int kTrig>
+__device__ __forceinline__ void eval_pairs(WaveLds &L, uint32_t head, uint32_t n, int lane, float sf2) {
+    if ((uint32_t)lane < n) {
+        const uint2 e = L.queue[(head + lane) & (kQueue - 1)];
+        const float d2 = __uint_as_float(e.x);
+        const uint32_t leaf = e.y & 63u, nb = (e.y >> 6) & 7u, cj = e.y >> 9;
+        const float y = L.cand[cj].w;
+        const float r = sqrtf(d2);
+        const float k = cov_sparse<true, kTrig>(r, sf2);
+        if (k > 0.0f) {
+            __hip_atomic_fetch_add(&L.acc[2 * nb][leaf], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const float ky = k * y;
+            if (ky != 0.0f)
+                __hip_atomic_fetch_add(&L.acc[2 * nb + 1][leaf], ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+}
+
+template <int kTrig>
+__global__ __launch_bounds__(kWavesPerWG *kWave) void bgk_predict_fuse_v2(BgkArgs a) {
+    __shared__ WaveLds s_lds[kWavesPerWG];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWavesPerWG + wv);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    WaveLds &L = s_lds[wv];
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = (uint32_t)lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+
+    // neighbour table (wave-uniform -> scalar registers)
+    int tb[7];
+    uint32_t p0[7], cnt[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        tb[b] = a.nbr[7 * blk + b];
+        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
+        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
+    }
+    // first chunk of every neighbour: issue all loads before anything depends on them
+    float4 q[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b)
+        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const uint32_t key = a.leaf_key[li];
+    const float4 off = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs = (off.x + cx) / a.ell, ys = (off.y + cy) / a.ell, zs = (off.z + cz) / a.ell;
+    float A = a.alpha[li], B = a.beta[li];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) L.acc[i][lane] = 0.0f;
+
+    const float lox = wave_min(xs), loy = wave_min(ys), loz = wave_min(zs);
+    const float hix = wave_max(xs), hiy = wave_max(ys), hiz = wave_max(zs);
+
+    uint32_t ncand = 0, qhead = 0, qcount = 0;
+
+    // box cull + ballot compaction of one chunk (lane = point); caller guarantees room
+    auto stage = [&](const float4 &p, bool valid, uint32_t b) {
+        bool keep = false;
+        if (valid) {
+            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
+            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
+            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
+            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) {
+            L.cand[slot] = p;
+            L.cand_nb[slot] = b << 6;
+        }
+        ncand += (uint32_t)__popcll(m);
+    };
+
+    // A (common case): the preloaded first chunks, as long as they fit
+    uint32_t deferred = 0;  // bit b: first chunk of neighbour b not staged yet
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        if (cnt[b] == 0) continue;
+        if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand)
+            stage(q[b], (uint32_t)lane < cnt[b], (uint32_t)b);
+        else
+            deferred |= 1u << b;
+    }
+    // chunks still to stage after the first round (rare: > 64 points in a block, or overflow)
+    uint32_t it_b = 0, it_base = (deferred & 1u) ? 0u : kWave;
+    bool more = true;
+    while (more) {
+        // B + C over the current candidate list; iteration j == ncand drains the queue
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = 0; j <= ncand; ++j) {
+            if (j < ncand) {
+                const float4 t = L.cand[j];
+                const uint32_t nbbits = L.cand_nb[j];
+                const float dx = t.x - xs, dy = t.y - ys, dz = t.z - zs;
+                const float d2 = dx * dx + (dy * dy + dz * dz);
+                const bool hit = active && d2 < 1.0f;  // k(r) <= 0 for every fp32 r >= 1
+                const unsigned long long m = __ballot(hit);
+                if (m == 0ull) continue;
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                if (hit)
+                    L.queue[(qhead + qcount + pos) & (kQueue - 1)] =
+                        make_uint2(__float_as_uint(d2), (uint32_t)lane | nbbits | (j << 9));
+                qcount += (uint32_t)__popcll(m);
+            }
+            const uint32_t n_eval = qcount >= (uint32_t)kWave ? (uint32_t)kWave : (j == ncand ? qcount : 0u);
+            if (n_eval) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                eval_pairs<kTrig>(L, qhead, n_eval, lane, a.sf2);
+                qhead = (qhead + n_eval) & (kQueue - 1);
+                qcount -= n_eval;
+            }
+        }
+        ncand = 0;
+        __builtin_amdgcn_wave_barrier();
+        // refill from the remaining chunks (generic, scalar re-reads of the neighbour table)
+        more = false;
+        while (it_b < 7) {
+            const int tbv = a.nbr[7 * blk + it_b];
+            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
+            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
+            if (it_base >= pc) {
+                ++it_b;
+                it_base = (it_b < 7 && ((deferred >> it_b) & 1u)) ? 0u : kWave;
+                continue;
+            }
+            if (ncand + (uint32_t)kWave > (uint32_t)kCand) break;
+            const bool valid = it_base + lane < pc;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) p = a.pts[pp0 + it_base + lane];
+            stage(p, valid, it_b);
+            it_base += kWave;
+            more = true;
+        }
+    }
+
+    // D. fuse in ExtendedBlock order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool updated = false;
+    const bool ungated = (a.flags & 1u) != 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        if (tb[b] < 0) continue;
+        const float kbar = L.acc[2 * b][lane], ybar = L.acc[2 * b + 1][lane];
+        if (kbar > 0.0f || ungated) {
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+    }
+    if (active) {
+        if (updated) {
+            a.alpha[li] = A;
+            a.beta[li] = B;
+            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[li] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Variant 3: variant 2's pipeline tightened after profiling (rocprofv3: variant 2 was
+// instruction-issue and LDS-latency bound at ~2 waves/SIMD):
+//   * one wave per workgroup (no wave waits for a slower sibling to release LDS),
+//   * DPP row reductions for the tile box instead of ds_bpermute shuffles,
+//   * candidates read four at a time (one LDS wait per four tests), neighbour slot carried
+//     in the candidate record, labels fetched only by the evaluation step,
+//   * inactive lanes carry NaN coordinates so no per-test lane mask is needed,
+//   * exact division by the constants 3 and 2*pi' via one FMA correction step and a lean
+//     correctly rounded sqrt (both swept exhaustively against IEEE results in the tests).
+// ---------------------------------------------------------------------------
+constexpr int kCand3 = 128;
+constexpr int kQueue3 = 128;
+
+struct __attribute__((aligned(16))) WaveLds3 {
+    float4 cand[kCand3];     // x/ell, y/ell, z/ell, bits(nb << 6)
+    float label[kCand3];
+    uint2 queue[kQueue3];    // d2 bits, leaf | nb << 6 | cand << 9
+    float acc[14][kWave];    // [2*nb] = kbar, [2*nb+1] = ybar
+};
+
+template <int kCtrl, int kRowMask = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, kRowMask, 0xF, false));
+}
+// min / max over the 64 lanes, result wave-uniform
+__device__ __forceinline__ float wave_min_dpp(float v) {
+    v = fminf(v, dpp_f<0xB1>(v));         // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_f<0x4E>(v));         // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_f<0x141>(v));        // row_half_mirror
+    v = fminf(v, dpp_f<0x140>(v));        // row_mirror
+    v = fminf(v, dpp_f<0x142, 0xA>(v));   // row_bcast15 into rows 1,3
+    v = fminf(v, dpp_f<0x143, 0xC>(v));   // row_bcast31 into rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    v = fmaxf(v, dpp_f<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_f<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// correctly rounded sqrt for x in {0} U [2^-100, 2^100]: hardware estimate (<= 1 ulp) plus the
+// standard one-ulp residual fix-up (no denormal pre-scaling: d2 is 0 or >= ~1e-15 here).
+__device__ __forceinline__ float sqrt_cr(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
+    float r = em <= 0.0f ? sm : s;
+    r = ep > 0.0f ? sp : r;
+    return r;
+}
+
+// covSparse elementwise (bgkinference.h:115-125) with the two constant divisions done by
+// div_const; bit-identical to cov_sparse<true, kTrig> (tests sweep the divisions exhaustively).
+template <int kTrig>
+__device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
+    const float t = (r * 2.0f) * 3.1415926f;
+    float s, c;
+    if (kTrig == 0) sincos_cr(t, s, c);
+    else if (kTrig == 1) sincos_0_2pi(t, s, c);
+    else { s = sinf(t); c = cosf(t); }
+    const float a = div_const((2.0f + c) * (1.0f - r), 3.0f, 0.333333343f);
+    const float b = div_const(s, 2.0f * 3.1415926f, 0.159154952f);
+    float k = (a + b) * sf2;
+    if (k < 0.0f) k = 0.0f;
+    return k;
+}
+
+template <int kTrig>
+__device__ __forceinline__ void eval_pairs3(WaveLds3 &L, uint32_t head, uint32_t n, int lane, float sf2, bool plain = false) {
+    if ((uint32_t)lane < n) {
+        const uint2 e = L.queue[(head + lane) & (kQueue3 - 1)];
+        const float d2 = __uint_as_float(e.x);
+        const float k = cov_sparse_fast<kTrig>(sqrt_cr(d2), sf2);
+        if (k > 0.0f) {
+            float *acc = &L.acc[0][0] + ((e.y >> 6) & 7u) * (2 * kWave) + (e.y & 63u);
+            const float y = L.label[e.y >> 9];
+            const float ky = k * y;
+            if (plain) {  // profiling ablation only (wrong sums)
+                acc[0] = k;
+                if (ky != 0.0f) acc[kWave] = ky;
+                return;
+            }
+            __hip_atomic_fetch_add(acc, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (ky != 0.0f) __hip_atomic_fetch_add(acc + kWave, ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+}
+
+template <int kTrig, int kWaves>
+__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v3(BgkArgs a) {
+    __shared__ WaveLds3 s_lds[kWaves];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t wg = blockIdx.x;
+    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
+    else if (a.remap == 2) {  // chunks of 8 consecutive logical workgroups stay on one XCD
+        const uint32_t G8 = gridDim.x & ~63u;
+        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
+    }
+    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    WaveLds3 &L = s_lds[wv];
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = (uint32_t)lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+
+    int tb[7];
+    uint32_t p0[7], cnt[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        tb[b] = a.nbr[7 * blk + b];
+        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
+        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
+    }
+    float4 q[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b)
+        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const uint32_t key = a.leaf_key[li];
+    const float4 off = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs0 = (off.x + cx) / a.ell, ys0 = (off.y + cy) / a.ell, zs0 = (off.z + cz) / a.ell;
+    float A = a.alpha[li], B = a.beta[li];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) L.acc[i][lane] = 0.0f;
+
+    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
+    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    // lanes beyond the tile never match (NaN compares false)
+    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;
+
+    uint32_t ncand = 0, qhead = 0, qcount = 0;
+
+    auto stage = [&](const float4 &p, bool valid, uint32_t b) {
+        bool keep = false;
+        if (valid) {
+            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
+            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
+            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
+            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) {
+            L.cand[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(b << 6));
+            L.label[slot] = p.w;
+        }
+        ncand += (uint32_t)__popcll(m);
+    };
+
+    uint32_t deferred = 0;
+    bool leftovers = false;  // anything the first round could not stage?
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        if (cnt[b] == 0) continue;
+        if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand3)
+            stage(q[b], (uint32_t)lane < cnt[b], (uint32_t)b);
+        else
+            deferred |= 1u << b;
+        leftovers |= cnt[b] > (uint32_t)kWave;
+    }
+    leftovers |= deferred != 0u;
+    uint32_t it_b = leftovers ? 0u : 7u, it_base = (deferred & 1u) ? 0u : kWave;
+    bool more = true;
+    while (more) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // B + C: four candidates per trip; the trip after the last one drains the queue
+        const uint32_t ntrip = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;
+        for (uint32_t g = 0; g <= ntrip; ++g) {
+            const bool last = g == ntrip;
+            float d2v[4];
+            uint32_t meta[4];
+            unsigned long long mv[4];
+            if (!last) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = L.cand[(4 * g + u) & (kCand3 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
+                    d2v[u] = dx * dx + (dy * dy + dz * dz);
+                    const bool hit = d2v[u] < 1.0f && (4 * g + u) < ncand;  // k(r) <= 0 for all fp32 r >= 1
+                    mv[u] = __ballot(hit);
+                    meta[u] = (uint32_t)lane | __float_as_uint(t[u].w) | ((4 * g + u) << 9);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!last && mv[u] != 0ull) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv[u], 0));
+                    if ((mv[u] >> lane) & 1ull)
+                        L.queue[(qhead + qcount + pos) & (kQueue3 - 1)] = make_uint2(__float_as_uint(d2v[u]), meta[u]);
+                    qcount += (uint32_t)__popcll(mv[u]);
+                }
+                const uint32_t n_eval = qcount >= (uint32_t)kWave ? (uint32_t)kWave : ((last && u == 0) ? qcount : 0u);
+                if (n_eval) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (!(a.flags & 0x100u)) eval_pairs3<kTrig>(L, qhead, n_eval, lane, a.sf2, (a.flags & 0x400u) != 0);
+                    qhead = (qhead + n_eval) & (kQueue3 - 1);
+                    qcount -= n_eval;
+                }
+            }
+        }
+        ncand = 0;
+        __builtin_amdgcn_wave_barrier();
+        more = false;
+        while (it_b < 7) {
+            const int tbv = a.nbr[7 * blk + it_b];
+            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
+            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
+            if (it_base >= pc) {
+                ++it_b;
+                it_base = (it_b < 7 && ((deferred >> it_b) & 1u)) ? 0u : kWave;
+                continue;
+            }
+            if (ncand + (uint32_t)kWave > (uint32_t)kCand3) break;
+            const bool valid = it_base + lane < pc;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) p = a.pts[pp0 + it_base + lane];
+            stage(p, valid, it_b);
+            it_base += kWave;
+            more = true;
+        }
+    }
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool updated = false;
+    const bool ungated = (a.flags & 1u) != 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        if (tb[b] < 0) continue;
+        const float kbar = L.acc[2 * b][lane], ybar = L.acc[2 * b + 1][lane];
+        if (kbar > 0.0f || ungated) {
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+    }
+    if (active) {
+        if (updated) {
+            a.alpha[li] = A;
+            a.beta[li] = B;
+            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[li] = 0;
+        }
+    }
+}
+
+// exhaustive sweeps of the two shortcuts used by variant 3 against the IEEE operations:
+// counts fp32 inputs in [lo_bits, hi_bits] (as unsigned bit patterns) where they differ.
+__global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatch) {
+    const uint64_t n = (uint64_t)hi_bits - lo_bits + 1;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo_bits + (uint32_t)i);
+        bool ok;
+        if (what == 0) ok = div_const(x, 3.0f, 0.333333343f) == x / 3.0f;
+        else if (what == 1) ok = div_const2(x, 2.0f * 3.1415926f, 0.159154952f) == x / (2.0f * 3.1415926f);
+        else if (what == 2) ok = sqrt_cr(x) == sqrtf(x);
+        else if (what == 4) ok = sqrtf(x) == (float)sqrt((double)x);
+        else if (what == 5) ok = div_const(x, 2.0f * 3.1415926f, 0.159154952f) == x / (2.0f * 3.1415926f);
+        else {  // sincos_cr vs the double-precision library functions rounded to float
+            float s, c;
+            sincos_cr(x, s, c);
+            ok = s == (float)sin((double)x) && c == (float)cos((double)x);
+        }
+        bad += ok ? 0 : 1;
+    }
+    if (bad) atomicAdd(mismatch, bad);
 }
 
 // diagnostics for the parity tests

@@ -550,6 +550,27 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
         prune_list.push_back(k);
     }
     stats.n_test_blocks = test.size();
+    // Device-side load balance: hand the GPU the heaviest test blocks first (longest-
+    // processing-time order, weight = training points in the 7-neighbourhood).  The blocks are
+    // independent, so the order only changes the layout of the packed arrays, not the results.
+    {
+        auto weight = [&](BlockHashKey k) {
+            const ExtendedBlock e = get_extended_block(k);
+            uint32_t w = 0;
+            for (int q = 0; q < 7; ++q) {
+                auto it = in_bbox.find(e[q]);
+                if (it != in_bbox.end() && it->second >= 0) w += train_off[it->second + 1] - train_off[it->second];
+            }
+            return w;
+        };
+        std::vector<std::pair<uint32_t, uint32_t>> order(test.size());  // (weight, position)
+        for (size_t i = 0; i < test.size(); ++i) order[i] = {weight(test[i].first), (uint32_t)i};
+        std::stable_sort(order.begin(), order.end(),
+                         [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first > b.first; });
+        std::vector<std::pair<BlockHashKey, uint32_t>> sorted(test.size());
+        for (size_t i = 0; i < test.size(); ++i) sorted[i] = test[order[i].second];
+        test.swap(sorted);
+    }
     const double t1 = wall();
     stats.t_partition = t1 - t0;
 

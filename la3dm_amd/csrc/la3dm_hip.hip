@@ -30,6 +30,12 @@ struct la3dm_ctx {
     std::string err;
     int opt_variant = 0;   // 0 default
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
+    int opt_time_kernel = 0;
+    int opt_waves = 1;  // waves per workgroup (variant 3)
+    int opt_remap = 2;
+    int opt_ablate = 0;  // profiling only: 1 skip kernel evaluation, 2 skip the candidate tests
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
+    size_t ev_used = 0;
     // scratch (device-pointer path)
     Arena pts_scaled;
     // staging (host-pointer path)
@@ -133,6 +139,10 @@ void la3dm_destroy(la3dm_ctx *ctx) {
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
+    for (auto &p : ctx->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -146,6 +156,23 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
     }
     if (!strcmp(name, "fast_trig")) {
         ctx->opt_fast_trig = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "waves_per_wg")) {
+        ctx->opt_waves = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "ablate")) {
+        ctx->opt_ablate = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "remap")) {
+        ctx->opt_remap = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "time_kernel")) {
+        ctx->opt_time_kernel = value;
+        ctx->ev_used = 0;
         return LA3DM_OK;
     }
     ctx->err = std::string("la3dm_set_option: unknown option ") + name;
@@ -203,18 +230,49 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.n_test_blk = s->n_test_blk;
     a.tpb_shift = tpb_shift;
     a.n_tasks = s->n_test_blk << tpb_shift;
-    a.flags = s->flags;
+    a.flags = s->flags | ((uint32_t)ctx->opt_ablate << 8);
+    a.remap = (uint32_t)ctx->opt_remap;
     a.sf2 = ctx->p.sf2;
     a.ell = ctx->p.ell;
     a.free_thresh = ctx->p.free_thresh;
     a.occupied_thresh = ctx->p.occupied_thresh;
     a.var_thresh = ctx->p.var_thresh;
     dim3 grid((a.n_tasks + kWavesPerWG - 1) / kWavesPerWG), block(kWavesPerWG * kWave);
-    switch (ctx->opt_fast_trig) {
-    case 1: hipLaunchKernelGGL(bgk_predict_fuse_v1<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(bgk_predict_fuse_v1<2>, grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL(bgk_predict_fuse_v1<0>, grid, block, 0, stream, a); break;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (ctx->opt_time_kernel) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> p;
+            HIP_TRY(ctx, hipEventCreate(&p.first));
+            HIP_TRY(ctx, hipEventCreate(&p.second));
+            ctx->ev_pool.push_back(p);
+        }
+        ev = &ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
     }
+#define LAUNCH_BGK(KERNEL, ...)                                                                 \
+    switch (ctx->opt_fast_trig) {                                                              \
+    case 1: hipLaunchKernelGGL((KERNEL<1 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
+    case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
+    default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, 0, stream, a); break;    \
+    }
+    if (ctx->opt_variant == 1) {
+        LAUNCH_BGK(bgk_predict_fuse_v1)
+    } else if (ctx->opt_variant == 2) {
+        LAUNCH_BGK(bgk_predict_fuse_v2)
+    } else {
+        const int w = ctx->opt_waves;
+        grid = dim3((a.n_tasks + w - 1) / w);
+        block = dim3(w * kWave);
+        if (w == 4) {
+            LAUNCH_BGK(bgk_predict_fuse_v3, , 4)
+        } else if (w == 2) {
+            LAUNCH_BGK(bgk_predict_fuse_v3, , 2)
+        } else {
+            LAUNCH_BGK(bgk_predict_fuse_v3, , 1)
+        }
+    }
+#undef LAUNCH_BGK
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
     HIP_TRY(ctx, hipGetLastError());
     if (out) {
         out->n_tiles = a.n_tasks;
@@ -269,6 +327,38 @@ int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_count
         HIP_TRY(ctx, hipMemcpyAsync(s->state, d.state, (size_t)s->n_leaf, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+int la3dm_kernel_times(la3dm_ctx *ctx, float *ms, uint32_t cap, uint32_t *n_out) {
+    if (!ctx || !n_out) return LA3DM_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t n = (uint32_t)ctx->ev_used;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pool[i].second));
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        if (ms && i < cap) ms[i] = t;
+    }
+    *n_out = n;
+    ctx->ev_used = 0;
+    return LA3DM_OK;
+}
+
+int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches) {
+    if (!ctx || !mismatches || hi_bits < lo_bits) return LA3DM_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = arena_reserve(ctx, ctx->h_diag_out, 16);
+    if (rc != LA3DM_OK) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->h_diag_out.ptr, 0, 8, st));
+    hipLaunchKernelGGL(sweep_check_kernel, dim3(4096), dim3(256), 0, st, what, lo_bits, hi_bits,
+                       (unsigned long long *)ctx->h_diag_out.ptr);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->h_diag_out.ptr, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *mismatches = v;
     return LA3DM_OK;
 }
 
