@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Generates the committed golden fixtures.  Run in the build container (needs /root/reference
+for the first file; the GPU box only reads the committed outputs).
+
+  ref_kat.npz      known answers captured from the REFERENCE's own std-only sources compiled in
+                   place (oracle/_ref, see oracle/ref_harness.cpp): block hashing, voxel LUT,
+                   leaf order, Occupancy::update sequences, OcTree::prune, R-tree box queries.
+  oracle_kat.npz   known answers of the CPU restatement for the parts the reference cannot pin
+                   (Eigen/PCL absent): kernel table k(r), per-block predict cases, voxel-grid
+                   filter case.  Regression pins + inputs for the GPU parity tests.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+YAML = (0.1, 3, 1.0, 0.2, 0.3, 0.7, 100.0, 0.001, 0.001)
+
+
+def ref_kat():
+    R = O.ref()
+    assert R is not None, "oracle/_ref not built (needs /root/reference)"
+    rng = np.random.default_rng(20260927)
+    out = {}
+    for depth in (3, 4, 5):
+        R.ref_configure(YAML[0], depth, *YAML[2:])
+        bs = R.ref_block_size()
+        out[f"d{depth}_block_size"] = np.float32(bs)
+        # hashing: random points, exact block-face points, negative coordinates
+        pts = np.concatenate([rng.uniform(-60, 60, (400, 3)),
+                              (rng.integers(-50, 50, (200, 3)) + 0.5) * bs,
+                              rng.integers(-50, 50, (100, 3)) * bs,
+                              [[0, 0, 0], [0.2, 0.2, 0.2], [0.39, -0.41, 7.45], [-3.75, 12.95, 4.25],
+                               [1, 1, 0.0997627]]]).astype(np.float32)
+        keys = np.array([R.ref_block_to_hash_key(*p) for p in pts], np.int64)
+        centres = np.zeros((len(pts), 3), np.float32)
+        ebs = np.zeros((len(pts), 7), np.int64)
+        t = np.zeros(3, np.float32)
+        e = np.zeros(7, np.int64)
+        for i, k in enumerate(keys):
+            R.ref_hash_key_to_block(int(k), t)
+            centres[i] = t
+            R.ref_get_extended_block(int(k), e)
+            ebs[i] = e
+        out[f"d{depth}_hash_pts"], out[f"d{depth}_hash_keys"] = pts, keys
+        out[f"d{depth}_hash_centres"], out[f"d{depth}_eblocks"] = centres, ebs
+        # LUT, depth-major
+        lut = []
+        for d in range(depth):
+            for i in range(8 ** d):
+                assert R.ref_lut(d, i, t)
+                lut.append(t.copy())
+        out[f"d{depth}_lut"] = np.asarray(lut, np.float32)
+        if depth == 5:
+            continue
+        # leaf order / positions of a fresh block, then random updates + prune rounds
+        cap = 8 ** (depth - 1)
+        for case in range(3):
+            c = (np.array([[0.8, 0.8, 0.0], [0.2, 0.2, 0.2], [-3.6, 12.8, 4.4]][case]) / 0.4 * bs).astype(np.float32)
+            b = R.ref_block_new(float(c[0]), float(c[1]), float(c[2]))
+            keys_l = np.zeros(cap, np.int32)
+            loc = np.zeros((cap, 3), np.float32)
+            sz = np.zeros(cap, np.float32)
+            n = R.ref_block_leaves(b, keys_l, loc, sz, cap)
+            tag = f"d{depth}_blk{case}"
+            out[f"{tag}_center"] = c
+            out[f"{tag}_fresh_keys"], out[f"{tag}_fresh_loc"], out[f"{tag}_fresh_size"] = keys_l[:n].copy(), loc[:n].copy(), sz[:n].copy()
+            ops = []   # (round, key, ybar, kbar)
+            dumps = []
+            for rnd in range(4):
+                n = R.ref_block_leaves(b, keys_l, loc, sz, cap)
+                cur = keys_l[:n].copy()
+                # drive whole sibling groups to one state so that pruning triggers
+                mode = rng.integers(0, 3, size=n)
+                for j, k in enumerate(cur):
+                    grp = (int(k) & 0xFFFF) // 8 + (int(k) >> 16) * 100000
+                    g = np.random.default_rng(grp + 17 * rnd + 1000 * case).integers(0, 4)
+                    if g == 0:
+                        yb, kb = 0.0, float(rng.uniform(0.5, 3))       # free
+                    elif g == 1:
+                        kb = float(rng.uniform(0.5, 3)); yb = kb       # occupied
+                    elif g == 2:
+                        kb = float(rng.uniform(0.0, 2)); yb = kb * float(rng.uniform(0, 1))
+                    else:
+                        continue
+                    R.ref_block_update(b, int(k), yb, kb)
+                    ops.append((rnd, int(k), yb, kb))
+                pr = R.ref_block_prune(b)
+                n = R.ref_block_leaves(b, keys_l, loc, sz, cap)
+                A = C.c_float(); B = C.c_float(); S = C.c_uint8(); P = C.c_float(); V = C.c_float()
+                rows = []
+                for k in keys_l[:n]:
+                    assert R.ref_block_node(b, int(k), C.byref(A), C.byref(B), C.byref(S), C.byref(P), C.byref(V))
+                    rows.append((int(k), A.value, B.value, S.value, P.value, V.value))
+                dumps.append((rnd, pr, np.asarray(rows, np.float64), loc[:n].copy(), sz[:n].copy()))
+            out[f"{tag}_ops"] = np.asarray(ops, np.float64)
+            for rnd, pr, rows, lc, s_ in dumps:
+                out[f"{tag}_r{rnd}_pruned"] = np.int32(pr)
+                out[f"{tag}_r{rnd}_leaves"] = rows
+                out[f"{tag}_r{rnd}_loc"] = lc
+                out[f"{tag}_r{rnd}_size"] = s_
+            R.ref_block_free(b)
+    # node update sequences
+    R.ref_configure(*YAML)
+    yb = np.concatenate([[0, 0.5, 0, 3, 2.5], rng.uniform(0, 1, 200)]).astype(np.float32)
+    kb = np.concatenate([[1e-9, 0.75, 2, 3, 2.5], rng.uniform(0, 1, 200)]).astype(np.float32)
+    kb[5:] = np.maximum(kb[5:], yb[5:])
+    n = len(yb)
+    A = np.zeros(n, np.float32); B = A.copy(); S = np.zeros(n, np.uint8); P = A.copy(); V = A.copy()
+    R.ref_node_sequence(yb, kb, n, A, B, S, P, V)
+    out.update(node_ybar=yb, node_kbar=kb, node_A=A, node_B=B, node_state=S, node_prob=P, node_var=V)
+    # R-tree closed-box rule: points on faces/corners/1-ulp off, queried through the reference's
+    # own RTree<int,float,3,float> with the box arithmetic of get_gp_points_in_bbox
+    bs = R.ref_block_size()
+    grid = (rng.integers(-6, 6, (300, 3)) + rng.choice([0.0, 0.5, -0.5], (300, 3))) * bs
+    pts = np.concatenate([rng.uniform(-2.5, 2.5, (2000, 3)), grid,
+                          np.nextafter((grid[:100]).astype(np.float32), np.float32(np.inf)),
+                          np.nextafter((grid[100:200]).astype(np.float32), np.float32(-np.inf)),
+                          [[0, 0, 0], [0.2, 0.2, 0.2], [0.2, 0, 0], [0.5, 0.5, 0.5], [-0.2, 0.1, 0.1]]]).astype(np.float32)
+    tree = R.ref_rtree_new(np.ascontiguousarray(pts), len(pts))
+    qkeys = sorted(set(int(R.ref_block_to_hash_key(*p)) for p in pts))
+    ids = np.zeros(len(pts), np.int32)
+    qk, qoff, qids = [], [0], []
+    for k in qkeys:
+        n = R.ref_rtree_block_query(tree, k, ids, len(ids))
+        qk.append(k)
+        qids.extend(sorted(ids[:n].tolist()))
+        qoff.append(len(qids))
+    R.ref_rtree_free(tree)
+    out.update(rtree_pts=pts, rtree_keys=np.asarray(qk, np.int64), rtree_off=np.asarray(qoff, np.int64),
+               rtree_ids=np.asarray(qids, np.int32))
+    np.savez_compressed(os.path.join(HERE, "ref_kat.npz"), **out)
+    print("ref_kat.npz:", len(out), "arrays")
+
+
+def oracle_kat():
+    rng = np.random.default_rng(7)
+    out = {}
+    r = np.concatenate([np.linspace(0, 1.25, 5001), rng.uniform(0.9, 1.0, 3000), [0.0, 0.5, 0.9, 0.99, 1.0, 1.05]]).astype(np.float32)
+    out["kernel_r"] = r
+    out["kernel_k_sf1"] = O.kernel(r, 1.0)
+    out["kernel_k_sf01"] = O.kernel(r, 0.1)
+    # per-block predict cases: rim pairs, empty-ish neighbours, duplicates
+    cases = []
+    for ci in range(6):
+        M = [64, 64, 8, 1, 64, 37][ci]
+        N = [16, 56, 3, 1, 320, 5][ci]
+        xs = rng.uniform(-0.2, 0.2, (M, 3)).astype(np.float32)
+        x = rng.uniform(-0.4, 0.4, (N, 3)).astype(np.float32)
+        if ci == 2:
+            x[1] = x[0]                       # duplicate training point
+            x[2] = xs[0] + np.float32(0.2) * np.array([1, 0, 0], np.float32)   # exactly at the rim
+        y = (rng.uniform(0, 1, N) < 0.3).astype(np.float32)
+        yb, kb = O.bgk_predict(1.0, 0.2, xs, x, y)
+        out[f"pred{ci}_xs"], out[f"pred{ci}_x"], out[f"pred{ci}_y"] = xs, x, y
+        out[f"pred{ci}_ybar"], out[f"pred{ci}_kbar"] = yb, kb
+    # voxel grid (restated PCL semantics)
+    pts = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    out["vg_in"] = pts
+    out["vg_out_0p1"] = O.voxel_grid(pts, 0.1)
+    out["vg_out_0p25"] = O.voxel_grid(pts, 0.25)
+    np.savez_compressed(os.path.join(HERE, "oracle_kat.npz"), **out)
+    print("oracle_kat.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    ref_kat()
+    oracle_kat()

@@ -1,0 +1,150 @@
+"""CPU tests of the PRODUCT's host side (not gpu): the C-ABI library loads and exports every
+declared symbol, refuses to run without a device, and the host-side BGKOctoMap (block hashing,
+front end, partition, packing, commit, prune) agrees with the oracle.  The device step is
+emulated here with the oracle's per-block predict (the oracle is only the checker)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, pcd_path
+
+YAML = dict(resolution=0.1, block_depth=3, sf2=1.0, ell=0.2, free_thresh=0.3, occupied_thresh=0.7, var_thresh=100.0,
+            prior_A=0.001, prior_B=0.001)
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(la3dm_\w+)\s*\(", txt)))
+
+
+def test_abi_exports_every_declared_symbol(built):
+    from la3dm_amd import _lib
+    h = C.CDLL(_lib.HIP_SO, mode=C.RTLD_GLOBAL)
+    names = _declared("la3dm_hip.h")
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(h, n), n
+    assert sorted(names) == sorted(_lib.HIP_SYMBOLS)
+    m = C.CDLL(_lib.MAP_SO)
+    mnames = [n for n in _declared("la3dm_map.h")]
+    for n in mnames:
+        assert hasattr(m, n), n
+    assert sorted(mnames) == sorted(_lib.MAP_SYMBOLS)
+
+
+def test_no_device_no_fallback(built):
+    """without a GPU the product refuses to run instead of computing on the CPU"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import la3dm_amd
+    from la3dm_amd import _lib
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        la3dm_amd.BGKOctoMap(**YAML, device=0)
+    m = la3dm_amd.BGKOctoMap(**YAML, device=-1)      # bookkeeping-only map
+    with pytest.raises(RuntimeError, match="no device context"):
+        m.insert_pointcloud(np.zeros((4, 3), np.float32), [0, 0, 0], 0.1)
+    p = _lib.Params()
+    out = C.c_void_p()
+    assert _lib.hip().la3dm_create(C.byref(p), C.byref(out)) == -1    # LA3DM_ERR_ARG (no LUT)
+    assert b"bad params" in _lib.hip().la3dm_last_error(None)
+
+
+@pytest.mark.parametrize("depth", [3, 4, 5])
+def test_host_hash_lut_against_reference_kat(built, depth):
+    import la3dm_amd
+    kat = np.load(os.path.join(GOLDEN, "ref_kat.npz"))
+    m = la3dm_amd.BGKOctoMap(**dict(YAML, block_depth=depth), device=-1)
+    assert np.float32(m.get_block_size()) == kat[f"d{depth}_block_size"]
+    for p, k, c, e in zip(kat[f"d{depth}_hash_pts"], kat[f"d{depth}_hash_keys"], kat[f"d{depth}_hash_centres"],
+                          kat[f"d{depth}_eblocks"]):
+        assert m.block_to_hash_key(*map(float, p)) == k
+        assert (m.hash_key_to_block(int(k)) == c).all()
+        assert (m.get_extended_block(int(k)) == e).all()
+    assert (m.lut() == kat[f"d{depth}_lut"]).all()
+
+
+def _emulate_device(pk, params):
+    """what la3dm_bgk_scan_* computes, done with the oracle's predict + node update"""
+    from oracle import oracle as O
+    o = O.OracleMap(**params)
+    lut = np.concatenate(o.lut())
+    base = [(8 ** d - 1) // 7 for d in range(8)]
+    a, b, s = C.c_float(), C.c_float(), C.c_uint8()
+    for t in range(pk.n_test_blk):
+        l0, l1 = int(pk.leaf_off[t]), int(pk.leaf_off[t + 1])
+        keys = pk.leaf_key[l0:l1]
+        xs = lut[[base[k >> 16] + (k & 0xFFFF) for k in keys]] + pk.blk_center[t]
+        for nb in pk.nbr[t]:
+            if nb < 0:
+                continue
+            p0, p1 = int(pk.train_off[nb]), int(pk.train_off[nb + 1])
+            yb, kb = O.bgk_predict(params["sf2"], params["ell"], xs, pk.train_xyzy[p0:p1, :3], pk.train_xyzy[p0:p1, 3])
+            for j in np.nonzero(kb > 0)[0]:
+                a.value, b.value, s.value = pk.alpha[l0 + j], pk.beta[l0 + j], pk.state[l0 + j] & 3
+                o.L.orc_node_update(o.h, C.byref(a), C.byref(b), C.byref(s), float(yb[j]), float(kb[j]))
+                pk.alpha[l0 + j], pk.beta[l0 + j], pk.state[l0 + j] = a.value, b.value, s.value | 0x80
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_prepare_pack_commit_against_oracle(built, depth):
+    """host front end + partition + pack + commit + prune == oracle, over three fused scans"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(YAML, block_depth=depth)
+    m = la3dm_amd.BGKOctoMap(**params, device=-1)
+    o = O.OracleMap(**params)
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        assert m.prepare(xyz, origin, 0.1, 0.5, 8.0)
+        assert (m.training_data() == O.get_training_data(xyz, origin, 0.1, 0.5, 8.0)).all()
+        pk = m.packed()
+        # structural checks of the packed scan
+        assert pk.leaf_off[0] == 0 and pk.leaf_off[-1] == pk.n_leaf and (np.diff(pk.leaf_off.astype(np.int64)) > 0).all()
+        assert (pk.nbr < pk.n_train_blk).all() and (pk.nbr >= -1).all()
+        assert pk.train_off[-1] == pk.n_train_pts and (np.diff(pk.train_off.astype(np.int64)) > 0).all()
+        w = [sum(int(pk.train_off[n + 1] - pk.train_off[n]) for n in row if n >= 0) for row in pk.nbr]
+        assert w == sorted(w, reverse=True)          # heaviest test blocks first
+        _emulate_device(pk, params)
+        m.commit()
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        st, so = m.stats(), o.stats()
+        for k in ("n_hits", "n_frees", "n_bbox_blocks", "n_train_blocks", "n_test_blocks", "voxel_updates",
+                  "pair_evals", "train_reads"):
+            assert st[k] == so[k], k
+        a, b = m.leaves(), o.leaves()
+        for k in ("block_key", "node_key", "loc", "size", "A", "B", "state", "classified"):
+            assert a[k].shape == b[k].shape and (a[k] == b[k]).all(), (i, k)
+    if depth == 3:
+        assert (a["node_key"] >> 16).min() < 2        # pruning produced coarse leaves
+
+
+def test_search_bbox_and_iteration(built):
+    import la3dm_amd
+    from oracle import oracle as O
+    m = la3dm_amd.BGKOctoMap(**YAML, device=-1)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    m.prepare(xyz, origin, 0.1, 0.5, 8.0)
+    _emulate_device(m.packed(), YAML)
+    m.commit()
+    lv = m.leaves()
+    i = int(np.argmax(lv["A"]))
+    e, a, b, s = m.search(*map(float, lv["loc"][i]))
+    assert e and np.float32(a) == lv["A"][i] and np.float32(b) == lv["B"][i] and s == lv["state"][i]
+    assert m.search(500.0, 500.0, 500.0)[0] is False
+    lo, hi = m.get_bbox()
+    assert (lo <= lv["loc"].min(0)).all() and (hi >= lv["loc"].max(0)).all()
+    assert m.block_count() == len(set(lv["block_key"].tolist()))
+
+
+def test_synthetic_scan_generator(built):
+    import la3dm_amd
+    xyz, origin = la3dm_amd.synthetic_scan(5000)
+    assert xyz.shape == (5000, 3) and xyz.dtype == np.float32 and (origin == [0, 0, 1]).all()
+    assert np.abs(xyz[:, :2]).max() < 10.2 and -0.1 < xyz[:, 2].min() and xyz[:, 2].max() < 5.1
+    x2, _ = la3dm_amd.synthetic_scan(5000)
+    assert (x2 == xyz).all()

@@ -1,0 +1,189 @@
+"""CPU tests of the ORACLE itself (not gpu): the restatement is pinned against
+  * tests/golden/ref_kat.npz  — answers captured from the reference's own std-only sources
+    compiled in place (oracle/_ref), and
+  * oracle/_ref directly when it is present (this container; travels prebuilt to the GPU box),
+and, for the Eigen/PCL-dependent arithmetic the reference cannot pin, against analytic
+properties and a float64 evaluation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pcd_path
+
+YAML = dict(resolution=0.1, block_depth=3, sf2=1.0, ell=0.2, free_thresh=0.3, occupied_thresh=0.7, var_thresh=100.0,
+            prior_A=0.001, prior_B=0.001)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return np.load(os.path.join(GOLDEN, "ref_kat.npz"))
+
+
+@pytest.fixture(scope="module")
+def O(built):
+    from oracle import oracle
+    return oracle
+
+
+@pytest.mark.parametrize("depth", [3, 4, 5])
+def test_hash_lut_against_reference_kat(O, kat, depth):
+    m = O.OracleMap(**dict(YAML, block_depth=depth))
+    assert np.float32(m.block_size) == kat[f"d{depth}_block_size"]
+    pts, keys = kat[f"d{depth}_hash_pts"], kat[f"d{depth}_hash_keys"]
+    for p, k, c, e in zip(pts, keys, kat[f"d{depth}_hash_centres"], kat[f"d{depth}_eblocks"]):
+        assert m.block_to_hash_key(*map(float, p)) == k
+        assert (m.hash_key_to_block(int(k)) == c).all()
+        assert (m.get_extended_block(int(k)) == e).all()
+    lut = np.concatenate(m.lut())
+    assert lut.shape == kat[f"d{depth}_lut"].shape and (lut == kat[f"d{depth}_lut"]).all()
+
+
+def test_survey_known_answers(O):
+    """SURVEY.md §9.3 literals (captured independently from the compiled reference)."""
+    m = O.OracleMap(**YAML)
+    assert m.block_to_hash_key(0, 0, 0) == 0x800008000080000
+    assert m.block_to_hash_key(0.2, 0.2, 0.2) == 0x800018000180001
+    assert m.block_to_hash_key(0.39, -0.41, 7.45) == 0x800017ffff80013
+    assert m.block_to_hash_key(-3.75, 12.95, 4.25) == 0x7fff7800208000b
+    m4 = O.OracleMap(**dict(YAML, block_depth=4))
+    assert m4.block_to_hash_key(0.39, -0.41, 7.45) == 0x800007ffff80009
+    assert np.float32(m.block_size) == np.float32(0.400000006) and np.float32(m4.block_size) == np.float32(0.800000012)
+    assert sum(a.shape[0] for a in m.lut()) == 73 and sum(a.shape[0] for a in m4.lut()) == 585
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_block_leaves_update_prune_against_reference_kat(O, kat, depth):
+    m = O.OracleMap(**dict(YAML, block_depth=depth))
+    L = m.L
+    cap = 8 ** (depth - 1)
+    for case in range(3):
+        tag = f"d{depth}_blk{case}"
+        c = kat[f"{tag}_center"]
+        b = L.orc_block_new(m.h, float(c[0]), float(c[1]), float(c[2]))
+        keys = np.zeros(cap, np.int32)
+        loc = np.zeros((cap, 3), np.float32)
+        n = L.orc_block_leaves(m.h, b, keys, loc, cap)
+        assert n == kat[f"{tag}_fresh_keys"].size
+        assert (keys[:n] == kat[f"{tag}_fresh_keys"]).all() and (loc[:n] == kat[f"{tag}_fresh_loc"]).all()
+        ops = kat[f"{tag}_ops"]
+        for rnd in range(4):
+            for _, k, yb, kb in ops[ops[:, 0] == rnd]:
+                L.orc_block_update(m.h, b, int(k), float(yb), float(kb))
+            assert L.orc_block_prune(m.h, b) == int(kat[f"{tag}_r{rnd}_pruned"])
+            n = L.orc_block_leaves(m.h, b, keys, loc, cap)
+            rows = kat[f"{tag}_r{rnd}_leaves"]
+            assert n == rows.shape[0]
+            assert (keys[:n] == rows[:, 0].astype(np.int32)).all()       # leaf order incl. collapsed parents
+            assert (loc[:n] == kat[f"{tag}_r{rnd}_loc"]).all()
+            A, B, S, Cl = C.c_float(), C.c_float(), C.c_uint8(), C.c_uint8()
+            for k, a, bb, s in zip(keys[:n], rows[:, 1], rows[:, 2], rows[:, 3]):
+                assert L.orc_block_node(b, int(k), C.byref(A), C.byref(B), C.byref(S), C.byref(Cl))
+                assert np.float32(A.value) == np.float32(a) and np.float32(B.value) == np.float32(bb) and S.value == int(s)
+        L.orc_block_free(b)
+
+
+def test_node_update_sequence_against_reference_kat(O, kat):
+    m = O.OracleMap(**YAML)
+    a, b, s = C.c_float(0.001), C.c_float(0.001), C.c_uint8(2)
+    for i in range(kat["node_ybar"].size):
+        m.L.orc_node_update(m.h, C.byref(a), C.byref(b), C.byref(s), float(kat["node_ybar"][i]), float(kat["node_kbar"][i]))
+        assert np.float32(a.value) == kat["node_A"][i] and np.float32(b.value) == kat["node_B"][i]
+        assert s.value == kat["node_state"][i]
+        assert np.float32(m.L.orc_node_prob(a.value, b.value)) == kat["node_prob"][i]
+        assert np.float32(m.L.orc_node_var(a.value, b.value)) == kat["node_var"][i]
+
+
+def test_closed_box_rule_against_reference_rtree(O, kat):
+    """membership of the restated closed-box test == the reference R-tree's Search results"""
+    m = O.OracleMap(**YAML)
+    pts = np.ascontiguousarray(kat["rtree_pts"])
+    ids = np.zeros(len(pts), np.int32)
+    off = kat["rtree_off"]
+    for i, k in enumerate(kat["rtree_keys"]):
+        n = m.L.orc_box_query(m.h, pts, len(pts), int(k), ids, len(ids))
+        assert sorted(ids[:n].tolist()) == kat["rtree_ids"][off[i]:off[i + 1]].tolist()
+
+
+def test_live_reference_layer_if_present(O):
+    """direct comparison with oracle/_ref on fresh random inputs (skipped where it was not built)"""
+    R = O.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built here")
+    rng = np.random.default_rng(5)
+    for depth in (3, 4):
+        R.ref_configure(0.1, depth, 1.0, 0.2, 0.3, 0.7, 100.0, 0.001, 0.001)
+        m = O.OracleMap(**dict(YAML, block_depth=depth))
+        e1, e2 = np.zeros(7, np.int64), None
+        for p in rng.uniform(-100, 100, (2000, 3)).astype(np.float32):
+            k = R.ref_block_to_hash_key(*map(float, p))
+            assert m.block_to_hash_key(*map(float, p)) == k
+            R.ref_get_extended_block(k, e1)
+            assert (m.get_extended_block(k) == e1).all()
+
+
+def test_kernel_properties(O):
+    L = O.lib()
+    assert L.orc_kernel(0.0, 1.0) == 1.0 and L.orc_kernel(0.0, 0.1) == np.float32(0.1)
+    assert np.float32(L.orc_kernel(0.5, 1.0)) == np.float32(0.1666667)
+    assert abs(L.orc_kernel(0.9, 1.0) - 8.4907e-05) < 1e-8
+    # the device skips pairs with d2 >= 1: the raw (unclamped) kernel must be <= 0 for EVERY fp32 r >= 1
+    assert L.orc_kernel_max_over(1.0, 1.6, 1.0) <= 0.0            # exhaustive: all 5.0M floats in [1, 1.6]
+    r = np.linspace(1.6, 400.0, 200001).astype(np.float32)        # beyond: (1-r)/3 <= -0.2 dominates |sin|/(2 pi)
+    assert all(L.orc_kernel_raw(float(x), 1.0) < 0 for x in r[::50])
+    # fp32 support radius is slightly below ell (truncated pi): clamp still needed below r = 1
+    rr = np.linspace(0.97, 1.0, 30001).astype(np.float32)
+    assert (O.kernel(rr) >= 0).all() and (O.kernel(rr[rr > 0.98]) == 0).mean() > 0.5
+    # agreement with a float64 evaluation of the same formula
+    rr = np.linspace(0, 1, 20001).astype(np.float32)
+    t = 2 * 3.1415926 * rr.astype(np.float64)
+    k64 = np.maximum((2 + np.cos(t)) * (1 - rr) / 3 + np.sin(t) / (2 * 3.1415926), 0)
+    assert np.abs(O.kernel(rr) - k64).max() < 4e-7
+
+
+def test_predict_golden_and_f64(O):
+    g = np.load(os.path.join(GOLDEN, "oracle_kat.npz"))
+    assert (O.kernel(g["kernel_r"], 1.0) == g["kernel_k_sf1"]).all()
+    assert (O.kernel(g["kernel_r"], 0.1) == g["kernel_k_sf01"]).all()
+    for ci in range(6):
+        xs, x, y = g[f"pred{ci}_xs"], g[f"pred{ci}_x"], g[f"pred{ci}_y"]
+        yb, kb = O.bgk_predict(1.0, 0.2, xs, x, y)
+        assert (yb == g[f"pred{ci}_ybar"]).all() and (kb == g[f"pred{ci}_kbar"]).all()
+        d = np.linalg.norm(xs[:, None, :].astype(np.float64) - x[None].astype(np.float64), axis=2) / 0.2
+        K = np.maximum((2 + np.cos(2 * 3.1415926 * d)) * (1 - d) / 3 + np.sin(2 * 3.1415926 * d) / (2 * 3.1415926), 0) * (d < 1)
+        np.testing.assert_allclose(kb, K.sum(1), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(yb, K @ y, rtol=2e-5, atol=2e-6)
+    assert (O.voxel_grid(g["vg_in"], 0.1) == g["vg_out_0p1"]).all()
+    assert (O.voxel_grid(g["vg_in"], 0.25) == g["vg_out_0p25"]).all()
+
+
+def test_front_end(O):
+    # beam_sample: d = free_res, 2 free_res ... < l, plus (l - free_res) when l > free_res
+    L = O.lib()
+    out = np.zeros((64, 3), np.float32)
+    n = L.orc_beam_sample(np.array([3, 0, 0], np.float32), np.zeros(3, np.float32), 0.5, out, 64)
+    assert n == 6 and np.allclose(out[:6, 0], [0.5, 1.0, 1.5, 2.0, 2.5, 2.5])
+    n = L.orc_beam_sample(np.array([0.3, 0, 0], np.float32), np.zeros(3, np.float32), 0.5, out, 64)
+    assert n == 0
+    # voxel grid: one centroid per occupied cell, cells in ascending linear index, mass conserved
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 1, (2000, 3)).astype(np.float32)
+    vg = O.voxel_grid(pts, 0.1)
+    cells = np.floor(pts * np.float32(10.0)).astype(int)
+    assert len(vg) == len({tuple(c) for c in cells})
+    # sim_structured scan 1 (config 1): sizes of SURVEY.md §8(d)
+    import la3dm_amd
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    xy = O.get_training_data(xyz, origin, 0.1, 0.5, 8.0)
+    assert (xy[:, 3] == 1).sum() == 1720 and (xy[:, 3] == 0).sum() == 3826
+    o = O.OracleMap(**YAML)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    st = o.stats()
+    assert (st["n_bbox_blocks"], st["n_train_blocks"], st["n_test_blocks"], st["voxel_updates"]) == (1764, 395, 764, 48896)
+    # max_range filter and empty input are silent no-ops
+    o2 = O.OracleMap(**YAML)
+    o2.insert_pointcloud(np.array([[20, 0, 0]], np.float32), [0, 0, 0], 0.1, 0.5, 8.0)
+    o2.insert_pointcloud(np.zeros((0, 3), np.float32), [0, 0, 0], 0.1, 0.5, 8.0)
+    assert o2.leaves()["A"].size == 0
