@@ -47,6 +47,7 @@ struct BgkArgs {
     uint32_t n_tasks;           // n_test_blk << tpb_shift
     uint32_t flags;
     uint32_t remap;             // 0 contiguous range per XCD, 1 identity, 2 chunks of 8
+    int32_t fix_exp;            // kernel values lie in [0, 2^fix_exp]
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
 };
 
@@ -503,8 +504,25 @@ struct __attribute__((aligned(16))) WaveLds3 {
     float4 cand[kCand3];     // x/ell, y/ell, z/ell, bits(nb << 6)
     float label[kCand3];
     uint2 queue[kQueue3];    // d2 bits, leaf | nb << 6 | cand << 9
-    float acc[14][kWave];    // [2*nb] = kbar, [2*nb+1] = ybar
+    // [2*nb] = kbar, [2*nb+1] = ybar as 64-bit fixed point (2^-kFixShift * 2^fix_exp units).
+    // LDS float atomics retire ~1 lane/clk on gfx950 (measured: 22 % of the kernel), integer
+    // atomics run at the plain-store rate, and an integer sum is order independent.
+    unsigned long long acc[14][kWave];
 };
+constexpr int kFixShift = 40;
+
+// v * 2^(kFixShift - fix_exp) as an integer, exact for v >= 2^(fix_exp - 16) and truncated below
+// 2^(fix_exp - 40) (v is a kernel value in [0, 2^fix_exp]).
+__device__ __forceinline__ unsigned long long to_fixed(float v, int fix_exp) {
+    const uint32_t bits = __float_as_uint(v);
+    const unsigned long long m = (bits & 0x7FFFFFu) | 0x800000u;
+    const int sh = (int)(bits >> 23) - 150 + kFixShift - fix_exp;  // value = m * 2^(e - 150)
+    return sh >= 0 ? (m << sh) : (sh > -64 ? (m >> (-sh)) : 0ull);
+}
+__device__ __forceinline__ float from_fixed(unsigned long long s, int fix_exp) {
+    const double d = (double)(uint32_t)(s >> 32) * 4294967296.0 + (double)(uint32_t)s;
+    return (float)__builtin_ldexp(d, fix_exp - kFixShift);
+}
 
 template <int kCtrl, int kRowMask = 0xF>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -558,22 +576,24 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
 }
 
 template <int kTrig>
-__device__ __forceinline__ void eval_pairs3(WaveLds3 &L, uint32_t head, uint32_t n, int lane, float sf2, bool plain = false) {
+__device__ __forceinline__ void eval_pairs3(WaveLds3 &L, uint32_t head, uint32_t n, int lane, float sf2, int fix_exp) {
     if ((uint32_t)lane < n) {
         const uint2 e = L.queue[(head + lane) & (kQueue3 - 1)];
         const float d2 = __uint_as_float(e.x);
         const float k = cov_sparse_fast<kTrig>(sqrt_cr(d2), sf2);
         if (k > 0.0f) {
-            float *acc = &L.acc[0][0] + ((e.y >> 6) & 7u) * (2 * kWave) + (e.y & 63u);
+            unsigned long long *acc = &L.acc[0][0] + ((e.y >> 6) & 7u) * (2 * kWave) + (e.y & 63u);
             const float y = L.label[e.y >> 9];
             const float ky = k * y;
-            if (plain) {  // profiling ablation only (wrong sums)
-                acc[0] = k;
-                if (ky != 0.0f) acc[kWave] = ky;
+            if (fix_exp & 0x100) {  // profiling ablation: 32-bit atomics on the low word
+                __hip_atomic_fetch_add((unsigned int *)acc, (unsigned int)to_fixed(k, fix_exp & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (ky > 0.0f)
+                    __hip_atomic_fetch_add((unsigned int *)(acc + kWave), (unsigned int)to_fixed(ky, fix_exp & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 return;
             }
-            __hip_atomic_fetch_add(acc, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (ky != 0.0f) __hip_atomic_fetch_add(acc + kWave, ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(acc, to_fixed(k, fix_exp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (ky > 0.0f)
+                __hip_atomic_fetch_add(acc + kWave, to_fixed(ky, fix_exp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     }
 }
@@ -620,7 +640,7 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v3(BgkArgs a) 
     const float xs0 = (off.x + cx) / a.ell, ys0 = (off.y + cy) / a.ell, zs0 = (off.z + cz) / a.ell;
     float A = a.alpha[li], B = a.beta[li];
 #pragma unroll
-    for (int i = 0; i < 14; ++i) L.acc[i][lane] = 0.0f;
+    for (int i = 0; i < 14; ++i) L.acc[i][lane] = 0ull;
 
     const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
     const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
@@ -695,7 +715,7 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v3(BgkArgs a) 
                 if (n_eval) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    if (!(a.flags & 0x100u)) eval_pairs3<kTrig>(L, qhead, n_eval, lane, a.sf2, (a.flags & 0x400u) != 0);
+                    if (!(a.flags & 0x100u)) eval_pairs3<kTrig>(L, qhead, n_eval, lane, a.sf2, a.fix_exp | ((a.flags & 0x400u) ? 0x100 : 0));
                     qhead = (qhead + n_eval) & (kQueue3 - 1);
                     qcount -= n_eval;
                 }
@@ -729,13 +749,268 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v3(BgkArgs a) 
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
         if (tb[b] < 0) continue;
-        const float kbar = L.acc[2 * b][lane], ybar = L.acc[2 * b + 1][lane];
+        const float kbar = from_fixed(L.acc[2 * b][lane], a.fix_exp), ybar = from_fixed(L.acc[2 * b + 1][lane], a.fix_exp);
         if (kbar > 0.0f || ungated) {
             A += ybar;
             B += kbar - ybar;
             updated = true;
         }
     }
+    if (active) {
+        if (updated) {
+            a.alpha[li] = A;
+            a.beta[li] = B;
+            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[li] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Variant 4 (default): variant 3 with the pair queue and the accumulators moved from LDS
+// into registers.  Profiling variant 3 showed (a) LDS float atomics retire ~1 lane/clk (22 %
+// of the kernel), (b) every KB of LDS per wave costs occupancy, and the kernel is
+// latency/issue bound at < 4 waves/SIMD.
+//   * hits of one candidate (a "run") are scattered into the free lanes of a 63-slot register
+//     batch with ds_permute_b32 (LDS crossbar, no LDS memory); a run never straddles batches;
+//   * when the next run does not fit, all 64 lanes evaluate k(r) for the batch, then the
+//     runs are replayed in candidate order: each leaf lane fetches its own k with
+//     ds_bpermute_b32 and adds it to its private (ybar, kbar) registers — the reference's
+//     sequential summation order, so the sums are bit-identical to the CPU restatement;
+//   * which lanes a run covered is recovered from a per-lane 32-candidate hit history
+//     (one bit per candidate) by a ballot — no masks stored;
+//   * the neighbour slot of a candidate is wave-uniform, so "flush (ybar, kbar) into
+//     (alpha, beta)" is a uniform branch in ExtendedBlock order, as in the reference loop.
+// LDS per wave: candidate list only (2.5 KB).
+// ---------------------------------------------------------------------------
+constexpr int kCand4 = 128;
+
+struct __attribute__((aligned(16))) WaveLds4 {
+    float4 cand[kCand4];  // x/ell, y/ell, z/ell, bits(nb)
+    float label[kCand4];
+};
+
+template <int kTrig, int kWaves>
+__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v4(BgkArgs a) {
+    __shared__ WaveLds4 s_lds[kWaves];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t wg = blockIdx.x;
+    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
+    else if (a.remap == 2) {
+        const uint32_t G8 = gridDim.x & ~63u;
+        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
+    }
+    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    WaveLds4 &L = s_lds[wv];
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = (uint32_t)lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+
+    int tb[7];
+    uint32_t p0[7], cnt[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        tb[b] = a.nbr[7 * blk + b];
+        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
+        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
+    }
+    float4 q[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b)
+        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const uint32_t key = a.leaf_key[li];
+    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs0 = (off4.x + cx) / a.ell, ys0 = (off4.y + cy) / a.ell, zs0 = (off4.z + cz) / a.ell;
+    float A = a.alpha[li], B = a.beta[li];
+
+    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
+    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
+
+    const bool ungated = (a.flags & 1u) != 0;
+    bool updated = false;
+    float kbar = 0.0f, ybar = 0.0f;
+    int cur_nb = -1;           // neighbour slot the (ybar, kbar) registers belong to (uniform)
+    uint32_t hist = 0;         // bit i: this leaf was hit by the candidate i steps back
+    uint32_t bd2 = 0;          // batch: d2 bits of the pair parked in this lane
+    uint32_t bcnt = 0;         // pairs in the batch (uniform)
+    uint32_t bruns = 0;        // candidates tested since the batch was opened (uniform, <= 32)
+    uint32_t jstep = 0;        // candidates of the current list tested so far (uniform)
+    uint32_t ncand = 0;
+
+    // Occupancy::update for the neighbour the registers belong to (bgkoctree_node.cpp:31-35)
+    auto flush_nb = [&]() {
+        if (kbar > 0.0f || ungated) {
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+        kbar = 0.0f;
+        ybar = 0.0f;
+    };
+
+    auto stage = [&](const float4 &p, bool valid, uint32_t b) {
+        bool keep = false;
+        if (valid) {
+            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
+            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
+            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
+            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) {
+            L.cand[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(b));
+            L.label[slot] = p.w;
+        }
+        ncand += (uint32_t)__popcll(m);
+    };
+
+    // A: first chunks in ExtendedBlock order; stop at the first neighbour that does not fit or
+    // has more than one chunk, so that candidates stay in (neighbour, point) order.
+    uint32_t it_b = 7, it_base = 0;
+    {
+        bool open = true;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            if (!open || cnt[b] == 0) continue;
+            if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand4) {
+                stage(q[b], (uint32_t)lane < cnt[b], (uint32_t)b);
+                if (cnt[b] > (uint32_t)kWave) {
+                    open = false;
+                    it_b = b;
+                    it_base = kWave;
+                }
+            } else {
+                open = false;
+                it_b = b;
+                it_base = 0;
+            }
+        }
+    }
+
+    bool more = true;
+    while (more) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // B/C/D over the staged candidates; trip j == ncand closes the last batch
+        const uint32_t ntrip = (ncand + 3u) >> 2;
+        for (uint32_t g = 0; g <= ntrip; ++g) {
+            const bool last = g == ntrip;
+            float d2v[4];
+            unsigned long long mv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d2v[u] = 0.f;
+                mv[u] = 0ull;
+            }
+            if (!last) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = L.cand[(4 * g + u) & (kCand4 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
+                    d2v[u] = dx * dx + (dy * dy + dz * dz);
+                    const bool hit = d2v[u] < 1.0f && (4 * g + u) < ncand;  // k(r) <= 0 for all fp32 r >= 1
+                    mv[u] = __ballot(hit);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = 4 * g + u;                 // candidate slot of this step
+                const uint32_t c = (uint32_t)__popcll(mv[u]);
+                const bool stepping = !last && j < ncand;
+                // close the batch when the next run does not fit, the history is full, or at the end
+                if ((bcnt + c > 63u) || bruns == 32u || (last && u == 0)) {
+                    if (bruns != 0u) {
+                        // C: every lane evaluates the pair parked in it
+                        float kv = 0.0f;
+                        if ((uint32_t)lane < bcnt) kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(bd2)), a.sf2);
+                        // D: replay the runs oldest first; candidate j - age used history bit age - 1
+                        uint32_t roff = 0;
+                        for (uint32_t age = bruns; age >= 1u; --age) {
+                            const bool mine = (hist >> (age - 1u)) & 1u;
+                            const unsigned long long m = __ballot(mine);
+                            if (m == 0ull) continue;
+                            const uint32_t cj = (jstep - age) & (kCand4 - 1);
+                            const int nbj = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(L.cand[cj].w));
+                            const float yj = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(L.label[cj])));
+                            if (nbj != cur_nb) {
+                                flush_nb();
+                                cur_nb = nbj;
+                            }
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            const float ks = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((roff + rank) << 2), __float_as_int(kv)));
+                            if (mine) {
+                                ybar += ks * yj;
+                                kbar += ks;
+                            }
+                            roff += (uint32_t)__popcll(m);
+                        }
+                    }
+                    bcnt = 0;
+                    bruns = 0;
+                    bd2 = 0;
+                    hist = 0;
+                }
+                if (stepping) {
+                    const bool hit = (mv[u] >> lane) & 1ull;
+                    hist = (hist << 1) | (hit ? 1u : 0u);
+                    ++bruns;
+                    ++jstep;
+                    if (c == 64u) {
+                        bd2 = __float_as_uint(d2v[u]);  // every leaf hit: identity placement (batch was just closed)
+                    } else if (c != 0u) {
+                        // B: scatter the run into lanes [bcnt, bcnt + c); misses aim at the spare lane 63
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv[u], 0));
+                        const uint32_t dst = hit ? (bcnt + rank) : 63u;
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)__float_as_uint(d2v[u]));
+                        if ((uint32_t)lane - bcnt < c) bd2 = got;
+                    }
+                    bcnt += c;
+                }
+            }
+        }
+        ncand = 0;
+        jstep = 0;
+        __builtin_amdgcn_wave_barrier();
+        // refill in order (rare: > 64 points in a block, or a crowded 7-neighbourhood)
+        more = false;
+        while (it_b < 7) {
+            const int tbv = a.nbr[7 * blk + it_b];
+            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
+            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
+            if (it_base >= pc) {
+                ++it_b;
+                it_base = 0;
+                continue;
+            }
+            if (ncand + (uint32_t)kWave > (uint32_t)kCand4) break;
+            const bool valid = it_base + lane < pc;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) p = a.pts[pp0 + it_base + lane];
+            stage(p, valid, it_b);
+            it_base += kWave;
+            more = true;
+        }
+    }
+    if (cur_nb >= 0) flush_nb();
+    if (ungated) {  // insert_training_data: update() runs for every trained neighbour, even with no pair in range
+#pragma unroll
+        for (int b = 0; b < 7; ++b) updated |= tb[b] >= 0;
+    }
+
     if (active) {
         if (updated) {
             a.alpha[li] = A;
