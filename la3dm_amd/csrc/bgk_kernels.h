@@ -1022,6 +1022,245 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v4(BgkArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 5: three tight phases per candidate round instead of variant 4's interleaving
+// (variant 4 is issue bound on scalar control flow: ~2000 SALU instructions per tile).
+//   B  test + push, branch free: four candidates per trip; hits of candidate j are written
+//      to ring[tail + rank] (rank = mbcnt of the hit mask), misses to a per-lane scratch
+//      slot; every lane shifts its own hit bit into a 64-candidate history.
+//   C  dense evaluation: lane i evaluates ring[p + i] and writes {k, k*y} back in place.
+//   D  ordered fuse: candidates are replayed in order; the hit mask is rebuilt from the
+//      history by a ballot, the leaf lane reads its own {k, k*y} at ring[off + rank]
+//      (conflict-free, contiguous) and adds them to its private (ybar, kbar) — the
+//      reference's summation order, so results stay bit-identical to the CPU restatement.
+//      A new neighbour slot is a precomputed bit per candidate: the flush into
+//      (alpha, beta) is a uniform branch in ExtendedBlock order.
+// LDS per wave: 64 candidates (1 KB) + 448-pair ring and scratch (4 KB).
+// ---------------------------------------------------------------------------
+constexpr int kCand5 = 64;
+constexpr int kRing5 = 448;
+
+struct __attribute__((aligned(16))) WaveLds5 {
+    float4 cand[kCand5 + 4];       // x/ell, y/ell, z/ell, label (+ padding slots)
+    uint2 ring[kRing5 + kWave];    // {d2, candidate} -> {k, k*y}; last 64 = per-lane scratch
+};
+
+template <int kTrig, int kWaves>
+__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) {
+    __shared__ WaveLds5 s_lds[kWaves];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t wg = blockIdx.x;
+    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
+    else if (a.remap == 2) {
+        const uint32_t G8 = gridDim.x & ~63u;
+        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
+    }
+    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    WaveLds5 &L = s_lds[wv];
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = (uint32_t)lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+
+    int tb[7];
+    uint32_t p0[7], cnt[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        tb[b] = a.nbr[7 * blk + b];
+        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
+        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
+    }
+    float4 q[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b)
+        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const uint32_t key = a.leaf_key[li];
+    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs0 = (off4.x + cx) / a.ell, ys0 = (off4.y + cy) / a.ell, zs0 = (off4.z + cz) / a.ell;
+    float A = a.alpha[li], B = a.beta[li];
+
+    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
+    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
+
+    const bool ungated = (a.flags & 1u) != 0;
+    bool updated = false;
+    float kbar = 0.0f, ybar = 0.0f;
+    uint32_t ncand = 0;
+    unsigned long long nbstart = 0;  // bit s: candidate slot s is the first of a new neighbour
+    int last_nb = -1;
+
+    auto flush_nb = [&]() {  // Occupancy::update, bgkoctree_node.cpp:31-35
+        if (kbar > 0.0f || ungated) {
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+        kbar = 0.0f;
+        ybar = 0.0f;
+    };
+
+    auto stage = [&](const float4 &p, bool valid, int b) {
+        bool keep = false;
+        if (valid) {
+            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
+            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
+            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
+            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (b != last_nb && m != 0ull) {
+            nbstart |= 1ull << ncand;
+            last_nb = b;
+        }
+        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) L.cand[slot] = p;
+        ncand += (uint32_t)__popcll(m);
+    };
+
+    // A: first chunks in ExtendedBlock order while they fit and no neighbour needs a 2nd chunk
+    uint32_t it_b = 7, it_base = 0;
+    {
+        bool open = true;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            if (!open || cnt[b] == 0) continue;
+            if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand5) {
+                stage(q[b], (uint32_t)lane < cnt[b], b);
+                if (cnt[b] > (uint32_t)kWave) {
+                    open = false;
+                    it_b = b;
+                    it_base = kWave;
+                }
+            } else {
+                open = false;
+                it_b = b;
+                it_base = 0;
+            }
+        }
+    }
+
+    bool more = true;
+    while (more) {
+        // pad the list to a multiple of four with points no leaf can reach
+        if (lane < 4) L.cand[ncand + lane] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
+        uint32_t g = 0;
+        while (g < ngroup) {
+            // ---- B: test + push ----
+            const uint32_t g0 = g;
+            uint32_t tail = 0;
+            unsigned long long hist = 0;
+            for (; g < ngroup && tail <= (uint32_t)(kRing5 - 4 * kWave); ++g) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
+                    const float d2 = dx * dx + (dy * dy + dz * dz);
+                    const bool hit = d2 < 1.0f;  // k(r) <= 0 for every fp32 r >= 1
+                    const unsigned long long m = __ballot(hit);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    const uint32_t slot = hit ? tail + rank : (uint32_t)(kRing5 + lane);
+                    L.ring[slot] = make_uint2(__float_as_uint(d2), 4 * g + u);
+                    tail += (uint32_t)__popcll(m);
+                    hist = (hist << 1) | (hit ? 1ull : 0ull);
+                }
+            }
+            const uint32_t nstep = 4 * (g - g0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- C: dense evaluation, {d2, candidate} -> {k, k*y} in place ----
+            for (uint32_t p = 0; p < ((a.flags & 0x100u) ? 0u : tail); p += kWave) {  // 0x100: profiling ablation
+                const uint32_t i = p + lane;
+                if (i < tail) {
+                    const uint2 e = L.ring[i];
+                    const float y = L.cand[e.y].w;
+                    const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(e.x)), a.sf2);
+                    L.ring[i] = make_uint2(__float_as_uint(kv), __float_as_uint(kv * y));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- D: ordered fuse, four candidates per trip (reads issued together) ----
+            uint32_t roff = 0;
+            unsigned long long starts = nbstart >> (4 * g0);
+            unsigned long long h = nstep ? hist << (64u - nstep) : 0ull;  // oldest candidate in bit 63
+            for (uint32_t s2 = 0; s2 < ((a.flags & 0x400u) ? 0u : nstep); s2 += 4) {  // 0x400: profiling ablation
+                const uint32_t sb = (uint32_t)starts & 0xFu;
+                starts >>= 4;
+                const uint32_t hh = (uint32_t)(h >> 32);
+                h <<= 4;
+                bool mine[4];
+                uint2 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mine[u] = (hh & (0x80000000u >> u)) != 0u;
+                    const unsigned long long m = __ballot(mine[u]);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    e[u] = L.ring[roff + rank];  // in bounds for every lane; only `mine` lanes use it
+                    roff += (uint32_t)__popcll(m);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (sb & (1u << u)) flush_nb();  // uniform
+                    // adding +0.0 leaves a non-negative-zero accumulator unchanged
+                    ybar += mine[u] ? __uint_as_float(e[u].y) : 0.0f;
+                    kbar += mine[u] ? __uint_as_float(e[u].x) : 0.0f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        ncand = 0;
+        nbstart = 0;
+        // refill in order (rare: > 64 points in a block, or a crowded 7-neighbourhood)
+        more = false;
+        while (it_b < 7) {
+            const int tbv = a.nbr[7 * blk + it_b];
+            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
+            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
+            if (it_base >= pc) {
+                ++it_b;
+                it_base = 0;
+                continue;
+            }
+            if (ncand != 0u) break;  // one 64-point chunk per refill round
+            const bool valid = it_base + lane < pc;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) p = a.pts[pp0 + it_base + lane];
+            stage(p, valid, (int)it_b);
+            it_base += kWave;
+            more = true;
+        }
+    }
+    flush_nb();
+    if (ungated) {  // insert_training_data: update() runs for every trained neighbour
+#pragma unroll
+        for (int b = 0; b < 7; ++b) updated |= tb[b] >= 0;
+    }
+
+    if (active) {
+        if (updated) {
+            a.alpha[li] = A;
+            a.beta[li] = B;
+            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[li] = 0;
+        }
+    }
+}
+
 // exhaustive sweeps of the two shortcuts used by variant 3 against the IEEE operations:
 // counts fp32 inputs in [lo_bits, hi_bits] (as unsigned bit patterns) where they differ.
 __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatch) {
