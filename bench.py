@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (kernel variant 3); 0 = library default")
     ap.add_argument("--remap", type=int, default=-1, help="workgroup->tile remap mode; -1 = library default")
+    ap.add_argument("--mode", choices=["scans", "shard"], default="scans",
+                    help="N>1 only. scans (default, weak scaling): one scan per GPU; shard (strong scaling, config-5 "
+                         "style): ONE scan, its test blocks dealt round-robin to the ranks (la3dm_amd/sharding.py)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): 1 skip k(r) evaluation, 2 skip tests")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-omp", action="store_true", help="also time the OpenMP oracle on all cores")
@@ -71,7 +74,8 @@ def main():
 
     # ---- build the workload (host side, untimed) -------------------------------------
     params = dict(la3dm_amd.BGK_YAML, resolution=args.resolution, block_depth=args.depth)
-    xyz, origin = la3dm_amd.synthetic_scan(args.rays, seed=1234 + rank)
+    shard_mode = world > 1 and args.mode == "shard"
+    xyz, origin = la3dm_amd.synthetic_scan(args.rays, seed=1234 + (0 if shard_mode else rank))
     m = la3dm_amd.BGKOctoMap(**params, device=local_rank)
     t0 = time.perf_counter()
     ok = m.prepare(xyz, origin, args.resolution, 0.5, -1.0)
@@ -81,6 +85,13 @@ def main():
     pk = m.packed()
     U = int(st["voxel_updates"])
     b_alg = 16 * int(st["train_reads"]) + 17 * U
+    if shard_mode:
+        from la3dm_amd import sharding
+        full = pk
+        pk = sharding.Shard(full, rank, world)     # this rank's test blocks; training CSR replicated
+        U = pk.n_leaf
+        reads = sum(int(full.train_off[n + 1] - full.train_off[n]) for n in pk.nbr.ravel() if n >= 0)
+        b_alg = 16 * reads + 17 * U
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -185,7 +196,7 @@ def main():
         out = {
             "metric": "voxel-updates/sec per scan (200k pts, 0.1 m res); HBM GB/s vs roofline",
             "value": value, "unit": "voxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if shard_mode else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BGKOctoMap synthetic {args.rays}-ray scan, {args.resolution} m res, "
                                    f"block_depth {args.depth}, bgkoctomap.yaml kernel params (configs[1])",
@@ -194,8 +205,10 @@ def main():
                        "hits": int(st["n_hits"]), "frees": int(st["n_frees"]),
                        "test_blocks": int(st["n_test_blocks"]), "train_blocks": int(st["n_train_blocks"]),
                        "voxel_updates_per_scan": U, "pair_evals_per_scan": int(st["pair_evals"]),
-                       "parallelism": "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)" if world > 1
-                       else "single GPU", "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "one scan, test blocks dealt round-robin to the ranks + RCCL all-gather of leaf "
+                                       "(alpha,beta,state)" if shard_mode else
+                                       "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)"), "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
                        "kernel_variant": args.variant, "waves_per_wg": args.waves, "remap": args.remap},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

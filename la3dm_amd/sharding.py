@@ -1,0 +1,73 @@
+"""Block sharding of one packed scan across GPUs (BASELINE config 5).
+
+Test blocks are independent given the per-scan training set, so a scan shards with no
+data-path collective: rank r takes every `world`-th test block of the (heaviest-first) packed
+order — near-perfect balance, and each rank's list stays heaviest-first.  The training CSR is
+replicated.  After the kernel, ONE all-gather of the per-rank leaf arrays (alpha | beta | state,
+padded to the largest shard) gives every rank the whole updated grid; `reassemble` scatters it
+back into the packed order, after which BGKOctoMap.commit() writes the nodes and prunes.
+
+Pure index bookkeeping (numpy); the collective itself is torch.distributed (RCCL on GPUs,
+gloo in the CPU tests).
+"""
+import numpy as np
+
+
+class Shard:
+    """The slice of a packed scan owned by one rank (numpy arrays, C-contiguous)."""
+
+    def __init__(self, pk, rank, world):
+        self.rank, self.world = rank, world
+        nt = pk.n_test_blk
+        self.blocks = np.arange(rank, nt, world, dtype=np.int64)      # indices into the packed order
+        lo = pk.leaf_off.astype(np.int64)
+        cnt = lo[self.blocks + 1] - lo[self.blocks]
+        self.leaf_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+        # global leaf index of every local leaf
+        self.leaf_index = (np.repeat(lo[self.blocks] - self.leaf_off[:-1].astype(np.int64), cnt)
+                           + np.arange(int(cnt.sum()), dtype=np.int64))
+        self.n_test_blk = int(self.blocks.size)
+        self.n_leaf = int(cnt.sum())
+        self.nbr = np.ascontiguousarray(pk.nbr[self.blocks])
+        self.blk_center = np.ascontiguousarray(pk.blk_center[self.blocks])
+        self.leaf_key = np.ascontiguousarray(pk.leaf_key[self.leaf_index])
+        self.alpha = np.ascontiguousarray(pk.alpha[self.leaf_index])
+        self.beta = np.ascontiguousarray(pk.beta[self.leaf_index])
+        self.state = np.zeros(self.n_leaf, np.uint8)
+        # replicated
+        self.train_xyzy, self.train_off = pk.train_xyzy, pk.train_off
+        self.n_train_pts, self.n_train_blk = pk.n_train_pts, pk.n_train_blk
+        self.flags = pk.flags
+
+
+def shard_leaf_counts(pk, world):
+    lo = pk.leaf_off.astype(np.int64)
+    cnt = np.diff(lo)
+    return [int(cnt[r::world].sum()) for r in range(world)]
+
+
+def pack_payload(alpha, beta, state, cap):
+    """alpha | beta | state of one shard as a byte vector padded to `cap` leaves (9 bytes/leaf)."""
+    out = np.zeros(9 * cap, np.uint8)
+    n = alpha.size
+    out[0:4 * n] = alpha.view(np.uint8)
+    out[4 * cap:4 * cap + 4 * n] = beta.view(np.uint8)
+    out[8 * cap:8 * cap + n] = state
+    return out
+
+
+def reassemble(pk, gathered, world):
+    """Scatter the all-gathered payloads ([world, 9*cap] bytes) into pk.alpha/beta/state."""
+    gathered = np.asarray(gathered, np.uint8).reshape(world, -1)
+    cap = gathered.shape[1] // 9
+    lo = pk.leaf_off.astype(np.int64)
+    for r in range(world):
+        blocks = np.arange(r, pk.n_test_blk, world, dtype=np.int64)
+        cnt = lo[blocks + 1] - lo[blocks]
+        n = int(cnt.sum())
+        start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        idx = np.repeat(lo[blocks] - start, cnt) + np.arange(n, dtype=np.int64)
+        row = gathered[r]
+        pk.alpha[idx] = row[0:4 * n].view(np.float32)
+        pk.beta[idx] = row[4 * cap:4 * cap + 4 * n].view(np.float32)
+        pk.state[idx] = row[8 * cap:8 * cap + n]
