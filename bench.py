@@ -63,6 +63,11 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    # LA3DM_BENCH_TEST_SINGLE_GPU=1: self-test of the N>1 code path on a 1-GPU box (all ranks on
+    # cuda:0, gloo instead of RCCL, payload staged through host memory) — never a measurement.
+    selftest = os.environ.get("LA3DM_BENCH_TEST_SINGLE_GPU") == "1"
+    if selftest:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -70,7 +75,10 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- build the workload (host side, untimed) -------------------------------------
     params = dict(la3dm_amd.BGK_YAML, resolution=args.resolution, block_depth=args.depth)
@@ -96,9 +104,25 @@ def main():
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
+    # The leaf arrays live in ONE buffer laid out alpha | beta | state with room for the largest
+    # rank, so the kernel's outputs are the all-gather payload (no packing copies).
+    cap = pk.n_leaf
+    if world > 1:
+        cdev = torch.device("cpu") if selftest else dev
+        n_leaf_max = torch.tensor([pk.n_leaf], device=cdev)
+        dist.all_reduce(n_leaf_max, op=dist.ReduceOp.MAX)
+        cap = int(n_leaf_max.item())
+    cap = (cap + 63) // 64 * 64
+    payload = torch.zeros(9 * cap, dtype=torch.uint8, device=dev)
+    n = pk.n_leaf
+    alpha_t = payload[0:4 * cap].view(torch.float32)[:n]
+    beta_t = payload[4 * cap:8 * cap].view(torch.float32)[:n]
+    state_t = payload[8 * cap:8 * cap + n]
+    alpha_t.copy_(up(pk.alpha))
+    beta_t.copy_(up(pk.beta))
     d = dict(train=up(pk.train_xyzy), train_off=up(pk.train_off.view(np.int32)), nbr=up(pk.nbr), center=up(pk.blk_center),
-             leaf_off=up(pk.leaf_off.view(np.int32)), leaf_key=up(pk.leaf_key.view(np.int32)), alpha=up(pk.alpha),
-             beta=up(pk.beta), state=torch.zeros(pk.n_leaf, dtype=torch.uint8, device=dev))
+             leaf_off=up(pk.leaf_off.view(np.int32)), leaf_key=up(pk.leaf_key.view(np.int32)), alpha=alpha_t,
+             beta=beta_t, state=state_t)
     scan = _lib.BgkScan()
     scan.train_xyzy = d["train"].data_ptr()
     scan.train_off = d["train_off"].data_ptr()
@@ -129,25 +153,19 @@ def main():
         m.set_option("ablate", args.ablate)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # all-gather buffers (N > 1): every rank contributes alpha|beta|state of its leaves, padded
-    gather_in = gather_out = None
-    if world > 1:
-        n_leaf_max = torch.tensor([pk.n_leaf], device=dev)
-        dist.all_reduce(n_leaf_max, op=dist.ReduceOp.MAX)
-        cap = int(n_leaf_max.item())
-        gather_in = torch.zeros(cap * 9, dtype=torch.uint8, device=dev)
-        gather_out = torch.zeros(world * cap * 9, dtype=torch.uint8, device=dev)
+    gather_out = torch.zeros(world * cap * 9, dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
         rc = H.la3dm_bgk_scan_device(ctx, C.byref(scan), stream, None)
         if rc != 0:
             raise RuntimeError(H.la3dm_last_error(ctx).decode())
         if world > 1:
-            n = pk.n_leaf
-            gather_in[0:4 * n].copy_(d["alpha"].view(torch.uint8))
-            gather_in[4 * cap:4 * cap + 4 * n].copy_(d["beta"].view(torch.uint8))
-            gather_in[8 * cap:8 * cap + n].copy_(d["state"])
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            if selftest:
+                host = torch.zeros(world * cap * 9, dtype=torch.uint8)
+                dist.all_gather_into_tensor(host, payload.cpu())
+                gather_out.copy_(host)
+            else:
+                dist.all_gather_into_tensor(gather_out, payload)
 
     def sync():
         torch.cuda.synchronize()
@@ -172,10 +190,11 @@ def main():
 
     total_U = U
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if selftest else dev
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        uu = torch.tensor([U], dtype=torch.float64, device=dev)
+        uu = torch.tensor([U], dtype=torch.float64, device=cdev)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
         total_U = int(uu.item())
 
