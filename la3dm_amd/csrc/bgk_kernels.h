@@ -42,6 +42,7 @@ struct BgkArgs {
     float *beta;
     uint8_t *state;
     const float4 *lut;          // voxel LUT, depth-major, w unused
+    const uint2 *nbr_range;     // [n_test_blk * 7] {first point, count} of each neighbour model (resolved by the prescale launch)
     uint32_t n_test_blk;
     uint32_t tpb_shift;         // log2(tiles per test block)
     uint32_t n_tasks;           // n_test_blk << tpb_shift
@@ -178,6 +179,27 @@ __global__ void bgk_prescale_points(const float4 *__restrict__ in, float4 *__res
     if (i >= n) return;
     float4 p = in[i];
     out[i] = make_float4(p.x / ell, p.y / ell, p.z / ell, p.w);
+}
+
+// Same launch shape, second job: resolve nbr[t][b] -> {train_off[nb], count} once per scan, so that
+// the predict kernel's prologue needs one dependent memory round trip less per tile.
+__global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell,
+                            const int32_t *__restrict__ nbr, const uint32_t *__restrict__ train_off,
+                            uint2 *__restrict__ nbr_range, uint32_t n_nbr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float4 p = in[i];
+        out[i] = make_float4(p.x / ell, p.y / ell, p.z / ell, p.w);
+    }
+    if (i < n_nbr) {
+        const int tb = nbr[i];
+        uint2 r = make_uint2(0u, 0u);
+        if (tb >= 0) {
+            r.x = train_off[tb];
+            r.y = train_off[tb + 1] - r.x;
+        }
+        nbr_range[i] = r;
+    }
 }
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -1072,9 +1094,10 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
     uint32_t p0[7], cnt[7];
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
-        tb[b] = a.nbr[7 * blk + b];
-        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
-        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
+        const uint2 r = a.nbr_range[7 * blk + b];
+        p0[b] = r.x;
+        cnt[b] = r.y;
+        tb[b] = r.y ? 0 : -1;  // only "has a trained model" matters below (a model has >= 1 point)
     }
     float4 q[7];
 #pragma unroll
@@ -1227,9 +1250,8 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
         // refill in order (rare: > 64 points in a block, or a crowded 7-neighbourhood)
         more = false;
         while (it_b < 7) {
-            const int tbv = a.nbr[7 * blk + it_b];
-            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
-            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
+            const uint2 rr = a.nbr_range[7 * blk + it_b];
+            const uint32_t pp0 = rr.x, pc = rr.y;
             if (it_base >= pc) {
                 ++it_b;
                 it_base = 0;

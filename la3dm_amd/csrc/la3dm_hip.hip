@@ -37,7 +37,7 @@ struct la3dm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
-    Arena pts_scaled;
+    Arena pts_scaled, nbr_range;
     // staging (host-pointer path)
     Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,
         h_diag_out;
@@ -135,7 +135,7 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
 void la3dm_destroy(la3dm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->pts_scaled, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
+    Arena *all[] = {&ctx->pts_scaled, &ctx->nbr_range, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
@@ -205,10 +205,14 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     // 1. x / ell once per training point
     rc = arena_reserve(ctx, ctx->pts_scaled, sizeof(float4) * (size_t)(s->n_train_pts ? s->n_train_pts : 1));
     if (rc != LA3DM_OK) return rc;
-    if (s->n_train_pts) {
-        dim3 g((s->n_train_pts + 255) / 256), b(256);
-        hipLaunchKernelGGL(bgk_prescale_points, g, b, 0, stream, (const float4 *)s->train_xyzy,
-                           (float4 *)ctx->pts_scaled.ptr, s->n_train_pts, ctx->p.ell);
+    rc = arena_reserve(ctx, ctx->nbr_range, sizeof(uint2) * 7 * (size_t)s->n_test_blk);
+    if (rc != LA3DM_OK) return rc;
+    {
+        const uint32_t n_nbr = 7u * s->n_test_blk;
+        const uint32_t n_thr = s->n_train_pts > n_nbr ? s->n_train_pts : n_nbr;
+        dim3 g((n_thr + 255) / 256), b(256);
+        hipLaunchKernelGGL(bgk_prepare, g, b, 0, stream, (const float4 *)s->train_xyzy, (float4 *)ctx->pts_scaled.ptr,
+                           s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, (uint2 *)ctx->nbr_range.ptr, n_nbr);
     }
 
     // 2. predict + fuse
@@ -227,6 +231,7 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.beta = s->beta;
     a.state = s->state;
     a.lut = ctx->d_lut;
+    a.nbr_range = (const uint2 *)ctx->nbr_range.ptr;
     a.n_test_blk = s->n_test_blk;
     a.tpb_shift = tpb_shift;
     a.n_tasks = s->n_test_blk << tpb_shift;
