@@ -67,6 +67,15 @@ typedef struct la3dm_params {
     int32_t device;       /* HIP device ordinal */
     const float *lut_xyz; /* host pointer, lut_count * 3 floats; copied */
     uint32_t lut_count;   /* sum_{d<block_depth} 8^d */
+    /* variant: 0 = BGKOctoMap (fields above), 1 = GPOctoMap: the statics of
+     * src/gpoctomap/gpoctomap.cpp:29-46 (var_thresh, prior_A/B unused; leaf arrays alpha/beta then
+     * carry the node's m_ivar/ivar, src/gpoctomap/gpoctree_node.h:34) */
+    int32_t variant;
+    float noise;          /* GP noise variance */
+    float l;              /* logistic length scale */
+    float min_ivar;       /* 1 / max_var */
+    float max_ivar;       /* 1 / min_var */
+    float min_known_ivar; /* 1 / max_known_var */
 } la3dm_params;
 
 /* One scan's worth of work for the BGK kernel.
@@ -95,6 +104,10 @@ typedef struct la3dm_bgk_scan {
     float *beta;               /* [n_leaf] in/out */
     uint8_t *state;            /* [n_leaf] out */
     uint32_t flags;
+    /* optional hints for la3dm_gp_scan_* (0 = unknown: the library computes them on the device and
+     * synchronises once): largest training block and sum over training blocks of N_b^2 */
+    uint32_t train_max_n;
+    uint64_t train_sum_n2;
 } la3dm_bgk_scan;
 
 /* Per-call work counters (filled by the *_scan_* calls when `out` is non-null). */
@@ -122,6 +135,15 @@ int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, la3dm_bgk_co
  * `stream` (a hipStream_t passed as void*, NULL = the default stream). The ctx's
  * scratch arena is reused by the next call, so calls must be stream-ordered. */
 int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, void *stream, la3dm_bgk_counters *out);
+
+/* GPOctoMap (variant 1).  Same scan layout; labels are +1 (hit) / -1 (free)
+ * (src/gpoctomap/gpoctomap.cpp:399); alpha/beta are the leaves' m_ivar/ivar.  Replaces
+ * GPR3f::train (include/gpoctomap/gpregressor.h:42-51: Matern-3/2 K + noise I, LLT, alpha) for every
+ * training block, GPR3f::predict (:80-92: m = Ks^T alpha, v = L^-1 Ks, var = sf2 - diag(v^T v)) for
+ * every (test block, neighbour), and the unconditional BCM Occupancy::update
+ * (src/gpoctomap/gpoctree_node.cpp:36-49) in ExtendedBlock order. */
+int la3dm_gp_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, la3dm_bgk_counters *out);
+int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, void *stream, la3dm_bgk_counters *out);
 
 /* Kernel timing.  After la3dm_set_option(ctx, "time_kernel", 1) every *_scan_device call
  * brackets its dominant kernel (bgk_predict_fuse) with HIP events on the launch stream.

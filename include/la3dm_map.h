@@ -25,6 +25,12 @@ typedef struct la3dm_scan_stats {
 /* BGKOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B) */
 la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float ell, float free_thresh,
                             float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device);
+/* GPOctoMap(resolution, block_depth, sf2, ell, noise, l, min_var, max_var, max_known_var, free_thresh, occupied_thresh)
+ * (src/gpoctomap/gpoctomap.cpp:23-25); every other call below works on either map kind.  For a GP map the
+ * leaf arrays A/B hold the node's m_ivar/ivar. */
+la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, float ell, float noise, float l,
+                               float min_var, float max_var, float max_known_var, float free_thresh,
+                               float occupied_thresh, int device);
 void la3dm_map_destroy(la3dm_map *m);
 const char *la3dm_map_last_error(void);
 

@@ -53,6 +53,8 @@ class BGKOctoMap:
         self.block_depth = block_depth
         self.device = device
 
+    _gp = False
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._M.la3dm_map_destroy(self._h)
@@ -139,7 +141,8 @@ class BGKOctoMap:
 
     def scan_host(self, packed: PackedScan):
         cnt = _lib.BgkCounters()
-        rc = _lib.hip().la3dm_bgk_scan_host(self.ctx(), C.byref(packed.c), C.byref(cnt))
+        fn = _lib.hip().la3dm_gp_scan_host if self._gp else _lib.hip().la3dm_bgk_scan_host
+        rc = fn(self.ctx(), C.byref(packed.c), C.byref(cnt))
         if rc != 0:
             raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
         return cnt
@@ -195,3 +198,20 @@ class BGKOctoMap:
         a = np.zeros((n, 3), np.float32)
         self._M.la3dm_map_lut(self._h, a.ctypes.data, n)
         return a
+
+
+class GPOctoMap(BGKOctoMap):
+    """Python mirror of la3dm::GPOctoMap (reference include/gpoctomap/gpoctomap.h): GP regression per block
+    (Matern-3/2, Cholesky) + BCM fusion.  leaves()["A"/"B"] are the nodes' m_ivar / ivar."""
+    _gp = True
+
+    def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, noise=0.01, l=100.0, min_var=0.001,
+                 max_var=1000.0, max_known_var=0.02, free_thresh=0.3, occupied_thresh=0.7, device=0):
+        self._M = _lib.maplib()
+        self._h = self._M.la3dm_map_create_gp(resolution, block_depth, sf2, ell, noise, l, min_var, max_var,
+                                              max_known_var, free_thresh, occupied_thresh, device)
+        if not self._h:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        self.resolution = resolution
+        self.block_depth = block_depth
+        self.device = device

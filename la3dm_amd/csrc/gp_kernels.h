@@ -1,0 +1,263 @@
+// gp_kernels.h — HIP kernels (gfx950, wave64) for the GPOctoMap per-scan path.
+//
+// Reference (CPU, Eigen):
+//   GPRegressor::train      include/gpoctomap/gpregressor.h:42-51   K = Matern(x,x) + noise I, LLT, alpha = K^-1 y
+//   GPRegressor::predict    include/gpoctomap/gpregressor.h:80-92   m = Ks^T alpha, v = L^-1 Ks, var = sf2 - diag(v^T v)
+//   covMaterniso3           include/gpoctomap/gpregressor.h:114-117 (1 + a) exp(-a) sf2, a = |(1.73205/ell)(x - x')|
+//   BCM Occupancy::update   src/gpoctomap/gpoctree_node.cpp:31-49
+//   update loop             src/gpoctomap/gpoctomap.cpp:306-319 (unconditional, ExtendedBlock order)
+//
+// Numerics: every inner product is an fp32 FMA chain in ascending index order — exactly the order
+// the oracle uses (and the order v_mfma_f32_32x32x2_f32 accumulates in), so the results are
+// bit-identical to the CPU restatement; exp() is the correctly rounded single-precision value
+// (f64 library exp rounded once).  Eigen's own LLT/GEMV/packet-exp orders are unpinned.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bgk_kernels.h"
+
+namespace la3dm_dev {
+
+struct GpArgs {
+    const float4 *pts;          // training points scaled by (float)(1.73205/ell), label in w
+    const uint32_t *train_off;
+    const uint2 *nbr_range;     // [n_test_blk * 7] {first point, count}
+    const int32_t *nbr;         // [n_test_blk * 7] training block index or -1
+    const unsigned long long *l_off;  // [n_train_blk] offset (floats) of each block's N x N factor
+    float *Lmat;                // Cholesky factors, row-major
+    float *alpha_k;             // [n_train_pts] K^-1 y
+    const float *blk_center;
+    const uint32_t *leaf_off;
+    const uint32_t *leaf_key;
+    float *m_ivar;
+    float *ivar;
+    uint8_t *state;
+    const float4 *lut;
+    float *vscratch;            // [n_tasks][vmax][64] when a block exceeds the LDS capacity, else null
+    uint32_t n_test_blk, tpb_shift, n_tasks, n_train_blk;
+    uint32_t vmax;              // rows of v per task in vscratch
+    float scale;                // (float)(1.73205 / ell)
+    float sf2, noise, l, min_ivar, max_ivar, min_known_ivar, free_thresh, occupied_thresh;
+};
+
+__device__ __forceinline__ float cr_expf_dev(float x) { return (float)exp((double)x); }
+
+__device__ __forceinline__ float matern3_dev(float ax, float ay, float az, float bx, float by, float bz, float sf2) {
+    const float dx = bx - ax, dy = by - ay, dz = bz - az;
+    const float d = sqrtf(dx * dx + (dy * dy + dz * dz));
+    return ((1 + d) * cr_expf_dev(-d)) * sf2;
+}
+
+// scale the training points (x * s, gpregressor.h:115) and resolve neighbour ranges
+__global__ void gp_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float s,
+                           const int32_t *__restrict__ nbr, const uint32_t *__restrict__ train_off,
+                           uint2 *__restrict__ nbr_range, uint32_t n_nbr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float4 p = in[i];
+        out[i] = make_float4(s * p.x, s * p.y, s * p.z, p.w);
+    }
+    if (i < n_nbr) {
+        const int tb = nbr[i];
+        uint2 r = make_uint2(0u, 0u);
+        if (tb >= 0) {
+            r.x = train_off[tb];
+            r.y = train_off[tb + 1] - r.x;
+        }
+        nbr_range[i] = r;
+    }
+}
+
+// exclusive scan of N_b^2 (one workgroup; n_train_blk is a few 10^4) + max N_b
+__global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32_t n_blk,
+                                  unsigned long long *__restrict__ l_off, unsigned long long *__restrict__ totals) {
+    __shared__ unsigned long long s_sum[256];
+    __shared__ uint32_t s_max[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_blk + 255u) / 256u;
+    const uint32_t b0 = tid * per, b1 = min(n_blk, b0 + per);
+    unsigned long long sum = 0;
+    uint32_t mx = 0;
+    for (uint32_t b = b0; b < b1; ++b) {
+        const unsigned long long n = train_off[b + 1] - train_off[b];
+        sum += n * n;
+        mx = max(mx, (uint32_t)n);
+    }
+    s_sum[tid] = sum;
+    s_max[tid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        uint32_t m = 0;
+        for (int i = 0; i < 256; ++i) {
+            const unsigned long long t = s_sum[i];
+            s_sum[i] = run;
+            run += t;
+            m = max(m, s_max[i]);
+        }
+        totals[0] = run;
+        totals[1] = m;
+    }
+    __syncthreads();
+    unsigned long long run = s_sum[tid];
+    for (uint32_t b = b0; b < b1; ++b) {
+        const unsigned long long n = train_off[b + 1] - train_off[b];
+        l_off[b] = run;
+        run += n * n;
+    }
+}
+
+// GPRegressor::train for one training block per workgroup (256 threads, rows strided over threads).
+// K is built in place in the block's N x N slot, factored column by column (FMA chains over k
+// ascending), then alpha = L^-T (L^-1 y).
+__global__ __launch_bounds__(256) void gp_train_kernel(GpArgs a) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t p0 = a.train_off[b];
+    const int N = (int)(a.train_off[b + 1] - p0);
+    if (N == 0) return;
+    float *L = a.Lmat + a.l_off[b];
+    const float4 *x = a.pts + p0;
+    const int tid = threadIdx.x;
+    __shared__ float s_d;
+    __shared__ float s_z;
+    // K(i, j), i >= j; + noise on the diagonal (gpregressor.h:44-46)
+    for (int e = tid; e < N * N; e += 256) {
+        const int i = e / N, j = e - i * N;
+        if (j > i) continue;
+        const float4 xi = x[i], xj = x[j];
+        float k = matern3_dev(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);  // dist(x, z)(i, j) = |z_j - x_i|
+        if (i == j) k = k + a.noise;
+        L[(size_t)i * N + j] = k;
+    }
+    __syncthreads();
+    // LLT (gpregressor.h:47)
+    for (int j = 0; j < N; ++j) {
+        if (tid == 0) {
+            float acc = L[(size_t)j * N + j];
+            for (int k = 0; k < j; ++k) acc = __builtin_fmaf(-L[(size_t)j * N + k], L[(size_t)j * N + k], acc);
+            s_d = sqrtf(acc);
+        }
+        __syncthreads();
+        const float d = s_d;
+        for (int i = j + 1 + tid; i < N; i += 256) {
+            float acc = L[(size_t)i * N + j];
+            for (int k = 0; k < j; ++k) acc = __builtin_fmaf(-L[(size_t)i * N + k], L[(size_t)j * N + k], acc);
+            L[(size_t)i * N + j] = acc / d;
+        }
+        if (tid == 0) L[(size_t)j * N + j] = d;
+        __syncthreads();
+    }
+    // alpha = llt.solve(y) (gpregressor.h:48): z = L^-1 y (chains over k ascending), alpha = L^-T z
+    // (chains over k descending).  Right-looking: rows owned by threads, accumulators in alpha_k.
+    float *al = a.alpha_k + p0;
+    for (int i = tid; i < N; i += 256) al[i] = x[i].w;
+    __syncthreads();
+    for (int j = 0; j < N; ++j) {
+        if (tid == 0) {
+            const float z = al[j] / L[(size_t)j * N + j];
+            al[j] = z;
+            s_z = z;
+        }
+        __syncthreads();
+        const float z = s_z;
+        for (int i = j + 1 + tid; i < N; i += 256) al[i] = __builtin_fmaf(-L[(size_t)i * N + j], z, al[i]);
+        __syncthreads();
+    }
+    for (int j = N - 1; j >= 0; --j) {
+        if (tid == 0) {
+            const float v = al[j] / L[(size_t)j * N + j];
+            al[j] = v;
+            s_z = v;
+        }
+        __syncthreads();
+        const float v = s_z;
+        for (int i = tid; i < j; i += 256) al[i] = __builtin_fmaf(-L[(size_t)j * N + i], v, al[i]);
+        __syncthreads();
+    }
+}
+
+// GP node update, src/gpoctomap/gpoctree_node.cpp:36-49 (double expression for ivar, double exp)
+__device__ __forceinline__ void gp_node_update_dev(const GpArgs &a, float &m_ivar, float &ivar, uint8_t &state, float new_m,
+                                                   float new_var) {
+    ivar = (float)((double)ivar + (1.0 / (double)new_var - (double)a.sf2));
+    m_ivar += new_m / new_var;
+    if (ivar < a.min_known_ivar) {
+        state = 2;
+    } else {
+        ivar = ivar > a.max_ivar ? a.max_ivar : ivar;
+        const float p = 1.0f / (1.0f + (float)exp((double)(-a.l * m_ivar / a.max_ivar)));
+        state = p > a.occupied_thresh ? 1 : (p < a.free_thresh ? 0 : 2);
+    }
+}
+
+// GPRegressor::predict + BCM fusion: one wave64 per leaf tile, lane = leaf (test point).
+// v = L^-1 Ks column by column per lane: v_k = (Ks_k - sum_{i<k} L_ki v_i) / L_kk with the row of L
+// wave-uniform (scalar loads) and the lane's v_i in LDS [row][lane] (or global scratch for large N).
+constexpr int kGpLdsRows = 96;
+
+__global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
+    __shared__ float s_v[kGpLdsRows][kWave];
+    const int lane = threadIdx.x;
+    const uint32_t task = blockIdx.x;
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = (uint32_t)lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+    const uint32_t key = a.leaf_key[li];
+    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    // 1.73205/ell * xs (gpregressor.h:115): position first (LUT + centre), then the scale
+    const float tx = a.scale * (off4.x + a.blk_center[3 * blk + 0]);
+    const float ty = a.scale * (off4.y + a.blk_center[3 * blk + 1]);
+    const float tz = a.scale * (off4.z + a.blk_center[3 * blk + 2]);
+    float m_ivar = a.m_ivar[li], ivar = a.ivar[li];
+    uint8_t state = 2;
+    bool updated = false;
+    float *vg = a.vscratch ? a.vscratch + (size_t)task * a.vmax * kWave : nullptr;
+
+    for (int nb = 0; nb < 7; ++nb) {
+        const uint2 r = a.nbr_range[7 * blk + nb];
+        const int N = (int)r.y;
+        if (N == 0) continue;
+        const int tb = a.nbr[7 * blk + nb];
+        const float *L = a.Lmat + a.l_off[tb];
+        const float4 *x = a.pts + r.x;
+        const float *al = a.alpha_k + r.x;
+        const bool in_lds = N <= kGpLdsRows;
+        float mj = 0.0f, ss = 0.0f;
+        for (int k = 0; k < N; ++k) {
+            const float4 xk = x[k];
+            const float ks = matern3_dev(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);  // Ks(k, j) = k(x_k, xs_j)
+            mj = __builtin_fmaf(ks, al[k], mj);
+            float acc = ks;
+            const float *Lk = L + (size_t)k * N;
+            if (in_lds) {
+                for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], s_v[i][lane], acc);
+            } else {
+                for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], vg[(size_t)i * kWave + lane], acc);
+            }
+            const float vk = acc / Lk[k];
+            if (in_lds) s_v[k][lane] = vk; else vg[(size_t)k * kWave + lane] = vk;
+            ss = __builtin_fmaf(vk, vk, ss);
+        }
+        const float var = a.sf2 - ss;
+        gp_node_update_dev(a, m_ivar, ivar, state, mj, var);
+        updated = true;
+    }
+    if (active) {
+        if (updated) {
+            a.m_ivar[li] = m_ivar;
+            a.ivar[li] = ivar;
+            a.state[li] = (uint8_t)(state | 0x80u);
+        } else {
+            a.state[li] = 0;
+        }
+    }
+}
+
+}  // namespace la3dm_dev

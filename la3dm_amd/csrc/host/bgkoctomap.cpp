@@ -35,8 +35,31 @@ float Occupancy::occupied_thresh = 0.7f;
 float Occupancy::var_thresh = 1000.0f;
 float Occupancy::prior_A = 0.5f;
 float Occupancy::prior_B = 0.5f;
+int Occupancy::variant = 0;
+float Occupancy::init_A = 0.5f;
+float Occupancy::init_B = 0.5f;
+float Occupancy::noise = 0.01f;
+float Occupancy::l = 100.f;
+float Occupancy::max_ivar = 1000.0f;
+float Occupancy::min_ivar = 0.001f;
+float Occupancy::min_known_ivar = 10.0f;
+
+float Occupancy::get_prob() const {
+    if (variant == 1) return 1.0f / (1.0f + (float)exp((double)(-l * m_A / max_ivar)));  // gpoctree_node.cpp:31-34
+    return m_A / (m_A + m_B);
+}
 
 void Occupancy::classify() {
+    if (variant == 1) {  // gpoctree_node.cpp:40-48
+        if (m_B < min_known_ivar) {
+            state = State::UNKNOWN;
+            return;
+        }
+        m_B = m_B > max_ivar ? max_ivar : m_B;
+        const float p = get_prob();
+        state = p > occupied_thresh ? State::OCCUPIED : (p < free_thresh ? State::FREE : State::UNKNOWN);
+        return;
+    }
     if (get_var() > var_thresh) {
         state = State::UNKNOWN;
         return;
@@ -45,12 +68,26 @@ void Occupancy::classify() {
     state = p > occupied_thresh ? State::OCCUPIED : (p < free_thresh ? State::FREE : State::UNKNOWN);
 }
 
-Occupancy::Occupancy(float A, float B) : classified(false), m_A(prior_A + A), m_B(prior_B + B) { classify(); }
+Occupancy::Occupancy(float A, float B) : classified(false) {
+    if (variant == 1) {  // Occupancy(m, var), gpoctree_node.cpp:19-29
+        m_A = A / B;
+        m_B = 1.0f / B;
+    } else {
+        m_A = prior_A + A;
+        m_B = prior_B + B;
+    }
+    classify();
+}
 
 void Occupancy::update(float ybar, float kbar) {
     classified = true;
-    m_A += ybar;
-    m_B += kbar - ybar;
+    if (variant == 1) {  // BCM: update(new_m, new_var), gpoctree_node.cpp:36-39
+        m_B = (float)((double)m_B + (1.0 / (double)kbar - (double)sf2));
+        m_A += ybar / kbar;
+    } else {
+        m_A += ybar;
+        m_B += kbar - ybar;
+    }
     classify();
 }
 
@@ -232,8 +269,25 @@ BGKOctoMap::BGKOctoMap() : BGKOctoMap(0.1f, 4, 1.0, 1.0, 0.3f, 0.7f, 1.0f, 1.0f,
 
 BGKOctoMap::BGKOctoMap(float resolution_, unsigned short block_depth_, float sf2, float ell, float free_thresh,
                        float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device)
+    : BGKOctoMap(0, resolution_, block_depth_, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B,
+                 nullptr, device) {}
+
+GPOctoMap::GPOctoMap(float resolution_, unsigned short block_depth_, float sf2, float ell, float noise, float l,
+                     float min_var, float max_var, float max_known_var, float free_thresh, float occupied_thresh,
+                     int device)
+    : BGKOctoMap(1, resolution_, block_depth_, sf2, ell, free_thresh, occupied_thresh, 0.0f, 0.0f, 0.0f,
+                 [&] {
+                     static thread_local GPParams g;
+                     g = GPParams{noise, l, min_var, max_var, max_known_var};
+                     return &g;
+                 }(),
+                 device) {}
+
+BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_depth_, float sf2, float ell,
+                       float free_thresh, float occupied_thresh, float var_thresh, float prior_A, float prior_B,
+                       const GPParams *gp, int device)
     : resolution(resolution_), block_size((float)pow(2, block_depth_ - 1) * resolution_), block_depth(block_depth_),
-      ctx(nullptr), scan_flags(0) {
+      ctx(nullptr), scan_flags(0), variant(variant_), train_max_n(0), train_sum_n2(0) {
     Block::resolution = resolution;
     Block::size = block_size;
     Block::key_loc_map = init_key_loc_map(resolution, block_depth);
@@ -245,9 +299,27 @@ BGKOctoMap::BGKOctoMap(float resolution_, unsigned short block_depth_, float sf2
     OcTreeNode::var_thresh = var_thresh;
     OcTreeNode::prior_A = prior_A;
     OcTreeNode::prior_B = prior_B;
+    OcTreeNode::variant = variant;
+    OcTreeNode::init_A = prior_A;
+    OcTreeNode::init_B = prior_B;
+    if (variant == 1) {  // src/gpoctomap/gpoctomap.cpp:37-44
+        OcTreeNode::noise = gp->noise;
+        OcTreeNode::l = gp->l;
+        OcTreeNode::min_ivar = 1.0f / gp->max_var;
+        OcTreeNode::max_ivar = 1.0f / gp->min_var;
+        OcTreeNode::min_known_ivar = 1.0f / gp->max_known_var;
+        OcTreeNode::init_A = 0.0f;
+        OcTreeNode::init_B = OcTreeNode::min_ivar;
+    }
 
     la3dm_params p;
     std::memset(&p, 0, sizeof(p));
+    p.variant = variant;
+    p.noise = OcTreeNode::noise;
+    p.l = OcTreeNode::l;
+    p.min_ivar = OcTreeNode::min_ivar;
+    p.max_ivar = OcTreeNode::max_ivar;
+    p.min_known_ivar = OcTreeNode::min_known_ivar;
     p.resolution = resolution;
     p.block_depth = block_depth;
     p.sf2 = sf2;
@@ -445,7 +517,8 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
     if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled);
     const size_t nf = sampled.size() / 3;
     xy.reserve(xy.size() + 4 * nf);
-    for (size_t i = 0; i < nf; ++i) xy.insert(xy.end(), {sampled[3 * i], sampled[3 * i + 1], sampled[3 * i + 2], 0.0f});
+    const float free_label = variant == 1 ? -1.0f : 0.0f;  // bgkoctomap.cpp:415 / gpoctomap.cpp:399
+    for (size_t i = 0; i < nf; ++i) xy.insert(xy.end(), {sampled[3 * i], sampled[3 * i + 1], sampled[3 * i + 2], free_label});
     stats.n_hits = kept;
     stats.n_frees = nf;
 }
@@ -537,6 +610,13 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
         i = j;
     }
     stats.n_train_blocks = n_train_blk;
+    train_max_n = 0;
+    train_sum_n2 = 0;
+    for (size_t b = 0; b + 1 < train_off.size(); ++b) {
+        const uint64_t nb = train_off[b + 1] - train_off[b];
+        train_max_n = std::max<uint32_t>(train_max_n, (uint32_t)nb);
+        train_sum_n2 += nb * nb;
+    }
 
     // test blocks: candidate blocks whose extended block holds any point; list order kept
     std::unordered_map<BlockHashKey, uint32_t> times_seen;
@@ -621,6 +701,10 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
     return !passes.empty();
 }
 
+int BGKOctoMap::run_scan(la3dm_bgk_scan *s, la3dm_bgk_counters *c) {
+    return variant == 1 ? la3dm_gp_scan_host(ctx, s, c) : la3dm_bgk_scan_host(ctx, s, c);
+}
+
 la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
     la3dm_bgk_scan s;
     std::memset(&s, 0, sizeof(s));
@@ -639,6 +723,8 @@ la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
     s.beta = ps.beta.data();
     s.state = ps.state.data();
     s.flags = scan_flags;
+    s.train_max_n = train_max_n;
+    s.train_sum_n2 = train_sum_n2;
     return s;
 }
 
@@ -678,7 +764,7 @@ void BGKOctoMap::commit() {
         refresh_pass(p);
         la3dm_bgk_scan s = packed(p);
         if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::commit: no device context");
-        if (la3dm_bgk_scan_host(ctx, &s, nullptr) != LA3DM_OK)
+        if (run_scan(&s, nullptr) != LA3DM_OK)
             throw std::runtime_error(std::string("BGKOctoMap::commit: ") + la3dm_last_error(ctx));
         write_nodes(p);
     }
@@ -716,7 +802,7 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
     {
         la3dm_bgk_scan s = packed(0);
         la3dm_bgk_counters c;
-        if (la3dm_bgk_scan_host(ctx, &s, &c) != LA3DM_OK)
+        if (run_scan(&s, &c) != LA3DM_OK)
             throw std::runtime_error(std::string("BGKOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
         stats.n_tiles += c.n_tiles;
     }
@@ -735,7 +821,7 @@ void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
     const double t1 = wall();
     {
         la3dm_bgk_scan s = packed(0);
-        if (la3dm_bgk_scan_host(ctx, &s, nullptr) != LA3DM_OK)
+        if (run_scan(&s, nullptr) != LA3DM_OK)
             throw std::runtime_error(std::string("BGKOctoMap::insert_training_data: ") + la3dm_last_error(ctx));
     }
     stats.t_device = wall() - t1;

@@ -78,7 +78,8 @@ class Occupancy {
     friend void ::la3dm_node_ab(const void *node, float *A, float *B);
 
 public:
-    Occupancy() : classified(false), m_A(prior_A), m_B(prior_B), state(State::UNKNOWN) {}
+    /// BGK: (prior_A, prior_B); GP: (m_ivar, ivar) = (0, min_ivar)  (gpoctree_node.h:34)
+    Occupancy() : classified(false), m_A(init_A), m_B(init_B), state(State::UNKNOWN) {}
     Occupancy(float A, float B);
     // like the reference, copying does not carry `classified`
     Occupancy(const Occupancy &o) : m_A(o.m_A), m_B(o.m_B), state(o.state) {}
@@ -93,8 +94,10 @@ public:
     /// never calls it — the GPU does the updates).
     void update(float ybar, float kbar);
 
-    float get_prob() const { return m_A / (m_A + m_B); }
-    float get_var() const { return (m_A * m_B) / ((m_A + m_B) * (m_A + m_B) * (m_A + m_B + 1.0f)); }
+    float get_prob() const;
+    float get_var() const {
+        return variant == 1 ? 1.0f / m_B : (m_A * m_B) / ((m_A + m_B) * (m_A + m_B) * (m_A + m_B + 1.0f));
+    }
     State get_state() const { return state; }
     void prune() { state = State::PRUNED; }
     bool operator==(const Occupancy &rhs) const { return state != State::UNKNOWN && state == rhs.state; }
@@ -108,6 +111,9 @@ private:
     State state;
 
     static float sf2, ell, prior_A, prior_B, free_thresh, occupied_thresh, var_thresh;
+    // GPOctoMap statics (src/gpoctomap/gpoctree_node.cpp:7-17); for GP nodes m_A holds m_ivar, m_B holds ivar
+    static int variant;  // 0 BGK, 1 GP
+    static float init_A, init_B, noise, l, max_ivar, min_ivar, min_known_ivar;
 };
 typedef Occupancy OcTreeNode;
 static_assert(sizeof(Occupancy) == 16, "node layout must match the reference (16 bytes)");
@@ -231,6 +237,15 @@ public:
     BGKOctoMap(const BGKOctoMap &) = delete;
     BGKOctoMap &operator=(const BGKOctoMap &) = delete;
 
+protected:
+    struct GPParams {
+        float noise, l, min_var, max_var, max_known_var;
+    };
+    /// shared constructor: variant 0 = BGK (gp == nullptr), 1 = GP
+    BGKOctoMap(int variant, float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh,
+               float occupied_thresh, float var_thresh, float prior_A, float prior_B, const GPParams *gp, int device);
+
+public:
     float get_resolution() const { return resolution; }
     float get_block_depth() const { return block_depth; }
     float get_block_size() const { return block_size; }
@@ -338,6 +353,19 @@ private:
     std::vector<BlockHashKey> prune_list;  // test_blocks in list order (with repeats)
     uint32_t scan_flags;
     ScanStats stats;
+    int variant;
+    uint32_t train_max_n;
+    uint64_t train_sum_n2;
+    int run_scan(la3dm_bgk_scan *s, la3dm_bgk_counters *c);
+};
+
+/// GPOctoMap: same skeleton, GP regression per block + BCM fusion (reference include/gpoctomap/gpoctomap.h).
+/// Constructor argument order as the reference (src/gpoctomap/gpoctomap.cpp:23-25).
+class GPOctoMap : public BGKOctoMap {
+public:
+    GPOctoMap() : GPOctoMap(0.1f, 4, 1.0, 1.0, 0.01, 100, 0.001f, 1000.0f, 0.02f, 0.3f, 0.7f) {}
+    GPOctoMap(float resolution, unsigned short block_depth, float sf2, float ell, float noise, float l, float min_var,
+              float max_var, float max_known_var, float free_thresh, float occupied_thresh, int device = 0);
 };
 
 }  // namespace la3dm

@@ -43,6 +43,20 @@ la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float 
     }
 }
 
+la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, float ell, float noise, float l,
+                               float min_var, float max_var, float max_known_var, float free_thresh,
+                               float occupied_thresh, int device) {
+    try {
+        la3dm_map *m = new la3dm_map;
+        m->map = new la3dm::GPOctoMap(resolution, (unsigned short)block_depth, sf2, ell, noise, l, min_var, max_var,
+                                      max_known_var, free_thresh, occupied_thresh, device);
+        return m;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
 void la3dm_map_destroy(la3dm_map *m) {
     if (!m) return;
     delete m->map;

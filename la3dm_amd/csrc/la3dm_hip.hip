@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bgk_kernels.h"
+#include "gp_kernels.h"
 
 using namespace la3dm_dev;
 
@@ -38,6 +39,7 @@ struct la3dm_ctx {
     size_t ev_used = 0;
     // scratch (device-pointer path)
     Arena pts_scaled, nbr_range;
+    Arena gp_loff, gp_totals, gp_L, gp_alpha, gp_v;
     // staging (host-pointer path)
     Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,
         h_diag_out;
@@ -135,7 +137,7 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
 void la3dm_destroy(la3dm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->pts_scaled, &ctx->nbr_range, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
+    Arena *all[] = {&ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
@@ -320,7 +322,9 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     return LA3DM_OK;
 }
 
-int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out) {
+typedef int (*scan_device_fn)(la3dm_ctx *, const la3dm_bgk_scan *, void *, la3dm_bgk_counters *);
+
+static int scan_host_common(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out, scan_device_fn run) {
     int rc = check_scan(ctx, s);
     if (rc != LA3DM_OK) return rc;
     if (out) memset(out, 0, sizeof(*out));
@@ -358,7 +362,7 @@ int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_count
     d.alpha = (float *)ctx->h_alpha.ptr;
     d.beta = (float *)ctx->h_beta.ptr;
     d.state = (uint8_t *)ctx->h_state.ptr;
-    rc = la3dm_bgk_scan_device(ctx, &d, st, out);
+    rc = run(ctx, &d, st, out);
     if (rc != LA3DM_OK) return rc;
     if (s->n_leaf) {
         HIP_TRY(ctx, hipMemcpyAsync(s->alpha, d.alpha, sizeof(float) * (size_t)s->n_leaf, hipMemcpyDeviceToHost, st));
@@ -367,6 +371,112 @@ int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_count
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return LA3DM_OK;
+}
+
+int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out) {
+    return scan_host_common(ctx, s, out, la3dm_bgk_scan_device);
+}
+
+int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_, la3dm_bgk_counters *out) {
+    int rc = check_scan(ctx, s);
+    if (rc != LA3DM_OK) return rc;
+    if (out) memset(out, 0, sizeof(*out));
+    if (s->n_test_blk == 0) return LA3DM_OK;
+    if (ctx->p.variant != 1) {
+        ctx->err = "la3dm_gp_scan: the context was not created with variant = 1 (GPOctoMap)";
+        return LA3DM_ERR_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npts = s->n_train_pts ? s->n_train_pts : 1, nblk = s->n_train_blk ? s->n_train_blk : 1;
+    if ((rc = arena_reserve(ctx, ctx->pts_scaled, sizeof(float4) * npts)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->nbr_range, sizeof(uint2) * 7 * (size_t)s->n_test_blk)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->gp_loff, sizeof(unsigned long long) * nblk)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->gp_totals, 16)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->gp_alpha, sizeof(float) * npts)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(gp_factor_offsets, dim3(1), dim3(256), 0, stream, s->train_off, s->n_train_blk,
+                       (unsigned long long *)ctx->gp_loff.ptr, (unsigned long long *)ctx->gp_totals.ptr);
+    unsigned long long sum_n2 = s->train_sum_n2;
+    uint32_t max_n = s->train_max_n;
+    if (sum_n2 == 0 || max_n == 0) {  // no hints: one synchronisation to size the factor arena
+        unsigned long long tot[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(tot, ctx->gp_totals.ptr, 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        sum_n2 = tot[0];
+        max_n = (uint32_t)tot[1];
+    }
+    if ((rc = arena_reserve(ctx, ctx->gp_L, sizeof(float) * (size_t)(sum_n2 ? sum_n2 : 1))) != LA3DM_OK) return rc;
+
+    uint32_t max_leaves = 1u << (3 * (ctx->p.block_depth - 1));
+    uint32_t tpb = (max_leaves + kWave - 1) / kWave, tpb_shift = 0;
+    while ((1u << tpb_shift) < tpb) ++tpb_shift;
+    GpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_test_blk = s->n_test_blk;
+    a.tpb_shift = tpb_shift;
+    a.n_tasks = s->n_test_blk << tpb_shift;
+    a.n_train_blk = s->n_train_blk;
+    a.vmax = 0;
+    a.vscratch = nullptr;
+    if (max_n > (uint32_t)kGpLdsRows) {
+        a.vmax = max_n;
+        if ((rc = arena_reserve(ctx, ctx->gp_v, sizeof(float) * (size_t)a.n_tasks * max_n * kWave)) != LA3DM_OK) return rc;
+        a.vscratch = (float *)ctx->gp_v.ptr;
+    }
+    a.pts = (const float4 *)ctx->pts_scaled.ptr;
+    a.train_off = s->train_off;
+    a.nbr_range = (const uint2 *)ctx->nbr_range.ptr;
+    a.nbr = s->nbr;
+    a.l_off = (const unsigned long long *)ctx->gp_loff.ptr;
+    a.Lmat = (float *)ctx->gp_L.ptr;
+    a.alpha_k = (float *)ctx->gp_alpha.ptr;
+    a.blk_center = s->blk_center;
+    a.leaf_off = s->leaf_off;
+    a.leaf_key = s->leaf_key;
+    a.m_ivar = s->alpha;
+    a.ivar = s->beta;
+    a.state = s->state;
+    a.lut = ctx->d_lut;
+    a.scale = (float)(1.73205 / (double)ctx->p.ell);
+    a.sf2 = ctx->p.sf2;
+    a.noise = ctx->p.noise;
+    a.l = ctx->p.l;
+    a.min_ivar = ctx->p.min_ivar;
+    a.max_ivar = ctx->p.max_ivar;
+    a.min_known_ivar = ctx->p.min_known_ivar;
+    a.free_thresh = ctx->p.free_thresh;
+    a.occupied_thresh = ctx->p.occupied_thresh;
+    {
+        const uint32_t n_nbr = 7u * s->n_test_blk;
+        const uint32_t n_thr = s->n_train_pts > n_nbr ? s->n_train_pts : n_nbr;
+        hipLaunchKernelGGL(gp_prepare, dim3((n_thr + 255) / 256), dim3(256), 0, stream, (const float4 *)s->train_xyzy,
+                           (float4 *)ctx->pts_scaled.ptr, s->n_train_pts, a.scale, s->nbr, s->train_off,
+                           (uint2 *)ctx->nbr_range.ptr, n_nbr);
+    }
+    if (s->n_train_blk) hipLaunchKernelGGL(gp_train_kernel, dim3(s->n_train_blk), dim3(256), 0, stream, a);
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (ctx->opt_time_kernel) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> p;
+            HIP_TRY(ctx, hipEventCreate(&p.first));
+            HIP_TRY(ctx, hipEventCreate(&p.second));
+            ctx->ev_pool.push_back(p);
+        }
+        ev = &ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
+    }
+    hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), 0, stream, a);
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    if (out) {
+        out->n_tiles = a.n_tasks;
+        out->scratch_bytes = sizeof(float) * (size_t)sum_n2 + sizeof(float4) * (size_t)s->n_train_pts;
+    }
+    return LA3DM_OK;
+}
+
+int la3dm_gp_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out) {
+    return scan_host_common(ctx, s, out, la3dm_gp_scan_device);
 }
 
 int la3dm_kernel_times(la3dm_ctx *ctx, float *ms, uint32_t cap, uint32_t *n_out) {

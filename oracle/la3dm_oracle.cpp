@@ -52,6 +52,9 @@ struct Params {
     float free_thresh, occupied_thresh, var_thresh;
     float prior_A, prior_B;
     float block_size;  // src/bgkoctomap/bgkoctomap.cpp:41
+    // GPOctoMap (variant 1): src/gpoctomap/gpoctomap.cpp:23-46
+    int variant;       // 0 = BGKOctoMap, 1 = GPOctoMap
+    float noise, l, min_ivar, max_ivar, min_known_ivar;
 };
 
 // include/bgkoctomap/bgkoctree_node.h:76-81 (classified, m_A, m_B, state)
@@ -86,6 +89,24 @@ inline void node_update(const Params &p, Node &n, float ybar, float kbar) {
         n.state = ST_UNKNOWN;
     else {
         float pr = node_prob(n);
+        n.state = pr > p.occupied_thresh ? ST_OCCUPIED : (pr < p.free_thresh ? ST_FREE : ST_UNKNOWN);
+    }
+}
+
+// GP node (variant 1): A holds m_ivar, B holds ivar.  src/gpoctomap/gpoctree_node.cpp:31-49.
+// exp() is evaluated in double; `ivar += 1.0 / new_var - sf2` is a double expression.
+inline float gp_node_prob(const Params &p, const Node &n) {
+    return 1.0f / (1.0f + (float)exp((double)(-p.l * n.A / p.max_ivar)));
+}
+inline void gp_node_update(const Params &p, Node &n, float new_m, float new_var) {
+    n.classified = 1;
+    n.B = (float)((double)n.B + (1.0 / (double)new_var - (double)p.sf2));
+    n.A += new_m / new_var;
+    if (n.B < p.min_known_ivar)
+        n.state = ST_UNKNOWN;
+    else {
+        n.B = n.B > p.max_ivar ? p.max_ivar : n.B;
+        float pr = gp_node_prob(p, n);
         n.state = pr > p.occupied_thresh ? ST_OCCUPIED : (pr < p.free_thresh ? ST_FREE : ST_UNKNOWN);
     }
 }
@@ -160,6 +181,7 @@ Block *block_new(const Params &p, V3 center) {
     size_t n = 1;
     for (int d = 0; d < p.block_depth; ++d, n *= 8) {
         Node def{0, p.prior_A, p.prior_B, ST_UNKNOWN};  // bgkoctree_node.h:34
+        if (p.variant == 1) def = Node{0, 0.0f, p.min_ivar, ST_UNKNOWN};  // gpoctree_node.h:34
         b->layer[d].assign(n, def);
     }
     return b;
@@ -283,6 +305,86 @@ void bgk_predict(float sf2, float ell, const float *xs, int M, const float *x, c
 }
 
 // ---------------------------------------------------------------------------
+// GPRegressor<3,float>: include/gpoctomap/gpregressor.h:42-51 (train), :80-92 (predict),
+// :114-117 (covMaterniso3).  Eigen internals (LLT, triangular solve, GEMV, packet exp) are
+// third-party and unpinned => PARITY UNPINNED for this block; restated with every inner
+// product as an fp32 FMA chain in ascending index order (the order an MFMA f32 tile
+// accumulates in) and exp() as the correctly rounded single-precision function.
+// ---------------------------------------------------------------------------
+inline float cr_expf(float x) { return (float)exp((double)x); }
+
+inline float matern3(const float *a, const float *b, float sf2) {  // a, b already scaled by 1.73205/ell
+    float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+    float d = sqrtf(dx * dx + (dy * dy + dz * dz));
+    return ((1 + d) * cr_expf(-d)) * sf2;
+}
+
+struct GPModel {
+    int N;
+    std::vector<float> xn;     // scaled training points
+    std::vector<float> alpha;  // K^-1 y
+    std::vector<float> L;      // lower Cholesky factor, row-major N x N
+};
+
+void gp_train(const Params &p, const float *x, const float *y, int N, GPModel &g) {
+    g.N = N;
+    g.xn.resize((size_t)N * 3);
+    const float s = (float)(1.73205 / p.ell);  // double quotient narrowed before the product (:115)
+    for (int i = 0; i < N * 3; ++i) g.xn[i] = s * x[i];
+    std::vector<float> K((size_t)N * N);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) K[(size_t)i * N + j] = matern3(&g.xn[3 * i], &g.xn[3 * j], p.sf2);
+    for (int i = 0; i < N; ++i) K[(size_t)i * N + i] = K[(size_t)i * N + i] + p.noise;  // K + noise * I (:46)
+    // LLT (:47): column by column, each entry an FMA chain over k ascending
+    g.L.assign((size_t)N * N, 0.0f);
+    float *L = g.L.data();
+    for (int j = 0; j < N; ++j) {
+        float acc = K[(size_t)j * N + j];
+        for (int k = 0; k < j; ++k) acc = fmaf(-L[(size_t)j * N + k], L[(size_t)j * N + k], acc);
+        const float d = sqrtf(acc);
+        L[(size_t)j * N + j] = d;
+        for (int i = j + 1; i < N; ++i) {
+            float a2 = K[(size_t)i * N + j];
+            for (int k = 0; k < j; ++k) a2 = fmaf(-L[(size_t)i * N + k], L[(size_t)j * N + k], a2);
+            L[(size_t)i * N + j] = a2 / d;
+        }
+    }
+    // alpha = llt.solve(y) (:48): forward with L (k ascending), backward with L^T (k descending)
+    std::vector<float> z(N);
+    for (int j = 0; j < N; ++j) {
+        float acc = y[j];
+        for (int k = 0; k < j; ++k) acc = fmaf(-L[(size_t)j * N + k], z[k], acc);
+        z[j] = acc / L[(size_t)j * N + j];
+    }
+    g.alpha.resize(N);
+    for (int j = N - 1; j >= 0; --j) {
+        float acc = z[j];
+        for (int k = N - 1; k > j; --k) acc = fmaf(-L[(size_t)k * N + j], g.alpha[k], acc);
+        g.alpha[j] = acc / L[(size_t)j * N + j];
+    }
+}
+
+void gp_predict(const Params &p, const GPModel &g, const float *xs, int M, float *m, float *var) {
+    const int N = g.N;
+    const float s = (float)(1.73205 / p.ell);
+    std::vector<float> v(N);
+    for (int j = 0; j < M; ++j) {
+        const float t[3] = {s * xs[3 * j], s * xs[3 * j + 1], s * xs[3 * j + 2]};
+        float mj = 0.0f, ss = 0.0f;
+        for (int k = 0; k < N; ++k) {
+            const float ks = matern3(&g.xn[3 * k], t, p.sf2);     // Ks(k, j), dist(x, xs)
+            mj = fmaf(ks, g.alpha[k], mj);                          // m = Ks^T alpha (:85)
+            float acc = ks;                                          // v = L^-1 Ks (:87)
+            for (int i = 0; i < k; ++i) acc = fmaf(-g.L[(size_t)k * N + i], v[i], acc);
+            v[k] = acc / g.L[(size_t)k * N + k];
+            ss = fmaf(v[k], v[k], ss);                               // (v^T v).diagonal() (:90)
+        }
+        m[j] = mj;
+        var[j] = p.sf2 - ss;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // pcl::VoxelGrid<PointXYZ>::applyFilter restated (PCL 1.10 filters/impl/voxel_grid.hpp;
 // third-party, absent from /root/reference, version unpinned => parity unpinned).
 // downsample_all_data_=true, min_points_per_voxel_=0, no field filter.
@@ -368,7 +470,7 @@ struct XY {
 
 // src/bgkoctomap/bgkoctomap.cpp:383-417
 void get_training_data(const std::vector<V3> &cloud, V3 origin, float ds_resolution, float free_resolution,
-                       float max_range, std::vector<XY> &xy, size_t *n_hits, size_t *n_frees) {
+                       float max_range, std::vector<XY> &xy, size_t *n_hits, size_t *n_frees, float free_label = 0.0f) {
     std::vector<V3> sampled_hits;
     if (ds_resolution < 0) sampled_hits = cloud; else voxel_grid(cloud, ds_resolution, sampled_hits);
     std::vector<V3> frees, frees_n;
@@ -388,7 +490,7 @@ void get_training_data(const std::vector<V3> &cloud, V3 origin, float ds_resolut
     if (n_hits) *n_hits = xy.size();
     std::vector<V3> sampled_frees;
     if (ds_resolution < 0) sampled_frees = frees; else voxel_grid(frees, ds_resolution, sampled_frees);
-    for (const V3 &f : sampled_frees) xy.push_back(XY{f, 0.0f});
+    for (const V3 &f : sampled_frees) xy.push_back(XY{f, free_label});  // 0 (bgkoctomap.cpp:415), -1 (gpoctomap.cpp:399)
     if (n_frees) *n_frees = sampled_frees.size();
 }
 
@@ -508,6 +610,27 @@ void insert_xy(Map &m, const std::vector<XY> &xy) {
     }
     st.n_train_blocks = (double)bgk_arr.size();
     st.n_test_blocks = (double)test_blocks.size();
+    // GPOctoMap: gpr->train per training block (gpoctomap.cpp:253-275)
+    std::unordered_map<int64_t, GPModel> gp_arr;
+    if (p.variant == 1) {
+        std::vector<int64_t> tkeys;
+        for (auto &kv : bgk_arr) {
+            tkeys.push_back(kv.first);
+            gp_arr.emplace(kv.first, GPModel());
+        }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic)
+#endif
+        for (long ti = 0; ti < (long)tkeys.size(); ++ti) {
+            const std::vector<int> &ids = bgk_arr[tkeys[ti]];
+            std::vector<float> bx(ids.size() * 3), by(ids.size());
+            for (size_t n = 0; n < ids.size(); ++n) {
+                bx[3 * n] = xy[ids[n]].p.x; bx[3 * n + 1] = xy[ids[n]].p.y; bx[3 * n + 2] = xy[ids[n]].p.z;
+                by[n] = xy[ids[n]].y;
+            }
+            gp_train(p, bx.data(), by.data(), (int)ids.size(), gp_arr.find(tkeys[ti])->second);
+        }
+    }
     double t1 = now_s();
     st.t_partition = t1 - t0;
 
@@ -553,9 +676,17 @@ void insert_xy(Map &m, const std::vector<XY> &xy) {
                 bx[3 * n] = xy[ids[n]].p.x; bx[3 * n + 1] = xy[ids[n]].p.y; bx[3 * n + 2] = xy[ids[n]].p.z;
                 by[n] = xy[ids[n]].y;
             }
-            bgk_predict(p.sf2, p.ell, xs.data(), M, bx.data(), by.data(), N, ybar.data(), kbar.data());
             pairs_ += (double)M * N;
             reads_ += N;
+            if (p.variant == 1) {  // GPOctoMap: gpoctomap.cpp:306-319, unconditional BCM update
+                gp_predict(p, gp_arr.find(eb[k])->second, xs.data(), M, ybar.data(), kbar.data());
+                for (int j = 0; j < M; ++j) {
+                    gp_node_update(p, block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF], ybar[j], kbar[j]);
+                    calls_ += 1;
+                }
+                continue;
+            }
+            bgk_predict(p.sf2, p.ell, xs.data(), M, bx.data(), by.data(), N, ybar.data(), kbar.data());
             for (int j = 0; j < M; ++j) {
                 Node &node = block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF];
                 if (kbar[j] > 0.0) {  // :331-333
@@ -598,12 +729,41 @@ void *orc_map_create(float resolution, int block_depth, float sf2, float ell, fl
                      float var_thresh, float prior_A, float prior_B) {
     Map *m = new Map;
     m->p = Params{resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B,
-                  (float)pow(2, block_depth - 1) * resolution};  // bgkoctomap.cpp:41
+                  (float)pow(2, block_depth - 1) * resolution,  // bgkoctomap.cpp:41
+                  0, 0.f, 0.f, 0.f, 0.f, 0.f};
+    m->lut = build_lut(resolution, block_depth);
+    std::memset(&m->st, 0, sizeof(Stats));
+    return m;
+}
+// GPOctoMap(resolution, block_depth, sf2, ell, noise, l, min_var, max_var, max_known_var, free_thresh,
+// occupied_thresh): src/gpoctomap/gpoctomap.cpp:23-46
+void *orc_gp_map_create(float resolution, int block_depth, float sf2, float ell, float noise, float l, float min_var,
+                        float max_var, float max_known_var, float free_thresh, float occupied_thresh) {
+    Map *m = new Map;
+    m->p = Params{resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, 0.f, 0.f, 0.f,
+                  (float)pow(2, block_depth - 1) * resolution,
+                  1, noise, l, 1.0f / max_var, 1.0f / min_var, 1.0f / max_known_var};
     m->lut = build_lut(resolution, block_depth);
     std::memset(&m->st, 0, sizeof(Stats));
     return m;
 }
 void orc_map_destroy(void *h) { delete (Map *)h; }
+// GPRegressor train + predict on one block (known-answer tests)
+void orc_gp_train_predict(void *h, const float *x, const float *y, int N, const float *xs, int M, float *alpha,
+                          float *L, float *m, float *var) {
+    Map *mp = (Map *)h;
+    GPModel g;
+    gp_train(mp->p, x, y, N, g);
+    if (alpha) std::memcpy(alpha, g.alpha.data(), sizeof(float) * N);
+    if (L) std::memcpy(L, g.L.data(), sizeof(float) * (size_t)N * N);
+    if (M) gp_predict(mp->p, g, xs, M, m, var);
+}
+void orc_gp_node_update(void *h, float *m_ivar, float *ivar, uint8_t *state, float new_m, float new_var) {
+    Node n{0, *m_ivar, *ivar, *state};
+    gp_node_update(((Map *)h)->p, n, new_m, new_var);
+    *m_ivar = n.A; *ivar = n.B; *state = n.state;
+}
+float orc_gp_node_prob(void *h, float m_ivar) { return gp_node_prob(((Map *)h)->p, Node{0, m_ivar, 0.f, 0}); }
 float orc_block_size(void *h) { return ((Map *)h)->p.block_size; }
 
 int64_t orc_block_to_hash_key(void *h, float x, float y, float z) { return block_to_hash_key(((Map *)h)->p, x, y, z); }
@@ -697,7 +857,8 @@ void orc_insert_pointcloud(void *h, const float *xyz, int64_t n, const float *or
     for (int64_t i = 0; i < n; ++i) cloud[i] = V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     std::vector<XY> xy;
     size_t nh = 0, nf = 0;
-    get_training_data(cloud, V3{origin[0], origin[1], origin[2]}, ds_resolution, free_res, max_range, xy, &nh, &nf);
+    get_training_data(cloud, V3{origin[0], origin[1], origin[2]}, ds_resolution, free_res, max_range, xy, &nh, &nf,
+                      m->p.variant == 1 ? -1.0f : 0.0f);
     m->st.n_hits = (double)nh; m->st.n_frees = (double)nf;
     m->st.t_frontend = now_s() - t0;
     insert_xy(*m, xy);

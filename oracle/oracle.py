@@ -39,6 +39,13 @@ def _load(name):
     lib = C.CDLL(os.path.join(_HERE, name))
     lib.orc_map_create.restype = C.c_void_p
     lib.orc_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7
+    lib.orc_gp_map_create.restype = C.c_void_p
+    lib.orc_gp_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 9
+    lib.orc_gp_train_predict.argtypes = [C.c_void_p, f32p, f32p, C.c_int, f32p, C.c_int, f32p, f32p, f32p, f32p]
+    lib.orc_gp_node_update.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                       C.c_float, C.c_float]
+    lib.orc_gp_node_prob.restype = C.c_float
+    lib.orc_gp_node_prob.argtypes = [C.c_void_p, C.c_float]
     lib.orc_map_destroy.argtypes = [C.c_void_p]
     lib.orc_block_size.restype = C.c_float
     lib.orc_block_size.argtypes = [C.c_void_p]
@@ -180,6 +187,31 @@ class OracleMap:
                                    out["B"], out["state"], out["classified"], n)
         assert m == n
         return out
+
+
+GP_YAML = dict(resolution=0.1, block_depth=3, sf2=1.0, ell=1.0, noise=0.01, l=100.0, min_var=0.001, max_var=1000.0,
+               max_known_var=0.02, free_thresh=0.3, occupied_thresh=0.7)   # config/methods/gpoctomap.yaml
+
+
+class OracleGPMap(OracleMap):
+    """CPU GPOctoMap restatement (constructor argument order of include/gpoctomap/gpoctomap.h)."""
+
+    def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, noise=0.01, l=100.0, min_var=0.001,
+                 max_var=1000.0, max_known_var=0.02, free_thresh=0.3, occupied_thresh=0.7, omp=False):
+        self.L = lib(omp)
+        self.h = self.L.orc_gp_map_create(resolution, block_depth, sf2, ell, noise, l, min_var, max_var,
+                                          max_known_var, free_thresh, occupied_thresh)
+        self.block_depth = block_depth
+
+    def train_predict(self, x, y, xs):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, 3)
+        y = np.ascontiguousarray(y, np.float32)
+        xs = np.ascontiguousarray(xs, np.float32).reshape(-1, 3)
+        n, m = x.shape[0], xs.shape[0]
+        alpha, Lm = np.zeros(n, np.float32), np.zeros((n, n), np.float32)
+        mu, var = np.zeros(m, np.float32), np.zeros(m, np.float32)
+        self.L.orc_gp_train_predict(self.h, x, y, n, xs, m, alpha, Lm, mu, var)
+        return alpha, Lm, mu, var
 
 
 def get_training_data(xyz, origin, ds_resolution, free_res, max_range):
