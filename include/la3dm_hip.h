@@ -76,6 +76,8 @@ typedef struct la3dm_params {
     float min_ivar;       /* 1 / max_var */
     float max_ivar;       /* 1 / min_var */
     float min_known_ivar; /* 1 / max_known_var */
+    /* variant 2 = BGKLVOctoMap (src/bgklvoctomap/bgklvoctomap.cpp:33-62): fields of variant 0 plus */
+    float min_W;          /* minimum total weight, src/bgklvoctomap/bgklvoctree_node.cpp:29-47 */
 } la3dm_params;
 
 /* One scan's worth of work for the BGK kernel.
@@ -144,6 +146,44 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, void *stre
  * (src/gpoctomap/gpoctree_node.cpp:36-49) in ExtendedBlock order. */
 int la3dm_gp_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, la3dm_bgk_counters *out);
 int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, void *stream, la3dm_bgk_counters *out);
+
+/* BGKLVOctoMap (variant 2): per-voxel inference against hit points and free-space line segments.
+ * Replaces, for every base-resolution leaf of every block, the body of the leaf loop of
+ * BGKLVOctoMap::insert_pointcloud (src/bgklvoctomap/bgklvoctomap.cpp:155-244): the +-ell box query, the
+ * one-row-per-ray de-duplication, BGKLV3f::predict (include/bgklvoctomap/bgklvinference.h:76-157: point-to-
+ * segment distance, r = min(d/ell, 1), sparse kernel without the < 0 clamp), the kbar > 0.001 gate and the LV
+ * Occupancy::update (src/bgklvoctomap/bgklvoctree_node.cpp:29-77).
+ *
+ *  - samples: every training sample in original order, (x, y, z, ray) with ray = -1 for a hit, else the index
+ *    of its segment (bgklvoctomap.cpp:303-423 builds them); a ray's samples are contiguous, first = segment start.
+ *  - sorted: the same samples bucketed on a grid of edge g aligned with the blocks (bucket = floor((v +
+ *    block_size/2) / g), g = 4 * resolution for block_depth >= 3 else block_size), buckets x-fastest over
+ *    [cell_min, cell_min + cell_dim), ascending original index inside a bucket; w = original index (int bits).
+ *  - rays: 8 floats per segment: start xyz, index of its first sample (int bits), end xyz, 0.
+ *  - blocks: centre, bucket coordinates of the block's lowest bucket, and dense per-node arrays of the
+ *    FINEST layer only (8^(block_depth-1) nodes per block, octree index order): alpha, beta in/out; state in:
+ *    LV code of the node (4 = pruned / not a base-resolution leaf: skipped); state out: LA3DM_LEAF_UPDATED |
+ *    new state when update() ran, LA3DM_LV_HAS_INFO when the voxel's box held any sample. */
+#define LA3DM_LV_HAS_INFO 0x40u
+enum { LA3DM_LV_FREE = 0, LA3DM_LV_OCCUPIED = 1, LA3DM_LV_UNKNOWN = 2, LA3DM_LV_UNCERTAIN = 3, LA3DM_LV_PRUNED = 4 };
+typedef struct la3dm_lv_scan {
+    const float *samples;     /* [n_samples * 4] */
+    const float *sorted;      /* [n_samples * 4] */
+    uint32_t n_samples;
+    const float *rays;        /* [n_rays * 8] */
+    uint32_t n_rays;
+    const uint32_t *cell_off; /* [cell_dim[0]*cell_dim[1]*cell_dim[2] + 1] */
+    int32_t cell_min[3];
+    int32_t cell_dim[3];
+    uint32_t n_blk;
+    const float *blk_center;  /* [n_blk * 3] */
+    const int32_t *blk_cell0; /* [n_blk * 3] */
+    float *alpha;             /* [n_blk * 8^(depth-1)] in/out */
+    float *beta;
+    uint8_t *state;           /* in/out */
+} la3dm_lv_scan;
+int la3dm_bgklv_scan_host(la3dm_ctx *ctx, const la3dm_lv_scan *scan, la3dm_bgk_counters *out);
+int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *scan, void *stream, la3dm_bgk_counters *out);
 
 /* Kernel timing.  After la3dm_set_option(ctx, "time_kernel", 1) every *_scan_device call
  * brackets its dominant kernel (bgk_predict_fuse) with HIP events on the launch stream.

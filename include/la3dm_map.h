@@ -31,6 +31,24 @@ la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float 
 la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, float ell, float noise, float l,
                                float min_var, float max_var, float max_known_var, float free_thresh,
                                float occupied_thresh, int device);
+/* BGKLVOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B,
+ * original_size, min_W) (src/bgklvoctomap/bgklvoctomap.cpp:33-43).  For an LV map la3dm_map_dump_leaves reports the
+ * reference's LV state codes (UNCERTAIN = 3, PRUNED = 4), node_key = (depth << 28) + index, and only blocks that hold a
+ * classified or collapsed leaf (the LV map allocates every block of each scan's bounding box). */
+la3dm_map *la3dm_map_create_lv(float resolution, int block_depth, float sf2, float ell, float free_thresh,
+                               float occupied_thresh, float var_thresh, float prior_A, float prior_B, int original_size,
+                               float min_W, int device);
+/* LV only: samples (x, y, z, ray) and segments (6 floats) of the last scan; counts via NULL pointers */
+uint64_t la3dm_map_lv_training(const la3dm_map *m, float *samples4, uint64_t cap_samples, float *rays6, uint64_t cap_rays,
+                               uint64_t *n_rays);
+/* LV only: n_hits, n_rays, n_samples, n_bbox_blocks, n_packed_blocks, n_info_blocks, voxels, voxel_updates,
+ * t_frontend, t_partition, t_device, t_commit, t_total */
+int la3dm_map_lv_stats(const la3dm_map *m, double *out13);
+/* LV only, split form: prepare -> la3dm_bgklv_scan_* on the packed arguments -> commit */
+int la3dm_map_lv_prepare(la3dm_map *m, const float *xyz, uint64_t n, const float *origin3, float ds_resolution,
+                         float free_res, float max_range);
+int la3dm_map_lv_packed(la3dm_map *m, la3dm_lv_scan *out);
+int la3dm_map_lv_commit(la3dm_map *m);
 void la3dm_map_destroy(la3dm_map *m);
 const char *la3dm_map_last_error(void);
 

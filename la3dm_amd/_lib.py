@@ -24,7 +24,7 @@ class Params(C.Structure):
                 ("free_thresh", C.c_float), ("occupied_thresh", C.c_float), ("var_thresh", C.c_float),
                 ("prior_A", C.c_float), ("prior_B", C.c_float), ("device", C.c_int32),
                 ("lut_xyz", C.c_void_p), ("lut_count", C.c_uint32), ("variant", C.c_int32), ("noise", C.c_float),
-                ("l", C.c_float), ("min_ivar", C.c_float), ("max_ivar", C.c_float), ("min_known_ivar", C.c_float)]
+                ("l", C.c_float), ("min_ivar", C.c_float), ("max_ivar", C.c_float), ("min_known_ivar", C.c_float), ("min_W", C.c_float)]
 
 
 class BgkScan(C.Structure):
@@ -33,6 +33,13 @@ class BgkScan(C.Structure):
                 ("leaf_off", C.c_void_p), ("n_test_blk", C.c_uint32), ("n_leaf", C.c_uint32),
                 ("leaf_key", C.c_void_p), ("alpha", C.c_void_p), ("beta", C.c_void_p), ("state", C.c_void_p),
                 ("flags", C.c_uint32), ("train_max_n", C.c_uint32), ("train_sum_n2", C.c_uint64)]
+
+
+class LvScan(C.Structure):
+    _fields_ = [("samples", C.c_void_p), ("sorted", C.c_void_p), ("n_samples", C.c_uint32), ("rays", C.c_void_p),
+                ("n_rays", C.c_uint32), ("cell_off", C.c_void_p), ("cell_min", C.c_int32 * 3), ("cell_dim", C.c_int32 * 3),
+                ("n_blk", C.c_uint32), ("blk_center", C.c_void_p), ("blk_cell0", C.c_void_p), ("alpha", C.c_void_p),
+                ("beta", C.c_void_p), ("state", C.c_void_p)]
 
 
 class BgkCounters(C.Structure):
@@ -51,8 +58,9 @@ class ScanStats(C.Structure):
 
 HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_destroy", "la3dm_last_error",
                "la3dm_set_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_gp_scan_host",
-               "la3dm_gp_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep"]
-MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
+               "la3dm_gp_scan_device", "la3dm_bgklv_scan_host", "la3dm_bgklv_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep"]
+MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
+               "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
                "la3dm_map_packed", "la3dm_map_commit", "la3dm_map_ctx", "la3dm_map_stats", "la3dm_map_training_size",
                "la3dm_map_training_data", "la3dm_map_block_size", "la3dm_map_block_count", "la3dm_map_leaf_count",
@@ -88,6 +96,10 @@ def hip():
         L.la3dm_gp_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_gp_scan_device.restype = C.c_int
         L.la3dm_gp_scan_device.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.c_void_p, C.POINTER(BgkCounters)]
+        L.la3dm_bgklv_scan_host.restype = C.c_int
+        L.la3dm_bgklv_scan_host.argtypes = [C.c_void_p, C.POINTER(LvScan), C.POINTER(BgkCounters)]
+        L.la3dm_bgklv_scan_device.restype = C.c_int
+        L.la3dm_bgklv_scan_device.argtypes = [C.c_void_p, C.POINTER(LvScan), C.c_void_p, C.POINTER(BgkCounters)]
         L.la3dm_kernel_times.restype = C.c_int
         L.la3dm_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.la3dm_diag_sweep.restype = C.c_int
@@ -110,6 +122,17 @@ def maplib():
         M.la3dm_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7 + [C.c_int]
         M.la3dm_map_create_gp.restype = C.c_void_p
         M.la3dm_map_create_gp.argtypes = [C.c_float, C.c_int] + [C.c_float] * 9 + [C.c_int]
+        M.la3dm_map_create_lv.restype = C.c_void_p
+        M.la3dm_map_create_lv.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7 + [C.c_int, C.c_float, C.c_int]
+        M.la3dm_map_lv_training.restype = C.c_uint64
+        M.la3dm_map_lv_training.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        M.la3dm_map_lv_stats.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.float64)]
+        M.la3dm_map_lv_prepare.restype = C.c_int
+        M.la3dm_map_lv_prepare.argtypes = [C.c_void_p, f32p, C.c_uint64, f32p, C.c_float, C.c_float, C.c_float]
+        M.la3dm_map_lv_packed.restype = C.c_int
+        M.la3dm_map_lv_packed.argtypes = [C.c_void_p, C.POINTER(LvScan)]
+        M.la3dm_map_lv_commit.restype = C.c_int
+        M.la3dm_map_lv_commit.argtypes = [C.c_void_p]
         M.la3dm_map_destroy.argtypes = [C.c_void_p]
         M.la3dm_map_last_error.restype = C.c_char_p
         M.la3dm_map_insert_pointcloud.restype = C.c_int

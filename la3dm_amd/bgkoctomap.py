@@ -106,8 +106,8 @@ class BGKOctoMap:
         m = self._M.la3dm_map_dump_leaves(self._h, *[out[k].ctypes.data for k in
                                                      ("block_key", "node_key", "loc", "size", "A", "B", "state",
                                                       "classified")], n)
-        assert m == n
-        return out
+        assert m <= n
+        return {k: v[:m] for k, v in out.items()} if m < n else out   # (an LV map only reports touched blocks)
 
     def block_count(self):
         return self._M.la3dm_map_block_count(self._h)
@@ -215,3 +215,49 @@ class GPOctoMap(BGKOctoMap):
         self.resolution = resolution
         self.block_depth = block_depth
         self.device = device
+
+
+LV_STATS = ["n_hits", "n_rays", "n_samples", "n_bbox_blocks", "n_packed_blocks", "n_info_blocks", "voxels",
+            "voxel_updates", "t_frontend", "t_partition", "t_device", "t_commit", "t_total"]
+
+
+class BGKLVOctoMap(BGKOctoMap):
+    """Python mirror of la3dm::BGKLVOctoMap (reference include/bgklvoctomap/bgklvoctomap.h): hits + free-space line
+    segments, per-voxel inference, variance-aware node (UNCERTAIN = 3, PRUNED = 4 in leaves()["state"])."""
+
+    def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, free_thresh=0.3, occupied_thresh=0.7,
+                 var_thresh=1.0, prior_A=1.0, prior_B=1.0, original_size=True, min_W=0.1, device=0):
+        self._M = _lib.maplib()
+        self._h = self._M.la3dm_map_create_lv(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+                                              prior_A, prior_B, int(original_size), min_W, device)
+        if not self._h:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        self.resolution = resolution
+        self.block_depth = block_depth
+        self.device = device
+
+    def lv_stats(self):
+        a = np.zeros(13, np.float64)
+        self._M.la3dm_map_lv_stats(self._h, a)
+        return dict(zip(LV_STATS, a.tolist()))
+
+    def lv_training(self):
+        nr = C.c_uint64()
+        n = self._M.la3dm_map_lv_training(self._h, None, 0, None, 0, C.byref(nr))
+        s, r = np.zeros((n, 4), np.float32), np.zeros((nr.value, 6), np.float32)
+        self._M.la3dm_map_lv_training(self._h, s.ctypes.data, n, r.ctypes.data, nr.value, C.byref(nr))
+        return s, r
+
+    def lv_prepare(self, cloud, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        xyz = np.ascontiguousarray(cloud, np.float32).reshape(-1, 3)
+        o = np.ascontiguousarray(origin, np.float32)
+        return bool(self._chk(self._M.la3dm_map_lv_prepare(self._h, xyz, xyz.shape[0], o, ds_resolution, free_res,
+                                                           max_range)))
+
+    def lv_packed(self):
+        s = _lib.LvScan()
+        self._chk(self._M.la3dm_map_lv_packed(self._h, C.byref(s)))
+        return s
+
+    def lv_commit(self):
+        self._chk(self._M.la3dm_map_lv_commit(self._h))

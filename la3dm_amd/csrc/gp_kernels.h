@@ -197,7 +197,8 @@ __device__ __forceinline__ void gp_node_update_dev(const GpArgs &a, float &m_iva
 constexpr int kGpLdsRows = 96;
 
 __global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
-    __shared__ float s_v[kGpLdsRows][kWave];
+    extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: sized per launch, LDS is the occupancy limiter
+    float (*s_v)[kWave] = reinterpret_cast<float (*)[kWave]>(s_vraw);
     const int lane = threadIdx.x;
     const uint32_t task = blockIdx.x;
     if (task >= a.n_tasks) return;

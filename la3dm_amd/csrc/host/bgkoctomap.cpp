@@ -44,7 +44,25 @@ float Occupancy::max_ivar = 1000.0f;
 float Occupancy::min_ivar = 0.001f;
 float Occupancy::min_known_ivar = 10.0f;
 
+float Occupancy::min_W = 0.1f;
+bool Occupancy::original_size = true;
+
+float Occupancy::get_var() const {
+    if (variant == 1) return 1.0f / m_B;
+    if (variant == 2) {  // bgklvoctree_node.cpp:49-63
+        const float prob = get_prob();
+        const float W = (m_A + m_B < min_W) ? min_W : m_A + m_B;
+        return (float)(m_A / W * pow(1 - prob, 2) + (W - m_A - m_B) / W * pow(0.5 - prob, 2) + m_B / W * pow(prob, 2));
+    }
+    return (m_A * m_B) / ((m_A + m_B) * (m_A + m_B) * (m_A + m_B + 1.0f));
+}
+
 float Occupancy::get_prob() const {
+    if (variant == 2) {  // bgklvoctree_node.cpp:29-47
+        const float W = (m_A + m_B < min_W) ? min_W : m_A + m_B;
+        if (m_A > m_B) return (float)(m_A / (W - m_B) + (W - m_A - m_B) * 0.5 / (W - m_B));
+        return (float)(0.5 * (W - m_B - m_A) / (W - m_A));
+    }
     if (variant == 1) return 1.0f / (1.0f + (float)exp((double)(-l * m_A / max_ivar)));  // gpoctree_node.cpp:31-34
     return m_A / (m_A + m_B);
 }
@@ -61,7 +79,7 @@ void Occupancy::classify() {
         return;
     }
     if (get_var() > var_thresh) {
-        state = State::UNKNOWN;
+        state = variant == 2 ? State::UNCERTAIN : State::UNKNOWN;
         return;
     }
     float p = get_prob();
@@ -278,7 +296,7 @@ GPOctoMap::GPOctoMap(float resolution_, unsigned short block_depth_, float sf2, 
     : BGKOctoMap(1, resolution_, block_depth_, sf2, ell, free_thresh, occupied_thresh, 0.0f, 0.0f, 0.0f,
                  [&] {
                      static thread_local GPParams g;
-                     g = GPParams{noise, l, min_var, max_var, max_known_var};
+                     g = GPParams{noise, l, min_var, max_var, max_known_var, 0.1f, true};
                      return &g;
                  }(),
                  device) {}
@@ -302,6 +320,10 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     OcTreeNode::variant = variant;
     OcTreeNode::init_A = prior_A;
     OcTreeNode::init_B = prior_B;
+    if (variant == 2) {  // src/bgklvoctomap/bgklvoctomap.cpp:60-61
+        OcTreeNode::min_W = gp->min_W;
+        OcTreeNode::original_size = gp->original_size;
+    }
     if (variant == 1) {  // src/gpoctomap/gpoctomap.cpp:37-44
         OcTreeNode::noise = gp->noise;
         OcTreeNode::l = gp->l;
@@ -320,6 +342,7 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     p.min_ivar = OcTreeNode::min_ivar;
     p.max_ivar = OcTreeNode::max_ivar;
     p.min_known_ivar = OcTreeNode::min_known_ivar;
+    p.min_W = OcTreeNode::min_W;
     p.resolution = resolution;
     p.block_depth = block_depth;
     p.sf2 = sf2;

@@ -62,7 +62,9 @@ typedef int OcTreeHashKey;     // (depth << 16) + index
 typedef int64_t BlockHashKey;  // 3 x 20-bit block indices
 typedef std::array<BlockHashKey, 7> ExtendedBlock;  // self,+x,-x,+y,-y,+z,-z
 
-enum class State : char { FREE, OCCUPIED, UNKNOWN, PRUNED };
+/// UNCERTAIN is used by the BGKLV variant only (reference bgklvoctree_node.h:11-13 numbers it 3 and PRUNED 4; the
+/// C view and the device use those codes for LV maps, this enum is symbolic).
+enum class State : char { FREE, OCCUPIED, UNKNOWN, PRUNED, UNCERTAIN };
 
 inline OcTreeHashKey node_to_hash_key(unsigned short depth, unsigned short index) { return (depth << 16) + index; }
 inline void hash_key_to_node(OcTreeHashKey key, unsigned short &depth, unsigned short &index) {
@@ -74,6 +76,7 @@ inline void hash_key_to_node(OcTreeHashKey key, unsigned short &depth, unsigned 
 /// (reference: include/bgkoctomap/bgkoctree_node.h:76-81).
 class Occupancy {
     friend class BGKOctoMap;
+    friend class BGKLVOctoMap;
     friend class OcTree;
     friend void ::la3dm_node_ab(const void *node, float *A, float *B);
 
@@ -95,12 +98,12 @@ public:
     void update(float ybar, float kbar);
 
     float get_prob() const;
-    float get_var() const {
-        return variant == 1 ? 1.0f / m_B : (m_A * m_B) / ((m_A + m_B) * (m_A + m_B) * (m_A + m_B + 1.0f));
-    }
+    float get_var() const;
     State get_state() const { return state; }
     void prune() { state = State::PRUNED; }
-    bool operator==(const Occupancy &rhs) const { return state != State::UNKNOWN && state == rhs.state; }
+    bool operator==(const Occupancy &rhs) const {
+        return state != State::UNKNOWN && state != State::UNCERTAIN && state == rhs.state;
+    }
 
     bool classified;
 
@@ -112,7 +115,9 @@ private:
 
     static float sf2, ell, prior_A, prior_B, free_thresh, occupied_thresh, var_thresh;
     // GPOctoMap statics (src/gpoctomap/gpoctree_node.cpp:7-17); for GP nodes m_A holds m_ivar, m_B holds ivar
-    static int variant;  // 0 BGK, 1 GP
+    static int variant;  // 0 BGK, 1 GP, 2 BGKLV
+    static float min_W;  // BGKLV (bgklvoctree_node.cpp:15)
+    static bool original_size;
     static float init_A, init_B, noise, l, max_ivar, min_ivar, min_known_ivar;
 };
 typedef Occupancy OcTreeNode;
@@ -122,6 +127,7 @@ static_assert(sizeof(Occupancy) == 16, "node layout must match the reference (16
 /// is node 8i+c of the next layer (c&4 -> +x, c&2 -> +y, c&1 -> +z).
 class OcTree {
     friend class BGKOctoMap;
+    friend class BGKLVOctoMap;
 
 public:
     OcTree();
@@ -184,6 +190,7 @@ std::vector<point3f> init_key_loc_map(float resolution, unsigned short max_depth
 
 class Block : public OcTree {
     friend class BGKOctoMap;
+    friend class BGKLVOctoMap;
     friend BlockHashKey block_to_hash_key(float x, float y, float z);
     friend point3f hash_key_to_block(BlockHashKey key);
     friend ExtendedBlock get_extended_block(BlockHashKey key);
@@ -228,18 +235,20 @@ public:
     typedef std::vector<GPPointType> GPPointCloud;
 
     BGKOctoMap();
+    virtual ~BGKOctoMap();
     /// Same argument order as the reference constructor (bgkoctomap.h:50-58); `device`
     /// is the HIP device ordinal (a negative ordinal builds a bookkeeping-only map without a
     /// GPU context — prepare()/packed()/commit() work, insert_* throw; used to test host logic).
     BGKOctoMap(float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh,
                float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device = 0);
-    ~BGKOctoMap();
     BGKOctoMap(const BGKOctoMap &) = delete;
     BGKOctoMap &operator=(const BGKOctoMap &) = delete;
 
 protected:
-    struct GPParams {
+    struct GPParams {  // variant-specific constructor arguments (GP: first five; BGKLV: last two)
         float noise, l, min_var, max_var, max_known_var;
+        float min_W;
+        bool original_size;
     };
     /// shared constructor: variant 0 = BGK (gp == nullptr), 1 = GP
     BGKOctoMap(int variant, float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh,
@@ -254,8 +263,8 @@ public:
     /// xyz, 4 for PCL's PointXYZ).  Mirrors insert_pointcloud(const PCLPointCloud&, ...)
     /// (bgkoctomap.h:82-84): ds_resolution < 0 disables the voxel-grid filter,
     /// max_range <= 0 disables the range gate. Empty training set => silent return.
-    void insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
-                           float free_res = 2.0f, float max_range = -1);
+    virtual void insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                                   float free_res = 2.0f, float max_range = -1);
     void insert_pointcloud(const PointCloud &cloud, const point3f &origin, float ds_resolution, float free_res = 2.0f,
                            float max_range = -1) {
         insert_pointcloud(cloud.empty() ? nullptr : &cloud[0].x(), cloud.size(), 3, origin, ds_resolution, free_res,
@@ -322,8 +331,9 @@ public:
     OcTreeNode search(float x, float y, float z) const { return search(point3f(x, y, z)); }
     Block *search(BlockHashKey key) const;
     size_t block_count() const { return block_arr.size(); }
+    int get_variant() const { return variant; }
 
-private:
+protected:
     void get_training_data(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                            float free_resolution, float max_range);
     bool partition_and_pack(bool ungated);
@@ -357,6 +367,49 @@ private:
     uint32_t train_max_n;
     uint64_t train_sum_n2;
     int run_scan(la3dm_bgk_scan *s, la3dm_bgk_counters *c);
+};
+
+/// BGKLVOctoMap: variance-aware BGK with free-space line segments and per-voxel inference
+/// (reference include/bgklvoctomap/bgklvoctomap.h; constructor order src/bgklvoctomap/bgklvoctomap.cpp:33-43).
+/// Every block of the scan's bounding box is allocated, every base-resolution leaf is inferred on the GPU.
+class BGKLVOctoMap : public BGKOctoMap {
+public:
+    BGKLVOctoMap() : BGKLVOctoMap(0.1f, 4, 1.0, 1.0, 0.3f, 0.7f, 1.0f, 1.0f, 1.0f, true, 0.1f) {}
+    BGKLVOctoMap(float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh, float occupied_thresh,
+                 float var_thresh, float prior_A, float prior_B, bool original_size, float min_W, int device = 0);
+    void insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                           float free_res = 2.0f, float max_range = -1) override;
+    using BGKOctoMap::insert_pointcloud;
+
+    struct LVStats {
+        uint64_t n_hits = 0, n_rays = 0, n_samples = 0, n_bbox_blocks = 0, n_packed_blocks = 0, n_info_blocks = 0,
+                 voxels = 0, voxel_updates = 0;
+        double t_frontend = 0, t_partition = 0, t_device = 0, t_commit = 0, t_total = 0;
+    };
+    const LVStats &lv_stats() const { return lvst; }
+    /// training samples (x, y, z, ray index or -1) and segments (6 floats) of the last scan
+    const std::vector<float> &lv_samples() const { return samples; }
+    const std::vector<float> &lv_rays() const { return rays6; }
+    /// split form used by the benchmark: prepare_lv packs (returns false if nothing to do), packed_lv exposes the
+    /// device-call arguments (host pointers), commit_lv writes the nodes and prunes
+    bool prepare_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution, float free_res,
+                    float max_range);
+    la3dm_lv_scan packed_lv();
+    void commit_lv();
+
+private:
+    void training_data_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                          float free_resolution, float max_range);
+    std::vector<float> samples;   // x, y, z, ray
+    std::vector<float> sorted;    // x, y, z, original index bits
+    std::vector<float> rays8, rays6;
+    std::vector<uint32_t> cell_off;
+    int32_t cell_min[3], cell_dim[3];
+    std::vector<float> lv_center, lv_alpha, lv_beta;
+    std::vector<int32_t> lv_cell0;
+    std::vector<uint8_t> lv_state;
+    std::vector<Block *> lv_blocks;
+    LVStats lvst;
 };
 
 /// GPOctoMap: same skeleton, GP regression per block + BCM fusion (reference include/gpoctomap/gpoctomap.h).

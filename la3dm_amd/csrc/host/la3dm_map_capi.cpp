@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,57 @@ la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, flo
         g_err = e.what();
         return nullptr;
     }
+}
+
+la3dm_map *la3dm_map_create_lv(float resolution, int block_depth, float sf2, float ell, float free_thresh,
+                               float occupied_thresh, float var_thresh, float prior_A, float prior_B, int original_size,
+                               float min_W, int device) {
+    try {
+        la3dm_map *m = new la3dm_map;
+        m->map = new la3dm::BGKLVOctoMap(resolution, (unsigned short)block_depth, sf2, ell, free_thresh, occupied_thresh,
+                                         var_thresh, prior_A, prior_B, original_size != 0, min_W, device);
+        return m;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+static la3dm::BGKLVOctoMap *as_lv(const la3dm_map *m) { return dynamic_cast<la3dm::BGKLVOctoMap *>(m->map); }
+
+uint64_t la3dm_map_lv_training(const la3dm_map *m, float *samples4, uint64_t cap_samples, float *rays6, uint64_t cap_rays,
+                               uint64_t *n_rays) {
+    la3dm::BGKLVOctoMap *lv = as_lv(m);
+    if (!lv) return 0;
+    const std::vector<float> &s = lv->lv_samples(), &r = lv->lv_rays();
+    if (samples4) std::memcpy(samples4, s.data(), sizeof(float) * std::min<size_t>(s.size(), 4 * cap_samples));
+    if (rays6) std::memcpy(rays6, r.data(), sizeof(float) * std::min<size_t>(r.size(), 6 * cap_rays));
+    if (n_rays) *n_rays = r.size() / 6;
+    return s.size() / 4;
+}
+
+int la3dm_map_lv_stats(const la3dm_map *m, double *o) {
+    la3dm::BGKLVOctoMap *lv = as_lv(m);
+    if (!lv) return -1;
+    const la3dm::BGKLVOctoMap::LVStats &s = lv->lv_stats();
+    const double v[13] = {(double)s.n_hits, (double)s.n_rays, (double)s.n_samples, (double)s.n_bbox_blocks,
+                          (double)s.n_packed_blocks, (double)s.n_info_blocks, (double)s.voxels, (double)s.voxel_updates,
+                          s.t_frontend, s.t_partition, s.t_device, s.t_commit, s.t_total};
+    std::memcpy(o, v, sizeof(v));
+    return 0;
+}
+
+int la3dm_map_lv_prepare(la3dm_map *m, const float *xyz, uint64_t n, const float *o, float ds, float free_res,
+                         float max_range) {
+    GUARD(la3dm::BGKLVOctoMap *lv = as_lv(m); if (!lv) throw std::runtime_error("not an LV map");
+          return lv->prepare_lv(xyz, (size_t)n, 3, point3f(o[0], o[1], o[2]), ds, free_res, max_range) ? 1 : 0;)
+}
+int la3dm_map_lv_packed(la3dm_map *m, la3dm_lv_scan *out) {
+    GUARD(la3dm::BGKLVOctoMap *lv = as_lv(m); if (!lv) throw std::runtime_error("not an LV map"); *out = lv->packed_lv();
+          return 0;)
+}
+int la3dm_map_lv_commit(la3dm_map *m) {
+    GUARD(la3dm::BGKLVOctoMap *lv = as_lv(m); if (!lv) throw std::runtime_error("not an LV map"); lv->commit_lv(); return 0;)
 }
 
 void la3dm_map_destroy(la3dm_map *m) {
@@ -152,11 +204,31 @@ uint64_t la3dm_map_dump_leaves(const la3dm_map *m, int64_t *block_key, int32_t *
         r.cl = nd.classified ? 1 : 0;
         rows.push_back(r);
     }
+    const bool lv = m->map->get_variant() == 2;
+    if (lv) {  // reference LV codes / key layout; keep only blocks with a classified or collapsed leaf
+        const int finest = (int)m->map->get_block_depth() - 1;
+        std::vector<Row> kept;
+        size_t i = 0;
+        while (i < rows.size()) {
+            size_t j = i;
+            bool touched = false;
+            for (; j < rows.size() && rows[j].bk == rows[i].bk; ++j) touched |= rows[j].cl != 0 || (rows[j].nk >> 16) < finest;
+            if (touched)
+                for (size_t k = i; k < j; ++k) {
+                    Row r = rows[k];
+                    r.st = r.st == 4 ? 3 : (r.st == 3 ? 4 : r.st);               // UNCERTAIN 3, PRUNED 4
+                    kept.push_back(r);
+                }
+            i = j;
+        }
+        rows.swap(kept);
+    }
     std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.bk < b.bk; });
     uint64_t n = std::min<uint64_t>(rows.size(), cap);
     for (uint64_t i = 0; i < n; ++i) {
         const Row &r = rows[i];
-        block_key[i] = r.bk; node_key[i] = r.nk;
+        block_key[i] = r.bk;
+        node_key[i] = lv ? (int32_t)(((uint32_t)(r.nk >> 16) << 28) + (uint32_t)(r.nk & 0xFFFF)) : r.nk;
         loc[3 * i] = r.loc[0]; loc[3 * i + 1] = r.loc[1]; loc[3 * i + 2] = r.loc[2];
         size[i] = r.size; state[i] = r.st; classified[i] = r.cl;
         const la3dm::OcTreeNode &nd = (*m->map->search((la3dm::BlockHashKey)r.bk))[r.nk];

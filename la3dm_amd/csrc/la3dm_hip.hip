@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -12,6 +13,7 @@
 
 #include "bgk_kernels.h"
 #include "gp_kernels.h"
+#include "lv_kernels.h"
 
 using namespace la3dm_dev;
 
@@ -40,6 +42,7 @@ struct la3dm_ctx {
     // scratch (device-pointer path)
     Arena pts_scaled, nbr_range;
     Arena gp_loff, gp_totals, gp_L, gp_alpha, gp_v;
+    Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;
     // staging (host-pointer path)
     Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,
         h_diag_out;
@@ -137,7 +140,8 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
 void la3dm_destroy(la3dm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
+    Arena *all[] = {&ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
+                    &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
@@ -465,7 +469,10 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
         ev = &ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(ctx, hipEventRecord(ev->first, stream));
     }
-    hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), 0, stream, a);
+    {
+        const uint32_t rows = max_n < (uint32_t)kGpLdsRows ? (max_n ? max_n : 1u) : (uint32_t)kGpLdsRows;
+        hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), rows * kWave * sizeof(float), stream, a);
+    }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
     HIP_TRY(ctx, hipGetLastError());
     if (out) {
@@ -477,6 +484,128 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
 
 int la3dm_gp_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out) {
     return scan_host_common(ctx, s, out, la3dm_gp_scan_device);
+}
+
+int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream_, la3dm_bgk_counters *out) {
+    if (!ctx) return LA3DM_ERR_ARG;
+    if (!s) {
+        ctx->err = "lv scan: null";
+        return LA3DM_ERR_ARG;
+    }
+    if (out) memset(out, 0, sizeof(*out));
+    if (s->n_blk == 0) return LA3DM_OK;
+    if (ctx->p.variant != 2) {
+        ctx->err = "la3dm_bgklv_scan: the context was not created with variant = 2 (BGKLVOctoMap)";
+        return LA3DM_ERR_ARG;
+    }
+    if (!s->sorted || !s->samples || !s->cell_off || !s->blk_center || !s->blk_cell0 || !s->alpha || !s->beta ||
+        !s->state || (s->n_rays && !s->rays)) {
+        ctx->err = "lv scan: null array pointer";
+        return LA3DM_ERR_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int d = ctx->p.block_depth;
+    LvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.samples = (const float4 *)s->samples;
+    a.sorted = (const float4 *)s->sorted;
+    a.rays = (const float4 *)s->rays;
+    a.cell_off = s->cell_off;
+    a.blk_center = s->blk_center;
+    a.blk_cell0 = s->blk_cell0;
+    a.alpha = s->alpha;
+    a.beta = s->beta;
+    a.state = s->state;
+    a.lut = ctx->d_lut;
+    for (int i = 0; i < 3; ++i) {
+        a.cell_min[i] = s->cell_min[i];
+        a.cell_dim[i] = s->cell_dim[i];
+    }
+    a.lut_base = 0;
+    for (int k = 0; k + 1 < d; ++k) a.lut_base += 1u << (3 * k);
+    a.nodes_per_blk = 1u << (3 * (d - 1));
+    const uint32_t cubes = (a.nodes_per_blk + kWave - 1) / kWave;  // 8^(d-3) for d >= 3, else 1
+    a.cubes_shift = 0;
+    while ((1u << a.cubes_shift) < cubes) ++a.cubes_shift;
+    a.cubes_bits = a.cubes_shift / 3;
+    a.n_tasks = s->n_blk << a.cubes_shift;
+    const double g = d >= 3 ? 4.0 * (double)ctx->p.resolution : (double)((float)pow(2, d - 1) * ctx->p.resolution);
+    a.reach = (int)ceil((double)ctx->p.ell / g);
+    a.sf2 = ctx->p.sf2;
+    a.ell = ctx->p.ell;
+    a.free_thresh = ctx->p.free_thresh;
+    a.occupied_thresh = ctx->p.occupied_thresh;
+    a.var_thresh = ctx->p.var_thresh;
+    a.min_W = ctx->p.min_W;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (ctx->opt_time_kernel) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> p;
+            HIP_TRY(ctx, hipEventCreate(&p.first));
+            HIP_TRY(ctx, hipEventCreate(&p.second));
+            ctx->ev_pool.push_back(p);
+        }
+        ev = &ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
+    }
+    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(a.n_tasks), dim3(kWave), 0, stream, a);
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    if (out) out->n_tiles = a.n_tasks;
+    return LA3DM_OK;
+}
+
+int la3dm_bgklv_scan_host(la3dm_ctx *ctx, const la3dm_lv_scan *s, la3dm_bgk_counters *out) {
+    if (!ctx) return LA3DM_ERR_ARG;
+    if (!s) {
+        ctx->err = "lv scan: null";
+        return LA3DM_ERR_ARG;
+    }
+    if (out) memset(out, 0, sizeof(*out));
+    if (s->n_blk == 0) return LA3DM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t ncell = (size_t)s->cell_dim[0] * s->cell_dim[1] * s->cell_dim[2];
+    const size_t nnode = (size_t)s->n_blk << (3 * (ctx->p.block_depth - 1));
+    struct Up {
+        Arena *a;
+        const void *src;
+        size_t bytes;
+    } ups[] = {
+        {&ctx->lv_samples, s->samples, sizeof(float) * 4 * (size_t)s->n_samples},
+        {&ctx->lv_sorted, s->sorted, sizeof(float) * 4 * (size_t)s->n_samples},
+        {&ctx->lv_rays, s->rays, sizeof(float) * 8 * (size_t)s->n_rays},
+        {&ctx->lv_cell, s->cell_off, sizeof(uint32_t) * (ncell + 1)},
+        {&ctx->lv_center, s->blk_center, sizeof(float) * 3 * (size_t)s->n_blk},
+        {&ctx->lv_cell0, s->blk_cell0, sizeof(int32_t) * 3 * (size_t)s->n_blk},
+        {&ctx->lv_alpha, s->alpha, sizeof(float) * nnode},
+        {&ctx->lv_beta, s->beta, sizeof(float) * nnode},
+        {&ctx->lv_state, s->state, nnode},
+    };
+    int rc;
+    for (auto &u : ups) {
+        rc = arena_reserve(ctx, *u.a, u.bytes ? u.bytes : 16);
+        if (rc != LA3DM_OK) return rc;
+        if (u.bytes) HIP_TRY(ctx, hipMemcpyAsync(u.a->ptr, u.src, u.bytes, hipMemcpyHostToDevice, st));
+    }
+    la3dm_lv_scan d = *s;
+    d.samples = (const float *)ctx->lv_samples.ptr;
+    d.sorted = (const float *)ctx->lv_sorted.ptr;
+    d.rays = (const float *)ctx->lv_rays.ptr;
+    d.cell_off = (const uint32_t *)ctx->lv_cell.ptr;
+    d.blk_center = (const float *)ctx->lv_center.ptr;
+    d.blk_cell0 = (const int32_t *)ctx->lv_cell0.ptr;
+    d.alpha = (float *)ctx->lv_alpha.ptr;
+    d.beta = (float *)ctx->lv_beta.ptr;
+    d.state = (uint8_t *)ctx->lv_state.ptr;
+    rc = la3dm_bgklv_scan_device(ctx, &d, st, out);
+    if (rc != LA3DM_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s->alpha, d.alpha, sizeof(float) * nnode, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(s->beta, d.beta, sizeof(float) * nnode, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(s->state, d.state, nnode, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return LA3DM_OK;
 }
 
 int la3dm_kernel_times(la3dm_ctx *ctx, float *ms, uint32_t cap, uint32_t *n_out) {

@@ -27,8 +27,8 @@ def build(force=False):
     """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
     need = force or not (os.path.exists(os.path.join(_HERE, "liboracle.so"))
                          and os.path.exists(os.path.join(_HERE, "liboracle_omp.so")))
-    if need or os.path.getmtime(os.path.join(_HERE, "la3dm_oracle.cpp")) > os.path.getmtime(
-            os.path.join(_HERE, "liboracle.so")):
+    if need or max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("la3dm_oracle.cpp", "la3dm_oracle_lv.cpp")) > \
+            os.path.getmtime(os.path.join(_HERE, "liboracle.so")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so", "liboracle_omp.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(
             os.path.join(_HERE, "_ref", "libla3dm_ref.so"))):
@@ -46,6 +46,29 @@ def _load(name):
                                        C.c_float, C.c_float]
     lib.orc_gp_node_prob.restype = C.c_float
     lib.orc_gp_node_prob.argtypes = [C.c_void_p, C.c_float]
+    lib.orc_lv_map_create.restype = C.c_void_p
+    lib.orc_lv_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7 + [C.c_int, C.c_float]
+    lib.orc_lv_map_destroy.argtypes = [C.c_void_p]
+    lib.orc_lv_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float]
+    lib.orc_lv_stats.argtypes = [C.c_void_p, f64p]
+    lib.orc_lv_training_data.restype = C.c_int64
+    lib.orc_lv_training_data.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.orc_lv_seg_dist.restype = C.c_float
+    lib.orc_lv_seg_dist.argtypes = [f32p, f32p, f32p]
+    lib.orc_lv_kernel.restype = C.c_float
+    lib.orc_lv_kernel.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.orc_lv_node_update.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                       C.c_float, C.c_float]
+    lib.orc_lv_node_prob.restype = C.c_float
+    lib.orc_lv_node_prob.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    lib.orc_lv_node_var.restype = C.c_float
+    lib.orc_lv_node_var.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    lib.orc_lv_block_count.restype = C.c_int64
+    lib.orc_lv_block_count.argtypes = [C.c_void_p]
+    lib.orc_lv_dump_leaves.restype = C.c_int64
+    lib.orc_lv_dump_leaves.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.orc_map_destroy.argtypes = [C.c_void_p]
     lib.orc_block_size.restype = C.c_float
     lib.orc_block_size.argtypes = [C.c_void_p]
@@ -212,6 +235,57 @@ class OracleGPMap(OracleMap):
         mu, var = np.zeros(m, np.float32), np.zeros(m, np.float32)
         self.L.orc_gp_train_predict(self.h, x, y, n, xs, m, alpha, Lm, mu, var)
         return alpha, Lm, mu, var
+
+
+LV_YAML = dict(resolution=0.1, block_depth=5, sf2=0.1, ell=0.2, free_thresh=0.3, occupied_thresh=0.7, var_thresh=0.2,
+               prior_A=0.001, prior_B=0.001, original_size=True, min_W=0.001)   # config/methods/bgklvoctomap.yaml
+LV_STATS = ["n_hits", "n_rays", "n_samples", "n_bbox_blocks", "n_info_blocks", "voxels_visited", "voxel_updates", "rows",
+            "t_frontend", "t_infer", "t_total"]
+
+
+class OracleLVMap:
+    """CPU BGKLVOctoMap restatement (constructor argument order of include/bgklvoctomap/bgklvoctomap.h)."""
+
+    def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, free_thresh=0.3, occupied_thresh=0.7,
+                 var_thresh=1.0, prior_A=1.0, prior_B=1.0, original_size=True, min_W=0.1):
+        self.L = lib()
+        self.h = self.L.orc_lv_map_create(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+                                          prior_A, prior_B, int(original_size), min_W)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_lv_map_destroy(self.h)
+            self.h = None
+
+    def insert_pointcloud(self, xyz, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        origin = np.ascontiguousarray(origin, np.float32)
+        self.L.orc_lv_insert_pointcloud(self.h, xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range)
+
+    def stats(self):
+        a = np.zeros(len(LV_STATS), np.float64)
+        self.L.orc_lv_stats(self.h, a)
+        return dict(zip(LV_STATS, a.tolist()))
+
+    def training_data(self, xyz, origin, ds_resolution, free_res, max_range):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        origin = np.ascontiguousarray(origin, np.float32)
+        nr = C.c_int64()
+        n = self.L.orc_lv_training_data(self.h, xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range, None, 0,
+                                        None, 0, C.byref(nr))
+        xy, rays = np.zeros((n, 4), np.float32), np.zeros((nr.value, 6), np.float32)
+        self.L.orc_lv_training_data(self.h, xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range,
+                                    xy.ctypes.data, n, rays.ctypes.data, nr.value, C.byref(nr))
+        return xy, rays
+
+    def leaves(self, all_blocks=False):
+        n = self.L.orc_lv_dump_leaves(self.h, int(all_blocks), None, None, None, None, None, None, None, None, 0)
+        out = dict(block_key=np.zeros(n, np.int64), node_key=np.zeros(n, np.int64), loc=np.zeros((n, 3), np.float32),
+                   size=np.zeros(n, np.float32), A=np.zeros(n, np.float32), B=np.zeros(n, np.float32),
+                   state=np.zeros(n, np.uint8), classified=np.zeros(n, np.uint8))
+        self.L.orc_lv_dump_leaves(self.h, int(all_blocks), *[out[k].ctypes.data for k in
+                                  ("block_key", "node_key", "loc", "size", "A", "B", "state", "classified")], n)
+        return out
 
 
 def get_training_data(xyz, origin, ds_resolution, free_res, max_range):

@@ -1,0 +1,72 @@
+"""GPU parity tests for BGKLVOctoMap (BASELINE config 4): HIP path vs the CPU oracle.
+
+The device sums each voxel's rows in the oracle's gather order and uses the same mixed float/double
+arithmetic, so alpha/beta/state are expected bit-identical; the written tolerance is |dp| <= 1e-5 on
+the LV occupancy probability."""
+import numpy as np
+import pytest
+
+from conftest import pcd_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _lv_prob(A, B, min_W):
+    A, B = A.astype(np.float64), B.astype(np.float64)
+    W = np.maximum(A + B, min_W)
+    return np.where(A > B, A / (W - B) + (W - A - B) * 0.5 / (W - B), 0.5 * (W - B - A) / (W - A))
+
+
+def _compare(m, o, params, tag):
+    a, b = m.leaves(), o.leaves()
+    assert a["A"].size == b["A"].size, tag
+    for k in ("block_key", "node_key", "loc", "size", "classified"):
+        assert (a[k] == b[k]).all(), (tag, k)
+    np.testing.assert_allclose(a["A"], b["A"], rtol=1e-5, atol=1e-7, err_msg=tag)
+    np.testing.assert_allclose(a["B"], b["B"], rtol=1e-5, atol=1e-7, err_msg=tag)
+    assert np.abs(_lv_prob(a["A"], a["B"], params["min_W"]) - _lv_prob(b["A"], b["B"], params["min_W"])).max() <= 1e-5, tag
+    assert (a["state"] == b["state"]).mean() >= 0.9999, tag
+    return float((a["A"] == b["A"]).mean()), float((a["B"] == b["B"]).mean())
+
+
+@pytest.mark.parametrize("res,depth,nscan", [(0.1, 4, 4), (0.05, 5, 3), (0.1, 3, 2)])
+def test_lv_sim_unstructured(built, res, depth, nscan):
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.LV_YAML, resolution=res, block_depth=depth)
+    m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+    o = O.OracleLVMap(**params)
+    for i in range(1, nscan + 1):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+        m.insert_pointcloud(xyz, origin, res, 0.1, 8.0)
+        o.insert_pointcloud(xyz, origin, res, 0.1, 8.0)
+        s, r = m.lv_training()
+        s2, r2 = o.training_data(xyz, origin, res, 0.1, 8.0)
+        assert (s == s2).all() and (r == r2).all()          # front end: samples and segments bit-identical
+        ea, eb = _compare(m, o, params, f"res{res} d{depth} scan{i}")
+    assert ea == 1.0 and eb == 1.0
+    lv = m.leaves()
+    assert (lv["state"] == 3).any()                           # UNCERTAIN voxels exist
+    assert ((lv["node_key"] >> 28) < depth - 1).any()         # pruning collapsed some groups
+
+
+def test_lv_edge_cases(built):
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.LV_YAML, resolution=0.1, block_depth=4)
+    m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+    o = O.OracleLVMap(**params)
+    m.insert_pointcloud(np.zeros((0, 3), np.float32), [0, 0, 0], 0.1, 0.1, 8.0)      # empty: no-op
+    assert m.leaves()["A"].size == 0
+    # max_range <= 0: the reference adds no hit samples, only rays (bgklvoctomap.cpp:322-334)
+    pts = np.array([[2.0, 0.3, 0.4], [1.5, -1.0, 0.2], [0.2, 2.5, 1.0]], np.float32)
+    m.insert_pointcloud(pts, [0, 0, 0.5], -1.0, 0.1, -1.0)
+    o.insert_pointcloud(pts, [0, 0, 0.5], -1.0, 0.1, -1.0)
+    s, _ = m.lv_training()
+    assert (s[:, 3] >= 0).all()
+    _compare(m, o, params, "norange")
+    # a far point beyond max_range still casts a (clipped) ray
+    pts = np.array([[30.0, 0.0, 1.0], [1.0, 1.0, 1.0]], np.float32)
+    m.insert_pointcloud(pts, [0, 0, 1.0], 0.1, 0.1, 8.0)
+    o.insert_pointcloud(pts, [0, 0, 1.0], 0.1, 0.1, 8.0)
+    _compare(m, o, params, "clipped")
