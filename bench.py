@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (kernel variant 3); 0 = library default")
     ap.add_argument("--remap", type=int, default=-1, help="workgroup->tile remap mode; -1 = library default")
+    ap.add_argument("--workload", choices=["bgk", "gp", "lv"], default="bgk",
+                    help="bgk = BASELINE configs[1] (default, the contract line); gp = configs[2] (GPOctoMap, 50k rays); "
+                         "lv = configs[3] (BGKLV, sim_unstructured scan, 0.05 m) — single-GPU side benches")
     ap.add_argument("--mode", choices=["scans", "shard"], default="scans",
                     help="N>1 only. scans (default, weak scaling): one scan per GPU; shard (strong scaling, config-5 "
                          "style): ONE scan, its test blocks dealt round-robin to the ranks (la3dm_amd/sharding.py)")
@@ -54,6 +57,9 @@ def main():
     import torch
     import la3dm_amd
     from la3dm_amd import _lib
+
+    if args.workload != "bgk":
+        return side_bench(args, torch, la3dm_amd, _lib)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,6 +249,108 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def side_bench(args, torch, la3dm_amd, _lib):
+    """configs[2] (GP) and configs[3] (LV) on one GPU: same timing protocol, inputs resident in HBM."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    H = _lib.hip()
+    stream = torch.cuda.current_stream().cuda_stream
+    keep = []
+
+    def up(ptr, nbytes):
+        if not ptr or nbytes == 0:
+            return 0
+        buf = (C.c_char * nbytes).from_address(ptr)
+        t = torch.frombuffer(buf, dtype=torch.uint8).to(dev)
+        keep.append(t)
+        return t.data_ptr()
+
+    if args.workload == "gp":
+        rays = 50000 if args.rays == 200000 else args.rays
+        params = dict(la3dm_amd.GP_YAML, block_depth=args.depth, resolution=args.resolution)
+        xyz, origin = la3dm_amd.synthetic_scan(rays)
+        m = la3dm_amd.GPOctoMap(**params, device=0)
+        assert m.prepare(xyz, origin, args.resolution, 0.1, -1.0)
+        st, pk = m.stats(), m.packed()
+        c = pk.c
+        scan = _lib.BgkScan()
+        for f, n in (("train_xyzy", 16 * c.n_train_pts), ("train_off", 4 * (c.n_train_blk + 1)), ("nbr", 28 * c.n_test_blk),
+                     ("blk_center", 12 * c.n_test_blk), ("leaf_off", 4 * (c.n_test_blk + 1)), ("leaf_key", 4 * c.n_leaf),
+                     ("alpha", 4 * c.n_leaf), ("beta", 4 * c.n_leaf), ("state", c.n_leaf)):
+            setattr(scan, f, up(getattr(c, f), n))
+        for f in ("n_train_pts", "n_train_blk", "n_test_blk", "n_leaf", "flags", "train_max_n", "train_sum_n2"):
+            setattr(scan, f, getattr(c, f))
+        nb = np.diff(pk.train_off.astype(np.int64))
+        flops = 0
+        for t in range(pk.n_test_blk):
+            L = int(pk.leaf_off[t + 1] - pk.leaf_off[t])
+            for q in pk.nbr[t]:
+                if q >= 0:
+                    flops += L * (int(nb[q]) ** 2 + 4 * int(nb[q]))
+        units, unit_name = int(st["voxel_updates"]), "voxel-updates/s"
+        call = lambda: H.la3dm_gp_scan_device(m.ctx(), C.byref(scan), stream, None)
+        kernel, bound, peak, peak_unit, work = "gp_predict_fuse_kernel", "mfma", 157.3, "TFLOP/s", flops / 1e12
+        workload = f"GPOctoMap synthetic {rays}-ray scan, {args.resolution} m, block_depth {args.depth}, gpoctomap.yaml (configs[2])"
+        extra = {"max_N": int(c.train_max_n), "train_blocks": int(c.n_train_blk), "test_blocks": int(c.n_test_blk),
+                 "flops_per_step": flops, "steps_include": "gp_train (Cholesky per training block) + gp_predict_fuse"}
+    else:
+        res = 0.05 if args.resolution == 0.1 else args.resolution
+        depth = 5 if args.depth == 3 else args.depth
+        params = dict(la3dm_amd.LV_YAML, resolution=res, block_depth=depth)
+        xyz, origin = la3dm_amd.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "sim_unstructured",
+                                                      "sim_unstructured_1.pcd"))
+        m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+        assert m.lv_prepare(xyz, origin, res, 0.1, 8.0)
+        c = m.lv_packed()
+        st = m.lv_stats()
+        ncell = c.cell_dim[0] * c.cell_dim[1] * c.cell_dim[2]
+        nnode = c.n_blk << (3 * (depth - 1))
+        scan = _lib.LvScan()
+        for f, n in (("samples", 16 * c.n_samples), ("sorted", 16 * c.n_samples), ("rays", 32 * c.n_rays),
+                     ("cell_off", 4 * (ncell + 1)), ("blk_center", 12 * c.n_blk), ("blk_cell0", 12 * c.n_blk),
+                     ("alpha", 4 * nnode), ("beta", 4 * nnode)):
+            setattr(scan, f, up(getattr(c, f), n))
+        state0 = torch.frombuffer((C.c_char * nnode).from_address(c.state), dtype=torch.uint8).to(dev)
+        state = state0.clone()
+        keep.extend([state0, state])
+        scan.state = state.data_ptr()
+        for f in ("n_samples", "n_rays", "n_blk"):
+            setattr(scan, f, getattr(c, f))
+        for i in range(3):
+            scan.cell_min[i], scan.cell_dim[i] = c.cell_min[i], c.cell_dim[i]
+        units, unit_name = int(st["voxels"]), "voxels/s"
+
+        def call():
+            state.copy_(state0)          # the state array is in/out: restore the node states (untimed-size copy, 0.5 MB)
+            return H.la3dm_bgklv_scan_device(m.ctx(), C.byref(scan), stream, None)
+        kernel, bound, peak, peak_unit = "bgklv_voxel_kernel", "hbm", 8000.0, "GB/s"
+        work = (16 * int(c.n_samples) + 9 * nnode) / 1e9     # samples read once + (alpha, beta, state) per voxel
+        workload = f"BGKLVOctoMap sim_unstructured scan 1, {res} m, block_depth {depth}, bgklvoctomap.yaml (configs[3])"
+        extra = {"samples": int(c.n_samples), "rays": int(c.n_rays), "packed_blocks": int(c.n_blk)}
+
+    for _ in range(args.warmup):
+        assert call() == 0, H.la3dm_last_error(m.ctx())
+    m.set_option("time_kernel", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert call() == 0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    kt = np.zeros(args.steps + 8, np.float32)
+    nk = C.c_uint32()
+    H.la3dm_kernel_times(m.ctx(), kt.ctypes.data, kt.size, C.byref(nk))
+    k_ms = float(kt[:nk.value].mean())
+    achieved = work / (k_ms * 1e-3)
+    print(json.dumps({
+        "metric": "voxel-updates/sec per scan; side bench", "value": units / dt, "unit": unit_name, "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.workload == "gp" else "sim_unstructured_1.pcd",
+        "config": dict({"workload": workload}, **extra),
+        "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": peak_unit, "frac": achieved / peak,
+                     "traffic": None, "kernel": kernel, "kernel_ms": k_ms}}))
 
 
 def cpu_baseline(params, xyz, origin, args, U, omp=False):

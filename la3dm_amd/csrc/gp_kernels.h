@@ -41,6 +41,8 @@ struct GpArgs {
     float sf2, noise, l, min_ivar, max_ivar, min_known_ivar, free_thresh, occupied_thresh;
 };
 
+constexpr int kGpTrainLdsMaxN = 128;  // blocks up to this size are factored by one wave in LDS
+
 __device__ __forceinline__ float cr_expf_dev(float x) { return (float)exp((double)x); }
 
 __device__ __forceinline__ float matern3_dev(float ax, float ay, float az, float bx, float by, float bz, float sf2) {
@@ -48,6 +50,8 @@ __device__ __forceinline__ float matern3_dev(float ax, float ay, float az, float
     const float d = sqrtf(dx * dx + (dy * dy + dz * dz));
     return ((1 + d) * cr_expf_dev(-d)) * sf2;
 }
+
+__device__ __forceinline__ float matern3_fast(float ax, float ay, float az, float bx, float by, float bz, float sf2);
 
 // scale the training points (x * s, gpregressor.h:115) and resolve neighbour ranges
 __global__ void gp_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float s,
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void gp_train_kernel(GpArgs a) {
     const uint32_t b = blockIdx.x;
     const uint32_t p0 = a.train_off[b];
     const int N = (int)(a.train_off[b + 1] - p0);
-    if (N == 0) return;
+    if (N == 0 || N <= kGpTrainLdsMaxN) return;  // small blocks: gp_train_wave_kernel
     float *L = a.Lmat + a.l_off[b];
     const float4 *x = a.pts + p0;
     const int tid = threadIdx.x;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void gp_train_kernel(GpArgs a) {
         const int i = e / N, j = e - i * N;
         if (j > i) continue;
         const float4 xi = x[i], xj = x[j];
-        float k = matern3_dev(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);  // dist(x, z)(i, j) = |z_j - x_i|
+        float k = matern3_fast(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);  // dist(x, z)(i, j) = |z_j - x_i|
         if (i == j) k = k + a.noise;
         L[(size_t)i * N + j] = k;
     }
@@ -177,6 +181,74 @@ __global__ __launch_bounds__(256) void gp_train_kernel(GpArgs a) {
     }
 }
 
+// Same arithmetic as gp_train_kernel for blocks with N <= 128: one wave64 per training block, the lower
+// triangle packed in LDS (row i at i(i+1)/2), lane = row (two rows per lane above 64), no workgroup barriers.
+// The factor is written to its global slot once, for the predict kernel.
+__global__ __launch_bounds__(kWave) void gp_train_wave_kernel(GpArgs a) {
+    extern __shared__ float s_l[];  // [N(N+1)/2 + N]
+    const uint32_t b = blockIdx.x;
+    const uint32_t p0 = a.train_off[b];
+    const int N = (int)(a.train_off[b + 1] - p0);
+    if (N == 0 || N > kGpTrainLdsMaxN) return;  // large blocks: gp_train_kernel
+    const int lane = threadIdx.x;
+    const float4 *x = a.pts + p0;
+    float *Lg = a.Lmat + a.l_off[b];
+    float *zs = s_l + (N * (N + 1)) / 2;  // right-hand side / solution
+    auto tri = [](int i, int j) { return (i * (i + 1)) / 2 + j; };
+    // K(i, j), i >= j, + noise on the diagonal
+    for (int i = lane; i < N; i += kWave) {
+        const float4 xi = x[i];
+        for (int j = 0; j <= i; ++j) {
+            const float4 xj = x[j];
+            float kv = matern3_fast(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);
+            if (i == j) kv = kv + a.noise;
+            s_l[tri(i, j)] = kv;
+        }
+        zs[i] = xi.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < N; ++j) {
+        // diagonal (every lane computes the same chain; wave-uniform result)
+        float dacc = s_l[tri(j, j)];
+        for (int k = 0; k < j; ++k) {
+            const float ljk = s_l[tri(j, k)];
+            dacc = __builtin_fmaf(-ljk, ljk, dacc);
+        }
+        const float d = sqrtf(dacc);
+        for (int i = j + 1 + lane; i < N; i += kWave) {
+            float acc = s_l[tri(i, j)];
+            for (int k = 0; k < j; ++k) acc = __builtin_fmaf(-s_l[tri(i, k)], s_l[tri(j, k)], acc);
+            s_l[tri(i, j)] = acc / d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_l[tri(j, j)] = d;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // forward then backward substitution, right-looking (chains over k ascending / descending)
+    for (int j = 0; j < N; ++j) {
+        const float z = zs[j] / s_l[tri(j, j)];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) zs[j] = z;
+        for (int i = j + 1 + lane; i < N; i += kWave) zs[i] = __builtin_fmaf(-s_l[tri(i, j)], z, zs[i]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int j = N - 1; j >= 0; --j) {
+        const float v = zs[j] / s_l[tri(j, j)];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) zs[j] = v;
+        for (int i = lane; i < j; i += kWave) zs[i] = __builtin_fmaf(-s_l[tri(j, i)], v, zs[i]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < N; i += kWave) {
+        a.alpha_k[p0 + i] = zs[i];
+        for (int j = 0; j <= i; ++j) Lg[(size_t)i * N + j] = s_l[tri(i, j)];
+    }
+}
+
 // GP node update, src/gpoctomap/gpoctree_node.cpp:36-49 (double expression for ivar, double exp)
 __device__ __forceinline__ void gp_node_update_dev(const GpArgs &a, float &m_ivar, float &ivar, uint8_t &state, float new_m,
                                                    float new_var) {
@@ -191,9 +263,44 @@ __device__ __forceinline__ void gp_node_update_dev(const GpArgs &a, float &m_iva
     }
 }
 
+// exp(x) for x in [-60, 0], correctly rounded to f32 in all but ~1e-7 of the cases (the same contract
+// as the oracle's (float)exp((double)x)): x = n ln2 + r, |r| <= ln2/2, degree-13 Taylor/Horner in
+// f64 (truncation < 2e-17 relative), scaled by 2^n through the exponent field.
+__device__ __forceinline__ float exp_cr_dev(float xf) {
+    const double x = (double)xf;
+    const double n = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);   // ln2 high part
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);          // ln2 low part
+    double p = 1.6059043836821613e-10;                             // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878680990e-09);              // 1/12!
+    p = __builtin_fma(p, r, 2.50521083854417188e-08);              // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858907e-07);              // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858907e-06);              // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873016e-05);              // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698413e-04);              // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888889e-03);              // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333e-03);              // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666667e-02);              // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666667e-01);              // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const long long bits = (long long)__double_as_longlong(p) + ((long long)(int)n << 52);  // p in [0.7, 1.5], n >= -87
+    return (float)__longlong_as_double(bits);
+}
+
+__device__ __forceinline__ float matern3_fast(float ax, float ay, float az, float bx, float by, float bz, float sf2) {
+    const float dx = bx - ax, dy = by - ay, dz = bz - az;
+    const float d = sqrtf(dx * dx + (dy * dy + dz * dz));
+    return ((1 + d) * exp_cr_dev(-d)) * sf2;
+}
+
 // GPRegressor::predict + BCM fusion: one wave64 per leaf tile, lane = leaf (test point).
-// v = L^-1 Ks column by column per lane: v_k = (Ks_k - sum_{i<k} L_ki v_i) / L_kk with the row of L
-// wave-uniform (scalar loads) and the lane's v_i in LDS [row][lane] (or global scratch for large N).
+// v = L^-1 Ks per lane: v_k = (Ks_k - sum_{i<k} L_ki v_i) / L_kk.  Four rows at a time: their FMA chains
+// over the already solved i are independent (latency hidden, one LDS read of v_i feeds four rows), each
+// chain still runs over i ascending — the oracle's order.  Rows of L are loaded with coalesced vector
+// loads (lane = column) and broadcast with v_readlane; v lives in LDS [row][lane] (global scratch for
+// blocks larger than the LDS slot).
 constexpr int kGpLdsRows = 96;
 
 __global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
@@ -229,22 +336,57 @@ __global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
         const float *L = a.Lmat + a.l_off[tb];
         const float4 *x = a.pts + r.x;
         const float *al = a.alpha_k + r.x;
-        const bool in_lds = N <= kGpLdsRows;
         float mj = 0.0f, ss = 0.0f;
-        for (int k = 0; k < N; ++k) {
-            const float4 xk = x[k];
-            const float ks = matern3_dev(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);  // Ks(k, j) = k(x_k, xs_j)
-            mj = __builtin_fmaf(ks, al[k], mj);
-            float acc = ks;
-            const float *Lk = L + (size_t)k * N;
-            if (in_lds) {
-                for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], s_v[i][lane], acc);
-            } else {
-                for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], vg[(size_t)i * kWave + lane], acc);
+        if (N <= kWave) {
+            // fast path: a row of L fits one register (lane = column)
+            for (int k0 = 0; k0 < N; k0 += 4) {
+                float Lr[4], acc[4], ks[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + u, N - 1);
+                    Lr[u] = lane <= k ? L[(size_t)k * N + lane] : 0.0f;
+                    const float4 xk = x[k];
+                    ks[u] = matern3_fast(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);  // Ks(k, j) = k(x_k, xs_j)
+                    acc[u] = ks[u];
+                }
+                for (int i = 0; i < k0; ++i) {  // four independent chains over the solved rows
+                    const float vi = s_v[i][lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[u] = __builtin_fmaf(-__int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lr[u]), i)), vi, acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // the 4x4 triangle
+                    const int k = k0 + u;
+                    if (k < N) {
+#pragma unroll
+                        for (int w = 0; w < u; ++w)
+                            acc[u] = __builtin_fmaf(-__int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lr[u]), k0 + w)),
+                                                    s_v[k0 + w][lane], acc[u]);
+                        const float vk = acc[u] / __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lr[u]), k));
+                        s_v[k][lane] = vk;
+                        mj = __builtin_fmaf(ks[u], al[k], mj);
+                        ss = __builtin_fmaf(vk, vk, ss);
+                    }
+                }
             }
-            const float vk = acc / Lk[k];
-            if (in_lds) s_v[k][lane] = vk; else vg[(size_t)k * kWave + lane] = vk;
-            ss = __builtin_fmaf(vk, vk, ss);
+        } else {
+            const bool in_lds = N <= kGpLdsRows;
+            for (int k = 0; k < N; ++k) {
+                const float4 xk = x[k];
+                const float ks = matern3_fast(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);
+                mj = __builtin_fmaf(ks, al[k], mj);
+                float acc = ks;
+                const float *Lk = L + (size_t)k * N;
+                if (in_lds) {
+                    for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], s_v[i][lane], acc);
+                } else {
+                    for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], vg[(size_t)i * kWave + lane], acc);
+                }
+                const float vk = acc / Lk[k];
+                if (in_lds) s_v[k][lane] = vk; else vg[(size_t)k * kWave + lane] = vk;
+                ss = __builtin_fmaf(vk, vk, ss);
+            }
         }
         const float var = a.sf2 - ss;
         gp_node_update_dev(a, m_ivar, ivar, state, mj, var);

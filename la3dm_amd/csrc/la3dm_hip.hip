@@ -457,7 +457,13 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
                            (float4 *)ctx->pts_scaled.ptr, s->n_train_pts, a.scale, s->nbr, s->train_off,
                            (uint2 *)ctx->nbr_range.ptr, n_nbr);
     }
-    if (s->n_train_blk) hipLaunchKernelGGL(gp_train_kernel, dim3(s->n_train_blk), dim3(256), 0, stream, a);
+    if (s->n_train_blk) {
+        const uint32_t nn = max_n < (uint32_t)kGpTrainLdsMaxN ? (max_n ? max_n : 1u) : (uint32_t)kGpTrainLdsMaxN;
+        hipLaunchKernelGGL(gp_train_wave_kernel, dim3(s->n_train_blk), dim3(kWave), sizeof(float) * (nn * (nn + 1) / 2 + nn),
+                           stream, a);
+        if (max_n > (uint32_t)kGpTrainLdsMaxN)
+            hipLaunchKernelGGL(gp_train_kernel, dim3(s->n_train_blk), dim3(256), 0, stream, a);
+    }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (ctx->opt_time_kernel) {
         if (ctx->ev_used == ctx->ev_pool.size()) {
