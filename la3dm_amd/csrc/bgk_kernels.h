@@ -1283,6 +1283,233 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 6: per-lane FIFOs.  Variant 5 pays a ballot + mbcnt per candidate twice (push and replay).
+// Here a hit is parked in the leaf's OWN next FIFO slot (no cross-lane work in the test loop), the
+// FIFO levels are flattened once per drain (one ballot per level, ~12, instead of one per candidate,
+// ~44) so that the kernel evaluation still runs on dense lanes, the values are written back in
+// place, and each leaf lane then adds its own values in FIFO order = candidate order = the
+// reference's summation order (bit-identical results).
+// LDS per wave: 64 candidates + 12 FIFO levels of (d2 -> k, candidate) + flatten list = 6.5 KB.
+// ---------------------------------------------------------------------------
+constexpr int kCand6 = 64;
+constexpr int kFifo6 = 12;
+
+struct __attribute__((aligned(16))) WaveLds6 {
+    float4 cand[kCand6 + 4];        // x/ell, y/ell, z/ell, label (+ padding slots)
+    float fifo[kFifo6][kWave];      // d2, overwritten by k(r)
+    uint16_t owner[kFifo6 * kWave]; // flattened (lane | level << 6)
+    uint8_t fcj[kFifo6][kWave];     // candidate slot of each parked pair
+    uint8_t seg[kCand6 + 4];        // neighbour slot of each candidate
+};
+
+template <int kTrig, int kWaves>
+__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v6(BgkArgs a) {
+    __shared__ WaveLds6 s_lds[kWaves];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t wg = blockIdx.x;
+    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
+    else if (a.remap == 2) {
+        const uint32_t G8 = gridDim.x & ~63u;
+        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
+    }
+    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    WaveLds6 &L = s_lds[wv];
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = (uint32_t)lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+
+    int tb[7];
+    uint32_t p0[7], cnt[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        const uint2 r = a.nbr_range[7 * blk + b];
+        p0[b] = r.x;
+        cnt[b] = r.y;
+        tb[b] = r.y ? 0 : -1;  // only "has a trained model" matters below (a model has >= 1 point)
+    }
+    float4 q[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b)
+        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const uint32_t key = a.leaf_key[li];
+    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs0 = (off4.x + cx) / a.ell, ys0 = (off4.y + cy) / a.ell, zs0 = (off4.z + cz) / a.ell;
+    float A = a.alpha[li], B = a.beta[li];
+
+    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
+    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
+
+    const bool ungated = (a.flags & 1u) != 0;
+    bool updated = false;
+    float kbar = 0.0f, ybar = 0.0f;
+    uint32_t ncand = 0;
+    int cur_seg = -1;       // per lane: neighbour slot the (ybar, kbar) registers belong to
+    uint32_t fcnt = 0;      // per lane: pairs parked in this lane's FIFO
+
+    auto flush_nb = [&]() {  // Occupancy::update, bgkoctree_node.cpp:31-35
+        if (kbar > 0.0f || ungated) {
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+        kbar = 0.0f;
+        ybar = 0.0f;
+    };
+
+    auto stage = [&](const float4 &p, bool valid, int b) {
+        bool keep = false;
+        if (valid) {
+            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
+            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
+            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
+            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) {
+            L.cand[slot] = p;
+            L.seg[slot] = (uint8_t)b;
+        }
+        ncand += (uint32_t)__popcll(m);
+    };
+
+    // A: first chunks in ExtendedBlock order while they fit and no neighbour needs a 2nd chunk
+    uint32_t it_b = 7, it_base = 0;
+    {
+        bool open = true;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            if (!open || cnt[b] == 0) continue;
+            if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand6) {
+                stage(q[b], (uint32_t)lane < cnt[b], b);
+                if (cnt[b] > (uint32_t)kWave) {
+                    open = false;
+                    it_b = b;
+                    it_base = kWave;
+                }
+            } else {
+                open = false;
+                it_b = b;
+                it_base = 0;
+            }
+        }
+    }
+
+    // evaluate every parked pair densely, then let each leaf lane add its own values in FIFO (= candidate) order
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // flatten level by level: entry (level k, lane l) exists iff cnt_l > k
+        uint32_t total = 0, maxc = 0;
+        for (uint32_t k2 = 0; k2 < (uint32_t)kFifo6; ++k2) {
+            const bool has = fcnt > k2;
+            const unsigned long long m = __ballot(has);
+            if (m == 0ull) break;
+            maxc = k2 + 1;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (has) L.owner[total + rank] = (uint16_t)((uint32_t)lane | (k2 << 6));
+            total += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t p = 0; p < ((a.flags & 0x100u) ? 0u : total); p += kWave) {  // 0x100: profiling ablation
+            const uint32_t i = p + lane;
+            if (i < total) {
+                const uint32_t o = L.owner[i];
+                float *slot = &L.fifo[o >> 6][o & 63u];
+                *slot = cov_sparse_fast<kTrig>(sqrt_cr(*slot), a.sf2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k2 = 0; k2 < ((a.flags & 0x400u) ? 0u : maxc); ++k2) {  // 0x400: profiling ablation
+            const bool act = k2 < fcnt;
+            const float kv = L.fifo[k2][lane];
+            const uint32_t cj = L.fcj[k2][lane];
+            const float y = L.cand[cj].w;
+            const int sg = (int)L.seg[cj];
+            if (act && sg != cur_seg) {
+                flush_nb();
+                cur_seg = sg;
+            }
+            if (act) {
+                ybar += kv * y;
+                kbar += kv;
+            }
+        }
+        fcnt = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    bool more = true;
+    while (more) {
+        if (lane < 4) L.cand[ncand + lane] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
+        for (uint32_t g = 0; g < ngroup; ++g) {
+            if (__any(fcnt > (uint32_t)(kFifo6 - 4))) drain();
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
+                const float d2 = dx * dx + (dy * dy + dz * dz);
+                // park unconditionally in the lane's next slot; only a hit (k(r) <= 0 for fp32 r >= 1) keeps it
+                L.fifo[fcnt][lane] = d2;
+                L.fcj[fcnt][lane] = (uint8_t)(4 * g + u);
+                fcnt += d2 < 1.0f ? 1u : 0u;
+            }
+        }
+        drain();
+        ncand = 0;
+        more = false;
+        while (it_b < 7) {
+            const uint2 rr = a.nbr_range[7 * blk + it_b];
+            const uint32_t pp0 = rr.x, pc = rr.y;
+            if (it_base >= pc) {
+                ++it_b;
+                it_base = 0;
+                continue;
+            }
+            if (ncand != 0u) break;  // one 64-point chunk per refill round
+            const bool valid = it_base + lane < pc;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) p = a.pts[pp0 + it_base + lane];
+            stage(p, valid, (int)it_b);
+            it_base += kWave;
+            more = true;
+        }
+    }
+    flush_nb();
+    if (ungated) {  // insert_training_data: update() runs for every trained neighbour
+#pragma unroll
+        for (int b = 0; b < 7; ++b) updated |= tb[b] >= 0;
+    }
+
+    if (active) {
+        if (updated) {
+            a.alpha[li] = A;
+            a.beta[li] = B;
+            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[li] = 0;
+        }
+    }
+}
+
 // exhaustive sweeps of the two shortcuts used by variant 3 against the IEEE operations:
 // counts fp32 inputs in [lo_bits, hi_bits] (as unsigned bit patterns) where they differ.
 __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatch) {

@@ -15,8 +15,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <stdexcept>
 #include <string>
 
@@ -467,6 +470,59 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
         span[a] = (int)std::floor(mx[a] * inv) - lo[a] + 1;
     }
     const int m1 = span[0], m2 = span[0] * span[1];
+    const size_t ncell = (size_t)span[0] * span[1] * span[2];
+    if (ncell <= ((size_t)1 << 24)) {
+        // dense accumulation: one pass in cloud order (the same per-cell summation order as sorting by
+        // (cell, index)), then the occupied cells in ascending index
+        struct Acc {
+            float x, y, z;
+            uint32_t n;
+        };
+        // zero pages on demand (calloc): only the touched part of the grid is ever paged in
+        Acc *acc = static_cast<Acc *>(std::calloc(ncell, sizeof(Acc)));
+        if (acc == nullptr) throw std::bad_alloc();
+        std::vector<uint32_t> touched;
+        touched.reserve(std::min(n, ncell));
+        // pass 1 (streaming): cell of every point; pass 2: accumulate with the target prefetched a few
+        // points ahead (the cloud arrives in ray order, i.e. every access is a cache miss)
+        std::vector<uint32_t> cells(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = in + 3 * i;
+            if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) {
+                cells[i] = 0xFFFFFFFFu;
+                continue;
+            }
+            const int c0 = (int)(std::floor(p[0] * inv) - (float)lo[0]);
+            const int c1 = (int)(std::floor(p[1] * inv) - (float)lo[1]);
+            const int c2 = (int)(std::floor(p[2] * inv) - (float)lo[2]);
+            cells[i] = (uint32_t)(c0 + c1 * m1 + c2 * m2);
+        }
+        constexpr size_t kAhead = 24;
+        for (size_t i = 0; i < n; ++i) {
+            if (i + kAhead < n && cells[i + kAhead] != 0xFFFFFFFFu) __builtin_prefetch(&acc[cells[i + kAhead]], 1, 1);
+            const uint32_t cell = cells[i];
+            if (cell == 0xFFFFFFFFu) continue;
+            const float *p = in + 3 * i;
+            Acc &a = acc[cell];
+            if (a.n == 0) touched.push_back(cell);
+            a.x += p[0];
+            a.y += p[1];
+            a.z += p[2];
+            ++a.n;
+        }
+        std::sort(touched.begin(), touched.end());
+        out.resize(3 * touched.size());
+        size_t o = 0;
+        for (uint32_t cell : touched) {
+            const Acc &a = acc[cell];
+            const float cnt = (float)a.n;
+            out[o++] = a.x / cnt;
+            out[o++] = a.y / cnt;
+            out[o++] = a.z / cnt;
+        }
+        std::free(acc);
+        return;
+    }
     std::vector<uint64_t> order;
     order.reserve(n);
     for (size_t i = 0; i < n; ++i) {
@@ -509,12 +565,16 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
         packed[3 * i + 2] = xyz[stride * i + 2];
     }
     std::vector<float> hits;
+    const double tt0 = wall();
     if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
+    const double tt1 = wall();
 
     xy.clear();
     std::vector<float> frees;
     const float x0 = origin.x(), y0 = origin.y(), z0 = origin.z();
     const size_t nh = hits.size() / 3;
+    xy.reserve(4 * nh);
+    frees.reserve(3 * nh * 8);
     size_t kept = 0;
     for (size_t i = 0; i < nh; ++i) {
         const float x = hits[3 * i], y = hits[3 * i + 1], z = hits[3 * i + 2];
@@ -522,22 +582,45 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
             const double l = (point3f(x, y, z) - origin).norm();
             if (l > max_range) continue;
         }
-        xy.insert(xy.end(), {x, y, z, 1.0f});
+        xy.push_back(x);
+        xy.push_back(y);
+        xy.push_back(z);
+        xy.push_back(1.0f);
         ++kept;
         // free-space samples along the beam: the origin itself, then every free_resolution,
         // then one sample free_resolution short of the hit
-        frees.insert(frees.end(), {x0, y0, z0});
         const float l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
         const float nx = (x - x0) / l, ny = (y - y0) / l, nz = (z - z0) / l;
-        for (float d = free_resolution; d < l; d += free_resolution)
-            frees.insert(frees.end(), {x0 + nx * d, y0 + ny * d, z0 + nz * d});
+        size_t w = frees.size();
+        const size_t room = 3 * ((size_t)(l / free_resolution) + 4);
+        frees.resize(w + room);
+        float *f = frees.data();
+        f[w++] = x0;
+        f[w++] = y0;
+        f[w++] = z0;
+        for (float d = free_resolution; d < l; d += free_resolution) {
+            if (w + 6 > frees.size()) {  // (float stepping can take one more step than l / free_resolution)
+                frees.resize(frees.size() + 64);
+                f = frees.data();
+            }
+            f[w++] = x0 + nx * d;
+            f[w++] = y0 + ny * d;
+            f[w++] = z0 + nz * d;
+        }
         if (l > free_resolution) {
             const float d = l - free_resolution;
-            frees.insert(frees.end(), {x0 + nx * d, y0 + ny * d, z0 + nz * d});
+            f[w++] = x0 + nx * d;
+            f[w++] = y0 + ny * d;
+            f[w++] = z0 + nz * d;
         }
+        frees.resize(w);
     }
     std::vector<float> sampled;
+    const double tt2 = wall();
     if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled);
+    if (getenv("LA3DM_TIMING"))
+        fprintf(stderr, "[la3dm] front end: grid(hits) %.4f beam %.4f grid(frees, %zu pts) %.4f\n", tt1 - tt0, tt2 - tt1,
+                frees.size() / 3, wall() - tt2);
     const size_t nf = sampled.size() / 3;
     xy.reserve(xy.size() + 4 * nf);
     const float free_label = variant == 1 ? -1.0f : 0.0f;  // bgkoctomap.cpp:415 / gpoctomap.cpp:399

@@ -283,6 +283,17 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
         } else {
             LAUNCH_BGK(bgk_predict_fuse_v3, , 1)
         }
+    } else if (ctx->opt_variant == 6) {
+        const int w = ctx->opt_waves;
+        grid = dim3((a.n_tasks + w - 1) / w);
+        block = dim3(w * kWave);
+        if (w == 4) {
+            LAUNCH_BGK(bgk_predict_fuse_v6, , 4)
+        } else if (w == 2) {
+            LAUNCH_BGK(bgk_predict_fuse_v6, , 2)
+        } else {
+            LAUNCH_BGK(bgk_predict_fuse_v6, , 1)
+        }
     } else if (ctx->opt_variant == 0 || ctx->opt_variant == 5) {
         const int w = ctx->opt_waves;
         grid = dim3((a.n_tasks + w - 1) / w);
