@@ -203,6 +203,49 @@ int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *
  * 3  sin/cos (f64 kernels rounded to f32) vs the f64 library functions rounded to f32. */
 int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident map: the block pool (alpha, beta, state of every node of
+ * every block) lives in HBM and BGKOctoMap::insert_pointcloud (src/bgkoctomap/bgkoctomap.cpp:214-366)
+ * runs start to finish on the GPU:
+ *   f1  get_training_data (:383-417), beam_sample (:433-458), downsample (:419-431, pcl::VoxelGrid)
+ *   f2  bbox / get_blocks_in_bbox (:464-495), closed-box gather (:497-552, rtree.h:1519-1532),
+ *       ExtendedBlock (bgkblock.cpp:85-130), block creation (:298-305)
+ *   E   la3dm_bgk_scan_device / la3dm_gp_scan_device (above)
+ *   f3  leaf enumeration (bgkoctree.h:62-147), node write-back, OcTree::prune (bgkoctree.cpp:101-148)
+ * Only the cloud goes in; the host reads nodes back on demand (la3dm_devmap_download).  Results are
+ * bit-identical to the host-orchestrated path.  Works for variant 0 (BGK) and 1 (GP) contexts. */
+typedef struct la3dm_devmap la3dm_devmap;
+
+typedef struct la3dm_devmap_stats {
+    uint64_t n_hits, n_frees;          /* training set after the front end */
+    uint64_t n_train_blocks;           /* blocks that hold training points */
+    uint64_t n_test_blocks;            /* test blocks (all passes) */
+    uint64_t n_bbox_blocks;            /* entries of the candidate list */
+    uint64_t voxel_updates;            /* U: leaves of the test blocks */
+    uint64_t train_reads;              /* sum over test blocks of their 7-neighbourhood training points */
+    uint64_t n_blocks;                 /* blocks in the pool after the scan */
+    uint32_t n_passes;                 /* 1 + repeats of a key in the candidate list */
+    double t_frontend, t_partition, t_pack, t_kernel, t_commit, t_total; /* seconds, host clock at sync points */
+} la3dm_devmap_stats;
+
+int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out);
+void la3dm_devmap_destroy(la3dm_devmap *dm);
+/* cloud: n points, `stride` floats apart (>= 3), host memory */
+int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride,
+                                        const float origin[3], float ds_resolution, float free_resolution,
+                                        float max_range, la3dm_devmap_stats *stats);
+/* cloud: n packed xyz triples in device memory; runs on the context's stream and returns after the last
+ * kernel has been enqueued and the few scalar read-backs the launch sizes depend on */
+int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
+                                          float ds_resolution, float free_resolution, float max_range,
+                                          la3dm_devmap_stats *stats);
+int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nodes_per_block);
+/* keys[n_blocks]; A, B, S [n_blocks * nodes_per_block], node order = depth-major (8^d - 1)/7 + index;
+ * S: bits 0-2 State (FREE 0, OCCUPIED 1, UNKNOWN 2, PRUNED 3), bit 7 = classified */
+int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, uint8_t *S);
+/* training set (x, y, z, label) of the last scan, for parity tests; *n = number of points */
+int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint32_t *n);
+
 #ifdef __cplusplus
 }
 #endif

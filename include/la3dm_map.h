@@ -67,6 +67,12 @@ int la3dm_map_packed(la3dm_map *m, la3dm_bgk_scan *out);
 int la3dm_map_commit(la3dm_map *m);
 la3dm_ctx *la3dm_map_ctx(la3dm_map *m);
 
+/* Device-resident mode (include/la3dm_hip.h, la3dm_devmap_*): the block pool lives in HBM, insert_pointcloud runs
+ * start to finish on the GPU, the host blocks are a lazily refreshed mirror.  Switch while the map is empty.
+ * insert_training_data and prepare/commit are refused in this mode. */
+int la3dm_map_set_device_resident(la3dm_map *m, int on);
+int la3dm_map_is_device_resident(const la3dm_map *m);
+
 int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out);
 uint64_t la3dm_map_training_size(const la3dm_map *m);
 int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap);

@@ -56,16 +56,28 @@ class ScanStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class DevmapStats(C.Structure):
+    """la3dm_devmap_stats (include/la3dm_hip.h)"""
+    _fields_ = [(k, C.c_uint64) for k in ("n_hits", "n_frees", "n_train_blocks", "n_test_blocks", "n_bbox_blocks",
+                                          "voxel_updates", "train_reads", "n_blocks")] + \
+               [("n_passes", C.c_uint32)] + \
+               [(k, C.c_double) for k in ("t_frontend", "t_partition", "t_pack", "t_kernel", "t_commit", "t_total")]
+
+
 HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_destroy", "la3dm_last_error",
                "la3dm_set_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_gp_scan_host",
-               "la3dm_gp_scan_device", "la3dm_bgklv_scan_host", "la3dm_bgklv_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep"]
+               "la3dm_gp_scan_device", "la3dm_bgklv_scan_host", "la3dm_bgklv_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep",
+               "la3dm_devmap_create", "la3dm_devmap_destroy", "la3dm_devmap_insert_pointcloud_host",
+               "la3dm_devmap_insert_pointcloud_device", "la3dm_devmap_block_count", "la3dm_devmap_download",
+               "la3dm_devmap_training_data"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
                "la3dm_map_packed", "la3dm_map_commit", "la3dm_map_ctx", "la3dm_map_stats", "la3dm_map_training_size",
                "la3dm_map_training_data", "la3dm_map_block_size", "la3dm_map_block_count", "la3dm_map_leaf_count",
                "la3dm_map_dump_leaves", "la3dm_map_search", "la3dm_map_get_bbox", "la3dm_map_block_to_hash_key",
-               "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut"]
+               "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut",
+               "la3dm_map_set_device_resident", "la3dm_map_is_device_resident"]
 
 _hip = None
 _map = None
@@ -106,6 +118,21 @@ def hip():
         L.la3dm_diag_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.la3dm_diag_eval.restype = C.c_int
         L.la3dm_diag_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.la3dm_devmap_create.restype = C.c_int
+        L.la3dm_devmap_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.la3dm_devmap_destroy.argtypes = [C.c_void_p]
+        L.la3dm_devmap_insert_pointcloud_host.restype = C.c_int
+        L.la3dm_devmap_insert_pointcloud_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                          C.c_float, C.c_float, C.c_float, C.POINTER(DevmapStats)]
+        L.la3dm_devmap_insert_pointcloud_device.restype = C.c_int
+        L.la3dm_devmap_insert_pointcloud_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float,
+                                                            C.c_float, C.c_float, C.POINTER(DevmapStats)]
+        L.la3dm_devmap_block_count.restype = C.c_int
+        L.la3dm_devmap_block_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.la3dm_devmap_download.restype = C.c_int
+        L.la3dm_devmap_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.la3dm_devmap_training_data.restype = C.c_int
+        L.la3dm_devmap_training_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         _hip = L
     return _hip
 
@@ -134,6 +161,10 @@ def maplib():
         M.la3dm_map_lv_commit.restype = C.c_int
         M.la3dm_map_lv_commit.argtypes = [C.c_void_p]
         M.la3dm_map_destroy.argtypes = [C.c_void_p]
+        M.la3dm_map_set_device_resident.restype = C.c_int
+        M.la3dm_map_set_device_resident.argtypes = [C.c_void_p, C.c_int]
+        M.la3dm_map_is_device_resident.restype = C.c_int
+        M.la3dm_map_is_device_resident.argtypes = [C.c_void_p]
         M.la3dm_map_last_error.restype = C.c_char_p
         M.la3dm_map_insert_pointcloud.restype = C.c_int
         M.la3dm_map_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_uint64, f32p, C.c_float, C.c_float, C.c_float]

@@ -55,6 +55,15 @@ class BGKOctoMap:
 
     _gp = False
 
+    def set_device_resident(self, on=True):
+        """Device-resident mode: the block pool lives in HBM and insert_pointcloud runs start to finish on the
+        GPU (front end, partition, predict + fuse, write-back, prune); queries refresh a host mirror lazily."""
+        self._chk(self._M.la3dm_map_set_device_resident(self._h, 1 if on else 0))
+        return self
+
+    def is_device_resident(self):
+        return bool(self._M.la3dm_map_is_device_resident(self._h))
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._M.la3dm_map_destroy(self._h)

@@ -1,0 +1,629 @@
+// devmap.hip — device-resident map: BGKOctoMap::insert_pointcloud start to finish on the GPU
+// (C ABI: the la3dm_devmap_* entry points of include/la3dm_hip.h; kernels: devmap_kernels.h).
+// The host only sizes launches (a handful of scalar read-backs per scan) and walks the float-stepped
+// candidate loops of get_blocks_in_bbox (a few dozen iterations per axis).  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "la3dm_ctx.h"
+#include "devmap_kernels.h"
+
+using namespace la3dm_dev;
+
+namespace {
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline uint32_t cdiv(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+inline uint32_t npb_of(int depth) {
+    uint32_t n = 0;
+    for (int d = 0; d < depth; ++d) n += 1u << (3 * d);
+    return n;
+}
+}  // namespace
+
+struct la3dm_devmap {
+    la3dm_ctx *ctx = nullptr;
+    uint32_t depth = 0, npb = 0, ncell = 0;
+    float block_size = 0.f, init_A = 0.f, init_B = 0.f;
+    // pool + table
+    size_t cap_blocks = 0;
+    uint32_t n_blocks = 0;
+    float *A = nullptr, *B = nullptr;
+    uint8_t *S = nullptr;
+    long long *blk_key = nullptr;
+    uint32_t tab_cap = 0;
+    long long *tab_key = nullptr;
+    uint32_t *tab_val = nullptr;
+    // small fixed buffers
+    uint32_t *d_cnt = nullptr, *h_cnt = nullptr;  // counters (device / pinned host)
+    uint32_t *d_mm = nullptr;
+    float *d_bbox = nullptr, *h_bbox = nullptr;
+    GridParams *d_gp = nullptr, *h_gp = nullptr;
+    // arenas (grow only)
+    Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
+    Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp;
+    Arena train, grid, axis_tab;
+    Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot;
+    Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
+    uint32_t n_xy = 0;
+    la3dm_devmap_stats stats;
+};
+
+#define DM_TRY(expr) HIP_TRY(dm->ctx, expr)
+#define DM_RESERVE(arena, bytes)                                                    \
+    do {                                                                            \
+        int rc_ = arena_reserve(dm->ctx, (arena), (bytes) ? (size_t)(bytes) : 16);  \
+        if (rc_ != LA3DM_OK) return rc_;                                            \
+    } while (0)
+
+static int dm_fail(la3dm_devmap *dm, int code, const std::string &msg) {
+    dm->ctx->err = msg;
+    return code;
+}
+
+// ---- library plumbing: device-wide sort / scan (rocPRIM through hipCUB) ---------------------------------
+static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
+                      uint32_t n, int end_bit) {
+    if (n == 0) return LA3DM_OK;
+    hipStream_t st = dm->ctx->stream;
+    size_t tmp = 0;
+    DM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    DM_RESERVE(dm->cub_tmp, tmp);
+    DM_TRY(hipcub::DeviceRadixSort::SortPairs(dm->cub_tmp.ptr, tmp, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    return LA3DM_OK;
+}
+
+static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, uint32_t n) {
+    if (n == 0) return LA3DM_OK;
+    hipStream_t st = dm->ctx->stream;
+    size_t tmp = 0;
+    DM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, st));
+    DM_RESERVE(dm->cub_tmp, tmp);
+    DM_TRY(hipcub::DeviceScan::ExclusiveSum(dm->cub_tmp.ptr, tmp, in, out, (int)n, st));
+    return LA3DM_OK;
+}
+
+static int read_counters(la3dm_devmap *dm) {
+    hipStream_t st = dm->ctx->stream;
+    DM_TRY(hipMemcpyAsync(dm->h_cnt, dm->d_cnt, sizeof(uint32_t) * kCntWords, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+// pcl::VoxelGrid centroid filter (bgkoctomap.cpp:419-431) on the device.  d_in: n packed xyz; the result is
+// written to `out` (reserved here) and its point count returned.  One read-back (cell count).
+static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out) {
+    hipStream_t st = dm->ctx->stream;
+    *n_out = 0;
+    if (n == 0) return LA3DM_OK;
+    const float inv = 1.0f / leaf;
+    DM_RESERVE(dm->k0, 4ull * n);
+    DM_RESERVE(dm->k1, 4ull * n);
+    DM_RESERVE(dm->v0, 4ull * n);
+    DM_RESERVE(dm->v1, 4ull * n);
+    DM_RESERVE(dm->flag, 4ull * n);
+    DM_RESERVE(dm->scan, 4ull * n);
+    DM_RESERVE(dm->seg_start, 4ull * (n + 1));
+    uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
+    uint32_t *flag = (uint32_t *)dm->flag.ptr, *scan = (uint32_t *)dm->scan.ptr, *seg_start = (uint32_t *)dm->seg_start.ptr;
+    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 256), 2048)), dim3(256), 0, st, d_in, n, dm->d_mm);
+    hipLaunchKernelGGL(dm_grid_params, dim3(1), dim3(64), 0, st, dm->d_mm, inv, dm->d_gp);
+    hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
+    int rc = sort_pairs(dm, k0, k1, v0, v1, n, 32);
+    if (rc != LA3DM_OK) return rc;
+    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGridValid, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(dm_heads, dim3(cdiv(n, 256)), dim3(256), 0, st, k1, n, flag, dm->d_cnt, (int)kCntGridValid);
+    rc = exclusive_scan(dm, flag, scan, n);
+    if (rc != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_seg_starts, dim3(cdiv(n, 256)), dim3(256), 0, st, k1, flag, scan, n, seg_start, (uint32_t *)nullptr,
+                       dm->d_cnt, (int)kCntGridSegs, (int)kCntGridValid);
+    DM_TRY(hipMemcpyAsync(dm->h_gp, dm->d_gp, sizeof(GridParams), hipMemcpyDeviceToHost, st));
+    rc = read_counters(dm);
+    if (rc != LA3DM_OK) return rc;
+    if (dm->h_gp->passthrough) {  // index space overflows int32: PCL returns the cloud unfiltered
+        DM_RESERVE(out, 12ull * n);
+        DM_TRY(hipMemcpyAsync(out.ptr, d_in, 12ull * n, hipMemcpyDeviceToDevice, st));
+        *n_out = n;
+        return LA3DM_OK;
+    }
+    const uint32_t nseg = dm->h_cnt[kCntGridSegs];
+    DM_RESERVE(out, 12ull * nseg);
+    if (nseg)
+        hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(nseg, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
+                           (int)kCntGridSegs, (float *)out.ptr);
+    *n_out = nseg;
+    return LA3DM_OK;
+}
+
+static int grow_pool(la3dm_devmap *dm, size_t want_blocks) {
+    if (want_blocks <= dm->cap_blocks) return LA3DM_OK;
+    hipStream_t st = dm->ctx->stream;
+    size_t cap = std::max<size_t>(want_blocks + want_blocks / 2, 4096);
+    float *A = nullptr, *B = nullptr;
+    uint8_t *S = nullptr;
+    long long *bk = nullptr;
+    const size_t nn = cap * dm->npb;
+    if (hipMalloc((void **)&A, 4 * nn) != hipSuccess || hipMalloc((void **)&B, 4 * nn) != hipSuccess ||
+        hipMalloc((void **)&S, nn) != hipSuccess || hipMalloc((void **)&bk, 8 * cap) != hipSuccess) {
+        if (A) (void)hipFree(A);
+        if (B) (void)hipFree(B);
+        if (S) (void)hipFree(S);
+        if (bk) (void)hipFree(bk);
+        return dm_fail(dm, LA3DM_ERR_OOM, "devmap: block pool allocation failed");
+    }
+    if (dm->n_blocks) {
+        const size_t on = (size_t)dm->n_blocks * dm->npb;
+        DM_TRY(hipMemcpyAsync(A, dm->A, 4 * on, hipMemcpyDeviceToDevice, st));
+        DM_TRY(hipMemcpyAsync(B, dm->B, 4 * on, hipMemcpyDeviceToDevice, st));
+        DM_TRY(hipMemcpyAsync(S, dm->S, on, hipMemcpyDeviceToDevice, st));
+        DM_TRY(hipMemcpyAsync(bk, dm->blk_key, 8ull * dm->n_blocks, hipMemcpyDeviceToDevice, st));
+        DM_TRY(hipStreamSynchronize(st));
+    }
+    if (dm->A) (void)hipFree(dm->A);
+    if (dm->B) (void)hipFree(dm->B);
+    if (dm->S) (void)hipFree(dm->S);
+    if (dm->blk_key) (void)hipFree(dm->blk_key);
+    dm->A = A;
+    dm->B = B;
+    dm->S = S;
+    dm->blk_key = bk;
+    dm->cap_blocks = cap;
+    return LA3DM_OK;
+}
+
+static int grow_table(la3dm_devmap *dm, size_t want_blocks) {
+    if (dm->tab_cap >= 2 * want_blocks && dm->tab_cap) return LA3DM_OK;
+    hipStream_t st = dm->ctx->stream;
+    uint32_t cap = 1u << 16;
+    while (cap < 4 * want_blocks) cap <<= 1;
+    long long *tk = nullptr;
+    uint32_t *tv = nullptr;
+    if (hipMalloc((void **)&tk, 8ull * cap) != hipSuccess || hipMalloc((void **)&tv, 4ull * cap) != hipSuccess) {
+        if (tk) (void)hipFree(tk);
+        return dm_fail(dm, LA3DM_ERR_OOM, "devmap: block table allocation failed");
+    }
+    DM_TRY(hipMemsetAsync(tk, 0xFF, 8ull * cap, st));
+    if (dm->n_blocks)
+        hipLaunchKernelGGL(dm_table_rebuild, dim3(cdiv(dm->n_blocks, 256)), dim3(256), 0, st, dm->blk_key, dm->n_blocks, tk, tv,
+                           cap - 1);
+    DM_TRY(hipStreamSynchronize(st));
+    if (dm->tab_key) (void)hipFree(dm->tab_key);
+    if (dm->tab_val) (void)hipFree(dm->tab_val);
+    dm->tab_key = tk;
+    dm->tab_val = tv;
+    dm->tab_cap = cap;
+    return LA3DM_OK;
+}
+
+// float-stepped candidate indices of one axis (get_blocks_in_bbox, bgkoctomap.cpp:486-495): the three nested
+// loops restart the inner sequences identically, so the candidate list is the product of three sequences.
+static std::vector<int> axis_sequence(float lo, float hi, float bs) {
+    std::vector<int> seq;
+    for (float v = lo - bs; v <= hi + 2 * bs; v += bs) {
+        seq.push_back((int)(int64_t)((double)v / (double)bs + 524288.5));
+        if (seq.size() > (1u << 20)) break;
+    }
+    return seq;
+}
+
+extern "C" {
+
+int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
+    if (!ctx || !out) return LA3DM_ERR_ARG;
+    *out = nullptr;
+    if (ctx->p.variant != 0 && ctx->p.variant != 1) {
+        ctx->err = "la3dm_devmap_create: the device-resident map supports variant 0 (BGK) and 1 (GP)";
+        return LA3DM_ERR_ARG;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    la3dm_devmap *dm = new la3dm_devmap;
+    dm->ctx = ctx;
+    dm->depth = (uint32_t)ctx->p.block_depth;
+    dm->npb = npb_of(ctx->p.block_depth);
+    dm->ncell = 1u << (3 * (dm->depth - 1));
+    dm->block_size = (float)pow(2, ctx->p.block_depth - 1) * ctx->p.resolution;  // bgkoctomap.cpp:36
+    if (ctx->p.variant == 1) {  // GP nodes start at (0, min_ivar), gpoctree_node.cpp:15-17
+        dm->init_A = 0.0f;
+        dm->init_B = ctx->p.min_ivar;
+    } else {
+        dm->init_A = ctx->p.prior_A;
+        dm->init_B = ctx->p.prior_B;
+    }
+    memset(&dm->stats, 0, sizeof(dm->stats));
+    bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
+              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
+              hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 8) == hipSuccess &&
+              hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
+              hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
+              hipMalloc((void **)&dm->d_gp, sizeof(GridParams)) == hipSuccess &&
+              hipHostMalloc((void **)&dm->h_gp, sizeof(GridParams)) == hipSuccess &&
+              hipMemset(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords) == hipSuccess;
+    if (!ok) {
+        ctx->err = "la3dm_devmap_create: allocation failed";
+        la3dm_devmap_destroy(dm);
+        return LA3DM_ERR_OOM;
+    }
+    *out = dm;
+    return LA3DM_OK;
+}
+
+void la3dm_devmap_destroy(la3dm_devmap *dm) {
+    if (!dm) return;
+    (void)hipSetDevice(dm->ctx->device);
+    Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
+                    &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
+                    &dm->cub_tmp, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
+                    &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->nleaf,
+                    &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
+    for (Arena *a : all)
+        if (a->ptr) (void)hipFree(a->ptr);
+    void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (dm->h_cnt) (void)hipHostFree(dm->h_cnt);
+    if (dm->h_bbox) (void)hipHostFree(dm->h_bbox);
+    if (dm->h_gp) (void)hipHostFree(dm->h_gp);
+    delete dm;
+}
+
+int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
+                                          float ds_resolution, float free_resolution, float max_range,
+                                          la3dm_devmap_stats *stats_out) {
+    if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
+    la3dm_ctx *ctx = dm->ctx;
+    DM_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    memset(&S, 0, sizeof(S));
+    S.n_blocks = dm->n_blocks;
+    dm->n_xy = 0;
+    const double t0 = wall();
+    int rc;
+    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+
+    // ---------------- f1: front end ----------------
+    const float *d_hits = d_xyz;
+    uint32_t n_h = n;
+    if (!(ds_resolution < 0)) {
+        if ((rc = voxel_grid(dm, d_xyz, n, ds_resolution, dm->hits, &n_h)) != LA3DM_OK) return rc;
+        d_hits = (const float *)dm->hits.ptr;
+    }
+    if (n_h == 0) {
+        if (stats_out) *stats_out = S;
+        return LA3DM_OK;
+    }
+    DM_RESERVE(dm->keep, 4ull * n_h);
+    DM_RESERVE(dm->nfree, 4ull * n_h);
+    DM_RESERVE(dm->keep_off, 4ull * n_h);
+    DM_RESERVE(dm->free_off, 4ull * n_h);
+    BeamArgs ba = {origin[0], origin[1], origin[2], free_resolution, max_range};
+    uint32_t *keep = (uint32_t *)dm->keep.ptr, *nfree = (uint32_t *)dm->nfree.ptr, *keep_off = (uint32_t *)dm->keep_off.ptr,
+             *free_off = (uint32_t *)dm->free_off.ptr;
+    hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree);
+    if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, keep_off, keep, n_h, dm->d_cnt, (int)kCntKept);
+    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    const uint32_t n_kept = dm->h_cnt[kCntKept], n_free_raw = dm->h_cnt[kCntFreeRaw];
+    if (n_kept == 0) {
+        if (stats_out) *stats_out = S;
+        return LA3DM_OK;
+    }
+    DM_RESERVE(dm->xy, 16ull * ((size_t)n_kept + n_free_raw));
+    DM_RESERVE(dm->frees_raw, 12ull * n_free_raw);
+    float4 *xy = (float4 *)dm->xy.ptr;
+    hipLaunchKernelGGL(dm_beam_write, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, keep_off, free_off, xy,
+                       (float *)dm->frees_raw.ptr);
+    const float *d_frees = (const float *)dm->frees_raw.ptr;
+    uint32_t n_f = n_free_raw;
+    if (!(ds_resolution < 0)) {
+        if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f)) != LA3DM_OK) return rc;
+        d_frees = (const float *)dm->frees_ds.ptr;
+    }
+    const float free_label = ctx->p.variant == 1 ? -1.0f : 0.0f;  // bgkoctomap.cpp:415 / gpoctomap.cpp:399
+    if (n_f)
+        hipLaunchKernelGGL(dm_append_frees, dim3(cdiv(n_f, 256)), dim3(256), 0, st, d_frees, n_f, n_kept, free_label, xy);
+    const uint32_t npts = n_kept + n_f;
+    dm->n_xy = npts;
+    S.n_hits = n_kept;
+    S.n_frees = n_f;
+
+    // ---------------- f2: partition ----------------
+    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 256), 2048)), dim3(256), 0, st, (const float *)xy, npts,
+                       dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox);
+    DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    const double t1 = wall();
+    S.t_frontend = t1 - t0;
+
+    const float bs = dm->block_size, half = bs / 2.0f;
+    std::vector<int> seq[3];
+    int smin[3], smax[3];
+    for (int a = 0; a < 3; ++a) {
+        seq[a] = axis_sequence(dm->h_bbox[a], dm->h_bbox[3 + a], bs);
+        if (seq[a].empty() || seq[a].size() > (1u << 20)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: degenerate training-set extent");
+        smin[a] = smax[a] = seq[a][0];
+        for (int v : seq[a]) {
+            smin[a] = std::min(smin[a], v);
+            smax[a] = std::max(smax[a], v);
+        }
+    }
+    PartArgs pa;
+    pa.bs = bs;
+    pa.half = half;
+    uint64_t ncid = 1;
+    for (int a = 0; a < 3; ++a) {
+        pa.g0[a] = smin[a] - 2;
+        pa.gn[a] = smax[a] - smin[a] + 5;
+        ncid *= (uint64_t)pa.gn[a];
+    }
+    if (ncid > (1ull << 27))
+        return dm_fail(dm, LA3DM_ERR_ARG, "devmap: scan extent / block size needs more than 2^27 block cells (set max_range)");
+    // axis tables: seq (int) | rank (u8) | mult (u8), three axes back to back
+    std::vector<uint8_t> tab;
+    size_t off_seq[3], off_rank[3], off_mult[3];
+    uint32_t max_occ = 1;
+    {
+        size_t o = 0;
+        for (int a = 0; a < 3; ++a) {
+            off_seq[a] = o;
+            o += 4 * seq[a].size();
+        }
+        for (int a = 0; a < 3; ++a) {
+            off_rank[a] = o;
+            o += seq[a].size();
+        }
+        for (int a = 0; a < 3; ++a) {
+            off_mult[a] = o;
+            o += (size_t)pa.gn[a];
+        }
+        tab.assign((o + 15) & ~(size_t)15, 0);
+        for (int a = 0; a < 3; ++a) {
+            memcpy(&tab[off_seq[a]], seq[a].data(), 4 * seq[a].size());
+            uint8_t *mult = &tab[off_mult[a]], *rank = &tab[off_rank[a]];
+            uint32_t mx = 0;
+            for (size_t k = 0; k < seq[a].size(); ++k) {
+                uint8_t &m = mult[seq[a][k] - pa.g0[a]];
+                if (m == 255) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: a candidate index repeats more than 255 times");
+                rank[k] = m++;
+                mx = std::max<uint32_t>(mx, m);
+            }
+            max_occ *= mx;
+        }
+    }
+    DM_RESERVE(dm->axis_tab, tab.size());
+    DM_TRY(hipMemcpyAsync(dm->axis_tab.ptr, tab.data(), tab.size(), hipMemcpyHostToDevice, st));
+    CandArgs ca;
+    for (int a = 0; a < 3; ++a) {
+        const uint8_t *base = (const uint8_t *)dm->axis_tab.ptr;
+        pa.mult[a] = base + off_mult[a];
+        ca.seq[a] = (const int *)(base + off_seq[a]);
+        ca.rank[a] = base + off_rank[a];
+        ca.nseq[a] = (int)seq[a].size();
+    }
+    ca.part = pa;
+    const uint64_t n_entries64 = (uint64_t)seq[0].size() * seq[1].size() * seq[2].size();
+    if (n_entries64 > (1ull << 30)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: candidate list too long");
+    const uint32_t n_entries = (uint32_t)n_entries64;
+    S.n_bbox_blocks = n_entries;
+
+    // membership pairs (block, point), grouped by block with ascending point index inside a block
+    DM_RESERVE(dm->flag, 4ull * npts);
+    DM_RESERVE(dm->scan, 4ull * npts);
+    uint32_t *m_cnt = (uint32_t *)dm->flag.ptr, *m_off = (uint32_t *)dm->scan.ptr;
+    hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const float4 *)xy, npts, pa, m_cnt);
+    if ((rc = exclusive_scan(dm, m_cnt, m_off, npts)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, m_off, m_cnt, npts, dm->d_cnt, (int)kCntMembers);
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    const uint32_t n_mem = dm->h_cnt[kCntMembers];
+    DM_RESERVE(dm->k0, 4ull * n_mem);
+    DM_RESERVE(dm->k1, 4ull * n_mem);
+    DM_RESERVE(dm->v0, 4ull * n_mem);
+    DM_RESERVE(dm->v1, 4ull * n_mem);
+    uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
+    hipLaunchKernelGGL(dm_members_write, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const float4 *)xy, npts, pa, m_off, k0, v0,
+                       dm->d_cnt);
+    int bits = 1;
+    while ((1ull << bits) < ncid) ++bits;
+    if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;
+    DM_RESERVE(dm->c_flag, 4ull * std::max(n_mem, n_entries));
+    DM_RESERVE(dm->c_scan, 4ull * std::max(n_mem, n_entries));
+    DM_RESERVE(dm->seg_start, 4ull * (n_mem + 1));
+    DM_RESERVE(dm->seg_key, 4ull * (n_mem + 1));
+    uint32_t *sflag = (uint32_t *)dm->c_flag.ptr, *sscan = (uint32_t *)dm->c_scan.ptr;
+    uint32_t *train_off = (uint32_t *)dm->seg_start.ptr, *seg_key = (uint32_t *)dm->seg_key.ptr;
+    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGridValid, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(dm_heads, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, k1, n_mem, sflag, dm->d_cnt, (int)kCntGridValid);
+    if ((rc = exclusive_scan(dm, sflag, sscan, n_mem)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_seg_starts, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, k1, sflag, sscan, n_mem, train_off, seg_key,
+                       dm->d_cnt, (int)kCntGeo, (int)kCntGridValid);
+    DM_RESERVE(dm->train, 16ull * n_mem);
+    hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, (const float4 *)xy, v1, n_mem,
+                       (float4 *)dm->train.ptr);
+    DM_RESERVE(dm->grid, 4ull * ncid);
+    DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
+    hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, (int32_t *)dm->grid.ptr);
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    if (dm->h_cnt[kCntError]) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
+    const uint32_t n_geo = dm->h_cnt[kCntGeo];
+    S.n_train_blocks = n_geo;
+    const double t2 = wall();
+    S.t_partition = t2 - t1;
+
+    // ---------------- passes over the candidate list (one unless a key repeats) ----------------
+    DM_RESERVE(dm->c_weight, 4ull * n_entries);
+    uint32_t *c_flag = (uint32_t *)dm->c_flag.ptr, *c_weight = (uint32_t *)dm->c_weight.ptr, *c_scan = (uint32_t *)dm->c_scan.ptr;
+    const uint32_t ncell = dm->ncell;
+    for (uint32_t pass = 0; pass < max_occ; ++pass) {
+        const double tp0 = wall();
+        ca.pass = pass;
+        hipLaunchKernelGGL(dm_candidates, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+                           (const uint32_t *)train_off, n_entries, c_flag, c_weight);
+        if ((rc = exclusive_scan(dm, c_flag, c_scan, n_entries)) != LA3DM_OK) return rc;
+        DM_RESERVE(dm->t_key0, 4ull * n_entries);
+        DM_RESERVE(dm->t_ent0, 4ull * n_entries);
+        hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
+                           (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        const uint32_t n_test = dm->h_cnt[kCntTest];
+        if (n_test == 0) continue;
+        S.n_test_blocks += n_test;
+        S.n_passes = pass + 1;
+        DM_RESERVE(dm->t_key1, 4ull * n_test);
+        DM_RESERVE(dm->t_ent1, 4ull * n_test);
+        // heaviest test blocks first (the blocks are independent: order only balances the launch)
+        if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
+                             (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
+            return rc;
+        DM_RESERVE(dm->t_blockkey, 8ull * n_test);
+        DM_RESERVE(dm->t_center, 12ull * n_test);
+        DM_RESERVE(dm->t_nbr, 28ull * n_test);
+        DM_RESERVE(dm->t_slot, 4ull * n_test);
+        hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+                           (const uint32_t *)dm->t_ent1.ptr, dm->d_cnt, (long long *)dm->t_blockkey.ptr, (float *)dm->t_center.ptr,
+                           (int32_t *)dm->t_nbr.ptr);
+        // blocks: find or create (bgkoctomap.cpp:298-305)
+        if ((rc = grow_pool(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
+        if ((rc = grow_table(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
+        DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntBlocks, &dm->n_blocks, 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const long long *)dm->t_blockkey.ptr,
+                           dm->d_cnt, dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key,
+                           (uint32_t *)dm->t_slot.ptr);
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        const uint32_t nb_new = dm->h_cnt[kCntBlocks];
+        if (nb_new > dm->n_blocks) {
+            const size_t first = (size_t)dm->n_blocks * dm->npb, count = (size_t)(nb_new - dm->n_blocks) * dm->npb;
+            hipLaunchKernelGGL(dm_pool_init, dim3(cdiv(count, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S, first, count,
+                               dm->init_A, dm->init_B);
+            dm->n_blocks = nb_new;
+        }
+        // pack: leaves in LeafIterator order
+        DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
+        DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
+        const size_t max_leaves = (size_t)n_test * ncell;
+        DM_RESERVE(dm->leaf_key, 4 * max_leaves);
+        DM_RESERVE(dm->leaf_alpha, 4 * max_leaves);
+        DM_RESERVE(dm->leaf_beta, 4 * max_leaves);
+        DM_RESERVE(dm->leaf_node, 4 * max_leaves);
+        DM_RESERVE(dm->leaf_state, max_leaves);
+        uint32_t *nleaf = (uint32_t *)dm->nleaf.ptr, *leaf_off = (uint32_t *)dm->leaf_off.ptr;
+        DM_TRY(hipMemsetAsync(nleaf + n_test, 0, 4, st));
+        hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
+        if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
+        hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
+        hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                           (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                           (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr);
+        double tp1 = tp0;
+        if (getenv("LA3DM_TIMING")) {
+            DM_TRY(hipStreamSynchronize(st));
+            tp1 = wall();
+            S.t_pack += tp1 - tp0;
+        }
+        // E: predict + fuse
+        la3dm_bgk_scan s;
+        memset(&s, 0, sizeof(s));
+        s.train_xyzy = (const float *)dm->train.ptr;
+        s.train_off = train_off;
+        s.n_train_pts = n_mem;
+        s.n_train_blk = n_geo;
+        s.nbr = (const int32_t *)dm->t_nbr.ptr;
+        s.blk_center = (const float *)dm->t_center.ptr;
+        s.leaf_off = leaf_off;
+        s.n_test_blk = n_test;
+        s.n_leaf = (uint32_t)std::min<size_t>(max_leaves, 0xFFFFFFFFu);
+        s.leaf_key = (const uint32_t *)dm->leaf_key.ptr;
+        s.alpha = (float *)dm->leaf_alpha.ptr;
+        s.beta = (float *)dm->leaf_beta.ptr;
+        s.state = (uint8_t *)dm->leaf_state.ptr;
+        s.flags = 0;
+        rc = ctx->p.variant == 1 ? la3dm_gp_scan_device(ctx, &s, st, nullptr) : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
+        if (rc != LA3DM_OK) return rc;
+        double tp2 = tp1;
+        if (getenv("LA3DM_TIMING")) {
+            DM_TRY(hipStreamSynchronize(st));
+            tp2 = wall();
+            S.t_kernel += tp2 - tp1;
+        }
+        // f3: write-back + prune
+        hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
+                           (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
+                           (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
+        hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, dm->A,
+                           dm->B, dm->S, dm->npb, dm->depth);
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        S.voxel_updates += dm->h_cnt[kCntLeaves];
+        if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;
+    }
+    DM_TRY(hipGetLastError());
+    S.n_blocks = dm->n_blocks;
+    S.t_total = wall() - t0;
+    if (!getenv("LA3DM_TIMING")) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit
+    if (stats_out) *stats_out = S;
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride, const float origin[3],
+                                        float ds_resolution, float free_resolution, float max_range,
+                                        la3dm_devmap_stats *stats_out) {
+    if (!dm || (n && !xyz) || stride < 3) return LA3DM_ERR_ARG;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    DM_RESERVE(dm->cloud, 12ull * n);
+    if (n) {
+        if (stride == 3) {
+            DM_TRY(hipMemcpyAsync(dm->cloud.ptr, xyz, 12ull * n, hipMemcpyHostToDevice, dm->ctx->stream));
+        } else {
+            DM_TRY(hipMemcpy2DAsync(dm->cloud.ptr, 12, xyz, 4ull * stride, 12, n, hipMemcpyHostToDevice, dm->ctx->stream));
+        }
+    }
+    return la3dm_devmap_insert_pointcloud_device(dm, (const float *)dm->cloud.ptr, n, origin, ds_resolution, free_resolution,
+                                                 max_range, stats_out);
+}
+
+int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nodes_per_block) {
+    if (!dm) return LA3DM_ERR_ARG;
+    if (n_blocks) *n_blocks = dm->n_blocks;
+    if (nodes_per_block) *nodes_per_block = dm->npb;
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, uint8_t *S) {
+    if (!dm) return LA3DM_ERR_ARG;
+    if (dm->n_blocks == 0) return LA3DM_OK;
+    if (!keys || !A || !B || !S) return LA3DM_ERR_ARG;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    const size_t nn = (size_t)dm->n_blocks * dm->npb;
+    DM_TRY(hipMemcpyAsync(keys, dm->blk_key, 8ull * dm->n_blocks, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(A, dm->A, 4 * nn, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(B, dm->B, 4 * nn, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(S, dm->S, nn, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint32_t *n) {
+    if (!dm || !n) return LA3DM_ERR_ARG;
+    *n = dm->n_xy;
+    if (!xyzy || cap < dm->n_xy) return dm->n_xy ? LA3DM_ERR_ARG : LA3DM_OK;
+    if (dm->n_xy == 0) return LA3DM_OK;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    DM_TRY(hipMemcpyAsync(xyzy, dm->xy.ptr, 16ull * dm->n_xy, hipMemcpyDeviceToHost, dm->ctx->stream));
+    DM_TRY(hipStreamSynchronize(dm->ctx->stream));
+    return LA3DM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,642 @@
+// devmap_kernels.h — HIP kernels (gfx950, wave64) of the device-resident map: the stages of
+// BGKOctoMap::insert_pointcloud on either side of the predict/fuse kernel.
+//
+// Reference behaviour followed (file:line relative to RobustFieldAutonomyLab/la3dm); every stage is
+// bit-identical to the host implementation in host/bgkoctomap.cpp, which the parity tests pin to the oracle:
+//   f1  get_training_data / beam_sample / downsample   src/bgkoctomap/bgkoctomap.cpp:383-458
+//       (pcl::VoxelGrid semantics: cell = floor(p * inv_leaf) - floor(min * inv_leaf), cells in ascending
+//        linear index, centroid = fp32 sum in cloud order / count)
+//   f2  bbox / get_blocks_in_bbox / closed-box gather   src/bgkoctomap/bgkoctomap.cpp:234-284, 464-552,
+//       include/common/rtree.h:1519-1532; hashing src/bgkoctomap/bgkblock.cpp:73-130
+//   f3  leaf enumeration (LeafIterator order)            include/bgkoctomap/bgkoctree.h:62-147
+//       OcTree::prune                                    src/bgkoctomap/bgkoctree.cpp:101-148
+//       node write-back (Occupancy::update results)      src/bgkoctomap/bgkoctree_node.cpp:31-44
+//
+// These are HBM/latency-bound integer and gather kernels (no MFMA work here): coalesced streams where the
+// data allows it, ballot/mbcnt compaction inside a wave, device-wide sorts and scans from rocPRIM/hipCUB.
+// Floating-point expressions follow the host code operation for operation (-ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace la3dm_dev {
+
+constexpr uint32_t kInvalidCell = 0xFFFFFFFFu;
+constexpr uint8_t kStatePruned = 3;   // State::PRUNED
+constexpr uint8_t kStateUnknown = 2;  // State::UNKNOWN
+constexpr uint8_t kClassifiedBit = 0x80;
+
+// (8^d - 1) / 7: first node of layer d in the depth-major node order of a block
+__device__ __forceinline__ uint32_t dm_layer_base(uint32_t depth) { return 0x249249u & ((1u << (3u * depth)) - 1u); }
+
+// counters[] slots (device u32 array mirrored into pinned host memory)
+enum DevCounter {
+    kCntGridSegs = 0,    // occupied voxel-grid cells of the current filter call
+    kCntGridValid = 1,   // finite points of the current filter call
+    kCntKept = 2,        // hits that passed the range gate
+    kCntFreeRaw = 3,     // beam samples before the second filter
+    kCntMembers = 4,     // (block, point) membership pairs
+    kCntGeo = 5,         // blocks that geometrically hold points
+    kCntTest = 6,        // test blocks of the current pass
+    kCntLeaves = 7,      // leaves of the current pass (U)
+    kCntBlocks = 8,      // blocks in the pool
+    kCntError = 9,       // sticky error bits
+    kCntTrainReads = 10, // low 32 bits of sum of neighbourhood sizes
+    kCntTrainReadsHi = 11,
+    kCntWords = 16
+};
+
+struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call
+    int lo[3];
+    int span[3];
+    int m1, m2;
+    int passthrough;  // 1: index space overflows int32 -> PCL hands the input back
+    int empty;        // 1: no finite point
+};
+
+// order-preserving float <-> uint32 map for atomicMin/atomicMax
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e);
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+// ---- min / max of the finite points; mm[0..2] = enc(min), mm[3..5] = enc(max) --------------------------
+__global__ void dm_minmax_init(uint32_t *mm) {
+    if (threadIdx.x < 3) mm[threadIdx.x] = 0xFFFFFFFFu;
+    else if (threadIdx.x < 6) mm[threadIdx.x] = 0u;
+}
+
+template <int kStride>
+__global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, uint32_t n, uint32_t *mm) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool any = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = p[(size_t)kStride * i], y = p[(size_t)kStride * i + 1], z = p[(size_t)kStride * i + 2];
+        if (!finite3(x, y, z)) continue;
+        any = true;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        }
+    }
+    any = __any(any);
+    if ((threadIdx.x & 63) == 0 && any) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&mm[a], enc_f32(mn[a]));
+            atomicMax(&mm[3 + a], enc_f32(mx[a]));
+        }
+    }
+}
+
+// decoded min/max for the host (bbox of the training set)
+__global__ void dm_minmax_decode(const uint32_t *mm, float *out) {
+    if (threadIdx.x < 6) out[threadIdx.x] = dec_f32(mm[threadIdx.x]);
+}
+
+__global__ void dm_grid_params(const uint32_t *mm, float inv, GridParams *gp) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    GridParams g;
+    g.passthrough = 0;
+    g.empty = mm[0] == 0xFFFFFFFFu && mm[3] == 0u;
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = dec_f32(mm[a]);
+        mx[a] = dec_f32(mm[3 + a]);
+    }
+    if (g.empty) {
+        for (int a = 0; a < 3; ++a) g.lo[a] = 0, g.span[a] = 1;
+        g.m1 = g.m2 = 1;
+        *gp = g;
+        return;
+    }
+    const long long ex = (long long)((mx[0] - mn[0]) * inv) + 1, ey = (long long)((mx[1] - mn[1]) * inv) + 1,
+                    ez = (long long)((mx[2] - mn[2]) * inv) + 1;
+    if (ex * ey * ez > 2147483647ll) g.passthrough = 1;
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = (int)floorf(mn[a] * inv);
+        g.span[a] = (int)floorf(mx[a] * inv) - g.lo[a] + 1;
+    }
+    g.m1 = g.span[0];
+    g.m2 = g.span[0] * g.span[1];
+    *gp = g;
+}
+
+// cell index of every point (kInvalidCell for non-finite points), value = cloud index
+__global__ __launch_bounds__(256) void dm_grid_cells(const float *__restrict__ p, uint32_t n, float inv,
+                                                    const GridParams *__restrict__ gp, uint32_t *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = p[3 * (size_t)i], y = p[3 * (size_t)i + 1], z = p[3 * (size_t)i + 2];
+    uint32_t cell = kInvalidCell;
+    if (finite3(x, y, z)) {
+        const int c0 = (int)(floorf(x * inv) - (float)gp->lo[0]);
+        const int c1 = (int)(floorf(y * inv) - (float)gp->lo[1]);
+        const int c2 = (int)(floorf(z * inv) - (float)gp->lo[2]);
+        cell = (uint32_t)(c0 + c1 * gp->m1 + c2 * gp->m2);
+    }
+    keys[i] = cell;
+    vals[i] = i;
+}
+
+// head flags of a sorted key array (invalid keys sort last); also records the number of valid entries
+__global__ __launch_bounds__(256) void dm_heads(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *flag,
+                                               uint32_t *counters, int valid_slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    const bool valid = k != kInvalidCell;
+    flag[i] = (valid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+    if (valid && (i + 1 == n || keys[i + 1] == kInvalidCell)) counters[valid_slot] = i + 1;
+}
+
+// seg_start[seg] = first sorted position of segment seg; seg_key[seg] = its key; also the total
+__global__ __launch_bounds__(256) void dm_seg_starts(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ flag,
+                                                    const uint32_t *__restrict__ scan, uint32_t n, uint32_t *seg_start,
+                                                    uint32_t *seg_key, uint32_t *counters, int seg_slot, int valid_slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) {
+        seg_start[scan[i]] = i;
+        if (seg_key) seg_key[scan[i]] = keys[i];
+    }
+    if (i + 1 == n) {
+        const uint32_t nseg = scan[i] + flag[i];
+        counters[seg_slot] = nseg;
+        seg_start[nseg] = counters[valid_slot];  // written by dm_heads (earlier launch)
+    }
+}
+
+// Centroid of one voxel-grid cell: fp32 sums in cloud order (the sort is stable, values ascend inside a
+// segment).  One wave per segment: the lanes gather a batch of 64 points, then the sums run through the
+// batch serially (v_readlane broadcast, uniform accumulators) — the cell next to the sensor holds one
+// sample per beam, so the chain must not be a dependent global-load chain.
+__global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict__ p, const uint32_t *__restrict__ vals,
+                                                        const uint32_t *__restrict__ seg_start,
+                                                        const uint32_t *__restrict__ counters, int seg_slot, float *out) {
+    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (seg >= counters[seg_slot]) return;
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_start[seg]), s1 = __builtin_amdgcn_readfirstlane(seg_start[seg + 1]);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (uint32_t b = s0; b < s1; b += 64) {
+        const uint32_t nb = min(64u, s1 - b);
+        float x = 0.f, y = 0.f, z = 0.f;
+        if ((uint32_t)lane < nb) {
+            const uint32_t v = vals[b + lane];
+            x = p[3 * (size_t)v];
+            y = p[3 * (size_t)v + 1];
+            z = p[3 * (size_t)v + 2];
+        }
+        if (nb == 64u) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                sx += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), j));
+                sy += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), j));
+                sz += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), j));
+            }
+        } else {
+            for (uint32_t j = 0; j < nb; ++j) {
+                sx += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), j));
+                sy += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), j));
+                sz += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), j));
+            }
+        }
+    }
+    if (lane == 0) {
+        const float cnt = (float)(s1 - s0);
+        out[3 * (size_t)seg] = sx / cnt;
+        out[3 * (size_t)seg + 1] = sy / cnt;
+        out[3 * (size_t)seg + 2] = sz / cnt;
+    }
+}
+
+// ---- beam sampling (bgkoctomap.cpp:383-417, 433-458) ------------------------------------------------
+struct BeamArgs {
+    float ox, oy, oz;
+    float free_res;
+    float max_range;
+};
+
+__device__ __forceinline__ float f32_sqrt_cr(float x) {  // correctly rounded (== (float)sqrt((double)x)):
+    return sqrtf(x);                                      // hipcc's default f32 sqrt is IEEE
+}
+
+// number of free-space samples of one beam: the origin, every free_res, one sample free_res short of the hit
+__device__ __forceinline__ uint32_t beam_count(float l, float fr) {
+    uint32_t c = 1;
+    for (float d = fr; d < l; d += fr) ++c;
+    if (l > fr) ++c;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
+                                                    uint32_t *nfree) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
+    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+    const float s = dx * dx + dy * dy + dz * dz;
+    bool k = true;
+    // point3f::norm() > max_range in f64: sqrt((double)s) > R  <=>  s > R*R (R*R is exact in f64 and the
+    // gap between a float s and R*R is far above half an ulp of the f64 root)
+    if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);
+    keep[i] = k ? 1u : 0u;
+    nfree[i] = k ? beam_count(f32_sqrt_cr(s), a.free_res) : 0u;
+}
+
+// hits that pass the gate -> xy (label 1) in order; their beam samples -> frees (xyz) in order
+__global__ __launch_bounds__(256) void dm_beam_write(const float *__restrict__ hits, uint32_t n, BeamArgs a,
+                                                    const uint32_t *__restrict__ keep,
+                                                    const uint32_t *__restrict__ keep_off,
+                                                    const uint32_t *__restrict__ free_off, float4 *xy, float *frees) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
+    xy[keep_off[i]] = make_float4(x, y, z, 1.0f);
+    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+    const float l = f32_sqrt_cr(dx * dx + dy * dy + dz * dz);
+    const float nx = dx / l, ny = dy / l, nz = dz / l;
+    float *f = frees + 3 * (size_t)free_off[i];
+    f[0] = a.ox; f[1] = a.oy; f[2] = a.oz;
+    f += 3;
+    for (float d = a.free_res; d < l; d += a.free_res) {
+        f[0] = a.ox + nx * d; f[1] = a.oy + ny * d; f[2] = a.oz + nz * d;
+        f += 3;
+    }
+    if (l > a.free_res) {
+        const float d = l - a.free_res;
+        f[0] = a.ox + nx * d; f[1] = a.oy + ny * d; f[2] = a.oz + nz * d;
+    }
+}
+
+// total = off[n-1] + cnt[n-1] of an exclusive scan
+__global__ void dm_scan_total(const uint32_t *off, const uint32_t *cnt, uint32_t n, uint32_t *counters, int slot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    counters[slot] = n ? off[n - 1] + cnt[n - 1] : 0u;
+}
+
+__global__ __launch_bounds__(256) void dm_append_frees(const float *__restrict__ pts, uint32_t n, uint32_t base, float label,
+                                                      float4 *xy) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    xy[base + i] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], label);
+}
+
+// ---- partition (stage B..D) -----------------------------------------------------------------------------
+struct PartArgs {
+    float bs, half;        // block size, size / 2
+    int g0[3];             // biased block index of grid cell 0 on each axis
+    int gn[3];             // grid extent
+    const uint8_t *mult[3];  // multiplicity of each biased index in the float-stepped candidate sequence,
+                             // indexed by (idx - g0[a]); 0 = not a candidate index
+};
+
+__device__ __forceinline__ long long axis_index(float v, float bs) {  // bgkblock.cpp:73-77, one axis
+    return (long long)((double)v / (double)bs + 524288.5);
+}
+__device__ __forceinline__ float axis_center(long long i, float bs) {  // bgkblock.cpp:79-83
+    return (float)(i - 524288) * bs;
+}
+
+struct AxisCandD {
+    int idx[3];
+    int n;
+};
+// biased block indices whose CLOSED fp32 box [c - h, c + h] holds v (what an R-tree box query sees)
+__device__ __forceinline__ AxisCandD axis_candidates_dev(float v, float bs, float h) {
+    AxisCandD r;
+    r.n = 0;
+    const long long i0 = axis_index(v, bs);
+    for (long long i = i0 - 1; i <= i0 + 1; ++i) {
+        const float c = axis_center(i, bs);
+        if (c - h <= v && v <= c + h) r.idx[r.n++] = (int)i;
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool grid_cid(const PartArgs &a, int ix, int iy, int iz, uint32_t &cid) {
+    const int x = ix - a.g0[0], y = iy - a.g0[1], z = iz - a.g0[2];
+    if ((unsigned)x >= (unsigned)a.gn[0] || (unsigned)y >= (unsigned)a.gn[1] || (unsigned)z >= (unsigned)a.gn[2]) return false;
+    cid = ((uint32_t)x * (uint32_t)a.gn[1] + (uint32_t)y) * (uint32_t)a.gn[2] + (uint32_t)z;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void dm_members_count(const float4 *__restrict__ xy, uint32_t n, PartArgs a, uint32_t *cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = xy[i];
+    const AxisCandD ax = axis_candidates_dev(p.x, a.bs, a.half), ay = axis_candidates_dev(p.y, a.bs, a.half),
+                    az = axis_candidates_dev(p.z, a.bs, a.half);
+    cnt[i] = (uint32_t)(ax.n * ay.n * az.n);
+}
+
+__global__ __launch_bounds__(256) void dm_members_write(const float4 *__restrict__ xy, uint32_t n, PartArgs a,
+                                                       const uint32_t *__restrict__ off, uint32_t *keys, uint32_t *vals,
+                                                       uint32_t *counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = xy[i];
+    const AxisCandD ax = axis_candidates_dev(p.x, a.bs, a.half), ay = axis_candidates_dev(p.y, a.bs, a.half),
+                    az = axis_candidates_dev(p.z, a.bs, a.half);
+    uint32_t o = off[i];
+    for (int u = 0; u < ax.n; ++u)
+        for (int v = 0; v < ay.n; ++v)
+            for (int w = 0; w < az.n; ++w) {
+                uint32_t cid = 0;
+                if (!grid_cid(a, ax.idx[u], ay.idx[v], az.idx[w], cid)) {
+                    atomicOr(&counters[kCntError], 1u);  // a point outside the index grid: cannot happen
+                    cid = 0;
+                }
+                keys[o] = cid;
+                vals[o] = i;
+                ++o;
+            }
+}
+
+__global__ __launch_bounds__(256) void dm_gather_train(const float4 *__restrict__ xy, const uint32_t *__restrict__ vals,
+                                                      uint32_t n, float4 *train) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) train[i] = xy[vals[i]];
+}
+
+// grid[cid] = segment (training block) index; -1 elsewhere (memset before)
+__global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ seg_key, const uint32_t *__restrict__ counters,
+                                                  int32_t *grid) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < counters[kCntGeo]) grid[seg_key[s]] = (int32_t)s;
+}
+
+struct CandArgs {
+    PartArgs part;
+    const int *seq[3];    // float-stepped candidate sequence per axis (biased indices, repeats kept)
+    const uint8_t *rank[3];  // occurrence number of each sequence entry among equal indices
+    int nseq[3];
+    uint32_t pass;        // occurrence number handled by this pass
+};
+
+// key -> the 7 ExtendedBlock members (self, +x, -x, +y, -y, +z, -z) by the reference's float path
+// (centre = (idx - 524288) * size, neighbour = re-hash of centre +- size), bgkblock.cpp:85-101
+__device__ __forceinline__ void extended_indices(int ix, int iy, int iz, float bs, int e[7][3]) {
+    const float cx = axis_center(ix, bs), cy = axis_center(iy, bs), cz = axis_center(iz, bs);
+    e[0][0] = ix; e[0][1] = iy; e[0][2] = iz;
+    const int x0 = (int)axis_index(0 + cx, bs), y0 = (int)axis_index(0 + cy, bs), z0 = (int)axis_index(0 + cz, bs);
+    e[1][0] = (int)axis_index(bs + cx, bs);  e[1][1] = y0; e[1][2] = z0;
+    e[2][0] = (int)axis_index(-bs + cx, bs); e[2][1] = y0; e[2][2] = z0;
+    e[3][0] = x0; e[3][1] = (int)axis_index(bs + cy, bs);  e[3][2] = z0;
+    e[4][0] = x0; e[4][1] = (int)axis_index(-bs + cy, bs); e[4][2] = z0;
+    e[5][0] = x0; e[5][1] = y0; e[5][2] = (int)axis_index(bs + cz, bs);
+    e[6][0] = x0; e[6][1] = y0; e[6][2] = (int)axis_index(-bs + cz, bs);
+}
+
+// one thread per entry of the candidate list (x-major, then y, then z — get_blocks_in_bbox order):
+// flag = "this entry is a test block of this pass", weight = training points in its 7-neighbourhood
+__global__ __launch_bounds__(256) void dm_candidates(CandArgs a, const int32_t *__restrict__ grid,
+                                                    const uint32_t *__restrict__ train_off, uint32_t n_entries,
+                                                    uint32_t *flag, uint32_t *weight) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint32_t kc = e % (uint32_t)a.nseq[2], kb = (e / (uint32_t)a.nseq[2]) % (uint32_t)a.nseq[1],
+                   ka = e / ((uint32_t)a.nseq[2] * (uint32_t)a.nseq[1]);
+    const int ix = a.seq[0][ka], iy = a.seq[1][kb], iz = a.seq[2][kc];
+    const PartArgs &p = a.part;
+    const uint32_t my = p.mult[1][iy - p.g0[1]], mz = p.mult[2][iz - p.g0[2]];
+    const uint32_t occ = ((uint32_t)a.rank[0][ka] * my + (uint32_t)a.rank[1][kb]) * mz + (uint32_t)a.rank[2][kc];
+    int eb[7][3];
+    extended_indices(ix, iy, iz, p.bs, eb);
+    bool any = false;
+    uint32_t w = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        uint32_t cid;
+        if (!grid_cid(p, eb[q][0], eb[q][1], eb[q][2], cid)) continue;
+        const int32_t s = grid[cid];
+        if (s < 0) continue;
+        any = true;  // the block geometrically holds points (R-tree hit)
+        const bool cand = p.mult[0][eb[q][0] - p.g0[0]] && p.mult[1][eb[q][1] - p.g0[1]] && p.mult[2][eb[q][2] - p.g0[2]];
+        if (cand) w += train_off[s + 1] - train_off[s];  // ... and was trained (it is in the candidate list)
+    }
+    flag[e] = (any && occ == a.pass) ? 1u : 0u;
+    weight[e] = w;
+}
+
+// compacted, ordered list of test entries; sort key = heaviest first (stable)
+__global__ __launch_bounds__(256) void dm_test_compact(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan,
+                                                      const uint32_t *__restrict__ weight, uint32_t n_entries,
+                                                      uint32_t *t_key, uint32_t *t_entry, uint32_t *counters) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    if (flag[e]) {
+        t_key[scan[e]] = 0xFFFFFFFFu - weight[e];
+        t_entry[scan[e]] = e;
+    }
+    if (e + 1 == n_entries) counters[kCntTest] = scan[e] + flag[e];
+}
+
+// per test block (heaviest first): key, centre, neighbour table (training-block index or -1)
+__global__ __launch_bounds__(256) void dm_test_build(CandArgs a, const int32_t *__restrict__ grid,
+                                                    const uint32_t *__restrict__ t_entry, const uint32_t *__restrict__ counters,
+                                                    long long *t_blockkey, float *center, int32_t *nbr) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= counters[kCntTest]) return;
+    const uint32_t e = t_entry[t];
+    const uint32_t kc = e % (uint32_t)a.nseq[2], kb = (e / (uint32_t)a.nseq[2]) % (uint32_t)a.nseq[1],
+                   ka = e / ((uint32_t)a.nseq[2] * (uint32_t)a.nseq[1]);
+    const int ix = a.seq[0][ka], iy = a.seq[1][kb], iz = a.seq[2][kc];
+    const PartArgs &p = a.part;
+    t_blockkey[t] = ((long long)ix << 40) | ((long long)iy << 20) | (long long)iz;
+    center[3 * (size_t)t] = axis_center(ix, p.bs);
+    center[3 * (size_t)t + 1] = axis_center(iy, p.bs);
+    center[3 * (size_t)t + 2] = axis_center(iz, p.bs);
+    int eb[7][3];
+    extended_indices(ix, iy, iz, p.bs, eb);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        int32_t s = -1;
+        uint32_t cid;
+        if (grid_cid(p, eb[q][0], eb[q][1], eb[q][2], cid)) {
+            const bool cand = p.mult[0][eb[q][0] - p.g0[0]] && p.mult[1][eb[q][1] - p.g0[1]] && p.mult[2][eb[q][2] - p.g0[2]];
+            if (cand) s = grid[cid];
+        }
+        nbr[7 * (size_t)t + q] = s;
+    }
+}
+
+// ---- block table (open addressing, linear probing) and pool ------------------------------------------------
+constexpr long long kEmptyKey = -1;
+
+__device__ __forceinline__ uint32_t hash_key64(long long k, uint32_t mask) {
+    unsigned long long x = (unsigned long long)k;
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    return (uint32_t)x & mask;
+}
+
+// find-or-create; new blocks take consecutive pool slots [old count, new count)
+__global__ __launch_bounds__(256) void dm_table_insert(const long long *__restrict__ keys, const uint32_t *__restrict__ counters,
+                                                      long long *tab_key, uint32_t *tab_val, uint32_t mask,
+                                                      uint32_t *n_blocks, long long *blk_key, uint32_t *slot) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= counters[kCntTest]) return;
+    const long long k = keys[t];
+    uint32_t h = hash_key64(k, mask);
+    for (;;) {
+        const long long cur = tab_key[h];
+        if (cur == k) {
+            // the creator may not have published the slot yet only if another thread of THIS launch holds the
+            // same key — keys of one pass are distinct, so the value is from an earlier launch
+            slot[t] = tab_val[h];
+            return;
+        }
+        if (cur == kEmptyKey) {
+            const long long prev = (long long)atomicCAS((unsigned long long *)&tab_key[h], (unsigned long long)kEmptyKey, (unsigned long long)k);
+            if (prev == kEmptyKey) {
+                const uint32_t s = atomicAdd(n_blocks, 1u);
+                tab_val[h] = s;
+                blk_key[s] = k;
+                slot[t] = s;
+                return;
+            }
+            if (prev == k) {
+                slot[t] = tab_val[h];
+                return;
+            }
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void dm_table_rebuild(const long long *__restrict__ blk_key, uint32_t n, long long *tab_key,
+                                                       uint32_t *tab_val, uint32_t mask) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const long long k = blk_key[s];
+    uint32_t h = hash_key64(k, mask);
+    for (;;) {
+        const long long prev = (long long)atomicCAS((unsigned long long *)&tab_key[h], (unsigned long long)kEmptyKey, (unsigned long long)k);
+        if (prev == kEmptyKey) {
+            tab_val[h] = s;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+// default nodes of new blocks: Occupancy() = {prior A, prior B, UNKNOWN, not classified}
+__global__ __launch_bounds__(256) void dm_pool_init(float *A, float *B, uint8_t *S, size_t first, size_t count, float a0, float b0) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    A[first + i] = a0;
+    B[first + i] = b0;
+    S[first + i] = kStateUnknown;
+}
+
+// Leaf of the finest-layer cell c of one block: climb while the node is PRUNED (a collapsed sibling group
+// lives on in its parent).  Returns the node offset inside the block and the leaf's OcTreeHashKey.
+__device__ __forceinline__ void covering_leaf(const uint8_t *__restrict__ Sb, uint32_t depth_last, uint32_t c, uint32_t &d,
+                                              uint32_t &i) {
+    d = depth_last;
+    i = c;
+    while (d > 0 && (Sb[dm_layer_base(d) + i] & 7u) == kStatePruned) {
+        --d;
+        i >>= 3;
+    }
+}
+
+// Leaves of the test blocks in LeafIterator order (descending DFS = descending finest-cell interval).
+// One wave per block, 64 finest cells per trip from the top; kEmit = false counts, true writes.
+template <bool kEmit>
+__global__ __launch_bounds__(256) void dm_leaves(const uint32_t *__restrict__ slot, const uint32_t *__restrict__ counters,
+                                                const uint8_t *__restrict__ S, const float *__restrict__ A,
+                                                const float *__restrict__ B, uint32_t npb, uint32_t block_depth,
+                                                uint32_t *nleaf, const uint32_t *__restrict__ leaf_off, uint32_t *leaf_key,
+                                                float *alpha, float *beta, uint32_t *leaf_node) {
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= counters[kCntTest]) return;
+    const size_t base = (size_t)slot[t] * npb;
+    const uint8_t *Sb = S + base;
+    const uint32_t dl = block_depth - 1, ncell = 1u << (3 * dl);
+    uint32_t out = kEmit ? leaf_off[t] : 0u;
+    for (uint32_t top = ncell; top > 0; top -= min(top, 64u)) {
+        const bool in = (uint32_t)lane < top;
+        const uint32_t c = in ? top - 1u - lane : 0u;  // lane order = descending cell index
+        uint32_t d, i;
+        covering_leaf(Sb, dl, c, d, i);
+        const uint32_t span = 3u * (dl - d);
+        const bool head = in && c == (((i + 1u) << span) - 1u);  // highest cell of the leaf's interval
+        const unsigned long long m = __ballot(head);
+        if (kEmit && head) {
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            const uint32_t node = dm_layer_base(d) + i;
+            leaf_key[out + r] = (d << 16) + i;
+            alpha[out + r] = A[base + node];
+            beta[out + r] = B[base + node];
+            leaf_node[out + r] = (uint32_t)(base + node);
+        }
+        out += (uint32_t)__popcll(m);
+    }
+    if (!kEmit && lane == 0) nleaf[t] = out;
+}
+
+// write-back of the leaves Occupancy::update ran for (state bit 7)
+__global__ __launch_bounds__(256) void dm_commit(const uint32_t *__restrict__ counters, const uint32_t *__restrict__ leaf_node,
+                                                const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                const uint8_t *__restrict__ state, float *A, float *B, uint8_t *S) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= counters[kCntLeaves]) return;
+    const uint8_t st = state[l];
+    if (!(st & 0x80u)) return;
+    const uint32_t node = leaf_node[l];
+    A[node] = alpha[l];
+    B[node] = beta[l];
+    S[node] = (uint8_t)((st & 3u) | kClassifiedBit);
+}
+
+// OcTree::prune for the test blocks (bgkoctree.cpp:101-148): bottom-up, a sibling group whose eight members
+// share one non-UNKNOWN state collapses into its parent (a copy of child 0), the children become PRUNED.
+// One wave per block; lanes = sibling groups of the layer.
+__global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slot, const uint32_t *__restrict__ counters,
+                                               float *A, float *B, uint8_t *S, uint32_t npb, uint32_t block_depth) {
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= counters[kCntTest]) return;
+    const size_t base = (size_t)slot[t] * npb;
+    for (int depth = (int)block_depth - 1; depth > 0; --depth) {
+        const uint32_t lb = dm_layer_base(depth), pb = dm_layer_base(depth - 1), ngroup = 1u << (3 * (depth - 1));
+        for (uint32_t g = lane; g < ngroup; g += 64) {
+            const size_t c0 = base + lb + 8u * g;
+            const uint8_t s0 = S[c0];
+            const uint8_t st0 = s0 & 7u;
+            if (st0 == kStatePruned || st0 == kStateUnknown) continue;
+            bool same = true;
+#pragma unroll
+            for (int c = 1; c < 8; ++c) same &= (S[c0 + c] & 7u) == st0;
+            if (!same) continue;
+            const size_t par = base + pb + g;
+            A[par] = A[c0];
+            B[par] = B[c0];
+            S[par] = (uint8_t)((S[par] & kClassifiedBit) | st0);  // the node copy does not carry `classified`
+#pragma unroll
+            for (int c = 0; c < 8; ++c) S[c0 + c] = (uint8_t)((S[c0 + c] & ~7u) | kStatePruned);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
+}  // namespace la3dm_dev

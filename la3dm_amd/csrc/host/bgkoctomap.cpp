@@ -135,6 +135,21 @@ bool OcTree::is_leaf(unsigned short depth, unsigned short index) const {
     return node_arr[depth + 1] == nullptr || node_arr[depth + 1][index * 8].get_state() == State::PRUNED;
 }
 
+void OcTree::load_nodes(const float *A, const float *B, const uint8_t *S, size_t n) {
+    if (slab == nullptr || n != layer_base(max_depth)) throw std::runtime_error("OcTree::load_nodes: node count mismatch");
+    bool pruned = false;
+    for (size_t i = 0; i < n; ++i) {
+        OcTreeNode &nd = slab[i];
+        nd.m_A = A[i];
+        nd.m_B = B[i];
+        nd.state = (State)(S[i] & 7u);
+        nd.classified = (S[i] & 0x80u) != 0;
+        pruned |= nd.state == State::PRUNED;
+    }
+    for (unsigned d = 0; d < max_depth; ++d) node_arr[d] = slab + layer_base(d);  // layers are never retired here
+    ever_pruned = pruned;
+}
+
 bool OcTree::is_leaf(OcTreeHashKey key) const { return is_leaf((unsigned short)(key >> 16), (unsigned short)(key & 0xFFFF)); }
 
 bool OcTree::search(OcTreeHashKey key) const {
@@ -367,10 +382,58 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
 
 BGKOctoMap::~BGKOctoMap() {
     for (auto &kv : block_arr) delete kv.second;
+    la3dm_devmap_destroy(dmap);
     la3dm_destroy(ctx);
 }
 
+// ------------------------------------------------------------- device-resident mode
+void BGKOctoMap::set_device_resident(bool on) {
+    if (on == (dmap != nullptr)) return;
+    if (!on) {
+        sync_mirror();
+        la3dm_devmap_destroy(dmap);
+        dmap = nullptr;
+        return;
+    }
+    if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::set_device_resident: the map has no GPU context");
+    if (!block_arr.empty()) throw std::runtime_error("BGKOctoMap::set_device_resident: switch modes while the map is empty");
+    if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKOctoMap::set_device_resident: ") + la3dm_last_error(ctx));
+}
+
+// Refresh the host mirror from the device pool: every block's nodes are overwritten with the device
+// state (alpha, beta, state, classified); PRUNED children keep their collapsed parents' leaf role.
+void BGKOctoMap::sync_mirror() const {
+    if (dmap == nullptr || !mirror_dirty) return;
+    uint32_t nb = 0, npb = 0;
+    if (la3dm_devmap_block_count(dmap, &nb, &npb) != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKOctoMap::sync_mirror: ") + la3dm_last_error(ctx));
+    std::vector<int64_t> keys(nb);
+    std::vector<float> A((size_t)nb * npb), B((size_t)nb * npb);
+    std::vector<uint8_t> S((size_t)nb * npb);
+    if (nb && la3dm_devmap_download(dmap, keys.data(), A.data(), B.data(), S.data()) != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKOctoMap::sync_mirror: ") + la3dm_last_error(ctx));
+    for (uint32_t b = 0; b < nb; ++b) {
+        auto it = block_arr.find(keys[b]);
+        if (it == block_arr.end()) it = block_arr.emplace(keys[b], new Block(hash_key_to_block(keys[b]))).first;
+        it->second->load_nodes(&A[(size_t)b * npb], &B[(size_t)b * npb], &S[(size_t)b * npb], npb);
+    }
+    mirror_dirty = false;
+}
+
+std::vector<float> BGKOctoMap::device_training_data() const {
+    std::vector<float> out;
+    if (dmap == nullptr) return out;
+    uint32_t n = 0;
+    la3dm_devmap_training_data(dmap, nullptr, 0, &n);
+    out.resize(4 * (size_t)n);
+    if (n && la3dm_devmap_training_data(dmap, out.data(), n, &n) != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKOctoMap::device_training_data: ") + la3dm_last_error(ctx));
+    return out;
+}
+
 Block *BGKOctoMap::search(BlockHashKey key) const {
+    sync_mirror();
     auto it = block_arr.find(key);
     return it == block_arr.end() ? nullptr : it->second;
 }
@@ -381,6 +444,7 @@ OcTreeNode BGKOctoMap::search(point3f p) const {
 }
 
 void BGKOctoMap::get_bbox(point3f &lim_min, point3f &lim_max) const {
+    sync_mirror();
     lim_min = point3f(0, 0, 0);
     lim_max = point3f(0, 0, 0);
     bool first = true;
@@ -885,6 +949,7 @@ void BGKOctoMap::commit() {
 
 bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                          float free_res, float max_range) {
+    if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::prepare: not available in device-resident mode");
     stats = ScanStats();
     const double t0 = wall();
     get_training_data(xyz, n, stride, origin, ds_resolution, free_res, max_range);
@@ -893,6 +958,7 @@ bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3
 }
 
 bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated) {
+    if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::prepare_training_data: not available in device-resident mode");
     stats = ScanStats();
     xy.assign(xyzy, xyzy + 4 * n);
     for (size_t i = 0; i < n; ++i) (xyzy[4 * i + 3] > 0.5f ? stats.n_hits : stats.n_frees)++;
@@ -903,6 +969,28 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
                                    float free_res, float max_range) {
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_pointcloud: no device context (there is no CPU path)");
+    if (dmap != nullptr) {  // device-resident mode: the whole scan runs on the GPU
+        const float o[3] = {origin.x(), origin.y(), origin.z()};
+        la3dm_devmap_stats ds;
+        if (la3dm_devmap_insert_pointcloud_host(dmap, xyz, (uint32_t)n, (uint32_t)stride, o, ds_resolution, free_res, max_range,
+                                                &ds) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
+        stats = ScanStats();
+        stats.n_hits = ds.n_hits;
+        stats.n_frees = ds.n_frees;
+        stats.n_bbox_blocks = ds.n_bbox_blocks;
+        stats.n_train_blocks = ds.n_train_blocks;
+        stats.n_test_blocks = ds.n_test_blocks;
+        stats.voxel_updates = ds.voxel_updates;
+        stats.t_frontend = ds.t_frontend;
+        stats.t_partition = ds.t_partition;
+        stats.t_pack = ds.t_pack;
+        stats.t_device = ds.t_kernel;
+        stats.t_commit = ds.t_commit;
+        stats.t_total = wall() - t0;
+        mirror_dirty = true;
+        return;
+    }
     if (!prepare(xyz, n, stride, origin, ds_resolution, free_res, max_range)) return;
     const double t1 = wall();
     {
@@ -920,6 +1008,7 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
 void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: no device context (there is no CPU path)");
+    if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: not available in device-resident mode");
     std::vector<float> flat;
     flat.reserve(cloud.size() * 4);
     for (const GPPointType &p : cloud) flat.insert(flat.end(), {p.first.x(), p.first.y(), p.first.z(), p.second});

@@ -136,6 +136,8 @@ public:
     OcTree &operator=(const OcTree &) = delete;
 
     bool prune();
+    /// overwrite every node from flat (alpha, beta, state|classified<<7) arrays in depth-major node order
+    void load_nodes(const float *A, const float *B, const uint8_t *S, size_t n);
     bool is_leaf(OcTreeHashKey key) const;
     bool is_leaf(unsigned short depth, unsigned short index) const;
     bool search(OcTreeHashKey key) const;
@@ -302,6 +304,18 @@ public:
     void commit();
     la3dm_ctx *device_ctx() const { return ctx; }
     const ScanStats &last_stats() const { return stats; }
+
+    // ---- device-resident mode: the block pool lives in HBM and a scan runs start
+    // to finish on the GPU (front end, partition, predict + fuse, write-back, prune — include/la3dm_hip.h,
+    // la3dm_devmap_*).  The host blocks become a mirror that is refreshed lazily, the first time a query
+    // (search, begin_leaf, get_bbox, block_count) follows a scan.  Must be switched on while the map is empty;
+    // insert_training_data and the split prepare()/commit() form stay on the host-orchestrated path and are
+    // refused in this mode.  Results are bit-identical to the host-orchestrated mode.
+    void set_device_resident(bool on);
+    bool is_device_resident() const { return dmap != nullptr; }
+    void sync_mirror() const;
+    /// training set (x, y, z, label) the device front end produced for the last scan
+    std::vector<float> device_training_data() const;
     const std::vector<float> &last_training_data() const { return xy; }  // x,y,z,label
 
     class LeafIterator {
@@ -324,13 +338,19 @@ public:
         std::unordered_map<BlockHashKey, Block *>::const_iterator block_it, end_block;
         OcTree::LeafIterator leaf_it, end_leaf;
     };
-    LeafIterator begin_leaf() const { return LeafIterator(this); }
+    LeafIterator begin_leaf() const {
+        sync_mirror();
+        return LeafIterator(this);
+    }
     LeafIterator end_leaf() const { return LeafIterator(block_arr.cend(), OcTree::LeafIterator()); }
 
     OcTreeNode search(point3f p) const;
     OcTreeNode search(float x, float y, float z) const { return search(point3f(x, y, z)); }
     Block *search(BlockHashKey key) const;
-    size_t block_count() const { return block_arr.size(); }
+    size_t block_count() const {
+        sync_mirror();
+        return block_arr.size();
+    }
     int get_variant() const { return variant; }
 
 protected:
@@ -343,8 +363,10 @@ protected:
     float resolution;
     float block_size;
     unsigned short block_depth;
-    std::unordered_map<BlockHashKey, Block *> block_arr;
+    mutable std::unordered_map<BlockHashKey, Block *> block_arr;
     la3dm_ctx *ctx;
+    la3dm_devmap *dmap = nullptr;
+    mutable bool mirror_dirty = false;
 
     // per-scan buffers (capacity reused across scans)
     std::vector<float> xy;               // training set: x,y,z,label

@@ -159,13 +159,25 @@ int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out) {
     return 0;
 }
 
-uint64_t la3dm_map_training_size(const la3dm_map *m) { return m->map->last_training_data().size() / 4; }
+uint64_t la3dm_map_training_size(const la3dm_map *m) {
+    if (m->map->is_device_resident()) {
+        try {
+            return m->map->device_training_data().size() / 4;
+        } catch (const std::exception &) {
+            return 0;
+        }
+    }
+    return m->map->last_training_data().size() / 4;
+}
 
 int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap) {
-    const std::vector<float> &v = m->map->last_training_data();
-    std::memcpy(xyzy, v.data(), sizeof(float) * std::min<size_t>(v.size(), 4 * cap));
-    return 0;
+    GUARD(const std::vector<float> dev = m->map->is_device_resident() ? m->map->device_training_data() : std::vector<float>();
+          const std::vector<float> &v = m->map->is_device_resident() ? dev : m->map->last_training_data();
+          std::memcpy(xyzy, v.data(), sizeof(float) * std::min<size_t>(v.size(), 4 * cap)); return 0;)
 }
+
+int la3dm_map_set_device_resident(la3dm_map *m, int on) { GUARD(m->map->set_device_resident(on != 0); return 0;) }
+int la3dm_map_is_device_resident(const la3dm_map *m) { return m->map->is_device_resident() ? 1 : 0; }
 
 float la3dm_map_block_size(const la3dm_map *m) { return m->map->get_block_size(); }
 uint64_t la3dm_map_block_count(const la3dm_map *m) { return m->map->block_count(); }

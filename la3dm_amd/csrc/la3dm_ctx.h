@@ -1,0 +1,66 @@
+// la3dm_ctx.h — internal: the device context shared by the translation units of libla3dm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/la3dm_hip.h"
+
+struct Arena {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct la3dm_ctx {
+    la3dm_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;  // used by the host-pointer entry points
+    float4 *d_lut = nullptr;
+    uint32_t lut_count = 0;
+    std::string err;
+    int opt_variant = 0;   // 0 default
+    int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
+    int opt_time_kernel = 0;
+    int opt_waves = 1;  // waves per workgroup (variant 3)
+    int opt_remap = 2;
+    int opt_ablate = 0;  // profiling only: 1 skip kernel evaluation, 2 skip the candidate tests
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
+    size_t ev_used = 0;
+    // scratch (device-pointer path)
+    Arena pts_scaled, nbr_range;
+    Arena gp_loff, gp_totals, gp_L, gp_alpha, gp_v;
+    Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;
+    // staging (host-pointer path)
+    Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,
+        h_diag_out;
+};
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+            return LA3DM_ERR_HIP;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+static inline int arena_reserve(la3dm_ctx *ctx, Arena &a, size_t bytes) {
+    if (bytes <= a.cap) return LA3DM_OK;
+    if (a.ptr) {
+        HIP_TRY(ctx, hipFree(a.ptr));
+        a.ptr = nullptr;
+        a.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&a.ptr, want);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+        a.ptr = nullptr;
+        return LA3DM_ERR_OOM;
+    }
+    a.cap = want;
+    return LA3DM_OK;
+}
+

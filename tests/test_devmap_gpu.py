@@ -1,0 +1,159 @@
+"""GPU parity tests of the device-resident map: front end, block partition,
+leaf enumeration, write-back and prune all run on the GPU (include/la3dm_hip.h, la3dm_devmap_*).
+
+Bar: every stage is integer / order work or strict-fp32 arithmetic in the reference's operation order, so the
+training set, the block/leaf structure and every node (alpha, beta, state, classified) must be BIT-IDENTICAL
+to the CPU oracle — no tolerance anywhere in this file.
+"""
+import numpy as np
+import pytest
+
+from conftest import pcd_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(params, gp=False):
+    import la3dm_amd
+    from oracle import oracle as O
+    if gp:
+        m = la3dm_amd.GPOctoMap(**params, device=0).set_device_resident(True)
+        o = O.OracleGPMap(**params)
+    else:
+        m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+        o = O.OracleMap(**params)
+    assert m.is_device_resident()
+    return m, o
+
+
+def _same(m, o, tag=""):
+    a, b = m.leaves(), o.leaves()
+    assert a["block_key"].size == b["block_key"].size, (tag, a["block_key"].size, b["block_key"].size)
+    for k in ("block_key", "node_key", "loc", "size", "classified", "state"):
+        assert (a[k] == b[k]).all(), (tag, k, int((a[k] != b[k]).sum()))
+    for k in ("A", "B"):
+        assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), (tag, k, int((a[k] != b[k]).sum()),
+                                                                        float(np.abs(a[k] - b[k]).max()))
+
+
+@pytest.mark.parametrize("case", [("sim_structured", 1, 0.1, 0.5, 8.0), ("sim_unstructured", 4, 0.1, 0.5, 8.0),
+                                  ("sim_structured", 7, 0.05, 0.3, -1.0), ("sim_structured", 2, -1.0, 0.5, 6.0)])
+def test_front_end_bit_identical(built, case):
+    """f1: voxel grid x2, range gate, beam samples == the oracle's get_training_data, bit for bit."""
+    import la3dm_amd
+    from oracle import oracle as O
+    ds, i, ds_res, fr, mr = case
+    xyz, origin = la3dm_amd.load_pcd(pcd_path(ds, i))
+    m, _ = _maps(dict(la3dm_amd.BGK_YAML))
+    m.insert_pointcloud(xyz, origin, ds_res, fr, mr)
+    t = m.training_data()
+    ref = O.get_training_data(xyz, origin, ds_res, fr, mr)
+    assert t.shape == ref.shape, (t.shape, ref.shape)
+    assert (t.view(np.uint32) == ref.view(np.uint32)).all(), int((t != ref).any(axis=1).sum())
+
+
+def test_front_end_synthetic_dense_origin_cell(built):
+    """the voxel next to the sensor receives one sample per beam (tens of thousands of points in one cell):
+    the centroid must still be the fp32 sum in cloud order"""
+    import la3dm_amd
+    from oracle import oracle as O
+    xyz, origin = la3dm_amd.synthetic_scan(50000)
+    m, _ = _maps(dict(la3dm_amd.BGK_YAML))
+    m.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
+    t = m.training_data()
+    ref = O.get_training_data(xyz, origin, 0.1, 0.5, -1.0)
+    assert t.shape == ref.shape
+    assert (t.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_sequence_with_pruning(built, depth):
+    """12 fused scans: block creation, posterior accumulation in the device pool, pruning and ragged leaf lists"""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+    m, o = _maps(params)
+    for i in range(1, 13):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        st, so = m.stats(), o.stats()
+        for k in ("n_hits", "n_frees", "n_bbox_blocks", "n_test_blocks", "voxel_updates"):
+            assert st[k] == so[k], (i, k, st[k], so[k])
+        if i in (1, 2, 6, 12):
+            _same(m, o, f"d{depth} scan{i}")
+    a = m.leaves()
+    assert (a["node_key"] >> 16).min() < depth - 1, "pruning must have produced coarse leaves"
+
+
+def test_long_term_reinsertion(built):
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML)
+    m, o = _maps(params)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    for _ in range(15):
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    _same(m, o, "long_term")
+
+
+def test_matches_host_orchestrated_mode(built):
+    """the same map class in its two modes: identical leaves, search() and get_bbox()"""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML)
+    md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+    mh = la3dm_amd.BGKOctoMap(**params, device=0)
+    for i in (3, 4, 5):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+        md.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        mh.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    _same(md, mh, "modes")
+    assert md.block_count() == mh.block_count()
+    lo_d, hi_d = md.get_bbox()
+    lo_h, hi_h = mh.get_bbox()
+    assert (lo_d == lo_h).all() and (hi_d == hi_h).all()
+    rng = np.random.default_rng(3)
+    for p in rng.uniform(-6, 6, (200, 3)):
+        assert md.search(*p) == mh.search(*p)
+
+
+def test_synthetic_scan(built):
+    import la3dm_amd
+    xyz, origin = la3dm_amd.synthetic_scan(30000)
+    for depth in (3, 4):
+        params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+        m, o = _maps(params)
+        for _ in range(2):
+            m.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
+            o.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
+        _same(m, o, f"synth d{depth}")
+
+
+def test_edge_cases(built):
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML)
+    m, o = _maps(params)
+    m.insert_pointcloud(np.zeros((0, 3), np.float32), [0, 0, 0], 0.1, 0.5, 8.0)
+    m.insert_pointcloud(np.array([[20, 0, 0]], np.float32), [0, 0, 0], 0.1, 0.5, 8.0)   # beyond max_range
+    assert m.block_count() == 0
+    pts = np.array([[0.2, 0.2, 0.2], [0.2, 0.0, 0.0], [0.6, 0.6, 0.6], [1.0, 1.0, 1.0], [-0.2, 0.1, 0.1],
+                    [np.nan, 0.0, 0.0]], np.float32)
+    m.insert_pointcloud(pts[:5], [0, 0, 0], -1.0, 0.5, -1.0)     # points on block faces / corners
+    o.insert_pointcloud(pts[:5], [0, 0, 0], -1.0, 0.5, -1.0)
+    _same(m, o, "faces")
+    m.insert_pointcloud(np.repeat(pts, 5, axis=0), [0.05, 0, 0], 0.1, 0.3, -1.0)   # duplicates + a NaN point
+    o.insert_pointcloud(np.repeat(pts, 5, axis=0), [0.05, 0, 0], 0.1, 0.3, -1.0)
+    _same(m, o, "dups")
+    with pytest.raises(RuntimeError):
+        m.insert_training_data(np.array([[0, 0, 0, 1]], np.float32))
+
+
+def test_gp_variant(built):
+    """GPOctoMap on the device-resident pool (same f1-f3 stages, GP regression kernels in the middle)"""
+    import la3dm_amd
+    params = dict(la3dm_amd.GP_YAML)
+    m, o = _maps(params, gp=True)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz[::3], origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz[::3], origin, 0.1, 0.5, 8.0)
+    _same(m, o, "gp")
