@@ -47,7 +47,7 @@ struct la3dm_devmap {
     GridParams *d_gp = nullptr, *h_gp = nullptr;
     // arenas (grow only)
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
-    Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp;
+    Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big;
     Arena train, grid, axis_tab;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
@@ -135,9 +135,15 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     }
     const uint32_t nseg = dm->h_cnt[kCntGridSegs];
     DM_RESERVE(out, 12ull * nseg);
-    if (nseg)
-        hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(nseg, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
-                           (int)kCntGridSegs, (float *)out.ptr);
+    if (nseg) {
+        // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
+        DM_RESERVE(dm->big, 4ull * (n / kBigCell + 1));
+        DM_TRY(hipMemsetAsync(dm->d_cnt + kCntBig, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(nseg, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
+                           (int)kCntGridSegs, (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
+        hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
+                           (const uint32_t *)dm->big.ptr, (float *)out.ptr);
+    }
     *n_out = nseg;
     return LA3DM_OK;
 }
@@ -222,6 +228,10 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         ctx->err = "la3dm_devmap_create: the device-resident map supports variant 0 (BGK) and 1 (GP)";
         return LA3DM_ERR_ARG;
     }
+    if (ctx->p.block_depth > 5) {  // dm_prune stages 3 bytes per node of a block in LDS
+        ctx->err = "la3dm_devmap_create: the device-resident map supports block_depth <= 5";
+        return LA3DM_ERR_ARG;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     la3dm_devmap *dm = new la3dm_devmap;
     dm->ctx = ctx;
@@ -259,7 +269,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     (void)hipSetDevice(dm->ctx->device);
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
-                    &dm->cub_tmp, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
+                    &dm->cub_tmp, &dm->big, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)
@@ -562,8 +572,11 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
                            (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
                            (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
-        hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, dm->A,
-                           dm->B, dm->S, dm->npb, dm->depth);
+        {
+            const uint32_t waves = dm->depth >= 6 ? 1u : 4u;  // LDS per wave: 3 bytes per node
+            hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, waves)), dim3(64 * waves), waves * prune_lds_stride(dm->npb), st,
+                               (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, dm->A, dm->B, dm->S, dm->npb, dm->depth);
+        }
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
         S.voxel_updates += dm->h_cnt[kCntLeaves];
         if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;

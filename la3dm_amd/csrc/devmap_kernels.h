@@ -43,6 +43,7 @@ enum DevCounter {
     kCntError = 9,       // sticky error bits
     kCntTrainReads = 10, // low 32 bits of sum of neighbourhood sizes
     kCntTrainReadsHi = 11,
+    kCntBig = 12,        // voxel-grid cells with more than kBigCell points
     kCntWords = 16
 };
 
@@ -180,46 +181,68 @@ __global__ __launch_bounds__(256) void dm_seg_starts(const uint32_t *__restrict_
 }
 
 // Centroid of one voxel-grid cell: fp32 sums in cloud order (the sort is stable, values ascend inside a
-// segment).  One wave per segment: the lanes gather a batch of 64 points, then the sums run through the
-// batch serially (v_readlane broadcast, uniform accumulators) — the cell next to the sensor holds one
-// sample per beam, so the chain must not be a dependent global-load chain.
+// segment).  One thread per cell for the ordinary cells; cells with more than kBigCell points (the voxels
+// next to the sensor collect one sample per beam — tens of thousands of points) go to dm_grid_centroids_big.
+constexpr uint32_t kBigCell = 64;
+
 __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict__ p, const uint32_t *__restrict__ vals,
-                                                        const uint32_t *__restrict__ seg_start,
-                                                        const uint32_t *__restrict__ counters, int seg_slot, float *out) {
-    const uint32_t seg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+                                                        const uint32_t *__restrict__ seg_start, uint32_t *counters,
+                                                        int seg_slot, int big_slot, uint32_t *big, float *out) {
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
     if (seg >= counters[seg_slot]) return;
-    const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_start[seg]), s1 = __builtin_amdgcn_readfirstlane(seg_start[seg + 1]);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (uint32_t b = s0; b < s1; b += 64) {
-        const uint32_t nb = min(64u, s1 - b);
-        float x = 0.f, y = 0.f, z = 0.f;
-        if ((uint32_t)lane < nb) {
-            const uint32_t v = vals[b + lane];
-            x = p[3 * (size_t)v];
-            y = p[3 * (size_t)v + 1];
-            z = p[3 * (size_t)v + 2];
-        }
-        if (nb == 64u) {
-#pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                sx += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), j));
-                sy += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), j));
-                sz += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), j));
-            }
-        } else {
-            for (uint32_t j = 0; j < nb; ++j) {
-                sx += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), j));
-                sy += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), j));
-                sz += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), j));
-            }
-        }
+    const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
+    if (s1 - s0 > kBigCell) {
+        big[atomicAdd(&counters[big_slot], 1u)] = seg;
+        return;
     }
-    if (lane == 0) {
-        const float cnt = (float)(s1 - s0);
-        out[3 * (size_t)seg] = sx / cnt;
-        out[3 * (size_t)seg + 1] = sy / cnt;
-        out[3 * (size_t)seg + 2] = sz / cnt;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (uint32_t j = s0; j < s1; ++j) {
+        const uint32_t v = vals[j];
+        sx += p[3 * (size_t)v];
+        sy += p[3 * (size_t)v + 1];
+        sz += p[3 * (size_t)v + 2];
+    }
+    const float cnt = (float)(s1 - s0);
+    out[3 * (size_t)seg] = sx / cnt;
+    out[3 * (size_t)seg + 1] = sy / cnt;
+    out[3 * (size_t)seg + 2] = sz / cnt;
+}
+
+// Large cells: one wave per (cell, coordinate).  The sum must stay a serial fp32 chain, so the wave turns it
+// into one dependent VALU op per point: lane j holds point j of a 64-point batch and 64 steps of
+// `v = wave_shr1(v) + x` (DPP full-wave shift, lane 0 fed with the running sum) leave the running prefix in
+// every lane — sum_{k} = sum_{k-1} + x_k exactly as the sequential loop.  Loads run two batches ahead.
+__global__ __launch_bounds__(64) void dm_grid_centroids_big(const float *__restrict__ p, const uint32_t *__restrict__ vals,
+                                                           const uint32_t *__restrict__ seg_start,
+                                                           const uint32_t *__restrict__ counters, int big_slot,
+                                                           const uint32_t *__restrict__ big, float *out) {
+    const int lane = threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    const uint32_t nbig = counters[big_slot];
+    for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
+        const uint32_t seg = big[i];
+        const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
+        float s = 0.f;
+        uint32_t b = s0;
+        uint32_t v0 = (b + lane < s1) ? vals[b + lane] : 0u;
+        float x_cur = (b + lane < s1) ? p[3 * (size_t)v0 + c] : 0.f;
+        uint32_t v1 = (b + 64 + lane < s1) ? vals[b + 64 + lane] : 0u;
+        for (; b < s1; b += 64) {
+            const uint32_t nb = min(64u, s1 - b);
+            const float x_next = (b + 64 + lane < s1) ? p[3 * (size_t)v1 + c] : 0.f;
+            const uint32_t v2 = (b + 128 + lane < s1) ? vals[b + 128 + lane] : 0u;
+            float v = x_cur;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                // wave_shr:1 — lane j receives lane j-1, lane 0 keeps `old` = the carry-in
+                const float sh = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(s), __float_as_int(v), 0x138, 0xF, 0xF, false));
+                v = sh + x_cur;
+            }
+            s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)nb - 1));
+            x_cur = x_next;
+            v1 = v2;
+        }
+        if (lane == 0) out[3 * (size_t)seg + c] = s / (float)(s1 - s0);
     }
 }
 
@@ -607,35 +630,58 @@ __global__ __launch_bounds__(256) void dm_commit(const uint32_t *__restrict__ co
 }
 
 // OcTree::prune for the test blocks (bgkoctree.cpp:101-148): bottom-up, a sibling group whose eight members
-// share one non-UNKNOWN state collapses into its parent (a copy of child 0), the children become PRUNED.
-// One wave per block; lanes = sibling groups of the layer.
+// share one non-UNKNOWN state collapses into its parent (alpha, beta, state of child 0 — `classified` is not
+// carried by the node copy), the children become PRUNED.  One wave per block; the states are staged in LDS
+// (the layers depend on each other), and a collapsed chain parent <- child 0 <- ... is resolved to its
+// bottom node first so that alpha/beta are copied once from nodes this launch never writes.
+// Dynamic LDS: 4 waves x prune_lds_stride(npb) bytes.
+__host__ __device__ inline uint32_t prune_lds_stride(uint32_t npb) { return (((npb + 1u) & ~1u) + 2u * npb + 15u) & ~15u; }
+
 __global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slot, const uint32_t *__restrict__ counters,
                                                float *A, float *B, uint8_t *S, uint32_t npb, uint32_t block_depth) {
-    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) uint8_t dm_prune_smem[];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + wv;
     const int lane = threadIdx.x & 63;
     if (t >= counters[kCntTest]) return;
+    uint8_t *sS = dm_prune_smem + wv * prune_lds_stride(npb);
+    uint16_t *src = (uint16_t *)(sS + ((npb + 1u) & ~1u));
     const size_t base = (size_t)slot[t] * npb;
+    for (uint32_t i = lane; i < npb; i += 64) {
+        sS[i] = S[base + i];
+        src[i] = (uint16_t)i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool any = false;
     for (int depth = (int)block_depth - 1; depth > 0; --depth) {
         const uint32_t lb = dm_layer_base(depth), pb = dm_layer_base(depth - 1), ngroup = 1u << (3 * (depth - 1));
         for (uint32_t g = lane; g < ngroup; g += 64) {
-            const size_t c0 = base + lb + 8u * g;
-            const uint8_t s0 = S[c0];
-            const uint8_t st0 = s0 & 7u;
+            const uint32_t c0 = lb + 8u * g;
+            const uint8_t st0 = sS[c0] & 7u;
             if (st0 == kStatePruned || st0 == kStateUnknown) continue;
             bool same = true;
 #pragma unroll
-            for (int c = 1; c < 8; ++c) same &= (S[c0 + c] & 7u) == st0;
+            for (int c = 1; c < 8; ++c) same &= (sS[c0 + c] & 7u) == st0;
             if (!same) continue;
-            const size_t par = base + pb + g;
-            A[par] = A[c0];
-            B[par] = B[c0];
-            S[par] = (uint8_t)((S[par] & kClassifiedBit) | st0);  // the node copy does not carry `classified`
+            const uint32_t par = pb + g;
+            sS[par] = (uint8_t)((sS[par] & kClassifiedBit) | st0);
+            src[par] = src[c0];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) S[c0 + c] = (uint8_t)((S[c0 + c] & ~7u) | kStatePruned);
+            for (int c = 0; c < 8; ++c) sS[c0 + c] = (uint8_t)((sS[c0 + c] & ~7u) | kStatePruned);
+            any = true;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (!__any(any)) return;
+    for (uint32_t i = lane; i < npb; i += 64) {
+        S[base + i] = sS[i];
+        const uint32_t sr = src[i];
+        if (sr != i) {
+            A[base + i] = A[base + sr];
+            B[base + i] = B[base + sr];
+        }
     }
 }
 
