@@ -245,6 +245,10 @@ int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nod
 int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, uint8_t *S);
 /* training set (x, y, z, label) of the last scan, for parity tests; *n = number of points */
 int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint32_t *n);
+/* test hook (host pointers, n entries): out_fast = the closed-form sum of m[i] copies of x[i] onto s[i] that
+ * the voxel-grid kernel uses for runs of identical samples, out_loop = the plain sequential fp32 loop */
+int la3dm_devmap_diag_add_repeat(la3dm_ctx *ctx, const float *s, const float *x, const uint32_t *m, uint32_t n,
+                                 float *out_fast, float *out_loop);
 
 #ifdef __cplusplus
 }

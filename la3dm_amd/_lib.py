@@ -69,7 +69,7 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_gp_scan_device", "la3dm_bgklv_scan_host", "la3dm_bgklv_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep",
                "la3dm_devmap_create", "la3dm_devmap_destroy", "la3dm_devmap_insert_pointcloud_host",
                "la3dm_devmap_insert_pointcloud_device", "la3dm_devmap_block_count", "la3dm_devmap_download",
-               "la3dm_devmap_training_data"]
+               "la3dm_devmap_training_data", "la3dm_devmap_diag_add_repeat"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
@@ -131,6 +131,8 @@ def hip():
         L.la3dm_devmap_block_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.la3dm_devmap_download.restype = C.c_int
         L.la3dm_devmap_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.la3dm_devmap_diag_add_repeat.restype = C.c_int
+        L.la3dm_devmap_diag_add_repeat.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2
         L.la3dm_devmap_training_data.restype = C.c_int
         L.la3dm_devmap_training_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         _hip = L

@@ -113,7 +113,7 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
     uint32_t *flag = (uint32_t *)dm->flag.ptr, *scan = (uint32_t *)dm->scan.ptr, *seg_start = (uint32_t *)dm->seg_start.ptr;
     hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 256), 2048)), dim3(256), 0, st, d_in, n, dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), 512)), dim3(256), 0, st, d_in, n, dm->d_mm);
     hipLaunchKernelGGL(dm_grid_params, dim3(1), dim3(64), 0, st, dm->d_mm, inv, dm->d_gp);
     hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
     int rc = sort_pairs(dm, k0, k1, v0, v1, n, 32);
@@ -348,7 +348,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
 
     // ---------------- f2: partition ----------------
     hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 256), 2048)), dim3(256), 0, st, (const float *)xy, npts,
+    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)xy, npts,
                        dm->d_mm);
     hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox);
     DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
@@ -625,6 +625,32 @@ int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, u
     DM_TRY(hipMemcpyAsync(B, dm->B, 4 * nn, hipMemcpyDeviceToHost, st));
     DM_TRY(hipMemcpyAsync(S, dm->S, nn, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_diag_add_repeat(la3dm_ctx *ctx, const float *s, const float *x, const uint32_t *m, uint32_t n,
+                                 float *out_fast, float *out_loop) {
+    if (!ctx || !s || !x || !m || !out_fast || !out_loop) return LA3DM_ERR_ARG;
+    if (n == 0) return LA3DM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, 20ull * n));
+    float *ds = (float *)d, *dx = ds + n, *df = dx + n, *dl = df + n;
+    uint32_t *dmm = (uint32_t *)(dl + n);
+    hipError_t e = hipMemcpy(ds, s, 4ull * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, 4ull * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dmm, m, 4ull * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dm_diag_add_repeat, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, ds, dx, dmm, n, df, dl);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_fast, df, 4ull * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_loop, dl, 4ull * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        ctx->err = std::string("la3dm_devmap_diag_add_repeat: ") + hipGetErrorString(e);
+        return LA3DM_ERR_HIP;
+    }
     return LA3DM_OK;
 }
 

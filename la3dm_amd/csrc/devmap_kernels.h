@@ -76,12 +76,11 @@ __global__ void dm_minmax_init(uint32_t *mm) {
 
 template <int kStride>
 __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, uint32_t n, uint32_t *mm) {
+    __shared__ float red[4][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    bool any = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float x = p[(size_t)kStride * i], y = p[(size_t)kStride * i + 1], z = p[(size_t)kStride * i + 2];
         if (!finite3(x, y, z)) continue;
-        any = true;
         mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
         mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
     }
@@ -92,12 +91,23 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
         }
     }
-    any = __any(any);
-    if ((threadIdx.x & 63) == 0 && any) {
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&mm[a], enc_f32(mn[a]));
-            atomicMax(&mm[3 + a], enc_f32(mx[a]));
+            red[wv][a] = mn[a];
+            red[wv][3 + a] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {  // one atomic per value per workgroup; an all-rejected workgroup contributes +-inf = no-op
+        const int a = threadIdx.x;
+        float v = red[0][a];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+        if (a < 3) {
+            if (v != INFINITY) atomicMin(&mm[a], enc_f32(v));
+        } else {
+            if (v != -INFINITY) atomicMax(&mm[a], enc_f32(v));
         }
     }
 }
@@ -208,9 +218,58 @@ __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict
     out[3 * (size_t)seg + 2] = sz / cnt;
 }
 
+// s after m sequential fp32 additions of the same x:  for (k < m) s = s + x;  — bit-exact, in O(binades
+// crossed) instead of O(m).  (Every beam contributes the sensor origin as its first free-space sample, so the
+// voxel that holds the origin sums tens of thousands of identical values.)  While s stays inside one binade
+// [2^e, 2^(e+1)) its ulp u is constant and round-to-nearest-even of s + x adds a constant number d of ulps:
+// with x = (q + r) u, 0 <= r < 1:  d = q (r < 1/2), q + 1 (r > 1/2); a tie r = 1/2 resolves to the even
+// neighbour, which after at most one step (s/u odd) makes every further step add q + (q & 1).  Steps that
+// could leave the binade, and everything irregular (zero / opposite sign / |s| < |x| / non-normal values), are
+// single real additions.
+__host__ __device__ inline float add_repeat_f32(float s, float x, uint32_t m) {
+    union FU { float f; uint32_t u; };
+    FU fx; fx.f = x;
+    const uint32_t xb = fx.u, xe = (xb >> 23) & 0xFFu;
+    if (m == 0 || (xb << 1) == 0u) return s;  // +-0 never changes a sum that is not -0 (and s is never -0 here)
+    const uint32_t mx = (xb & 0x7FFFFFu) | 0x800000u;
+    while (m > 0) {
+        FU fs; fs.f = s;
+        const uint32_t sb = fs.u, se = (sb >> 23) & 0xFFu;
+        const bool regular = se != 0u && se != 0xFFu && xe != 0u && xe != 0xFFu && ((sb ^ xb) >> 31) == 0u && se >= xe;
+        if (regular) {
+            const uint32_t shift = se - xe;
+            if (shift > 24u) return s;  // x < u / 2: s + x rounds back to s for good
+            const uint32_t S = (sb & 0x7FFFFFu) | 0x800000u;
+            const uint32_t q = mx >> shift, r = mx & ((1u << shift) - 1u), half = shift ? (1u << (shift - 1u)) : 0u;
+            uint32_t d;
+            bool jump = true;
+            if (shift == 0u || r < half) d = q;
+            else if (r > half) d = q + 1u;
+            else {  // tie
+                d = q + (q & 1u);
+                jump = (S & 1u) == 0u;
+            }
+            if (jump) {
+                if (d == 0u) return s;
+                uint32_t k = (0xFFFFFFu - S) / d;  // steps that provably stay inside the binade
+                if (k > m) k = m;
+                if (k > 0u) {
+                    fs.u = (sb & 0xFF800000u) | ((S + k * d) & 0x7FFFFFu);
+                    s = fs.f;
+                    m -= k;
+                    if (m == 0) break;
+                }
+            }
+        }
+        s = s + x;  // one real addition (binade crossing or irregular operands)
+        --m;
+    }
+    return s;
+}
+
 // Large cells: one wave per (cell, coordinate).  The sum must stay a serial fp32 chain, so the wave turns it
 // into one dependent VALU op per point: lane j holds point j of a 64-point batch and 64 steps of
-// `v = wave_shr1(v) + x` (DPP full-wave shift, lane 0 fed with the running sum) leave the running prefix in
+// `v = wave_shr1(v) + x` (DPP full-wave shift, lane 0 holds carry-in + x_0) leave the running prefix in
 // every lane — sum_{k} = sum_{k-1} + x_k exactly as the sequential loop.  Loads run two batches ahead.
 __global__ __launch_bounds__(64) void dm_grid_centroids_big(const float *__restrict__ p, const uint32_t *__restrict__ vals,
                                                            const uint32_t *__restrict__ seg_start,
@@ -223,27 +282,83 @@ __global__ __launch_bounds__(64) void dm_grid_centroids_big(const float *__restr
         const uint32_t seg = big[i];
         const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
         float s = 0.f;
-        uint32_t b = s0;
-        uint32_t v0 = (b + lane < s1) ? vals[b + lane] : 0u;
-        float x_cur = (b + lane < s1) ? p[3 * (size_t)v0 + c] : 0.f;
-        uint32_t v1 = (b + 64 + lane < s1) ? vals[b + 64 + lane] : 0u;
-        for (; b < s1; b += 64) {
-            const uint32_t nb = min(64u, s1 - b);
-            const float x_next = (b + 64 + lane < s1) ? p[3 * (size_t)v1 + c] : 0.f;
-            const uint32_t v2 = (b + 128 + lane < s1) ? vals[b + 128 + lane] : 0u;
-            float v = x_cur;
+        uint32_t run_x = 0u, run_len = 0u;  // pending run of identical values (bits, count)
+        // kSub sub-batches of 64 points per trip; indices are fetched two trips ahead, values one trip ahead,
+        // so one memory round trip overlaps kSub * 64 chain steps
+        constexpr int kSub = 8;
+        constexpr uint32_t kTrip = 64u * kSub;
+        uint32_t vi[kSub];
+        float xn[kSub];
 #pragma unroll
-            for (int t = 0; t < 64; ++t) {
-                // wave_shr:1 — lane j receives lane j-1, lane 0 keeps `old` = the carry-in
-                const float sh = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(s), __float_as_int(v), 0x138, 0xF, 0xF, false));
-                v = sh + x_cur;
-            }
-            s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)nb - 1));
-            x_cur = x_next;
-            v1 = v2;
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t j = s0 + 64u * u + lane;
+            const uint32_t v0 = j < s1 ? vals[j] : 0u;
+            xn[u] = j < s1 ? p[3 * (size_t)v0 + c] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t j = s0 + kTrip + 64u * u + lane;
+            vi[u] = j < s1 ? vals[j] : 0u;
+        }
+        for (uint32_t b = s0; b < s1; b += kTrip) {
+            float xc[kSub];
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) xc[u] = xn[u];
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) {
+                const uint32_t j1 = b + kTrip + 64u * u + lane, j2 = j1 + kTrip;
+                xn[u] = j1 < s1 ? p[3 * (size_t)vi[u] + c] : 0.f;
+                vi[u] = j2 < s1 ? vals[j2] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kSub; ++u) {
+                const uint32_t bu = b + 64u * u;
+                if (bu >= s1) break;
+                const uint32_t nb = min(64u, s1 - bu);
+                // a sub-batch of identical values extends the pending run (summed in closed form when it ends)
+                const uint32_t xfirst = __builtin_amdgcn_readfirstlane(__float_as_uint(xc[u]));
+                const bool uniform = __ballot((uint32_t)lane >= nb || __float_as_uint(xc[u]) == xfirst) == ~0ull;
+                if (uniform && (run_len == 0u || xfirst == run_x)) {
+                    run_x = xfirst;
+                    run_len += nb;
+                    continue;
+                }
+                if (run_len) {
+                    s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
+                    run_len = 0;
+                }
+                if (uniform) {
+                    run_x = xfirst;
+                    run_len = nb;
+                    continue;
+                }
+                // lane 0 takes the carry-in first: (s + x_0) + x_1 + ... is the sequential order
+                const float x0 = lane == 0 ? s + xc[u] : xc[u];
+                float v = x0;
+#pragma unroll
+                for (int t = 0; t < 64; ++t) {
+                    // wave_shr:1 with bound_ctrl — lane j receives lane j-1, lane 0 receives 0 (0 + x is exact);
+                    // folds into one v_add_f32_dpp per step
+                    const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+                    v = sh + x0;
+                }
+                s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)nb - 1));
+            }
+        }
+        if (run_len) s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
         if (lane == 0) out[3 * (size_t)seg + c] = s / (float)(s1 - s0);
     }
+}
+
+// test hook: out_fast[i] = add_repeat_f32(s[i], x[i], m[i]), out_loop[i] = the plain loop
+__global__ void dm_diag_add_repeat(const float *s, const float *x, const uint32_t *m, uint32_t n, float *out_fast, float *out_loop) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_fast[i] = add_repeat_f32(s[i], x[i], m[i]);
+    float acc = s[i];
+    const float xi = x[i];
+    for (uint32_t k = 0; k < m[i]; ++k) acc = acc + xi;
+    out_loop[i] = acc;
 }
 
 // ---- beam sampling (bgkoctomap.cpp:383-417, 433-458) ------------------------------------------------

@@ -66,6 +66,33 @@ def test_front_end_synthetic_dense_origin_cell(built):
     assert (t.view(np.uint32) == ref.view(np.uint32)).all()
 
 
+def test_add_repeat_closed_form(built):
+    """the closed-form 'add x m times' used for runs of identical samples == the sequential fp32 loop, bit for bit
+    (binade crossings, ties to even, x below half an ulp, opposite signs, zeros, denormals, inf/nan)"""
+    import ctypes as C
+    import la3dm_amd
+    from la3dm_amd import _lib
+    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+    ctx = m._M.la3dm_map_ctx(m._h)
+    rng = np.random.default_rng(5)
+    n = 60000
+    x = (rng.uniform(0.5, 2.0, n) * 2.0 ** rng.integers(-12, 6, n)).astype(np.float32) * rng.choice([-1, 1], n).astype(np.float32)
+    s = np.where(rng.random(n) < 0.3, 0.0, x * rng.uniform(-2, 3000, n) * 2.0 ** rng.integers(-2, 8, n)).astype(np.float32)
+    cnt = rng.integers(0, 40000, n).astype(np.uint32)
+    # hand-picked: exact ties (x = 1, 0.5, 1.5, 3 * 2^-k), zeros, denormal, inf, nan, large sums
+    sp_x = np.array([1.0, 0.5, 1.5, 0.75, 1.0, -1.0, 0.0, -0.0, 1e-40, np.inf, np.nan, 1.0, 3.0, 0.1, 1e-3, 1.0], np.float32)
+    sp_s = np.array([2.0 ** 24, 2.0 ** 24 + 2, 2.0 ** 24 - 7, 2.0 ** 23 + 1, 0.0, 5.0, 3.0, 0.0, 1.0, 1.0, 1.0, 2.0 ** 25,
+                     2.0 ** 24 + 2, 0.0, 0.0, 16777215.0], np.float32)
+    sp_m = np.array([100, 100, 100, 1000, 20000000 // 512, 30, 9, 9, 1000, 3, 3, 77, 50000, 200000, 300000, 9], np.uint32)
+    x, s, cnt = np.concatenate([x, sp_x]), np.concatenate([s, sp_s]), np.concatenate([cnt, sp_m])
+    f, l = np.zeros_like(x), np.zeros_like(x)
+    rc = _lib.hip().la3dm_devmap_diag_add_repeat(ctx, s.ctypes.data, x.ctypes.data, cnt.ctypes.data, x.size, f.ctypes.data,
+                                                 l.ctypes.data)
+    assert rc == 0
+    same = (f.view(np.uint32) == l.view(np.uint32)) | (np.isnan(f) & np.isnan(l))
+    assert same.all(), (int((~same).sum()), s[~same][:5], x[~same][:5], cnt[~same][:5], f[~same][:5], l[~same][:5])
+
+
 @pytest.mark.parametrize("depth", [3, 4])
 def test_sequence_with_pruning(built, depth):
     """12 fused scans: block creation, posterior accumulation in the device pool, pruning and ragged leaf lists"""
