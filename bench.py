@@ -51,6 +51,7 @@ def main():
                          "style): ONE scan, its test blocks dealt round-robin to the ranks (la3dm_amd/sharding.py)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): 1 skip k(r) evaluation, 2 skip tests")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (device-resident insert_pointcloud) leg")
     ap.add_argument("--cpu-omp", action="store_true", help="also time the OpenMP oracle on all cores")
     args = ap.parse_args()
 
@@ -209,6 +210,7 @@ def main():
         value = total_U / (dt / args.steps)
         achieved = b_alg / (k_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "bgk_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -216,6 +218,7 @@ def main():
                     tj = json.load(f)
                 key = f"rays{args.rays}_d{args.depth}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                valu = tj.get(key, {}).get("valu_insts_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -242,6 +245,14 @@ def main():
             "host": {"prepare_s": t_prepare, "frontend_s": st["t_frontend"], "partition_s": st["t_partition"],
                      "pack_s": st["t_pack"]},
         }
+        if valu is not None:
+            # the kernel is VALU-issue bound, not HBM bound: wave64 VALU instructions retire one per 4 cycles per
+            # SIMD; 256 CUs x 4 SIMDs at 2.4 GHz = 6.144e11 wave-instructions/s (PMC count from profiles/)
+            rate = valu / (k_ms * 1e-3)
+            out["roofline"]["valu_issue"] = {"achieved": rate, "peak": 6.144e11, "unit": "wave-instr/s",
+                                             "frac": rate / 6.144e11, "valu_insts_per_launch": valu}
+        if world == 1 and not shard_mode and not args.no_e2e:
+            out["end_to_end"] = end_to_end(la3dm_amd, params, xyz, origin, args, U)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(params, xyz, origin, args, U)
             if args.cpu_omp:
@@ -351,6 +362,25 @@ def side_bench(args, torch, la3dm_amd, _lib):
         "config": dict({"workload": workload}, **extra),
         "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": peak_unit, "frac": achieved / peak,
                      "traffic": None, "kernel": kernel, "kernel_ms": k_ms}}))
+
+
+def end_to_end(la3dm_amd, params, xyz, origin, args, U):
+    """Whole BGKOctoMap::insert_pointcloud calls in device-resident mode (front end, partition, predict + fuse,
+    write-back, prune on the GPU; the cloud is uploaded from host memory inside the timed region)."""
+    m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+    m.insert_pointcloud(xyz, origin, args.resolution, 0.5, -1.0)  # warm-up: arenas, block creation
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.insert_pointcloud(xyz, origin, args.resolution, 0.5, -1.0)
+    dt = (time.perf_counter() - t0) / n
+    st = m.stats()
+    return {"what": "BGKOctoMap.insert_pointcloud, device-resident map, host cloud -> updated pool in HBM "
+                    "(same scan re-inserted; PCIe upload of the cloud included)",
+            "ms_per_insert": dt * 1e3, "voxel_updates_per_s": int(st["voxel_updates"]) / dt,
+            "voxel_updates_per_scan": int(st["voxel_updates"]), "calls": n,
+            "stages_s": {"frontend": st["t_frontend"], "partition": st["t_partition"],
+                         "pack_kernel_commit_prune": st["t_pack"]}}
 
 
 def cpu_baseline(params, xyz, origin, args, U, omp=False):
