@@ -86,6 +86,14 @@ uint64_t la3dm_map_dump_leaves(const la3dm_map *m, int64_t *block_key, int32_t *
 /* search(x, y, z): returns 1 if the block exists */
 int la3dm_map_search(const la3dm_map *m, float x, float y, float z, float *A, float *B, uint8_t *state);
 int la3dm_map_get_bbox(const la3dm_map *m, float *lim_min3, float *lim_max3);
+/* Block(center).get_index(p) / get_node / get_point (reference bgkblock.cpp:131-150) */
+void la3dm_map_block_grid(const la3dm_map *m, const float *center3, const float *p3, int32_t *idx3, int32_t *node_key,
+                          float *point3);
+/* BGKOctoMap::RayCaster(map, start, end) driven to its end (reference bgkoctomap.h:91-214): one row per next() call —
+ * voxel centre, block key, node key, valid (block exists), a copy of the node.  Returns the number of steps
+ * (rows beyond `cap` are counted but not written). */
+uint64_t la3dm_map_raycast(const la3dm_map *m, const float *start3, const float *end3, float *p_xyz, int64_t *block_key,
+                           int32_t *node_key, uint8_t *valid, float *A, float *B, uint8_t *state, uint64_t cap);
 
 /* host bookkeeping primitives (known-answer tests) */
 int64_t la3dm_map_block_to_hash_key(const la3dm_map *m, float x, float y, float z);

@@ -77,7 +77,8 @@ MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv",
                "la3dm_map_training_data", "la3dm_map_block_size", "la3dm_map_block_count", "la3dm_map_leaf_count",
                "la3dm_map_dump_leaves", "la3dm_map_search", "la3dm_map_get_bbox", "la3dm_map_block_to_hash_key",
                "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut",
-               "la3dm_map_set_device_resident", "la3dm_map_is_device_resident"]
+               "la3dm_map_set_device_resident", "la3dm_map_is_device_resident", "la3dm_map_raycast",
+               "la3dm_map_block_grid"]
 
 _hip = None
 _map = None
@@ -163,6 +164,9 @@ def maplib():
         M.la3dm_map_lv_commit.restype = C.c_int
         M.la3dm_map_lv_commit.argtypes = [C.c_void_p]
         M.la3dm_map_destroy.argtypes = [C.c_void_p]
+        M.la3dm_map_block_grid.argtypes = [C.c_void_p, f32p, f32p, np.ctypeslib.ndpointer(np.int32), C.POINTER(C.c_int32), f32p]
+        M.la3dm_map_raycast.restype = C.c_uint64
+        M.la3dm_map_raycast.argtypes = [C.c_void_p, f32p, f32p] + [C.c_void_p] * 7 + [C.c_uint64]
         M.la3dm_map_set_device_resident.restype = C.c_int
         M.la3dm_map_set_device_resident.argtypes = [C.c_void_p, C.c_int]
         M.la3dm_map_is_device_resident.restype = C.c_int

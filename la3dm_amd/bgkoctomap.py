@@ -105,6 +105,17 @@ class BGKOctoMap:
         e = self._M.la3dm_map_search(self._h, x, y, z, C.byref(a), C.byref(b), C.byref(s))
         return bool(e), a.value, b.value, s.value
 
+    def raycast(self, start, end, cap=4096):
+        """RayCaster(map, start, end) driven to its end: dict of p, block_key, node_key, valid, A, B, state per step."""
+        s3, e3 = np.ascontiguousarray(start, np.float32), np.ascontiguousarray(end, np.float32)
+        out = dict(p=np.zeros((cap, 3), np.float32), block_key=np.zeros(cap, np.int64), node_key=np.zeros(cap, np.int32),
+                   valid=np.zeros(cap, np.uint8), A=np.zeros(cap, np.float32), B=np.zeros(cap, np.float32),
+                   state=np.zeros(cap, np.uint8))
+        n = self._M.la3dm_map_raycast(self._h, s3, e3, *[out[k].ctypes.data for k in
+                                                          ("p", "block_key", "node_key", "valid", "A", "B", "state")], cap)
+        n = min(int(n), cap)
+        return {k: v[:n] for k, v in out.items()}
+
     def leaves(self):
         """All leaves (begin_leaf()..end_leaf()), blocks by ascending hash key, leaves in
         LeafIterator order: dict of block_key, node_key, loc, size, A, B, state, classified."""

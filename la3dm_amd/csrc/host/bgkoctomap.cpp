@@ -300,6 +300,97 @@ OcTreeNode &Block::search(point3f p) const {
     return node_arr[max_depth - 1][index];
 }
 
+void Block::get_index(const point3f &p, unsigned short &x, unsigned short &y, unsigned short &z) const {
+    const int cells = cell_num();
+    auto cell = [&](float v, float c) {
+        const int i = (int)((v - c) / resolution + cells / 2);
+        return (unsigned short)std::max(0, std::min(i, cells - 1));
+    };
+    x = cell(p.x(), center.x());
+    y = cell(p.y(), center.y());
+    z = cell(p.z(), center.z());
+}
+
+OcTreeHashKey Block::get_node(unsigned short x, unsigned short y, unsigned short z) {
+    unsigned index = 0;
+    for (int level = max_depth - 2; level >= 0; --level)
+        index = index * 8 + ((((x >> level) & 1u) << 2) | (((y >> level) & 1u) << 1) | ((z >> level) & 1u));
+    return node_to_hash_key((unsigned short)(max_depth - 1), (unsigned short)index);
+}
+
+// ------------------------------------------------------------------ RayCaster
+BGKOctoMap::RayCaster::RayCaster(const BGKOctoMap *m, const point3f &start, const point3f &end_)
+    : map(m), block(nullptr), n(0), lim(1 << (m->block_depth - 1)) {
+    key = block_to_hash_key(start);
+    block = map->search(key);
+    if (block == nullptr) return;  // the walk only starts inside an existing block
+    unsigned short x, y, z;
+    block->get_index(start, x, y, z);
+    idx[0] = x;
+    idx[1] = y;
+    idx[2] = z;
+    block_center = block->get_center();
+    current_p = start;
+    const float res = map->resolution;
+    const int a0[3] = {(int)(start.x() / res), (int)(start.y() / res), (int)(start.z() / res)};
+    const int a1[3] = {(int)(end_.x() / res), (int)(end_.y() / res), (int)(end_.z() / res)};
+    int d[3];
+    for (int a = 0; a < 3; ++a) {
+        d[a] = std::abs(a1[a] - a0[a]);
+        inc[a] = a1[a] > a0[a] ? 1 : (a1[a] == a0[a] ? 0 : -1);
+    }
+    n = 1 + d[0] + d[1] + d[2];
+    err_xy = d[0] - d[1];
+    err_xz = d[0] - d[2];
+    err_yz = d[1] - d[2];
+    for (int a = 0; a < 3; ++a) d2[a] = 2 * d[a];
+}
+
+// leave the block through the face of `axis`: neighbour centre = centre +- size on that axis, re-hashed
+void BGKOctoMap::RayCaster::enter_block(int axis, int step) {
+    block_center(axis) += step * map->block_size;
+    key = block_to_hash_key(block_center);
+    block = map->search(key);
+    idx[axis] = step > 0 ? 0 : lim - 1;
+}
+
+bool BGKOctoMap::RayCaster::next(point3f &p, OcTreeNode &node, BlockHashKey &block_key, OcTreeHashKey &node_key) {
+    node_key = Block::get_node((unsigned short)idx[0], (unsigned short)idx[1], (unsigned short)idx[2]);
+    block_key = key;
+    const bool valid = block != nullptr;
+    if (valid) {
+        node = (*block)[node_key];
+        current_p = block->get_point((unsigned short)idx[0], (unsigned short)idx[1], (unsigned short)idx[2]);
+    }
+    p = current_p;
+    const float res = map->resolution;
+    auto step = [&](int axis) {
+        idx[axis] += inc[axis];
+        current_p(axis) += inc[axis] * res;
+        if (idx[axis] >= lim || idx[axis] < 0) enter_block(axis, inc[axis]);
+    };
+    // same case order as the reference; when no case applies the walk repeats the voxel (n still counts down)
+    if (err_xy > 0 && err_xz > 0) {
+        step(0);
+        err_xy -= d2[1];
+        err_xz -= d2[2];
+    } else if (err_xy < 0 && err_yz > 0) {
+        step(1);
+        err_xy += d2[0];
+        err_yz -= d2[2];
+    } else if (err_yz < 0 && err_xz < 0) {
+        step(2);
+        err_xz += d2[0];
+        err_yz += d2[1];
+    } else if (err_xy == 0) {  // diagonal move in the xy plane: two voxel steps at once
+        step(0);
+        step(1);
+        n -= 2;
+    }
+    --n;
+    return valid;
+}
+
 // ----------------------------------------------------------------- BGKOctoMap
 BGKOctoMap::BGKOctoMap() : BGKOctoMap(0.1f, 4, 1.0, 1.0, 0.3f, 0.7f, 1.0f, 1.0f, 1.0f) {}
 

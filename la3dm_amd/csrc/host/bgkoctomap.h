@@ -212,6 +212,16 @@ public:
     ExtendedBlock get_extended_block() const;
     /// voxel containing p (index clamped into the block), at the finest layer
     OcTreeNode &search(point3f p) const;
+    // ---- finest-layer grid view of a block (reference bgkblock.cpp:131-147, index_map :34-67) ----
+    /// voxels per block edge.  (The reference keeps a static cell_num that is initialised once from the default
+    /// statics — 8 — and never updated by the map constructor, so its grid view is only meaningful at
+    /// block_depth 4; this is the value it has there.)
+    static unsigned short cell_num() { return (unsigned short)(1u << (max_depth - 1)); }
+    /// grid cell of p, clamped into the block; truncation toward zero as in the reference
+    void get_index(const point3f &p, unsigned short &x, unsigned short &y, unsigned short &z) const;
+    /// finest-layer node of grid cell (x, y, z): per level the child bit 4 is +x, 2 is +y, 1 is +z
+    static OcTreeHashKey get_node(unsigned short x, unsigned short y, unsigned short z);
+    point3f get_point(unsigned short x, unsigned short y, unsigned short z) const { return lut(get_node(x, y, z)) + center; }
     OcTreeNode &search(float x, float y, float z) const { return search(point3f(x, y, z)); }
 
 private:
@@ -317,6 +327,28 @@ public:
     /// training set (x, y, z, label) the device front end produced for the last scan
     std::vector<float> device_training_data() const;
     const std::vector<float> &last_training_data() const { return xy; }  // x,y,z,label
+
+    /// Voxel walk along the segment start -> end at the base resolution (reference bgkoctomap.h:91-214):
+    /// an integer DDA on the voxel indices of the two end points with one error term per axis pair, crossing
+    /// into neighbour blocks (which may be missing: next() then reports valid = false).  Starts only if the
+    /// block that holds `start` exists.
+    class RayCaster {
+    public:
+        RayCaster(const BGKOctoMap *map, const point3f &start, const point3f &end);
+        bool end() const { return n <= 0; }
+        /// current voxel: centre (or the dead-reckoned position when its block is missing), a copy of its
+        /// node, block and node key; then advance.  Returns whether the block exists.
+        bool next(point3f &p, OcTreeNode &node, BlockHashKey &block_key, OcTreeHashKey &node_key);
+
+    private:
+        void enter_block(int axis, int inc);
+        const BGKOctoMap *map;
+        Block *block;
+        point3f block_center, current_p;
+        int idx[3], inc[3], d2[3];   // voxel index inside the block, step sign, 2 * |delta| per axis
+        int err_xy, err_xz, err_yz, n, lim;
+        BlockHashKey key;
+    };
 
     class LeafIterator {
     public:

@@ -257,6 +257,39 @@ int la3dm_map_search(const la3dm_map *m, float x, float y, float z, float *A, fl
     return b != nullptr;
 }
 
+void la3dm_map_block_grid(const la3dm_map *, const float *c3, const float *p3, int32_t *idx3, int32_t *node_key, float *point3) {
+    la3dm::Block b(point3f(c3[0], c3[1], c3[2]));
+    unsigned short x, y, z;
+    b.get_index(point3f(p3[0], p3[1], p3[2]), x, y, z);
+    idx3[0] = x; idx3[1] = y; idx3[2] = z;
+    *node_key = la3dm::Block::get_node(x, y, z);
+    const point3f q = b.get_point(x, y, z);
+    point3[0] = q.x(); point3[1] = q.y(); point3[2] = q.z();
+}
+
+uint64_t la3dm_map_raycast(const la3dm_map *m, const float *s3, const float *e3, float *p_xyz, int64_t *block_key,
+                           int32_t *node_key, uint8_t *valid, float *A, float *B, uint8_t *state, uint64_t cap) {
+    BGKOctoMap::RayCaster rc(m->map, point3f(s3[0], s3[1], s3[2]), point3f(e3[0], e3[1], e3[2]));
+    uint64_t n = 0;
+    while (!rc.end()) {
+        point3f p;
+        la3dm::OcTreeNode nd;
+        la3dm::BlockHashKey bk;
+        la3dm::OcTreeHashKey nk;
+        const bool ok = rc.next(p, nd, bk, nk);
+        if (n < cap) {
+            p_xyz[3 * n] = p.x(); p_xyz[3 * n + 1] = p.y(); p_xyz[3 * n + 2] = p.z();
+            block_key[n] = bk;
+            node_key[n] = nk;
+            valid[n] = ok ? 1 : 0;
+            la3dm_node_ab(&nd, &A[n], &B[n]);
+            state[n] = (uint8_t)nd.get_state();
+        }
+        ++n;
+    }
+    return n;
+}
+
 int la3dm_map_get_bbox(const la3dm_map *m, float *lo, float *hi) {
     point3f a, b;
     m->map->get_bbox(a, b);

@@ -961,4 +961,110 @@ int orc_box_query(void *h, const float *xyz, int n, int64_t key, int32_t *ids, i
     return f;
 }
 
+// ---------------------------------------------------------------------------
+// RayCaster: include/bgkoctomap/bgkoctomap.h:91-214 (voxel walk start -> end), on top of
+// Block::get_index / get_node / get_point (src/bgkoctomap/bgkblock.cpp:131-150) and
+// init_index_map (:34-67: finest-layer keys stably sorted by x, then y, then z of their LUT offsets).
+// One output row per next() call; returns the number of calls until end().
+// Deviation (documented in DESIGN.md): the reference never updates the static Block::cell_num after its
+// static initialisation from the default statics (0.8 / 0.1 = 8, bgkblock.cpp:103-105 vs bgkoctomap.cpp:31-56),
+// so its get_index() is only meaningful at block_depth 4; cell_num here is size / resolution, which is the
+// same number at that depth (pinned by tests/golden/ref_kat_grid.npz).
+// ---------------------------------------------------------------------------
+// Block(center).get_index(p) -> cell, get_node -> key, get_point -> centre (bgkblock.cpp:131-150)
+void orc_block_grid(void *h, const float *c3, const float *p3, int32_t *idx3, int32_t *node_key, float *point3) {
+    Map *m = (Map *)h;
+    const Params &P = m->p;
+    const int dl = P.block_depth - 1, lim = 1 << dl;
+    const int cell_num = (int)round(P.block_size / P.resolution);
+    auto clip = [&](int a) { return std::max(0, std::min(a, cell_num - 1)); };
+    for (int a = 0; a < 3; ++a) idx3[a] = clip((int)((p3[a] - c3[a]) / P.resolution + cell_num / 2));
+    const std::vector<V3> &loc = m->lut[dl];
+    std::vector<int> order(loc.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return loc[a].x < loc[b].x; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return loc[a].y < loc[b].y; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return loc[a].z < loc[b].z; });
+    const int i = order[(size_t)idx3[0] + (size_t)idx3[1] * lim + (size_t)idx3[2] * lim * lim];
+    *node_key = (dl << 16) + i;
+    point3[0] = loc[i].x + c3[0]; point3[1] = loc[i].y + c3[1]; point3[2] = loc[i].z + c3[2];
+}
+
+int64_t orc_raycast(void *h, const float *s3, const float *e3, float *p_xyz, int64_t *block_key, int32_t *node_key,
+                    uint8_t *valid, float *A, float *B, uint8_t *state, int64_t cap) {
+    Map *m = (Map *)h;
+    const Params &P = m->p;
+    const int dl = P.block_depth - 1;
+    const int lim = 1 << dl;
+    // index_map: position in the (z, y, x)-sorted order of the finest layer -> node index
+    std::vector<int> order((size_t)1 << (3 * dl));
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    const std::vector<V3> &loc = m->lut[dl];
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return loc[a].x < loc[b].x; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return loc[a].y < loc[b].y; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return loc[a].z < loc[b].z; });
+    auto find_block = [&](int64_t key) -> Block * {
+        auto it = m->blocks.find(key);
+        return it == m->blocks.end() ? nullptr : it->second;
+    };
+    int64_t key = block_to_hash_key(P, s3[0], s3[1], s3[2]);
+    Block *blk = find_block(key);
+    if (blk == nullptr) return 0;
+    const int cell_num = (int)round(P.block_size / P.resolution);
+    auto clip = [&](int a) { return std::max(0, std::min(a, cell_num - 1)); };
+    int x = clip((int)((s3[0] - blk->center.x) / P.resolution + cell_num / 2));
+    int y = clip((int)((s3[1] - blk->center.y) / P.resolution + cell_num / 2));
+    int z = clip((int)((s3[2] - blk->center.z) / P.resolution + cell_num / 2));
+    V3 block_lim = blk->center, cur{s3[0], s3[1], s3[2]};
+    const int x0 = (int)(s3[0] / P.resolution), y0 = (int)(s3[1] / P.resolution), z0 = (int)(s3[2] / P.resolution);
+    const int x1 = (int)(e3[0] / P.resolution), y1 = (int)(e3[1] / P.resolution), z1 = (int)(e3[2] / P.resolution);
+    int dx = abs(x1 - x0), dy = abs(y1 - y0), dz = abs(z1 - z0);
+    int n = 1 + dx + dy + dz;
+    const int x_inc = x1 > x0 ? 1 : (x1 == x0 ? 0 : -1), y_inc = y1 > y0 ? 1 : (y1 == y0 ? 0 : -1),
+              z_inc = z1 > z0 ? 1 : (z1 == z0 ? 0 : -1);
+    int xy_error = dx - dy, xz_error = dx - dz, yz_error = dy - dz;
+    dx *= 2; dy *= 2; dz *= 2;
+    int64_t rows = 0;
+    while (n > 0) {
+        const int nk = (dl << 16) + order[(size_t)x + (size_t)y * lim + (size_t)z * lim * lim];
+        Node nd{0, P.prior_A, P.prior_B, ST_UNKNOWN};
+        if (blk != nullptr) {
+            nd = blk->layer[dl][nk & 0xFFFF];
+            const V3 &o = loc[nk & 0xFFFF];
+            cur = V3{o.x + blk->center.x, o.y + blk->center.y, o.z + blk->center.z};
+        }
+        if (rows < cap) {
+            p_xyz[3 * rows] = cur.x; p_xyz[3 * rows + 1] = cur.y; p_xyz[3 * rows + 2] = cur.z;
+            block_key[rows] = key; node_key[rows] = nk; valid[rows] = blk != nullptr;
+            A[rows] = nd.A; B[rows] = nd.B; state[rows] = nd.state;
+        }
+        ++rows;
+        auto cross = [&](float &lim_axis, int inc, int &i) {
+            if (i >= lim || i < 0) {
+                lim_axis += inc * P.block_size;
+                key = block_to_hash_key(P, block_lim.x, block_lim.y, block_lim.z);
+                blk = find_block(key);
+                i = inc > 0 ? 0 : lim - 1;
+            }
+        };
+        if (xy_error > 0 && xz_error > 0) {
+            x += x_inc; cur.x += x_inc * P.resolution; xy_error -= dy; xz_error -= dz;
+            cross(block_lim.x, x_inc, x);
+        } else if (xy_error < 0 && yz_error > 0) {
+            y += y_inc; cur.y += y_inc * P.resolution; xy_error += dx; yz_error -= dz;
+            cross(block_lim.y, y_inc, y);
+        } else if (yz_error < 0 && xz_error < 0) {
+            z += z_inc; cur.z += z_inc * P.resolution; xz_error += dx; yz_error += dy;
+            cross(block_lim.z, z_inc, z);
+        } else if (xy_error == 0) {
+            x += x_inc; y += y_inc; n -= 2;
+            cur.x += x_inc * P.resolution; cur.y += y_inc * P.resolution;
+            cross(block_lim.x, x_inc, x);
+            cross(block_lim.y, y_inc, y);
+        }
+        --n;
+    }
+    return rows;
+}
+
 }  // extern "C"

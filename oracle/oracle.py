@@ -108,6 +108,9 @@ def _load(name):
     lib.orc_block_count.argtypes = [C.c_void_p]
     lib.orc_leaf_count.restype = C.c_int64
     lib.orc_leaf_count.argtypes = [C.c_void_p]
+    lib.orc_block_grid.argtypes = [C.c_void_p, f32p, f32p, i32p, C.POINTER(C.c_int32), f32p]
+    lib.orc_raycast.restype = C.c_int64
+    lib.orc_raycast.argtypes = [C.c_void_p, f32p, f32p, f32p, i64p, i32p, u8p, f32p, f32p, u8p, C.c_int64]
     lib.orc_dump_leaves.restype = C.c_int64
     lib.orc_dump_leaves.argtypes = [C.c_void_p, i64p, i32p, f32p, f32p, f32p, f32p, u8p, u8p, C.c_int64]
     lib.orc_block_new.restype = C.c_void_p
@@ -200,6 +203,17 @@ class OracleMap:
         a = np.zeros(len(STATS_FIELDS), np.float64)
         self.L.orc_stats(self.h, a)
         return dict(zip(STATS_FIELDS, a.tolist()))
+
+    def raycast(self, start, end, cap=4096):
+        """RayCaster restatement: one row per next() call"""
+        s3, e3 = np.ascontiguousarray(start, np.float32), np.ascontiguousarray(end, np.float32)
+        out = dict(p=np.zeros((cap, 3), np.float32), block_key=np.zeros(cap, np.int64), node_key=np.zeros(cap, np.int32),
+                   valid=np.zeros(cap, np.uint8), A=np.zeros(cap, np.float32), B=np.zeros(cap, np.float32),
+                   state=np.zeros(cap, np.uint8))
+        n = self.L.orc_raycast(self.h, s3, e3, out["p"], out["block_key"], out["node_key"], out["valid"], out["A"],
+                               out["B"], out["state"], cap)
+        n = min(int(n), cap)
+        return {k: v[:n] for k, v in out.items()}
 
     def leaves(self):
         n = self.L.orc_leaf_count(self.h)
@@ -353,6 +367,7 @@ def ref():
         R.ref_block_new.argtypes = [C.c_float] * 3
         R.ref_block_free.argtypes = [C.c_void_p]
         R.ref_block_extended.argtypes = [C.c_void_p, i64p]
+        R.ref_block_grid.argtypes = [C.c_void_p, f32p, i32p, C.POINTER(C.c_int32), f32p]
         R.ref_block_leaves.restype = C.c_int
         R.ref_block_leaves.argtypes = [C.c_void_p, i32p, f32p, f32p, C.c_int]
         R.ref_block_update.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]

@@ -85,6 +85,16 @@ void ref_block_extended(void *b, int64_t *out7) {
     ExtendedBlock eb = ((Block *) b)->get_extended_block();
     for (int i = 0; i < 7; ++i) out7[i] = eb[i];
 }
+// grid view of a block (bgkblock.cpp:131-150): cell of p, its node key, its centre
+void ref_block_grid(void *b, const float *p3, int32_t *idx3, int32_t *node_key, float *point3) {
+    Block *blk = (Block *) b;
+    unsigned short x, y, z;
+    blk->get_index(point3f(p3[0], p3[1], p3[2]), x, y, z);
+    idx3[0] = x; idx3[1] = y; idx3[2] = z;
+    *node_key = blk->get_node(x, y, z);
+    point3f q = blk->get_point(x, y, z);
+    point3[0] = q.x(); point3[1] = q.y(); point3[2] = q.z();
+}
 int ref_block_leaves(void *b, int32_t *keys, float *loc_xyz, float *sizes, int cap) {
     Block *blk = (Block *) b;
     int n = 0;

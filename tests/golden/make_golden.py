@@ -23,6 +23,36 @@ from oracle import oracle as O  # noqa: E402
 YAML = (0.1, 3, 1.0, 0.2, 0.3, 0.7, 100.0, 0.001, 0.001)
 
 
+def ref_grid_kat():
+    """Block::get_index / get_node / get_point (the RayCaster's primitives) from the reference's compiled sources."""
+    R = O.ref()
+    assert R is not None, "oracle/_ref not built (needs /root/reference)"
+    rng = np.random.default_rng(20260928)
+    out = {}
+    for depth in (3, 4):
+        R.ref_configure(YAML[0], depth, *YAML[2:])
+        bs = R.ref_block_size()
+        for case, c in enumerate([[0.8, 0.8, 0.0], [-3.6, 12.8, 4.4]]):
+            c = (np.array(c) / 0.4 * bs).astype(np.float32)
+            b = R.ref_block_new(float(c[0]), float(c[1]), float(c[2]))
+            pts = np.concatenate([c + rng.uniform(-0.75 * bs, 0.75 * bs, (300, 3)),       # inside and outside (clamped)
+                                  c + (rng.integers(-5, 6, (100, 3)) * YAML[0]),            # on voxel faces
+                                  [c, c - bs / 2, c + bs / 2]]).astype(np.float32)
+            idx = np.zeros((len(pts), 3), np.int32)
+            key = np.zeros(len(pts), np.int32)
+            loc = np.zeros((len(pts), 3), np.float32)
+            t3, k1, i3 = np.zeros(3, np.float32), C.c_int32(), np.zeros(3, np.int32)
+            for i, p in enumerate(pts):
+                R.ref_block_grid(b, np.ascontiguousarray(p), i3, C.byref(k1), t3)
+                idx[i], key[i], loc[i] = i3, k1.value, t3
+            R.ref_block_free(b)
+            tag = f"d{depth}_c{case}"
+            out[f"{tag}_center"], out[f"{tag}_pts"] = c, pts
+            out[f"{tag}_idx"], out[f"{tag}_key"], out[f"{tag}_point"] = idx, key, loc
+    np.savez_compressed(os.path.join(HERE, "ref_kat_grid.npz"), **out)
+    print("ref_kat_grid.npz:", len(out), "arrays")
+
+
 def ref_kat():
     R = O.ref()
     assert R is not None, "oracle/_ref not built (needs /root/reference)"
@@ -170,5 +200,9 @@ def oracle_kat():
 
 
 if __name__ == "__main__":
-    ref_kat()
-    oracle_kat()
+    if len(sys.argv) > 1 and sys.argv[1] == "grid":   # added later: does not disturb the older fixtures
+        ref_grid_kat()
+    else:
+        ref_kat()
+        oracle_kat()
+        ref_grid_kat()

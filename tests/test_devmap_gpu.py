@@ -143,6 +143,29 @@ def test_matches_host_orchestrated_mode(built):
         assert md.search(*p) == mh.search(*p)
 
 
+def test_raycaster_on_device_resident_map(built):
+    """RayCaster over the lazily mirrored pool: voxel walk, keys and node copies == the oracle's"""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML, block_depth=4)
+    m, o = _maps(params)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    rng = np.random.default_rng(2)
+    lv = o.leaves()
+    for _ in range(40):
+        s3 = lv["loc"][rng.integers(0, lv["loc"].shape[0])] + rng.uniform(-0.04, 0.04, 3).astype(np.float32)
+        e3 = s3 + rng.uniform(-4, 4, 3).astype(np.float32)
+        a, b = m.raycast(s3, e3), o.raycast(s3, e3)
+        assert a["p"].shape == b["p"].shape
+        for k in ("p", "block_key", "node_key", "valid"):
+            assert (a[k] == b[k]).all(), k
+        v = a["valid"].astype(bool)
+        for k in ("A", "B", "state"):
+            assert (a[k][v] == b[k][v]).all(), k
+
+
 def test_synthetic_scan(built):
     import la3dm_amd
     xyz, origin = la3dm_amd.synthetic_scan(30000)

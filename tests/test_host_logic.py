@@ -141,6 +141,74 @@ def test_search_bbox_and_iteration(built):
     assert m.block_count() == len(set(lv["block_key"].tolist()))
 
 
+def test_block_grid_against_reference_kat(built):
+    """Block::get_index / get_node / get_point (the RayCaster's primitives): host code and oracle vs answers
+    captured from the reference's own compiled sources (tests/golden/ref_kat_grid.npz).
+
+    Pinned at block_depth 4 only: the reference initialises the static Block::cell_num once from its default
+    statics (0.8 / 0.1 = 8 cells, src/bgkoctomap/bgkblock.cpp:103-105) and its constructor never updates it
+    (src/bgkoctomap/bgkoctomap.cpp:31-56), so for any other depth its get_index / search(point) address cells
+    that do not exist (the depth-3 fixture shows indices up to 7 in a 4-cell block).  This build uses
+    cell_num = 2^(block_depth-1), which is what the reference computes for its default depth."""
+    import la3dm_amd
+    depth = 4
+    quirk = np.load(os.path.join(GOLDEN, "ref_kat_grid.npz"))["d3_c0_idx"]
+    assert quirk.max() > 3
+    from la3dm_amd import _lib
+    from oracle import oracle as O
+    kat = np.load(os.path.join(GOLDEN, "ref_kat_grid.npz"))
+    params = dict(YAML, block_depth=depth)
+    m = la3dm_amd.BGKOctoMap(**params, device=-1)
+    o = O.OracleMap(**params)
+    M = _lib.maplib()
+    idx, key, pt = np.zeros(3, np.int32), C.c_int32(), np.zeros(3, np.float32)
+    for case in (0, 1):
+        tag = f"d{depth}_c{case}"
+        c = np.ascontiguousarray(kat[f"{tag}_center"])
+        for p, ri, rk, rp in zip(kat[f"{tag}_pts"], kat[f"{tag}_idx"], kat[f"{tag}_key"], kat[f"{tag}_point"]):
+            p = np.ascontiguousarray(p)
+            M.la3dm_map_block_grid(m._h, c, p, idx, C.byref(key), pt)
+            assert (idx == ri).all() and key.value == rk and (pt == rp).all(), ("host", p)
+            o.L.orc_block_grid(o.h, c, p, idx, C.byref(key), pt)
+            assert (idx == ri).all() and key.value == rk and (pt == rp).all(), ("oracle", p)
+
+
+def test_raycaster_against_oracle(built):
+    """RayCaster walks: host class vs oracle restatement on the same block set (voxel centres, keys, validity),
+    plus a hand-checkable axis-aligned walk."""
+    import la3dm_amd
+    from oracle import oracle as O
+    m = la3dm_amd.BGKOctoMap(**YAML, device=-1)
+    o = O.OracleMap(**YAML)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    m.prepare(xyz, origin, 0.1, 0.5, 8.0)           # creates the blocks (nodes stay at the prior)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    rng = np.random.default_rng(11)
+    lv = o.leaves()
+    starts = lv["loc"][rng.integers(0, lv["loc"].shape[0], 60)] + rng.uniform(-0.04, 0.04, (60, 3)).astype(np.float32)
+    ends = starts + rng.uniform(-3, 3, (60, 3)).astype(np.float32)
+    ends[:10, 1:] = starts[:10, 1:]                 # axis-aligned
+    ends[10:20, 2] = starts[10:20, 2]               # planar
+    ends[20:25] = starts[20:25] + np.float32(0.7) * np.sign(rng.uniform(-1, 1, (5, 3))).astype(np.float32)  # diagonals
+    nsteps = 0
+    for s3, e3 in zip(starts, ends):
+        a, b = m.raycast(s3, e3), o.raycast(s3, e3)
+        assert a["p"].shape == b["p"].shape and a["p"].shape[0] >= 1
+        for k in ("p", "block_key", "node_key", "valid"):
+            assert (a[k] == b[k]).all(), k
+        nsteps += a["p"].shape[0]
+    assert nsteps > 500
+    # outside the map nothing starts
+    assert m.raycast([500, 500, 500], [501, 500, 500])["p"].shape[0] == 0
+    # axis-aligned: consecutive voxel centres one resolution apart, one row per voxel
+    s3 = lv["loc"][int(np.argmin(np.abs(lv["loc"] - lv["loc"].mean(0)).sum(1)))]
+    w = m.raycast(s3, s3 + np.array([1.25, 0, 0], np.float32))
+    assert w["p"].shape[0] == 1 + abs(int((s3[0] + 1.25) / 0.1) - int(s3[0] / 0.1))
+    v = w["valid"].astype(bool)
+    d = np.diff(w["p"][:, 0])[v[1:] & v[:-1]]
+    assert np.allclose(d, 0.1, atol=1e-5) and (w["p"][v][:, 1:] == w["p"][v][0, 1:]).all()
+
+
 def test_synthetic_scan_generator(built):
     import la3dm_amd
     xyz, origin = la3dm_amd.synthetic_scan(5000)
