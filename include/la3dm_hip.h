@@ -203,6 +203,15 @@ int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *
  * 3  sin/cos (f64 kernels rounded to f32) vs the f64 library functions rounded to f32. */
 int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 
+/* BGKLOctoMap (params.variant = 3): block-level BGK with free-space line segments.  Replaces
+ * BGKLInference::train/predict (include/bgkloctomap/bgklinference.h:44-88: point_to_line_dist :104-140,
+ * covSparseLine :186-200) + the update loop gated on kbar > 0.001 (src/bgkloctomap/bgkloctomap.cpp:206-231).
+ * Same la3dm_bgk_scan layout, except that train_xyzy holds ROWS OF 8 FLOATS {x0,y0,z0, x1,y1,z1, label, 0}
+ * (hits = degenerate segments with label 1; one row per beam and block with label 0), n_train_pts = number of
+ * rows and train_off is the CSR over training blocks in rows. */
+int la3dm_bgkl_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out);
+int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream, la3dm_bgk_counters *out);
+
 /* ------------------------------------------------------------------------------------------------
  * Device-resident map: the block pool (alpha, beta, state of every node of
  * every block) lives in HBM and BGKOctoMap::insert_pointcloud (src/bgkoctomap/bgkoctomap.cpp:214-366)

@@ -31,6 +31,14 @@ la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float 
 la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, float ell, float noise, float l,
                                float min_var, float max_var, float max_known_var, float free_thresh,
                                float occupied_thresh, int device);
+/* BGKLOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B)
+ * (src/bgkloctomap/bgkloctomap.cpp:31-57): block-level BGK whose free-space evidence are beam segments. */
+la3dm_map *la3dm_map_create_l(float resolution, int block_depth, float sf2, float ell, float free_thresh,
+                              float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device);
+/* BGKLOctoMap only: beam index per training sample (-1 = hit) and beams (6 floats) of the last scan; returns the number
+ * of samples (the samples themselves come from la3dm_map_training_data) */
+uint64_t la3dm_map_l_training(const la3dm_map *m, int32_t *ray_idx, uint64_t cap, float *rays6, uint64_t cap_rays,
+                              uint64_t *n_rays);
 /* BGKLVOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B,
  * original_size, min_W) (src/bgklvoctomap/bgklvoctomap.cpp:33-43).  For an LV map la3dm_map_dump_leaves reports the
  * reference's LV state codes (UNCERTAIN = 3, PRUNED = 4), node_key = (depth << 28) + index, and only blocks that hold a

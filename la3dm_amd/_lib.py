@@ -69,7 +69,8 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_gp_scan_device", "la3dm_bgklv_scan_host", "la3dm_bgklv_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep",
                "la3dm_devmap_create", "la3dm_devmap_destroy", "la3dm_devmap_insert_pointcloud_host",
                "la3dm_devmap_insert_pointcloud_device", "la3dm_devmap_block_count", "la3dm_devmap_download",
-               "la3dm_devmap_training_data", "la3dm_devmap_diag_add_repeat"]
+               "la3dm_devmap_training_data", "la3dm_devmap_diag_add_repeat", "la3dm_bgkl_scan_host",
+               "la3dm_bgkl_scan_device"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
@@ -78,7 +79,7 @@ MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv",
                "la3dm_map_dump_leaves", "la3dm_map_search", "la3dm_map_get_bbox", "la3dm_map_block_to_hash_key",
                "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut",
                "la3dm_map_set_device_resident", "la3dm_map_is_device_resident", "la3dm_map_raycast",
-               "la3dm_map_block_grid"]
+               "la3dm_map_block_grid", "la3dm_map_create_l", "la3dm_map_l_training"]
 
 _hip = None
 _map = None
@@ -105,6 +106,10 @@ def hip():
         L.la3dm_bgk_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_bgk_scan_device.restype = C.c_int
         L.la3dm_bgk_scan_device.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.c_void_p, C.POINTER(BgkCounters)]
+        L.la3dm_bgkl_scan_host.restype = C.c_int
+        L.la3dm_bgkl_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
+        L.la3dm_bgkl_scan_device.restype = C.c_int
+        L.la3dm_bgkl_scan_device.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.c_void_p, C.POINTER(BgkCounters)]
         L.la3dm_gp_scan_host.restype = C.c_int
         L.la3dm_gp_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_gp_scan_device.restype = C.c_int
@@ -150,6 +155,10 @@ def maplib():
         f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         M.la3dm_map_create.restype = C.c_void_p
         M.la3dm_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7 + [C.c_int]
+        M.la3dm_map_create_l.restype = C.c_void_p
+        M.la3dm_map_create_l.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7 + [C.c_int]
+        M.la3dm_map_l_training.restype = C.c_uint64
+        M.la3dm_map_l_training.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         M.la3dm_map_create_gp.restype = C.c_void_p
         M.la3dm_map_create_gp.argtypes = [C.c_float, C.c_int] + [C.c_float] * 9 + [C.c_int]
         M.la3dm_map_create_lv.restype = C.c_void_p

@@ -237,6 +237,32 @@ class GPOctoMap(BGKOctoMap):
         self.device = device
 
 
+class BGKLOctoMap(BGKOctoMap):
+    """Python mirror of la3dm::BGKLOctoMap (reference include/bgkloctomap/bgkloctomap.h): block-level BGK whose
+    free-space evidence are the beams themselves (line segments)."""
+
+    def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, free_thresh=0.3, occupied_thresh=0.7,
+                 var_thresh=1.0, prior_A=1.0, prior_B=1.0, device=0):
+        self._M = _lib.maplib()
+        self._h = self._M.la3dm_map_create_l(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+                                             prior_A, prior_B, device)
+        if not self._h:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        self.resolution = resolution
+        self.block_depth = block_depth
+        self.device = device
+
+    def l_training(self):
+        """(samples (n, 4) x,y,z,beam index or -1; beams (m, 6)) of the last scan"""
+        nr = C.c_uint64()
+        n = self._M.la3dm_map_l_training(self._h, None, 0, None, 0, C.byref(nr))
+        idx, rays = np.zeros(n, np.int32), np.zeros((nr.value, 6), np.float32)
+        self._M.la3dm_map_l_training(self._h, idx.ctypes.data, n, rays.ctypes.data, nr.value, C.byref(nr))
+        xy = self.training_data()
+        xy[:, 3] = idx
+        return xy, rays
+
+
 LV_STATS = ["n_hits", "n_rays", "n_samples", "n_bbox_blocks", "n_packed_blocks", "n_info_blocks", "voxels",
             "voxel_updates", "t_frontend", "t_partition", "t_device", "t_commit", "t_total"]
 

@@ -426,7 +426,7 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     OcTreeNode::var_thresh = var_thresh;
     OcTreeNode::prior_A = prior_A;
     OcTreeNode::prior_B = prior_B;
-    OcTreeNode::variant = variant;
+    OcTreeNode::variant = variant == 3 ? 0 : variant;  // BGKLOctoMap shares the BGK node (bgkloctree_node.cpp)
     OcTreeNode::init_A = prior_A;
     OcTreeNode::init_B = prior_B;
     if (variant == 2) {  // src/bgklvoctomap/bgklvoctomap.cpp:60-61
@@ -784,6 +784,91 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
     stats.n_frees = nf;
 }
 
+// BGKLOctoMap front end (src/bgkloctomap/bgkloctomap.cpp:300-343, beam_sample :359-381): hits are re-projected as
+// origin + n * l, free samples step down from l - free_resolution while d > 0 and are not voxel-filtered, every sample
+// of a beam (the origin sample first) remembers its beam; the beam itself is origin -> origin + n * (l - free_resolution).
+void BGKOctoMap::get_training_data_l(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                                     float free_resolution, float max_range) {
+    std::vector<float> packed(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        packed[3 * i] = xyz[stride * i];
+        packed[3 * i + 1] = xyz[stride * i + 1];
+        packed[3 * i + 2] = xyz[stride * i + 2];
+    }
+    std::vector<float> hits;
+    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
+    xy.clear();
+    l_ray_idx.clear();
+    l_rays.clear();
+    const float x0 = origin.x(), y0 = origin.y(), z0 = origin.z();
+    const size_t nh = hits.size() / 3;
+    int32_t idx = 0;
+    for (size_t i = 0; i < nh; ++i) {
+        const float x = hits[3 * i], y = hits[3 * i + 1], z = hits[3 * i + 2];
+        if (max_range > 0) {
+            const double lr = (point3f(x, y, z) - origin).norm();
+            if (lr > max_range) continue;
+        }
+        float l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
+        const float nx = (x - x0) / l, ny = (y - y0) / l, nz = (z - z0) / l;
+        const float ex = x0 + nx * l, ey = y0 + ny * l, ez = z0 + nz * l;
+        xy.insert(xy.end(), {ex, ey, ez, 1.0f});
+        l_ray_idx.push_back(-1);
+        xy.insert(xy.end(), {x0, y0, z0, 0.0f});
+        l_ray_idx.push_back(idx);
+        {   // beam_sample from the re-projected end point
+            const float l2 = (float)sqrt((ex - x0) * (ex - x0) + (ey - y0) * (ey - y0) + (ez - z0) * (ez - z0));
+            const float mx = (ex - x0) / l2, my = (ey - y0) / l2, mz = (ez - z0) / l2;
+            float d = l2 - free_resolution;
+            while (d > 0.0) {
+                xy.insert(xy.end(), {x0 + mx * d, y0 + my * d, z0 + mz * d, 0.0f});
+                l_ray_idx.push_back(idx);
+                d -= free_resolution;
+            }
+        }
+        l = l - free_resolution;
+        l_rays.insert(l_rays.end(), {x0, y0, z0, x0 + nx * l, y0 + ny * l, z0 + nz * l});
+        ++idx;
+    }
+    stats.n_hits = (uint64_t)idx;
+    stats.n_frees = xy.size() / 4 - (uint64_t)idx;
+}
+
+// Training rows of every block (bgkloctomap.cpp:141-170): members in CSR order; a hit becomes a degenerate segment with
+// label 1, a free sample contributes its beam once per block (at the position of the beam's first sample) with label 0.
+void BGKOctoMap::build_rows_l() {
+    train_rows.clear();
+    rows_off.assign(1, 0u);
+    std::vector<uint32_t> stamp(l_rays.size() / 6, 0xFFFFFFFFu);
+    for (size_t b = 0; b + 1 < train_off.size(); ++b) {
+        for (uint32_t k = train_off[b]; k < train_off[b + 1]; ++k) {
+            const uint32_t src = train_src[k];
+            const int32_t r = l_ray_idx[src];
+            if (r < 0) {
+                const float *p = &xy[4 * (size_t)src];
+                train_rows.insert(train_rows.end(), {p[0], p[1], p[2], p[0], p[1], p[2], 1.0f, 0.0f});
+            } else if (stamp[r] != (uint32_t)b) {
+                stamp[r] = (uint32_t)b;
+                const float *q = &l_rays[6 * (size_t)r];
+                train_rows.insert(train_rows.end(), {q[0], q[1], q[2], q[3], q[4], q[5], 0.0f, 0.0f});
+            }
+        }
+        rows_off.push_back((uint32_t)(train_rows.size() / 8));
+    }
+    // work counters in rows (what the oracle counts for this variant)
+    stats.train_reads = stats.pair_evals = 0;
+    for (const Pass &ps : passes)
+        for (size_t t = 0; t < ps.blocks.size(); ++t) {
+            uint64_t nr = 0;
+            for (int q = 0; q < 7; ++q) {
+                const int32_t tb = ps.nbr[7 * t + q];
+                if (tb >= 0) nr += rows_off[tb + 1] - rows_off[tb];
+            }
+            stats.train_reads += nr;
+            stats.pair_evals += nr * (ps.leaf_off[t + 1] - ps.leaf_off[t]);
+        }
+}
+
 // ------------------------------------------------- partition + pack (stages B..E host part)
 namespace {
 struct AxisCand {
@@ -808,6 +893,7 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
     passes.clear();
     prune_list.clear();
     train_xyzy.clear();
+    train_src.clear();
     train_off.assign(1, 0u);
     const size_t npts = xy.size() / 4;
     if (npts == 0) return false;
@@ -865,6 +951,7 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
             for (size_t k = i; k < j; ++k) {
                 const float *p = &xy[4 * (size_t)members[k].pt];
                 train_xyzy.insert(train_xyzy.end(), p, p + 4);
+                if (variant == 3) train_src.push_back(members[k].pt);
             }
             train_off.push_back((uint32_t)(train_xyzy.size() / 4));
         }
@@ -963,6 +1050,7 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
 }
 
 int BGKOctoMap::run_scan(la3dm_bgk_scan *s, la3dm_bgk_counters *c) {
+    if (variant == 3) return la3dm_bgkl_scan_host(ctx, s, c);
     return variant == 1 ? la3dm_gp_scan_host(ctx, s, c) : la3dm_bgk_scan_host(ctx, s, c);
 }
 
@@ -986,6 +1074,11 @@ la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
     s.flags = scan_flags;
     s.train_max_n = train_max_n;
     s.train_sum_n2 = train_sum_n2;
+    if (variant == 3) {  // BGKLOctoMap: segment rows (8 floats) instead of points
+        s.train_xyzy = train_rows.data();
+        s.train_off = rows_off.data();
+        s.n_train_pts = (uint32_t)(train_rows.size() / 8);
+    }
     return s;
 }
 
@@ -1043,6 +1136,13 @@ bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3
     if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::prepare: not available in device-resident mode");
     stats = ScanStats();
     const double t0 = wall();
+    if (variant == 3) {
+        get_training_data_l(xyz, n, stride, origin, ds_resolution, free_res, max_range);
+        stats.t_frontend = wall() - t0;
+        const bool work = partition_and_pack(false);
+        build_rows_l();
+        return work;
+    }
     get_training_data(xyz, n, stride, origin, ds_resolution, free_res, max_range);
     stats.t_frontend = wall() - t0;
     return partition_and_pack(false);

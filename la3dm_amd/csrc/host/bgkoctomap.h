@@ -421,6 +421,32 @@ protected:
     uint32_t train_max_n;
     uint64_t train_sum_n2;
     int run_scan(la3dm_bgk_scan *s, la3dm_bgk_counters *c);
+
+    // ---- variant 3 (BGKLOctoMap): training samples keep their beam, training blocks hold segment rows ----
+    void get_training_data_l(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
+                             float free_resolution, float max_range);
+    void build_rows_l();
+    std::vector<int32_t> l_ray_idx;     // per training sample: -1 = hit, else index into l_rays
+    std::vector<float> l_rays;          // 6 floats per beam: origin -> hit shortened by free_resolution
+    std::vector<uint32_t> train_src;    // training sample index of every CSR member
+    std::vector<float> train_rows;      // 8 floats per row {x0,y0,z0,x1,y1,z1,label,0}
+    std::vector<uint32_t> rows_off;     // CSR over training blocks
+
+public:
+    const std::vector<int32_t> &last_ray_index() const { return l_ray_idx; }
+    const std::vector<float> &last_rays() const { return l_rays; }
+};
+
+/// BGKLOctoMap: block-level BGK whose free-space evidence are the beams themselves (line segments) instead of
+/// down-sampled free points (reference include/bgkloctomap/bgkloctomap.h, src/bgkloctomap/bgkloctomap.cpp:31-57).
+/// Same node type and constructor argument order as BGKOctoMap.
+class BGKLOctoMap : public BGKOctoMap {
+public:
+    BGKLOctoMap() : BGKLOctoMap(0.1f, 4, 1.0, 1.0, 0.3f, 0.7f, 1.0f, 1.0f, 1.0f) {}
+    BGKLOctoMap(float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh, float occupied_thresh,
+                float var_thresh, float prior_A, float prior_B, int device = 0)
+        : BGKOctoMap(3, resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B, nullptr,
+                     device) {}
 };
 
 /// BGKLVOctoMap: variance-aware BGK with free-space line segments and per-voxel inference

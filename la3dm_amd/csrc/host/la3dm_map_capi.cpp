@@ -58,6 +58,29 @@ la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, flo
     }
 }
 
+la3dm_map *la3dm_map_create_l(float resolution, int block_depth, float sf2, float ell, float free_thresh,
+                              float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device) {
+    try {
+        la3dm_map *m = new la3dm_map;
+        m->map = new la3dm::BGKLOctoMap(resolution, (unsigned short)block_depth, sf2, ell, free_thresh, occupied_thresh,
+                                        var_thresh, prior_A, prior_B, device);
+        return m;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
+uint64_t la3dm_map_l_training(const la3dm_map *m, int32_t *ray_idx, uint64_t cap, float *rays6, uint64_t cap_rays,
+                              uint64_t *n_rays) {
+    const std::vector<int32_t> &ri = m->map->last_ray_index();
+    const std::vector<float> &ry = m->map->last_rays();
+    if (ray_idx) std::memcpy(ray_idx, ri.data(), sizeof(int32_t) * std::min<size_t>(ri.size(), cap));
+    if (rays6) std::memcpy(rays6, ry.data(), sizeof(float) * 6 * std::min<size_t>(ry.size() / 6, cap_rays));
+    if (n_rays) *n_rays = ry.size() / 6;
+    return ri.size();
+}
+
 la3dm_map *la3dm_map_create_lv(float resolution, int block_depth, float sf2, float ell, float free_thresh,
                                float occupied_thresh, float var_thresh, float prior_A, float prior_B, int original_size,
                                float min_W, int device) {

@@ -14,6 +14,7 @@
 #include "bgk_kernels.h"
 #include "gp_kernels.h"
 #include "lv_kernels.h"
+#include "bgkl_kernels.h"
 
 using namespace la3dm_dev;
 
@@ -285,7 +286,8 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
 
 typedef int (*scan_device_fn)(la3dm_ctx *, const la3dm_bgk_scan *, void *, la3dm_bgk_counters *);
 
-static int scan_host_common(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out, scan_device_fn run) {
+static int scan_host_common(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out, scan_device_fn run,
+                            size_t row_floats = 4) {
     int rc = check_scan(ctx, s);
     if (rc != LA3DM_OK) return rc;
     if (out) memset(out, 0, sizeof(*out));
@@ -297,7 +299,7 @@ static int scan_host_common(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_c
         const void *src;
         size_t bytes;
     } ups[] = {
-        {&ctx->h_train, s->train_xyzy, sizeof(float) * 4 * (size_t)s->n_train_pts},
+        {&ctx->h_train, s->train_xyzy, sizeof(float) * row_floats * (size_t)s->n_train_pts},
         {&ctx->h_train_off, s->train_off, sizeof(uint32_t) * ((size_t)s->n_train_blk + 1)},
         {&ctx->h_nbr, s->nbr, sizeof(int32_t) * 7 * (size_t)s->n_test_blk},
         {&ctx->h_center, s->blk_center, sizeof(float) * 3 * (size_t)s->n_test_blk},
@@ -517,6 +519,51 @@ int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream
     HIP_TRY(ctx, hipGetLastError());
     if (out) out->n_tiles = a.n_tasks;
     return LA3DM_OK;
+}
+
+// ---- BGKLOctoMap (row f4): rows of 8 floats in s->train_xyzy, CSR over training blocks in s->train_off ----
+int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_, la3dm_bgk_counters *out) {
+    int rc = check_scan(ctx, s);
+    if (rc != LA3DM_OK) return rc;
+    if (out) memset(out, 0, sizeof(*out));
+    if (s->n_test_blk == 0) return LA3DM_OK;
+    if (ctx->p.variant != 3) {
+        ctx->err = "la3dm_bgkl_scan: the context was not created with variant = 3 (BGKLOctoMap)";
+        return LA3DM_ERR_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t max_leaves = 1u << (3 * (ctx->p.block_depth - 1));
+    const uint32_t tpb = (max_leaves + kWave - 1) / kWave;
+    uint32_t tpb_shift = 0;
+    while ((1u << tpb_shift) < tpb) ++tpb_shift;
+    BgklArgs a;
+    a.rows = s->train_xyzy;
+    a.row_off = s->train_off;
+    a.nbr = s->nbr;
+    a.blk_center = s->blk_center;
+    a.leaf_off = s->leaf_off;
+    a.leaf_key = s->leaf_key;
+    a.alpha = s->alpha;
+    a.beta = s->beta;
+    a.state = s->state;
+    a.lut = ctx->d_lut;
+    a.n_test_blk = s->n_test_blk;
+    a.tpb_shift = tpb_shift;
+    a.n_tasks = s->n_test_blk << tpb_shift;
+    a.sf2 = ctx->p.sf2;
+    a.ell = ctx->p.ell;
+    a.free_thresh = ctx->p.free_thresh;
+    a.occupied_thresh = ctx->p.occupied_thresh;
+    a.var_thresh = ctx->p.var_thresh;
+    hipLaunchKernelGGL(bgkl_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), 0, stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    if (out) out->n_tiles = a.n_tasks;
+    return LA3DM_OK;
+}
+
+int la3dm_bgkl_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out) {
+    return scan_host_common(ctx, s, out, la3dm_bgkl_scan_device, 8);
 }
 
 int la3dm_bgklv_scan_host(la3dm_ctx *ctx, const la3dm_lv_scan *s, la3dm_bgk_counters *out) {

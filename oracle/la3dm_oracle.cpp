@@ -495,6 +495,96 @@ void get_training_data(const std::vector<V3> &cloud, V3 origin, float ds_resolut
 }
 
 // ---------------------------------------------------------------------------
+// BGKLOctoMap (block-level BGK with free-space line segments; variant 3 here)
+//   get_training_data / beam_sample   src/bgkloctomap/bgkloctomap.cpp:300-343, 359-381
+//   point_to_line_dist / covSparseLine include/bgkloctomap/bgklinference.h:104-140, 186-200
+// ---------------------------------------------------------------------------
+struct Seg {
+    V3 a, b;
+};
+struct LData {
+    std::vector<int> ray_idx;  // per training sample: -1 = hit, else index into rays
+    std::vector<Seg> rays;     // origin -> hit shortened by free_resolution
+};
+
+// Hits are re-projected as origin + n * l; free samples step DOWN from l - free_resolution while d > 0 and are
+// NOT voxel-filtered; every sample of a beam (and the origin sample that precedes them) carries the beam's index.
+void get_training_data_l(const std::vector<V3> &cloud, V3 origin, float ds_resolution, float free_resolution, float max_range,
+                         std::vector<XY> &xy, LData &ld) {
+    std::vector<V3> sampled_hits;
+    if (ds_resolution < 0) sampled_hits = cloud; else voxel_grid(cloud, ds_resolution, sampled_hits);
+    xy.clear();
+    ld.ray_idx.clear();
+    ld.rays.clear();
+    int idx = 0;
+    for (const V3 &p : sampled_hits) {
+        if (max_range > 0) {
+            float ddx = p.x - origin.x, ddy = p.y - origin.y, ddz = p.z - origin.z;
+            double l = sqrt((double)(ddx * ddx + ddy * ddy + ddz * ddz));
+            if (l > max_range) continue;
+        }
+        float l = (float)sqrt((p.x - origin.x) * (p.x - origin.x) + (p.y - origin.y) * (p.y - origin.y) +
+                              (p.z - origin.z) * (p.z - origin.z));
+        const float nx = (p.x - origin.x) / l, ny = (p.y - origin.y) / l, nz = (p.z - origin.z) / l;
+        const V3 occ{origin.x + nx * l, origin.y + ny * l, origin.z + nz * l};
+        xy.push_back(XY{occ, 1.0f});
+        ld.ray_idx.push_back(-1);
+        // beam_sample(occ_endpt, origin, ...): its own l and n from the re-projected end point
+        {
+            xy.push_back(XY{origin, 0.0f});
+            ld.ray_idx.push_back(idx);
+            const float l2 = (float)sqrt((occ.x - origin.x) * (occ.x - origin.x) + (occ.y - origin.y) * (occ.y - origin.y) +
+                                         (occ.z - origin.z) * (occ.z - origin.z));
+            const float mx = (occ.x - origin.x) / l2, my = (occ.y - origin.y) / l2, mz = (occ.z - origin.z) / l2;
+            float d = l2 - free_resolution;
+            while (d > 0.0) {
+                xy.push_back(XY{V3{origin.x + mx * d, origin.y + my * d, origin.z + mz * d}, 0.0f});
+                ld.ray_idx.push_back(idx);
+                d -= free_resolution;
+            }
+        }
+        l = l - free_resolution;
+        ld.rays.push_back(Seg{origin, V3{origin.x + nx * l, origin.y + ny * l, origin.z + nz * l}});
+        ++idx;
+    }
+}
+
+// point_to_line_dist for one (point, segment) pair: point3f arithmetic in float, norms and dots through double,
+// b = c1 / c2 in double narrowed to float by point3f::operator*(float) (bgklinference.h:104-140)
+inline float seg_dist_l(V3 p, V3 p0, V3 p1) {
+    auto sub = [](V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto norm = [](V3 a) { return sqrt((double)(a.x * a.x + a.y * a.y + a.z * a.z)); };
+    auto dot = [](V3 a, V3 b) { return (double)(a.x * b.x + a.y * b.y + a.z * b.z); };
+    const V3 line_vec = sub(p1, p0);
+    const float line_len = (float)norm(line_vec);
+    const V3 pnt_vec = sub(p, p0);
+    if (line_len < 0.0001f) return (float)norm(sub(p, p0));
+    const double c1 = dot(pnt_vec, line_vec), c2 = dot(line_vec, line_vec);
+    if (c1 <= 0) return (float)norm(sub(p, p0));
+    if (c2 <= c1) return (float)norm(sub(p, p1));
+    const float b = (float)(c1 / c2);
+    const V3 nearest{p0.x + line_vec.x * b, p0.y + line_vec.y * b, p0.z + line_vec.z * b};
+    return (float)norm(sub(p, nearest));
+}
+
+// BGKLInference::predict (bgklinference.h:80-88): rows = 6-float segments, labels y
+void bgkl_predict(float sf2, float ell, const float *xs, int M, const Seg *rows, const float *y, int N, float *ybar,
+                  float *kbar) {
+    for (int i = 0; i < M; ++i) {
+        const V3 q{xs[3 * i], xs[3 * i + 1], xs[3 * i + 2]};
+        float sy = 0.0f, sk = 0.0f;
+        for (int j = 0; j < N; ++j) {
+            const float r = seg_dist_l(q, rows[j].a, rows[j].b) / ell;  // Kxz /= ell
+            const float k = cov_sparse_elem(r, sf2);                     // formula + `< 0 -> 0` clean-up
+            sy += k * y[j];
+            sk += k;
+        }
+        ybar[i] = sy;
+        kbar[i] = sk;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Map
 // ---------------------------------------------------------------------------
 struct Stats {
@@ -570,7 +660,7 @@ double now_s() {
 }
 
 // Stages B..G of BGKOctoMap::insert_pointcloud, src/bgkoctomap/bgkoctomap.cpp:229-366
-void insert_xy(Map &m, const std::vector<XY> &xy) {
+void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr) {
     const Params &p = m.p;
     Stats &st = m.st;
     if (xy.empty()) return;  // :230-232
@@ -631,6 +721,28 @@ void insert_xy(Map &m, const std::vector<XY> &xy) {
             gp_train(p, bx.data(), by.data(), (int)ids.size(), gp_arr.find(tkeys[ti])->second);
         }
     }
+    // BGKLOctoMap: per training block, hits become degenerate segments (label 1) and every beam that has a sample
+    // in the block contributes its segment once, at the position of its first sample (bgkloctomap.cpp:141-170)
+    std::unordered_map<int64_t, std::pair<std::vector<Seg>, std::vector<float>>> bgkl_arr;
+    if (p.variant == 3) {
+        std::vector<int> stamp(ld->rays.size(), -1);
+        int serial = 0;
+        for (auto &kv : bgk_arr) {
+            auto &rows = bgkl_arr[kv.first];
+            for (int id : kv.second) {
+                const int r = ld->ray_idx[id];
+                if (r < 0) {
+                    rows.first.push_back(Seg{xy[id].p, xy[id].p});
+                    rows.second.push_back(1.0f);
+                } else if (stamp[r] != serial) {
+                    stamp[r] = serial;
+                    rows.first.push_back(ld->rays[r]);
+                    rows.second.push_back(0.0f);
+                }
+            }
+            ++serial;
+        }
+    }
     double t1 = now_s();
     st.t_partition = t1 - t0;
 
@@ -669,6 +781,19 @@ void insert_xy(Map &m, const std::vector<XY> &xy) {
         for (int k = 0; k < 7; ++k) {
             auto it = bgk_arr.find(eb[k]);
             if (it == bgk_arr.end()) continue;
+            if (p.variant == 3) {  // BGKLOctoMap: bgkloctomap.cpp:206-231, gate kbar > 0.001
+                const auto &rows = bgkl_arr.find(eb[k])->second;
+                const int NR = (int)rows.second.size();
+                pairs_ += (double)M * NR;
+                reads_ += NR;
+                bgkl_predict(p.sf2, p.ell, xs.data(), M, rows.first.data(), rows.second.data(), NR, ybar.data(), kbar.data());
+                for (int j = 0; j < M; ++j)
+                    if (kbar[j] > 0.001f) {
+                        node_update(p, block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF], ybar[j], kbar[j]);
+                        calls_ += 1;
+                    }
+                continue;
+            }
             const std::vector<int> &ids = it->second;
             int N = (int)ids.size();
             bx.resize((size_t)N * 3); by.resize(N);
@@ -745,6 +870,14 @@ void *orc_gp_map_create(float resolution, int block_depth, float sf2, float ell,
                   1, noise, l, 1.0f / max_var, 1.0f / min_var, 1.0f / max_known_var};
     m->lut = build_lut(resolution, block_depth);
     std::memset(&m->st, 0, sizeof(Stats));
+    return m;
+}
+// BGKLOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B):
+// src/bgkloctomap/bgkloctomap.cpp:31-57 (same node as BGKOctoMap, bgkloctree_node.cpp)
+void *orc_l_map_create(float resolution, int block_depth, float sf2, float ell, float free_thresh, float occupied_thresh,
+                       float var_thresh, float prior_A, float prior_B) {
+    Map *m = (Map *)orc_map_create(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B);
+    m->p.variant = 3;
     return m;
 }
 void orc_map_destroy(void *h) { delete (Map *)h; }
@@ -863,6 +996,47 @@ void orc_insert_pointcloud(void *h, const float *xyz, int64_t n, const float *or
     m->st.t_frontend = now_s() - t0;
     insert_xy(*m, xy);
     m->st.t_total = now_s() - t0;
+}
+// BGKLOctoMap::insert_pointcloud, src/bgkloctomap/bgkloctomap.cpp:83-296
+void orc_l_insert_pointcloud(void *h, const float *xyz, int64_t n, const float *origin, float ds_resolution, float free_res,
+                             float max_range) {
+    Map *m = (Map *)h;
+    double t0 = now_s();
+    std::vector<V3> cloud(n);
+    for (int64_t i = 0; i < n; ++i) cloud[i] = V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    std::vector<XY> xy;
+    LData ld;
+    get_training_data_l(cloud, V3{origin[0], origin[1], origin[2]}, ds_resolution, free_res, max_range, xy, ld);
+    m->st.n_hits = (double)ld.rays.size();
+    m->st.n_frees = (double)(xy.size() - ld.rays.size());
+    m->st.t_frontend = now_s() - t0;
+    insert_xy(*m, xy, &ld);
+    m->st.t_total = now_s() - t0;
+}
+// training set of BGKLOctoMap: samples (x, y, z, ray index or -1) and rays (6 floats); counts via null pointers
+int64_t orc_l_training_data(const float *xyz, int64_t n, const float *origin, float ds, float free_res, float max_range,
+                            float *out_xyzr, int64_t cap, float *out_rays, int64_t cap_rays, int64_t *n_rays) {
+    std::vector<V3> cloud(n);
+    for (int64_t i = 0; i < n; ++i) cloud[i] = V3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    std::vector<XY> xy;
+    LData ld;
+    get_training_data_l(cloud, V3{origin[0], origin[1], origin[2]}, ds, free_res, max_range, xy, ld);
+    if (out_xyzr)
+        for (int64_t i = 0; i < std::min<int64_t>(cap, (int64_t)xy.size()); ++i) {
+            out_xyzr[4 * i] = xy[i].p.x; out_xyzr[4 * i + 1] = xy[i].p.y; out_xyzr[4 * i + 2] = xy[i].p.z;
+            out_xyzr[4 * i + 3] = (float)ld.ray_idx[i];
+        }
+    if (out_rays)
+        for (int64_t i = 0; i < std::min<int64_t>(cap_rays, (int64_t)ld.rays.size()); ++i) {
+            const Seg &sg = ld.rays[i];
+            const float v[6] = {sg.a.x, sg.a.y, sg.a.z, sg.b.x, sg.b.y, sg.b.z};
+            std::memcpy(out_rays + 6 * i, v, sizeof(v));
+        }
+    if (n_rays) *n_rays = (int64_t)ld.rays.size();
+    return (int64_t)xy.size();
+}
+float orc_l_seg_dist(const float *p, const float *p0, const float *p1) {
+    return seg_dist_l(V3{p[0], p[1], p[2]}, V3{p0[0], p0[1], p0[2]}, V3{p1[0], p1[1], p1[2]});
 }
 // stages B..G on a prepared training set (x,y,z,label per point)
 void orc_insert_xy(void *h, const float *xyzy, int64_t n) {

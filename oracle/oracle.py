@@ -101,6 +101,14 @@ def _load(name):
     lib.orc_get_training_data.argtypes = [f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                           C.c_int64]
     lib.orc_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float]
+    lib.orc_l_map_create.restype = C.c_void_p
+    lib.orc_l_map_create.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7
+    lib.orc_l_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float]
+    lib.orc_l_training_data.restype = C.c_int64
+    lib.orc_l_training_data.argtypes = [f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.orc_l_seg_dist.restype = C.c_float
+    lib.orc_l_seg_dist.argtypes = [f32p, f32p, f32p]
     lib.orc_insert_xy.argtypes = [C.c_void_p, f32p, C.c_int64]
     lib.orc_stats.argtypes = [C.c_void_p, f64p]
     lib.orc_num_threads.restype = C.c_int
@@ -224,6 +232,39 @@ class OracleMap:
                                    out["B"], out["state"], out["classified"], n)
         assert m == n
         return out
+
+
+L_YAML = dict(resolution=0.1, block_depth=3, sf2=0.1, ell=0.2, free_thresh=0.3, occupied_thresh=0.7, var_thresh=0.15,
+              prior_A=0.001, prior_B=0.001)   # config/methods/bgkloctomap.yaml (free_resolution 0.3, ds_resolution 0.1)
+
+
+class OracleLMap(OracleMap):
+    """CPU BGKLOctoMap restatement (block-level BGK with free-space line segments, include/bgkloctomap/bgkloctomap.h)."""
+
+    def __init__(self, resolution=0.1, block_depth=3, sf2=0.1, ell=0.2, free_thresh=0.3, occupied_thresh=0.7,
+                 var_thresh=0.15, prior_A=0.001, prior_B=0.001, omp=False):
+        self.L = lib(omp)
+        self.h = self.L.orc_l_map_create(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+                                         prior_A, prior_B)
+        self.block_depth = block_depth
+
+    def insert_pointcloud(self, xyz, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        origin = np.ascontiguousarray(origin, np.float32)
+        self.L.orc_l_insert_pointcloud(self.h, xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range)
+
+
+def l_training_data(xyz, origin, ds_resolution, free_res, max_range):
+    """BGKLOctoMap training set: samples (x, y, z, ray index or -1), rays (6 floats)"""
+    L = lib()
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    origin = np.ascontiguousarray(origin, np.float32)
+    nr = C.c_int64()
+    n = L.orc_l_training_data(xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range, None, 0, None, 0, C.byref(nr))
+    xy, rays = np.zeros((n, 4), np.float32), np.zeros((nr.value, 6), np.float32)
+    L.orc_l_training_data(xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range, xy.ctypes.data, n,
+                          rays.ctypes.data, nr.value, C.byref(nr))
+    return xy, rays
 
 
 GP_YAML = dict(resolution=0.1, block_depth=3, sf2=1.0, ell=1.0, noise=0.01, l=100.0, min_var=0.001, max_var=1000.0,

@@ -99,3 +99,25 @@ def test_lv_host_front_end(built, res, depth):
         assert (s[first, :3] == r[:, :3]).all()
         pk = m.lv_packed()
         assert pk.n_samples == len(s) and pk.n_rays == len(r) and pk.n_blk == m.lv_stats()["n_packed_blocks"]
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_bgkl_host_front_end_and_rows(built, depth):
+    """BGKLOctoMap host side (bookkeeping-only map): training samples, beam indices and beams == oracle, and the
+    per-block segment rows have the oracle's counts (pair_evals / train_reads are counted in rows)"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.L_YAML, block_depth=depth)
+    m = la3dm_amd.BGKLOctoMap(**params, device=-1)
+    o = O.OracleLMap(**params)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 2))
+    assert m.prepare(xyz, origin, 0.1, 0.3, 8.0)
+    xy, rays = m.l_training()
+    rxy, rrays = O.l_training_data(xyz, origin, 0.1, 0.3, 8.0)
+    assert xy.shape == rxy.shape and rays.shape == rrays.shape
+    assert (xy.view(np.uint32) == rxy.view(np.uint32)).all() and (rays.view(np.uint32) == rrays.view(np.uint32)).all()
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+    st, so = m.stats(), o.stats()
+    for k in ("n_hits", "n_frees", "n_bbox_blocks", "n_train_blocks", "n_test_blocks", "voxel_updates", "pair_evals",
+              "train_reads"):
+        assert st[k] == so[k], (k, st[k], so[k])
