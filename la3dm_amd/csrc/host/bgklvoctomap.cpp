@@ -112,50 +112,81 @@ void BGKLVOctoMap::training_data_lv(const float *xyz, size_t n, size_t stride, c
     const double offset = OcTreeNode::ell * pow(2, 0.5);
     const double influence = OcTreeNode::ell;
     const float ox = origin.x(), oy = origin.y(), oz = origin.z();
-    std::vector<point3f> nearby;
+    // Phase 1 (parallel over beams — each beam only reads the hit list): range gate, shortening against nearby hits,
+    // the downward-ray filter and the segment end points.  Phase 2 emits samples and rays in beam order.
+    struct Beam {
+        uint8_t hit, skip;
+        float fo[3], fe[3];
+    };
+    std::vector<Beam> beams(nh);
+    // a small team: the loop is ~30 ms of single-core work; a team as large as the machine costs more in start-up
+    // and spin-waiting (which also disturbs the HIP runtime's threads) than it saves
+#pragma omp parallel num_threads(16)
+    {
+        std::vector<point3f> nearby;
+#pragma omp for schedule(dynamic, 16)
+        for (long hh = 0; hh < (long)nh; ++hh) {
+            const size_t h = (size_t)hh;
+            Beam &bm = beams[h];
+            bm.hit = bm.skip = 0;
+            const point3f p(hits[3 * h], hits[3 * h + 1], hits[3 * h + 2]);
+            double l = (p - origin).norm();
+            const float nx = (float)((p.x() - ox) / l), ny = (float)((p.y() - oy) / l), nz = (float)((p.z() - oz) / l);
+            if (max_range > 0) {
+                if (l < max_range) {
+                    l = (float)sqrt((p.x() - ox) * (p.x() - ox) + (p.y() - oy) * (p.y() - oy) + (p.z() - oz) * (p.z() - oz));
+                    l = l - offset;
+                    bm.hit = 1;
+                } else {
+                    l = max_range - offset;
+                }
+            }
+            point3f nearest_point = p;
+            point3f free_endpt((float)(ox + nx * l), (float)(oy + ny * l), (float)(oz + nz * l));
+            nearby.clear();
+            for (size_t q = 0; q < nh; ++q) {
+                const point3f p0(hits[3 * q], hits[3 * q + 1], hits[3 * q + 2]);
+                if (max_range > 0 && (p0 - origin).norm() > max_range) continue;
+                if (p.z() > (offset + oz) && p0.z() < oz + influence) continue;  // keeps free space above the floor
+                const double dist1 = (free_endpt - p0).norm(), dist2 = (origin - p0).norm();
+                if (dist1 < influence || (dist1 < l && dist2 < l)) nearby.push_back(p0);
+            }
+            const point3f line_vec = free_endpt - origin;
+            for (const point3f &p1 : nearby) {
+                const point3f pnt_vec = p1 - origin;
+                const double b = (double)(pnt_vec.x() * line_vec.x() + pnt_vec.y() * line_vec.y() + pnt_vec.z() * line_vec.z());
+                if (b > pow(l, 2)) continue;
+                const point3f nearest = origin + line_vec * (float)(b / pow(line_vec.norm(), 2));
+                if ((p1 - nearest).norm() < influence) {
+                    nearest_point = p1;
+                    l = b / line_vec.norm();
+                }
+            }
+            if (l < max_range / 5.0 && l / (offset - nearest_point.z()) > 0) {  // downward rays close to the sensor
+                bm.skip = 1;
+                continue;
+            }
+            free_endpt = point3f((float)(ox + nx * l), (float)(oy + ny * l), (float)(oz + nz * l));
+            point3f free_origin = free_endpt;
+            if (l > influence * 1.0)
+                free_origin = point3f((float)(ox + nx * influence * 1.0), (float)(oy + ny * influence * 1.0),
+                                      (float)(oz + nz * influence * 1.0));
+            for (int a2 = 0; a2 < 3; ++a2) {
+                bm.fo[a2] = free_origin(a2);
+                bm.fe[a2] = free_endpt(a2);
+            }
+        }
+    }
     uint32_t ray = 0;
     lvst.n_hits = 0;
     for (size_t h = 0; h < nh; ++h) {
-        const point3f p(hits[3 * h], hits[3 * h + 1], hits[3 * h + 2]);
-        double l = (p - origin).norm();
-        const float nx = (float)((p.x() - ox) / l), ny = (float)((p.y() - oy) / l), nz = (float)((p.z() - oz) / l);
-        if (max_range > 0) {
-            if (l < max_range) {
-                l = (float)sqrt((p.x() - ox) * (p.x() - ox) + (p.y() - oy) * (p.y() - oy) + (p.z() - oz) * (p.z() - oz));
-                l = l - offset;
-                samples.insert(samples.end(), {p.x(), p.y(), p.z(), -1.0f});
-                ++lvst.n_hits;
-            } else {
-                l = max_range - offset;
-            }
+        const Beam &bm = beams[h];
+        if (bm.hit) {
+            samples.insert(samples.end(), {hits[3 * h], hits[3 * h + 1], hits[3 * h + 2], -1.0f});
+            ++lvst.n_hits;
         }
-        point3f nearest_point = p;
-        point3f free_endpt((float)(ox + nx * l), (float)(oy + ny * l), (float)(oz + nz * l));
-        nearby.clear();
-        for (size_t q = 0; q < nh; ++q) {
-            const point3f p0(hits[3 * q], hits[3 * q + 1], hits[3 * q + 2]);
-            if (max_range > 0 && (p0 - origin).norm() > max_range) continue;
-            if (p.z() > (offset + oz) && p0.z() < oz + influence) continue;  // keeps free space above the floor
-            const double dist1 = (free_endpt - p0).norm(), dist2 = (origin - p0).norm();
-            if (dist1 < influence || (dist1 < l && dist2 < l)) nearby.push_back(p0);
-        }
-        const point3f line_vec = free_endpt - origin;
-        for (const point3f &p1 : nearby) {
-            const point3f pnt_vec = p1 - origin;
-            const double b = (double)(pnt_vec.x() * line_vec.x() + pnt_vec.y() * line_vec.y() + pnt_vec.z() * line_vec.z());
-            if (b > pow(l, 2)) continue;
-            const point3f nearest = origin + line_vec * (float)(b / pow(line_vec.norm(), 2));
-            if ((p1 - nearest).norm() < influence) {
-                nearest_point = p1;
-                l = b / line_vec.norm();
-            }
-        }
-        if (l < max_range / 5.0 && l / (offset - nearest_point.z()) > 0) continue;  // downward rays close to the sensor
-        free_endpt = point3f((float)(ox + nx * l), (float)(oy + ny * l), (float)(oz + nz * l));
-        point3f free_origin = free_endpt;
-        if (l > influence * 1.0)
-            free_origin = point3f((float)(ox + nx * influence * 1.0), (float)(oy + ny * influence * 1.0),
-                                  (float)(oz + nz * influence * 1.0));
+        if (bm.skip) continue;
+        const point3f free_origin(bm.fo[0], bm.fo[1], bm.fo[2]), free_endpt(bm.fe[0], bm.fe[1], bm.fe[2]);
         const uint32_t first = (uint32_t)(samples.size() / 4);
         samples.insert(samples.end(), {free_origin.x(), free_origin.y(), free_origin.z(), (float)ray});
         {  // samples from the segment end back towards its start
