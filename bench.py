@@ -52,7 +52,8 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): 1 skip k(r) evaluation, 2 skip tests")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (device-resident insert_pointcloud) leg")
-    ap.add_argument("--cpu-omp", action="store_true", help="also time the OpenMP oracle on all cores")
+    ap.add_argument("--no-cpu-omp", dest="cpu_omp", action="store_false",
+                    help="skip the all-core OpenMP run of the oracle (cpu_baseline_omp)")
     args = ap.parse_args()
 
     import torch

@@ -178,6 +178,24 @@ def test_synthetic_scan(built):
         _same(m, o, f"synth d{depth}")
 
 
+def test_growing_map_moving_sensor(built):
+    """a sensor moving through a large scene: the block pool is re-allocated and the hash table rebuilt several
+    times while earlier blocks keep being updated (overlapping scans)"""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML)
+    m, o = _maps(params)
+    xyz, origin = la3dm_amd.synthetic_scan(20000)
+    origin = np.asarray(origin, np.float32)
+    nb = []
+    for k, off in enumerate([(0, 0, 0), (6.0, 0, 0), (12.0, 3.0, 0), (3.0, 0.5, 0), (18.0, -4.0, 0.2), (24.0, 0, 0)]):
+        off = np.array(off, np.float32)
+        m.insert_pointcloud(xyz + off, origin + off, 0.1, 0.5, -1.0)
+        o.insert_pointcloud(xyz + off, origin + off, 0.1, 0.5, -1.0)
+        nb.append(m.stats()["n_test_blocks"])
+    _same(m, o, "moving")
+    assert m.block_count() > 60000      # > 2 pool re-allocations (x1.5 growth) and a table rebuild (> 16 k blocks)
+
+
 def test_edge_cases(built):
     import la3dm_amd
     params = dict(la3dm_amd.BGK_YAML)
