@@ -199,10 +199,44 @@ def oracle_kat():
     print("oracle_kat.npz:", len(out), "arrays")
 
 
+def scan_kat():
+    """Full-scan leaf dumps of the CPU restatement (regression pins of the whole path; the GPU tests compare the HIP
+    path against these files directly, besides the live oracle): sim_structured scan 1 (BASELINE configs[0]) for
+    BGKOctoMap at depth 3 and 4, GPOctoMap, BGKLOctoMap; sim_unstructured scan 1 for BGKLVOctoMap at 0.05 m."""
+    sys.path.insert(0, os.path.join(ROOT))
+    import la3dm_amd
+    out = {}
+    xyz, origin = la3dm_amd.load_pcd(os.path.join(HERE, "data", "sim_structured", "sim_structured_1.pcd"))
+
+    def put(tag, lv, keys=("block_key", "node_key", "A", "B", "state", "classified")):
+        for k in keys:
+            out[f"{tag}_{k}"] = lv[k]
+
+    for depth in (3, 4):
+        o = O.OracleMap(**dict(O.BGK_YAML, block_depth=depth))
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        put(f"bgk_d{depth}", o.leaves())
+    o = O.OracleGPMap(**O.GP_YAML)
+    o.insert_pointcloud(xyz[::3], origin, 0.1, 0.5, 8.0)
+    put("gp_d3", o.leaves())
+    o = O.OracleLMap(**O.L_YAML)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+    put("bgkl_d3", o.leaves())
+    xyz_u, origin_u = la3dm_amd.load_pcd(os.path.join(HERE, "data", "sim_unstructured", "sim_unstructured_1.pcd"))
+    o = O.OracleLVMap(**dict(O.LV_YAML, resolution=0.05))
+    o.insert_pointcloud(xyz_u, origin_u, 0.05, 0.1, 8.0)
+    put("lv_d5", o.leaves())
+    np.savez_compressed(os.path.join(HERE, "scan_kat.npz"), **out)
+    print("scan_kat.npz:", len(out), "arrays,", {k: int(v.shape[0]) for k, v in out.items() if k.endswith("_A")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "grid":   # added later: does not disturb the older fixtures
         ref_grid_kat()
+    elif len(sys.argv) > 1 and sys.argv[1] == "scan":
+        scan_kat()
     else:
         ref_kat()
         oracle_kat()
         ref_grid_kat()
+        scan_kat()

@@ -187,3 +187,21 @@ def test_front_end(O):
     o2.insert_pointcloud(np.array([[20, 0, 0]], np.float32), [0, 0, 0], 0.1, 0.5, 8.0)
     o2.insert_pointcloud(np.zeros((0, 3), np.float32), [0, 0, 0], 0.1, 0.5, 8.0)
     assert o2.leaves()["A"].size == 0
+
+
+def test_full_scan_fixtures_reproduced(O):
+    """the committed full-scan leaf dumps (tests/golden/scan_kat.npz) pin the whole restated path: any change of the
+    oracle that moves a single bit of a leaf shows up here"""
+    import la3dm_amd
+    kat = np.load(os.path.join(GOLDEN, "scan_kat.npz"))
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    o = O.OracleMap(**O.BGK_YAML)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    lv = o.leaves()
+    for k in ("block_key", "node_key", "A", "B", "state", "classified"):
+        assert lv[k].shape == kat[f"bgk_d3_{k}"].shape and (lv[k] == kat[f"bgk_d3_{k}"]).all(), k
+    o = O.OracleLMap(**O.L_YAML)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+    lv = o.leaves()
+    for k in ("block_key", "node_key", "A", "B", "state", "classified"):
+        assert lv[k].shape == kat[f"bgkl_d3_{k}"].shape and (lv[k] == kat[f"bgkl_d3_{k}"]).all(), k
