@@ -295,13 +295,137 @@ __device__ __forceinline__ float matern3_fast(float ax, float ay, float az, floa
     return ((1 + d) * exp_cr_dev(-d)) * sf2;
 }
 
+// ---------------------------------------------------------------------------
+// v = L^-1 Ks for training blocks with N > 64 on the matrix cores, bit-identical to the FMA chains.
+//
+// v_mfma_f32_32x32x2_f32 accumulates D = C + A B as a chain of fp32 FMAs over k ascending (measured: 0 mismatches
+// against fmaf chains, scratch/mfma/mfma_order.hip), so a blocked forward substitution whose off-diagonal updates
+//      C[K] = Ks[K] - sum_{J<K} L[K][J] V[J]            (J ascending, k ascending inside a block)
+// run on MFMA reproduces  acc = fma(-L_ki, v_i, acc), i = 0..k-1  of the oracle exactly; the 32 x 32 diagonal
+// blocks continue each chain on the VALU.  Layout: one wave handles the tile's 64 leaves as two 32-column
+// accumulators; lane (c = lane % 32, h = lane / 32) owns rows 8g + 4h + j of a block for leaves c and 32 + c, so the
+// serial row order alternates between the half-waves every four rows: chains (m, sum v^2) and the freshly solved
+// v are handed over with a lane ^ 32 exchange.  V lives in the task's global scratch [row][64] (L2 resident),
+// which is also the B operand of the MFMAs; L is read in place (A operand, negated on load).
+// Returns m = Ks^T alpha and ss = sum v_k^2 for leaf = lane.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+
+__device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__restrict__ L, const float4 *__restrict__ x,
+                                              const float *__restrict__ al, const int N, const float tx, const float ty,
+                                              const float tz, float *__restrict__ vg, const int lane, float &mj_out,
+                                              float &ss_out) {
+    const int c = lane & 31, h = lane >> 5;
+    const float t0x = __shfl(tx, c), t0y = __shfl(ty, c), t0z = __shfl(tz, c);
+    const float t1x = __shfl(tx, 32 + c), t1y = __shfl(ty, 32 + c), t1z = __shfl(tz, 32 + c);
+    float mj0 = 0.0f, mj1 = 0.0f, ss0 = 0.0f, ss1 = 0.0f;  // the live copies sit in half 0 at every block start
+    const int nblk = (N + 31) >> 5;
+    for (int K = 0; K < nblk; ++K) {
+        const int R0 = 32 * K;
+        f32x16 C0, C1;
+        float alv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // Ks(k, j) = k(x_k, xs_j) in accumulator layout
+            const int row = R0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const bool valid = row < N;
+            const float4 xr = valid ? x[row] : make_float4(0.f, 0.f, 0.f, 0.f);
+            C0[r] = valid ? matern3_fast(xr.x, xr.y, xr.z, t0x, t0y, t0z, a.sf2) : 0.0f;
+            C1[r] = valid ? matern3_fast(xr.x, xr.y, xr.z, t1x, t1y, t1z, a.sf2) : 0.0f;
+            alv[r] = valid ? al[row] : 0.0f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // m = Ks^T alpha, rows in order: 4 rows in half 0, 4 rows in half 1, ...
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (h == hh) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mj0 = __builtin_fmaf(C0[4 * g + j], alv[4 * g + j], mj0);
+                        mj1 = __builtin_fmaf(C1[4 * g + j], alv[4 * g + j], mj1);
+                    }
+                }
+                mj0 = xhalf(mj0);
+                mj1 = xhalf(mj1);
+            }
+        }
+        // off-diagonal blocks on the matrix cores: C -= L[K][J] V[J]
+        {
+            const int arow = R0 + c;
+            const bool avalid = arow < N;
+            const float *Lrow = L + (size_t)(avalid ? arow : 0) * N;
+            for (int J = 0; J < K; ++J) {
+#pragma unroll 4
+                for (int m2 = 0; m2 < 16; ++m2) {
+                    const int kcol = 32 * J + 2 * m2 + h;
+                    const float av = avalid ? -Lrow[kcol] : 0.0f;
+                    const float b0 = vg[(size_t)kcol * kWave + c], b1 = vg[(size_t)kcol * kWave + 32 + c];
+                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, C0, 0, 0, 0);
+                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, C1, 0, 0, 0);
+                }
+            }
+        }
+        // diagonal block: rows in order, four at a time in alternating half-waves
+        float vb0[32], vb1[32];
+#pragma unroll
+        for (int G = 0; G < 8; ++G) {
+            const int hh = G & 1, base = 4 * (G >> 1);
+            float n0[4], n1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * G + j;
+                const int row = R0 + r;
+                const bool valid = row < N;  // wave-uniform
+                const float *Ld = L + (size_t)(valid ? row : 0) * N + R0;
+                float acc0 = C0[base + j], acc1 = C1[base + j];
+#pragma unroll
+                for (int w = 0; w < r; ++w) {
+                    const float lw = valid ? Ld[w] : 0.0f;
+                    acc0 = __builtin_fmaf(-lw, vb0[w], acc0);
+                    acc1 = __builtin_fmaf(-lw, vb1[w], acc1);
+                }
+                const float d = valid ? Ld[r] : 1.0f;
+                const float v0 = acc0 / d, v1 = acc1 / d;
+                vb0[r] = v0;  // right in the owning half; the other half is repaired after the group
+                vb1[r] = v1;
+                n0[j] = v0;
+                n1[j] = v1;
+                if (h == hh) {
+                    ss0 = __builtin_fmaf(v0, v0, ss0);
+                    ss1 = __builtin_fmaf(v1, v1, ss1);
+                    if (valid) {
+                        vg[(size_t)row * kWave + c] = v0;
+                        vg[(size_t)row * kWave + 32 + c] = v1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o0 = xhalf(n0[j]), o1 = xhalf(n1[j]);
+                vb0[4 * G + j] = h == hh ? n0[j] : o0;
+                vb1[4 * G + j] = h == hh ? n1[j] : o1;
+            }
+            ss0 = xhalf(ss0);
+            ss1 = xhalf(ss1);
+        }
+        // V[K] is read back as MFMA B operands by the other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    const float m1x = xhalf(mj1), s1x = xhalf(ss1);
+    mj_out = h == 0 ? mj0 : m1x;
+    ss_out = h == 0 ? ss0 : s1x;
+}
+
 // GPRegressor::predict + BCM fusion: one wave64 per leaf tile, lane = leaf (test point).
 // v = L^-1 Ks per lane: v_k = (Ks_k - sum_{i<k} L_ki v_i) / L_kk.  Four rows at a time: their FMA chains
 // over the already solved i are independent (latency hidden, one LDS read of v_i feeds four rows), each
 // chain still runs over i ascending — the oracle's order.  Rows of L are loaded with coalesced vector
-// loads (lane = column) and broadcast with v_readlane; v lives in LDS [row][lane] (global scratch for
-// blocks larger than the LDS slot).
-constexpr int kGpLdsRows = 96;
+// loads (lane = column) and broadcast with v_readlane; v lives in LDS [row][lane].  Blocks with more than 64
+// rows go through gp_solve_mfma (above).
+constexpr int kGpLdsRows = 64;  // blocks up to one wave of rows are solved in LDS; larger ones on the matrix cores
 
 __global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
     extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: sized per launch, LDS is the occupancy limiter
@@ -371,22 +495,7 @@ __global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
                 }
             }
         } else {
-            const bool in_lds = N <= kGpLdsRows;
-            for (int k = 0; k < N; ++k) {
-                const float4 xk = x[k];
-                const float ks = matern3_fast(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);
-                mj = __builtin_fmaf(ks, al[k], mj);
-                float acc = ks;
-                const float *Lk = L + (size_t)k * N;
-                if (in_lds) {
-                    for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], s_v[i][lane], acc);
-                } else {
-                    for (int i = 0; i < k; ++i) acc = __builtin_fmaf(-Lk[i], vg[(size_t)i * kWave + lane], acc);
-                }
-                const float vk = acc / Lk[k];
-                if (in_lds) s_v[k][lane] = vk; else vg[(size_t)k * kWave + lane] = vk;
-                ss = __builtin_fmaf(vk, vk, ss);
-            }
+            gp_solve_mfma(a, L, x, al, N, tx, ty, tz, vg, lane, mj, ss);
         }
         const float var = a.sf2 - ss;
         gp_node_update_dev(a, m_ivar, ivar, state, mj, var);
