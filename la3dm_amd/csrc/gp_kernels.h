@@ -8,8 +8,9 @@
 //   update loop             src/gpoctomap/gpoctomap.cpp:306-319 (unconditional, ExtendedBlock order)
 //
 // Numerics: every inner product is an fp32 FMA chain in ascending index order — exactly the order
-// the oracle uses (and the order v_mfma_f32_32x32x2_f32 accumulates in), so the results are
-// bit-identical to the CPU restatement; exp() is the correctly rounded single-precision value
+// the oracle uses and, as measured on MI355X (scratch/mfma/mfma_order.hip), the order
+// v_mfma_f32_32x32x2_f32 accumulates in — so the results are bit-identical to the CPU restatement
+// whether a chain runs on the VALU or on the matrix cores; exp() is the correctly rounded single-precision value
 // (f64 library exp rounded once).  Eigen's own LLT/GEMV/packet-exp orders are unpinned.
 #pragma once
 #include <hip/hip_runtime.h>
