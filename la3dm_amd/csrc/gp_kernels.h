@@ -43,6 +43,7 @@ struct GpArgs {
 };
 
 constexpr int kGpTrainLdsMaxN = 128;  // blocks up to this size are factored by one wave in LDS
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float cr_expf_dev(float x) { return (float)exp((double)x); }
 
@@ -113,72 +114,195 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
     }
 }
 
-// GPRegressor::train for one training block per workgroup (256 threads, rows strided over threads).
-// K is built in place in the block's N x N slot, factored column by column (FMA chains over k
-// ascending), then alpha = L^-T (L^-1 y).
-__global__ __launch_bounds__(256) void gp_train_kernel(GpArgs a) {
+// GPRegressor::train for training blocks with N > 128: one wave64 per block, blocked 32 x 32, the factor built in
+// place in the block's N x N slot of Lmat.  Every entry is the oracle's chain
+//     L_ij = (K_ij - sum_{k<j} L_ik L_jk) / d_j,   d_j = sqrt(K_jj - sum_{k<j} L_jk^2),   k ascending:
+// the part of each chain that runs over earlier block columns is a 32x32x2 MFMA sequence (A = -L[I][T],
+// B = L[J][T]^T, T then k ascending — v_mfma_f32_32x32x2_f32 accumulates as a sequential fp32 FMA chain, see
+// gp_solve_mfma), the part inside block column J continues on the VALU after a transpose through LDS to
+// lane = row (diagonal block: unblocked Cholesky, row j broadcast with v_readlane; blocks below it: a forward
+// substitution against the diagonal block, two row blocks per pass in the two half-waves).
+// alpha = L^-T (L^-1 y) follows with lane = row inside a 32-row block and the solved part as wave-uniform scalars.
+constexpr int kTrT = 33;  // padded tile row (floats)
+
+__device__ __forceinline__ float rl(float v, int lane_idx) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx));
+}
+
+__global__ __launch_bounds__(kWave) void gp_train_kernel(GpArgs a) {
+    __shared__ float s_tile[2][32][kTrT];
     const uint32_t b = blockIdx.x;
     const uint32_t p0 = a.train_off[b];
     const int N = (int)(a.train_off[b + 1] - p0);
-    if (N == 0 || N <= kGpTrainLdsMaxN) return;  // small blocks: gp_train_wave_kernel
+    if (N <= kGpTrainLdsMaxN) return;  // small blocks: gp_train_wave_kernel
     float *L = a.Lmat + a.l_off[b];
     const float4 *x = a.pts + p0;
-    const int tid = threadIdx.x;
-    __shared__ float s_d;
-    __shared__ float s_z;
-    // K(i, j), i >= j; + noise on the diagonal (gpregressor.h:44-46)
-    for (int e = tid; e < N * N; e += 256) {
-        const int i = e / N, j = e - i * N;
-        if (j > i) continue;
-        const float4 xi = x[i], xj = x[j];
-        float k = matern3_fast(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);  // dist(x, z)(i, j) = |z_j - x_i|
-        if (i == j) k = k + a.noise;
-        L[(size_t)i * N + j] = k;
-    }
-    __syncthreads();
-    // LLT (gpregressor.h:47)
-    for (int j = 0; j < N; ++j) {
-        if (tid == 0) {
-            float acc = L[(size_t)j * N + j];
-            for (int k = 0; k < j; ++k) acc = __builtin_fmaf(-L[(size_t)j * N + k], L[(size_t)j * N + k], acc);
-            s_d = sqrtf(acc);
+    const int lane = threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+    const int nblk = (N + 31) >> 5;
+
+    // K(i, j) for the 32 x 32 block (RI, RJ) in accumulator layout: rows 8g + 4h + j, column c; the padding
+    // beyond N is the identity so that padded rows factor to d = 1 and contribute nothing
+    auto kblock = [&](int RI, int RJ, f32x16 &C) {
+        const int col = RJ + c;
+        const float4 xc = col < N ? x[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = RI + 8 * (r >> 2) + 4 * h + (r & 3);
+            float kv = 0.0f;
+            if (row < N && col < N) {
+                const float4 xr = x[row];
+                kv = matern3_fast(xr.x, xr.y, xr.z, xc.x, xc.y, xc.z, a.sf2);
+                if (row == col) kv = kv + a.noise;
+            } else if (row == col) {
+                kv = 1.0f;
+            }
+            C[r] = kv;
         }
-        __syncthreads();
-        const float d = s_d;
-        for (int i = j + 1 + tid; i < N; i += 256) {
-            float acc = L[(size_t)i * N + j];
-            for (int k = 0; k < j; ++k) acc = __builtin_fmaf(-L[(size_t)i * N + k], L[(size_t)j * N + k], acc);
-            L[(size_t)i * N + j] = acc / d;
+    };
+    // accumulator layout -> tile[row][col]
+    auto to_tile = [&](const f32x16 &C, int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_tile[t][8 * (r >> 2) + 4 * h + (r & 3)][c] = C[r];
+    };
+
+    for (int J = 0; J < nblk; ++J) {
+        const int RJ = 32 * J;
+        // ---------------- diagonal block ----------------
+        float dg[32];  // lane = row (both half-waves hold the same rows): row (lane % 32) of L[J][J]
+        {
+            f32x16 C;
+            kblock(RJ, RJ, C);
+            const int arow = RJ + c;
+            const float *Lrow = L + (size_t)(arow < N ? arow : 0) * N;
+            for (int T = 0; T < J; ++T) {
+#pragma unroll 4
+                for (int m2 = 0; m2 < 16; ++m2) {
+                    const float lv = arow < N ? Lrow[32 * T + 2 * m2 + h] : 0.0f;
+                    C = __builtin_amdgcn_mfma_f32_32x32x2f32(-lv, lv, C, 0, 0, 0);
+                }
+            }
+            to_tile(C, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int w = 0; w < 32; ++w) dg[w] = s_tile[0][c][w];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                float acc = dg[j];
+#pragma unroll
+                for (int w = 0; w < j; ++w) acc = __builtin_fmaf(-dg[w], rl(dg[w], j), acc);
+                const float d = sqrtf(rl(acc, j));
+                dg[j] = c == j ? d : acc / d;  // rows above the diagonal hold junk that is never read
+            }
+            if (h == 0 && arow < N) {
+                float *dst = L + (size_t)arow * N + RJ;
+#pragma unroll
+                for (int w = 0; w < 32; ++w)
+                    if (w <= c && RJ + w < N) dst[w] = dg[w];
+            }
         }
-        if (tid == 0) L[(size_t)j * N + j] = d;
-        __syncthreads();
+        // ---------------- blocks below the diagonal, two per pass ----------------
+        for (int I = J + 1; I < nblk; I += 2) {
+            const int RI0 = 32 * I, RI1 = 32 * (I + 1);
+            const bool two = I + 1 < nblk;
+            f32x16 C0, C1;
+            kblock(RI0, RJ, C0);
+            if (two) kblock(RI1, RJ, C1);
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) C1[r] = 0.0f;
+            }
+            {
+                const int r0 = RI0 + c, r1 = RI1 + c, rb = RJ + c;
+                const float *A0 = L + (size_t)(r0 < N ? r0 : 0) * N, *A1 = L + (size_t)(two && r1 < N ? r1 : 0) * N;
+                const float *Bp = L + (size_t)(rb < N ? rb : 0) * N;
+                for (int T = 0; T < J; ++T) {
+#pragma unroll 4
+                    for (int m2 = 0; m2 < 16; ++m2) {
+                        const int kc = 32 * T + 2 * m2 + h;
+                        const float bv = rb < N ? Bp[kc] : 0.0f;
+                        const float a0 = r0 < N ? -A0[kc] : 0.0f;
+                        const float a1 = (two && r1 < N) ? -A1[kc] : 0.0f;
+                        C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, C0, 0, 0, 0);
+                        C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, C1, 0, 0, 0);
+                    }
+                }
+            }
+            to_tile(C0, 0);
+            to_tile(C1, 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float rw[32];  // lane = row: half 0 -> block I, half 1 -> block I + 1
+#pragma unroll
+            for (int w = 0; w < 32; ++w) rw[w] = s_tile[h][c][w];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                float acc = rw[j];
+#pragma unroll
+                for (int w = 0; w < j; ++w) acc = __builtin_fmaf(-rw[w], rl(dg[w], j), acc);
+                rw[j] = acc / rl(dg[j], j);
+            }
+            const int orow = (h ? RI1 : RI0) + c;
+            if (orow < N && (h == 0 || two)) {
+                float *dst = L + (size_t)orow * N + RJ;
+#pragma unroll
+                for (int w = 0; w < 32; ++w)
+                    if (RJ + w < N) dst[w] = rw[w];
+            }
+        }
+        // the block column is read back (as MFMA operands) by other lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    // alpha = llt.solve(y) (gpregressor.h:48): z = L^-1 y (chains over k ascending), alpha = L^-T z
-    // (chains over k descending).  Right-looking: rows owned by threads, accumulators in alpha_k.
+
+    // ---------------- alpha = llt.solve(y) (gpregressor.h:48) ----------------
+    // forward: z_j = (y_j - sum_{k<j} L_jk z_k) / L_jj, k ascending.  lane = row inside a 32-row block.
     float *al = a.alpha_k + p0;
-    for (int i = tid; i < N; i += 256) al[i] = x[i].w;
-    __syncthreads();
-    for (int j = 0; j < N; ++j) {
-        if (tid == 0) {
-            const float z = al[j] / L[(size_t)j * N + j];
-            al[j] = z;
-            s_z = z;
+    for (int K = 0; K < nblk; ++K) {
+        const int row = 32 * K + c;
+        const bool valid = row < N;
+        const float *Lr = L + (size_t)(valid ? row : 0) * N;
+        float acc = valid ? x[row].w : 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 32 * K; ++k) acc = __builtin_fmaf(-(valid ? Lr[k] : 0.0f), al[k], acc);
+#pragma unroll 4
+        for (int w = 0; w < 32; ++w) {
+            const int rw_ = 32 * K + w;
+            const float dd = rw_ < N ? L[(size_t)rw_ * N + rw_] : 1.0f;
+            const float z = rl(acc, w) / dd;
+            if (c == w) acc = z;
+            else if (c > w) acc = __builtin_fmaf(-(valid ? Lr[32 * K + w] : 0.0f), z, acc);
         }
-        __syncthreads();
-        const float z = s_z;
-        for (int i = j + 1 + tid; i < N; i += 256) al[i] = __builtin_fmaf(-L[(size_t)i * N + j], z, al[i]);
-        __syncthreads();
+        if (h == 0 && valid) al[row] = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    for (int j = N - 1; j >= 0; --j) {
-        if (tid == 0) {
-            const float v = al[j] / L[(size_t)j * N + j];
-            al[j] = v;
-            s_z = v;
+    // backward: alpha_j = (z_j - sum_{k>j} L_kj alpha_k) / L_jj, k descending
+    for (int K = nblk - 1; K >= 0; --K) {
+        const int row = 32 * K + c;
+        const bool valid = row < N;
+        float acc = valid ? al[row] : 0.0f;
+#pragma unroll 8
+        for (int k = N - 1; k >= 32 * K + 32; --k) acc = __builtin_fmaf(-(valid ? L[(size_t)k * N + row] : 0.0f), al[k], acc);
+#pragma unroll 4
+        for (int w = 31; w >= 0; --w) {
+            const int rw_ = 32 * K + w;
+            if (rw_ >= N) continue;  // wave-uniform: padded rows take no part
+            const float dd = L[(size_t)rw_ * N + rw_];
+            const float v = rl(acc, w) / dd;
+            if (c == w) acc = v;
+            else if (c < w) acc = __builtin_fmaf(-(valid ? L[(size_t)rw_ * N + row] : 0.0f), v, acc);
         }
-        __syncthreads();
-        const float v = s_z;
-        for (int i = tid; i < j; i += 256) al[i] = __builtin_fmaf(-L[(size_t)j * N + i], v, al[i]);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0 && valid) al[row] = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 
@@ -310,8 +434,6 @@ __device__ __forceinline__ float matern3_fast(float ax, float ay, float az, floa
 // which is also the B operand of the MFMAs; L is read in place (A operand, negated on load).
 // Returns m = Ks^T alpha and ss = sum v_k^2 for leaf = lane.
 // ---------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 
 __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__restrict__ L, const float4 *__restrict__ x,

@@ -421,7 +421,7 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
         hipLaunchKernelGGL(gp_train_wave_kernel, dim3(s->n_train_blk), dim3(kWave), sizeof(float) * (nn * (nn + 1) / 2 + nn),
                            stream, a);
         if (max_n > (uint32_t)kGpTrainLdsMaxN)
-            hipLaunchKernelGGL(gp_train_kernel, dim3(s->n_train_blk), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(gp_train_kernel, dim3(s->n_train_blk), dim3(kWave), 0, stream, a);
     }
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (ctx->opt_time_kernel) {
