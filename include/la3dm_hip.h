@@ -203,6 +203,11 @@ int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *
  * 3  sin/cos (f64 kernels rounded to f32) vs the f64 library functions rounded to f32. */
 int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 
+/* Test hook for the property the GP kernels' matrix-core paths rely on: D = A B (A 32 x K row-major, B K x 32
+ * row-major, K even, host pointers) through v_mfma_f32_32x32x2_f32 versus fmaf chains over k ascending, compared
+ * on the device; *mismatches = number of outputs whose bits differ (0 on gfx950). */
+int la3dm_diag_mfma_chain(la3dm_ctx *ctx, const float *A, const float *B, int K, uint32_t *mismatches);
+
 /* BGKLOctoMap (params.variant = 3): block-level BGK with free-space line segments.  Replaces
  * BGKLInference::train/predict (include/bgkloctomap/bgklinference.h:44-88: point_to_line_dist :104-140,
  * covSparseLine :186-200) + the update loop gated on kbar > 0.001 (src/bgkloctomap/bgkloctomap.cpp:206-231).

@@ -70,7 +70,7 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_devmap_create", "la3dm_devmap_destroy", "la3dm_devmap_insert_pointcloud_host",
                "la3dm_devmap_insert_pointcloud_device", "la3dm_devmap_block_count", "la3dm_devmap_download",
                "la3dm_devmap_training_data", "la3dm_devmap_diag_add_repeat", "la3dm_bgkl_scan_host",
-               "la3dm_bgkl_scan_device"]
+               "la3dm_bgkl_scan_device", "la3dm_diag_mfma_chain"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
@@ -106,6 +106,8 @@ def hip():
         L.la3dm_bgk_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_bgk_scan_device.restype = C.c_int
         L.la3dm_bgk_scan_device.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.c_void_p, C.POINTER(BgkCounters)]
+        L.la3dm_diag_mfma_chain.restype = C.c_int
+        L.la3dm_diag_mfma_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
         L.la3dm_bgkl_scan_host.restype = C.c_int
         L.la3dm_bgkl_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_bgkl_scan_device.restype = C.c_int

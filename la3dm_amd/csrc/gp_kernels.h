@@ -635,4 +635,27 @@ __global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
     }
 }
 
+// Test hook for the property gp_solve_mfma / gp_train_kernel rely on: D = A B through v_mfma_f32_32x32x2_f32
+// (k ascending, two per instruction) against per-element fmaf chains over k ascending.  One wave; counts the
+// outputs whose bits differ.  A is 32 x K, B is K x 32 (row-major), K even.
+__global__ __launch_bounds__(kWave) void gp_diag_mfma_chain(const float *__restrict__ A, const float *__restrict__ B, int K,
+                                                           unsigned int *mismatches) {
+    const int lane = threadIdx.x;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int k = 0; k < K; k += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(lane & 31) * K + k + (lane >> 5)], B[(k + (lane >> 5)) * 32 + (lane & 31)],
+                                                   acc, 0, 0, 0);
+    unsigned int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), col = lane & 31;
+        float c = 0.0f;
+        for (int k = 0; k < K; ++k) c = __builtin_fmaf(A[row * K + k], B[k * 32 + col], c);
+        bad += __float_as_uint(c) != __float_as_uint(acc[r]);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace la3dm_dev

@@ -451,6 +451,28 @@ int la3dm_gp_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counte
     return scan_host_common(ctx, s, out, la3dm_gp_scan_device);
 }
 
+int la3dm_diag_mfma_chain(la3dm_ctx *ctx, const float *A, const float *B, int K, uint32_t *mismatches) {
+    if (!ctx || !A || !B || !mismatches || K <= 0 || (K & 1)) return LA3DM_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, sizeof(float) * (64 * (size_t)K + 1)));
+    unsigned int *dm = (unsigned int *)(d + 64 * (size_t)K);
+    hipError_t e = hipMemcpy(d, A, sizeof(float) * 32 * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 32 * (size_t)K, B, sizeof(float) * 32 * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dm, 0, 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gp_diag_mfma_chain, dim3(1), dim3(kWave), 0, ctx->stream, d, d + 32 * (size_t)K, K, dm);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(mismatches, dm, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        ctx->err = std::string("la3dm_diag_mfma_chain: ") + hipGetErrorString(e);
+        return LA3DM_ERR_HIP;
+    }
+    return LA3DM_OK;
+}
+
 int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream_, la3dm_bgk_counters *out) {
     if (!ctx) return LA3DM_ERR_ARG;
     if (!s) {

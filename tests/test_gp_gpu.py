@@ -59,3 +59,38 @@ def test_gp_block_kat(built):
     m.insert_pointcloud(pts, [0.0, 0.0, 3.0], -1.0, 0.35, -1.0)
     o.insert_pointcloud(pts, [0.0, 0.0, 3.0], -1.0, 0.35, -1.0)
     _compare(m, o, params, "kat")
+
+
+def test_mfma_accumulates_like_an_fma_chain(built):
+    """the property the MFMA Cholesky / solve rely on: v_mfma_f32_32x32x2_f32 == fmaf chains over k ascending,
+    bit for bit, for values of mixed magnitude and sign"""
+    import ctypes as C
+    import la3dm_amd
+    from la3dm_amd import _lib
+    m = la3dm_amd.GPOctoMap(**la3dm_amd.GP_YAML, device=0)
+    rng = np.random.default_rng(9)
+    for K in (2, 34, 64, 530):
+        A = (rng.uniform(-1, 1, (32, K)) * 10.0 ** rng.integers(-4, 3, (32, K))).astype(np.float32)
+        B = (rng.uniform(-1, 1, (K, 32)) * 10.0 ** rng.integers(-4, 3, (K, 32))).astype(np.float32)
+        bad = C.c_uint32(123)
+        assert _lib.hip().la3dm_diag_mfma_chain(m.ctx(), A.ctypes.data, B.ctypes.data, K, C.byref(bad)) == 0
+        assert bad.value == 0, (K, bad.value)
+
+
+def test_gp_large_blocks_on_matrix_cores(built):
+    """depth 4, dense scan: training blocks with hundreds of points go through the MFMA Cholesky and the MFMA
+    forward substitution; every leaf must still equal the oracle bit for bit"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.GP_YAML, block_depth=4)
+    m = la3dm_amd.GPOctoMap(**params, device=0)
+    o = O.OracleGPMap(**params, omp=True)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    xyz = xyz[::2]
+    m.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+    a, b = m.leaves(), o.leaves()
+    for k in ("block_key", "node_key", "state", "classified"):
+        assert (a[k] == b[k]).all(), k
+    for k in ("A", "B"):
+        assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), (k, float(np.abs(a[k] - b[k]).max()))
