@@ -430,11 +430,16 @@ __device__ __forceinline__ float matern3_fast(float ax, float ay, float az, floa
 // blocks continue each chain on the VALU.  Layout: one wave handles the tile's 64 leaves as two 32-column
 // accumulators; lane (c = lane % 32, h = lane / 32) owns rows 8g + 4h + j of a block for leaves c and 32 + c, so the
 // serial row order alternates between the half-waves every four rows: chains (m, sum v^2) and the freshly solved
-// v are handed over with a lane ^ 32 exchange.  V lives in the task's global scratch [row][64] (L2 resident),
+// v are handed over with v_permlane32_swap_b32 (the owner half's value broadcast to both halves).  V lives in the task's global scratch [row][64] (L2 resident),
 // which is also the B operand of the MFMAs; L is read in place (A operand, negated on load).
 // Returns m = Ks^T alpha and ss = sum v_k^2 for leaf = lane.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+// value of half-wave `half` (lanes 32*half .. 32*half+31, by lane % 32) in BOTH half-waves: one
+// v_permlane32_swap_b32 (gfx950; measured semantics: result[0] = {a.lo, b.lo}, result[1] = {a.hi, b.hi})
+__device__ __forceinline__ float bcast_half(float v, int half) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(half ? r[1] : r[0]);
+}
 
 __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__restrict__ L, const float4 *__restrict__ x,
                                               const float *__restrict__ al, const int N, const float tx, const float ty,
@@ -443,7 +448,7 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
     const int c = lane & 31, h = lane >> 5;
     const float t0x = __shfl(tx, c), t0y = __shfl(ty, c), t0z = __shfl(tz, c);
     const float t1x = __shfl(tx, 32 + c), t1y = __shfl(ty, 32 + c), t1z = __shfl(tz, 32 + c);
-    float mj0 = 0.0f, mj1 = 0.0f, ss0 = 0.0f, ss1 = 0.0f;  // the live copies sit in half 0 at every block start
+    float mj0 = 0.0f, mj1 = 0.0f, ss0 = 0.0f, ss1 = 0.0f;
     const int nblk = (N + 31) >> 5;
     for (int K = 0; K < nblk; ++K) {
         const int R0 = 32 * K;
@@ -469,23 +474,42 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                         mj1 = __builtin_fmaf(C1[4 * g + j], alv[4 * g + j], mj1);
                     }
                 }
-                mj0 = xhalf(mj0);
-                mj1 = xhalf(mj1);
+                mj0 = bcast_half(mj0, hh);  // both halves continue from the owner's value
+                mj1 = bcast_half(mj1, hh);
             }
         }
-        // off-diagonal blocks on the matrix cores: C -= L[K][J] V[J]
+        // off-diagonal blocks on the matrix cores: C -= L[K][J] V[J].  The operands of block J + 1 are fetched
+        // while the 32 MFMAs of block J run (one memory round trip per block instead of one per k-pair).
         {
             const int arow = R0 + c;
             const bool avalid = arow < N;
             const float *Lrow = L + (size_t)(avalid ? arow : 0) * N;
-            for (int J = 0; J < K; ++J) {
-#pragma unroll 4
+            float av[16];
+            float2 bv[16];
+            auto fetch = [&](int J, float (&A_)[16], float2 (&B_)[16]) {
+#pragma unroll
                 for (int m2 = 0; m2 < 16; ++m2) {
                     const int kcol = 32 * J + 2 * m2 + h;
-                    const float av = avalid ? -Lrow[kcol] : 0.0f;
-                    const float b0 = vg[(size_t)kcol * kWave + c], b1 = vg[(size_t)kcol * kWave + 32 + c];
-                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, C0, 0, 0, 0);
-                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, C1, 0, 0, 0);
+                    A_[m2] = avalid ? -Lrow[kcol] : 0.0f;
+                    B_[m2] = *reinterpret_cast<const float2 *>(vg + (size_t)kcol * kWave + 2 * c);
+                }
+            };
+            if (K > 0) fetch(0, av, bv);
+            for (int J = 0; J < K; ++J) {
+                float an[16];
+                float2 bn[16];
+                if (J + 1 < K) fetch(J + 1, an, bn);
+#pragma unroll
+                for (int m2 = 0; m2 < 16; ++m2) {
+                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m2], bv[m2].x, C0, 0, 0, 0);
+                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m2], bv[m2].y, C1, 0, 0, 0);
+                }
+                if (J + 1 < K) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 16; ++m2) {
+                        av[m2] = an[m2];
+                        bv[m2] = bn[m2];
+                    }
                 }
             }
         }
@@ -517,29 +541,24 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 if (h == hh) {
                     ss0 = __builtin_fmaf(v0, v0, ss0);
                     ss1 = __builtin_fmaf(v1, v1, ss1);
-                    if (valid) {
-                        vg[(size_t)row * kWave + c] = v0;
-                        vg[(size_t)row * kWave + 32 + c] = v1;
-                    }
+                    if (valid) *reinterpret_cast<float2 *>(vg + (size_t)row * kWave + 2 * c) = make_float2(v0, v1);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float o0 = xhalf(n0[j]), o1 = xhalf(n1[j]);
-                vb0[4 * G + j] = h == hh ? n0[j] : o0;
-                vb1[4 * G + j] = h == hh ? n1[j] : o1;
+                vb0[4 * G + j] = bcast_half(n0[j], hh);
+                vb1[4 * G + j] = bcast_half(n1[j], hh);
             }
-            ss0 = xhalf(ss0);
-            ss1 = xhalf(ss1);
+            ss0 = bcast_half(ss0, hh);
+            ss1 = bcast_half(ss1, hh);
         }
         // V[K] is read back as MFMA B operands by the other lanes of this wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    const float m1x = xhalf(mj1), s1x = xhalf(ss1);
-    mj_out = h == 0 ? mj0 : m1x;
-    ss_out = h == 0 ? ss0 : s1x;
+    mj_out = h == 0 ? mj0 : mj1;  // every chain value is present in both half-waves
+    ss_out = h == 0 ? ss0 : ss1;
 }
 
 // GPRegressor::predict + BCM fusion: one wave64 per leaf tile, lane = leaf (test point).
@@ -550,7 +569,7 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
 // rows go through gp_solve_mfma (above).
 constexpr int kGpLdsRows = 64;  // blocks up to one wave of rows are solved in LDS; larger ones on the matrix cores
 
-__global__ __launch_bounds__(kWave) void gp_predict_fuse_kernel(GpArgs a) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void gp_predict_fuse_kernel(GpArgs a) {
     extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: sized per launch, LDS is the occupancy limiter
     float (*s_v)[kWave] = reinterpret_cast<float (*)[kWave]>(s_vraw);
     const int lane = threadIdx.x;
