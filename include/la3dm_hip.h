@@ -126,7 +126,8 @@ void la3dm_destroy(la3dm_ctx *ctx);
 const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last create error */
 
 /* Options: "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial,
- * 2 = OCML; "bgk_variant" selects the kernel implementation (A/B measurements);
+ * 2 = OCML; "bgk_variant" is accepted and ignored (one implementation is built; the
+ * measurement history of the earlier variants is in DESIGN.md); "waves_per_wg" 1/2/4, "remap" 0-2, "ablate" (profiling);
  * "time_kernel" see la3dm_kernel_times. */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
 

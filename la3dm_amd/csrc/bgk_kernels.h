@@ -48,7 +48,6 @@ struct BgkArgs {
     uint32_t n_tasks;           // n_test_blk << tpb_shift
     uint32_t flags;
     uint32_t remap;             // 0 contiguous range per XCD, 1 identity, 2 chunks of 8
-    int32_t fix_exp;            // kernel values lie in [0, 2^fix_exp]
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
 };
 
@@ -173,14 +172,6 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
     return k;
 }
 
-// x / ell per coordinate (bgkinference.h:114); label rides in w.
-__global__ void bgk_prescale_points(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 p = in[i];
-    out[i] = make_float4(p.x / ell, p.y / ell, p.z / ell, p.w);
-}
-
 // Same launch shape, second job: resolve nbr[t][b] -> {train_off[nb], count} once per scan, so that
 // the predict kernel's prologue needs one dependent memory round trip less per tile.
 __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell,
@@ -202,18 +193,6 @@ __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ 
     }
 }
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// Occupancy::update tail: variance / probability / state (bgkoctree_node.cpp:36-43)
 __device__ __forceinline__ uint8_t classify(float A, float B, const BgkArgs &a) {
     float s = A + B;
     float var = (A * B) / ((s * s) * (s + 1.0f));
@@ -223,329 +202,8 @@ __device__ __forceinline__ uint8_t classify(float A, float B, const BgkArgs &a) 
 }
 
 // ---------------------------------------------------------------------------
-// Variant 1: lane = leaf, wave-uniform skip of points no lane can see.
+// Wave64 reductions on the DPP network, lean square root, kernel with constant reciprocals
 // ---------------------------------------------------------------------------
-template <int kTrig>
-__global__ __launch_bounds__(kWavesPerWG *kWave) void bgk_predict_fuse_v1(BgkArgs a) {
-    __shared__ float4 s_pts[kWavesPerWG][kWave];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWavesPerWG + wv);
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
-    // leaf position: LUT[key] + centre (f32), then / ell
-    const uint32_t key = a.leaf_key[li];
-    const float4 off = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs = (off.x + cx) / a.ell, ys = (off.y + cy) / a.ell, zs = (off.z + cz) / a.ell;
-    float A = a.alpha[li], B = a.beta[li];
-
-    // tile bounding box in scaled coordinates (inactive lanes replicate lane 0's leaf)
-    const float lox = wave_min(xs), loy = wave_min(ys), loz = wave_min(zs);
-    const float hix = wave_max(xs), hiy = wave_max(ys), hiz = wave_max(zs);
-
-    bool updated = false;
-    const bool ungated = (a.flags & 1u) != 0;
-    float4 *sp = s_pts[wv];
-
-    for (int nb = 0; nb < 7; ++nb) {
-        const int tb = a.nbr[7 * blk + nb];
-        if (tb < 0) continue;
-        const uint32_t p0 = a.train_off[tb], p1 = a.train_off[tb + 1];
-        float ybar = 0.0f, kbar = 0.0f;
-        for (uint32_t base = p0; base < p1; base += kWave) {
-            // stage: lane = point
-            const uint32_t pi = base + lane;
-            bool keep = false;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pi < p1) {
-                q = a.pts[pi];
-                float ex = fmaxf(fmaxf(lox - q.x, q.x - hix), 0.0f);
-                float ey = fmaxf(fmaxf(loy - q.y, q.y - hiy), 0.0f);
-                float ez = fmaxf(fmaxf(loz - q.z, q.z - hiz), 0.0f);
-                keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
-            }
-            const unsigned long long m = __ballot(keep);
-            const int n = __popcll(m);
-            const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            __builtin_amdgcn_wave_barrier();
-            if (keep) sp[slot] = q;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // evaluate: lane = leaf
-            for (int j = 0; j < n; ++j) {
-                const float4 t = sp[j];
-                const float dx = t.x - xs, dy = t.y - ys, dz = t.z - zs;
-                const float d2 = dx * dx + (dy * dy + dz * dz);
-                if (d2 < 1.0f) {  // k(r) <= 0 for every fp32 r >= 1 (tests/test_oracle.py)
-                    const float r = sqrtf(d2);
-                    const float k = cov_sparse<true, kTrig>(r, a.sf2);
-                    ybar += k * t.w;
-                    kbar += k;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (kbar > 0.0f || ungated) {
-            A += ybar;
-            B += kbar - ybar;
-            updated = true;
-        }
-    }
-    if (active) {
-        if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
-        } else {
-            a.state[li] = 0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Variant 2 (default): pair compaction.
-//   A. stage: lane = training point; all <=7 neighbour chunks are loaded up front
-//      (independent 16-byte loads in flight together), culled against the tile's box,
-//      ballot/mbcnt-compacted into the wave's LDS candidate list.
-//   B. test: lane = leaf; for each candidate (LDS broadcast) d2 = dx^2 + (dy^2 + dz^2);
-//      lanes with d2 < 1 append {d2, leaf | nb | candidate} to an LDS ring queue.
-//   C. evaluate: whenever 64 pairs are queued every lane takes one pair — sqrt, the
-//      sparse kernel (correctly rounded sin/cos) at full lane utilisation — and adds
-//      k and k*y to the (neighbour, leaf) accumulators with LDS float atomics.
-//   D. fuse: lane = leaf; the 7 (ybar, kbar) pairs are applied in ExtendedBlock order
-//      exactly like the reference's update loop; alpha/beta/state are written once.
-// Only ~7.5 % of the (leaf, point) pairs lie inside the kernel support, so moving the
-// ~75-instruction kernel evaluation off the sparse lane mask is the main lever.
-// ---------------------------------------------------------------------------
-constexpr int kCand = 128;   // candidate list capacity per wave
-constexpr int kQueue = 256;  // pair ring capacity per wave (power of two)
-
-struct __attribute__((aligned(16))) WaveLds {
-    float4 cand[kCand];      // x/ell, y/ell, z/ell, label
-    uint32_t cand_nb[kCand]; // neighbour slot << 6
-    uint2 queue[kQueue];     // d2 bits, leaf | nb << 6 | cand << 9
-    float acc[14][kWave];    // [2*nb] = kbar, [2*nb+1] = ybar
-};
-
-template <int kTrig>
-__device__ __forceinline__ void eval_pairs(WaveLds &L, uint32_t head, uint32_t n, int lane, float sf2) {
-    if ((uint32_t)lane < n) {
-        const uint2 e = L.queue[(head + lane) & (kQueue - 1)];
-        const float d2 = __uint_as_float(e.x);
-        const uint32_t leaf = e.y & 63u, nb = (e.y >> 6) & 7u, cj = e.y >> 9;
-        const float y = L.cand[cj].w;
-        const float r = sqrtf(d2);
-        const float k = cov_sparse<true, kTrig>(r, sf2);
-        if (k > 0.0f) {
-            __hip_atomic_fetch_add(&L.acc[2 * nb][leaf], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const float ky = k * y;
-            if (ky != 0.0f)
-                __hip_atomic_fetch_add(&L.acc[2 * nb + 1][leaf], ky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-    }
-}
-
-template <int kTrig>
-__global__ __launch_bounds__(kWavesPerWG *kWave) void bgk_predict_fuse_v2(BgkArgs a) {
-    __shared__ WaveLds s_lds[kWavesPerWG];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const uint32_t wg = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWavesPerWG + wv);
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    WaveLds &L = s_lds[wv];
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
-    // neighbour table (wave-uniform -> scalar registers)
-    int tb[7];
-    uint32_t p0[7], cnt[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        tb[b] = a.nbr[7 * blk + b];
-        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
-        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
-    }
-    // first chunk of every neighbour: issue all loads before anything depends on them
-    float4 q[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b)
-        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const uint32_t key = a.leaf_key[li];
-    const float4 off = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs = (off.x + cx) / a.ell, ys = (off.y + cy) / a.ell, zs = (off.z + cz) / a.ell;
-    float A = a.alpha[li], B = a.beta[li];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) L.acc[i][lane] = 0.0f;
-
-    const float lox = wave_min(xs), loy = wave_min(ys), loz = wave_min(zs);
-    const float hix = wave_max(xs), hiy = wave_max(ys), hiz = wave_max(zs);
-
-    uint32_t ncand = 0, qhead = 0, qcount = 0;
-
-    // box cull + ballot compaction of one chunk (lane = point); caller guarantees room
-    auto stage = [&](const float4 &p, bool valid, uint32_t b) {
-        bool keep = false;
-        if (valid) {
-            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
-            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
-            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
-            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
-        }
-        const unsigned long long m = __ballot(keep);
-        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (keep) {
-            L.cand[slot] = p;
-            L.cand_nb[slot] = b << 6;
-        }
-        ncand += (uint32_t)__popcll(m);
-    };
-
-    // A (common case): the preloaded first chunks, as long as they fit
-    uint32_t deferred = 0;  // bit b: first chunk of neighbour b not staged yet
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        if (cnt[b] == 0) continue;
-        if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand)
-            stage(q[b], (uint32_t)lane < cnt[b], (uint32_t)b);
-        else
-            deferred |= 1u << b;
-    }
-    // chunks still to stage after the first round (rare: > 64 points in a block, or overflow)
-    uint32_t it_b = 0, it_base = (deferred & 1u) ? 0u : kWave;
-    bool more = true;
-    while (more) {
-        // B + C over the current candidate list; iteration j == ncand drains the queue
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t j = 0; j <= ncand; ++j) {
-            if (j < ncand) {
-                const float4 t = L.cand[j];
-                const uint32_t nbbits = L.cand_nb[j];
-                const float dx = t.x - xs, dy = t.y - ys, dz = t.z - zs;
-                const float d2 = dx * dx + (dy * dy + dz * dz);
-                const bool hit = active && d2 < 1.0f;  // k(r) <= 0 for every fp32 r >= 1
-                const unsigned long long m = __ballot(hit);
-                if (m == 0ull) continue;
-                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                if (hit)
-                    L.queue[(qhead + qcount + pos) & (kQueue - 1)] =
-                        make_uint2(__float_as_uint(d2), (uint32_t)lane | nbbits | (j << 9));
-                qcount += (uint32_t)__popcll(m);
-            }
-            const uint32_t n_eval = qcount >= (uint32_t)kWave ? (uint32_t)kWave : (j == ncand ? qcount : 0u);
-            if (n_eval) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                eval_pairs<kTrig>(L, qhead, n_eval, lane, a.sf2);
-                qhead = (qhead + n_eval) & (kQueue - 1);
-                qcount -= n_eval;
-            }
-        }
-        ncand = 0;
-        __builtin_amdgcn_wave_barrier();
-        // refill from the remaining chunks (generic, scalar re-reads of the neighbour table)
-        more = false;
-        while (it_b < 7) {
-            const int tbv = a.nbr[7 * blk + it_b];
-            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
-            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
-            if (it_base >= pc) {
-                ++it_b;
-                it_base = (it_b < 7 && ((deferred >> it_b) & 1u)) ? 0u : kWave;
-                continue;
-            }
-            if (ncand + (uint32_t)kWave > (uint32_t)kCand) break;
-            const bool valid = it_base + lane < pc;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) p = a.pts[pp0 + it_base + lane];
-            stage(p, valid, it_b);
-            it_base += kWave;
-            more = true;
-        }
-    }
-
-    // D. fuse in ExtendedBlock order
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bool updated = false;
-    const bool ungated = (a.flags & 1u) != 0;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        if (tb[b] < 0) continue;
-        const float kbar = L.acc[2 * b][lane], ybar = L.acc[2 * b + 1][lane];
-        if (kbar > 0.0f || ungated) {
-            A += ybar;
-            B += kbar - ybar;
-            updated = true;
-        }
-    }
-    if (active) {
-        if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
-        } else {
-            a.state[li] = 0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Variant 3: variant 2's pipeline tightened after profiling (rocprofv3: variant 2 was
-// instruction-issue and LDS-latency bound at ~2 waves/SIMD):
-//   * one wave per workgroup (no wave waits for a slower sibling to release LDS),
-//   * DPP row reductions for the tile box instead of ds_bpermute shuffles,
-//   * candidates read four at a time (one LDS wait per four tests), neighbour slot carried
-//     in the candidate record, labels fetched only by the evaluation step,
-//   * inactive lanes carry NaN coordinates so no per-test lane mask is needed,
-//   * exact division by the constants 3 and 2*pi' via one FMA correction step and a lean
-//     correctly rounded sqrt (both swept exhaustively against IEEE results in the tests).
-// ---------------------------------------------------------------------------
-constexpr int kCand3 = 128;
-constexpr int kQueue3 = 128;
-
-struct __attribute__((aligned(16))) WaveLds3 {
-    float4 cand[kCand3];     // x/ell, y/ell, z/ell, bits(nb << 6)
-    float label[kCand3];
-    uint2 queue[kQueue3];    // d2 bits, leaf | nb << 6 | cand << 9
-    // [2*nb] = kbar, [2*nb+1] = ybar as 64-bit fixed point (2^-kFixShift * 2^fix_exp units).
-    // LDS float atomics retire ~1 lane/clk on gfx950 (measured: 22 % of the kernel), integer
-    // atomics run at the plain-store rate, and an integer sum is order independent.
-    unsigned long long acc[14][kWave];
-};
-constexpr int kFixShift = 40;
-
-// v * 2^(kFixShift - fix_exp) as an integer, exact for v >= 2^(fix_exp - 16) and truncated below
-// 2^(fix_exp - 40) (v is a kernel value in [0, 2^fix_exp]).
-__device__ __forceinline__ unsigned long long to_fixed(float v, int fix_exp) {
-    const uint32_t bits = __float_as_uint(v);
-    const unsigned long long m = (bits & 0x7FFFFFu) | 0x800000u;
-    const int sh = (int)(bits >> 23) - 150 + kFixShift - fix_exp;  // value = m * 2^(e - 150)
-    return sh >= 0 ? (m << sh) : (sh > -64 ? (m >> (-sh)) : 0ull);
-}
-__device__ __forceinline__ float from_fixed(unsigned long long s, int fix_exp) {
-    const double d = (double)(uint32_t)(s >> 32) * 4294967296.0 + (double)(uint32_t)s;
-    return (float)__builtin_ldexp(d, fix_exp - kFixShift);
-}
-
 template <int kCtrl, int kRowMask = 0xF>
 __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, kRowMask, 0xF, false));
@@ -597,456 +255,9 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     return k;
 }
 
-template <int kTrig>
-__device__ __forceinline__ void eval_pairs3(WaveLds3 &L, uint32_t head, uint32_t n, int lane, float sf2, int fix_exp) {
-    if ((uint32_t)lane < n) {
-        const uint2 e = L.queue[(head + lane) & (kQueue3 - 1)];
-        const float d2 = __uint_as_float(e.x);
-        const float k = cov_sparse_fast<kTrig>(sqrt_cr(d2), sf2);
-        if (k > 0.0f) {
-            unsigned long long *acc = &L.acc[0][0] + ((e.y >> 6) & 7u) * (2 * kWave) + (e.y & 63u);
-            const float y = L.label[e.y >> 9];
-            const float ky = k * y;
-            if (fix_exp & 0x100) {  // profiling ablation: 32-bit atomics on the low word
-                __hip_atomic_fetch_add((unsigned int *)acc, (unsigned int)to_fixed(k, fix_exp & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (ky > 0.0f)
-                    __hip_atomic_fetch_add((unsigned int *)(acc + kWave), (unsigned int)to_fixed(ky, fix_exp & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                return;
-            }
-            __hip_atomic_fetch_add(acc, to_fixed(k, fix_exp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (ky > 0.0f)
-                __hip_atomic_fetch_add(acc + kWave, to_fixed(ky, fix_exp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-    }
-}
-
-template <int kTrig, int kWaves>
-__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v3(BgkArgs a) {
-    __shared__ WaveLds3 s_lds[kWaves];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    uint32_t wg = blockIdx.x;
-    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
-    else if (a.remap == 2) {  // chunks of 8 consecutive logical workgroups stay on one XCD
-        const uint32_t G8 = gridDim.x & ~63u;
-        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
-    }
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    WaveLds3 &L = s_lds[wv];
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
-    int tb[7];
-    uint32_t p0[7], cnt[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        tb[b] = a.nbr[7 * blk + b];
-        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
-        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
-    }
-    float4 q[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b)
-        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const uint32_t key = a.leaf_key[li];
-    const float4 off = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs0 = (off.x + cx) / a.ell, ys0 = (off.y + cy) / a.ell, zs0 = (off.z + cz) / a.ell;
-    float A = a.alpha[li], B = a.beta[li];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) L.acc[i][lane] = 0ull;
-
-    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
-    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
-    // lanes beyond the tile never match (NaN compares false)
-    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;
-
-    uint32_t ncand = 0, qhead = 0, qcount = 0;
-
-    auto stage = [&](const float4 &p, bool valid, uint32_t b) {
-        bool keep = false;
-        if (valid) {
-            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
-            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
-            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
-            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
-        }
-        const unsigned long long m = __ballot(keep);
-        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (keep) {
-            L.cand[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(b << 6));
-            L.label[slot] = p.w;
-        }
-        ncand += (uint32_t)__popcll(m);
-    };
-
-    uint32_t deferred = 0;
-    bool leftovers = false;  // anything the first round could not stage?
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        if (cnt[b] == 0) continue;
-        if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand3)
-            stage(q[b], (uint32_t)lane < cnt[b], (uint32_t)b);
-        else
-            deferred |= 1u << b;
-        leftovers |= cnt[b] > (uint32_t)kWave;
-    }
-    leftovers |= deferred != 0u;
-    uint32_t it_b = leftovers ? 0u : 7u, it_base = (deferred & 1u) ? 0u : kWave;
-    bool more = true;
-    while (more) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // B + C: four candidates per trip; the trip after the last one drains the queue
-        const uint32_t ntrip = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;
-        for (uint32_t g = 0; g <= ntrip; ++g) {
-            const bool last = g == ntrip;
-            float d2v[4];
-            uint32_t meta[4];
-            unsigned long long mv[4];
-            if (!last) {
-                float4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = L.cand[(4 * g + u) & (kCand3 - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
-                    d2v[u] = dx * dx + (dy * dy + dz * dz);
-                    const bool hit = d2v[u] < 1.0f && (4 * g + u) < ncand;  // k(r) <= 0 for all fp32 r >= 1
-                    mv[u] = __ballot(hit);
-                    meta[u] = (uint32_t)lane | __float_as_uint(t[u].w) | ((4 * g + u) << 9);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!last && mv[u] != 0ull) {
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv[u], 0));
-                    if ((mv[u] >> lane) & 1ull)
-                        L.queue[(qhead + qcount + pos) & (kQueue3 - 1)] = make_uint2(__float_as_uint(d2v[u]), meta[u]);
-                    qcount += (uint32_t)__popcll(mv[u]);
-                }
-                const uint32_t n_eval = qcount >= (uint32_t)kWave ? (uint32_t)kWave : ((last && u == 0) ? qcount : 0u);
-                if (n_eval) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (!(a.flags & 0x100u)) eval_pairs3<kTrig>(L, qhead, n_eval, lane, a.sf2, a.fix_exp | ((a.flags & 0x400u) ? 0x100 : 0));
-                    qhead = (qhead + n_eval) & (kQueue3 - 1);
-                    qcount -= n_eval;
-                }
-            }
-        }
-        ncand = 0;
-        __builtin_amdgcn_wave_barrier();
-        more = false;
-        while (it_b < 7) {
-            const int tbv = a.nbr[7 * blk + it_b];
-            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
-            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
-            if (it_base >= pc) {
-                ++it_b;
-                it_base = (it_b < 7 && ((deferred >> it_b) & 1u)) ? 0u : kWave;
-                continue;
-            }
-            if (ncand + (uint32_t)kWave > (uint32_t)kCand3) break;
-            const bool valid = it_base + lane < pc;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) p = a.pts[pp0 + it_base + lane];
-            stage(p, valid, it_b);
-            it_base += kWave;
-            more = true;
-        }
-    }
-
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bool updated = false;
-    const bool ungated = (a.flags & 1u) != 0;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        if (tb[b] < 0) continue;
-        const float kbar = from_fixed(L.acc[2 * b][lane], a.fix_exp), ybar = from_fixed(L.acc[2 * b + 1][lane], a.fix_exp);
-        if (kbar > 0.0f || ungated) {
-            A += ybar;
-            B += kbar - ybar;
-            updated = true;
-        }
-    }
-    if (active) {
-        if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
-        } else {
-            a.state[li] = 0;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Variant 4 (default): variant 3 with the pair queue and the accumulators moved from LDS
-// into registers.  Profiling variant 3 showed (a) LDS float atomics retire ~1 lane/clk (22 %
-// of the kernel), (b) every KB of LDS per wave costs occupancy, and the kernel is
-// latency/issue bound at < 4 waves/SIMD.
-//   * hits of one candidate (a "run") are scattered into the free lanes of a 63-slot register
-//     batch with ds_permute_b32 (LDS crossbar, no LDS memory); a run never straddles batches;
-//   * when the next run does not fit, all 64 lanes evaluate k(r) for the batch, then the
-//     runs are replayed in candidate order: each leaf lane fetches its own k with
-//     ds_bpermute_b32 and adds it to its private (ybar, kbar) registers — the reference's
-//     sequential summation order, so the sums are bit-identical to the CPU restatement;
-//   * which lanes a run covered is recovered from a per-lane 32-candidate hit history
-//     (one bit per candidate) by a ballot — no masks stored;
-//   * the neighbour slot of a candidate is wave-uniform, so "flush (ybar, kbar) into
-//     (alpha, beta)" is a uniform branch in ExtendedBlock order, as in the reference loop.
-// LDS per wave: candidate list only (2.5 KB).
-// ---------------------------------------------------------------------------
-constexpr int kCand4 = 128;
-
-struct __attribute__((aligned(16))) WaveLds4 {
-    float4 cand[kCand4];  // x/ell, y/ell, z/ell, bits(nb)
-    float label[kCand4];
-};
-
-template <int kTrig, int kWaves>
-__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v4(BgkArgs a) {
-    __shared__ WaveLds4 s_lds[kWaves];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    uint32_t wg = blockIdx.x;
-    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
-    else if (a.remap == 2) {
-        const uint32_t G8 = gridDim.x & ~63u;
-        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
-    }
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    WaveLds4 &L = s_lds[wv];
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
-    int tb[7];
-    uint32_t p0[7], cnt[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        tb[b] = a.nbr[7 * blk + b];
-        p0[b] = tb[b] >= 0 ? a.train_off[tb[b]] : 0u;
-        cnt[b] = tb[b] >= 0 ? a.train_off[tb[b] + 1] - p0[b] : 0u;
-    }
-    float4 q[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b)
-        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const uint32_t key = a.leaf_key[li];
-    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs0 = (off4.x + cx) / a.ell, ys0 = (off4.y + cy) / a.ell, zs0 = (off4.z + cz) / a.ell;
-    float A = a.alpha[li], B = a.beta[li];
-
-    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
-    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
-    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
-
-    const bool ungated = (a.flags & 1u) != 0;
-    bool updated = false;
-    float kbar = 0.0f, ybar = 0.0f;
-    int cur_nb = -1;           // neighbour slot the (ybar, kbar) registers belong to (uniform)
-    uint32_t hist = 0;         // bit i: this leaf was hit by the candidate i steps back
-    uint32_t bd2 = 0;          // batch: d2 bits of the pair parked in this lane
-    uint32_t bcnt = 0;         // pairs in the batch (uniform)
-    uint32_t bruns = 0;        // candidates tested since the batch was opened (uniform, <= 32)
-    uint32_t jstep = 0;        // candidates of the current list tested so far (uniform)
-    uint32_t ncand = 0;
-
-    // Occupancy::update for the neighbour the registers belong to (bgkoctree_node.cpp:31-35)
-    auto flush_nb = [&]() {
-        if (kbar > 0.0f || ungated) {
-            A += ybar;
-            B += kbar - ybar;
-            updated = true;
-        }
-        kbar = 0.0f;
-        ybar = 0.0f;
-    };
-
-    auto stage = [&](const float4 &p, bool valid, uint32_t b) {
-        bool keep = false;
-        if (valid) {
-            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
-            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
-            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
-            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
-        }
-        const unsigned long long m = __ballot(keep);
-        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (keep) {
-            L.cand[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(b));
-            L.label[slot] = p.w;
-        }
-        ncand += (uint32_t)__popcll(m);
-    };
-
-    // A: first chunks in ExtendedBlock order; stop at the first neighbour that does not fit or
-    // has more than one chunk, so that candidates stay in (neighbour, point) order.
-    uint32_t it_b = 7, it_base = 0;
-    {
-        bool open = true;
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            if (!open || cnt[b] == 0) continue;
-            if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand4) {
-                stage(q[b], (uint32_t)lane < cnt[b], (uint32_t)b);
-                if (cnt[b] > (uint32_t)kWave) {
-                    open = false;
-                    it_b = b;
-                    it_base = kWave;
-                }
-            } else {
-                open = false;
-                it_b = b;
-                it_base = 0;
-            }
-        }
-    }
-
-    bool more = true;
-    while (more) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // B/C/D over the staged candidates; trip j == ncand closes the last batch
-        const uint32_t ntrip = (ncand + 3u) >> 2;
-        for (uint32_t g = 0; g <= ntrip; ++g) {
-            const bool last = g == ntrip;
-            float d2v[4];
-            unsigned long long mv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                d2v[u] = 0.f;
-                mv[u] = 0ull;
-            }
-            if (!last) {
-                float4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = L.cand[(4 * g + u) & (kCand4 - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
-                    d2v[u] = dx * dx + (dy * dy + dz * dz);
-                    const bool hit = d2v[u] < 1.0f && (4 * g + u) < ncand;  // k(r) <= 0 for all fp32 r >= 1
-                    mv[u] = __ballot(hit);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t j = 4 * g + u;                 // candidate slot of this step
-                const uint32_t c = (uint32_t)__popcll(mv[u]);
-                const bool stepping = !last && j < ncand;
-                // close the batch when the next run does not fit, the history is full, or at the end
-                if ((bcnt + c > 63u) || bruns == 32u || (last && u == 0)) {
-                    if (bruns != 0u) {
-                        // C: every lane evaluates the pair parked in it
-                        float kv = 0.0f;
-                        if ((uint32_t)lane < bcnt) kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(bd2)), a.sf2);
-                        // D: replay the runs oldest first; candidate j - age used history bit age - 1
-                        uint32_t roff = 0;
-                        for (uint32_t age = bruns; age >= 1u; --age) {
-                            const bool mine = (hist >> (age - 1u)) & 1u;
-                            const unsigned long long m = __ballot(mine);
-                            if (m == 0ull) continue;
-                            const uint32_t cj = (jstep - age) & (kCand4 - 1);
-                            const int nbj = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(L.cand[cj].w));
-                            const float yj = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(L.label[cj])));
-                            if (nbj != cur_nb) {
-                                flush_nb();
-                                cur_nb = nbj;
-                            }
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                            const float ks = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((roff + rank) << 2), __float_as_int(kv)));
-                            if (mine) {
-                                ybar += ks * yj;
-                                kbar += ks;
-                            }
-                            roff += (uint32_t)__popcll(m);
-                        }
-                    }
-                    bcnt = 0;
-                    bruns = 0;
-                    bd2 = 0;
-                    hist = 0;
-                }
-                if (stepping) {
-                    const bool hit = (mv[u] >> lane) & 1ull;
-                    hist = (hist << 1) | (hit ? 1u : 0u);
-                    ++bruns;
-                    ++jstep;
-                    if (c == 64u) {
-                        bd2 = __float_as_uint(d2v[u]);  // every leaf hit: identity placement (batch was just closed)
-                    } else if (c != 0u) {
-                        // B: scatter the run into lanes [bcnt, bcnt + c); misses aim at the spare lane 63
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mv[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv[u], 0));
-                        const uint32_t dst = hit ? (bcnt + rank) : 63u;
-                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)__float_as_uint(d2v[u]));
-                        if ((uint32_t)lane - bcnt < c) bd2 = got;
-                    }
-                    bcnt += c;
-                }
-            }
-        }
-        ncand = 0;
-        jstep = 0;
-        __builtin_amdgcn_wave_barrier();
-        // refill in order (rare: > 64 points in a block, or a crowded 7-neighbourhood)
-        more = false;
-        while (it_b < 7) {
-            const int tbv = a.nbr[7 * blk + it_b];
-            const uint32_t pp0 = tbv >= 0 ? a.train_off[tbv] : 0u;
-            const uint32_t pc = tbv >= 0 ? a.train_off[tbv + 1] - pp0 : 0u;
-            if (it_base >= pc) {
-                ++it_b;
-                it_base = 0;
-                continue;
-            }
-            if (ncand + (uint32_t)kWave > (uint32_t)kCand4) break;
-            const bool valid = it_base + lane < pc;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) p = a.pts[pp0 + it_base + lane];
-            stage(p, valid, it_b);
-            it_base += kWave;
-            more = true;
-        }
-    }
-    if (cur_nb >= 0) flush_nb();
-    if (ungated) {  // insert_training_data: update() runs for every trained neighbour, even with no pair in range
-#pragma unroll
-        for (int b = 0; b < 7; ++b) updated |= tb[b] >= 0;
-    }
-
-    if (active) {
-        if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
-        } else {
-            a.state[li] = 0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Variant 5: three tight phases per candidate round instead of variant 4's interleaving
-// (variant 4 is issue bound on scalar control flow: ~2000 SALU instructions per tile).
+// bgk_predict_fuse_v5 (the kernel; variants 1-4 and 6 of the measurement history in DESIGN.md are gone):
+// three tight phases per candidate round.
 //   B  test + push, branch free: four candidates per trip; hits of candidate j are written
 //      to ring[tail + rank] (rank = mbcnt of the hit mask), misses to a per-lane scratch
 //      slot; every lane shifts its own hit bit into a 64-candidate history.
@@ -1283,234 +494,7 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
     }
 }
 
-// ---------------------------------------------------------------------------
-// Variant 6: per-lane FIFOs.  Variant 5 pays a ballot + mbcnt per candidate twice (push and replay).
-// Here a hit is parked in the leaf's OWN next FIFO slot (no cross-lane work in the test loop), the
-// FIFO levels are flattened once per drain (one ballot per level, ~12, instead of one per candidate,
-// ~44) so that the kernel evaluation still runs on dense lanes, the values are written back in
-// place, and each leaf lane then adds its own values in FIFO order = candidate order = the
-// reference's summation order (bit-identical results).
-// LDS per wave: 64 candidates + 12 FIFO levels of (d2 -> k, candidate) + flatten list = 6.5 KB.
-// ---------------------------------------------------------------------------
-constexpr int kCand6 = 64;
-constexpr int kFifo6 = 12;
-
-struct __attribute__((aligned(16))) WaveLds6 {
-    float4 cand[kCand6 + 4];        // x/ell, y/ell, z/ell, label (+ padding slots)
-    float fifo[kFifo6][kWave];      // d2, overwritten by k(r)
-    uint16_t owner[kFifo6 * kWave]; // flattened (lane | level << 6)
-    uint8_t fcj[kFifo6][kWave];     // candidate slot of each parked pair
-    uint8_t seg[kCand6 + 4];        // neighbour slot of each candidate
-};
-
-template <int kTrig, int kWaves>
-__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v6(BgkArgs a) {
-    __shared__ WaveLds6 s_lds[kWaves];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    uint32_t wg = blockIdx.x;
-    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
-    else if (a.remap == 2) {
-        const uint32_t G8 = gridDim.x & ~63u;
-        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
-    }
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg * kWaves + wv);
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    WaveLds6 &L = s_lds[wv];
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
-    int tb[7];
-    uint32_t p0[7], cnt[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        const uint2 r = a.nbr_range[7 * blk + b];
-        p0[b] = r.x;
-        cnt[b] = r.y;
-        tb[b] = r.y ? 0 : -1;  // only "has a trained model" matters below (a model has >= 1 point)
-    }
-    float4 q[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b)
-        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const uint32_t key = a.leaf_key[li];
-    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs0 = (off4.x + cx) / a.ell, ys0 = (off4.y + cy) / a.ell, zs0 = (off4.z + cz) / a.ell;
-    float A = a.alpha[li], B = a.beta[li];
-
-    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
-    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
-    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
-
-    const bool ungated = (a.flags & 1u) != 0;
-    bool updated = false;
-    float kbar = 0.0f, ybar = 0.0f;
-    uint32_t ncand = 0;
-    int cur_seg = -1;       // per lane: neighbour slot the (ybar, kbar) registers belong to
-    uint32_t fcnt = 0;      // per lane: pairs parked in this lane's FIFO
-
-    auto flush_nb = [&]() {  // Occupancy::update, bgkoctree_node.cpp:31-35
-        if (kbar > 0.0f || ungated) {
-            A += ybar;
-            B += kbar - ybar;
-            updated = true;
-        }
-        kbar = 0.0f;
-        ybar = 0.0f;
-    };
-
-    auto stage = [&](const float4 &p, bool valid, int b) {
-        bool keep = false;
-        if (valid) {
-            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
-            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
-            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
-            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
-        }
-        const unsigned long long m = __ballot(keep);
-        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (keep) {
-            L.cand[slot] = p;
-            L.seg[slot] = (uint8_t)b;
-        }
-        ncand += (uint32_t)__popcll(m);
-    };
-
-    // A: first chunks in ExtendedBlock order while they fit and no neighbour needs a 2nd chunk
-    uint32_t it_b = 7, it_base = 0;
-    {
-        bool open = true;
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            if (!open || cnt[b] == 0) continue;
-            if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand6) {
-                stage(q[b], (uint32_t)lane < cnt[b], b);
-                if (cnt[b] > (uint32_t)kWave) {
-                    open = false;
-                    it_b = b;
-                    it_base = kWave;
-                }
-            } else {
-                open = false;
-                it_b = b;
-                it_base = 0;
-            }
-        }
-    }
-
-    // evaluate every parked pair densely, then let each leaf lane add its own values in FIFO (= candidate) order
-    auto drain = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // flatten level by level: entry (level k, lane l) exists iff cnt_l > k
-        uint32_t total = 0, maxc = 0;
-        for (uint32_t k2 = 0; k2 < (uint32_t)kFifo6; ++k2) {
-            const bool has = fcnt > k2;
-            const unsigned long long m = __ballot(has);
-            if (m == 0ull) break;
-            maxc = k2 + 1;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (has) L.owner[total + rank] = (uint16_t)((uint32_t)lane | (k2 << 6));
-            total += (uint32_t)__popcll(m);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t p = 0; p < ((a.flags & 0x100u) ? 0u : total); p += kWave) {  // 0x100: profiling ablation
-            const uint32_t i = p + lane;
-            if (i < total) {
-                const uint32_t o = L.owner[i];
-                float *slot = &L.fifo[o >> 6][o & 63u];
-                *slot = cov_sparse_fast<kTrig>(sqrt_cr(*slot), a.sf2);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t k2 = 0; k2 < ((a.flags & 0x400u) ? 0u : maxc); ++k2) {  // 0x400: profiling ablation
-            const bool act = k2 < fcnt;
-            const float kv = L.fifo[k2][lane];
-            const uint32_t cj = L.fcj[k2][lane];
-            const float y = L.cand[cj].w;
-            const int sg = (int)L.seg[cj];
-            if (act && sg != cur_seg) {
-                flush_nb();
-                cur_seg = sg;
-            }
-            if (act) {
-                ybar += kv * y;
-                kbar += kv;
-            }
-        }
-        fcnt = 0;
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    bool more = true;
-    while (more) {
-        if (lane < 4) L.cand[ncand + lane] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
-        for (uint32_t g = 0; g < ngroup; ++g) {
-            if (__any(fcnt > (uint32_t)(kFifo6 - 4))) drain();
-            float4 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
-                const float d2 = dx * dx + (dy * dy + dz * dz);
-                // park unconditionally in the lane's next slot; only a hit (k(r) <= 0 for fp32 r >= 1) keeps it
-                L.fifo[fcnt][lane] = d2;
-                L.fcj[fcnt][lane] = (uint8_t)(4 * g + u);
-                fcnt += d2 < 1.0f ? 1u : 0u;
-            }
-        }
-        drain();
-        ncand = 0;
-        more = false;
-        while (it_b < 7) {
-            const uint2 rr = a.nbr_range[7 * blk + it_b];
-            const uint32_t pp0 = rr.x, pc = rr.y;
-            if (it_base >= pc) {
-                ++it_b;
-                it_base = 0;
-                continue;
-            }
-            if (ncand != 0u) break;  // one 64-point chunk per refill round
-            const bool valid = it_base + lane < pc;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) p = a.pts[pp0 + it_base + lane];
-            stage(p, valid, (int)it_b);
-            it_base += kWave;
-            more = true;
-        }
-    }
-    flush_nb();
-    if (ungated) {  // insert_training_data: update() runs for every trained neighbour
-#pragma unroll
-        for (int b = 0; b < 7; ++b) updated |= tb[b] >= 0;
-    }
-
-    if (active) {
-        if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
-        } else {
-            a.state[li] = 0;
-        }
-    }
-}
-
-// exhaustive sweeps of the two shortcuts used by variant 3 against the IEEE operations:
+// exhaustive sweeps of the kernel's shortcuts against the IEEE operations:
 // counts fp32 inputs in [lo_bits, hi_bits] (as unsigned bit patterns) where they differ.
 __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatch) {
     const uint64_t n = (uint64_t)hi_bits - lo_bits + 1;

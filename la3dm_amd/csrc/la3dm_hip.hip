@@ -190,8 +190,6 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.n_tasks = s->n_test_blk << tpb_shift;
     a.flags = s->flags | ((uint32_t)ctx->opt_ablate << 8);
     a.remap = (uint32_t)ctx->opt_remap;
-    a.fix_exp = 0;
-    while ((float)(1ll << a.fix_exp) < ctx->p.sf2 && a.fix_exp < 20) ++a.fix_exp;
     a.sf2 = ctx->p.sf2;
     a.ell = ctx->p.ell;
     a.free_thresh = ctx->p.free_thresh;
@@ -215,33 +213,7 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
     default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, 0, stream, a); break;    \
     }
-    if (ctx->opt_variant == 1) {
-        LAUNCH_BGK(bgk_predict_fuse_v1)
-    } else if (ctx->opt_variant == 2) {
-        LAUNCH_BGK(bgk_predict_fuse_v2)
-    } else if (ctx->opt_variant == 3) {
-        const int w = ctx->opt_waves;
-        grid = dim3((a.n_tasks + w - 1) / w);
-        block = dim3(w * kWave);
-        if (w == 4) {
-            LAUNCH_BGK(bgk_predict_fuse_v3, , 4)
-        } else if (w == 2) {
-            LAUNCH_BGK(bgk_predict_fuse_v3, , 2)
-        } else {
-            LAUNCH_BGK(bgk_predict_fuse_v3, , 1)
-        }
-    } else if (ctx->opt_variant == 6) {
-        const int w = ctx->opt_waves;
-        grid = dim3((a.n_tasks + w - 1) / w);
-        block = dim3(w * kWave);
-        if (w == 4) {
-            LAUNCH_BGK(bgk_predict_fuse_v6, , 4)
-        } else if (w == 2) {
-            LAUNCH_BGK(bgk_predict_fuse_v6, , 2)
-        } else {
-            LAUNCH_BGK(bgk_predict_fuse_v6, , 1)
-        }
-    } else if (ctx->opt_variant == 0 || ctx->opt_variant == 5) {
+    {
         const int w = ctx->opt_waves;
         grid = dim3((a.n_tasks + w - 1) / w);
         block = dim3(w * kWave);
@@ -251,27 +223,6 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
             LAUNCH_BGK(bgk_predict_fuse_v5, , 2)
         } else {
             LAUNCH_BGK(bgk_predict_fuse_v5, , 1)
-        }
-    } else {
-        const int w = ctx->opt_waves;
-        grid = dim3((a.n_tasks + w - 1) / w);
-        block = dim3(w * kWave);
-        if (w == 4) {
-            LAUNCH_BGK(bgk_predict_fuse_v4, , 4)
-        } else if (w == 2) {
-            LAUNCH_BGK(bgk_predict_fuse_v4, , 2)
-        } else {
-            LAUNCH_BGK(bgk_predict_fuse_v4, , 1)
-        }
-    }
-    if (false) {
-        const int w = 1;
-        if (w == 4) {
-            LAUNCH_BGK(bgk_predict_fuse_v3, , 4)
-        } else if (w == 2) {
-            LAUNCH_BGK(bgk_predict_fuse_v3, , 2)
-        } else {
-            LAUNCH_BGK(bgk_predict_fuse_v3, , 1)
         }
     }
 #undef LAUNCH_BGK
