@@ -225,3 +225,34 @@ def test_gp_variant(built):
         m.insert_pointcloud(xyz[::3], origin, 0.1, 0.5, 8.0)
         o.insert_pointcloud(xyz[::3], origin, 0.1, 0.5, 8.0)
     _same(m, o, "gp")
+
+
+def test_randomised_small_scenes(built):
+    """seeded random scenes and map parameters (resolution, depth, length scale, sampling, range gate, voxel filter
+    on/off): both map modes must reproduce the oracle bit for bit over three fused scans each"""
+    import la3dm_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(2026)
+    for case in range(12):
+        res = float(rng.choice([0.05, 0.1, 0.2]))
+        depth = int(rng.choice([1, 2, 3, 4]))
+        params = dict(resolution=res, block_depth=depth, sf2=float(rng.choice([0.1, 1.0])),
+                      ell=float(rng.choice([1.5, 2.0, 3.0])) * res, free_thresh=0.3, occupied_thresh=0.7,
+                      var_thresh=float(rng.choice([0.05, 100.0])), prior_A=0.001, prior_B=0.001)
+        md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+        mh = la3dm_amd.BGKOctoMap(**params, device=0)
+        o = O.OracleMap(**params)
+        for scan in range(3):
+            n = int(rng.integers(1, 400))
+            origin = rng.uniform(-1, 1, 3).astype(np.float32)
+            # points on a few planes / blobs around the sensor, some exactly on voxel and block faces
+            pts = origin + rng.normal(0, 1.0, (n, 3)).astype(np.float32) * rng.uniform(0.2, 3.0)
+            k = n // 4
+            pts[:k] = np.round(pts[:k] / res) * res
+            ds = float(rng.choice([-1.0, res, 2 * res]))
+            fr = float(rng.choice([0.3, 0.5, 1.0])) * max(res * 4, 0.2)
+            mr = float(rng.choice([-1.0, 2.5, 6.0]))
+            for m in (md, mh, o):
+                m.insert_pointcloud(pts, origin, ds, fr, mr)
+            _same(md, o, f"case{case} scan{scan} device-resident {params} ds={ds} fr={fr} mr={mr}")
+            _same(mh, o, f"case{case} scan{scan} host-orchestrated")
