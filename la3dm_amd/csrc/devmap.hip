@@ -49,7 +49,7 @@ struct la3dm_devmap {
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
     Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big;
     Arena train, grid, axis_tab;
-    Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot;
+    Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
     uint32_t n_xy = 0;
     la3dm_devmap_stats stats;
@@ -270,7 +270,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
                     &dm->cub_tmp, &dm->big, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
-                    &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->nleaf,
+                    &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
@@ -474,6 +474,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     DM_RESERVE(dm->c_weight, 4ull * n_entries);
     uint32_t *c_flag = (uint32_t *)dm->c_flag.ptr, *c_weight = (uint32_t *)dm->c_weight.ptr, *c_scan = (uint32_t *)dm->c_scan.ptr;
     const uint32_t ncell = dm->ncell;
+    uint32_t n_test0 = 0;
     for (uint32_t pass = 0; pass < max_occ; ++pass) {
         const double tp0 = wall();
         ca.pass = pass;
@@ -572,16 +573,26 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
                            (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
                            (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
-        {
-            const uint32_t waves = dm->depth >= 6 ? 1u : 4u;  // LDS per wave: 3 bytes per node
-            hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, waves)), dim3(64 * waves), waves * prune_lds_stride(dm->npb), st,
-                               (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, dm->A, dm->B, dm->S, dm->npb, dm->depth);
+        // The reference prunes after ALL test blocks have been predicted (bgkoctomap.cpp:344-353): with repeated keys
+        // the later passes must still see the un-pruned leaves, so the prune of pass 0 (which holds every distinct
+        // test block) is deferred to the end of the pass loop.
+        if (max_occ == 1) {
+            hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
+                               (const uint32_t *)dm->t_slot.ptr, n_test, dm->A, dm->B, dm->S, dm->npb, dm->depth);
+        } else if (pass == 0) {
+            DM_RESERVE(dm->t_slot0, 4ull * n_test);
+            DM_TRY(hipMemcpyAsync(dm->t_slot0.ptr, dm->t_slot.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
+            n_test0 = n_test;
         }
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
         S.voxel_updates += dm->h_cnt[kCntLeaves];
         if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;
     }
+    if (max_occ > 1 && n_test0)
+        hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test0, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
+                           (const uint32_t *)dm->t_slot0.ptr, n_test0, dm->A, dm->B, dm->S, dm->npb, dm->depth);
     DM_TRY(hipGetLastError());
+    DM_TRY(hipStreamSynchronize(st));
     S.n_blocks = dm->n_blocks;
     S.t_total = wall() - t0;
     if (!getenv("LA3DM_TIMING")) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit

@@ -752,13 +752,13 @@ __global__ __launch_bounds__(256) void dm_commit(const uint32_t *__restrict__ co
 // Dynamic LDS: 4 waves x prune_lds_stride(npb) bytes.
 __host__ __device__ inline uint32_t prune_lds_stride(uint32_t npb) { return (((npb + 1u) & ~1u) + 2u * npb + 15u) & ~15u; }
 
-__global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slot, const uint32_t *__restrict__ counters,
-                                               float *A, float *B, uint8_t *S, uint32_t npb, uint32_t block_depth) {
+__global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slot, uint32_t n_test, float *A, float *B,
+                                               uint8_t *S, uint32_t npb, uint32_t block_depth) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dm_prune_smem[];
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + wv;
     const int lane = threadIdx.x & 63;
-    if (t >= counters[kCntTest]) return;
+    if (t >= n_test) return;
     uint8_t *sS = dm_prune_smem + wv * prune_lds_stride(npb);
     uint16_t *src = (uint16_t *)(sS + ((npb + 1u) & ~1u));
     const size_t base = (size_t)slot[t] * npb;

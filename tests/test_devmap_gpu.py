@@ -256,3 +256,28 @@ def test_randomised_small_scenes(built):
                 m.insert_pointcloud(pts, origin, ds, fr, mr)
             _same(md, o, f"case{case} scan{scan} device-resident {params} ds={ds} fr={fr} mr={mr}")
             _same(mh, o, f"case{case} scan{scan} host-orchestrated")
+
+
+@pytest.mark.parametrize("x0", [4096.2, 1000.2, 50000.2])
+def test_float_stepped_candidate_list_repeats_and_gaps(built, x0):
+    """get_blocks_in_bbox steps floats: far from the origin a block index repeats (the serial reference then processes
+    that test block twice, the second time on the first pass's posterior) or is skipped (its points stay
+    geometrically visible to the neighbours' R-tree queries but train nothing).  x0 values found by replaying the
+    loop: 4096.2 and 50000.2 repeat an index, 1000.2 skips one.  All three implementations must agree bit for bit."""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.BGK_YAML)
+    rng = np.random.default_rng(7)
+    n = 6000
+    pts = np.stack([np.float32(x0) + rng.uniform(0, 12.0, n), rng.uniform(-2, 2, n), rng.uniform(0, 2, n)], 1).astype(np.float32)
+    pts[0] = (np.float32(x0), 0, 1)
+    pts[1] = (np.float32(x0) + np.float32(12.0), 0, 1)
+    origin = np.array([x0 + 6.0, 0.0, 1.0], np.float32)
+    md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+    mh = la3dm_amd.BGKOctoMap(**params, device=0)
+    o = O.OracleMap(**params)
+    for m in (md, mh, o):
+        m.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)
+        m.insert_pointcloud(pts[::2], origin, 0.1, 0.5, -1.0)
+    _same(mh, o, "host-orchestrated")
+    _same(md, o, "device-resident")
