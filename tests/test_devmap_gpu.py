@@ -281,3 +281,28 @@ def test_float_stepped_candidate_list_repeats_and_gaps(built, x0):
         m.insert_pointcloud(pts[::2], origin, 0.1, 0.5, -1.0)
     _same(mh, o, "host-orchestrated")
     _same(md, o, "device-resident")
+
+
+def test_voxel_grid_index_overflow_passthrough_and_depth5(built):
+    """(a) a cloud whose voxel-grid index space exceeds int32: pcl::VoxelGrid hands the input back unfiltered (both
+    filter calls); (b) block_depth 5 (4096 leaves per block, the deepest the device-resident map supports)"""
+    import la3dm_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    params = dict(la3dm_amd.BGK_YAML)
+    m, o = _maps(params)
+    pts = (rng.uniform(-1, 1, (150, 3)) * np.array([110.0, 110.0, 30.0])).astype(np.float32)   # 2200 x 2200 x 600 cells
+    origin = np.zeros(3, np.float32)
+    m.insert_pointcloud(pts, origin, 0.1, 2.0, -1.0)
+    o.insert_pointcloud(pts, origin, 0.1, 2.0, -1.0)
+    t, ref = m.training_data(), O.get_training_data(pts, origin, 0.1, 2.0, -1.0)
+    assert t.shape == ref.shape and (t.view(np.uint32) == ref.view(np.uint32)).all()
+    assert (t[:, 3] == 1).sum() == 150                      # nothing was merged: the filter passed the cloud through
+    _same(m, o, "passthrough")
+    params = dict(la3dm_amd.BGK_YAML, block_depth=5, resolution=0.05)
+    m, o = _maps(params)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 3))
+    for _ in range(2):
+        m.insert_pointcloud(xyz[::5], origin, 0.05, 0.5, 5.0)
+        o.insert_pointcloud(xyz[::5], origin, 0.05, 0.5, 5.0)
+    _same(m, o, "depth5")
