@@ -1,0 +1,86 @@
+"""Seeded random small scenes through every map variant (GPU vs CPU oracle, bit for bit): a broad sweep over
+parameters and geometry that the hand-made cases do not reach (points on voxel / block faces, tiny clouds, short
+beams, range gates, voxel filter on and off, depths 2-4)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rng, res):
+    n = int(rng.integers(1, 300))
+    origin = rng.uniform(-1, 1, 3).astype(np.float32)
+    pts = origin + rng.normal(0, 1.0, (n, 3)).astype(np.float32) * rng.uniform(0.3, 2.5)
+    k = n // 4
+    pts[:k] = np.round(pts[:k] / res) * res
+    return pts.astype(np.float32), origin
+
+
+def _same(a, b, tag, keys=("block_key", "node_key", "classified", "state")):
+    assert a["A"].size == b["A"].size, (tag, a["A"].size, b["A"].size)
+    for k in keys:
+        assert (a[k] == b[k]).all(), (tag, k, int((a[k] != b[k]).sum()))
+    for k in ("A", "B"):
+        d = a[k].view(np.uint32) != b[k].view(np.uint32)
+        assert not d.any(), (tag, k, int(d.sum()), float(np.abs(a[k] - b[k]).max()))
+
+
+def test_bgkl_random(built):
+    import la3dm_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(101)
+    for case in range(8):
+        res = float(rng.choice([0.05, 0.1, 0.2]))
+        params = dict(resolution=res, block_depth=int(rng.choice([2, 3, 4])), sf2=float(rng.choice([0.1, 1.0])),
+                      ell=float(rng.choice([1.5, 2.0, 3.0])) * res, free_thresh=0.3, occupied_thresh=0.7,
+                      var_thresh=float(rng.choice([0.15, 100.0])), prior_A=0.001, prior_B=0.001)
+        m, o = la3dm_amd.BGKLOctoMap(**params, device=0), O.OracleLMap(**params)
+        for scan in range(3):
+            pts, origin = _scene(rng, res)
+            ds = float(rng.choice([-1.0, res]))
+            fr = float(rng.choice([0.2, 0.3, 0.6]))
+            mr = float(rng.choice([-1.0, 3.0]))
+            m.insert_pointcloud(pts, origin, ds, fr, mr)
+            o.insert_pointcloud(pts, origin, ds, fr, mr)
+            _same(m.leaves(), o.leaves(), f"bgkl case{case} scan{scan} {params} ds={ds} fr={fr} mr={mr}")
+
+
+def test_gp_random(built):
+    import la3dm_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(202)
+    for case in range(6):
+        res = float(rng.choice([0.1, 0.2]))
+        params = dict(resolution=res, block_depth=int(rng.choice([2, 3, 4])), sf2=1.0, ell=float(rng.choice([0.5, 1.0])),
+                      noise=float(rng.choice([0.01, 0.05])), l=100.0, min_var=0.001, max_var=1000.0, max_known_var=0.02,
+                      free_thresh=0.3, occupied_thresh=0.7)
+        for resident in (False, True):
+            m, o = la3dm_amd.GPOctoMap(**params, device=0), O.OracleGPMap(**params)
+            if resident:
+                m.set_device_resident(True)
+            r2 = np.random.default_rng(1000 + case)
+            for scan in range(2):
+                pts, origin = _scene(r2, res)
+                ds, fr = float(r2.choice([-1.0, res])), float(r2.choice([0.2, 0.5]))
+                m.insert_pointcloud(pts, origin, ds, fr, 4.0)
+                o.insert_pointcloud(pts, origin, ds, fr, 4.0)
+                _same(m.leaves(), o.leaves(), f"gp case{case} scan{scan} resident={resident} {params}")
+
+
+def test_bgklv_random(built):
+    import la3dm_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(303)
+    for case in range(6):
+        res = float(rng.choice([0.05, 0.1]))
+        params = dict(resolution=res, block_depth=int(rng.choice([3, 4, 5])), sf2=0.1, ell=float(rng.choice([0.2, 0.3])),
+                      free_thresh=0.3, occupied_thresh=0.7, var_thresh=0.2, prior_A=0.001, prior_B=0.001,
+                      original_size=True, min_W=0.001)
+        m, o = la3dm_amd.BGKLVOctoMap(**params, device=0), O.OracleLVMap(**params)
+        for scan in range(2):
+            pts, origin = _scene(rng, res)
+            pts = pts[:120]
+            fr = float(rng.choice([0.1, 0.2]))
+            m.insert_pointcloud(pts, origin, res, fr, 8.0)
+            o.insert_pointcloud(pts, origin, res, fr, 8.0)
+            _same(m.leaves(), o.leaves(), f"lv case{case} scan{scan} {params} fr={fr}")
