@@ -47,7 +47,7 @@ struct la3dm_devmap {
     GridParams *d_gp = nullptr, *h_gp = nullptr;
     // arenas (grow only)
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
-    Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big;
+    Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big, chunk_desc;
     Arena train, grid, axis_tab;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
@@ -141,8 +141,13 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
         DM_TRY(hipMemsetAsync(dm->d_cnt + kCntBig, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(nseg, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
                            (int)kCntGridSegs, (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
+        const uint32_t nchunk = n / kChunk;
+        DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
+        if (nchunk)
+            hipLaunchKernelGGL(dm_big_chunks, dim3(nchunk), dim3(64), 0, st, d_in, v1, flag, scan, dm->d_cnt, (int)kCntGridValid,
+                               (uint4 *)dm->chunk_desc.ptr);
         hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
-                           (const uint32_t *)dm->big.ptr, (float *)out.ptr);
+                           (const uint32_t *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
     }
     *n_out = nseg;
     return LA3DM_OK;
@@ -269,7 +274,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     (void)hipSetDevice(dm->ctx->device);
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
-                    &dm->cub_tmp, &dm->big, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
+                    &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)

@@ -267,14 +267,54 @@ __host__ __device__ inline float add_repeat_f32(float s, float x, uint32_t m) {
     return s;
 }
 
+// Chunk descriptors for the large cells: chunk q = sorted positions [512 q, 512 q + 512).  If the whole chunk lies in
+// one cell, desc[q] = {bit c set when all 512 values of coordinate c are identical, x bits, y bits, z bits}; else
+// {0, ...}.  Fully parallel (one wave per chunk) — it lets the serial kernel below skip whole chunks of the run of
+// identical samples (the sensor origin, once per beam) without touching their data.
+constexpr uint32_t kChunk = 512;
+
+__global__ __launch_bounds__(64) void dm_big_chunks(const float *__restrict__ p, const uint32_t *__restrict__ vals,
+                                                        const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan,
+                                                        const uint32_t *__restrict__ counters, int valid_slot, uint4 *desc) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t i0 = q * kChunk;
+    uint4 d = make_uint4(0u, 0u, 0u, 0u);
+    if (i0 + kChunk <= counters[valid_slot]) {
+        const uint32_t sa = scan[i0] + flag[i0], sb = scan[i0 + kChunk - 1] + flag[i0 + kChunk - 1];
+        if (sa == sb) {
+            uint32_t first[3];
+            bool same[3] = {true, true, true};
+#pragma unroll
+            for (int u = 0; u < (int)(kChunk / 64); ++u) {
+                const uint32_t v = vals[i0 + 64u * u + lane];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t xb = __float_as_uint(p[3 * (size_t)v + c]);
+                    if (u == 0) first[c] = __builtin_amdgcn_readfirstlane(xb);
+                    same[c] = same[c] && xb == first[c];
+                }
+            }
+            uint32_t bits = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bits |= (__ballot(same[c]) == ~0ull ? 1u : 0u) << c;
+            d = make_uint4(bits, first[0], first[1], first[2]);
+        }
+    }
+    if (lane == 0) desc[q] = d;
+}
+
 // Large cells: one wave per (cell, coordinate).  The sum must stay a serial fp32 chain, so the wave turns it
 // into one dependent VALU op per point: lane j holds point j of a 64-point batch and 64 steps of
 // `v = wave_shr1(v) + x` (DPP full-wave shift, lane 0 holds carry-in + x_0) leave the running prefix in
-// every lane — sum_{k} = sum_{k-1} + x_k exactly as the sequential loop.  Loads run two batches ahead.
+// every lane — sum_{k} = sum_{k-1} + x_k exactly as the sequential loop.  Loads run two batches ahead.  Runs of
+// identical values are summed in closed form (add_repeat_f32); chunks that dm_big_chunks found uniform extend the
+// pending run without loading anything.
 __global__ __launch_bounds__(64) void dm_grid_centroids_big(const float *__restrict__ p, const uint32_t *__restrict__ vals,
                                                            const uint32_t *__restrict__ seg_start,
                                                            const uint32_t *__restrict__ counters, int big_slot,
-                                                           const uint32_t *__restrict__ big, float *out) {
+                                                           const uint32_t *__restrict__ big, const uint4 *__restrict__ desc,
+                                                           float *out) {
     const int lane = threadIdx.x;
     const uint32_t c = blockIdx.y;
     const uint32_t nbig = counters[big_slot];
@@ -283,68 +323,98 @@ __global__ __launch_bounds__(64) void dm_grid_centroids_big(const float *__restr
         const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
         float s = 0.f;
         uint32_t run_x = 0u, run_len = 0u;  // pending run of identical values (bits, count)
-        // kSub sub-batches of 64 points per trip; indices are fetched two trips ahead, values one trip ahead,
-        // so one memory round trip overlaps kSub * 64 chain steps
-        constexpr int kSub = 8;
-        constexpr uint32_t kTrip = 64u * kSub;
-        uint32_t vi[kSub];
-        float xn[kSub];
-#pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-            const uint32_t j = s0 + 64u * u + lane;
-            const uint32_t v0 = j < s1 ? vals[j] : 0u;
-            xn[u] = j < s1 ? p[3 * (size_t)v0 + c] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-            const uint32_t j = s0 + kTrip + 64u * u + lane;
-            vi[u] = j < s1 ? vals[j] : 0u;
-        }
-        for (uint32_t b = s0; b < s1; b += kTrip) {
-            float xc[kSub];
-#pragma unroll
-            for (int u = 0; u < kSub; ++u) xc[u] = xn[u];
+
+        // generic path over sorted positions [lo, hi): kSub sub-batches of 64 points per trip; indices are fetched two
+        // trips ahead, values one trip ahead, so one memory round trip overlaps kSub * 64 chain steps
+        auto process = [&](const uint32_t lo, const uint32_t hi) {
+            if (lo >= hi) return;
+            constexpr int kSub = 8;
+            constexpr uint32_t kTrip = 64u * kSub;
+            uint32_t vi[kSub];
+            float xn[kSub];
 #pragma unroll
             for (int u = 0; u < kSub; ++u) {
-                const uint32_t j1 = b + kTrip + 64u * u + lane, j2 = j1 + kTrip;
-                xn[u] = j1 < s1 ? p[3 * (size_t)vi[u] + c] : 0.f;
-                vi[u] = j2 < s1 ? vals[j2] : 0u;
+                const uint32_t j = lo + 64u * u + lane;
+                const uint32_t v0 = j < hi ? vals[j] : 0u;
+                xn[u] = j < hi ? p[3 * (size_t)v0 + c] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < kSub; ++u) {
-                const uint32_t bu = b + 64u * u;
-                if (bu >= s1) break;
-                const uint32_t nb = min(64u, s1 - bu);
-                // a sub-batch of identical values extends the pending run (summed in closed form when it ends)
-                const uint32_t xfirst = __builtin_amdgcn_readfirstlane(__float_as_uint(xc[u]));
-                const bool uniform = __ballot((uint32_t)lane >= nb || __float_as_uint(xc[u]) == xfirst) == ~0ull;
-                if (uniform && (run_len == 0u || xfirst == run_x)) {
-                    run_x = xfirst;
-                    run_len += nb;
-                    continue;
-                }
-                if (run_len) {
-                    s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
-                    run_len = 0;
-                }
-                if (uniform) {
-                    run_x = xfirst;
-                    run_len = nb;
-                    continue;
-                }
-                // lane 0 takes the carry-in first: (s + x_0) + x_1 + ... is the sequential order
-                const float x0 = lane == 0 ? s + xc[u] : xc[u];
-                float v = x0;
+                const uint32_t j = lo + kTrip + 64u * u + lane;
+                vi[u] = j < hi ? vals[j] : 0u;
+            }
+            for (uint32_t b = lo; b < hi; b += kTrip) {
+                float xc[kSub];
 #pragma unroll
-                for (int t = 0; t < 64; ++t) {
-                    // wave_shr:1 with bound_ctrl — lane j receives lane j-1, lane 0 receives 0 (0 + x is exact);
-                    // folds into one v_add_f32_dpp per step
-                    const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
-                    v = sh + x0;
+                for (int u = 0; u < kSub; ++u) xc[u] = xn[u];
+#pragma unroll
+                for (int u = 0; u < kSub; ++u) {
+                    const uint32_t j1 = b + kTrip + 64u * u + lane, j2 = j1 + kTrip;
+                    xn[u] = j1 < hi ? p[3 * (size_t)vi[u] + c] : 0.f;
+                    vi[u] = j2 < hi ? vals[j2] : 0u;
                 }
-                s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)nb - 1));
+#pragma unroll
+                for (int u = 0; u < kSub; ++u) {
+                    const uint32_t bu = b + 64u * u;
+                    if (bu >= hi) break;
+                    const uint32_t nb = min(64u, hi - bu);
+                    // a sub-batch of identical values extends the pending run (summed in closed form when it ends)
+                    const uint32_t xfirst = __builtin_amdgcn_readfirstlane(__float_as_uint(xc[u]));
+                    const bool uniform = __ballot((uint32_t)lane >= nb || __float_as_uint(xc[u]) == xfirst) == ~0ull;
+                    if (uniform && (run_len == 0u || xfirst == run_x)) {
+                        run_x = xfirst;
+                        run_len += nb;
+                        continue;
+                    }
+                    if (run_len) {
+                        s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
+                        run_len = 0;
+                    }
+                    if (uniform) {
+                        run_x = xfirst;
+                        run_len = nb;
+                        continue;
+                    }
+                    // lane 0 takes the carry-in first: (s + x_0) + x_1 + ... is the sequential order
+                    const float x0 = lane == 0 ? s + xc[u] : xc[u];
+                    float v = x0;
+#pragma unroll
+                    for (int t = 0; t < 64; ++t) {
+                        // wave_shr:1 with bound_ctrl — lane j receives lane j-1, lane 0 receives 0 (0 + x is exact);
+                        // folds into one v_add_f32_dpp per step
+                        const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+                        v = sh + x0;
+                    }
+                    s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)nb - 1));
+                }
+            }
+        };
+
+        // head up to the first chunk boundary, whole chunks by descriptor, tail
+        const uint32_t a = min(s1, (s0 + kChunk - 1u) & ~(kChunk - 1u));
+        const uint32_t z = max(a, s1 & ~(kChunk - 1u));
+        process(s0, a);
+        for (uint32_t q0 = a / kChunk; q0 < z / kChunk; q0 += 64u) {
+            const uint32_t nq = min(64u, z / kChunk - q0);
+            uint4 dl = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)lane < nq) dl = desc[q0 + lane];  // 64 descriptors per load
+            const uint32_t dflag = (dl.x >> c) & 1u, dval = c == 0 ? dl.y : (c == 1 ? dl.z : dl.w);
+            for (uint32_t k = 0; k < nq; ++k) {
+                const uint32_t f = __builtin_amdgcn_readlane(dflag, (int)k);
+                if (f) {
+                    const uint32_t xb = __builtin_amdgcn_readlane(dval, (int)k);
+                    if (run_len && xb != run_x) {
+                        s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
+                        run_len = 0;
+                    }
+                    run_x = xb;
+                    run_len += kChunk;
+                } else {
+                    process((q0 + k) * kChunk, (q0 + k + 1u) * kChunk);
+                }
             }
         }
+        process(z, s1);
         if (run_len) s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
         if (lane == 0) out[3 * (size_t)seg + c] = s / (float)(s1 - s0);
     }
