@@ -85,22 +85,28 @@ class BGKOctoMap:
         return self._M.la3dm_map_block_size(self._h)
 
     def insert_pointcloud(self, cloud, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        """BGKOctoMap::insert_pointcloud(cloud, origin, ds_resolution, free_res, max_range)
+        (include/bgkoctomap/bgkoctomap.h:82-84, src/bgkoctomap/bgkoctomap.cpp:214-366): ds_resolution < 0 skips the
+        voxel-grid filter, max_range <= 0 the range gate; an empty training set is a silent no-op."""
         xyz = np.ascontiguousarray(cloud, np.float32).reshape(-1, 3)
         o = np.ascontiguousarray(origin, np.float32)
         self._chk(self._M.la3dm_map_insert_pointcloud(self._h, xyz, xyz.shape[0], o, ds_resolution, free_res,
                                                       max_range))
 
     def insert_training_data(self, xyzy):
+        """BGKOctoMap::insert_training_data(GPPointCloud) (bgkoctomap.h:86, bgkoctomap.cpp:82-212): rows x, y, z, label;
+        every leaf of every test block is updated (no kbar gate)."""
         a = np.ascontiguousarray(xyzy, np.float32).reshape(-1, 4)
         self._chk(self._M.la3dm_map_insert_training_data(self._h, a, a.shape[0]))
 
     def get_bbox(self):
+        """BGKOctoMap::get_bbox (bgkoctomap.h:89, bgkoctomap.cpp:368-381): block centres +- half a block"""
         lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
         self._M.la3dm_map_get_bbox(self._h, lo, hi)
         return lo, hi
 
     def search(self, x, y, z):
-        """-> (exists, alpha, beta, state)"""
+        """BGKOctoMap::search(x, y, z) (bgkoctomap.h:315-319, bgkoctomap.cpp:554-567) -> (exists, alpha, beta, state)"""
         a, b, s = C.c_float(), C.c_float(), C.c_uint8()
         e = self._M.la3dm_map_search(self._h, x, y, z, C.byref(a), C.byref(b), C.byref(s))
         return bool(e), a.value, b.value, s.value
