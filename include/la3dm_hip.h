@@ -238,6 +238,7 @@ typedef struct la3dm_devmap_stats {
     uint64_t n_bbox_blocks;            /* entries of the candidate list */
     uint64_t voxel_updates;            /* U: leaves of the test blocks */
     uint64_t train_reads;              /* sum over test blocks of their 7-neighbourhood training points */
+    uint64_t pair_evals;               /* sum over test blocks of neighbourhood points x leaves (P) */
     uint64_t n_blocks;                 /* blocks in the pool after the scan */
     uint32_t n_passes;                 /* 1 + repeats of a key in the candidate list */
     double t_frontend, t_partition, t_pack, t_kernel, t_commit, t_total; /* seconds, host clock at sync points */

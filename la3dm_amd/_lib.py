@@ -59,7 +59,7 @@ class ScanStats(C.Structure):
 class DevmapStats(C.Structure):
     """la3dm_devmap_stats (include/la3dm_hip.h)"""
     _fields_ = [(k, C.c_uint64) for k in ("n_hits", "n_frees", "n_train_blocks", "n_test_blocks", "n_bbox_blocks",
-                                          "voxel_updates", "train_reads", "n_blocks")] + \
+                                          "voxel_updates", "train_reads", "pair_evals", "n_blocks")] + \
                [("n_passes", C.c_uint32)] + \
                [(k, C.c_double) for k in ("t_frontend", "t_partition", "t_pack", "t_kernel", "t_commit", "t_total")]
 

@@ -42,6 +42,7 @@ struct la3dm_devmap {
     uint32_t *tab_val = nullptr;
     // small fixed buffers
     uint32_t *d_cnt = nullptr, *h_cnt = nullptr;  // counters (device / pinned host)
+    unsigned long long *d_acc = nullptr;          // 64-bit work counters (train_reads, pair_evals)
     uint32_t *d_mm = nullptr;
     float *d_bbox = nullptr, *h_bbox = nullptr;
     GridParams *d_gp = nullptr, *h_gp = nullptr;
@@ -255,6 +256,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 8) == hipSuccess &&
+              hipMalloc((void **)&dm->d_acc, sizeof(unsigned long long) * 2) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
               hipMalloc((void **)&dm->d_gp, sizeof(GridParams)) == hipSuccess &&
@@ -279,7 +281,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
-    void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp};
+    void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp, dm->d_acc};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (dm->h_cnt) (void)hipHostFree(dm->h_cnt);
@@ -302,6 +304,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     const double t0 = wall();
     int rc;
     DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+    DM_TRY(hipMemsetAsync(dm->d_acc, 0, sizeof(unsigned long long) * 2, st));
 
     // ---------------- f1: front end ----------------
     const float *d_hits = d_xyz;
@@ -467,11 +470,11 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
                        (float4 *)dm->train.ptr);
     DM_RESERVE(dm->grid, 4ull * ncid);
     DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
-    hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, (int32_t *)dm->grid.ptr);
+    hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if (dm->h_cnt[kCntError]) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
     const uint32_t n_geo = dm->h_cnt[kCntGeo];
-    S.n_train_blocks = n_geo;
+    S.n_train_blocks = dm->h_cnt[kCntTrained];
     const double t2 = wall();
     S.t_partition = t2 - t1;
 
@@ -537,6 +540,8 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                            (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                            (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
+                           (const uint32_t *)nleaf, n_test, dm->d_acc);
         if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
         hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
         hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
@@ -597,7 +602,13 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test0, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot0.ptr, n_test0, dm->A, dm->B, dm->S, dm->npb, dm->depth);
     DM_TRY(hipGetLastError());
-    DM_TRY(hipStreamSynchronize(st));
+    {
+        unsigned long long acc[2] = {0, 0};
+        DM_TRY(hipMemcpyAsync(acc, dm->d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));
+        S.train_reads = acc[0];
+        S.pair_evals = acc[1];
+    }
     S.n_blocks = dm->n_blocks;
     S.t_total = wall() - t0;
     if (!getenv("LA3DM_TIMING")) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit

@@ -44,6 +44,7 @@ enum DevCounter {
     kCntTrainReads = 10, // low 32 bits of sum of neighbourhood sizes
     kCntTrainReadsHi = 11,
     kCntBig = 12,        // voxel-grid cells with more than kBigCell points
+    kCntTrained = 13,    // blocks with training points that are in the candidate list
     kCntWords = 16
 };
 
@@ -581,10 +582,36 @@ __global__ __launch_bounds__(256) void dm_gather_train(const float4 *__restrict_
 }
 
 // grid[cid] = segment (training block) index; -1 elsewhere (memset before)
-__global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ seg_key, const uint32_t *__restrict__ counters,
+// also counts the trained blocks (= blocks with points that are in the candidate list) in counters[kCntTrained]
+__global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ seg_key, uint32_t *counters, PartArgs a,
                                                   int32_t *grid) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < counters[kCntGeo]) grid[seg_key[s]] = (int32_t)s;
+    if (s >= counters[kCntGeo]) return;
+    const uint32_t cid = seg_key[s];
+    grid[cid] = (int32_t)s;
+    const uint32_t z = cid % (uint32_t)a.gn[2], y = (cid / (uint32_t)a.gn[2]) % (uint32_t)a.gn[1],
+                   x = cid / ((uint32_t)a.gn[2] * (uint32_t)a.gn[1]);
+    if (a.mult[0][x] && a.mult[1][y] && a.mult[2][z]) atomicAdd(&counters[kCntTrained], 1u);
+}
+
+// work counters of one pass: sum over test blocks of their neighbourhood size (train_reads) and of
+// neighbourhood size x leaf count (pair_evals); acc[0], acc[1] are 64-bit
+__global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf,
+                                                    uint32_t n_test, unsigned long long *acc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long w = 0, pw = 0;
+    if (t < n_test) {
+        w = 0xFFFFFFFFu - t_key[t];  // the sort key of the test list is ~weight
+        pw = w * nleaf[t];
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        w += __shfl_xor(w, o);
+        pw += __shfl_xor(pw, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (w | pw)) {
+        atomicAdd(&acc[0], w);
+        atomicAdd(&acc[1], pw);
+    }
 }
 
 struct CandArgs {

@@ -469,6 +469,17 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     int rc = la3dm_create(&p, &ctx);
     if (rc != LA3DM_OK)
         throw std::runtime_error(std::string("BGKOctoMap: GPU context creation failed: ") + la3dm_last_error(nullptr));
+    // Device-resident by default where it exists (BGK and GP maps, block_depth <= 5): insert_pointcloud then runs
+    // start to finish on the GPU.  insert_training_data and the split prepare()/commit() form move the map back to
+    // the host-orchestrated mode on their own (ensure_host_mode).  LA3DM_DEVICE_RESIDENT=0 keeps the host mode.
+    const char *env = getenv("LA3DM_DEVICE_RESIDENT");
+    if ((variant == 0 || variant == 1) && block_depth <= 5 && !(env && env[0] == '0')) {
+        if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK) dmap = nullptr;
+    }
+}
+
+void BGKOctoMap::ensure_host_mode() {
+    if (dmap != nullptr) set_device_resident(false);
 }
 
 BGKOctoMap::~BGKOctoMap() {
@@ -487,7 +498,8 @@ void BGKOctoMap::set_device_resident(bool on) {
         return;
     }
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::set_device_resident: the map has no GPU context");
-    if (!block_arr.empty()) throw std::runtime_error("BGKOctoMap::set_device_resident: switch modes while the map is empty");
+    if (!block_arr.empty())
+        throw std::runtime_error("BGKOctoMap::set_device_resident: a map that already holds host blocks stays host-orchestrated");
     if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK)
         throw std::runtime_error(std::string("BGKOctoMap::set_device_resident: ") + la3dm_last_error(ctx));
 }
@@ -1133,7 +1145,7 @@ void BGKOctoMap::commit() {
 
 bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                          float free_res, float max_range) {
-    if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::prepare: not available in device-resident mode");
+    ensure_host_mode();
     stats = ScanStats();
     const double t0 = wall();
     if (variant == 3) {
@@ -1149,7 +1161,7 @@ bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3
 }
 
 bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated) {
-    if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::prepare_training_data: not available in device-resident mode");
+    ensure_host_mode();
     stats = ScanStats();
     xy.assign(xyzy, xyzy + 4 * n);
     for (size_t i = 0; i < n; ++i) (xyzy[4 * i + 3] > 0.5f ? stats.n_hits : stats.n_frees)++;
@@ -1173,6 +1185,8 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
         stats.n_train_blocks = ds.n_train_blocks;
         stats.n_test_blocks = ds.n_test_blocks;
         stats.voxel_updates = ds.voxel_updates;
+        stats.train_reads = ds.train_reads;
+        stats.pair_evals = ds.pair_evals;
         stats.t_frontend = ds.t_frontend;
         stats.t_partition = ds.t_partition;
         stats.t_pack = ds.t_pack;
@@ -1199,7 +1213,7 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
 void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: no device context (there is no CPU path)");
-    if (dmap != nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: not available in device-resident mode");
+    ensure_host_mode();
     std::vector<float> flat;
     flat.reserve(cloud.size() * 4);
     for (const GPPointType &p : cloud) flat.insert(flat.end(), {p.first.x(), p.first.y(), p.first.z(), p.second});

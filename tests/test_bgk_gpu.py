@@ -18,8 +18,8 @@ P_TOL = 1e-5
 def _maps(params):
     import la3dm_amd
     from oracle import oracle as O
-    m = la3dm_amd.BGKOctoMap(**params, device=0)
-    o = O.OracleMap(**params)
+    m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)   # this file: host-orchestrated mode
+    o = O.OracleMap(**params)                                                  # (tests/test_devmap_gpu.py: the default)
     return m, o
 
 

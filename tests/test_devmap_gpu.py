@@ -104,7 +104,8 @@ def test_sequence_with_pruning(built, depth):
         m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
         o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
         st, so = m.stats(), o.stats()
-        for k in ("n_hits", "n_frees", "n_bbox_blocks", "n_test_blocks", "voxel_updates"):
+        for k in ("n_hits", "n_frees", "n_bbox_blocks", "n_train_blocks", "n_test_blocks", "voxel_updates", "train_reads",
+                  "pair_evals"):
             assert st[k] == so[k], (i, k, st[k], so[k])
         if i in (1, 2, 6, 12):
             _same(m, o, f"d{depth} scan{i}")
@@ -128,7 +129,8 @@ def test_matches_host_orchestrated_mode(built):
     import la3dm_amd
     params = dict(la3dm_amd.BGK_YAML)
     md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
-    mh = la3dm_amd.BGKOctoMap(**params, device=0)
+    mh = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
+    assert md.is_device_resident() and not mh.is_device_resident()
     for i in (3, 4, 5):
         xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
         md.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
@@ -211,8 +213,13 @@ def test_edge_cases(built):
     m.insert_pointcloud(np.repeat(pts, 5, axis=0), [0.05, 0, 0], 0.1, 0.3, -1.0)   # duplicates + a NaN point
     o.insert_pointcloud(np.repeat(pts, 5, axis=0), [0.05, 0, 0], 0.1, 0.3, -1.0)
     _same(m, o, "dups")
-    with pytest.raises(RuntimeError):
-        m.insert_training_data(np.array([[0, 0, 0, 1]], np.float32))
+    # insert_training_data is host-orchestrated: the call moves the map out of the device-resident mode (one download
+    # of the pool) and keeps the content
+    before = m.leaves()
+    m.insert_training_data(np.zeros((0, 4), np.float32))
+    assert not m.is_device_resident()
+    after = m.leaves()
+    assert all((before[k] == after[k]).all() for k in before)
 
 
 def test_gp_variant(built):
@@ -240,7 +247,7 @@ def test_randomised_small_scenes(built):
                       ell=float(rng.choice([1.5, 2.0, 3.0])) * res, free_thresh=0.3, occupied_thresh=0.7,
                       var_thresh=float(rng.choice([0.05, 100.0])), prior_A=0.001, prior_B=0.001)
         md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
-        mh = la3dm_amd.BGKOctoMap(**params, device=0)
+        mh = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
         o = O.OracleMap(**params)
         for scan in range(3):
             n = int(rng.integers(1, 400))
@@ -274,7 +281,7 @@ def test_float_stepped_candidate_list_repeats_and_gaps(built, x0):
     pts[1] = (np.float32(x0) + np.float32(12.0), 0, 1)
     origin = np.array([x0 + 6.0, 0.0, 1.0], np.float32)
     md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
-    mh = la3dm_amd.BGKOctoMap(**params, device=0)
+    mh = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
     o = O.OracleMap(**params)
     for m in (md, mh, o):
         m.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)

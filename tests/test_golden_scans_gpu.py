@@ -35,8 +35,8 @@ def test_bgk(built, kat, depth, mode):
     import la3dm_amd
     xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
     m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, block_depth=depth), device=0)
-    if mode == "device-resident":
-        m.set_device_resident(True)
+    m.set_device_resident(mode == "device-resident")
+    assert m.is_device_resident() == (mode == "device-resident")
     m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
     _check(f"bgk_d{depth}", m.leaves(), kat)
 

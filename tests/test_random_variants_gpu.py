@@ -56,8 +56,8 @@ def test_gp_random(built):
                       free_thresh=0.3, occupied_thresh=0.7)
         for resident in (False, True):
             m, o = la3dm_amd.GPOctoMap(**params, device=0), O.OracleGPMap(**params)
-            if resident:
-                m.set_device_resident(True)
+            m.set_device_resident(resident)
+            assert m.is_device_resident() == resident
             r2 = np.random.default_rng(1000 + case)
             for scan in range(2):
                 pts, origin = _scene(r2, res)
