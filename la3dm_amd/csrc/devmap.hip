@@ -42,7 +42,6 @@ struct la3dm_devmap {
     uint32_t *tab_val = nullptr;
     // small fixed buffers
     uint32_t *d_cnt = nullptr, *h_cnt = nullptr;  // counters (device / pinned host)
-    unsigned long long *d_acc = nullptr;          // 64-bit work counters (train_reads, pair_evals)
     uint32_t *d_mm = nullptr;
     float *d_bbox = nullptr, *h_bbox = nullptr;
     GridParams *d_gp = nullptr, *h_gp = nullptr;
@@ -256,7 +255,6 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 8) == hipSuccess &&
-              hipMalloc((void **)&dm->d_acc, sizeof(unsigned long long) * 2) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
               hipMalloc((void **)&dm->d_gp, sizeof(GridParams)) == hipSuccess &&
@@ -281,7 +279,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
-    void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp, dm->d_acc};
+    void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (dm->h_cnt) (void)hipHostFree(dm->h_cnt);
@@ -304,7 +302,6 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     const double t0 = wall();
     int rc;
     DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
-    DM_TRY(hipMemsetAsync(dm->d_acc, 0, sizeof(unsigned long long) * 2, st));
 
     // ---------------- f1: front end ----------------
     const float *d_hits = d_xyz;
@@ -541,7 +538,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
                            (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                            (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
         hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
-                           (const uint32_t *)nleaf, n_test, dm->d_acc);
+                           (const uint32_t *)nleaf, n_test, dm->d_cnt);
         if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
         hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
         hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
@@ -596,19 +593,15 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         }
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
         S.voxel_updates += dm->h_cnt[kCntLeaves];
+        S.train_reads = (uint64_t)dm->h_cnt[kCntTrainReads] | ((uint64_t)dm->h_cnt[kCntTrainReads + 1] << 32);
+        S.pair_evals = (uint64_t)dm->h_cnt[kCntPairEvals] | ((uint64_t)dm->h_cnt[kCntPairEvals + 1] << 32);
         if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;
     }
     if (max_occ > 1 && n_test0)
         hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test0, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot0.ptr, n_test0, dm->A, dm->B, dm->S, dm->npb, dm->depth);
     DM_TRY(hipGetLastError());
-    {
-        unsigned long long acc[2] = {0, 0};
-        DM_TRY(hipMemcpyAsync(acc, dm->d_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
-        DM_TRY(hipStreamSynchronize(st));
-        S.train_reads = acc[0];
-        S.pair_evals = acc[1];
-    }
+    if (max_occ > 1) DM_TRY(hipStreamSynchronize(st));  // (single pass: the pass's own read-back was the last sync)
     S.n_blocks = dm->n_blocks;
     S.t_total = wall() - t0;
     if (!getenv("LA3DM_TIMING")) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit

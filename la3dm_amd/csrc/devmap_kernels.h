@@ -45,6 +45,7 @@ enum DevCounter {
     kCntTrainReadsHi = 11,
     kCntBig = 12,        // voxel-grid cells with more than kBigCell points
     kCntTrained = 13,    // blocks with training points that are in the candidate list
+    kCntPairEvals = 14,  // 64-bit (words 14, 15): sum of neighbourhood points x leaves; kCntTrainReads likewise (10, 11)
     kCntWords = 16
 };
 
@@ -595,9 +596,11 @@ __global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ 
 }
 
 // work counters of one pass: sum over test blocks of their neighbourhood size (train_reads) and of
-// neighbourhood size x leaf count (pair_evals); acc[0], acc[1] are 64-bit
+// neighbourhood size x leaf count (pair_evals), accumulated as 64-bit words inside the counter block
 __global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf,
-                                                    uint32_t n_test, unsigned long long *acc) {
+                                                    uint32_t n_test, uint32_t *counters) {
+    unsigned long long *acc_reads = reinterpret_cast<unsigned long long *>(counters + kCntTrainReads);
+    unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long w = 0, pw = 0;
     if (t < n_test) {
@@ -609,8 +612,8 @@ __global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict_
         pw += __shfl_xor(pw, o);
     }
     if ((threadIdx.x & 63) == 0 && (w | pw)) {
-        atomicAdd(&acc[0], w);
-        atomicAdd(&acc[1], pw);
+        atomicAdd(acc_reads, w);
+        atomicAdd(acc_pairs, pw);
     }
 }
 
