@@ -48,7 +48,7 @@ struct la3dm_devmap {
     // arenas (grow only)
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
     Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big, chunk_desc;
-    Arena train, grid, axis_tab;
+    Arena train, grid, axis_tab, m_code;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
     uint32_t n_xy = 0;
@@ -274,7 +274,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     (void)hipSetDevice(dm->ctx->device);
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
-                    &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
+                    &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)
@@ -436,7 +436,9 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     DM_RESERVE(dm->flag, 4ull * npts);
     DM_RESERVE(dm->scan, 4ull * npts);
     uint32_t *m_cnt = (uint32_t *)dm->flag.ptr, *m_off = (uint32_t *)dm->scan.ptr;
-    hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const float4 *)xy, npts, pa, m_cnt);
+    DM_RESERVE(dm->m_code, 16ull * npts);
+    hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const float4 *)xy, npts, pa, m_cnt,
+                       (int4 *)dm->m_code.ptr);
     if ((rc = exclusive_scan(dm, m_cnt, m_off, npts)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, m_off, m_cnt, npts, dm->d_cnt, (int)kCntMembers);
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
@@ -446,8 +448,8 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     DM_RESERVE(dm->v0, 4ull * n_mem);
     DM_RESERVE(dm->v1, 4ull * n_mem);
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
-    hipLaunchKernelGGL(dm_members_write, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const float4 *)xy, npts, pa, m_off, k0, v0,
-                       dm->d_cnt);
+    hipLaunchKernelGGL(dm_members_write, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const int4 *)dm->m_code.ptr, npts, pa, m_off,
+                       k0, v0, dm->d_cnt);
     int bits = 1;
     while ((1ull << bits) < ncid) ++bits;
     if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;

@@ -544,29 +544,33 @@ __device__ __forceinline__ bool grid_cid(const PartArgs &a, int ix, int iy, int 
     return true;
 }
 
-__global__ __launch_bounds__(256) void dm_members_count(const float4 *__restrict__ xy, uint32_t n, PartArgs a, uint32_t *cnt) {
+// per point: its closed-box candidates per axis, packed {first index x, y, z, nx | ny << 2 | nz << 4} (the f64 index
+// arithmetic runs once; the write pass replays the code), and the number of (block, point) pairs
+__global__ __launch_bounds__(256) void dm_members_count(const float4 *__restrict__ xy, uint32_t n, PartArgs a, uint32_t *cnt,
+                                                       int4 *code) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = xy[i];
     const AxisCandD ax = axis_candidates_dev(p.x, a.bs, a.half), ay = axis_candidates_dev(p.y, a.bs, a.half),
                     az = axis_candidates_dev(p.z, a.bs, a.half);
     cnt[i] = (uint32_t)(ax.n * ay.n * az.n);
+    // the candidates of one axis are consecutive indices (a closed box can only be shared with an adjacent block)
+    code[i] = make_int4(ax.n ? ax.idx[0] : 0, ay.n ? ay.idx[0] : 0, az.n ? az.idx[0] : 0, ax.n | (ay.n << 2) | (az.n << 4));
 }
 
-__global__ __launch_bounds__(256) void dm_members_write(const float4 *__restrict__ xy, uint32_t n, PartArgs a,
+__global__ __launch_bounds__(256) void dm_members_write(const int4 *__restrict__ code, uint32_t n, PartArgs a,
                                                        const uint32_t *__restrict__ off, uint32_t *keys, uint32_t *vals,
                                                        uint32_t *counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 p = xy[i];
-    const AxisCandD ax = axis_candidates_dev(p.x, a.bs, a.half), ay = axis_candidates_dev(p.y, a.bs, a.half),
-                    az = axis_candidates_dev(p.z, a.bs, a.half);
+    const int4 cd = code[i];
+    const int nx = cd.w & 3, ny = (cd.w >> 2) & 3, nz = (cd.w >> 4) & 3;
     uint32_t o = off[i];
-    for (int u = 0; u < ax.n; ++u)
-        for (int v = 0; v < ay.n; ++v)
-            for (int w = 0; w < az.n; ++w) {
+    for (int u = 0; u < nx; ++u)
+        for (int v = 0; v < ny; ++v)
+            for (int w = 0; w < nz; ++w) {
                 uint32_t cid = 0;
-                if (!grid_cid(a, ax.idx[u], ay.idx[v], az.idx[w], cid)) {
+                if (!grid_cid(a, cd.x + u, cd.y + v, cd.z + w, cid)) {
                     atomicOr(&counters[kCntError], 1u);  // a point outside the index grid: cannot happen
                     cid = 0;
                 }
