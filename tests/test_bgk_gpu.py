@@ -179,3 +179,27 @@ def test_insert_training_data_ungated(built):
     m.insert_training_data(np.array([[0.0, 0.0, 0.0, 1.0]], np.float32))
     lv = m.leaves()
     assert lv["classified"].all() and lv["A"].size == 7 * 64
+
+
+def test_cpp_example(built):
+    """examples/static_map.cpp drives la3dm::BGKOctoMap from C++ like the reference's static node (construct, insert
+    three scans, get_bbox, begin_leaf..end_leaf): same leaf statistics as the Python binding of the same class"""
+    import os
+    import subprocess
+    import la3dm_amd
+    from conftest import ROOT, GOLDEN
+    exe = os.path.join(ROOT, "examples", "static_map")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "data", "sim_structured"), "sim_structured", "3"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    tok = r.stdout.split()
+    got = {tok[i]: tok[i + 1] for i in (0, 2, 4, 6, 8)}
+    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    lv = m.leaves()
+    assert int(got["leaves"]) == lv["A"].size
+    assert int(got["occupied"]) == int((lv["state"] == 1).sum()) and int(got["free"]) == int((lv["state"] == 0).sum())
+    assert int(got["unknown"]) == int((lv["state"] == 2).sum()) and int(got["blocks"]) == m.block_count()
+    assert "device_resident 1" in r.stdout

@@ -209,6 +209,20 @@ def test_raycaster_against_oracle(built):
     assert np.allclose(d, 0.1, atol=1e-5) and (w["p"][v][:, 1:] == w["p"][v][0, 1:]).all()
 
 
+def test_cpp_example_builds_and_fails_loudly_without_gpu(built):
+    """examples/static_map.cpp (the reference's static node loop against the C++ class) is built by build(); without a
+    HIP device it must stop with an error — there is no CPU inference path to fall back to"""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "static_map")
+    assert os.path.exists(exe)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_bgk_gpu.py::test_cpp_example")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "data", "sim_structured"), "sim_structured", "1"], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+
+
 def test_synthetic_scan_generator(built):
     import la3dm_amd
     xyz, origin = la3dm_amd.synthetic_scan(5000)
