@@ -259,6 +259,11 @@ int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nod
 /* keys[n_blocks]; A, B, S [n_blocks * nodes_per_block], node order = depth-major (8^d - 1)/7 + index;
  * S: bits 0-2 State (FREE 0, OCCUPIED 1, UNKNOWN 2, PRUNED 3), bit 7 = classified */
 int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, uint8_t *S);
+/* BGKOctoMap::search(x, y, z) (include/bgkoctomap/bgkoctomap.h:315-319) for n query points (host pointers, packed xyz),
+ * answered from the device pool without refreshing a host mirror: exists[i] = the block exists; A/B/state = the
+ * finest-layer node that holds the point (a default node when the block is missing). */
+int la3dm_devmap_search_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint8_t *exists, float *A, float *B,
+                             uint8_t *state);
 /* training set (x, y, z, label) of the last scan, for parity tests; *n = number of points */
 int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint32_t *n);
 /* test hook (host pointers, n entries): out_fast = the closed-form sum of m[i] copies of x[i] onto s[i] that

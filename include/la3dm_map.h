@@ -93,6 +93,9 @@ uint64_t la3dm_map_dump_leaves(const la3dm_map *m, int64_t *block_key, int32_t *
                                float *A, float *B, uint8_t *state, uint8_t *classified, uint64_t cap);
 /* search(x, y, z): returns 1 if the block exists */
 int la3dm_map_search(const la3dm_map *m, float x, float y, float z, float *A, float *B, uint8_t *state);
+/* search for n points at once (packed xyz); device-resident maps answer from the device pool without a mirror refresh */
+int la3dm_map_search_many(const la3dm_map *m, const float *xyz, uint64_t n, uint8_t *exists, float *A, float *B,
+                          uint8_t *state);
 int la3dm_map_get_bbox(const la3dm_map *m, float *lim_min3, float *lim_max3);
 /* Block(center).get_index(p) / get_node / get_point (reference bgkblock.cpp:131-150) */
 void la3dm_map_block_grid(const la3dm_map *m, const float *center3, const float *p3, int32_t *idx3, int32_t *node_key,

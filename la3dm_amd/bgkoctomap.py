@@ -111,6 +111,16 @@ class BGKOctoMap:
         e = self._M.la3dm_map_search(self._h, x, y, z, C.byref(a), C.byref(b), C.byref(s))
         return bool(e), a.value, b.value, s.value
 
+    def search_many(self, points):
+        """search(x, y, z) for an (n, 3) array of points -> dict(exists, A, B, state); a device-resident map answers
+        from the device pool (no host mirror refresh)"""
+        q = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        n = q.shape[0]
+        out = dict(exists=np.zeros(n, np.uint8), A=np.zeros(n, np.float32), B=np.zeros(n, np.float32),
+                   state=np.zeros(n, np.uint8))
+        self._chk(self._M.la3dm_map_search_many(self._h, q, n, *[out[k].ctypes.data for k in ("exists", "A", "B", "state")]))
+        return out
+
     def raycast(self, start, end, cap=4096):
         """RayCaster(map, start, end) driven to its end: dict of p, block_key, node_key, valid, A, B, state per step."""
         s3, e3 = np.ascontiguousarray(start, np.float32), np.ascontiguousarray(end, np.float32)

@@ -48,7 +48,7 @@ struct la3dm_devmap {
     // arenas (grow only)
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
     Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big, chunk_desc;
-    Arena train, grid, axis_tab, m_code;
+    Arena train, grid, axis_tab, m_code, q_out;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
     uint32_t n_xy = 0;
@@ -274,7 +274,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     (void)hipSetDevice(dm->ctx->device);
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
-                    &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
+                    &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->q_out, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
     for (Arena *a : all)
@@ -646,6 +646,37 @@ int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, u
     DM_TRY(hipMemcpyAsync(A, dm->A, 4 * nn, hipMemcpyDeviceToHost, st));
     DM_TRY(hipMemcpyAsync(B, dm->B, 4 * nn, hipMemcpyDeviceToHost, st));
     DM_TRY(hipMemcpyAsync(S, dm->S, nn, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_search_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint8_t *exists, float *A, float *B,
+                             uint8_t *state) {
+    if (!dm || (n && (!xyz || !exists || !A || !B || !state))) return LA3DM_ERR_ARG;
+    if (n == 0) return LA3DM_OK;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    if (dm->n_blocks == 0) {  // empty map: every query misses
+        for (uint32_t i = 0; i < n; ++i) {
+            exists[i] = 0;
+            A[i] = dm->init_A;
+            B[i] = dm->init_B;
+            state[i] = kStateUnknown;
+        }
+        return LA3DM_OK;
+    }
+    DM_RESERVE(dm->cloud, 12ull * n);
+    DM_RESERVE(dm->q_out, 10ull * n + 16);
+    float *qA = (float *)dm->q_out.ptr, *qB = qA + n;
+    uint8_t *qe = (uint8_t *)(qB + n), *qs = qe + n;
+    DM_TRY(hipMemcpyAsync(dm->cloud.ptr, xyz, 12ull * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dm_search, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float *)dm->cloud.ptr, n, dm->tab_key, dm->tab_val,
+                       dm->tab_cap - 1, dm->A, dm->B, dm->S, dm->npb, dm->depth, dm->block_size, dm->ctx->p.resolution,
+                       dm->init_A, dm->init_B, qe, qA, qB, qs);
+    DM_TRY(hipMemcpyAsync(A, qA, 4ull * n, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(B, qB, 4ull * n, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(exists, qe, n, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(state, qs, n, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
     return LA3DM_OK;
 }

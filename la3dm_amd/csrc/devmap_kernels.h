@@ -777,6 +777,46 @@ __global__ __launch_bounds__(256) void dm_table_rebuild(const long long *__restr
     }
 }
 
+// BGKOctoMap::search(point) for a batch of query points, straight from the device pool (bgkoctomap.cpp:554-567 ->
+// Block::search, bgkblock.cpp:152-160): block by hash of the point, finest-layer voxel by the clamped cell index
+// (child bit 4 = +x, 2 = +y, 1 = +z per level); a missing block answers with a default node.
+__global__ __launch_bounds__(256) void dm_search(const float *__restrict__ q, uint32_t n, const long long *__restrict__ tab_key,
+                                                const uint32_t *__restrict__ tab_val, uint32_t mask, const float *__restrict__ A,
+                                                const float *__restrict__ B, const uint8_t *__restrict__ S, uint32_t npb,
+                                                uint32_t block_depth, float bs, float resolution, float a0, float b0,
+                                                uint8_t *exists, float *oA, float *oB, uint8_t *ostate) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = q[3 * (size_t)i], y = q[3 * (size_t)i + 1], z = q[3 * (size_t)i + 2];
+    const long long ix = axis_index(x, bs), iy = axis_index(y, bs), iz = axis_index(z, bs);
+    const long long key = (ix << 40) | (iy << 20) | iz;
+    uint32_t h = hash_key64(key, mask);
+    long long cur;
+    while ((cur = tab_key[h]) != key && cur != kEmptyKey) h = (h + 1) & mask;
+    if (cur != key) {
+        exists[i] = 0;
+        oA[i] = a0;
+        oB[i] = b0;
+        ostate[i] = kStateUnknown;
+        return;
+    }
+    const int cells = 1 << (block_depth - 1);
+    const float c[3] = {axis_center(ix, bs), axis_center(iy, bs), axis_center(iz, bs)}, v[3] = {x, y, z};
+    int ci[3];
+    for (int a = 0; a < 3; ++a) {
+        const int t = (int)floorf((v[a] - c[a]) / resolution + cells / 2.0f);
+        ci[a] = max(0, min(t, cells - 1));
+    }
+    uint32_t index = 0;
+    for (int level = (int)block_depth - 2; level >= 0; --level)
+        index = index * 8u + (uint32_t)((((ci[0] >> level) & 1) << 2) | (((ci[1] >> level) & 1) << 1) | ((ci[2] >> level) & 1));
+    const size_t node = (size_t)tab_val[h] * npb + dm_layer_base(block_depth - 1) + index;
+    exists[i] = 1;
+    oA[i] = A[node];
+    oB[i] = B[node];
+    ostate[i] = S[node] & 7u;
+}
+
 // default nodes of new blocks: Occupancy() = {prior A, prior B, UNKNOWN, not classified}
 __global__ __launch_bounds__(256) void dm_pool_init(float *A, float *B, uint8_t *S, size_t first, size_t count, float a0, float b0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -157,7 +157,9 @@ bool OcTree::search(OcTreeHashKey key) const {
     return node_arr != nullptr && node_arr[d] != nullptr && node_arr[d][i].get_state() != State::PRUNED;
 }
 
-OcTreeNode &OcTree::operator[](OcTreeHashKey key) const { return node_arr[key >> 16][key & 0xFFFF]; }
+// Nodes stay addressable after their layer was retired by prune() (the reference frees the layer and would read
+// freed memory here): the slab keeps them, with state PRUNED.
+OcTreeNode &OcTree::operator[](OcTreeHashKey key) const { return slab[layer_base((unsigned)(key >> 16)) + (key & 0xFFFF)]; }
 
 // Bottom-up collapse of sibling groups that share one non-UNKNOWN state; the parent becomes a
 // copy of child 0 (not an average) and a layer with nothing left to collapse is retired.
@@ -297,7 +299,7 @@ OcTreeNode &Block::search(point3f p) const {
     unsigned index = 0;
     for (int level = max_depth - 2; level >= 0; --level)
         index = index * 8 + ((((ix >> level) & 1) << 2) | (((iy >> level) & 1) << 1) | ((iz >> level) & 1));
-    return node_arr[max_depth - 1][index];
+    return slab[layer_base(max_depth - 1) + index];  // also valid when prune() retired the finest layer
 }
 
 void Block::get_index(const point3f &p, unsigned short &x, unsigned short &y, unsigned short &z) const {
@@ -544,6 +546,22 @@ Block *BGKOctoMap::search(BlockHashKey key) const {
 OcTreeNode BGKOctoMap::search(point3f p) const {
     Block *b = search(block_to_hash_key(p));
     return b == nullptr ? OcTreeNode() : OcTreeNode(b->search(p));
+}
+
+void BGKOctoMap::search_many(const float *xyz, size_t n, uint8_t *exists, float *A, float *B, uint8_t *state) const {
+    if (dmap != nullptr) {
+        if (la3dm_devmap_search_host(dmap, xyz, (uint32_t)n, exists, A, B, state) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::search_many: ") + la3dm_last_error(ctx));
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const point3f p(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        exists[i] = search(block_to_hash_key(p)) != nullptr;
+        const OcTreeNode nd = search(p);
+        A[i] = nd.m_A;
+        B[i] = nd.m_B;
+        state[i] = (uint8_t)nd.get_state();
+    }
 }
 
 void BGKOctoMap::get_bbox(point3f &lim_min, point3f &lim_max) const {

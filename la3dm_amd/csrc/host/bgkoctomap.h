@@ -381,6 +381,9 @@ public:
     OcTreeNode search(point3f p) const;
     OcTreeNode search(float x, float y, float z) const { return search(point3f(x, y, z)); }
     Block *search(BlockHashKey key) const;
+    /// search(x, y, z) for n points at once (packed xyz).  In device-resident mode the answers come straight from the
+    /// device pool (no mirror refresh); otherwise from the host blocks.  exists[i] = the block exists.
+    void search_many(const float *xyz, size_t n, uint8_t *exists, float *A, float *B, uint8_t *state) const;
     size_t block_count() const {
         sync_mirror();
         return block_arr.size();

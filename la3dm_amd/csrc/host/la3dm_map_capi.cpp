@@ -313,6 +313,11 @@ uint64_t la3dm_map_raycast(const la3dm_map *m, const float *s3, const float *e3,
     return n;
 }
 
+int la3dm_map_search_many(const la3dm_map *m, const float *xyz, uint64_t n, uint8_t *exists, float *A, float *B,
+                          uint8_t *state) {
+    GUARD(m->map->search_many(xyz, (size_t)n, exists, A, B, state); return 0;)
+}
+
 int la3dm_map_get_bbox(const la3dm_map *m, float *lo, float *hi) {
     point3f a, b;
     m->map->get_bbox(a, b);

@@ -168,6 +168,34 @@ def test_raycaster_on_device_resident_map(built):
             assert (a[k][v] == b[k][v]).all(), k
 
 
+def test_batched_search_on_the_device_pool(built):
+    """search() for many points answered from the device pool == the host map's search (incl. pruned regions, voxel
+    faces and missing blocks), before and after the mirror exists"""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML)
+    md = la3dm_amd.BGKOctoMap(**params, device=0)
+    mh = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
+    assert md.search_many(np.zeros((3, 3), np.float32))["exists"].sum() == 0          # empty map
+    for i in (1, 2, 3, 4):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        md.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        mh.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    rng = np.random.default_rng(8)
+    q = np.concatenate([rng.uniform(-3, 12, (20000, 3)), np.round(rng.uniform(-2, 10, (5000, 3)) * 10) / 10,
+                        [[500, 500, 500]]]).astype(np.float32)
+    a, b = md.search_many(q), mh.search_many(q)
+    assert md.is_device_resident()
+    for k in ("exists", "state"):
+        assert (a[k] == b[k]).all(), k
+    for k in ("A", "B"):
+        assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), k
+    assert 0 < int(a["exists"].sum()) < q.shape[0]
+    for p in q[:50]:
+        e, A, B, s = mh.search(*map(float, p))
+        j = int(np.nonzero((q == p).all(1))[0][0])
+        assert bool(a["exists"][j]) == e and a["A"][j] == np.float32(A) and a["state"][j] == s
+
+
 def test_synthetic_scan(built):
     import la3dm_amd
     xyz, origin = la3dm_amd.synthetic_scan(30000)
