@@ -470,10 +470,13 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     DM_RESERVE(dm->grid, 4ull * ncid);
     DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
     hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
-    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
-    if (dm->h_cnt[kCntError]) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
-    const uint32_t n_geo = dm->h_cnt[kCntGeo];
-    S.n_train_blocks = dm->h_cnt[kCntTrained];
+    // the segment count is only needed on the host by the GP launches; the BGK path reads it (and the error flag)
+    // together with the test-block count of the first pass
+    uint32_t n_geo = n_mem;
+    if (ctx->p.variant == 1) {
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        n_geo = dm->h_cnt[kCntGeo];
+    }
     const double t2 = wall();
     S.t_partition = t2 - t1;
 
@@ -493,6 +496,10 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
                            (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        if (dm->h_cnt[kCntError])
+            return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
+        if (ctx->p.variant != 1) n_geo = dm->h_cnt[kCntGeo];
+        S.n_train_blocks = dm->h_cnt[kCntTrained];
         const uint32_t n_test = dm->h_cnt[kCntTest];
         if (n_test == 0) continue;
         S.n_test_blocks += n_test;
@@ -517,14 +524,10 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const long long *)dm->t_blockkey.ptr,
                            dm->d_cnt, dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key,
                            (uint32_t *)dm->t_slot.ptr);
-        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
-        const uint32_t nb_new = dm->h_cnt[kCntBlocks];
-        if (nb_new > dm->n_blocks) {
-            const size_t first = (size_t)dm->n_blocks * dm->npb, count = (size_t)(nb_new - dm->n_blocks) * dm->npb;
-            hipLaunchKernelGGL(dm_pool_init, dim3(cdiv(count, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S, first, count,
-                               dm->init_A, dm->init_B);
-            dm->n_blocks = nb_new;
-        }
+        // default nodes for the blocks this launch created: slots [old count, new count); the new count stays on
+        // the device (read back with the pass's other counters), the launch covers the worst case of n_test new blocks
+        hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)n_test * dm->npb, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S,
+                           dm->n_blocks, (const uint32_t *)(dm->d_cnt + kCntBlocks), dm->npb, dm->init_A, dm->init_B);
         // pack: leaves in LeafIterator order
         DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
         DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
@@ -594,6 +597,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
             n_test0 = n_test;
         }
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        dm->n_blocks = dm->h_cnt[kCntBlocks];
         S.voxel_updates += dm->h_cnt[kCntLeaves];
         S.train_reads = (uint64_t)dm->h_cnt[kCntTrainReads] | ((uint64_t)dm->h_cnt[kCntTrainReads + 1] << 32);
         S.pair_evals = (uint64_t)dm->h_cnt[kCntPairEvals] | ((uint64_t)dm->h_cnt[kCntPairEvals + 1] << 32);

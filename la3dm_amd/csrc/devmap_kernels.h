@@ -817,10 +817,14 @@ __global__ __launch_bounds__(256) void dm_search(const float *__restrict__ q, ui
     ostate[i] = S[node] & 7u;
 }
 
-// default nodes of new blocks: Occupancy() = {prior A, prior B, UNKNOWN, not classified}
-__global__ __launch_bounds__(256) void dm_pool_init(float *A, float *B, uint8_t *S, size_t first, size_t count, float a0, float b0) {
+// default nodes of the blocks created by the last dm_table_insert — slots [old_blocks, *new_blocks):
+// Occupancy() = {prior A, prior B, UNKNOWN, not classified}
+__global__ __launch_bounds__(256) void dm_pool_init(float *A, float *B, uint8_t *S, uint32_t old_blocks,
+                                                   const uint32_t *__restrict__ new_blocks, uint32_t npb, float a0, float b0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t count = (size_t)(*new_blocks - old_blocks) * npb;
     if (i >= count) return;
+    const size_t first = (size_t)old_blocks * npb;
     A[first + i] = a0;
     B[first + i] = b0;
     S[first + i] = kStateUnknown;
