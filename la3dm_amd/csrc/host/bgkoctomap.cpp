@@ -14,6 +14,7 @@
 #include "bgkoctomap.h"
 
 #include <algorithm>
+#include <parallel/algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,7 @@
 namespace la3dm {
 
 namespace {
+constexpr int kHostThreads = 16;  // OpenMP team of the host-side loops (start-up and spin-wait cost grow with the team)
 double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline uint32_t layer_base(unsigned depth) { return 0x249249u & ((1u << (3u * depth)) - 1u); }
 }  // namespace
@@ -962,8 +964,13 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
                 for (int c = 0; c < az.n; ++c)
                     members.push_back(Member{(ax.idx[a] << 40) | (ay.idx[b] << 20) | az.idx[c], (uint32_t)i});
     }
-    // group by block; inside a block keep ascending point index
-    std::stable_sort(members.begin(), members.end(), [](const Member &a, const Member &b) { return a.key < b.key; });
+    // group by block; inside a block keep ascending point index.  (libstdc++ parallel mode, a small team: the sort is
+    // the largest single item of the host partition; a stable sort has one result whatever the thread count.)
+    if (members.size() > 100000)
+        __gnu_parallel::stable_sort(members.begin(), members.end(), [](const Member &a, const Member &b) { return a.key < b.key; },
+                                    __gnu_parallel::default_parallel_tag(kHostThreads));
+    else
+        std::stable_sort(members.begin(), members.end(), [](const Member &a, const Member &b) { return a.key < b.key; });
 
     // "geo" blocks = every block that geometrically holds points (what an R-tree query sees);
     // trained blocks = geo blocks that are also in the candidate list.
@@ -1067,9 +1074,9 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
         ps.alpha.resize(nl);
         ps.beta.resize(nl);
         ps.state.assign(nl, 0);
-        size_t l = 0;
-        for (size_t b = 0; b < ps.blocks.size(); ++b)
-            for (; l < ps.leaf_off[b + 1]; ++l) {
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+        for (long b = 0; b < (long)ps.blocks.size(); ++b)
+            for (size_t l = ps.leaf_off[b]; l < ps.leaf_off[b + 1]; ++l) {
                 const OcTreeNode &nd = (*ps.blocks[b])[(OcTreeHashKey)ps.leaf_key[l]];
                 ps.alpha[l] = nd.m_A;
                 ps.beta[l] = nd.m_B;
@@ -1114,9 +1121,9 @@ la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
 
 void BGKOctoMap::refresh_pass(size_t p) {
     Pass &ps = passes[p];
-    size_t l = 0;
-    for (size_t b = 0; b < ps.blocks.size(); ++b)
-        for (; l < ps.leaf_off[b + 1]; ++l) {
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+    for (long b = 0; b < (long)ps.blocks.size(); ++b)
+        for (size_t l = ps.leaf_off[b]; l < ps.leaf_off[b + 1]; ++l) {
             const OcTreeNode &nd = (*ps.blocks[b])[(OcTreeHashKey)ps.leaf_key[l]];
             ps.alpha[l] = nd.m_A;
             ps.beta[l] = nd.m_B;
@@ -1125,9 +1132,9 @@ void BGKOctoMap::refresh_pass(size_t p) {
 
 void BGKOctoMap::write_nodes(size_t p) {
     Pass &ps = passes[p];
-    size_t l = 0;
-    for (size_t b = 0; b < ps.blocks.size(); ++b)
-        for (; l < ps.leaf_off[b + 1]; ++l) {
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+    for (long b = 0; b < (long)ps.blocks.size(); ++b)
+        for (size_t l = ps.leaf_off[b]; l < ps.leaf_off[b + 1]; ++l) {
             const uint8_t st = ps.state[l];
             if (!(st & LA3DM_LEAF_UPDATED)) continue;
             OcTreeNode &nd = (*ps.blocks[b])[(OcTreeHashKey)ps.leaf_key[l]];
@@ -1154,9 +1161,11 @@ void BGKOctoMap::commit() {
     }
     const double t1 = wall();
     stats.t_commit = t1 - t0;
-    for (BlockHashKey k : prune_list) {
-        auto it = block_arr.find(k);
-        if (it != block_arr.end()) it->second->prune();
+    // the blocks of pass 0 are the distinct test blocks (prune_list only repeats some of them; prune is idempotent)
+    if (!passes.empty()) {
+        std::vector<Block *> &blks = passes[0].blocks;
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+        for (long b = 0; b < (long)blks.size(); ++b) blks[b]->prune();
     }
     stats.t_prune = wall() - t1;
 }
