@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <parallel/algorithm>
+#include <omp.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -668,12 +669,16 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
         // zero pages on demand (calloc): only the touched part of the grid is ever paged in
         Acc *acc = static_cast<Acc *>(std::calloc(ncell, sizeof(Acc)));
         if (acc == nullptr) throw std::bad_alloc();
-        std::vector<uint32_t> touched;
-        touched.reserve(std::min(n, ncell));
-        // pass 1 (streaming): cell of every point; pass 2: accumulate with the target prefetched a few
-        // points ahead (the cloud arrives in ray order, i.e. every access is a cache miss)
+        // pass 1 (streaming, parallel): cell of every point.  pass 2: every thread of a small team owns a contiguous
+        // range of cells and walks the whole cell list in cloud order, accumulating only its own cells — each cell
+        // still sums its points in cloud order (one owner), and the owners' touched lists, each sorted, concatenate
+        // to the ascending cell order.  The accumulation target is prefetched a few points ahead (the cloud arrives in
+        // ray order: every access is a cache miss).
         std::vector<uint32_t> cells(n);
-        for (size_t i = 0; i < n; ++i) {
+        const int team = n > 200000 ? kHostThreads : 1;
+#pragma omp parallel for num_threads(team) schedule(static)
+        for (long ii = 0; ii < (long)n; ++ii) {
+            const size_t i = (size_t)ii;
             const float *p = in + 3 * i;
             if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) {
                 cells[i] = 0xFFFFFFFFu;
@@ -684,28 +689,43 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
             const int c2 = (int)(std::floor(p[2] * inv) - (float)lo[2]);
             cells[i] = (uint32_t)(c0 + c1 * m1 + c2 * m2);
         }
-        constexpr size_t kAhead = 24;
-        for (size_t i = 0; i < n; ++i) {
-            if (i + kAhead < n && cells[i + kAhead] != 0xFFFFFFFFu) __builtin_prefetch(&acc[cells[i + kAhead]], 1, 1);
-            const uint32_t cell = cells[i];
-            if (cell == 0xFFFFFFFFu) continue;
-            const float *p = in + 3 * i;
-            Acc &a = acc[cell];
-            if (a.n == 0) touched.push_back(cell);
-            a.x += p[0];
-            a.y += p[1];
-            a.z += p[2];
-            ++a.n;
+        std::vector<std::vector<uint32_t>> touched(team);
+        std::vector<size_t> first(team + 1, 0);
+#pragma omp parallel num_threads(team)
+        {
+            const int t = omp_get_thread_num(), nt = omp_get_num_threads();  // the runtime may grant fewer threads
+            const uint32_t c_lo = (uint32_t)((uint64_t)ncell * t / nt), c_hi = (uint32_t)((uint64_t)ncell * (t + 1) / nt);
+            std::vector<uint32_t> &mine = touched[t];
+            constexpr size_t kAhead = 24;
+            for (size_t i = 0; i < n; ++i) {
+                if (i + kAhead < n) {
+                    const uint32_t ca = cells[i + kAhead];
+                    if (ca >= c_lo && ca < c_hi) __builtin_prefetch(&acc[ca], 1, 1);
+                }
+                const uint32_t cell = cells[i];
+                if (cell < c_lo || cell >= c_hi) continue;  // (0xFFFFFFFF = non-finite point: owned by nobody)
+                const float *p = in + 3 * i;
+                Acc &a = acc[cell];
+                if (a.n == 0) mine.push_back(cell);
+                a.x += p[0];
+                a.y += p[1];
+                a.z += p[2];
+                ++a.n;
+            }
+            std::sort(mine.begin(), mine.end());
         }
-        std::sort(touched.begin(), touched.end());
-        out.resize(3 * touched.size());
-        size_t o = 0;
-        for (uint32_t cell : touched) {
-            const Acc &a = acc[cell];
-            const float cnt = (float)a.n;
-            out[o++] = a.x / cnt;
-            out[o++] = a.y / cnt;
-            out[o++] = a.z / cnt;
+        for (int t = 0; t < team; ++t) first[t + 1] = first[t] + touched[t].size();
+        out.resize(3 * first[team]);
+#pragma omp parallel for num_threads(team) schedule(static)
+        for (int t = 0; t < team; ++t) {
+            size_t o = 3 * first[t];
+            for (uint32_t cell : touched[t]) {
+                const Acc &a = acc[cell];
+                const float cnt = (float)a.n;
+                out[o++] = a.x / cnt;
+                out[o++] = a.y / cnt;
+                out[o++] = a.z / cnt;
+            }
         }
         std::free(acc);
         return;
