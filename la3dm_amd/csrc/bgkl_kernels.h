@@ -35,23 +35,78 @@ struct BgklArgs {
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
 };
 
-__global__ __launch_bounds__(kWave) void bgkl_predict_fuse_kernel(BgklArgs a) {
-    const int lane = threadIdx.x;
-    const uint32_t task = blockIdx.x;
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
+// Split path for the tiles around the sensor.  Every beam crosses the sensor's block, so a 200 k-ray scan hands a
+// handful of tiles ~10^5 rows each and the row-serial kernel below becomes one long straggler wave.  Only the two
+// fp32 running sums have to be serial; the distance test and the kernel evaluation do not.  A tile whose seven
+// neighbours hold more than `threshold` rows is cut into items of kLItemRows rows:
+//   bgkl_split_mark    per tile: row total, item count, first item (atomic bump; item order across tiles is free)
+//   bgkl_split_items   item descriptors {tile, neighbour, row range}
+//   bgkl_split_eval<0> one wave per item: distance test, per row {hit mask, label, running hit count}
+//   bgkl_split_bdesc   per 64-row batch: where its values live
+//   bgkl_split_eval<1> same rows again: k(d / ell) of the hit lanes, written in (row, lane) order
+//   bgkl_split_fuse    one wave per split tile replays the rows in order: values staged through LDS one batch
+//                      ahead, every lane adds its own hits (or +0) to (ybar, kbar) -> same sums, bit for bit
+constexpr int kLItemRows = 256;
+constexpr int kLBatch = 64;
+constexpr int kLBatches = kLItemRows / kLBatch;
+constexpr int kLPre = 16;  // values per lane fetched one batch ahead (the rest of a batch is loaded when it starts)
+
+struct BgklSplit {
+    uint32_t *task_item;          // [2 * n_tasks] {first item or 0xFFFFFFFF, item count}
+    uint32_t *counters;           // [0] items, [2..3] hit values (64-bit)
+    uint4 *item_desc;             // {tile, neighbour slot, row begin, row end}
+    uint4 *rowrec;                // [items * kLItemRows] {mask lo, mask hi, label, hits before the row inside its batch}
+    uint32_t *batch_off;          // [items * kLBatches] hits before the batch inside its item
+    unsigned long long *item_val; // [items] first value of the item
+    uint32_t *item_hits;          // [items]
+    uint4 *bdesc;                 // [items * kLBatches] {value index lo, hi, values, rows | slot << 16}
+    float *vals;
+    uint32_t threshold;
+};
+
+// leaf of this lane: false when the tile holds no leaves
+__device__ __forceinline__ bool bgkl_leaf(const BgklArgs &a, uint32_t task, int lane, uint32_t &blk, uint32_t &li, bool &active,
+                                          float &px, float &py, float &pz) {
+    blk = task >> a.tpb_shift;
     const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
     const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
     const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
+    if (l0 >= l1) return false;
     const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
+    active = (uint32_t)lane < nl;
+    li = l0 + (active ? lane : 0);
     const uint32_t key = a.leaf_key[li];
     const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float px = off4.x + a.blk_center[3 * blk + 0], py = off4.y + a.blk_center[3 * blk + 1],
-                pz = off4.z + a.blk_center[3 * blk + 2];  // Block::get_loc
+    px = off4.x + a.blk_center[3 * blk + 0];  // Block::get_loc
+    py = off4.y + a.blk_center[3 * blk + 1];
+    pz = off4.z + a.blk_center[3 * blk + 2];
+    return true;
+}
+
+__device__ __forceinline__ void bgkl_store(const BgklArgs &a, uint32_t li, bool active, bool updated, float A, float B) {
+    if (!active) return;
+    if (updated) {
+        a.alpha[li] = A;
+        a.beta[li] = B;
+        BgkArgs c;  // thresholds for classify()
+        c.free_thresh = a.free_thresh;
+        c.occupied_thresh = a.occupied_thresh;
+        c.var_thresh = a.var_thresh;
+        a.state[li] = (uint8_t)(classify(A, B, c) | 0x80u);
+    } else {
+        a.state[li] = 0;
+    }
+}
+
+__global__ __launch_bounds__(kWave) void bgkl_predict_fuse_kernel(BgklArgs a, const uint32_t *__restrict__ task_item) {
+    const int lane = threadIdx.x;
+    const uint32_t task = blockIdx.x;
+    if (task >= a.n_tasks) return;
+    if (task_item && task_item[2 * task] != 0xFFFFFFFFu) return;  // split tile
+    uint32_t blk, li;
+    bool active;
+    float px, py, pz;
+    if (!bgkl_leaf(a, task, lane, blk, li, active, px, py, pz)) return;
     float A = a.alpha[li], B = a.beta[li];
     bool updated = false;
 
@@ -78,19 +133,197 @@ __global__ __launch_bounds__(kWave) void bgkl_predict_fuse_kernel(BgklArgs a) {
             updated = true;
         }
     }
-    if (active) {
-        if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            BgkArgs c;  // thresholds for classify()
-            c.free_thresh = a.free_thresh;
-            c.occupied_thresh = a.occupied_thresh;
-            c.var_thresh = a.var_thresh;
-            a.state[li] = (uint8_t)(classify(A, B, c) | 0x80u);
-        } else {
-            a.state[li] = 0;
+    bgkl_store(a, li, active, updated, A, B);
+}
+
+__global__ void bgkl_split_mark(BgklArgs a, BgklSplit s) {
+    const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift, tile = task & ((1u << a.tpb_shift) - 1u);
+    uint32_t first = 0xFFFFFFFFu, n = 0;
+    if (a.leaf_off[blk] + tile * kWave < a.leaf_off[blk + 1]) {
+        unsigned long long total = 0;
+        uint32_t items = 0;
+        for (int b = 0; b < 7; ++b) {
+            const int32_t tb = a.nbr[7 * blk + b];
+            if (tb < 0) continue;
+            const uint32_t c = a.row_off[tb + 1] - a.row_off[tb];
+            total += c;
+            items += (c + kLItemRows - 1) / kLItemRows;
+        }
+        if (total > (unsigned long long)s.threshold) {
+            first = atomicAdd(&s.counters[0], items);
+            n = items;
         }
     }
+    s.task_item[2 * task] = first;
+    s.task_item[2 * task + 1] = n;
+}
+
+__global__ void bgkl_split_items(BgklArgs a, BgklSplit s) {
+    const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= a.n_tasks) return;
+    uint32_t it = s.task_item[2 * task];
+    if (it == 0xFFFFFFFFu) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    for (int b = 0; b < 7; ++b) {
+        const int32_t tb = a.nbr[7 * blk + b];
+        if (tb < 0) continue;
+        const uint32_t r0 = a.row_off[tb], r1 = a.row_off[tb + 1];
+        for (uint32_t r = r0; r < r1; r += kLItemRows) s.item_desc[it++] = make_uint4(task, (uint32_t)b, r, min(r + (uint32_t)kLItemRows, r1));
+    }
+}
+
+template <bool kWrite>
+__global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s) {
+    const int lane = threadIdx.x;
+    const uint32_t it = blockIdx.x;
+    const uint4 dsc = s.item_desc[it];
+    uint32_t blk, li;
+    bool active;
+    float px, py, pz;
+    if (!bgkl_leaf(a, dsc.x, lane, blk, li, active, px, py, pz)) return;  // (split tiles always hold leaves)
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(dsc.z), nrows = __builtin_amdgcn_readfirstlane(dsc.w) - r0;
+    uint4 *rec = s.rowrec + (size_t)it * kLItemRows;
+    const unsigned long long vb = kWrite ? s.item_val[it] : 0ull;
+    uint32_t off = 0, boff = 0;
+    uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t j = 0; j < nrows; ++j) {
+        const size_t row = (size_t)r0 + j;
+        const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * row);
+        const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
+        if (kWrite) {
+            const uint2 mm = *reinterpret_cast<const uint2 *>(rec + j);  // wave-uniform
+            const unsigned long long m = ((unsigned long long)mm.y << 32) | mm.x;
+            if (m == 0ull) continue;
+            const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+            if ((m >> lane) & 1ull) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mm.y, __builtin_amdgcn_mbcnt_lo(mm.x, 0));
+                s.vals[vb + off + rank] = cov_sparse<true, 0>(d / a.ell, a.sf2);
+            }
+            off += (uint32_t)__popcll(m);
+        } else {
+            const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+            const unsigned long long m = __ballot(active && d < a.ell);
+            if ((j & 63u) == 0u) {
+                boff = off;
+                if (lane == 0) s.batch_off[it * kLBatches + (j >> 6)] = off;
+            }
+            if ((uint32_t)lane == (j & 63u)) mine = make_uint4((uint32_t)m, (uint32_t)(m >> 32), __float_as_uint(p1.z), off - boff);
+            off += (uint32_t)__popcll(m);
+            if ((j & 63u) == 63u || j + 1 == nrows) {
+                if ((uint32_t)lane <= (j & 63u)) rec[(j & ~63u) + lane] = mine;
+            }
+        }
+    }
+    if (!kWrite && lane == 0) {
+        s.item_hits[it] = off;
+        s.item_val[it] = atomicAdd(reinterpret_cast<unsigned long long *>(s.counters + 2), (unsigned long long)off);
+    }
+}
+
+__global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_items * kLBatches) return;
+    const uint32_t it = q / kLBatches, k = q % kLBatches;
+    const uint4 dsc = s.item_desc[it];
+    const uint32_t nrows = dsc.w - dsc.z;
+    uint4 d = make_uint4(0u, 0u, 0u, 0u);
+    if (k * kLBatch < nrows) {
+        const uint32_t nr = min(nrows - k * kLBatch, (uint32_t)kLBatch);
+        const uint32_t o0 = s.batch_off[q];
+        const uint32_t o1 = ((k + 1) * kLBatch < nrows) ? s.batch_off[q + 1] : s.item_hits[it];
+        const unsigned long long v = s.item_val[it] + o0;
+        d = make_uint4((uint32_t)v, (uint32_t)(v >> 32), o1 - o0, nr | (dsc.y << 16));
+    }
+    s.bdesc[q] = d;
+}
+
+__global__ __launch_bounds__(kWave) void bgkl_split_fuse(BgklArgs a, BgklSplit s) {
+    __shared__ uint4 s_rec[kLBatch];
+    __shared__ float s_val[kLBatch * kWave + kWave];
+    const int lane = threadIdx.x;
+    const uint32_t task = blockIdx.x;
+    if (task >= a.n_tasks) return;
+    const uint32_t first = s.task_item[2 * task];
+    if (first == 0xFFFFFFFFu) return;
+    const uint32_t q0 = first * kLBatches, q1 = (first + s.task_item[2 * task + 1]) * kLBatches;
+    uint32_t blk, li;
+    bool active;
+    float px, py, pz;
+    if (!bgkl_leaf(a, task, lane, blk, li, active, px, py, pz)) return;
+    float A = a.alpha[li], B = a.beta[li];
+    bool updated = false;
+    float ybar = 0.0f, kbar = 0.0f;
+    int cur_b = -1;
+    auto flush = [&]() {
+        if (kbar > 0.001f) {  // bgkloctomap.cpp:226-227
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+        ybar = 0.0f;
+        kbar = 0.0f;
+    };
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rec1;
+    float pre1[kLPre];
+    auto issue = [&](const uint4 &D, uint32_t q) {  // loads of batch q, consumed one trip later
+        const uint32_t nr = D.w & 0xFFFFu, span = D.z;
+        const unsigned long long v = ((unsigned long long)D.y << 32) | D.x;
+        rec1 = (uint32_t)lane < nr ? s.rowrec[(size_t)q * kLBatch + lane] : zero4;
+#pragma unroll
+        for (int u = 0; u < kLPre; ++u) pre1[u] = (uint32_t)(lane + kWave * u) < span ? s.vals[v + lane + kWave * u] : 0.0f;
+    };
+    uint4 D1 = s.bdesc[q0];
+    uint4 D2 = q0 + 1 < q1 ? s.bdesc[q0 + 1] : zero4;
+    issue(D1, q0);
+    const uint32_t lsh = (uint32_t)lane & 31u;
+    for (uint32_t q = q0; q < q1; ++q) {
+        const uint4 D = D1;
+        D1 = D2;
+        D2 = q + 2 < q1 ? s.bdesc[q + 2] : zero4;
+        const uint32_t nr = __builtin_amdgcn_readfirstlane(D.w & 0xFFFFu), span = __builtin_amdgcn_readfirstlane(D.z);
+        const int b = (int)__builtin_amdgcn_readfirstlane(D.w >> 16);
+        if (nr) {
+            const unsigned long long v = ((unsigned long long)D.y << 32) | D.x;
+            s_rec[lane] = rec1;
+#pragma unroll
+            for (int u = 0; u < kLPre; ++u)
+                if ((uint32_t)(lane + kWave * u) < span) s_val[lane + kWave * u] = pre1[u];
+            for (uint32_t i = lane + kWave * kLPre; i < span; i += kWave) s_val[i] = s.vals[v + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (q + 1 < q1) issue(D1, q + 1);
+        if (nr) {
+            if (b != cur_b) {
+                if (cur_b >= 0) flush();
+                cur_b = b;
+            }
+            for (uint32_t j0 = 0; j0 < nr; j0 += 8) {
+                float v[8], t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint4 r = s_rec[j0 + u];  // broadcast read; rows past nr hold a zero mask
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(r.y, __builtin_amdgcn_mbcnt_lo(r.x, 0));
+                    const uint32_t msk = (uint32_t)((int32_t)((lane < 32 ? r.x : r.y) << (31u - lsh)) >> 31);
+                    const float raw = s_val[r.w + rank];
+                    v[u] = __uint_as_float(__float_as_uint(raw) & msk);
+                    t[u] = __uint_as_float(__float_as_uint(raw * __uint_as_float(r.z)) & msk);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ybar += t[u];
+                    kbar += v[u];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (cur_b >= 0) flush();
+    bgkl_store(a, li, active, updated, A, B);
 }
 
 }  // namespace la3dm_dev

@@ -25,12 +25,14 @@ struct la3dm_ctx {
     int opt_time_kernel = 0;
     int opt_waves = 1;  // waves per workgroup (variant 3)
     int opt_remap = 2;
+    int opt_l_split_rows = 4096;  // BGK-L: tiles with more rows than this are split over waves (< 0: never)
     int opt_ablate = 0;  // profiling only: 1 skip kernel evaluation, 2 skip the candidate tests
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
     Arena pts_scaled, nbr_range;
     Arena gp_loff, gp_totals, gp_L, gp_alpha, gp_v;
+    Arena l_task_item, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_val, l_item_hits, l_bdesc, l_vals;
     Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;
     // staging (host-pointer path)
     Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,

@@ -87,3 +87,24 @@ def test_edge_cases(built):
     m.insert_pointcloud(np.repeat(pts, 3, axis=0), [0, 0, 0.5], -1.0, 0.2, -1.0)
     o.insert_pointcloud(np.repeat(pts, 3, axis=0), [0, 0, 0.5], -1.0, 0.2, -1.0)
     _same(m, o, "dups")
+
+
+@pytest.mark.parametrize("rows,depth", [(0, 3), (0, 4), (300, 3), (70, 4)])
+def test_split_tiles(built, rows, depth):
+    """tiles with more than `bgkl_split_rows` rows run the split path (distance test / kernel evaluation spread over
+    waves, ordered replay of the sums): same bits as the row-serial kernel and the oracle, whatever the threshold"""
+    import la3dm_amd
+    params = dict(la3dm_amd.L_YAML, block_depth=depth)
+    m, o = _maps(params)
+    m.set_option("bgkl_split_rows", rows)
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        _same(m, o, f"split rows>{rows} d{depth} scan{i}")
+    xyz, origin = la3dm_amd.synthetic_scan(6000)                 # every beam crosses the sensor's block
+    m.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    _same(m, o, f"split rows>{rows} d{depth} synthetic")
+    m.insert_pointcloud(np.zeros((0, 3), np.float32), origin, 0.1, 0.3, 8.0)
+    _same(m, o, "empty after split")
