@@ -128,7 +128,8 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
 /* Options: "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial,
  * 2 = OCML; "bgk_variant" is accepted and ignored (one implementation is built; the
  * measurement history of the earlier variants is in DESIGN.md); "waves_per_wg" 1/2/4, "remap" 0-2, "ablate" (profiling);
- * "time_kernel" see la3dm_kernel_times. */
+ * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
+ * rows than this take the split path (default 4096, < 0 = never; results do not depend on it). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */
