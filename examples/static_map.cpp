@@ -125,6 +125,19 @@ int main(int argc, char **argv) {
                     (unsigned long long)n, (unsigned long long)occ, (unsigned long long)fre, (unsigned long long)unk,
                     map.block_count(), lim_min.x(), lim_min.y(), lim_min.z(), lim_max.x(), lim_max.y(), lim_max.z(),
                     map.is_device_resident() ? 1 : 0, (unsigned long long)h);
+        // the node's publish step (bgkoctomap_static_node.cpp:101-136): cube lists per marker level, occupied cells
+        // coloured by height, free cells by probability — scanned on the GPU when the map is device resident
+        la3dm::BGKOctoMap::Cells occupied, free_cells;
+        map.export_cells(la3dm::State::OCCUPIED, true, 0.0f, 0.0f, occupied);
+        map.export_cells(la3dm::State::FREE, true, 0.0f, 0.0f, free_cells);
+        for (const auto *c : {&occupied, &free_cells}) {
+            size_t per_level[10] = {0};
+            for (int32_t l : c->level) ++per_level[l < 10 ? l : 9];
+            std::printf("%s cubes %zu by level:", c == &occupied ? "occupied" : "free", c->level.size());
+            for (int l = 0; l < 10; ++l)
+                if (per_level[l]) std::printf(" [%d] %zu", l, per_level[l]);
+            std::printf("\n");
+        }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -265,6 +265,18 @@ int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, u
  * finest-layer node that holds the point (a default node when the block is missing). */
 int la3dm_devmap_search_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint8_t *exists, float *A, float *B,
                              uint8_t *state);
+/* Leaf export = the publish loop of the static node (src/bgkoctomap/bgkoctomap_static_node.cpp:101-136) with the
+ * cube-list bookkeeping of MarkerArrayPub (include/common/markerarray_pub.h:104-147) minus ROS, run on the pool:
+ * state 1 = OCCUPIED leaves coloured by height (heightMapColor when min_z < max_z, else the marker default),
+ * state 0 = FREE leaves coloured by probability.  original_size 0 expands a collapsed leaf into the
+ * base-resolution cells of get_pruned_locs (bgkoctomap.h:269-287).  cells/rgba: 4 floats per cell {x, y, z, size} /
+ * {r, g, b, a}; level = (int) log2(size / resolution) = index of the CUBE_LIST marker.  Order: pool blocks, leaves
+ * in LeafIterator order.  Call with cells = rgba = level = NULL to get *count, then with buffers (host pointers). */
+int la3dm_devmap_export_cells(la3dm_devmap *dm, int state, int original_size, float min_z, float max_z, float *cells,
+                              float *rgba, int32_t *level, uint64_t cap, uint64_t *count);
+/* smallest / largest block index per axis (the 20-bit fields of BlockHashKey): get_bbox
+ * (src/bgkoctomap/bgkoctomap.cpp:368-381) without a download */
+int la3dm_devmap_key_bounds(la3dm_devmap *dm, int32_t lo[3], int32_t hi[3]);
 /* training set (x, y, z, label) of the last scan, for parity tests; *n = number of points */
 int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint32_t *n);
 /* test hook (host pointers, n entries): out_fast = the closed-form sum of m[i] copies of x[i] onto s[i] that

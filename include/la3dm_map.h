@@ -106,6 +106,15 @@ void la3dm_map_block_grid(const la3dm_map *m, const float *center3, const float 
 uint64_t la3dm_map_raycast(const la3dm_map *m, const float *start3, const float *end3, float *p_xyz, int64_t *block_key,
                            int32_t *node_key, uint8_t *valid, float *A, float *B, uint8_t *state, uint64_t cap);
 
+/* Cube lists of the map: the publish loop of the static node (reference bgkoctomap_static_node.cpp:101-136) with
+ * MarkerArrayPub::insert_point3d / heightMapColor (markerarray_pub.h:21-147) minus ROS.  state 1 = OCCUPIED leaves
+ * coloured by height between min_z and max_z (min_z == max_z: the map's bbox), 0 = FREE leaves coloured by
+ * probability; original_size 0 expands collapsed leaves into base-resolution cells (get_pruned_locs).  cells / rgba:
+ * 4 floats per cell {x, y, z, size} / {r, g, b, a}; level = (int) log2(size / resolution).  Device-resident maps are
+ * scanned on the GPU.  Call with NULL buffers for *count, then with buffers of that capacity. */
+int la3dm_map_export_cells(const la3dm_map *m, int state, int original_size, float min_z, float max_z, float *cells,
+                           float *rgba, int32_t *level, uint64_t cap, uint64_t *count);
+
 /* host bookkeeping primitives (known-answer tests) */
 int64_t la3dm_map_block_to_hash_key(const la3dm_map *m, float x, float y, float z);
 void la3dm_map_hash_key_to_block(const la3dm_map *m, int64_t key, float *out3);

@@ -132,6 +132,23 @@ class BGKOctoMap:
         n = min(int(n), cap)
         return {k: v[:n] for k, v in out.items()}
 
+    def export_cells(self, state="occupied", original_size=True, min_z=0.0, max_z=0.0):
+        """Cube lists of the map (the static node's publish loop + MarkerArrayPub::insert_point3d / heightMapColor,
+        reference bgkoctomap_static_node.cpp:101-136, markerarray_pub.h:21-147, minus ROS): dict of cells (n, 4)
+        {x, y, z, size}, rgba (n, 4), level (n,) = (int) log2(size / resolution).  state "occupied": coloured by
+        height between min_z and max_z (equal: the map's bbox); "free": coloured by probability.  original_size
+        False expands collapsed leaves (get_pruned_locs).  Device-resident maps are scanned on the GPU."""
+        st = {"occupied": 1, "free": 0}[state]
+        n = C.c_uint64(0)
+        if self._M.la3dm_map_export_cells(self._h, st, int(bool(original_size)), min_z, max_z, None, None, None, 0, C.byref(n)) != 0:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        k = int(n.value)
+        out = dict(cells=np.zeros((k, 4), np.float32), rgba=np.zeros((k, 4), np.float32), level=np.zeros(k, np.int32))
+        if k and self._M.la3dm_map_export_cells(self._h, st, int(bool(original_size)), min_z, max_z, out["cells"].ctypes.data,
+                                                out["rgba"].ctypes.data, out["level"].ctypes.data, k, C.byref(n)) != 0:
+            raise RuntimeError(self._M.la3dm_map_last_error().decode())
+        return out
+
     def leaves(self):
         """All leaves (begin_leaf()..end_leaf()), blocks by ascending hash key, leaves in
         LeafIterator order: dict of block_key, node_key, loc, size, A, B, state, classified."""

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -681,6 +682,86 @@ int la3dm_devmap_search_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uin
     DM_TRY(hipMemcpyAsync(B, qB, 4ull * n, hipMemcpyDeviceToHost, st));
     DM_TRY(hipMemcpyAsync(exists, qe, n, hipMemcpyDeviceToHost, st));
     DM_TRY(hipMemcpyAsync(state, qs, n, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_key_bounds(la3dm_devmap *dm, int32_t lo[3], int32_t hi[3]) {
+    if (!dm || !lo || !hi) return LA3DM_ERR_ARG;
+    if (dm->n_blocks == 0) return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_key_bounds: the map holds no blocks");
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    DM_RESERVE(dm->q_out, 64);
+    uint32_t *mm = (uint32_t *)dm->q_out.ptr;
+    DM_TRY(hipMemsetAsync(mm, 0xFF, 12, st));
+    DM_TRY(hipMemsetAsync(mm + 3, 0, 12, st));
+    hipLaunchKernelGGL(dm_key_bounds, dim3(std::min(cdiv(dm->n_blocks, 256), 64u)), dim3(256), 0, st, dm->blk_key, dm->n_blocks, mm);
+    uint32_t h[6];
+    DM_TRY(hipMemcpyAsync(h, mm, 24, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = (int32_t)h[a];
+        hi[a] = (int32_t)h[3 + a];
+    }
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_export_cells(la3dm_devmap *dm, int state, int original_size, float min_z, float max_z, float *cells,
+                              float *rgba, int32_t *level, uint64_t cap, uint64_t *count) {
+    if (!dm || !count || (state != 0 && state != 1)) return LA3DM_ERR_ARG;
+    *count = 0;
+    if (dm->n_blocks == 0) return LA3DM_OK;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    const la3dm_params &p = dm->ctx->p;
+    ExportArgs a;
+    memset(&a, 0, sizeof(a));
+    a.blk_key = dm->blk_key;
+    a.S = dm->S;
+    a.A = dm->A;
+    a.B = dm->B;
+    a.lut = dm->ctx->d_lut;
+    a.n_blocks = dm->n_blocks;
+    a.npb = dm->npb;
+    a.depth = dm->depth;
+    a.want_state = state;
+    a.original = original_size ? 1 : 0;
+    a.variant = p.variant;
+    a.coloured = min_z < max_z ? 1 : 0;
+    a.block_size = dm->block_size;
+    a.resolution = p.resolution;
+    a.min_z = min_z;
+    a.max_z = max_z;
+    a.gp_l = p.l;
+    a.gp_max_ivar = p.max_ivar;
+    for (uint32_t d = 0; d < dm->depth && d < 8; ++d) {
+        a.size_of_depth[d] = float(dm->block_size / pow(2, d));                       // Block::get_size, bgkblock.h:69-73
+        a.level_of_depth[d] = (int)log2(a.size_of_depth[d] / p.resolution);            // markerarray_pub.h:112-114
+    }
+    DM_RESERVE(dm->c_scan, 8ull * (dm->n_blocks + 1));
+    uint32_t *cnt = (uint32_t *)dm->c_scan.ptr, *off = cnt + dm->n_blocks + 1;
+    a.blk_cnt = cnt;
+    a.blk_off = off;
+    DM_TRY(hipMemsetAsync(cnt + dm->n_blocks, 0, 4, st));
+    hipLaunchKernelGGL(dm_export<false>, dim3(cdiv(dm->n_blocks, 4)), dim3(256), 0, st, a);
+    int rc = exclusive_scan(dm, cnt, off, dm->n_blocks + 1);
+    if (rc != LA3DM_OK) return rc;
+    uint32_t total = 0;
+    DM_TRY(hipMemcpyAsync(&total, off + dm->n_blocks, 4, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    *count = total;
+    if (!cells && !rgba && !level) return LA3DM_OK;  // size query
+    if (!cells || !rgba || !level || cap < total) return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_export_cells: buffers too small");
+    if (total == 0) return LA3DM_OK;
+    DM_RESERVE(dm->q_out, 36ull * total + 64);
+    a.cells = (float4 *)dm->q_out.ptr;
+    a.rgba = a.cells + total;
+    a.level = (int32_t *)(a.rgba + total);
+    hipLaunchKernelGGL(dm_export<true>, dim3(cdiv(dm->n_blocks, 4)), dim3(256), 0, st, a);
+    DM_TRY(hipGetLastError());
+    DM_TRY(hipMemcpyAsync(cells, a.cells, 16ull * total, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(rgba, a.rgba, 16ull * total, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(level, a.level, 4ull * total, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
     return LA3DM_OK;
 }

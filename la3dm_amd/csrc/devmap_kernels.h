@@ -948,4 +948,168 @@ __global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slo
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Leaf export (row f3): the publish loop of the static node, src/bgkoctomap/bgkoctomap_static_node.cpp:101-136,
+// with the cube-list bookkeeping of MarkerArrayPub::insert_point3d and heightMapColor
+// (include/common/markerarray_pub.h:21-147), minus ROS: every leaf in `want_state` becomes a cell
+// {x, y, z, size}, a colour and a marker level; with original_size == 0 a collapsed leaf is expanded into the
+// base-resolution cells of get_pruned_locs (bgkoctomap.h:269-287: float-stepped loops, kept verbatim).
+// One wave per pool block, cells in LeafIterator order; kEmit = false counts, true writes at blk_off[slot].
+// ---------------------------------------------------------------------------------------------------------
+struct ExportArgs {
+    const long long *blk_key;
+    const uint8_t *S;
+    const float *A;
+    const float *B;
+    const float4 *lut;
+    uint32_t *blk_cnt;         // [n_blocks + 1] (count pass; the last entry stays 0)
+    const uint32_t *blk_off;   // exclusive scan of blk_cnt
+    float4 *cells;
+    float4 *rgba;
+    int32_t *level;
+    uint32_t n_blocks, npb, depth;
+    int want_state, original, variant, coloured;
+    float block_size, resolution, min_z, max_z, gp_l, gp_max_ivar;
+    float size_of_depth[8];    // Block::get_size per layer (host expression)
+    int level_of_depth[8];     // (int) log2(size / resolution)
+};
+
+__device__ inline void height_map_color(double h, float4 &c) {  // markerarray_pub.h:21-76 (s = v = 1)
+    h -= floor(h);
+    h *= 6;
+    const int i = (int)floor(h);
+    double f = h - i;
+    if (!(i & 1)) f = 1 - f;
+    const double v = 1.0, m = 0.0, n = 1.0 - f;
+    double r, g, b;
+    switch (i) {
+    case 6:
+    case 0: r = v; g = n; b = m; break;
+    case 1: r = n; g = v; b = m; break;
+    case 2: r = m; g = v; b = n; break;
+    case 3: r = m; g = n; b = v; break;
+    case 4: r = n; g = m; b = v; break;
+    case 5: r = v; g = m; b = n; break;
+    default: r = 1; g = 0.5; b = 0.5; break;
+    }
+    c = make_float4((float)r, (float)g, (float)b, 1.0f);
+}
+
+__device__ inline float4 export_colour(const ExportArgs &a, float z, float A, float B) {
+    if (a.want_state == 1) {  // insert_point3d(x, y, z, min_z, max_z, size): coloured by height when min_z < max_z
+        if (!a.coloured) return make_float4(0.0f, 0.0f, 1.0f, 1.0f);  // the marker's default colour
+        const double h = (1.0 - (double)fminf(fmaxf((z - a.min_z) / (a.max_z - a.min_z), 0.0f), 1.0f)) * 0.8;
+        float4 c;
+        height_map_color(h, c);
+        return c;
+    }
+    float prob;  // insert_point3d(..., prob)
+    if (a.variant == 1) prob = 1.0f / (1.0f + (float)exp((double)(-a.gp_l * A / a.gp_max_ivar)));
+    else prob = A / (A + B);
+    if (prob < 0.5f) return make_float4(0.8f, 0.8f, 0.8f, 1.0f);
+    float4 c;
+    height_map_color(fmin(2.0 - 2.0 * (double)prob, 0.6), c);
+    return c;
+}
+
+template <bool kEmit>
+__global__ __launch_bounds__(256) void dm_export(ExportArgs a) {
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (slot >= a.n_blocks) return;
+    const size_t base = (size_t)slot * a.npb;
+    const uint8_t *Sb = a.S + base;
+    const long long key = a.blk_key[slot];
+    const float cx = axis_center(key >> 40, a.block_size), cy = axis_center((key >> 20) & 0xFFFFF, a.block_size),
+                cz = axis_center(key & 0xFFFFF, a.block_size);
+    const uint32_t dl = a.depth - 1, ncell = 1u << (3 * dl);
+    uint32_t out = kEmit ? a.blk_off[slot] : 0u;
+    for (uint32_t top = ncell; top > 0; top -= min(top, 64u)) {
+        const bool in = (uint32_t)lane < top;
+        const uint32_t c = in ? top - 1u - lane : 0u;  // lane order = descending cell index = LeafIterator order
+        uint32_t d, i;
+        covering_leaf(Sb, dl, c, d, i);
+        const uint32_t span = 3u * (dl - d);
+        const uint32_t node = dm_layer_base(d) + i;
+        const bool head = in && c == (((i + 1u) << span) - 1u) && (int)(Sb[node] & 7u) == a.want_state;
+        // cells of this leaf
+        float lx = 0.f, ly = 0.f, lz = 0.f, x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
+        uint32_t nx = 1, ny = 1, nz = 1;
+        const float size = a.size_of_depth[d];
+        if (head) {
+            const float4 o = a.lut[node];
+            lx = o.x + cx;
+            ly = o.y + cy;
+            lz = o.z + cz;
+            if (!a.original) {
+                x0 = (float)((double)lx - (double)size * 0.5 + (double)a.resolution * 0.5);
+                y0 = (float)((double)ly - (double)size * 0.5 + (double)a.resolution * 0.5);
+                z0 = (float)((double)lz - (double)size * 0.5 + (double)a.resolution * 0.5);
+                x1 = (float)((double)lx + (double)size * 0.5);
+                y1 = (float)((double)ly + (double)size * 0.5);
+                z1 = (float)((double)lz + (double)size * 0.5);
+                nx = ny = nz = 0;
+                for (float x = x0; x < x1; x += a.resolution) ++nx;
+                for (float y = y0; y < y1; y += a.resolution) ++ny;
+                for (float z = z0; z < z1; z += a.resolution) ++nz;
+            }
+        }
+        const uint32_t mine = head ? nx * ny * nz : 0u;
+        uint32_t incl = mine;  // inclusive prefix over the lanes
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t up = __shfl_up(incl, sft, 64);
+            if (lane >= sft) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (kEmit && mine) {
+            uint32_t w = out + incl - mine;
+            const float A = a.A[base + node], B = a.B[base + node];
+            if (a.original) {
+                a.cells[w] = make_float4(lx, ly, lz, size);
+                a.rgba[w] = export_colour(a, lz, A, B);
+                a.level[w] = a.level_of_depth[d];
+            } else {
+                for (float x = x0; x < x1; x += a.resolution)
+                    for (float y = y0; y < y1; y += a.resolution)
+                        for (float z = z0; z < z1; z += a.resolution) {
+                            a.cells[w] = make_float4(x, y, z, a.resolution);
+                            a.rgba[w] = export_colour(a, z, A, B);
+                            a.level[w] = 0;  // (int) log2(resolution / resolution)
+                            ++w;
+                        }
+            }
+        }
+        out += total;
+    }
+    if (!kEmit && lane == 0) a.blk_cnt[slot] = out;
+}
+
+// index box of the pool's blocks (get_bbox without a download): mm[0..2] = min, mm[3..5] = max of the 20-bit indices
+__global__ void dm_key_bounds(const long long *__restrict__ blk_key, uint32_t n, uint32_t *mm) {
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const long long k = blk_key[i];
+        const uint32_t v[3] = {(uint32_t)(k >> 40) & 0xFFFFFu, (uint32_t)(k >> 20) & 0xFFFFFu, (uint32_t)k & 0xFFFFFu};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], v[a]);
+            hi[a] = max(hi[a], v[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            lo[a] = min(lo[a], (uint32_t)__shfl_down(lo[a], sft, 64));
+            hi[a] = max(hi[a], (uint32_t)__shfl_down(hi[a], sft, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&mm[a], lo[a]);
+            atomicMax(&mm[3 + a], hi[a]);
+        }
+    }
+}
+
 }  // namespace la3dm_dev

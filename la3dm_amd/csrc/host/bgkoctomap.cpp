@@ -567,7 +567,107 @@ void BGKOctoMap::search_many(const float *xyz, size_t n, uint8_t *exists, float 
     }
 }
 
+namespace {
+// heightMapColor, include/common/markerarray_pub.h:21-76 (s = v = 1)
+void height_map_color(double h, float *rgba) {
+    h -= floor(h);
+    h *= 6;
+    const int i = (int)floor(h);
+    double f = h - i;
+    if (!(i & 1)) f = 1 - f;
+    const double v = 1.0, m = 0.0, n = 1.0 - f;
+    double r, g, b;
+    switch (i) {
+    case 6:
+    case 0: r = v; g = n; b = m; break;
+    case 1: r = n; g = v; b = m; break;
+    case 2: r = m; g = v; b = n; break;
+    case 3: r = m; g = n; b = v; break;
+    case 4: r = n; g = m; b = v; break;
+    case 5: r = v; g = m; b = n; break;
+    default: r = 1; g = 0.5; b = 0.5; break;
+    }
+    rgba[0] = (float)r;
+    rgba[1] = (float)g;
+    rgba[2] = (float)b;
+    rgba[3] = 1.0f;
+}
+}  // namespace
+
+size_t BGKOctoMap::export_cells(State state, bool original_size, float min_z, float max_z, Cells &out) const {
+    if (state != State::OCCUPIED && state != State::FREE)
+        throw std::runtime_error("BGKOctoMap::export_cells: state must be OCCUPIED or FREE");
+    out.xyz_size.clear();
+    out.rgba.clear();
+    out.level.clear();
+    if (min_z == max_z) {  // bgkoctomap_static_node.cpp:103-108
+        point3f lo, hi;
+        get_bbox(lo, hi);
+        min_z = lo.z();
+        max_z = hi.z();
+    }
+    if (dmap != nullptr) {
+        uint64_t n = 0;
+        if (la3dm_devmap_export_cells(dmap, (int)state, original_size ? 1 : 0, min_z, max_z, nullptr, nullptr, nullptr, 0, &n) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::export_cells: ") + la3dm_last_error(ctx));
+        out.xyz_size.resize(4 * n);
+        out.rgba.resize(4 * n);
+        out.level.resize(n);
+        if (n && la3dm_devmap_export_cells(dmap, (int)state, original_size ? 1 : 0, min_z, max_z, out.xyz_size.data(), out.rgba.data(),
+                                           out.level.data(), n, &n) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::export_cells: ") + la3dm_last_error(ctx));
+        return (size_t)n;
+    }
+    auto push = [&](float x, float y, float z, float size, const OcTreeNode &nd) {
+        out.xyz_size.insert(out.xyz_size.end(), {x, y, z, size});
+        out.level.push_back(size > 0 ? (int)log2(size / resolution) : 0);  // markerarray_pub.h:110-114
+        float c[4] = {0.0f, 0.0f, 1.0f, 1.0f};                             // the marker's default colour
+        if (state == State::OCCUPIED) {
+            if (min_z < max_z) {
+                const double h = (1.0 - std::min(std::max((z - min_z) / (max_z - min_z), 0.0f), 1.0f)) * 0.8;
+                height_map_color(h, c);
+            }
+        } else {
+            const float prob = nd.get_prob();
+            if (prob < 0.5f) {
+                c[0] = c[1] = c[2] = 0.8f;
+            } else {
+                height_map_color(std::min(2.0 - 2.0 * prob, 0.6), c);
+            }
+        }
+        out.rgba.insert(out.rgba.end(), c, c + 4);
+    };
+    for (auto it = begin_leaf(); it != end_leaf(); ++it) {
+        if (it.get_node().get_state() != state) continue;
+        if (original_size) {
+            const point3f p = it.get_loc();
+            push(p.x(), p.y(), p.z(), it.get_size(), it.get_node());
+        } else {
+            for (const point3f &p : it.get_pruned_locs()) push(p.x(), p.y(), p.z(), resolution, it.get_node());
+        }
+    }
+    return out.level.size();
+}
+
 void BGKOctoMap::get_bbox(point3f &lim_min, point3f &lim_max) const {
+    if (dmap != nullptr) {  // index box of the pool's keys; centre = (index - 524288) * size is monotone in the index
+        lim_min = point3f(0, 0, 0);
+        lim_max = point3f(0, 0, 0);
+        uint32_t nb = 0, npb = 0;
+        if (la3dm_devmap_block_count(dmap, &nb, &npb) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::get_bbox: ") + la3dm_last_error(ctx));
+        if (nb == 0) return;
+        int32_t lo[3], hi[3];
+        if (la3dm_devmap_key_bounds(dmap, lo, hi) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::get_bbox: ") + la3dm_last_error(ctx));
+        const BlockHashKey klo = ((int64_t)lo[0] << 40) | ((int64_t)lo[1] << 20) | (int64_t)lo[2];
+        const BlockHashKey khi = ((int64_t)hi[0] << 40) | ((int64_t)hi[1] << 20) | (int64_t)hi[2];
+        lim_min = hash_key_to_block(klo);
+        lim_max = hash_key_to_block(khi);
+        lim_min -= point3f(block_size, block_size, block_size) * 0.5;
+        lim_max += point3f(block_size, block_size, block_size) * 0.5;
+        return;
+    }
     sync_mirror();
     lim_min = point3f(0, 0, 0);
     lim_max = point3f(0, 0, 0);

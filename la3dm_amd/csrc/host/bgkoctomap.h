@@ -390,6 +390,19 @@ public:
     }
     int get_variant() const { return variant; }
 
+    /// Cube lists of the map = the publish loop of the static node (src/bgkoctomap/bgkoctomap_static_node.cpp:101-136)
+    /// with MarkerArrayPub::insert_point3d / heightMapColor (include/common/markerarray_pub.h:21-147) minus ROS.
+    /// `state` OCCUPIED: cells coloured by height between min_z and max_z (min_z == max_z: the map's bbox, as the node
+    /// does); FREE: coloured by probability.  original_size false expands collapsed leaves (get_pruned_locs).
+    /// level[i] = (int) log2(size / resolution) = the CUBE_LIST marker the cell goes to.  In device-resident mode the
+    /// pool is scanned on the GPU (no mirror refresh).  Returns the number of cells.
+    struct Cells {
+        std::vector<float> xyz_size;  // 4 per cell
+        std::vector<float> rgba;      // 4 per cell
+        std::vector<int32_t> level;
+    };
+    size_t export_cells(State state, bool original_size, float min_z, float max_z, Cells &out) const;
+
 protected:
     void get_training_data(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                            float free_resolution, float max_range);

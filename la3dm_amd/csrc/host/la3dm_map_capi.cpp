@@ -313,6 +313,21 @@ uint64_t la3dm_map_raycast(const la3dm_map *m, const float *s3, const float *e3,
     return n;
 }
 
+int la3dm_map_export_cells(const la3dm_map *m, int state, int original_size, float min_z, float max_z, float *cells,
+                           float *rgba, int32_t *level, uint64_t cap, uint64_t *count) {
+    GUARD(
+        if (count == nullptr || (state != 0 && state != 1)) throw std::runtime_error("la3dm_map_export_cells: bad argument");
+        BGKOctoMap::Cells c;
+        const size_t n = m->map->export_cells(state == 1 ? la3dm::State::OCCUPIED : la3dm::State::FREE, original_size != 0, min_z, max_z, c);
+        *count = n;
+        if (cells == nullptr && rgba == nullptr && level == nullptr) return 0;
+        if (cells == nullptr || rgba == nullptr || level == nullptr || cap < n) throw std::runtime_error("la3dm_map_export_cells: buffers too small");
+        std::copy(c.xyz_size.begin(), c.xyz_size.end(), cells);
+        std::copy(c.rgba.begin(), c.rgba.end(), rgba);
+        std::copy(c.level.begin(), c.level.end(), level);
+        return 0;)
+}
+
 int la3dm_map_search_many(const la3dm_map *m, const float *xyz, uint64_t n, uint8_t *exists, float *A, float *B,
                           uint8_t *state) {
     GUARD(m->map->search_many(xyz, (size_t)n, exists, A, B, state); return 0;)

@@ -1095,6 +1095,115 @@ int64_t orc_dump_leaves(void *h, int64_t *block_key, int32_t *node_key, float *l
     return n;
 }
 
+// ---- leaf export: src/bgkoctomap/bgkoctomap_static_node.cpp:101-136 (the publish loop), get_bbox
+// src/bgkoctomap/bgkoctomap.cpp:368-381, MarkerArrayPub::insert_point3d + heightMapColor
+// include/common/markerarray_pub.h:21-147, get_pruned_locs include/bgkoctomap/bgkoctomap.h:269-287.
+// Blocks in ascending hash key (the reference walks an unordered_map; a cube list has no order), leaves in
+// LeafIterator order, expanded cells in the loop order x, y, z.
+static void height_map_color(double h, float *rgba) {  // markerarray_pub.h:21-76
+    double s = 1.0, v = 1.0;
+    h -= floor(h);
+    h *= 6;
+    int i;
+    double m, n, f;
+    i = (int)floor(h);
+    f = h - i;
+    if (!(i & 1)) f = 1 - f;  // if i is even
+    m = v * (1 - s);
+    n = v * (1 - s * f);
+    double r, g, b;
+    switch (i) {
+    case 6:
+    case 0: r = v; g = n; b = m; break;
+    case 1: r = n; g = v; b = m; break;
+    case 2: r = m; g = v; b = n; break;
+    case 3: r = m; g = n; b = v; break;
+    case 4: r = n; g = m; b = v; break;
+    case 5: r = v; g = m; b = n; break;
+    default: r = 1; g = 0.5; b = 0.5; break;
+    }
+    rgba[0] = (float)r; rgba[1] = (float)g; rgba[2] = (float)b; rgba[3] = 1.0f;
+}
+void orc_height_map_color(double h, float *rgba) { height_map_color(h, rgba); }
+
+void orc_get_bbox(void *h, float *lo3, float *hi3) {
+    Map *m = (Map *)h;
+    for (int a = 0; a < 3; ++a) lo3[a] = hi3[a] = 0.0f;
+    bool first = true;
+    for (auto &kv : m->blocks) {
+        const V3 &c = kv.second->center;
+        const float v[3] = {c.x, c.y, c.z};
+        for (int a = 0; a < 3; ++a) {
+            if (first || v[a] < lo3[a]) lo3[a] = v[a];
+            if (first || v[a] > hi3[a]) hi3[a] = v[a];
+        }
+        first = false;
+    }
+    if (!first) {
+        const float half = m->p.block_size * 0.5f;  // point3f(block_size, ...) * 0.5  (point3f::operator*(float))
+        for (int a = 0; a < 3; ++a) { lo3[a] -= half; hi3[a] += half; }
+    }
+}
+
+int64_t orc_export_cells(void *h, int state, int original_size, float min_z, float max_z, float *cells, float *rgba,
+                         int32_t *level, int64_t cap) {
+    Map *m = (Map *)h;
+    if (min_z == max_z) {  // static node :103-108
+        float lo[3], hi[3];
+        orc_get_bbox(h, lo, hi);
+        min_z = lo[2];
+        max_z = hi[2];
+    }
+    std::vector<int64_t> bk;
+    for (auto &kv : m->blocks) bk.push_back(kv.first);
+    std::sort(bk.begin(), bk.end());
+    int64_t n = 0;
+    auto insert = [&](float x, float y, float z, float size, const Node &nd) {
+        if (n < cap) {
+            cells[4 * n] = x; cells[4 * n + 1] = y; cells[4 * n + 2] = z; cells[4 * n + 3] = size;
+            int depth = 0;
+            if (size > 0) depth = (int)log2(size / m->p.resolution);
+            level[n] = depth;
+            float *c = rgba + 4 * n;
+            c[0] = 0.0f; c[1] = 0.0f; c[2] = 1.0f; c[3] = 1.0f;  // marker default (ctor, :96-101)
+            if (state == ST_OCCUPIED) {
+                if (min_z < max_z) {
+                    double hh = (1.0 - std::min(std::max((z - min_z) / (max_z - min_z), 0.0f), 1.0f)) * 0.8;
+                    height_map_color(hh, c);
+                }
+            } else {
+                const float prob = m->p.variant == 1 ? gp_node_prob(m->p, nd) : node_prob(nd);
+                if (prob < 0.5) { c[0] = 0.8f; c[1] = 0.8f; c[2] = 0.8f; c[3] = 1.0f; }
+                else height_map_color(std::min(2.0 - 2.0 * prob, 0.6), c);
+            }
+        }
+        ++n;
+    };
+    std::vector<int> keys;
+    for (int64_t key : bk) {
+        Block *b = m->blocks[key];
+        enumerate_leaves(m->p, *b, keys);
+        for (int k : keys) {
+            const Node &nd = b->layer[k >> 16][k & 0xFFFF];
+            if ((int)nd.state != state) continue;
+            const V3 &o = m->lut[k >> 16][k & 0xFFFF];
+            const float cx = o.x + b->center.x, cy = o.y + b->center.y, cz = o.z + b->center.z;
+            const float size = float(m->p.block_size / pow(2, k >> 16));
+            if (original_size) {
+                insert(cx, cy, cz, size, nd);
+            } else {
+                const float res = m->p.resolution;
+                float x0 = cx - size * 0.5 + res * 0.5, y0 = cy - size * 0.5 + res * 0.5, z0 = cz - size * 0.5 + res * 0.5;
+                float x1 = cx + size * 0.5, y1 = cy + size * 0.5, z1 = cz + size * 0.5;
+                for (float x = x0; x < x1; x += res)
+                    for (float y = y0; y < y1; y += res)
+                        for (float z = z0; z < z1; z += res) insert(x, y, z, res, nd);
+            }
+        }
+    }
+    return n;
+}
+
 // ---- single-block access (known-answer tests against oracle/_ref) ----
 void *orc_block_new(void *h, float cx, float cy, float cz) { return block_new(((Map *)h)->p, V3{cx, cy, cz}); }
 void orc_block_free(void *b) { delete (Block *)b; }

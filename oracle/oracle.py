@@ -119,6 +119,10 @@ def _load(name):
     lib.orc_block_grid.argtypes = [C.c_void_p, f32p, f32p, i32p, C.POINTER(C.c_int32), f32p]
     lib.orc_raycast.restype = C.c_int64
     lib.orc_raycast.argtypes = [C.c_void_p, f32p, f32p, f32p, i64p, i32p, u8p, f32p, f32p, u8p, C.c_int64]
+    lib.orc_export_cells.restype = C.c_int64
+    lib.orc_export_cells.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p, i32p, C.c_int64]
+    lib.orc_get_bbox.argtypes = [C.c_void_p, f32p, f32p]
+    lib.orc_height_map_color.argtypes = [C.c_double, f32p]
     lib.orc_dump_leaves.restype = C.c_int64
     lib.orc_dump_leaves.argtypes = [C.c_void_p, i64p, i32p, f32p, f32p, f32p, f32p, u8p, u8p, C.c_int64]
     lib.orc_block_new.restype = C.c_void_p
@@ -221,6 +225,23 @@ class OracleMap:
         n = self.L.orc_raycast(self.h, s3, e3, out["p"], out["block_key"], out["node_key"], out["valid"], out["A"],
                                out["B"], out["state"], cap)
         n = min(int(n), cap)
+        return {k: v[:n] for k, v in out.items()}
+
+    def get_bbox(self):
+        lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self.L.orc_get_bbox(self.h, lo, hi)
+        return lo, hi
+
+    def export_cells(self, state="occupied", original_size=True, min_z=0.0, max_z=0.0):
+        """the static node's publish loop (cube lists): cells (n, 4), rgba (n, 4), level (n,)"""
+        st = {"occupied": 1, "free": 0}[state]
+        e = np.zeros(4, np.float32)
+        n = int(self.L.orc_export_cells(self.h, st, int(bool(original_size)), min_z, max_z, e, e, np.zeros(1, np.int32), 0))
+        out = dict(cells=np.zeros((max(n, 1), 4), np.float32), rgba=np.zeros((max(n, 1), 4), np.float32),
+                   level=np.zeros(max(n, 1), np.int32))
+        m = int(self.L.orc_export_cells(self.h, st, int(bool(original_size)), min_z, max_z, out["cells"], out["rgba"],
+                                        out["level"], n))
+        assert m == n
         return {k: v[:n] for k, v in out.items()}
 
     def leaves(self):

@@ -203,3 +203,9 @@ def test_cpp_example(built):
     assert int(got["occupied"]) == int((lv["state"] == 1).sum()) and int(got["free"]) == int((lv["state"] == 0).sum())
     assert int(got["unknown"]) == int((lv["state"] == 2).sum()) and int(got["blocks"]) == m.block_count()
     assert "device_resident 1" in r.stdout
+    lines = r.stdout.strip().splitlines()
+    occ = m.export_cells("occupied")
+    assert lines[-2].startswith(f"occupied cubes {occ['level'].size} by level:")
+    for l, c in zip(*np.unique(occ["level"], return_counts=True)):
+        assert f" [{l}] {c}" in lines[-2]
+    assert lines[-1].startswith(f"free cubes {m.export_cells('free')['level'].size} by level:")

@@ -341,3 +341,45 @@ def test_voxel_grid_index_overflow_passthrough_and_depth5(built):
         m.insert_pointcloud(xyz[::5], origin, 0.05, 0.5, 5.0)
         o.insert_pointcloud(xyz[::5], origin, 0.05, 0.5, 5.0)
     _same(m, o, "depth5")
+
+
+def _sorted_cells(e):
+    rows = np.concatenate([e["cells"], e["rgba"], e["level"][:, None].astype(np.float32)], axis=1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+@pytest.mark.parametrize("depth,gp", [(3, False), (4, False), (3, True)])
+def test_leaf_export_on_the_device_pool(built, depth, gp):
+    """f3 leaf export: the static node's publish loop (occupied cells coloured by height, free cells by
+    probability, collapsed leaves kept or expanded) runs on the pool — no mirror refresh — and equals the oracle's
+    restatement cell for cell; get_bbox comes from the pool's key box."""
+    import la3dm_amd
+    params = dict(la3dm_amd.GP_YAML if gp else la3dm_amd.BGK_YAML, block_depth=depth)
+    m, o = _maps(params, gp=gp)
+    assert m.export_cells("occupied")["cells"].shape == (0, 4)                # empty pool
+    for i in (1, 2, 3, 4):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz if not gp else xyz[::3], origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz if not gp else xyz[::3], origin, 0.1, 0.5, 8.0)
+    lo, hi = m.get_bbox()
+    olo, ohi = o.get_bbox()
+    assert (lo == olo).all() and (hi == ohi).all()
+    n = 0
+    for state in ("occupied", "free"):
+        for original in (True, False):
+            for zr in ((0.0, 0.0), (-0.3, 1.7)):
+                a, b = m.export_cells(state, original, *zr), o.export_cells(state, original, *zr)
+                assert a["cells"].shape == b["cells"].shape, (state, original, zr, a["cells"].shape, b["cells"].shape)
+                assert (_sorted_cells(a) == _sorted_cells(b)).all(), (state, original, zr)
+                n += a["cells"].shape[0]
+    assert n > 10000
+    occ = m.export_cells("occupied")
+    if not gp:
+        assert occ["level"].max() >= 1                                        # collapsed (coarse) occupied leaves
+    # the host-orchestrated mode walks its blocks on the CPU: same cells
+    h = (la3dm_amd.GPOctoMap if gp else la3dm_amd.BGKOctoMap)(**params, device=0).set_device_resident(False)
+    for i in (1, 2, 3, 4):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        h.insert_pointcloud(xyz if not gp else xyz[::3], origin, 0.1, 0.5, 8.0)
+    for state in ("occupied", "free"):
+        assert (_sorted_cells(h.export_cells(state, False)) == _sorted_cells(m.export_cells(state, False))).all()

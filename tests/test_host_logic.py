@@ -209,6 +209,64 @@ def test_raycaster_against_oracle(built):
     assert np.allclose(d, 0.1, atol=1e-5) and (w["p"][v][:, 1:] == w["p"][v][0, 1:]).all()
 
 
+def _sorted_cells(e):
+    rows = np.concatenate([e["cells"], e["rgba"], e["level"][:, None].astype(np.float32)], axis=1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def test_height_map_color_known_answers(built):
+    """heightMapColor (reference markerarray_pub.h:21-76, s = v = 1) at hand-derived points of the HSV wheel"""
+    from oracle import oracle as O
+    L = O.lib()
+    kat = {0.0: (1, 0, 0), 1 / 6: (1, 1, 0), 0.25: (0.5, 1, 0), 0.5: (0, 1, 1), 0.8: (0.8, 0, 1), 1.0: (1, 0, 0),
+           2 / 3: (0, 0, 1), 1.25: (0.5, 1, 0)}
+    for h, rgb in kat.items():
+        c = np.zeros(4, np.float32)
+        L.orc_height_map_color(h, c)
+        assert np.allclose(c[:3], rgb, atol=2e-7) and c[3] == 1.0, (h, c)
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_export_cells_against_oracle(built, depth):
+    """cube lists of the map (the static node's publish loop + MarkerArrayPub): host class vs oracle restatement, both
+    states, original and expanded sizes, bbox-derived and explicit height range"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(YAML, block_depth=depth)
+    m = la3dm_amd.BGKOctoMap(**params, device=-1)
+    o = O.OracleMap(**params)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        assert m.prepare(xyz, origin, 0.1, 0.5, 8.0)
+        _emulate_device(m.packed(), params)
+        m.commit()
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    lo, hi = m.get_bbox()
+    olo, ohi = o.get_bbox()
+    assert (lo == olo).all() and (hi == ohi).all()
+    n_total = 0
+    for state in ("occupied", "free"):
+        for original in (True, False):
+            for zr in ((0.0, 0.0), (-0.5, 2.0), (3.0, 1.0)):
+                a = m.export_cells(state, original, *zr)
+                b = o.export_cells(state, original, *zr)
+                assert a["cells"].shape == b["cells"].shape and a["cells"].shape[0] > 0, (state, original, zr)
+                assert (_sorted_cells(a) == _sorted_cells(b)).all(), (state, original, zr)
+                n_total += a["cells"].shape[0]
+                if not original:
+                    assert (a["level"] == 0).all() and (a["cells"][:, 3] == np.float32(0.1)).all()
+                if state == "occupied" and zr == (3.0, 1.0):
+                    assert (a["rgba"] == np.array([0, 0, 1, 1], np.float32)).all()   # uncoloured: the marker default
+    lv = m.leaves()
+    e = m.export_cells("occupied", True)
+    assert e["cells"].shape[0] == int((lv["state"] == 1).sum())
+    assert set(np.unique(e["level"]).tolist()) <= set(range(depth))
+    assert e["level"].max() >= 1                                                     # pruned (coarse) occupied leaves
+    assert m.export_cells("occupied", False)["cells"].shape[0] > e["cells"].shape[0]
+    empty = la3dm_amd.BGKOctoMap(**params, device=-1).export_cells("free", True)
+    assert empty["cells"].shape == (0, 4)
+
+
 def test_cpp_example_builds_and_fails_loudly_without_gpu(built):
     """examples/static_map.cpp (the reference's static node loop against the C++ class) is built by build(); without a
     HIP device it must stop with an error — there is no CPU inference path to fall back to"""
