@@ -4,6 +4,7 @@
 // candidate loops of get_blocks_in_bbox (a few dozen iterations per axis).  No CPU fallback.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -74,9 +75,14 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
     if (n == 0) return LA3DM_OK;
     hipStream_t st = dm->ctx->stream;
     size_t tmp = 0;
-    DM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    // rocPRIM's default hands anything up to 2^20 items to its merge sort (log2(n / 1024) partition + merge launch
+    // pairs, whatever end_bit says); the keys here have 10-27 significant bits, so above 2^18 items Onesweep (one
+    // launch per 8 bits) is the shorter chain (measured: membership sort of ~5.6e5 pairs 210 -> 170 us; below that
+    // its per-pass state resets cost more than the merge launches)
+    using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (1u << 18)>;
+    DM_TRY(rocprim::radix_sort_pairs<sort_config>(nullptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, (unsigned)end_bit, st));
     DM_RESERVE(dm->cub_tmp, tmp);
-    DM_TRY(hipcub::DeviceRadixSort::SortPairs(dm->cub_tmp.ptr, tmp, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    DM_TRY(rocprim::radix_sort_pairs<sort_config>(dm->cub_tmp.ptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, (unsigned)end_bit, st));
     return LA3DM_OK;
 }
 
