@@ -70,20 +70,26 @@ static int dm_fail(la3dm_devmap *dm, int code, const std::string &msg) {
 }
 
 // ---- library plumbing: device-wide sort / scan (rocPRIM through hipCUB) ---------------------------------
-static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
-                      uint32_t n, int end_bit) {
-    if (n == 0) return LA3DM_OK;
+template <size_t kMergeLimit>
+static int sort_pairs_cfg(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
+                          uint32_t n, int end_bit) {
     hipStream_t st = dm->ctx->stream;
     size_t tmp = 0;
-    // rocPRIM's default hands anything up to 2^20 items to its merge sort (log2(n / 1024) partition + merge launch
-    // pairs, whatever end_bit says); the keys here have 10-27 significant bits, so above 2^18 items Onesweep (one
-    // launch per 8 bits) is the shorter chain (measured: membership sort of ~5.6e5 pairs 210 -> 170 us; below that
-    // its per-pass state resets cost more than the merge launches)
-    using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (1u << 18)>;
+    using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, kMergeLimit>;
     DM_TRY(rocprim::radix_sort_pairs<sort_config>(nullptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, (unsigned)end_bit, st));
     DM_RESERVE(dm->cub_tmp, tmp);
     DM_TRY(rocprim::radix_sort_pairs<sort_config>(dm->cub_tmp.ptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, (unsigned)end_bit, st));
     return LA3DM_OK;
+}
+
+// Stable sort of (key, value) pairs on the low `end_bit` key bits.  rocPRIM's default hands anything up to 2^20
+// items to its merge sort (log2(n / 1024) partition + merge launch pairs, whatever end_bit says); Onesweep is one
+// launch (+ two state resets) per 8 key bits, so it is the shorter chain above 2^18 items (measured: membership
+// sort of ~5.6e5 pairs 210 -> 170 us; for 4e4 pairs even a 16-bit key sorts faster through the merge path).
+static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
+                      uint32_t n, int end_bit) {
+    if (n == 0) return LA3DM_OK;
+    return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit);
 }
 
 static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, uint32_t n) {
