@@ -301,32 +301,21 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     delete dm;
 }
 
-int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
-                                          float ds_resolution, float free_resolution, float max_range,
-                                          la3dm_devmap_stats *stats_out) {
-    if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
+// f1 (bgkoctomap.cpp:383-458): voxel grid over the hits, range gate + beam samples, voxel grid over the free samples;
+// leaves the labelled training set in dm->xy (hits first), its size in dm->n_xy, and the scan's bbox in dm->h_bbox.
+static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3], float ds_resolution,
+                     float free_resolution, float max_range) {
     la3dm_ctx *ctx = dm->ctx;
-    DM_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
-    memset(&S, 0, sizeof(S));
-    S.n_blocks = dm->n_blocks;
-    dm->n_xy = 0;
-    const double t0 = wall();
     int rc;
-    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
-
-    // ---------------- f1: front end ----------------
     const float *d_hits = d_xyz;
     uint32_t n_h = n;
     if (!(ds_resolution < 0)) {
         if ((rc = voxel_grid(dm, d_xyz, n, ds_resolution, dm->hits, &n_h)) != LA3DM_OK) return rc;
         d_hits = (const float *)dm->hits.ptr;
     }
-    if (n_h == 0) {
-        if (stats_out) *stats_out = S;
-        return LA3DM_OK;
-    }
+    if (n_h == 0) return LA3DM_OK;
     DM_RESERVE(dm->keep, 4ull * n_h);
     DM_RESERVE(dm->nfree, 4ull * n_h);
     DM_RESERVE(dm->keep_off, 4ull * n_h);
@@ -341,10 +330,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_kept = dm->h_cnt[kCntKept], n_free_raw = dm->h_cnt[kCntFreeRaw];
-    if (n_kept == 0) {
-        if (stats_out) *stats_out = S;
-        return LA3DM_OK;
-    }
+    if (n_kept == 0) return LA3DM_OK;
     DM_RESERVE(dm->xy, 16ull * ((size_t)n_kept + n_free_raw));
     DM_RESERVE(dm->frees_raw, 12ull * n_free_raw);
     float4 *xy = (float4 *)dm->xy.ptr;
@@ -364,16 +350,37 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     S.n_hits = n_kept;
     S.n_frees = n_f;
 
-    // ---------------- f2: partition ----------------
+    // bbox of the training set (get_blocks_in_bbox walks it on the host)
     hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
     hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)xy, npts,
                        dm->d_mm);
     hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox);
     DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
-    const double t1 = wall();
-    S.t_frontend = t1 - t0;
+    return LA3DM_OK;
+}
 
+// Host-side facts of the scan in flight, shared by the partition and the passes.
+struct ScanPlan {
+    PartArgs pa;
+    CandArgs ca;
+    uint64_t ncid = 0;       // cells of the dense block-index grid
+    uint32_t n_entries = 0;  // candidate list (product of the three axis sequences)
+    uint32_t max_occ = 1;    // passes: how often the most repeated candidate key occurs
+    uint32_t n_mem = 0;      // (block, point) membership pairs = gathered training rows
+    uint32_t n_geo = 0;      // training blocks
+    uint32_t *train_off = nullptr;
+};
+
+// f2 (bgkoctomap.cpp:234-284, 486-552): candidate sequences of get_blocks_in_bbox, closed-box membership of every
+// training point, CSR by block, dense block-index grid.
+static int partition(la3dm_devmap *dm, ScanPlan &P) {
+    la3dm_ctx *ctx = dm->ctx;
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    const uint32_t npts = dm->n_xy;
+    const float4 *xy = (const float4 *)dm->xy.ptr;
+    int rc;
     const float bs = dm->block_size, half = bs / 2.0f;
     std::vector<int> seq[3];
     int smin[3], smax[3];
@@ -386,7 +393,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
             smax[a] = std::max(smax[a], v);
         }
     }
-    PartArgs pa;
+    PartArgs &pa = P.pa;
     pa.bs = bs;
     pa.half = half;
     uint64_t ncid = 1;
@@ -431,7 +438,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     }
     DM_RESERVE(dm->axis_tab, tab.size());
     DM_TRY(hipMemcpyAsync(dm->axis_tab.ptr, tab.data(), tab.size(), hipMemcpyHostToDevice, st));
-    CandArgs ca;
+    CandArgs &ca = P.ca;
     for (int a = 0; a < 3; ++a) {
         const uint8_t *base = (const uint8_t *)dm->axis_tab.ptr;
         pa.mult[a] = base + off_mult[a];
@@ -450,7 +457,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     DM_RESERVE(dm->scan, 4ull * npts);
     uint32_t *m_cnt = (uint32_t *)dm->flag.ptr, *m_off = (uint32_t *)dm->scan.ptr;
     DM_RESERVE(dm->m_code, 16ull * npts);
-    hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const float4 *)xy, npts, pa, m_cnt,
+    hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, xy, npts, pa, m_cnt,
                        (int4 *)dm->m_code.ptr);
     if ((rc = exclusive_scan(dm, m_cnt, m_off, npts)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, m_off, m_cnt, npts, dm->d_cnt, (int)kCntMembers);
@@ -478,7 +485,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     hipLaunchKernelGGL(dm_seg_starts, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, k1, sflag, sscan, n_mem, train_off, seg_key,
                        dm->d_cnt, (int)kCntGeo, (int)kCntGridValid);
     DM_RESERVE(dm->train, 16ull * n_mem);
-    hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, (const float4 *)xy, v1, n_mem,
+    hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, v1, n_mem,
                        (float4 *)dm->train.ptr);
     DM_RESERVE(dm->grid, 4ull * ncid);
     DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
@@ -490,132 +497,177 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
         n_geo = dm->h_cnt[kCntGeo];
     }
-    const double t2 = wall();
-    S.t_partition = t2 - t1;
+    P.ncid = ncid;
+    P.n_entries = n_entries;
+    P.max_occ = max_occ;
+    P.n_mem = n_mem;
+    P.n_geo = n_geo;
+    P.train_off = train_off;
+    return LA3DM_OK;
+}
 
-    // ---------------- passes over the candidate list (one unless a key repeats) ----------------
-    DM_RESERVE(dm->c_weight, 4ull * n_entries);
+// One pass over the candidate list (bgkoctomap.cpp:286-353): test-block decision, find-or-create, leaves in
+// LeafIterator order, predict + fuse, write-back, prune.  A pass holds every candidate key once; keys the float
+// stepping of get_blocks_in_bbox repeats come back in later passes, as in the serial reference.
+static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_test0) {
+    la3dm_ctx *ctx = dm->ctx;
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    CandArgs &ca = P.ca;
+    const uint32_t n_entries = P.n_entries, max_occ = P.max_occ, n_mem = P.n_mem, ncell = dm->ncell;
+    uint32_t *train_off = P.train_off;
     uint32_t *c_flag = (uint32_t *)dm->c_flag.ptr, *c_weight = (uint32_t *)dm->c_weight.ptr, *c_scan = (uint32_t *)dm->c_scan.ptr;
-    const uint32_t ncell = dm->ncell;
-    uint32_t n_test0 = 0;
-    for (uint32_t pass = 0; pass < max_occ; ++pass) {
-        const double tp0 = wall();
-        ca.pass = pass;
-        hipLaunchKernelGGL(dm_candidates, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
-                           (const uint32_t *)train_off, n_entries, c_flag, c_weight);
-        if ((rc = exclusive_scan(dm, c_flag, c_scan, n_entries)) != LA3DM_OK) return rc;
-        DM_RESERVE(dm->t_key0, 4ull * n_entries);
-        DM_RESERVE(dm->t_ent0, 4ull * n_entries);
-        hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
-                           (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
-        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
-        if (dm->h_cnt[kCntError])
-            return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
-        if (ctx->p.variant != 1) n_geo = dm->h_cnt[kCntGeo];
-        S.n_train_blocks = dm->h_cnt[kCntTrained];
-        const uint32_t n_test = dm->h_cnt[kCntTest];
-        if (n_test == 0) continue;
-        S.n_test_blocks += n_test;
-        S.n_passes = pass + 1;
-        DM_RESERVE(dm->t_key1, 4ull * n_test);
-        DM_RESERVE(dm->t_ent1, 4ull * n_test);
-        // heaviest test blocks first (the blocks are independent: order only balances the launch)
-        if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
-                             (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
-            return rc;
-        DM_RESERVE(dm->t_blockkey, 8ull * n_test);
-        DM_RESERVE(dm->t_center, 12ull * n_test);
-        DM_RESERVE(dm->t_nbr, 28ull * n_test);
-        DM_RESERVE(dm->t_slot, 4ull * n_test);
-        hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
-                           (const uint32_t *)dm->t_ent1.ptr, dm->d_cnt, (long long *)dm->t_blockkey.ptr, (float *)dm->t_center.ptr,
-                           (int32_t *)dm->t_nbr.ptr);
-        // blocks: find or create (bgkoctomap.cpp:298-305)
-        if ((rc = grow_pool(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
-        if ((rc = grow_table(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
-        DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntBlocks, &dm->n_blocks, 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const long long *)dm->t_blockkey.ptr,
-                           dm->d_cnt, dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key,
-                           (uint32_t *)dm->t_slot.ptr);
-        // default nodes for the blocks this launch created: slots [old count, new count); the new count stays on
-        // the device (read back with the pass's other counters), the launch covers the worst case of n_test new blocks
-        hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)n_test * dm->npb, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S,
-                           dm->n_blocks, (const uint32_t *)(dm->d_cnt + kCntBlocks), dm->npb, dm->init_A, dm->init_B);
-        // pack: leaves in LeafIterator order
-        DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
-        DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
-        const size_t max_leaves = (size_t)n_test * ncell;
-        DM_RESERVE(dm->leaf_key, 4 * max_leaves);
-        DM_RESERVE(dm->leaf_alpha, 4 * max_leaves);
-        DM_RESERVE(dm->leaf_beta, 4 * max_leaves);
-        DM_RESERVE(dm->leaf_node, 4 * max_leaves);
-        DM_RESERVE(dm->leaf_state, max_leaves);
-        uint32_t *nleaf = (uint32_t *)dm->nleaf.ptr, *leaf_off = (uint32_t *)dm->leaf_off.ptr;
-        DM_TRY(hipMemsetAsync(nleaf + n_test, 0, 4, st));
-        hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
-                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
-                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
-                           (const uint32_t *)nleaf, n_test, dm->d_cnt);
-        if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
-        hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
-        hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
-                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
-                           (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
-                           (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr);
-        double tp1 = tp0;
-        if (getenv("LA3DM_TIMING")) {
-            DM_TRY(hipStreamSynchronize(st));
-            tp1 = wall();
-            S.t_pack += tp1 - tp0;
-        }
-        // E: predict + fuse
-        la3dm_bgk_scan s;
-        memset(&s, 0, sizeof(s));
-        s.train_xyzy = (const float *)dm->train.ptr;
-        s.train_off = train_off;
-        s.n_train_pts = n_mem;
-        s.n_train_blk = n_geo;
-        s.nbr = (const int32_t *)dm->t_nbr.ptr;
-        s.blk_center = (const float *)dm->t_center.ptr;
-        s.leaf_off = leaf_off;
-        s.n_test_blk = n_test;
-        s.n_leaf = (uint32_t)std::min<size_t>(max_leaves, 0xFFFFFFFFu);
-        s.leaf_key = (const uint32_t *)dm->leaf_key.ptr;
-        s.alpha = (float *)dm->leaf_alpha.ptr;
-        s.beta = (float *)dm->leaf_beta.ptr;
-        s.state = (uint8_t *)dm->leaf_state.ptr;
-        s.flags = 0;
-        rc = ctx->p.variant == 1 ? la3dm_gp_scan_device(ctx, &s, st, nullptr) : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
-        if (rc != LA3DM_OK) return rc;
-        double tp2 = tp1;
-        if (getenv("LA3DM_TIMING")) {
-            DM_TRY(hipStreamSynchronize(st));
-            tp2 = wall();
-            S.t_kernel += tp2 - tp1;
-        }
-        // f3: write-back + prune
-        hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
-                           (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
-                           (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
-        // The reference prunes after ALL test blocks have been predicted (bgkoctomap.cpp:344-353): with repeated keys
-        // the later passes must still see the un-pruned leaves, so the prune of pass 0 (which holds every distinct
-        // test block) is deferred to the end of the pass loop.
-        if (max_occ == 1) {
-            hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
-                               (const uint32_t *)dm->t_slot.ptr, n_test, dm->A, dm->B, dm->S, dm->npb, dm->depth);
-        } else if (pass == 0) {
-            DM_RESERVE(dm->t_slot0, 4ull * n_test);
-            DM_TRY(hipMemcpyAsync(dm->t_slot0.ptr, dm->t_slot.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
-            n_test0 = n_test;
-        }
-        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
-        dm->n_blocks = dm->h_cnt[kCntBlocks];
-        S.voxel_updates += dm->h_cnt[kCntLeaves];
-        S.train_reads = (uint64_t)dm->h_cnt[kCntTrainReads] | ((uint64_t)dm->h_cnt[kCntTrainReads + 1] << 32);
-        S.pair_evals = (uint64_t)dm->h_cnt[kCntPairEvals] | ((uint64_t)dm->h_cnt[kCntPairEvals + 1] << 32);
-        if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;
+    uint32_t &n_geo = P.n_geo;
+    int rc;
+    const double tp0 = wall();
+    ca.pass = pass;
+    hipLaunchKernelGGL(dm_candidates, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+                       (const uint32_t *)train_off, n_entries, c_flag, c_weight);
+    if ((rc = exclusive_scan(dm, c_flag, c_scan, n_entries)) != LA3DM_OK) return rc;
+    DM_RESERVE(dm->t_key0, 4ull * n_entries);
+    DM_RESERVE(dm->t_ent0, 4ull * n_entries);
+    hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
+                       (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    if (dm->h_cnt[kCntError])
+        return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
+    if (ctx->p.variant != 1) n_geo = dm->h_cnt[kCntGeo];
+    S.n_train_blocks = dm->h_cnt[kCntTrained];
+    const uint32_t n_test = dm->h_cnt[kCntTest];
+    if (n_test == 0) return LA3DM_OK;
+    S.n_test_blocks += n_test;
+    S.n_passes = pass + 1;
+    DM_RESERVE(dm->t_key1, 4ull * n_test);
+    DM_RESERVE(dm->t_ent1, 4ull * n_test);
+    // heaviest test blocks first (the blocks are independent: order only balances the launch)
+    if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
+                         (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
+        return rc;
+    DM_RESERVE(dm->t_blockkey, 8ull * n_test);
+    DM_RESERVE(dm->t_center, 12ull * n_test);
+    DM_RESERVE(dm->t_nbr, 28ull * n_test);
+    DM_RESERVE(dm->t_slot, 4ull * n_test);
+    hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+                       (const uint32_t *)dm->t_ent1.ptr, dm->d_cnt, (long long *)dm->t_blockkey.ptr, (float *)dm->t_center.ptr,
+                       (int32_t *)dm->t_nbr.ptr);
+    // blocks: find or create (bgkoctomap.cpp:298-305)
+    if ((rc = grow_pool(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
+    if ((rc = grow_table(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
+    DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntBlocks, &dm->n_blocks, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const long long *)dm->t_blockkey.ptr,
+                       dm->d_cnt, dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key,
+                       (uint32_t *)dm->t_slot.ptr);
+    // default nodes for the blocks this launch created: slots [old count, new count); the new count stays on
+    // the device (read back with the pass's other counters), the launch covers the worst case of n_test new blocks
+    hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)n_test * dm->npb, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S,
+                       dm->n_blocks, (const uint32_t *)(dm->d_cnt + kCntBlocks), dm->npb, dm->init_A, dm->init_B);
+    // pack: leaves in LeafIterator order
+    DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
+    DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
+    const size_t max_leaves = (size_t)n_test * ncell;
+    DM_RESERVE(dm->leaf_key, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_alpha, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_beta, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_node, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_state, max_leaves);
+    uint32_t *nleaf = (uint32_t *)dm->nleaf.ptr, *leaf_off = (uint32_t *)dm->leaf_off.ptr;
+    DM_TRY(hipMemsetAsync(nleaf + n_test, 0, 4, st));
+    hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                       (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
+                       (const uint32_t *)nleaf, n_test, dm->d_cnt);
+    if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
+    hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                       (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                       (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                       (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr);
+    double tp1 = tp0;
+    if (getenv("LA3DM_TIMING")) {
+        DM_TRY(hipStreamSynchronize(st));
+        tp1 = wall();
+        S.t_pack += tp1 - tp0;
     }
+    // E: predict + fuse
+    la3dm_bgk_scan s;
+    memset(&s, 0, sizeof(s));
+    s.train_xyzy = (const float *)dm->train.ptr;
+    s.train_off = train_off;
+    s.n_train_pts = n_mem;
+    s.n_train_blk = n_geo;
+    s.nbr = (const int32_t *)dm->t_nbr.ptr;
+    s.blk_center = (const float *)dm->t_center.ptr;
+    s.leaf_off = leaf_off;
+    s.n_test_blk = n_test;
+    s.n_leaf = (uint32_t)std::min<size_t>(max_leaves, 0xFFFFFFFFu);
+    s.leaf_key = (const uint32_t *)dm->leaf_key.ptr;
+    s.alpha = (float *)dm->leaf_alpha.ptr;
+    s.beta = (float *)dm->leaf_beta.ptr;
+    s.state = (uint8_t *)dm->leaf_state.ptr;
+    s.flags = 0;
+    rc = ctx->p.variant == 1 ? la3dm_gp_scan_device(ctx, &s, st, nullptr) : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
+    if (rc != LA3DM_OK) return rc;
+    double tp2 = tp1;
+    if (getenv("LA3DM_TIMING")) {
+        DM_TRY(hipStreamSynchronize(st));
+        tp2 = wall();
+        S.t_kernel += tp2 - tp1;
+    }
+    // f3: write-back + prune
+    hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
+                       (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
+                       (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
+    // The reference prunes after ALL test blocks have been predicted (bgkoctomap.cpp:344-353): with repeated keys
+    // the later passes must still see the un-pruned leaves, so the prune of pass 0 (which holds every distinct
+    // test block) is deferred to the end of the pass loop.
+    if (max_occ == 1) {
+        hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
+                           (const uint32_t *)dm->t_slot.ptr, n_test, dm->A, dm->B, dm->S, dm->npb, dm->depth);
+    } else if (pass == 0) {
+        DM_RESERVE(dm->t_slot0, 4ull * n_test);
+        DM_TRY(hipMemcpyAsync(dm->t_slot0.ptr, dm->t_slot.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
+        *n_test0 = n_test;
+    }
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    dm->n_blocks = dm->h_cnt[kCntBlocks];
+    S.voxel_updates += dm->h_cnt[kCntLeaves];
+    S.train_reads = (uint64_t)dm->h_cnt[kCntTrainReads] | ((uint64_t)dm->h_cnt[kCntTrainReads + 1] << 32);
+    S.pair_evals = (uint64_t)dm->h_cnt[kCntPairEvals] | ((uint64_t)dm->h_cnt[kCntPairEvals + 1] << 32);
+    if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
+                                          float ds_resolution, float free_resolution, float max_range,
+                                          la3dm_devmap_stats *stats_out) {
+    if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
+    la3dm_ctx *ctx = dm->ctx;
+    DM_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    memset(&S, 0, sizeof(S));
+    S.n_blocks = dm->n_blocks;
+    dm->n_xy = 0;
+    const double t0 = wall();
+    int rc;
+    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+
+    if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
+    if (dm->n_xy == 0) {  // empty cloud, or every hit beyond max_range
+        if (stats_out) *stats_out = S;
+        return LA3DM_OK;
+    }
+    const double t1 = wall();
+    S.t_frontend = t1 - t0;
+    ScanPlan P;
+    if ((rc = partition(dm, P)) != LA3DM_OK) return rc;
+    S.t_partition = wall() - t1;
+    DM_RESERVE(dm->c_weight, 4ull * P.n_entries);
+    const uint32_t max_occ = P.max_occ;
+    uint32_t n_test0 = 0;
+    for (uint32_t pass = 0; pass < max_occ; ++pass)
+        if ((rc = run_pass(dm, P, pass, &n_test0)) != LA3DM_OK) return rc;
     if (max_occ > 1 && n_test0)
         hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test0, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot0.ptr, n_test0, dm->A, dm->B, dm->S, dm->npb, dm->depth);
