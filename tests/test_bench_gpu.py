@@ -1,0 +1,64 @@
+"""bench.py contract (one JSON line, required keys) on one GPU, and the N > 1 code path in its single-GPU self-test
+mode: two ranks on cuda:0, gloo instead of RCCL, the all-gather payload staged through host memory — it exercises the
+launch protocol (torch.distributed.run, RANK / WORLD_SIZE / MASTER_*), the shard / scan split, the barrier + max
+timing and the aggregate, never a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(built):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--rays", "50000",
+                        "--no-cpu-omp"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in KEYS + ("cpu_baseline", "end_to_end"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1 and d["value"] > 0 and d["dtype"] == "f32"
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["kernel_ms"] > 0 and rf["algorithmic_bytes_per_launch"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    assert d["value"] > 100 * d["cpu_baseline"]["value"]
+    assert d["end_to_end"]["ms_per_insert"] > 0
+
+
+@pytest.mark.parametrize("mode,scaling", [("scans", "weak"), ("shard", "strong")])
+def test_two_ranks_self_test(built, mode, scaling):
+    env = dict(os.environ, LA3DM_BENCH_TEST_SINGLE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--rays", "50000", "--no-cpu", "--no-e2e", "--mode", mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = _last_json(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0 and d["steps"] == 3
+    per_rank = d["config"]["voxel_updates_per_scan"]
+    total = d["value"] * d["ms_per_step"] * 1e-3
+    # whole-job aggregate: both ranks' leaves (weak: two scans; strong: the two halves of one scan)
+    assert abs(total - 2 * per_rank) / total < 0.35
