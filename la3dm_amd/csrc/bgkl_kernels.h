@@ -39,21 +39,29 @@ struct BgklArgs {
 // handful of tiles ~10^5 rows each and the row-serial kernel below becomes one long straggler wave.  Only the two
 // fp32 running sums have to be serial; the distance test and the kernel evaluation do not.  A tile whose seven
 // neighbours hold more than `threshold` rows is cut into items of kLItemRows rows:
-//   bgkl_split_mark    per tile: row total, item count, first item (atomic bump; item order across tiles is free)
-//   bgkl_split_items   item descriptors {tile, neighbour, row range}
+//   bgkl_split_mark    per tile: row total, item count, first item, index in the list of split tiles (atomic
+//                      bumps; the order of items and tiles is free, every tile is independent)
+//   bgkl_split_items   item descriptors {tile, neighbour, row range}, first item of each (tile, neighbour)
 //   bgkl_split_eval<0> one wave per item: distance test, per row {hit mask, label, running hit count}
 //   bgkl_split_bdesc   per 64-row batch: where its values live
 //   bgkl_split_eval<1> same rows again: k(d / ell) of the hit lanes, written in (row, lane) order
-//   bgkl_split_fuse    one wave per split tile replays the rows in order: values staged through LDS one batch
-//                      ahead, every lane adds its own hits (or +0) to (ybar, kbar) -> same sums, bit for bit
+//   bgkl_split_fuse    one workgroup per (split tile, neighbour) — the seven (ybar, kbar) pairs of a tile are
+//                      independent chains.  Seven producer waves expand the next 64-row batch into dense
+//                      [row][leaf] tiles in LDS ({k or +0}, {k * label or +0}; loads issued one trip ahead, row
+//                      records two trips ahead) while wave 0 adds the current batch row by row: 2 LDS reads +
+//                      2 adds per row on the serial chain -> same sums as the row-serial kernel, bit for bit
+//   bgkl_split_apply   per split tile: the gated update of (alpha, beta) in ExtendedBlock order + state
 constexpr int kLItemRows = 256;
 constexpr int kLBatch = 64;
 constexpr int kLBatches = kLItemRows / kLBatch;
-constexpr int kLPre = 16;  // values per lane fetched one batch ahead (the rest of a batch is loaded when it starts)
+constexpr int kLProducers = 7;
+constexpr int kLRowsPerProducer = (kLBatch + kLProducers - 1) / kLProducers;  // 10
 
 struct BgklSplit {
-    uint32_t *task_item;          // [2 * n_tasks] {first item or 0xFFFFFFFF, item count}
-    uint32_t *counters;           // [0] items, [2..3] hit values (64-bit)
+    uint32_t *task_item;          // [2 * n_tasks] {first item or 0xFFFFFFFF, index in split_list}
+    uint32_t *counters;           // [0] items, [1] split tiles, [2..3] hit values (64-bit)
+    uint32_t *split_list;         // [split tiles] tile
+    uint32_t *nb_first;           // [split tiles * 8] first item of neighbour slot b; [7] = end
     uint4 *item_desc;             // {tile, neighbour slot, row begin, row end}
     uint4 *rowrec;                // [items * kLItemRows] {mask lo, mask hi, label, hits before the row inside its batch}
     uint32_t *batch_off;          // [items * kLBatches] hits before the batch inside its item
@@ -61,6 +69,7 @@ struct BgklSplit {
     uint32_t *item_hits;          // [items]
     uint4 *bdesc;                 // [items * kLBatches] {value index lo, hi, values, rows | slot << 16}
     float *vals;
+    float2 *part;                 // [split tiles * 7 * 64] (ybar, kbar) of one neighbour
     uint32_t threshold;
 };
 
@@ -140,7 +149,7 @@ __global__ void bgkl_split_mark(BgklArgs a, BgklSplit s) {
     const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.tpb_shift, tile = task & ((1u << a.tpb_shift) - 1u);
-    uint32_t first = 0xFFFFFFFFu, n = 0;
+    uint32_t first = 0xFFFFFFFFu, idx = 0;
     if (a.leaf_off[blk] + tile * kWave < a.leaf_off[blk + 1]) {
         unsigned long long total = 0;
         uint32_t items = 0;
@@ -153,11 +162,12 @@ __global__ void bgkl_split_mark(BgklArgs a, BgklSplit s) {
         }
         if (total > (unsigned long long)s.threshold) {
             first = atomicAdd(&s.counters[0], items);
-            n = items;
+            idx = atomicAdd(&s.counters[1], 1u);
+            s.split_list[idx] = task;
         }
     }
     s.task_item[2 * task] = first;
-    s.task_item[2 * task + 1] = n;
+    s.task_item[2 * task + 1] = idx;
 }
 
 __global__ void bgkl_split_items(BgklArgs a, BgklSplit s) {
@@ -165,13 +175,16 @@ __global__ void bgkl_split_items(BgklArgs a, BgklSplit s) {
     if (task >= a.n_tasks) return;
     uint32_t it = s.task_item[2 * task];
     if (it == 0xFFFFFFFFu) return;
+    const uint32_t h = s.task_item[2 * task + 1];
     const uint32_t blk = task >> a.tpb_shift;
     for (int b = 0; b < 7; ++b) {
+        s.nb_first[8 * h + b] = it;
         const int32_t tb = a.nbr[7 * blk + b];
         if (tb < 0) continue;
         const uint32_t r0 = a.row_off[tb], r1 = a.row_off[tb + 1];
         for (uint32_t r = r0; r < r1; r += kLItemRows) s.item_desc[it++] = make_uint4(task, (uint32_t)b, r, min(r + (uint32_t)kLItemRows, r1));
     }
+    s.nb_first[8 * h + 7] = it;
 }
 
 template <bool kWrite>
@@ -239,90 +252,111 @@ __global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {
     s.bdesc[q] = d;
 }
 
-__global__ __launch_bounds__(kWave) void bgkl_split_fuse(BgklArgs a, BgklSplit s) {
-    __shared__ uint4 s_rec[kLBatch];
-    __shared__ float s_val[kLBatch * kWave + kWave];
+__global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(BgklArgs a, BgklSplit s) {
+    __shared__ float s_k[2][kLBatch][kWave];   // k of (row, leaf), +0 where the leaf is out of reach
+    __shared__ float s_ky[2][kLBatch][kWave];  // k * label
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t h = blockIdx.x / 7u, b = blockIdx.x % 7u;
+    const uint32_t it0 = s.nb_first[8 * h + b], it1 = s.nb_first[8 * h + b + 1];
+    if (it0 == it1) return;  // no trained model in this slot (uniform over the workgroup)
+    const uint32_t q0 = it0 * kLBatches;
+    const int nb = (int)((it1 - it0) * kLBatches);  // batches of this chain (the last item may end with empty ones)
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    const int pw = wave - 1;
+
+    // producer state: row records of the batch two trips ahead (lane k holds row pw + 7 k; asked for on one trip,
+    // used on the next), values of the batch one trip ahead (asked for on one trip, written to LDS on the next)
+    uint4 rec = zero4;
+    float val[kLRowsPerProducer], lab[kLRowsPerProducer];
+#pragma unroll
+    for (int k = 0; k < kLRowsPerProducer; ++k) val[k] = lab[k] = 0.0f;
+    float ybar = 0.0f, kbar = 0.0f;
+
+    for (int i = -3; i < nb; ++i) {
+        if (wave == 0) {
+            // ---- consumer: batch i, in row order ----
+            if (i >= 0) {
+                const int buf = i & 1;
+#pragma unroll 16
+                for (int r = 0; r < kLBatch; ++r) {
+                    ybar += s_ky[buf][r][lane];
+                    kbar += s_k[buf][r][lane];
+                }
+            }
+        } else {
+            // ---- producers ----
+            // (w) batch i + 1: the values asked for on the previous trip -> LDS (+0 where the leaf is out of reach
+            //     and in the rows past the end of the batch)
+            if (i + 1 >= 0 && i + 1 < nb) {
+                const int buf = (i + 1) & 1;
+#pragma unroll
+                for (int k = 0; k < kLRowsPerProducer; ++k) {
+                    const int r = pw + kLProducers * k;
+                    if (r < kLBatch) {
+                        s_k[buf][r][lane] = val[k];
+                        s_ky[buf][r][lane] = val[k] * lab[k];  // k * label, rounded once as in the row-serial kernel
+                    }
+                }
+            }
+            // (v) batch i + 2: its row records arrived -> ask for the hit lanes' values
+            uint4 rec_next = zero4;
+            if (i + 2 >= 0 && i + 2 < nb) {
+                const uint4 D = s.bdesc[q0 + (uint32_t)(i + 2)];
+                const uint32_t nr = __builtin_amdgcn_readfirstlane(D.w & 0xFFFFu);
+                const unsigned long long v0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(D.y) << 32) | __builtin_amdgcn_readfirstlane(D.x);
+#pragma unroll
+                for (int k = 0; k < kLRowsPerProducer; ++k) {
+                    const uint32_t r = (uint32_t)(pw + kLProducers * k);
+                    float v = 0.0f, l = 0.0f;
+                    if (r < nr) {  // uniform
+                        const uint32_t mlo = __builtin_amdgcn_readlane(rec.x, k), mhi = __builtin_amdgcn_readlane(rec.y, k);
+                        const uint32_t woff = __builtin_amdgcn_readlane(rec.w, k);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
+                        if ((((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u) {
+                            v = s.vals[v0 + woff + rank];
+                            l = __uint_as_float(__builtin_amdgcn_readlane(rec.z, k));
+                        }
+                    }
+                    val[k] = v;
+                    lab[k] = l;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kLRowsPerProducer; ++k) val[k] = lab[k] = 0.0f;
+            }
+            // (r) batch i + 3: ask for its row records, one per lane
+            if (i + 3 < nb) {
+                const uint4 D = s.bdesc[q0 + (uint32_t)(i + 3)];
+                const uint32_t nr = D.w & 0xFFFFu;
+                const uint32_t r = (uint32_t)(pw + kLProducers * lane);
+                if (lane < kLRowsPerProducer && r < nr) rec_next = s.rowrec[(size_t)(q0 + (uint32_t)(i + 3)) * kLBatch + r];
+            }
+            rec = rec_next;
+        }
+        __syncthreads();
+    }
+    if (wave == 0) s.part[((size_t)h * 7u + b) * kWave + lane] = make_float2(ybar, kbar);
+}
+
+__global__ __launch_bounds__(kWave) void bgkl_split_apply(BgklArgs a, BgklSplit s) {
     const int lane = threadIdx.x;
-    const uint32_t task = blockIdx.x;
-    if (task >= a.n_tasks) return;
-    const uint32_t first = s.task_item[2 * task];
-    if (first == 0xFFFFFFFFu) return;
-    const uint32_t q0 = first * kLBatches, q1 = (first + s.task_item[2 * task + 1]) * kLBatches;
+    const uint32_t h = blockIdx.x;
+    const uint32_t task = s.split_list[h];
     uint32_t blk, li;
     bool active;
     float px, py, pz;
     if (!bgkl_leaf(a, task, lane, blk, li, active, px, py, pz)) return;
     float A = a.alpha[li], B = a.beta[li];
     bool updated = false;
-    float ybar = 0.0f, kbar = 0.0f;
-    int cur_b = -1;
-    auto flush = [&]() {
-        if (kbar > 0.001f) {  // bgkloctomap.cpp:226-227
-            A += ybar;
-            B += kbar - ybar;
+    for (uint32_t b = 0; b < 7; ++b) {
+        if (a.nbr[7 * blk + b] < 0) continue;
+        const float2 yk = s.part[((size_t)h * 7u + b) * kWave + lane];
+        if (yk.y > 0.001f) {  // bgkloctomap.cpp:226-227
+            A += yk.x;
+            B += yk.y - yk.x;
             updated = true;
         }
-        ybar = 0.0f;
-        kbar = 0.0f;
-    };
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 rec1;
-    float pre1[kLPre];
-    auto issue = [&](const uint4 &D, uint32_t q) {  // loads of batch q, consumed one trip later
-        const uint32_t nr = D.w & 0xFFFFu, span = D.z;
-        const unsigned long long v = ((unsigned long long)D.y << 32) | D.x;
-        rec1 = (uint32_t)lane < nr ? s.rowrec[(size_t)q * kLBatch + lane] : zero4;
-#pragma unroll
-        for (int u = 0; u < kLPre; ++u) pre1[u] = (uint32_t)(lane + kWave * u) < span ? s.vals[v + lane + kWave * u] : 0.0f;
-    };
-    uint4 D1 = s.bdesc[q0];
-    uint4 D2 = q0 + 1 < q1 ? s.bdesc[q0 + 1] : zero4;
-    issue(D1, q0);
-    const uint32_t lsh = (uint32_t)lane & 31u;
-    for (uint32_t q = q0; q < q1; ++q) {
-        const uint4 D = D1;
-        D1 = D2;
-        D2 = q + 2 < q1 ? s.bdesc[q + 2] : zero4;
-        const uint32_t nr = __builtin_amdgcn_readfirstlane(D.w & 0xFFFFu), span = __builtin_amdgcn_readfirstlane(D.z);
-        const int b = (int)__builtin_amdgcn_readfirstlane(D.w >> 16);
-        if (nr) {
-            const unsigned long long v = ((unsigned long long)D.y << 32) | D.x;
-            s_rec[lane] = rec1;
-#pragma unroll
-            for (int u = 0; u < kLPre; ++u)
-                if ((uint32_t)(lane + kWave * u) < span) s_val[lane + kWave * u] = pre1[u];
-            for (uint32_t i = lane + kWave * kLPre; i < span; i += kWave) s_val[i] = s.vals[v + i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (q + 1 < q1) issue(D1, q + 1);
-        if (nr) {
-            if (b != cur_b) {
-                if (cur_b >= 0) flush();
-                cur_b = b;
-            }
-            for (uint32_t j0 = 0; j0 < nr; j0 += 8) {
-                float v[8], t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint4 r = s_rec[j0 + u];  // broadcast read; rows past nr hold a zero mask
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(r.y, __builtin_amdgcn_mbcnt_lo(r.x, 0));
-                    const uint32_t msk = (uint32_t)((int32_t)((lane < 32 ? r.x : r.y) << (31u - lsh)) >> 31);
-                    const float raw = s_val[r.w + rank];
-                    v[u] = __uint_as_float(__float_as_uint(raw) & msk);
-                    t[u] = __uint_as_float(__float_as_uint(raw * __uint_as_float(r.z)) & msk);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    ybar += t[u];
-                    kbar += v[u];
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
-    if (cur_b >= 0) flush();
     bgkl_store(a, li, active, updated, A, B);
 }
 

@@ -87,7 +87,7 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
 void la3dm_destroy(la3dm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->l_task_item, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_val, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
+    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_val, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
@@ -542,20 +542,23 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     const bool split = ctx->opt_l_split_rows >= 0;
     if (split) {
         if ((rc = arena_reserve(ctx, ctx->l_task_item, sizeof(uint32_t) * 2 * (size_t)a.n_tasks)) != LA3DM_OK) return rc;
+        if ((rc = arena_reserve(ctx, ctx->l_split_list, sizeof(uint32_t) * (size_t)a.n_tasks)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_counters, 16)) != LA3DM_OK) return rc;
         sp.task_item = (uint32_t *)ctx->l_task_item.ptr;
+        sp.split_list = (uint32_t *)ctx->l_split_list.ptr;
         sp.counters = (uint32_t *)ctx->l_counters.ptr;
         HIP_TRY(ctx, hipMemsetAsync(sp.counters, 0, 16, stream));
         hipLaunchKernelGGL(bgkl_split_mark, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
     }
     hipLaunchKernelGGL(bgkl_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), 0, stream, a, (const uint32_t *)sp.task_item);
     HIP_TRY(ctx, hipGetLastError());
-    uint32_t n_items = 0;
+    uint32_t head[2] = {0, 0};  // items, split tiles
     unsigned long long n_vals = 0;
     if (split) {
-        HIP_TRY(ctx, hipMemcpyAsync(&n_items, sp.counters, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipMemcpyAsync(head, sp.counters, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
     }
+    const uint32_t n_items = head[0], n_split = head[1];
     if (n_items) {
         if ((rc = arena_reserve(ctx, ctx->l_item_desc, sizeof(uint4) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_rowrec, sizeof(uint4) * (size_t)n_items * kLItemRows)) != LA3DM_OK) return rc;
@@ -563,12 +566,16 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         if ((rc = arena_reserve(ctx, ctx->l_item_val, sizeof(unsigned long long) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_item_hits, sizeof(uint32_t) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_bdesc, sizeof(uint4) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;
+        if ((rc = arena_reserve(ctx, ctx->l_nb_first, sizeof(uint32_t) * 8 * (size_t)n_split)) != LA3DM_OK) return rc;
+        if ((rc = arena_reserve(ctx, ctx->l_part, sizeof(float2) * 7 * kWave * (size_t)n_split)) != LA3DM_OK) return rc;
         sp.item_desc = (uint4 *)ctx->l_item_desc.ptr;
         sp.rowrec = (uint4 *)ctx->l_rowrec.ptr;
         sp.batch_off = (uint32_t *)ctx->l_batch_off.ptr;
         sp.item_val = (unsigned long long *)ctx->l_item_val.ptr;
         sp.item_hits = (uint32_t *)ctx->l_item_hits.ptr;
         sp.bdesc = (uint4 *)ctx->l_bdesc.ptr;
+        sp.nb_first = (uint32_t *)ctx->l_nb_first.ptr;
+        sp.part = (float2 *)ctx->l_part.ptr;
         hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_eval<false>, dim3(n_items), dim3(kWave), 0, stream, a, sp);
         HIP_TRY(ctx, hipMemcpyAsync(&n_vals, sp.counters + 2, 8, hipMemcpyDeviceToHost, stream));
@@ -577,7 +584,8 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         sp.vals = (float *)ctx->l_vals.ptr;
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
         hipLaunchKernelGGL(bgkl_split_eval<true>, dim3(n_items), dim3(kWave), 0, stream, a, sp);
-        hipLaunchKernelGGL(bgkl_split_fuse, dim3(a.n_tasks), dim3(kWave), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (1 + kLProducers)), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_apply, dim3(n_split), dim3(kWave), 0, stream, a, sp);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (out) {
