@@ -949,38 +949,74 @@ void BGKOctoMap::get_training_data_l(const float *xyz, size_t n, size_t stride, 
     }
     std::vector<float> hits;
     if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
-    xy.clear();
-    l_ray_idx.clear();
-    l_rays.clear();
     const float x0 = origin.x(), y0 = origin.y(), z0 = origin.z();
     const size_t nh = hits.size() / 3;
-    int32_t idx = 0;
-    for (size_t i = 0; i < nh; ++i) {
+    // pass 1: range gate and sample count per hit (the float-stepped while loop, kept verbatim); pass 2: fill
+    std::vector<uint32_t> first(nh + 1, 0u);  // first xy entry of hit i; kept hits only contribute
+    std::vector<uint8_t> kept(nh, 0);
+    auto end_point = [&](size_t i, float &ex, float &ey, float &ez, float &nx, float &ny, float &nz, float &l) {
+        const float x = hits[3 * i], y = hits[3 * i + 1], z = hits[3 * i + 2];
+        l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
+        nx = (x - x0) / l;
+        ny = (y - y0) / l;
+        nz = (z - z0) / l;
+        ex = x0 + nx * l;
+        ey = y0 + ny * l;
+        ez = z0 + nz * l;
+    };
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+    for (long i = 0; i < (long)nh; ++i) {
         const float x = hits[3 * i], y = hits[3 * i + 1], z = hits[3 * i + 2];
         if (max_range > 0) {
             const double lr = (point3f(x, y, z) - origin).norm();
             if (lr > max_range) continue;
         }
-        float l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
-        const float nx = (x - x0) / l, ny = (y - y0) / l, nz = (z - z0) / l;
-        const float ex = x0 + nx * l, ey = y0 + ny * l, ez = z0 + nz * l;
-        xy.insert(xy.end(), {ex, ey, ez, 1.0f});
-        l_ray_idx.push_back(-1);
-        xy.insert(xy.end(), {x0, y0, z0, 0.0f});
-        l_ray_idx.push_back(idx);
+        kept[i] = 1;
+        float ex, ey, ez, nx, ny, nz, l;
+        end_point((size_t)i, ex, ey, ez, nx, ny, nz, l);
+        const float l2 = (float)sqrt((ex - x0) * (ex - x0) + (ey - y0) * (ey - y0) + (ez - z0) * (ez - z0));
+        uint32_t c = 2;  // the re-projected hit and the origin sample
+        for (float d = l2 - free_resolution; d > 0.0; d -= free_resolution) ++c;
+        first[i + 1] = c;
+    }
+    std::vector<int32_t> beam(nh, -1);
+    int32_t idx = 0;
+    for (size_t i = 0; i < nh; ++i) {
+        first[i + 1] += first[i];
+        if (kept[i]) beam[i] = idx++;
+    }
+    xy.resize(4 * (size_t)first[nh]);
+    l_ray_idx.resize(first[nh]);
+    l_rays.resize(6 * (size_t)idx);
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+    for (long i = 0; i < (long)nh; ++i) {
+        if (!kept[i]) continue;
+        float ex, ey, ez, nx, ny, nz, l;
+        end_point((size_t)i, ex, ey, ez, nx, ny, nz, l);
+        const int32_t id = beam[i];
+        size_t w = first[i];
+        auto put = [&](float a, float b, float c, float lab, int32_t ray) {
+            float *o = &xy[4 * w];
+            o[0] = a;
+            o[1] = b;
+            o[2] = c;
+            o[3] = lab;
+            l_ray_idx[w++] = ray;
+        };
+        put(ex, ey, ez, 1.0f, -1);
+        put(x0, y0, z0, 0.0f, id);
         {   // beam_sample from the re-projected end point
             const float l2 = (float)sqrt((ex - x0) * (ex - x0) + (ey - y0) * (ey - y0) + (ez - z0) * (ez - z0));
             const float mx = (ex - x0) / l2, my = (ey - y0) / l2, mz = (ez - z0) / l2;
             float d = l2 - free_resolution;
             while (d > 0.0) {
-                xy.insert(xy.end(), {x0 + mx * d, y0 + my * d, z0 + mz * d, 0.0f});
-                l_ray_idx.push_back(idx);
+                put(x0 + mx * d, y0 + my * d, z0 + mz * d, 0.0f, id);
                 d -= free_resolution;
             }
         }
         l = l - free_resolution;
-        l_rays.insert(l_rays.end(), {x0, y0, z0, x0 + nx * l, y0 + ny * l, z0 + nz * l});
-        ++idx;
+        const float ray[6] = {x0, y0, z0, x0 + nx * l, y0 + ny * l, z0 + nz * l};
+        std::memcpy(&l_rays[6 * (size_t)id], ray, sizeof(ray));
     }
     stats.n_hits = (uint64_t)idx;
     stats.n_frees = xy.size() / 4 - (uint64_t)idx;
@@ -989,23 +1025,40 @@ void BGKOctoMap::get_training_data_l(const float *xyz, size_t n, size_t stride, 
 // Training rows of every block (bgkloctomap.cpp:141-170): members in CSR order; a hit becomes a degenerate segment with
 // label 1, a free sample contributes its beam once per block (at the position of the beam's first sample) with label 0.
 void BGKOctoMap::build_rows_l() {
-    train_rows.clear();
-    rows_off.assign(1, 0u);
-    std::vector<uint32_t> stamp(l_rays.size() / 6, 0xFFFFFFFFu);
-    for (size_t b = 0; b + 1 < train_off.size(); ++b) {
+    // Members of a block are in ascending source order and the samples of one beam are consecutive in `xy`, so the
+    // entries of a beam are adjacent inside a block: "once per block" = "differs from the previous entry's beam".
+    const long nblk = (long)train_off.size() - 1;
+    rows_off.assign((size_t)std::max(nblk, 0L) + 1, 0u);
+    auto emits = [&](uint32_t k, uint32_t k0) {
+        const int32_t r = l_ray_idx[train_src[k]];
+        return r < 0 || k == k0 || l_ray_idx[train_src[k - 1]] != r;
+    };
+#pragma omp parallel for num_threads(kHostThreads) schedule(dynamic, 256)
+    for (long b = 0; b < nblk; ++b) {
+        uint32_t c = 0;
+        for (uint32_t k = train_off[b]; k < train_off[b + 1]; ++k) c += emits(k, train_off[b]) ? 1u : 0u;
+        rows_off[b + 1] = c;
+    }
+    for (long b = 0; b < nblk; ++b) rows_off[b + 1] += rows_off[b];
+    train_rows.resize(8 * (size_t)rows_off[(size_t)std::max(nblk, 0L)]);
+#pragma omp parallel for num_threads(kHostThreads) schedule(dynamic, 256)
+    for (long b = 0; b < nblk; ++b) {
+        float *o = train_rows.data() + 8 * (size_t)rows_off[b];
         for (uint32_t k = train_off[b]; k < train_off[b + 1]; ++k) {
+            if (!emits(k, train_off[b])) continue;
             const uint32_t src = train_src[k];
             const int32_t r = l_ray_idx[src];
             if (r < 0) {
                 const float *p = &xy[4 * (size_t)src];
-                train_rows.insert(train_rows.end(), {p[0], p[1], p[2], p[0], p[1], p[2], 1.0f, 0.0f});
-            } else if (stamp[r] != (uint32_t)b) {
-                stamp[r] = (uint32_t)b;
+                const float row[8] = {p[0], p[1], p[2], p[0], p[1], p[2], 1.0f, 0.0f};
+                std::memcpy(o, row, sizeof(row));
+            } else {
                 const float *q = &l_rays[6 * (size_t)r];
-                train_rows.insert(train_rows.end(), {q[0], q[1], q[2], q[3], q[4], q[5], 0.0f, 0.0f});
+                const float row[8] = {q[0], q[1], q[2], q[3], q[4], q[5], 0.0f, 0.0f};
+                std::memcpy(o, row, sizeof(row));
             }
+            o += 8;
         }
-        rows_off.push_back((uint32_t)(train_rows.size() / 8));
     }
     // work counters in rows (what the oracle counts for this variant)
     stats.train_reads = stats.pair_evals = 0;
@@ -1075,14 +1128,31 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
         uint32_t pt;
     };
     std::vector<Member> members;
-    members.reserve(npts + npts / 8);
-    for (size_t i = 0; i < npts; ++i) {
-        const AxisCand ax = axis_candidates(xy[4 * i], bs, h), ay = axis_candidates(xy[4 * i + 1], bs, h),
-                       az = axis_candidates(xy[4 * i + 2], bs, h);
-        for (int a = 0; a < ax.n; ++a)
-            for (int b = 0; b < ay.n; ++b)
-                for (int c = 0; c < az.n; ++c)
-                    members.push_back(Member{(ax.idx[a] << 40) | (ay.idx[b] << 20) | az.idx[c], (uint32_t)i});
+    {
+        // contiguous point ranges per thread, concatenated in range order: the list is the serial loop's list
+        const int team = npts > 100000 ? kHostThreads : 1;
+        std::vector<std::vector<Member>> part((size_t)team);
+#pragma omp parallel for num_threads(team) schedule(static, 1)
+        for (int t = 0; t < team; ++t) {
+            const size_t i0 = npts * (size_t)t / (size_t)team, i1 = npts * (size_t)(t + 1) / (size_t)team;
+            std::vector<Member> &out = part[(size_t)t];
+            out.reserve((i1 - i0) + (i1 - i0) / 8);
+            for (size_t i = i0; i < i1; ++i) {
+                const AxisCand ax = axis_candidates(xy[4 * i], bs, h), ay = axis_candidates(xy[4 * i + 1], bs, h),
+                               az = axis_candidates(xy[4 * i + 2], bs, h);
+                for (int a = 0; a < ax.n; ++a)
+                    for (int b = 0; b < ay.n; ++b)
+                        for (int c = 0; c < az.n; ++c)
+                            out.push_back(Member{(ax.idx[a] << 40) | (ay.idx[b] << 20) | az.idx[c], (uint32_t)i});
+            }
+        }
+        std::vector<size_t> off((size_t)team + 1, 0);
+        for (int t = 0; t < team; ++t) off[(size_t)t + 1] = off[(size_t)t] + part[(size_t)t].size();
+        members.resize(off[(size_t)team]);
+#pragma omp parallel for num_threads(team) schedule(static, 1)
+        for (int t = 0; t < team; ++t)
+            if (!part[(size_t)t].empty())
+                std::memcpy(members.data() + off[(size_t)t], part[(size_t)t].data(), part[(size_t)t].size() * sizeof(Member));
     }
     // group by block; inside a block keep ascending point index.  (libstdc++ parallel mode, a small team: the sort is
     // the largest single item of the host partition; a stable sort has one result whatever the thread count.)
@@ -1095,24 +1165,34 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
     // "geo" blocks = every block that geometrically holds points (what an R-tree query sees);
     // trained blocks = geo blocks that are also in the candidate list.
     std::unordered_map<BlockHashKey, char> geo;
-    geo.reserve(members.size() / 4 + 16);
-    train_xyzy.reserve(members.size() * 4);
     uint32_t n_train_blk = 0;
-    for (size_t i = 0; i < members.size();) {
-        size_t j = i;
-        while (j < members.size() && members[j].key == members[i].key) ++j;
-        geo.emplace(members[i].key, 1);
-        auto it = in_bbox.find(members[i].key);
-        if (it != in_bbox.end()) {
+    {
+        std::vector<size_t> start;  // first member of every block group (+ end)
+        for (size_t i = 0; i < members.size(); ++i)
+            if (i == 0 || members[i].key != members[i - 1].key) start.push_back(i);
+        start.push_back(members.size());
+        geo.reserve(start.size() * 2 + 16);
+        std::vector<size_t> tgroup;  // groups that are training blocks, in key order
+        for (size_t g = 0; g + 1 < start.size(); ++g) {
+            const BlockHashKey key = members[start[g]].key;
+            geo.emplace(key, 1);
+            auto it = in_bbox.find(key);
+            if (it == in_bbox.end()) continue;
             it->second = (int32_t)n_train_blk++;
-            for (size_t k = i; k < j; ++k) {
-                const float *p = &xy[4 * (size_t)members[k].pt];
-                train_xyzy.insert(train_xyzy.end(), p, p + 4);
-                if (variant == 3) train_src.push_back(members[k].pt);
-            }
-            train_off.push_back((uint32_t)(train_xyzy.size() / 4));
+            tgroup.push_back(g);
+            train_off.push_back(train_off.back() + (uint32_t)(start[g + 1] - start[g]));
         }
-        i = j;
+        train_xyzy.resize(4 * (size_t)train_off.back());
+        if (variant == 3) train_src.resize(train_off.back());
+#pragma omp parallel for num_threads(kHostThreads) schedule(dynamic, 256)
+        for (long b = 0; b < (long)tgroup.size(); ++b) {
+            const size_t g = tgroup[(size_t)b];
+            size_t w = train_off[(size_t)b];
+            for (size_t k = start[g]; k < start[g + 1]; ++k, ++w) {
+                std::memcpy(&train_xyzy[4 * w], &xy[4 * (size_t)members[k].pt], 4 * sizeof(float));
+                if (variant == 3) train_src[w] = members[k].pt;
+            }
+        }
     }
     stats.n_train_blocks = n_train_blk;
     train_max_n = 0;
