@@ -13,7 +13,10 @@ value = voxel-updates (leaves of test blocks) per second, whole job.
 
 N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling — every rank
 owns one scan of the same size (different seed), runs the kernel on its blocks, and one RCCL
-all-gather reassembles the updated (alpha, beta, state) grid of all ranks on every rank.
+all-gather reassembles the updated (alpha, beta, state) grid of all ranks on every rank.  The leaf arrays
+are double-buffered: the gather of scan k runs on RCCL's stream under the kernel of scan k + 1 (a buffer is
+reused only after its gather has finished; all K kernels and all K gathers complete inside the timed region;
+--no-overlap serialises them).
 
 Adds to the JSON line: "roofline" (algorithmic bytes / HIP-event kernel time vs 8 TB/s) and,
 at N=1, "cpu_baseline" (the CPU oracle timed on the host cores on the same scan).
@@ -50,6 +53,8 @@ def main():
                     help="N>1 only. scans (default, weak scaling): one scan per GPU; shard (strong scaling, config-5 "
                          "style): ONE scan, its test blocks dealt round-robin to the ranks (la3dm_amd/sharding.py)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): 1 skip k(r) evaluation, 2 skip tests")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: one leaf buffer, every all-gather finishes before the next kernel starts")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (device-resident insert_pointcloud) leg")
     ap.add_argument("--no-cpu-omp", dest="cpu_omp", action="store_false",
@@ -121,31 +126,37 @@ def main():
         dist.all_reduce(n_leaf_max, op=dist.ReduceOp.MAX)
         cap = int(n_leaf_max.item())
     cap = (cap + 63) // 64 * 64
-    payload = torch.zeros(9 * cap, dtype=torch.uint8, device=dev)
     n = pk.n_leaf
-    alpha_t = payload[0:4 * cap].view(torch.float32)[:n]
-    beta_t = payload[4 * cap:8 * cap].view(torch.float32)[:n]
-    state_t = payload[8 * cap:8 * cap + n]
-    alpha_t.copy_(up(pk.alpha))
-    beta_t.copy_(up(pk.beta))
     d = dict(train=up(pk.train_xyzy), train_off=up(pk.train_off.view(np.int32)), nbr=up(pk.nbr), center=up(pk.blk_center),
-             leaf_off=up(pk.leaf_off.view(np.int32)), leaf_key=up(pk.leaf_key.view(np.int32)), alpha=alpha_t,
-             beta=beta_t, state=state_t)
-    scan = _lib.BgkScan()
-    scan.train_xyzy = d["train"].data_ptr()
-    scan.train_off = d["train_off"].data_ptr()
-    scan.n_train_pts = pk.n_train_pts
-    scan.n_train_blk = pk.n_train_blk
-    scan.nbr = d["nbr"].data_ptr()
-    scan.blk_center = d["center"].data_ptr()
-    scan.leaf_off = d["leaf_off"].data_ptr()
-    scan.n_test_blk = pk.n_test_blk
-    scan.n_leaf = pk.n_leaf
-    scan.leaf_key = d["leaf_key"].data_ptr()
-    scan.alpha = d["alpha"].data_ptr()
-    scan.beta = d["beta"].data_ptr()
-    scan.state = d["state"].data_ptr()
-    scan.flags = 0
+             leaf_off=up(pk.leaf_off.view(np.int32)), leaf_key=up(pk.leaf_key.view(np.int32)))
+    # N > 1: two leaf buffers, so that the all-gather of scan k (RCCL's own stream) runs under the kernel of scan k + 1
+    n_buf = 2 if (world > 1 and not args.no_overlap) else 1
+    payloads, scans, keep = [], [], []
+    for _ in range(n_buf):
+        payload = torch.zeros(9 * cap, dtype=torch.uint8, device=dev)
+        alpha_t = payload[0:4 * cap].view(torch.float32)[:n]
+        beta_t = payload[4 * cap:8 * cap].view(torch.float32)[:n]
+        state_t = payload[8 * cap:8 * cap + n]
+        alpha_t.copy_(up(pk.alpha))
+        beta_t.copy_(up(pk.beta))
+        scan = _lib.BgkScan()
+        scan.train_xyzy = d["train"].data_ptr()
+        scan.train_off = d["train_off"].data_ptr()
+        scan.n_train_pts = pk.n_train_pts
+        scan.n_train_blk = pk.n_train_blk
+        scan.nbr = d["nbr"].data_ptr()
+        scan.blk_center = d["center"].data_ptr()
+        scan.leaf_off = d["leaf_off"].data_ptr()
+        scan.n_test_blk = pk.n_test_blk
+        scan.n_leaf = pk.n_leaf
+        scan.leaf_key = d["leaf_key"].data_ptr()
+        scan.alpha = alpha_t.data_ptr()
+        scan.beta = beta_t.data_ptr()
+        scan.state = state_t.data_ptr()
+        scan.flags = 0
+        payloads.append(payload)
+        scans.append(scan)
+        keep.append((alpha_t, beta_t, state_t))
 
     H = _lib.hip()
     ctx = m.ctx()
@@ -161,21 +172,34 @@ def main():
         m.set_option("ablate", args.ablate)
     stream = torch.cuda.current_stream().cuda_stream
 
-    gather_out = torch.zeros(world * cap * 9, dtype=torch.uint8, device=dev) if world > 1 else None
+    gather_out = [torch.zeros(world * cap * 9, dtype=torch.uint8, device=dev) for _ in range(n_buf)] if world > 1 else None
+    pending = [None] * n_buf
+    counter = [0]
 
     def step():
-        rc = H.la3dm_bgk_scan_device(ctx, C.byref(scan), stream, None)
+        b = counter[0] % n_buf
+        counter[0] += 1
+        if pending[b] is not None:       # the gather that still reads this buffer (two scans ago)
+            pending[b].wait()
+            pending[b] = None
+        rc = H.la3dm_bgk_scan_device(ctx, C.byref(scans[b]), stream, None)
         if rc != 0:
             raise RuntimeError(H.la3dm_last_error(ctx).decode())
         if world > 1:
             if selftest:
                 host = torch.zeros(world * cap * 9, dtype=torch.uint8)
-                dist.all_gather_into_tensor(host, payload.cpu())
-                gather_out.copy_(host)
+                dist.all_gather_into_tensor(host, payloads[b].cpu())
+                gather_out[b].copy_(host)
+            elif n_buf > 1:
+                pending[b] = dist.all_gather_into_tensor(gather_out[b], payloads[b], async_op=True)
             else:
-                dist.all_gather_into_tensor(gather_out, payload)
+                dist.all_gather_into_tensor(gather_out[b], payloads[b])
 
     def sync():
+        for b in range(n_buf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -237,7 +261,9 @@ def main():
                        "parallelism": ("single GPU" if world == 1 else
                                        "one scan, test blocks dealt round-robin to the ranks + RCCL all-gather of leaf "
                                        "(alpha,beta,state)" if shard_mode else
-                                       "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)"), "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
+                                       "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)") +
+                                      (", gather of scan k under the kernel of scan k+1 (two leaf buffers)" if n_buf > 1 else ""),
+                       "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
                        "kernel_variant": args.variant, "waves_per_wg": args.waves, "remap": args.remap},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
