@@ -492,7 +492,7 @@ int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream
         ev = &ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(ctx, hipEventRecord(ev->first, stream));
     }
-    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(a.n_tasks), dim3(kWave), 0, stream, a);
+    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(a.n_tasks), dim3(kLvWaves * kWave), 0, stream, a);
     if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
     HIP_TRY(ctx, hipGetLastError());
     if (out) out->n_tiles = a.n_tasks;

@@ -6,9 +6,9 @@
 //   covSparseLine                    include/bgklvoctomap/bgklvinference.h:143-156 (r = min(d/ell, 1), no < 0 clamp)
 //   LV Occupancy                     src/bgklvoctomap/bgklvoctree_node.cpp:29-77
 //
-// One wave64 = one 4x4x4 cube of base-resolution voxels = 64 consecutive nodes of the finest layer =
-// one bucket of the gather grid.  Lane = voxel.  The wave walks the (2r+1)^3 buckets around its own
-// z-major; a bucket's samples are loaded 64 at a time (lane = sample, coalesced 16 B), culled against
+// One workgroup = one 4x4x4 cube of base-resolution voxels = 64 consecutive nodes of the finest layer =
+// one bucket of the gather grid.  Lane = voxel.  The workgroup walks the (2r+1)^3 buckets around its own
+// z-major; a bucket's samples are loaded 64 per wave (lane = sample, coalesced 16 B), culled against
 // the cube's +-ell box, ballot-compacted in order into LDS together with what the de-duplication needs
 // (previous sample of the same ray, segment end points), and then every lane tests each staged sample
 // against its own closed +-ell box.  A hit adds one row; a ray adds one row at its lowest-index sample
@@ -89,9 +89,25 @@ struct __attribute__((aligned(16))) LvCand {
     float4 r1;    // segment end
 };
 
-__global__ __launch_bounds__(kWave) void bgklv_voxel_kernel(LvArgs a) {
-    __shared__ LvCand s_c[kWave];
-    const int lane = threadIdx.x;
+// One workgroup of kLvWaves waves per cube.  Every wave stages its own 64 samples of a bucket (ordered compaction
+// across the waves through LDS), then the staged candidates are evaluated kLvWaves at a time — wave w takes
+// candidates w, w + kLvWaves, ... of a 64-candidate round, lane = voxel, and writes {k or +0, k * y or +0} into a
+// dense [candidate][voxel] tile — and wave 0 adds the tile row by row: the cube next to the sensor, which sees every
+// beam, spreads its distance / kernel evaluations over the CU's four SIMDs while the two running sums keep the
+// gather order (adding +0 leaves a sum that started at +0 unchanged: it can never be -0).
+constexpr int kLvWaves = 8;
+
+struct LvLds {
+    LvCand cand[kLvWaves * kWave];
+    float k[kWave][kWave];
+    float ky[kWave][kWave];
+    uint32_t cnt[kLvWaves];
+    uint32_t info[kLvWaves][kWave];
+};
+
+__global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) {
+    __shared__ LvLds L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t task = blockIdx.x;
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.cubes_shift;
@@ -110,8 +126,9 @@ __global__ __launch_bounds__(kWave) void bgklv_voxel_kernel(LvArgs a) {
     const float inf = __builtin_inff();
     const float tlx = wave_min_dpp(active ? lox : inf), tly = wave_min_dpp(active ? loy : inf), tlz = wave_min_dpp(active ? loz : inf);
     const float thx = wave_max_dpp(active ? hix : -inf), thy = wave_max_dpp(active ? hiy : -inf), thz = wave_max_dpp(active ? hiz : -inf);
-    if (!(tlx <= thx)) {  // no base-resolution leaf in this cube
-        if (in_range) a.state[ni] = 0;
+    __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
+    if (!(tlx <= thx)) {  // no base-resolution leaf in this cube (uniform over the workgroup)
+        if (wave == 0 && in_range) a.state[ni] = 0;
         return;
     }
     // bucket of this cube: the octree index interleaves (x, y, z) bits, coarsest first
@@ -135,9 +152,9 @@ __global__ __launch_bounds__(kWave) void bgklv_voxel_kernel(LvArgs a) {
                 if (x < 0 || y < 0 || z < 0 || x >= a.cell_dim[0] || y >= a.cell_dim[1] || z >= a.cell_dim[2]) continue;
                 const uint32_t cell = ((uint32_t)z * a.cell_dim[1] + (uint32_t)y) * a.cell_dim[0] + (uint32_t)x;
                 const uint32_t c0 = a.cell_off[cell], c1 = a.cell_off[cell + 1];
-                for (uint32_t base = c0; base < c1; base += kWave) {
-                    // stage: lane = sample
-                    const uint32_t si = base + lane;
+                for (uint32_t base = c0; base < c1; base += kLvWaves * kWave) {
+                    // stage: lane = sample, wave w takes samples [base + 64 w, base + 64 w + 64)
+                    const uint32_t si = base + (uint32_t)wave * kWave + lane;
                     bool keep = false;
                     LvCand c;
                     if (si < c1) {
@@ -160,41 +177,65 @@ __global__ __launch_bounds__(kWave) void bgklv_voxel_kernel(LvArgs a) {
                         }
                     }
                     const unsigned long long m = __ballot(keep);
-                    const int n = __popcll(m);
                     const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                    __builtin_amdgcn_wave_barrier();
-                    if (keep) s_c[slot] = c;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // test + evaluate: lane = voxel
-                    for (int j = 0; j < n; ++j) {
-                        const float4 p = s_c[j].p;
-                        const bool inb = active && !(lox > p.x || p.x > hix || loy > p.y || p.y > hiy || loz > p.z || p.z > hiz);
-                        if (!__any(inb)) continue;
-                        bool count = inb;
-                        float ax = p.x, ay = p.y, az = p.z, bx = p.x, by = p.y, bz = p.z, yv = 1.0f;
-                        if (p.w != 0.0f) {  // a ray sample (uniform): is it this ray's lowest-index sample in my box?
-                            const float4 r0 = s_c[j].r0, r1 = s_c[j].r1, pv = s_c[j].prev;
-                            ax = r0.x; ay = r0.y; az = r0.z; bx = r1.x; by = r1.y; bz = r1.z;
-                            yv = 0.0f;
-                            if (p.w == 2.0f) {
-                                const bool first_in = !(lox > r0.x || r0.x > hix || loy > r0.y || r0.y > hiy || loz > r0.z || r0.z > hiz);
-                                const bool prev_in = !(lox > pv.x || pv.x > hix || loy > pv.y || pv.y > hiy || loz > pv.z || pv.z > hiz);
-                                count = inb && !first_in && !prev_in;
+                    if (lane == 0) L.cnt[wave] = (uint32_t)__popcll(m);
+                    __syncthreads();
+                    uint32_t before = 0, total = 0;
+#pragma unroll
+                    for (int v = 0; v < kLvWaves; ++v) {
+                        const uint32_t cv = L.cnt[v];
+                        before += v < wave ? cv : 0u;
+                        total += cv;
+                    }
+                    if (keep) L.cand[before + slot] = c;
+                    __syncthreads();
+                    // rounds of 64 staged candidates: evaluate (all waves), then add in order (wave 0)
+                    for (uint32_t r0 = 0; r0 < total; r0 += kWave) {
+                        const uint32_t nr = min(total - r0, (uint32_t)kWave);
+                        for (uint32_t j = wave; j < nr; j += kLvWaves) {
+                            const LvCand &cd = L.cand[r0 + j];
+                            const float4 p = cd.p;
+                            const bool inb = active && !(lox > p.x || p.x > hix || loy > p.y || p.y > hiy || loz > p.z || p.z > hiz);
+                            float kv = 0.0f, kyv = 0.0f;
+                            if (__any(inb)) {
+                                bool count = inb;
+                                float ax = p.x, ay = p.y, az = p.z, bx = p.x, by = p.y, bz = p.z, yv = 1.0f;
+                                if (p.w != 0.0f) {  // a ray sample (uniform): is it this ray's lowest-index sample in my box?
+                                    const float4 q0 = cd.r0, q1 = cd.r1, pv = cd.prev;
+                                    ax = q0.x; ay = q0.y; az = q0.z; bx = q1.x; by = q1.y; bz = q1.z;
+                                    yv = 0.0f;
+                                    if (p.w == 2.0f) {
+                                        const bool first_in = !(lox > q0.x || q0.x > hix || loy > q0.y || q0.y > hiy || loz > q0.z || q0.z > hiz);
+                                        const bool prev_in = !(lox > pv.x || pv.x > hix || loy > pv.y || pv.y > hiy || loz > pv.z || pv.z > hiz);
+                                        count = inb && !first_in && !prev_in;
+                                    }
+                                }
+                                info |= inb;
+                                if (count) {
+                                    const float d = seg_dist_dev(cx, cy, cz, ax, ay, az, bx, by, bz);
+                                    kv = cov_sparse_line_dev(d, a.ell, a.sf2);
+                                    kyv = kv * yv;
+                                }
+                            }
+                            L.k[j][lane] = kv;
+                            L.ky[j][lane] = kyv;
+                        }
+                        __syncthreads();
+                        if (wave == 0) {
+                            for (uint32_t j = 0; j < nr; ++j) {
+                                ybar += L.ky[j][lane];
+                                kbar += L.k[j][lane];
                             }
                         }
-                        info |= inb;
-                        if (count) {
-                            const float d = seg_dist_dev(cx, cy, cz, ax, ay, az, bx, by, bz);
-                            const float kv = cov_sparse_line_dev(d, a.ell, a.sf2);
-                            ybar += kv * yv;
-                            kbar += kv;
-                        }
+                        __syncthreads();
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
-    if (!in_range) return;
+    L.info[wave][lane] = info ? 1u : 0u;
+    __syncthreads();
+    if (wave != 0 || !in_range) return;
+#pragma unroll
+    for (int v = 1; v < kLvWaves; ++v) info |= L.info[v][lane] != 0u;
     uint8_t out = info ? 0x40u : 0u;
     if (active && info && kbar > 0.001f) {  // bgklvoctomap.cpp:236-238
         float A = a.alpha[ni], B = a.beta[ni];
