@@ -8,10 +8,11 @@
 //   Occupancy::update             src/bgkloctomap/bgkloctree_node.cpp:31-44     (same node as BGKOctoMap)
 //
 // Training rows are 8 floats {x0, y0, z0, x1, y1, z1, label, 0}: hits are degenerate segments with label 1,
-// each beam that has a sample inside the block contributes its segment once with label 0.  One wave64 = one
-// leaf tile, lane = leaf; rows are wave-uniform (scalar loads); the distance runs on every lane, the kernel
-// evaluation only when some lane of the tile lies within ell of the segment.  Sums run in row order, so the
-// results are bit-identical to the CPU restatement.
+// each beam that has a sample inside the block contributes its segment once with label 0.  One workgroup = one
+// leaf tile, lane = leaf; the rows of a neighbour are evaluated eight at a time (one per wave, mixed f32/f64 segment
+// distance on every lane, k(d / ell) where the leaf is within ell) into a dense LDS tile and added in row order by
+// wave 0, so the results are bit-identical to the CPU restatement.  Tiles with very many rows (the blocks around
+// the sensor on large scans) take the split path further down.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -107,8 +108,18 @@ __device__ __forceinline__ void bgkl_store(const BgklArgs &a, uint32_t li, bool 
     }
 }
 
-__global__ __launch_bounds__(kWave) void bgkl_predict_fuse_kernel(BgklArgs a, const uint32_t *__restrict__ task_item) {
-    const int lane = threadIdx.x;
+// One workgroup of kW waves per tile: the rows of a neighbour are taken 64 at a time, wave w evaluates rows
+// w, w + kW, ... (lane = leaf) into a dense [row][leaf] LDS tile ({k or +0}, {k * label or +0}), wave 0 adds the
+// tile row by row — the distance tests and kernel evaluations of a tile spread over the CU's four SIMDs, the two
+// running sums keep the row order (a sum that starts at +0 can never be -0, so adding +0 changes nothing).
+// kW = 8 when the scan has few tiles (each is a serial chain and the GPU is mostly empty: latency counts), kW = 1
+// (no LDS, rows straight into the sums) when there are many (the launch is throughput-bound).
+constexpr int kLWaves = 8;
+constexpr uint32_t kLWideTiles = 4096;
+
+template <int kW>
+__global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a, const uint32_t *__restrict__ task_item) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t task = blockIdx.x;
     if (task >= a.n_tasks) return;
     if (task_item && task_item[2 * task] != 0xFFFFFFFFu) return;  // split tile
@@ -124,25 +135,54 @@ __global__ __launch_bounds__(kWave) void bgkl_predict_fuse_kernel(BgklArgs a, co
         if (tb < 0) continue;
         const uint32_t r0 = __builtin_amdgcn_readfirstlane(a.row_off[tb]), r1 = __builtin_amdgcn_readfirstlane(a.row_off[tb + 1]);
         float ybar = 0.0f, kbar = 0.0f;
-        for (uint32_t j = r0; j < r1; ++j) {
-            const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j);       // x0 y0 z0 x1
-            const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j + 4);   // y1 z1 label -
-            const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-            const bool hit = active && d < a.ell;  // d >= ell  =>  d / ell >= 1  =>  the kernel is <= 0 and cleaned to 0
-            if (__ballot(hit) == 0ull) continue;
-            if (hit) {
-                const float kv = cov_sparse<true, 0>(d / a.ell, a.sf2);
-                ybar += kv * p1.z;
-                kbar += kv;
+        if constexpr (kW == 1) {  // one wave: rows in order, straight into the sums
+            for (uint32_t j = r0; j < r1; ++j) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j);       // x0 y0 z0 x1
+                const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j + 4);   // y1 z1 label -
+                const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                const bool hit = active && d < a.ell;  // d >= ell  =>  d / ell >= 1  =>  the kernel is <= 0 and cleaned to 0
+                if (__ballot(hit) == 0ull) continue;
+                if (hit) {
+                    const float kv = cov_sparse<true, 0>(d / a.ell, a.sf2);
+                    ybar += kv * p1.z;
+                    kbar += kv;
+                }
+            }
+        } else {
+            __shared__ float s_k[kWave][kWave];
+            __shared__ float s_ky[kWave][kWave];
+            for (uint32_t q = r0; q < r1; q += kWave) {
+                const uint32_t nr = min(r1 - q, (uint32_t)kWave);
+                for (uint32_t j = wave; j < nr; j += kW) {
+                    const size_t row = (size_t)q + j;
+                    const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * row);
+                    const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
+                    const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                    float kv = 0.0f, kyv = 0.0f;
+                    if (active && d < a.ell) {
+                        kv = cov_sparse<true, 0>(d / a.ell, a.sf2);
+                        kyv = kv * p1.z;
+                    }
+                    s_k[j][lane] = kv;
+                    s_ky[j][lane] = kyv;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    for (uint32_t j = 0; j < nr; ++j) {
+                        ybar += s_ky[j][lane];
+                        kbar += s_k[j][lane];
+                    }
+                }
+                __syncthreads();
             }
         }
-        if (kbar > 0.001f) {  // bgkloctomap.cpp:226-227
+        if (kbar > 0.001f) {  // bgkloctomap.cpp:226-227 (only wave 0 holds the sums)
             A += ybar;
             B += kbar - ybar;
             updated = true;
         }
     }
-    bgkl_store(a, li, active, updated, A, B);
+    if (wave == 0) bgkl_store(a, li, active, updated, A, B);
 }
 
 __global__ void bgkl_split_mark(BgklArgs a, BgklSplit s) {

@@ -108,3 +108,18 @@ def test_split_tiles(built, rows, depth):
     _same(m, o, f"split rows>{rows} d{depth} synthetic")
     m.insert_pointcloud(np.zeros((0, 3), np.float32), origin, 0.1, 0.3, 8.0)
     _same(m, o, "empty after split")
+
+
+def test_many_tiles_one_wave_per_tile(built):
+    """above 4096 tiles the row-serial kernel runs one wave per tile (throughput form) instead of eight (latency form):
+    a scan large enough to take that launch, with the tiles around the sensor on the split path"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.L_YAML)
+    m = la3dm_amd.BGKLOctoMap(**params, device=0)
+    o = O.OracleLMap(**params, omp=True)
+    xyz, origin = la3dm_amd.synthetic_scan(20000)
+    m.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    assert m.stats()["n_test_blocks"] > 4096
+    _same(m, o, "20k rays")
