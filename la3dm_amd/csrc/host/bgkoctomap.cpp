@@ -1108,11 +1108,21 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
 
     // bounding box of the training set, candidate block list (float-stepped, repeats kept)
     float lo[3] = {xy[0], xy[1], xy[2]}, hi[3] = {xy[0], xy[1], xy[2]};
-    for (size_t i = 1; i < npts; ++i)
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], xy[4 * i + a]);
-            hi[a] = std::max(hi[a], xy[4 * i + a]);
+    {
+        float l0 = lo[0], l1 = lo[1], l2 = lo[2], h0 = hi[0], h1 = hi[1], h2 = hi[2];
+#pragma omp parallel for num_threads(npts > 100000 ? kHostThreads : 1) schedule(static) reduction(min : l0, l1, l2) reduction(max : h0, h1, h2)
+        for (long i = 1; i < (long)npts; ++i) {
+            const float *p = &xy[4 * (size_t)i];
+            l0 = std::min(l0, p[0]);
+            l1 = std::min(l1, p[1]);
+            l2 = std::min(l2, p[2]);
+            h0 = std::max(h0, p[0]);
+            h1 = std::max(h1, p[1]);
+            h2 = std::max(h2, p[2]);
         }
+        lo[0] = l0; lo[1] = l1; lo[2] = l2;
+        hi[0] = h0; hi[1] = h1; hi[2] = h2;
+    }
     std::vector<BlockHashKey> bbox_keys;
     for (float x = lo[0] - bs; x <= hi[0] + 2 * bs; x += bs)
         for (float y = lo[1] - bs; y <= hi[1] + 2 * bs; y += bs)
@@ -1243,31 +1253,87 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
     for (auto &t : test) max_occ = std::max(max_occ, t.second);
     passes.resize(test.empty() ? 0 : max_occ + 1);
     stats.voxel_updates = stats.train_reads = stats.pair_evals = 0;
-    for (auto &t : test) {
-        Pass &ps = passes[t.second];
-        auto bit = block_arr.find(t.first);
-        if (bit == block_arr.end()) bit = block_arr.emplace(t.first, new Block(hash_key_to_block(t.first))).first;
-        Block *blk = bit->second;
-        ps.keys.push_back(t.first);
-        ps.blocks.push_back(blk);
-        const point3f c = blk->get_center();
-        ps.center.insert(ps.center.end(), {c.x(), c.y(), c.z()});
-        const ExtendedBlock e = blk->get_extended_block();
-        uint64_t npts_nb = 0;
-        for (int q = 0; q < 7; ++q) {
-            auto it = in_bbox.find(e[q]);
-            const int32_t tb = it == in_bbox.end() ? -1 : it->second;
-            ps.nbr.push_back(tb);
-            if (tb >= 0) npts_nb += train_off[tb + 1] - train_off[tb];
+    // find or create the blocks (bgkoctomap.cpp:298-305): look-ups and insertions in list order on one thread, the
+    // constructors of the missing ones (a node slab each) on the team
+    const long ntest = (long)test.size();
+    std::vector<Block *> tblk((size_t)ntest, nullptr);
+    {
+        std::vector<long> missing;
+        std::unordered_map<BlockHashKey, long> first_missing;
+        for (long t = 0; t < ntest; ++t) {
+            auto bit = block_arr.find(test[(size_t)t].first);
+            if (bit != block_arr.end()) tblk[(size_t)t] = bit->second;
+            else if (first_missing.emplace(test[(size_t)t].first, t).second) missing.push_back(t);
         }
-        if (ps.leaf_off.empty()) ps.leaf_off.push_back(0u);
-        const size_t before = ps.leaf_key.size();
-        blk->collect_leaves(ps.leaf_key);
-        const size_t nl = ps.leaf_key.size() - before;
-        ps.leaf_off.push_back((uint32_t)ps.leaf_key.size());
-        stats.voxel_updates += nl;
-        stats.train_reads += npts_nb;
-        stats.pair_evals += npts_nb * nl;
+#pragma omp parallel for num_threads(kHostThreads) schedule(static)
+        for (long k = 0; k < (long)missing.size(); ++k) {
+            const long t = missing[(size_t)k];
+            tblk[(size_t)t] = new Block(hash_key_to_block(test[(size_t)t].first));
+        }
+        for (long t : missing) block_arr.emplace(test[(size_t)t].first, tblk[(size_t)t]);
+        for (long t = 0; t < ntest; ++t)
+            if (tblk[(size_t)t] == nullptr) tblk[(size_t)t] = tblk[(size_t)first_missing[test[(size_t)t].first]];
+    }
+    // position of every test block inside its pass, then neighbour table / centre / leaf count on the team
+    std::vector<uint32_t> pos((size_t)ntest), nleaf((size_t)ntest);
+    for (long t = 0; t < ntest; ++t) {
+        Pass &ps = passes[test[(size_t)t].second];
+        pos[(size_t)t] = (uint32_t)ps.blocks.size();
+        ps.keys.push_back(test[(size_t)t].first);
+        ps.blocks.push_back(tblk[(size_t)t]);
+    }
+    for (Pass &ps : passes) {
+        ps.center.resize(3 * ps.blocks.size());
+        ps.nbr.resize(7 * ps.blocks.size());
+        ps.leaf_off.assign(ps.blocks.size() + 1, 0u);
+    }
+    uint64_t sum_reads = 0, sum_pairs = 0, sum_leaves = 0;
+#pragma omp parallel num_threads(kHostThreads) reduction(+ : sum_reads, sum_pairs, sum_leaves)
+    {
+        std::vector<uint32_t> scratch;
+#pragma omp for schedule(static)
+        for (long t = 0; t < ntest; ++t) {
+            Pass &ps = passes[test[(size_t)t].second];
+            const uint32_t b = pos[(size_t)t];
+            Block *blk = tblk[(size_t)t];
+            const point3f c = blk->get_center();
+            ps.center[3 * (size_t)b] = c.x();
+            ps.center[3 * (size_t)b + 1] = c.y();
+            ps.center[3 * (size_t)b + 2] = c.z();
+            const ExtendedBlock e = blk->get_extended_block();
+            uint64_t npts_nb = 0;
+            for (int q = 0; q < 7; ++q) {
+                auto it = in_bbox.find(e[q]);
+                const int32_t tb = it == in_bbox.end() ? -1 : it->second;
+                ps.nbr[7 * (size_t)b + q] = tb;
+                if (tb >= 0) npts_nb += train_off[tb + 1] - train_off[tb];
+            }
+            scratch.clear();
+            blk->collect_leaves(scratch);
+            nleaf[(size_t)t] = (uint32_t)scratch.size();
+            ps.leaf_off[(size_t)b + 1] = (uint32_t)scratch.size();
+            sum_leaves += scratch.size();
+            sum_reads += npts_nb;
+            sum_pairs += npts_nb * scratch.size();
+        }
+    }
+    stats.voxel_updates = sum_leaves;
+    stats.train_reads = sum_reads;
+    stats.pair_evals = sum_pairs;
+    for (Pass &ps : passes) {
+        for (size_t b = 0; b < ps.blocks.size(); ++b) ps.leaf_off[b + 1] += ps.leaf_off[b];
+        ps.leaf_key.resize(ps.leaf_off.back());
+    }
+#pragma omp parallel num_threads(kHostThreads)
+    {
+        std::vector<uint32_t> scratch;
+#pragma omp for schedule(static)
+        for (long t = 0; t < ntest; ++t) {
+            Pass &ps = passes[test[(size_t)t].second];
+            scratch.clear();
+            tblk[(size_t)t]->collect_leaves(scratch);
+            std::memcpy(ps.leaf_key.data() + ps.leaf_off[pos[(size_t)t]], scratch.data(), scratch.size() * sizeof(uint32_t));
+        }
     }
     for (Pass &ps : passes) {
         const size_t nl = ps.leaf_key.size();
