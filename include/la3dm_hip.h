@@ -215,7 +215,9 @@ int la3dm_diag_mfma_chain(la3dm_ctx *ctx, const float *A, const float *B, int K,
  * covSparseLine :186-200) + the update loop gated on kbar > 0.001 (src/bgkloctomap/bgkloctomap.cpp:206-231).
  * Same la3dm_bgk_scan layout, except that train_xyzy holds ROWS OF 8 FLOATS {x0,y0,z0, x1,y1,z1, label, 0}
  * (hits = degenerate segments with label 1; one row per beam and block with label 0), n_train_pts = number of
- * rows and train_off is the CSR over training blocks in rows. */
+ * rows and train_off is the CSR over training blocks in rows.  The device form enqueues on `stream`; it waits for
+ * the stream once (item count) and, when some tile exceeds "bgkl_split_rows", a second time (value count) to size
+ * the scratch of the split path — set the option < 0 for a call that never blocks. */
 int la3dm_bgkl_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out);
 int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream, la3dm_bgk_counters *out);
 
