@@ -258,6 +258,10 @@ int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint
 int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
                                           float ds_resolution, float free_resolution, float max_range,
                                           la3dm_devmap_stats *stats);
+/* BGKOctoMap::insert_training_data (src/bgkoctomap/bgkoctomap.cpp:82-212) on the pool: n labelled points
+ * {x, y, z, label} (host pointer) take the place of the front end's output; every leaf of every test block is updated
+ * for every neighbour model (LA3DM_SCAN_UPDATE_UNGATED), then the test blocks are pruned. */
+int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats);
 int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nodes_per_block);
 /* keys[n_blocks]; A, B, S [n_blocks * nodes_per_block], node order = depth-major (8^d - 1)/7 + index;
  * S: bits 0-2 State (FREE 0, OCCUPIED 1, UNKNOWN 2, PRUNED 3), bit 7 = classified */

@@ -301,6 +301,20 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     delete dm;
 }
 
+// bbox of the training set in dm->xy (bbox(), bgkoctomap.cpp:464-484) -> dm->h_bbox; get_blocks_in_bbox walks it on
+// the host.  One synchronisation.
+static int training_bbox(la3dm_devmap *dm) {
+    hipStream_t st = dm->ctx->stream;
+    const uint32_t npts = dm->n_xy;
+    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)dm->xy.ptr, npts,
+                       dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox);
+    DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
 // f1 (bgkoctomap.cpp:383-458): voxel grid over the hits, range gate + beam samples, voxel grid over the free samples;
 // leaves the labelled training set in dm->xy (hits first), its size in dm->n_xy, and the scan's bbox in dm->h_bbox.
 static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3], float ds_resolution,
@@ -350,14 +364,7 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     S.n_hits = n_kept;
     S.n_frees = n_f;
 
-    // bbox of the training set (get_blocks_in_bbox walks it on the host)
-    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)xy, npts,
-                       dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox);
-    DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
-    DM_TRY(hipStreamSynchronize(st));
-    return LA3DM_OK;
+    return training_bbox(dm);
 }
 
 // Host-side facts of the scan in flight, shared by the partition and the passes.
@@ -370,6 +377,7 @@ struct ScanPlan {
     uint32_t n_mem = 0;      // (block, point) membership pairs = gathered training rows
     uint32_t n_geo = 0;      // training blocks
     uint32_t *train_off = nullptr;
+    uint32_t flags = 0;      // la3dm_bgk_scan.flags of the passes (LA3DM_SCAN_UPDATE_UNGATED for insert_training_data)
 };
 
 // f2 (bgkoctomap.cpp:234-284, 486-552): candidate sequences of get_blocks_in_bbox, closed-box membership of every
@@ -605,7 +613,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.alpha = (float *)dm->leaf_alpha.ptr;
     s.beta = (float *)dm->leaf_beta.ptr;
     s.state = (uint8_t *)dm->leaf_state.ptr;
-    s.flags = 0;
+    s.flags = P.flags;
     rc = ctx->p.variant == 1 ? la3dm_gp_scan_device(ctx, &s, st, nullptr) : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
     if (rc != LA3DM_OK) return rc;
     double tp2 = tp1;
@@ -638,22 +646,11 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     return LA3DM_OK;
 }
 
-int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
-                                          float ds_resolution, float free_resolution, float max_range,
-                                          la3dm_devmap_stats *stats_out) {
-    if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
-    la3dm_ctx *ctx = dm->ctx;
-    DM_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+// Stages B..G on the training set in dm->xy (partition, passes, deferred prune); t0 = start of the call.
+static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_devmap_stats *stats_out) {
+    hipStream_t st = dm->ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
-    memset(&S, 0, sizeof(S));
-    S.n_blocks = dm->n_blocks;
-    dm->n_xy = 0;
-    const double t0 = wall();
     int rc;
-    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
-
-    if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
     if (dm->n_xy == 0) {  // empty cloud, or every hit beyond max_range
         if (stats_out) *stats_out = S;
         return LA3DM_OK;
@@ -661,6 +658,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     const double t1 = wall();
     S.t_frontend = t1 - t0;
     ScanPlan P;
+    P.flags = flags;
     if ((rc = partition(dm, P)) != LA3DM_OK) return rc;
     S.t_partition = wall() - t1;
     DM_RESERVE(dm->c_weight, 4ull * P.n_entries);
@@ -678,6 +676,51 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     if (!getenv("LA3DM_TIMING")) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit
     if (stats_out) *stats_out = S;
     return LA3DM_OK;
+}
+
+// BGKOctoMap::insert_training_data (bgkoctomap.cpp:82-212) on the pool: n labelled points {x, y, z, label} (host
+// pointer) instead of a scan; every leaf of every test block is updated for every neighbour model (no kbar gate).
+int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats_out) {
+    if (!dm || (n && !xyzy)) return LA3DM_ERR_ARG;
+    la3dm_ctx *ctx = dm->ctx;
+    DM_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    memset(&S, 0, sizeof(S));
+    S.n_blocks = dm->n_blocks;
+    dm->n_xy = 0;
+    const double t0 = wall();
+    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+    if (n == 0) {  // bgkoctomap.cpp:83-84
+        if (stats_out) *stats_out = S;
+        return LA3DM_OK;
+    }
+    DM_RESERVE(dm->xy, 16ull * n);
+    DM_TRY(hipMemcpyAsync(dm->xy.ptr, xyzy, 16ull * n, hipMemcpyHostToDevice, st));
+    dm->n_xy = n;
+    for (uint32_t i = 0; i < n; ++i) (xyzy[4 * (size_t)i + 3] > 0.5f ? S.n_hits : S.n_frees)++;
+    int rc = training_bbox(dm);
+    if (rc != LA3DM_OK) return rc;
+    return scan_training_set(dm, LA3DM_SCAN_UPDATE_UNGATED, t0, stats_out);
+}
+
+int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
+                                          float ds_resolution, float free_resolution, float max_range,
+                                          la3dm_devmap_stats *stats_out) {
+    if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
+    la3dm_ctx *ctx = dm->ctx;
+    DM_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    memset(&S, 0, sizeof(S));
+    S.n_blocks = dm->n_blocks;
+    dm->n_xy = 0;
+    const double t0 = wall();
+    int rc;
+    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+
+    if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
+    return scan_training_set(dm, 0u, t0, stats_out);
 }
 
 int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride, const float origin[3],

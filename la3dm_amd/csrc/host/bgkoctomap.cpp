@@ -475,8 +475,8 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     if (rc != LA3DM_OK)
         throw std::runtime_error(std::string("BGKOctoMap: GPU context creation failed: ") + la3dm_last_error(nullptr));
     // Device-resident by default where it exists (BGK and GP maps, block_depth <= 5): insert_pointcloud then runs
-    // start to finish on the GPU.  insert_training_data and the split prepare()/commit() form move the map back to
-    // the host-orchestrated mode on their own (ensure_host_mode).  LA3DM_DEVICE_RESIDENT=0 keeps the host mode.
+    // start to finish on the GPU (insert_training_data too).  The split prepare()/commit() form moves the map back to
+    // the host-orchestrated mode on its own (ensure_host_mode).  LA3DM_DEVICE_RESIDENT=0 keeps the host mode.
     const char *env = getenv("LA3DM_DEVICE_RESIDENT");
     if ((variant == 0 || variant == 1) && block_depth <= 5 && !(env && env[0] == '0')) {
         if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK) dmap = nullptr;
@@ -1461,6 +1461,23 @@ bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated
     return partition_and_pack(ungated);
 }
 
+void BGKOctoMap::take_device_stats(const la3dm_devmap_stats &ds) {
+    stats = ScanStats();
+    stats.n_hits = ds.n_hits;
+    stats.n_frees = ds.n_frees;
+    stats.n_bbox_blocks = ds.n_bbox_blocks;
+    stats.n_train_blocks = ds.n_train_blocks;
+    stats.n_test_blocks = ds.n_test_blocks;
+    stats.voxel_updates = ds.voxel_updates;
+    stats.train_reads = ds.train_reads;
+    stats.pair_evals = ds.pair_evals;
+    stats.t_frontend = ds.t_frontend;
+    stats.t_partition = ds.t_partition;
+    stats.t_pack = ds.t_pack;
+    stats.t_device = ds.t_kernel;
+    stats.t_commit = ds.t_commit;
+}
+
 void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                                    float free_res, float max_range) {
     const double t0 = wall();
@@ -1471,20 +1488,7 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
         if (la3dm_devmap_insert_pointcloud_host(dmap, xyz, (uint32_t)n, (uint32_t)stride, o, ds_resolution, free_res, max_range,
                                                 &ds) != LA3DM_OK)
             throw std::runtime_error(std::string("BGKOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
-        stats = ScanStats();
-        stats.n_hits = ds.n_hits;
-        stats.n_frees = ds.n_frees;
-        stats.n_bbox_blocks = ds.n_bbox_blocks;
-        stats.n_train_blocks = ds.n_train_blocks;
-        stats.n_test_blocks = ds.n_test_blocks;
-        stats.voxel_updates = ds.voxel_updates;
-        stats.train_reads = ds.train_reads;
-        stats.pair_evals = ds.pair_evals;
-        stats.t_frontend = ds.t_frontend;
-        stats.t_partition = ds.t_partition;
-        stats.t_pack = ds.t_pack;
-        stats.t_device = ds.t_kernel;
-        stats.t_commit = ds.t_commit;
+        take_device_stats(ds);
         stats.t_total = wall() - t0;
         mirror_dirty = true;
         return;
@@ -1506,10 +1510,18 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
 void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: no device context (there is no CPU path)");
-    ensure_host_mode();
     std::vector<float> flat;
     flat.reserve(cloud.size() * 4);
     for (const GPPointType &p : cloud) flat.insert(flat.end(), {p.first.x(), p.first.y(), p.first.z(), p.second});
+    if (dmap != nullptr) {  // device-resident mode
+        la3dm_devmap_stats ds;
+        if (la3dm_devmap_insert_training_data_host(dmap, flat.data(), (uint32_t)cloud.size(), &ds) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKOctoMap::insert_training_data: ") + la3dm_last_error(ctx));
+        take_device_stats(ds);
+        stats.t_total = wall() - t0;
+        mirror_dirty = true;
+        return;
+    }
     if (!prepare_training_data(flat.data(), cloud.size(), true)) return;
     const double t1 = wall();
     {

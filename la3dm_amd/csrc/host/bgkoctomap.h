@@ -326,6 +326,7 @@ public:
     void ensure_host_mode();
     bool is_device_resident() const { return dmap != nullptr; }
     void sync_mirror() const;
+    void take_device_stats(const la3dm_devmap_stats &ds);
     /// training set (x, y, z, label) the device front end produced for the last scan
     std::vector<float> device_training_data() const;
     const std::vector<float> &last_training_data() const { return xy; }  // x,y,z,label

@@ -659,8 +659,10 @@ double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Stages B..G of BGKOctoMap::insert_pointcloud, src/bgkoctomap/bgkoctomap.cpp:229-366
-void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr) {
+// Stages B..G of BGKOctoMap::insert_pointcloud, src/bgkoctomap/bgkoctomap.cpp:229-366; with `ungated` the same
+// stages as BGKOctoMap::insert_training_data runs them (:82-212): node.update for every leaf of a test block and
+// every neighbour model, whatever kbar is (:179-185).
+void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr, bool ungated = false) {
     const Params &p = m.p;
     Stats &st = m.st;
     if (xy.empty()) return;  // :230-232
@@ -814,7 +816,7 @@ void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr) {
             bgk_predict(p.sf2, p.ell, xs.data(), M, bx.data(), by.data(), N, ybar.data(), kbar.data());
             for (int j = 0; j < M; ++j) {
                 Node &node = block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF];
-                if (kbar[j] > 0.0) {  // :331-333
+                if (kbar[j] > 0.0 || ungated) {  // :331-333
                     node_update(p, node, ybar[j], kbar[j]);
                     calls_ += 1;
                 }
@@ -1039,6 +1041,17 @@ float orc_l_seg_dist(const float *p, const float *p0, const float *p1) {
     return seg_dist_l(V3{p[0], p[1], p[2]}, V3{p0[0], p0[1], p0[2]}, V3{p1[0], p1[1], p1[2]});
 }
 // stages B..G on a prepared training set (x,y,z,label per point)
+void orc_insert_training_data(void *h, const float *xyzy, int64_t n) {
+    Map *m = (Map *)h;
+    std::vector<XY> xy(n);
+    double nh = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        xy[i] = XY{V3{xyzy[4 * i], xyzy[4 * i + 1], xyzy[4 * i + 2]}, xyzy[4 * i + 3]};
+        nh += xyzy[4 * i + 3] > 0.5f;
+    }
+    m->st.n_hits = nh; m->st.n_frees = (double)n - nh; m->st.t_frontend = 0;
+    insert_xy(*m, xy, nullptr, true);
+}
 void orc_insert_xy(void *h, const float *xyzy, int64_t n) {
     Map *m = (Map *)h;
     double t0 = now_s();

@@ -110,6 +110,7 @@ def _load(name):
     lib.orc_l_seg_dist.restype = C.c_float
     lib.orc_l_seg_dist.argtypes = [f32p, f32p, f32p]
     lib.orc_insert_xy.argtypes = [C.c_void_p, f32p, C.c_int64]
+    lib.orc_insert_training_data.argtypes = [C.c_void_p, f32p, C.c_int64]
     lib.orc_stats.argtypes = [C.c_void_p, f64p]
     lib.orc_num_threads.restype = C.c_int
     lib.orc_block_count.restype = C.c_int64
@@ -206,6 +207,11 @@ class OracleMap:
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         origin = np.ascontiguousarray(origin, np.float32)
         self.L.orc_insert_pointcloud(self.h, xyz, xyz.shape[0], origin, ds_resolution, free_res, max_range)
+
+    def insert_training_data(self, xyzy):
+        """BGKOctoMap::insert_training_data: the scan stages from a labelled set, updates not gated on kbar"""
+        xyzy = np.ascontiguousarray(xyzy, np.float32).reshape(-1, 4)
+        self.L.orc_insert_training_data(self.h, xyzy, xyzy.shape[0])
 
     def insert_xy(self, xyzy):
         xyzy = np.ascontiguousarray(xyzy, np.float32).reshape(-1, 4)

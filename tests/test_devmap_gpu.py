@@ -383,3 +383,33 @@ def test_leaf_export_on_the_device_pool(built, depth, gp):
         h.insert_pointcloud(xyz if not gp else xyz[::3], origin, 0.1, 0.5, 8.0)
     for state in ("occupied", "free"):
         assert (_sorted_cells(h.export_cells(state, False)) == _sorted_cells(m.export_cells(state, False))).all()
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_insert_training_data_on_the_pool(built, depth):
+    """BGKOctoMap::insert_training_data (labelled points instead of a scan, updates not gated on kbar) on the
+    device-resident pool == the oracle's restatement == the host-orchestrated mode, bit for bit; scans and labelled
+    sets interleave on the same map"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+    m, o = _maps(params)
+    h = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    xy = O.get_training_data(xyz, origin, 0.1, 0.5, 8.0)            # a realistic labelled set: scan 1's training data
+    for mm in (m, o, h):
+        mm.insert_training_data(xy)
+    assert m.is_device_resident() and not h.is_device_resident()
+    _same(m, o, "training data")
+    _same(h, o, "training data, host mode")
+    lv = m.leaves()
+    assert lv["classified"].mean() > 0.95       # ungated: every leaf of a test block (collapsed parents lose the flag)
+    xyz2, origin2 = la3dm_amd.load_pcd(pcd_path("sim_structured", 2))
+    for mm in (m, o, h):
+        mm.insert_pointcloud(xyz2, origin2, 0.1, 0.5, 8.0)
+    pts = np.array([[0.3, 0.2, 0.1, 1.0], [0.35, 0.2, 0.1, 0.0], [5.0, 5.0, 1.0, 1.0]], np.float32)
+    for mm in (m, o, h):
+        mm.insert_training_data(pts)
+        mm.insert_training_data(np.zeros((0, 4), np.float32))
+    _same(m, o, "interleaved")
+    _same(h, o, "interleaved, host mode")
