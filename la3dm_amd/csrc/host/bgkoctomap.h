@@ -318,10 +318,11 @@ public:
     // ---- device-resident mode: the block pool lives in HBM and a scan runs start
     // to finish on the GPU (front end, partition, predict + fuse, write-back, prune — include/la3dm_hip.h,
     // la3dm_devmap_*).  The host blocks become a mirror that is refreshed lazily, the first time a query
-    // (search, begin_leaf, get_bbox, block_count) follows a scan.  This is the DEFAULT for BGK and GP maps with
-    // a GPU context (block_depth <= 5; LA3DM_DEVICE_RESIDENT=0 disables it).  insert_training_data and the split
-    // prepare()/commit() form are host-orchestrated: calling them moves the map to the host mode for good
-    // (the pool is downloaded once).  Results are bit-identical in both modes.
+    // (search, begin_leaf, block_count) follows a scan; get_bbox, search_many and export_cells are answered from
+    // the pool without a refresh.  This is the DEFAULT for BGK and GP maps with a GPU context (block_depth <= 5;
+    // LA3DM_DEVICE_RESIDENT=0 disables it); insert_pointcloud and insert_training_data both run on the pool.  The
+    // split prepare()/commit() form is host-orchestrated: calling it moves the map to the host mode for good (the
+    // pool is downloaded once).  Results are bit-identical in both modes.
     void set_device_resident(bool on);
     void ensure_host_mode();
     bool is_device_resident() const { return dmap != nullptr; }
