@@ -111,7 +111,9 @@ static int read_counters(la3dm_devmap *dm) {
 
 // pcl::VoxelGrid centroid filter (bgkoctomap.cpp:419-431) on the device.  d_in: n packed xyz; the result is
 // written to `out` (reserved here) and its point count returned.  One read-back (cell count).
-static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out) {
+// key_bits: number of low key bits that can differ between cells (32 = unknown); must satisfy
+// cell count <= 2^key_bits - 1 so that the all-ones key of a non-finite point still sorts behind every cell.
+static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out, int key_bits = 32) {
     hipStream_t st = dm->ctx->stream;
     *n_out = 0;
     if (n == 0) return LA3DM_OK;
@@ -129,7 +131,7 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), 512)), dim3(256), 0, st, d_in, n, dm->d_mm);
     hipLaunchKernelGGL(dm_grid_params, dim3(1), dim3(64), 0, st, dm->d_mm, inv, dm->d_gp);
     hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
-    int rc = sort_pairs(dm, k0, k1, v0, v1, n, 32);
+    int rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
     if (rc != LA3DM_OK) return rc;
     DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGridValid, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(dm_heads, dim3(cdiv(n, 256)), dim3(256), 0, st, k1, n, flag, dm->d_cnt, (int)kCntGridValid);
@@ -325,9 +327,26 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     int rc;
     const float *d_hits = d_xyz;
     uint32_t n_h = n;
+    int free_key_bits = 32;
     if (!(ds_resolution < 0)) {
         if ((rc = voxel_grid(dm, d_xyz, n, ds_resolution, dm->hits, &n_h)) != LA3DM_OK) return rc;
         d_hits = (const float *)dm->hits.ptr;
+        // The free samples lie between the origin and a (downsampled) hit, i.e. inside the box of the raw hits and
+        // the origin, give or take an ulp: their grid has at most (that box + one cell on every side) cells, which
+        // bounds the significant bits of their sort keys (one Onesweep pass per 8 bits).
+        const GridParams &g = *dm->h_gp;
+        if (!g.passthrough && !g.empty) {
+            const float inv = 1.0f / ds_resolution;
+            double cells = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                const double oc = floor((double)origin[a] * (double)inv);
+                const double lo = std::min((double)g.lo[a], oc) - 1.0, hi = std::max((double)g.lo[a] + g.span[a] - 1.0, oc) + 1.0;
+                cells *= hi - lo + 1.0;
+            }
+            int b = 1;
+            while (b < 32 && (double)((1ull << b) - 1ull) < cells) ++b;
+            free_key_bits = b;
+        }
     }
     if (n_h == 0) return LA3DM_OK;
     DM_RESERVE(dm->keep, 4ull * n_h);
@@ -353,7 +372,7 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     const float *d_frees = (const float *)dm->frees_raw.ptr;
     uint32_t n_f = n_free_raw;
     if (!(ds_resolution < 0)) {
-        if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f)) != LA3DM_OK) return rc;
+        if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f, free_key_bits)) != LA3DM_OK) return rc;
         d_frees = (const float *)dm->frees_ds.ptr;
     }
     const float free_label = ctx->p.variant == 1 ? -1.0f : 0.0f;  // bgkoctomap.cpp:415 / gpoctomap.cpp:399

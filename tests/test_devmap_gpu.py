@@ -241,10 +241,12 @@ def test_edge_cases(built):
     m.insert_pointcloud(np.repeat(pts, 5, axis=0), [0.05, 0, 0], 0.1, 0.3, -1.0)   # duplicates + a NaN point
     o.insert_pointcloud(np.repeat(pts, 5, axis=0), [0.05, 0, 0], 0.1, 0.3, -1.0)
     _same(m, o, "dups")
-    # insert_training_data is host-orchestrated: the call moves the map out of the device-resident mode (one download
-    # of the pool) and keeps the content
+    # an empty labelled set is a no-op on the pool; the split prepare()/commit() form is host-orchestrated: the call
+    # moves the map out of the device-resident mode (one download of the pool) and keeps the content
     before = m.leaves()
     m.insert_training_data(np.zeros((0, 4), np.float32))
+    assert m.is_device_resident()
+    m.prepare(np.zeros((0, 3), np.float32), [0, 0, 0], 0.1, 0.5, 8.0)
     assert not m.is_device_resident()
     after = m.leaves()
     assert all((before[k] == after[k]).all() for k in before)
