@@ -228,10 +228,12 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
  *   f1  get_training_data (:383-417), beam_sample (:433-458), downsample (:419-431, pcl::VoxelGrid)
  *   f2  bbox / get_blocks_in_bbox (:464-495), closed-box gather (:497-552, rtree.h:1519-1532),
  *       ExtendedBlock (bgkblock.cpp:85-130), block creation (:298-305)
- *   E   la3dm_bgk_scan_device / la3dm_gp_scan_device (above)
+ *   E   la3dm_bgk_scan_device / la3dm_gp_scan_device / la3dm_bgkl_scan_device (above)
  *   f3  leaf enumeration (bgkoctree.h:62-147), node write-back, OcTree::prune (bgkoctree.cpp:101-148)
  * Only the cloud goes in; the host reads nodes back on demand (la3dm_devmap_download).  Results are
- * bit-identical to the host-orchestrated path.  Works for variant 0 (BGK) and 1 (GP) contexts. */
+ * bit-identical to the host-orchestrated path.  Works for variant 0 (BGK), 1 (GP) and 3 (BGK-L: the front end of
+ * src/bgkloctomap/bgkloctomap.cpp:300-381 and the training rows of :141-170 take the place of f1 / the gather)
+ * contexts. */
 typedef struct la3dm_devmap la3dm_devmap;
 
 typedef struct la3dm_devmap_stats {

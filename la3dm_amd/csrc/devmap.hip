@@ -53,6 +53,7 @@ struct la3dm_devmap {
     Arena train, grid, axis_tab, m_code, q_out;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
+    Arena l_ray_idx, l_rays, l_rows, l_rows_off, l_rflag, l_rscan;  // BGKLOctoMap: beam of every sample, beam segments, training rows
     uint32_t n_xy = 0;
     la3dm_devmap_stats stats;
 };
@@ -244,8 +245,8 @@ extern "C" {
 int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     if (!ctx || !out) return LA3DM_ERR_ARG;
     *out = nullptr;
-    if (ctx->p.variant != 0 && ctx->p.variant != 1) {
-        ctx->err = "la3dm_devmap_create: the device-resident map supports variant 0 (BGK) and 1 (GP)";
+    if (ctx->p.variant != 0 && ctx->p.variant != 1 && ctx->p.variant != 3) {
+        ctx->err = "la3dm_devmap_create: the device-resident map supports variant 0 (BGK), 1 (GP) and 3 (BGK-L)";
         return LA3DM_ERR_ARG;
     }
     if (ctx->p.block_depth > 5) {  // dm_prune stages 3 bytes per node of a block in LDS
@@ -356,6 +357,25 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     BeamArgs ba = {origin[0], origin[1], origin[2], free_resolution, max_range};
     uint32_t *keep = (uint32_t *)dm->keep.ptr, *nfree = (uint32_t *)dm->nfree.ptr, *keep_off = (uint32_t *)dm->keep_off.ptr,
              *free_off = (uint32_t *)dm->free_off.ptr;
+    if (ctx->p.variant == 3) {  // BGKLOctoMap: samples keep their beam, no second voxel filter
+        hipLaunchKernelGGL(dm_l_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree);
+        if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
+        if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
+        hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, keep_off, keep, n_h, dm->d_cnt, (int)kCntKept);
+        hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        const uint32_t n_beams = dm->h_cnt[kCntKept], n_samples = dm->h_cnt[kCntFreeRaw];
+        if (n_beams == 0) return LA3DM_OK;
+        DM_RESERVE(dm->xy, 16ull * n_samples);
+        DM_RESERVE(dm->l_ray_idx, 4ull * n_samples);
+        DM_RESERVE(dm->l_rays, 24ull * n_beams);
+        hipLaunchKernelGGL(dm_l_beam_write, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, keep_off, free_off,
+                           (float4 *)dm->xy.ptr, (int32_t *)dm->l_ray_idx.ptr, (float *)dm->l_rays.ptr);
+        dm->n_xy = n_samples;
+        S.n_hits = n_beams;
+        S.n_frees = n_samples - n_beams;
+        return training_bbox(dm);
+    }
     hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree);
     if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
     if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
@@ -396,6 +416,7 @@ struct ScanPlan {
     uint32_t n_mem = 0;      // (block, point) membership pairs = gathered training rows
     uint32_t n_geo = 0;      // training blocks
     uint32_t *train_off = nullptr;
+    uint32_t *rows_off = nullptr;  // BGKLOctoMap: CSR of the training rows over the training blocks
     uint32_t flags = 0;      // la3dm_bgk_scan.flags of the passes (LA3DM_SCAN_UPDATE_UNGATED for insert_training_data)
 };
 
@@ -511,9 +532,24 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     if ((rc = exclusive_scan(dm, sflag, sscan, n_mem)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_seg_starts, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, k1, sflag, sscan, n_mem, train_off, seg_key,
                        dm->d_cnt, (int)kCntGeo, (int)kCntGridValid);
-    DM_RESERVE(dm->train, 16ull * n_mem);
-    hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, v1, n_mem,
-                       (float4 *)dm->train.ptr);
+    if (ctx->p.variant == 3) {  // training rows: hits as degenerate segments, every beam once per block
+        DM_RESERVE(dm->l_rflag, 4ull * n_mem);
+        DM_RESERVE(dm->l_rscan, 4ull * n_mem);
+        DM_RESERVE(dm->l_rows, 32ull * n_mem);
+        DM_RESERVE(dm->l_rows_off, 4ull * ((size_t)n_mem + 2));
+        uint32_t *rflag = (uint32_t *)dm->l_rflag.ptr, *rscan = (uint32_t *)dm->l_rscan.ptr;
+        hipLaunchKernelGGL(dm_l_row_flags, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, v1, sflag, n_mem,
+                           (const int32_t *)dm->l_ray_idx.ptr, rflag);
+        if ((rc = exclusive_scan(dm, rflag, rscan, n_mem)) != LA3DM_OK) return rc;
+        hipLaunchKernelGGL(dm_l_rows_write, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, v1, n_mem, rflag, rscan, xy,
+                           (const int32_t *)dm->l_ray_idx.ptr, (const float *)dm->l_rays.ptr, (float4 *)dm->l_rows.ptr);
+        hipLaunchKernelGGL(dm_l_rows_off, dim3(cdiv((size_t)n_mem + 1, 256)), dim3(256), 0, st, train_off, dm->d_cnt, rflag, rscan,
+                           n_mem, (uint32_t *)dm->l_rows_off.ptr);
+        P.rows_off = (uint32_t *)dm->l_rows_off.ptr;
+    } else {
+        DM_RESERVE(dm->train, 16ull * n_mem);
+        hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, v1, n_mem, (float4 *)dm->train.ptr);
+    }
     DM_RESERVE(dm->grid, 4ull * ncid);
     DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
     hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
@@ -602,8 +638,12 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                        (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
-                       (const uint32_t *)nleaf, n_test, dm->d_cnt);
+    if (ctx->p.variant == 3)
+        hipLaunchKernelGGL(dm_l_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
+                           (const uint32_t *)P.rows_off, (const uint32_t *)nleaf, n_test, dm->d_cnt);
+    else
+        hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
+                           (const uint32_t *)nleaf, n_test, dm->d_cnt);
     if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
     hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
@@ -622,6 +662,10 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.train_xyzy = (const float *)dm->train.ptr;
     s.train_off = train_off;
     s.n_train_pts = n_mem;
+    if (ctx->p.variant == 3) {  // rows of 8 floats; n_mem bounds their number
+        s.train_xyzy = (const float *)dm->l_rows.ptr;
+        s.train_off = P.rows_off;
+    }
     s.n_train_blk = n_geo;
     s.nbr = (const int32_t *)dm->t_nbr.ptr;
     s.blk_center = (const float *)dm->t_center.ptr;
@@ -633,7 +677,9 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.beta = (float *)dm->leaf_beta.ptr;
     s.state = (uint8_t *)dm->leaf_state.ptr;
     s.flags = P.flags;
-    rc = ctx->p.variant == 1 ? la3dm_gp_scan_device(ctx, &s, st, nullptr) : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
+    rc = ctx->p.variant == 1   ? la3dm_gp_scan_device(ctx, &s, st, nullptr)
+         : ctx->p.variant == 3 ? la3dm_bgkl_scan_device(ctx, &s, st, nullptr)
+                               : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
     if (rc != LA3DM_OK) return rc;
     double tp2 = tp1;
     if (getenv("LA3DM_TIMING")) {
@@ -702,6 +748,7 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
 int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats_out) {
     if (!dm || (n && !xyzy)) return LA3DM_ERR_ARG;
     la3dm_ctx *ctx = dm->ctx;
+    if (ctx->p.variant == 3) return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_insert_training_data: a BGK-L map needs beams, not labelled points");
     DM_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;

@@ -492,6 +492,142 @@ __global__ __launch_bounds__(256) void dm_beam_write(const float *__restrict__ h
     }
 }
 
+// ---- BGKLOctoMap front end (src/bgkloctomap/bgkloctomap.cpp:300-343, beam_sample :359-381): a hit is re-projected
+// as origin + n * l, its free samples step DOWN from l - free_resolution while d > 0 (no second voxel filter), every
+// sample of a beam — the origin sample first — remembers its beam, and the beam itself is the segment
+// origin -> origin + n * (l - free_resolution).  Per kept hit, in order: {hit, origin sample, free samples}.
+struct LBeam {
+    float ex, ey, ez;  // re-projected end point
+    float nx, ny, nz;  // direction
+    float l;           // range
+    float mx, my, mz;  // direction of the re-projected end point
+    float l2;          // its range
+};
+__device__ __forceinline__ LBeam l_beam(float x, float y, float z, const BeamArgs &a) {
+    LBeam b;
+    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+    b.l = f32_sqrt_cr(dx * dx + dy * dy + dz * dz);
+    b.nx = dx / b.l;
+    b.ny = dy / b.l;
+    b.nz = dz / b.l;
+    b.ex = a.ox + b.nx * b.l;
+    b.ey = a.oy + b.ny * b.l;
+    b.ez = a.oz + b.nz * b.l;
+    const float fx = b.ex - a.ox, fy = b.ey - a.oy, fz = b.ez - a.oz;
+    b.l2 = f32_sqrt_cr(fx * fx + fy * fy + fz * fz);
+    b.mx = fx / b.l2;
+    b.my = fy / b.l2;
+    b.mz = fz / b.l2;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void dm_l_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
+                                                      uint32_t *nsamp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
+    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+    const float s = dx * dx + dy * dy + dz * dz;
+    bool k = true;
+    if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);  // see dm_beam_count
+    uint32_t c = 0;
+    if (k) {
+        const LBeam b = l_beam(x, y, z, a);
+        c = 2;  // the re-projected hit and the origin sample
+        for (float d = b.l2 - a.free_res; d > 0.0f; d -= a.free_res) ++c;
+    }
+    keep[i] = k ? 1u : 0u;
+    nsamp[i] = c;
+}
+
+__global__ __launch_bounds__(256) void dm_l_beam_write(const float *__restrict__ hits, uint32_t n, BeamArgs a,
+                                                      const uint32_t *__restrict__ keep, const uint32_t *__restrict__ beam_of,
+                                                      const uint32_t *__restrict__ samp_off, float4 *xy, int32_t *ray_idx,
+                                                      float *rays) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const LBeam b = l_beam(hits[3 * (size_t)i], hits[3 * (size_t)i + 1], hits[3 * (size_t)i + 2], a);
+    const int32_t id = (int32_t)beam_of[i];
+    size_t w = samp_off[i];
+    xy[w] = make_float4(b.ex, b.ey, b.ez, 1.0f);
+    ray_idx[w++] = -1;
+    xy[w] = make_float4(a.ox, a.oy, a.oz, 0.0f);
+    ray_idx[w++] = id;
+    for (float d = b.l2 - a.free_res; d > 0.0f; d -= a.free_res) {
+        xy[w] = make_float4(a.ox + b.mx * d, a.oy + b.my * d, a.oz + b.mz * d, 0.0f);
+        ray_idx[w++] = id;
+    }
+    const float l = b.l - a.free_res;
+    float *r = rays + 6 * (size_t)id;
+    r[0] = a.ox; r[1] = a.oy; r[2] = a.oz;
+    r[3] = a.ox + b.nx * l; r[4] = a.oy + b.ny * l; r[5] = a.oz + b.nz * l;
+}
+
+// Training rows of every block (bgkloctomap.cpp:141-170): a hit becomes a degenerate segment with label 1, a beam
+// contributes its segment once per block.  The members of a block are in ascending sample order and the samples of
+// one beam are consecutive, so "once per block" = "differs from the previous member's beam".
+__global__ __launch_bounds__(256) void dm_l_row_flags(const uint32_t *__restrict__ member_pt, const uint32_t *__restrict__ head,
+                                                     uint32_t n_mem, const int32_t *__restrict__ ray_idx, uint32_t *rflag) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_mem) return;
+    const int32_t r = ray_idx[member_pt[k]];
+    rflag[k] = (r < 0 || head[k] || ray_idx[member_pt[k - 1]] != r) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void dm_l_rows_write(const uint32_t *__restrict__ member_pt, uint32_t n_mem,
+                                                      const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ rscan,
+                                                      const float4 *__restrict__ xy, const int32_t *__restrict__ ray_idx,
+                                                      const float *__restrict__ rays, float4 *rows) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_mem || !rflag[k]) return;
+    const uint32_t src = member_pt[k];
+    const int32_t r = ray_idx[src];
+    float4 *o = rows + 2 * (size_t)rscan[k];
+    if (r < 0) {
+        const float4 p = xy[src];
+        o[0] = make_float4(p.x, p.y, p.z, p.x);
+        o[1] = make_float4(p.y, p.z, 1.0f, 0.0f);
+    } else {
+        const float *q = rays + 6 * (size_t)r;
+        o[0] = make_float4(q[0], q[1], q[2], q[3]);
+        o[1] = make_float4(q[4], q[5], 0.0f, 0.0f);
+    }
+}
+
+// CSR of the rows over the training blocks: rows_off[b] = rows before the block's first member
+__global__ __launch_bounds__(256) void dm_l_rows_off(const uint32_t *__restrict__ train_off, const uint32_t *__restrict__ counters,
+                                                    const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ rscan,
+                                                    uint32_t n_mem, uint32_t *rows_off) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_geo = counters[kCntGeo];
+    if (b > n_geo) return;
+    rows_off[b] = b < n_geo ? rscan[train_off[b]] : rscan[n_mem - 1] + rflag[n_mem - 1];
+}
+
+// work counters of a pass in rows (what the oracle counts for this variant)
+__global__ __launch_bounds__(256) void dm_l_test_stats(const int32_t *__restrict__ nbr, const uint32_t *__restrict__ rows_off,
+                                                      const uint32_t *__restrict__ nleaf, uint32_t n_test, uint32_t *counters) {
+    unsigned long long *acc_reads = reinterpret_cast<unsigned long long *>(counters + kCntTrainReads);
+    unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long w = 0, pw = 0;
+    if (t < n_test) {
+        for (int q = 0; q < 7; ++q) {
+            const int32_t tb = nbr[7 * (size_t)t + q];
+            if (tb >= 0) w += rows_off[tb + 1] - rows_off[tb];
+        }
+        pw = w * nleaf[t];
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        w += __shfl_xor(w, o);
+        pw += __shfl_xor(pw, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (w | pw)) {
+        atomicAdd(acc_reads, w);
+        atomicAdd(acc_pairs, pw);
+    }
+}
+
 // total = off[n-1] + cnt[n-1] of an exclusive scan
 __global__ void dm_scan_total(const uint32_t *off, const uint32_t *cnt, uint32_t n, uint32_t *counters, int slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -478,7 +478,7 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     // start to finish on the GPU (insert_training_data too).  The split prepare()/commit() form moves the map back to
     // the host-orchestrated mode on its own (ensure_host_mode).  LA3DM_DEVICE_RESIDENT=0 keeps the host mode.
     const char *env = getenv("LA3DM_DEVICE_RESIDENT");
-    if ((variant == 0 || variant == 1) && block_depth <= 5 && !(env && env[0] == '0')) {
+    if ((variant == 0 || variant == 1 || variant == 3) && block_depth <= 5 && !(env && env[0] == '0')) {
         if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK) dmap = nullptr;
     }
 }
@@ -1513,7 +1513,7 @@ void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
     std::vector<float> flat;
     flat.reserve(cloud.size() * 4);
     for (const GPPointType &p : cloud) flat.insert(flat.end(), {p.first.x(), p.first.y(), p.first.z(), p.second});
-    if (dmap != nullptr) {  // device-resident mode
+    if (dmap != nullptr && variant != 3) {  // device-resident mode (a BGK-L map has no beams for a labelled set)
         la3dm_devmap_stats ds;
         if (la3dm_devmap_insert_training_data_host(dmap, flat.data(), (uint32_t)cloud.size(), &ds) != LA3DM_OK)
             throw std::runtime_error(std::string("BGKOctoMap::insert_training_data: ") + la3dm_last_error(ctx));

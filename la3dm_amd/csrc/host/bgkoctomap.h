@@ -319,7 +319,7 @@ public:
     // to finish on the GPU (front end, partition, predict + fuse, write-back, prune — include/la3dm_hip.h,
     // la3dm_devmap_*).  The host blocks become a mirror that is refreshed lazily, the first time a query
     // (search, begin_leaf, block_count) follows a scan; get_bbox, search_many and export_cells are answered from
-    // the pool without a refresh.  This is the DEFAULT for BGK and GP maps with a GPU context (block_depth <= 5;
+    // the pool without a refresh.  This is the DEFAULT for BGK, GP and BGK-L maps with a GPU context (block_depth <= 5;
     // LA3DM_DEVICE_RESIDENT=0 disables it); insert_pointcloud and insert_training_data both run on the pool.  The
     // split prepare()/commit() form is host-orchestrated: calling it moves the map to the host mode for good (the
     // pool is downloaded once).  Results are bit-identical in both modes.

@@ -3,7 +3,8 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, la3dm_amd
 from oracle import oracle as O
 # BGK-L at a size where the split path carries the tiles around the sensor (threshold 4096 rows)
-xyz, origin = la3dm_amd.synthetic_scan(30000)
+nrays = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+xyz, origin = la3dm_amd.synthetic_scan(nrays)
 m = la3dm_amd.BGKLOctoMap(**la3dm_amd.L_YAML, device=0)
 o = O.OracleLMap(**la3dm_amd.L_YAML, omp=True)
 for rep in range(2):
@@ -12,4 +13,4 @@ for rep in range(2):
 a, b = m.leaves(), o.leaves()
 ok = a["A"].size == b["A"].size and all((a[k] == b[k]).all() for k in ("block_key", "node_key", "state", "classified")) \
     and (a["A"].view(np.uint32) == b["A"].view(np.uint32)).all() and (a["B"].view(np.uint32) == b["B"].view(np.uint32)).all()
-print("bgkl 30000 rays: leaves", a["A"].size, "bit-identical", bool(ok), "gpu %.4f s  cpu(omp) %.2f s" % (t1 - t0, t2 - t1), flush=True)
+print("bgkl", nrays, "rays device-resident", m.is_device_resident(), ": leaves", a["A"].size, "bit-identical", bool(ok), "gpu %.4f s  cpu(omp) %.2f s" % (t1 - t0, t2 - t1), flush=True)

@@ -1,4 +1,5 @@
-"""GPU parity tests of BGKLOctoMap: block-level BGK with free-space line segments.
+"""GPU parity tests of BGKLOctoMap: block-level BGK with free-space line segments, in the
+default device-resident mode (the whole insert_pointcloud on the GPU) and in the host-orchestrated mode.
 
 HIP path (la3dm_bgkl_scan_* through the map class) vs the CPU oracle restatement of
 src/bgkloctomap/bgkloctomap.cpp + include/bgkloctomap/bgklinference.h.  The sums run in row order and sin/cos are
@@ -13,10 +14,13 @@ from conftest import pcd_path
 pytestmark = pytest.mark.gpu
 
 
-def _maps(params):
+def _maps(params, resident=True):
     import la3dm_amd
     from oracle import oracle as O
-    return la3dm_amd.BGKLOctoMap(**params, device=0), O.OracleLMap(**params)
+    m = la3dm_amd.BGKLOctoMap(**params, device=0)
+    assert m.is_device_resident()                      # the default: front end, rows, partition, prune on the GPU too
+    m.set_device_resident(resident)
+    return m, O.OracleLMap(**params)
 
 
 def _same(m, o, tag=""):
@@ -123,3 +127,26 @@ def test_many_tiles_one_wave_per_tile(built):
     o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
     assert m.stats()["n_test_blocks"] > 4096
     _same(m, o, "20k rays")
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_host_orchestrated_mode(built, depth):
+    """the same scans through the host-orchestrated path (host front end / partition / rows, la3dm_bgkl_scan_host):
+    same bits as the oracle, hence as the device-resident mode"""
+    import la3dm_amd
+    params = dict(la3dm_amd.L_YAML, block_depth=depth)
+    m, o = _maps(params, resident=False)
+    assert not m.is_device_resident()
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        st, so = m.stats(), o.stats()
+        for k in ("n_hits", "n_frees", "n_train_blocks", "n_test_blocks", "voxel_updates", "pair_evals", "train_reads"):
+            assert st[k] == so[k], (i, k, st[k], so[k])
+    _same(m, o, f"host mode d{depth}")
+    xyz, origin = la3dm_amd.synthetic_scan(6000)
+    m.set_option("bgkl_split_rows", 300)
+    m.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    _same(m, o, "host mode synthetic")

@@ -35,6 +35,7 @@ def test_bgkl_random(built):
                       ell=float(rng.choice([1.5, 2.0, 3.0])) * res, free_thresh=0.3, occupied_thresh=0.7,
                       var_thresh=float(rng.choice([0.15, 100.0])), prior_A=0.001, prior_B=0.001)
         m, o = la3dm_amd.BGKLOctoMap(**params, device=0), O.OracleLMap(**params)
+        m.set_device_resident(case % 2 == 0)            # both modes: the GPU front end / rows and the host ones
         for scan in range(3):
             pts, origin = _scene(rng, res)
             ds = float(rng.choice([-1.0, res]))
