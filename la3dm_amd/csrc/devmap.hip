@@ -55,6 +55,7 @@ struct la3dm_devmap {
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
     Arena l_ray_idx, l_rays, l_rows, l_rows_off, l_rflag, l_rscan;  // BGKLOctoMap: beam of every sample, beam segments, training rows
     uint32_t n_xy = 0;
+    bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
     la3dm_devmap_stats stats;
 };
 
@@ -268,6 +269,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         dm->init_B = ctx->p.prior_B;
     }
     memset(&dm->stats, 0, sizeof(dm->stats));
+    dm->stage_timing = getenv("LA3DM_TIMING") != nullptr;
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 8) == hipSuccess &&
@@ -651,7 +653,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
                        (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
                        (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr);
     double tp1 = tp0;
-    if (getenv("LA3DM_TIMING")) {
+    if (dm->stage_timing) {
         DM_TRY(hipStreamSynchronize(st));
         tp1 = wall();
         S.t_pack += tp1 - tp0;
@@ -682,7 +684,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
                                : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
     if (rc != LA3DM_OK) return rc;
     double tp2 = tp1;
-    if (getenv("LA3DM_TIMING")) {
+    if (dm->stage_timing) {
         DM_TRY(hipStreamSynchronize(st));
         tp2 = wall();
         S.t_kernel += tp2 - tp1;
@@ -707,7 +709,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     S.voxel_updates += dm->h_cnt[kCntLeaves];
     S.train_reads = (uint64_t)dm->h_cnt[kCntTrainReads] | ((uint64_t)dm->h_cnt[kCntTrainReads + 1] << 32);
     S.pair_evals = (uint64_t)dm->h_cnt[kCntPairEvals] | ((uint64_t)dm->h_cnt[kCntPairEvals + 1] << 32);
-    if (getenv("LA3DM_TIMING")) S.t_commit += wall() - tp2;
+    if (dm->stage_timing) S.t_commit += wall() - tp2;
     return LA3DM_OK;
 }
 
@@ -738,7 +740,7 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
     if (max_occ > 1) DM_TRY(hipStreamSynchronize(st));  // (single pass: the pass's own read-back was the last sync)
     S.n_blocks = dm->n_blocks;
     S.t_total = wall() - t0;
-    if (!getenv("LA3DM_TIMING")) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit
+    if (!dm->stage_timing) S.t_pack = S.t_total - S.t_frontend - S.t_partition;  // pack + kernel + commit, unsplit
     if (stats_out) *stats_out = S;
     return LA3DM_OK;
 }
