@@ -63,6 +63,9 @@ const char *la3dm_map_last_error(void);
 /* insert_pointcloud(cloud, origin, ds_resolution, free_res, max_range); xyz packed, 3 floats per point */
 int la3dm_map_insert_pointcloud(la3dm_map *m, const float *xyz, uint64_t n, const float *origin3, float ds_resolution,
                                 float free_res, float max_range);
+/* the same for a cloud that already lives in HBM on the map's device (n packed xyz triples); device-resident maps only */
+int la3dm_map_insert_pointcloud_device(la3dm_map *m, const float *d_xyz, uint64_t n, const float *origin3, float ds_resolution,
+                                       float free_resolution, float max_range);
 /* insert_training_data(GPPointCloud): x,y,z,label per point */
 int la3dm_map_insert_training_data(la3dm_map *m, const float *xyzy, uint64_t n);
 

@@ -74,7 +74,7 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_devmap_export_cells", "la3dm_devmap_key_bounds",
                "la3dm_devmap_insert_training_data_host"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
-               "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud",
+               "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud", "la3dm_map_insert_pointcloud_device",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
                "la3dm_map_packed", "la3dm_map_commit", "la3dm_map_ctx", "la3dm_map_stats", "la3dm_map_training_size",
                "la3dm_map_training_data", "la3dm_map_block_size", "la3dm_map_block_count", "la3dm_map_leaf_count",
@@ -193,6 +193,8 @@ def maplib():
         M.la3dm_map_is_device_resident.restype = C.c_int
         M.la3dm_map_is_device_resident.argtypes = [C.c_void_p]
         M.la3dm_map_last_error.restype = C.c_char_p
+        M.la3dm_map_insert_pointcloud_device.restype = C.c_int
+        M.la3dm_map_insert_pointcloud_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, f32p, C.c_float, C.c_float, C.c_float]
         M.la3dm_map_insert_pointcloud.restype = C.c_int
         M.la3dm_map_insert_pointcloud.argtypes = [C.c_void_p, f32p, C.c_uint64, f32p, C.c_float, C.c_float, C.c_float]
         M.la3dm_map_insert_training_data.restype = C.c_int

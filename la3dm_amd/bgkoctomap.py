@@ -93,6 +93,13 @@ class BGKOctoMap:
         self._chk(self._M.la3dm_map_insert_pointcloud(self._h, xyz, xyz.shape[0], o, ds_resolution, free_res,
                                                       max_range))
 
+    def insert_pointcloud_device(self, d_xyz, n, origin, ds_resolution, free_res=2.0, max_range=-1.0):
+        """insert_pointcloud for a cloud already in HBM: d_xyz = device address of n packed float32 xyz triples on the
+        map's GPU (e.g. torch_tensor.data_ptr() of a contiguous (n, 3) float32 CUDA tensor); device-resident maps only."""
+        o = np.ascontiguousarray(origin, np.float32)
+        self._chk(self._M.la3dm_map_insert_pointcloud_device(self._h, int(d_xyz), int(n), o, ds_resolution, free_res, max_range))
+        return self
+
     def insert_training_data(self, xyzy):
         """BGKOctoMap::insert_training_data(GPPointCloud) (bgkoctomap.h:86, bgkoctomap.cpp:82-212): rows x, y, z, label;
         every leaf of every test block is updated (no kbar gate)."""

@@ -1507,6 +1507,19 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
     stats.t_total = wall() - t0;
 }
 
+void BGKOctoMap::insert_pointcloud_device(const float *d_xyz, size_t n, const point3f &origin, float ds_resolution, float free_res,
+                                          float max_range) {
+    const double t0 = wall();
+    if (dmap == nullptr) throw std::runtime_error("BGKOctoMap::insert_pointcloud_device: the map is not device resident");
+    const float o[3] = {origin.x(), origin.y(), origin.z()};
+    la3dm_devmap_stats ds;
+    if (la3dm_devmap_insert_pointcloud_device(dmap, d_xyz, (uint32_t)n, o, ds_resolution, free_res, max_range, &ds) != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKOctoMap::insert_pointcloud_device: ") + la3dm_last_error(ctx));
+    take_device_stats(ds);
+    stats.t_total = wall() - t0;
+    mirror_dirty = true;
+}
+
 void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: no device context (there is no CPU path)");

@@ -293,6 +293,10 @@ public:
     /// Pre-labelled training points (y = 1 hit, 0 free); updates are not gated on kbar
     /// (reference bgkoctomap.cpp:82-212, without its null dereference).
     void insert_training_data(const GPPointCloud &xy);
+    /// insert_pointcloud for a cloud that already lives in HBM (n packed xyz triples on the map's device): the
+    /// device-resident mode only; nothing crosses PCIe but the scalars that size the launches.
+    void insert_pointcloud_device(const float *d_xyz, size_t n, const point3f &origin, float ds_resolution,
+                                  float free_res = 2.0f, float max_range = -1);
 
     void get_bbox(point3f &lim_min, point3f &lim_max) const;
 

@@ -143,6 +143,11 @@ int la3dm_map_insert_pointcloud(la3dm_map *m, const float *xyz, uint64_t n, cons
     GUARD(m->map->insert_pointcloud(xyz, (size_t)n, 3, point3f(o[0], o[1], o[2]), ds, free_res, max_range); return 0;)
 }
 
+int la3dm_map_insert_pointcloud_device(la3dm_map *m, const float *d_xyz, uint64_t n, const float *o, float ds, float free_res,
+                                       float max_range) {
+    GUARD(m->map->insert_pointcloud_device(d_xyz, (size_t)n, point3f(o[0], o[1], o[2]), ds, free_res, max_range); return 0;)
+}
+
 int la3dm_map_insert_training_data(la3dm_map *m, const float *xyzy, uint64_t n) {
     GUARD(BGKOctoMap::GPPointCloud c; c.reserve(n);
           for (uint64_t i = 0; i < n; ++i)

@@ -415,3 +415,23 @@ def test_insert_training_data_on_the_pool(built, depth):
         mm.insert_training_data(np.zeros((0, 4), np.float32))
     _same(m, o, "interleaved")
     _same(h, o, "interleaved, host mode")
+
+
+def test_cloud_already_in_hbm(built):
+    """insert_pointcloud_device: the cloud is a device buffer (here a torch tensor); same map as the host-cloud call"""
+    import torch
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML)
+    a, o = _maps(params)
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        d = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).to("cuda:0")
+        torch.cuda.synchronize()
+        a.insert_pointcloud_device(d.data_ptr(), d.shape[0], origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        st, so = a.stats(), o.stats()
+        assert st["n_hits"] == so["n_hits"] and st["voxel_updates"] == so["voxel_updates"]
+    _same(a, o, "device cloud")
+    h = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
+    with pytest.raises(RuntimeError, match="not device resident"):
+        h.insert_pointcloud_device(d.data_ptr(), d.shape[0], origin, 0.1, 0.5, 8.0)
