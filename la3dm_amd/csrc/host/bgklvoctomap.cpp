@@ -295,10 +295,17 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
         return false;
     };
     const size_t npb = (size_t)1 << (3 * (depth - 1));
+    {   // the missing blocks' constructors (a node slab each) on the team, insertion in key order on one thread
+        std::vector<BlockHashKey> missing;
+        for (BlockHashKey k : keys)
+            if (block_arr.find(k) == block_arr.end()) missing.push_back(k);
+        std::vector<Block *> made(missing.size(), nullptr);
+#pragma omp parallel for num_threads(16) schedule(static)
+        for (long i = 0; i < (long)missing.size(); ++i) made[(size_t)i] = new Block(hash_key_to_block(missing[(size_t)i]));
+        for (size_t i = 0; i < missing.size(); ++i) block_arr.emplace(missing[i], made[i]);
+    }
     for (BlockHashKey k : keys) {
-        auto it = block_arr.find(k);
-        if (it == block_arr.end()) it = block_arr.emplace(k, new Block(hash_key_to_block(k))).first;
-        Block *blk = it->second;
+        Block *blk = block_arr.find(k)->second;
         const point3f c = blk->get_center();
         // lowest bucket of the block: its lower corner is c - size/2, i.e. bucket floor((c - size/2 + size/2)/g)
         const int64_t b0[3] = {(int64_t)std::llround((double)c.x() / g), (int64_t)std::llround((double)c.y() / g),
@@ -315,7 +322,9 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
     lv_alpha.resize(lv_blocks.size() * npb);
     lv_beta.resize(lv_blocks.size() * npb);
     lv_state.resize(lv_blocks.size() * npb);
-    for (size_t b = 0; b < lv_blocks.size(); ++b) {
+#pragma omp parallel for num_threads(16) schedule(static)
+    for (long bb = 0; bb < (long)lv_blocks.size(); ++bb) {
+        const size_t b = (size_t)bb;
         const OcTreeNode *layer = lv_blocks[b]->node_arr[depth - 1];
         for (size_t i = 0; i < npb; ++i) {
             lv_alpha[b * npb + i] = layer[i].m_A;
@@ -354,9 +363,10 @@ void BGKLVOctoMap::commit_lv() {
     const double t0 = wall();
     const unsigned depth = (unsigned)get_block_depth();
     const size_t npb = (size_t)1 << (3 * (depth - 1));
-    lvst.voxel_updates = 0;
-    lvst.n_info_blocks = 0;
-    for (size_t b = 0; b < lv_blocks.size(); ++b) {
+    uint64_t updates = 0, info_blocks = 0;
+#pragma omp parallel for num_threads(16) schedule(dynamic, 4) reduction(+ : updates, info_blocks)
+    for (long bb = 0; bb < (long)lv_blocks.size(); ++bb) {
+        const size_t b = (size_t)bb;
         OcTreeNode *layer = lv_blocks[b]->node_arr[depth - 1];
         bool info = false;
         for (size_t i = 0; i < npb; ++i) {
@@ -367,13 +377,15 @@ void BGKLVOctoMap::commit_lv() {
             layer[i].m_A = lv_alpha[b * npb + i];
             layer[i].m_B = lv_beta[b * npb + i];
             layer[i].state = state_from_lv(st & 7u);
-            ++lvst.voxel_updates;
+            ++updates;
         }
         if (info) {
-            ++lvst.n_info_blocks;
+            ++info_blocks;
             if (OcTreeNode::original_size) lv_blocks[b]->prune();
         }
     }
+    lvst.voxel_updates = updates;
+    lvst.n_info_blocks = info_blocks;
     lvst.t_commit = wall() - t0;
 }
 
