@@ -2,7 +2,6 @@ import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, la3dm_amd
 from conftest import pcd_path
-from oracle import oracle as O
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 for rows in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "-1,16384,4096,1024".split(","))]:
     for name, (xyz, origin), mr in (("sim_structured_1", la3dm_amd.load_pcd(pcd_path("sim_structured", 1)), 8.0),
