@@ -435,3 +435,22 @@ def test_cloud_already_in_hbm(built):
     h = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
     with pytest.raises(RuntimeError, match="not device resident"):
         h.insert_pointcloud_device(d.data_ptr(), d.shape[0], origin, 0.1, 0.5, 8.0)
+
+
+def test_config5_scan_at_full_size(built):
+    """BASELINE configs[4]'s scan (1 M rays, 0.05 m) on one GPU, device-resident: every leaf bit-identical to the
+    oracle (its OpenMP build: the restatement is the same code, the blocks are independent)"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.BGK_YAML, resolution=0.05)
+    xyz, origin = la3dm_amd.synthetic_scan(1000000)
+    m = la3dm_amd.BGKOctoMap(**params, device=0)
+    assert m.is_device_resident()
+    o = O.OracleMap(**params, omp=True)
+    m.insert_pointcloud(xyz, origin, 0.05, 0.5, -1.0)
+    o.insert_pointcloud(xyz, origin, 0.05, 0.5, -1.0)
+    st, so = m.stats(), o.stats()
+    for k in ("n_hits", "n_frees", "n_train_blocks", "n_test_blocks", "voxel_updates", "pair_evals", "train_reads"):
+        assert st[k] == so[k], (k, st[k], so[k])
+    assert st["voxel_updates"] > 15_000_000
+    _same(m, o, "1M rays @ 0.05 m")
