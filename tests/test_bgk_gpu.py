@@ -209,3 +209,41 @@ def test_cpp_example(built):
     for l, c in zip(*np.unique(occ["level"], return_counts=True)):
         assert f" [{l}] {c}" in lines[-2]
     assert lines[-1].startswith(f"free cubes {m.export_cells('free')['level'].size} by level:")
+
+
+def test_block_sharded_scan_through_the_kernel(built):
+    """configs[4]'s decomposition with the real kernel: one scan cut into 8 shards of test blocks (la3dm_amd/sharding.py),
+    every shard through la3dm_bgk_scan_host, the payloads reassembled as the all-gather would deliver them, commit +
+    prune: same map as the unsharded path and the oracle (the 2-rank gloo test covers the collective itself)"""
+    import ctypes as C
+    import la3dm_amd
+    from la3dm_amd import _lib, sharding
+    from oracle import oracle as O
+    world = 8
+    params = dict(la3dm_amd.BGK_YAML)
+    m = la3dm_amd.BGKOctoMap(**params, device=0)
+    o = O.OracleMap(**params)
+    H = _lib.hip()
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        assert m.prepare(xyz, origin, 0.1, 0.5, 8.0)           # (the split form: host-orchestrated mode)
+        pk = m.packed()
+        cap = max(sharding.shard_leaf_counts(pk, world))
+        gathered = np.zeros((world, 9 * cap), np.uint8)
+        for r in range(world):
+            sh = sharding.Shard(pk, r, world)
+            s = _lib.BgkScan()
+            keep = [np.ascontiguousarray(a) for a in (sh.train_xyzy, sh.train_off, sh.nbr, sh.blk_center, sh.leaf_off, sh.leaf_key)]
+            s.train_xyzy, s.train_off, s.nbr, s.blk_center, s.leaf_off, s.leaf_key = [a.ctypes.data for a in keep]
+            s.n_train_pts, s.n_train_blk, s.n_test_blk, s.n_leaf = sh.n_train_pts, sh.n_train_blk, sh.n_test_blk, sh.n_leaf
+            s.alpha, s.beta, s.state, s.flags = sh.alpha.ctypes.data, sh.beta.ctypes.data, sh.state.ctypes.data, sh.flags
+            assert H.la3dm_bgk_scan_host(m.ctx(), C.byref(s), None) == 0, H.la3dm_last_error(m.ctx())
+            gathered[r] = sharding.pack_payload(sh.alpha, sh.beta, sh.state, cap)
+        sharding.reassemble(pk, gathered, world)
+        m.commit()
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    a, b = m.leaves(), o.leaves()
+    for k in ("block_key", "node_key", "state", "classified"):
+        assert (a[k] == b[k]).all(), k
+    for k in ("A", "B"):
+        assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), k
