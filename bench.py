@@ -49,9 +49,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (kernel variant 3); 0 = library default")
     ap.add_argument("--remap", type=int, default=-1, help="workgroup->tile remap mode; -1 = library default")
-    ap.add_argument("--workload", choices=["bgk", "gp", "lv"], default="bgk",
+    ap.add_argument("--workload", choices=["bgk", "gp", "lv", "l"], default="bgk",
                     help="bgk = BASELINE configs[1] (default, the contract line); gp = configs[2] (GPOctoMap, 50k rays); "
-                         "lv = configs[3] (BGKLV, sim_unstructured scan, 0.05 m) — single-GPU side benches")
+                         "lv = configs[3] (BGKLV, sim_unstructured scan, 0.05 m), l = BGKLOctoMap insert (row f4) — single-GPU side benches")
     ap.add_argument("--mode", choices=["scans", "shard"], default="scans",
                     help="N>1 only. scans (default, weak scaling): one scan per GPU; shard (strong scaling, config-5 "
                          "style): ONE scan, its test blocks dealt round-robin to the ranks (la3dm_amd/sharding.py)")
@@ -308,6 +308,8 @@ def side_bench(args, torch, la3dm_amd, _lib):
         keep.append(t)
         return t.data_ptr()
 
+    if args.workload == "l":
+        return l_bench(args, torch, la3dm_amd)
     if args.workload == "gp":
         rays = 50000 if args.rays == 200000 else args.rays
         params = dict(la3dm_amd.GP_YAML, block_depth=args.depth, resolution=args.resolution)
@@ -392,6 +394,52 @@ def side_bench(args, torch, la3dm_amd, _lib):
         "config": dict({"workload": workload}, **extra),
         "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": peak_unit, "frac": achieved / peak,
                      "traffic": None, "kernel": kernel, "kernel_ms": k_ms}}))
+
+
+def l_bench(args, torch, la3dm_amd):
+    """BGKLOctoMap (row f4) at the insert level: whole insert_pointcloud calls of the synthetic scan on the
+    device-resident pool (front end with beam tags, rows, partition, predict + fuse incl. the split path, prune),
+    the CPU restatement on all cores beside it."""
+    params = dict(la3dm_amd.L_YAML, resolution=args.resolution, block_depth=args.depth)
+    xyz, origin = la3dm_amd.synthetic_scan(args.rays)
+    fr = 0.3
+    m = la3dm_amd.BGKLOctoMap(**params, device=0)
+    assert m.is_device_resident()
+    for _ in range(max(args.warmup, 1)):
+        m.insert_pointcloud(xyz, origin, args.resolution, fr, -1.0)
+    steps = min(args.steps, 20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.insert_pointcloud(xyz, origin, args.resolution, fr, -1.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = m.stats()
+    U, rows = int(st["voxel_updates"]), int(st["train_reads"])
+    b_alg = 32 * rows + 17 * U                     # a row (8 floats) per (tile, neighbour) pair + 17 B per leaf
+    out = {"metric": "voxel-updates/sec per scan; side bench", "value": U / dt, "unit": "voxel-updates/s", "n_gpus": 1,
+           "steps": steps, "warmup": max(args.warmup, 1), "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BGKLOctoMap synthetic {args.rays}-ray scan re-inserted, {args.resolution} m, block_depth "
+                                  f"{args.depth}, bgkloctomap.yaml, free_resolution {fr}; a step = one insert_pointcloud "
+                                  "(host cloud -> updated pool in HBM)",
+                      "voxel_updates_per_scan": U, "rows_read_per_scan": rows, "pair_evals_per_scan": int(st["pair_evals"]),
+                      "test_blocks": int(st["n_test_blocks"])},
+           "roofline": {"bound": "hbm", "achieved": b_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": b_alg / dt / 1e9 / 8000.0, "traffic": None, "kernel": "insert_pointcloud (all kernels)",
+                        "kernel_ms": dt * 1e3, "algorithmic_bytes_per_launch": b_alg}}
+    if not args.no_cpu:
+        from oracle import oracle as O
+        o = O.OracleLMap(**params, omp=True)
+        o.insert_pointcloud(xyz, origin, args.resolution, fr, -1.0)
+        t0 = time.perf_counter()
+        o.insert_pointcloud(xyz, origin, args.resolution, fr, -1.0)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": float(o.stats()["voxel_updates"]) / tc, "unit": "voxel-updates/s",
+                               "cores": O.lib(True).orc_num_threads(), "kind": "port",
+                               "sample": "the same scan re-inserted once into the OpenMP build of the restatement",
+                               "insert_pointcloud_s": tc}
+    print(json.dumps(out))
 
 
 def end_to_end(la3dm_amd, params, xyz, origin, args, U):
