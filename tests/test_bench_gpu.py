@@ -62,3 +62,14 @@ def test_two_ranks_self_test(built, mode, scaling):
     total = d["value"] * d["ms_per_step"] * 1e-3
     # whole-job aggregate: both ranks' leaves (weak: two scans; strong: the two halves of one scan)
     assert abs(total - 2 * per_rank) / total < 0.35
+
+
+@pytest.mark.parametrize("workload,extra", [("gp", ["--rays", "20000"]), ("lv", []), ("l", ["--rays", "20000"])])
+def test_side_benches(built, workload, extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
+                        "--no-cpu"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["roofline"]["kernel_ms"] > 0
