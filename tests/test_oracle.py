@@ -205,3 +205,53 @@ def test_full_scan_fixtures_reproduced(O):
     lv = o.leaves()
     for k in ("block_key", "node_key", "A", "B", "state", "classified"):
         assert lv[k].shape == kat[f"bgkl_d3_{k}"].shape and (lv[k] == kat[f"bgkl_d3_{k}"]).all(), k
+
+
+def test_reference_rtree_gather_order_stays_within_the_tolerance(O):
+    """The restatement gathers a block's training points in ascending index; the reference gets them in the traversal
+    order of its R-tree (include/common/rtree.h — compiled from the reference's own source in oracle/_ref), which only
+    permutes the fp32 sums of Ks*y.  Measured here on a real scan with the REAL tree: the per-leaf posterior after the
+    7-neighbour fusion moves by far less than the 1e-5 the north star allows (and the orders do differ)."""
+    R = O.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built here")
+    import la3dm_amd
+    from conftest import pcd_path
+    R.ref_configure(0.1, 3, 1.0, 0.2, 0.3, 0.7, 100.0, 0.001, 0.001)
+    m = O.OracleMap(**YAML)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    xy = O.get_training_data(xyz, origin, 0.1, 0.5, 8.0)
+    pts = np.ascontiguousarray(xy[:, :3])
+    tree = R.ref_rtree_new(pts, pts.shape[0])
+    ids = np.zeros(pts.shape[0], np.int32)
+    keys = sorted({m.block_to_hash_key(*map(float, p)) for p in pts[:: max(1, pts.shape[0] // 150)]})
+    reordered, worst, n_leaf = 0, 0.0, 0
+    e = np.zeros(7, np.int64)
+    for key in keys:
+        c = m.hash_key_to_block(key)
+        b = m.L.orc_block_new(m.h, float(c[0]), float(c[1]), float(c[2]))
+        lk, loc = np.zeros(64, np.int32), np.zeros((64, 3), np.float32)
+        nl = m.L.orc_block_leaves(m.h, b, lk, loc, 64)
+        m.L.orc_block_free(b)
+        xs = loc[:nl]
+        A = {"ref": np.full(nl, 0.001, np.float32), "asc": np.full(nl, 0.001, np.float32)}
+        B = {"ref": np.full(nl, 0.001, np.float32), "asc": np.full(nl, 0.001, np.float32)}
+        R.ref_get_extended_block(key, e)
+        for nb in e:
+            n = R.ref_rtree_block_query(tree, int(nb), ids, ids.size)
+            if n == 0:
+                continue
+            order = {"ref": ids[:n].copy(), "asc": np.sort(ids[:n])}
+            reordered += int((order["ref"] != order["asc"]).any())
+            for tag in ("ref", "asc"):
+                ybar, kbar = O.bgk_predict(1.0, 0.2, xs, pts[order[tag]], xy[order[tag], 3])
+                upd = kbar > 0
+                A[tag] = np.where(upd, A[tag] + ybar, A[tag]).astype(np.float32)
+                B[tag] = np.where(upd, B[tag] + (kbar - ybar), B[tag]).astype(np.float32)
+        p_ref, p_asc = A["ref"] / (A["ref"] + B["ref"]), A["asc"] / (A["asc"] + B["asc"])
+        worst = max(worst, float(np.abs(p_ref - p_asc).max()))
+        n_leaf += nl
+    R.ref_rtree_free(tree)
+    assert reordered > 50 and n_leaf > 5000       # the tree's order really differs from ascending index
+    assert worst <= 1e-5, worst
+    assert worst < 2e-6                           # in fact: a few ulps of the sums
