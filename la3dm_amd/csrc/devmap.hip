@@ -644,7 +644,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         hipLaunchKernelGGL(dm_l_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
                            (const uint32_t *)P.rows_off, (const uint32_t *)nleaf, n_test, dm->d_cnt);
     else
-        hipLaunchKernelGGL(dm_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
+        hipLaunchKernelGGL(dm_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
                            (const uint32_t *)nleaf, n_test, dm->d_cnt);
     if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);

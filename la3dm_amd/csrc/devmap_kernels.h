@@ -739,21 +739,33 @@ __global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ 
 // neighbourhood size x leaf count (pair_evals), accumulated as 64-bit words inside the counter block
 __global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf,
                                                     uint32_t n_test, uint32_t *counters) {
+    // grid-stride partial sums, one pair of 64-bit atomics per workgroup (a few dozen in all: the per-wave version
+    // serialised ~1300 atomics on two addresses)
+    __shared__ unsigned long long s_w[4], s_pw[4];
     unsigned long long *acc_reads = reinterpret_cast<unsigned long long *>(counters + kCntTrainReads);
     unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long w = 0, pw = 0;
-    if (t < n_test) {
-        w = 0xFFFFFFFFu - t_key[t];  // the sort key of the test list is ~weight
-        pw = w * nleaf[t];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_test; t += gridDim.x * blockDim.x) {
+        const unsigned long long wt = 0xFFFFFFFFu - t_key[t];  // the sort key of the test list is ~weight
+        w += wt;
+        pw += wt * nleaf[t];
     }
     for (int o = 32; o >= 1; o >>= 1) {
         w += __shfl_xor(w, o);
         pw += __shfl_xor(pw, o);
     }
-    if ((threadIdx.x & 63) == 0 && (w | pw)) {
-        atomicAdd(acc_reads, w);
-        atomicAdd(acc_pairs, pw);
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = w;
+        s_pw[threadIdx.x >> 6] = pw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        pw = s_pw[0] + s_pw[1] + s_pw[2] + s_pw[3];
+        if (w | pw) {
+            atomicAdd(acc_reads, w);
+            atomicAdd(acc_pairs, pw);
+        }
     }
 }
 
