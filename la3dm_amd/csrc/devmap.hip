@@ -641,7 +641,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
                        (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
     if (ctx->p.variant == 3)
-        hipLaunchKernelGGL(dm_l_test_stats, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
+        hipLaunchKernelGGL(dm_l_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
                            (const uint32_t *)P.rows_off, (const uint32_t *)nleaf, n_test, dm->d_cnt);
     else
         hipLaunchKernelGGL(dm_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,

@@ -607,24 +607,35 @@ __global__ __launch_bounds__(256) void dm_l_rows_off(const uint32_t *__restrict_
 // work counters of a pass in rows (what the oracle counts for this variant)
 __global__ __launch_bounds__(256) void dm_l_test_stats(const int32_t *__restrict__ nbr, const uint32_t *__restrict__ rows_off,
                                                       const uint32_t *__restrict__ nleaf, uint32_t n_test, uint32_t *counters) {
+    __shared__ unsigned long long s_w[4], s_pw[4];
     unsigned long long *acc_reads = reinterpret_cast<unsigned long long *>(counters + kCntTrainReads);
     unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long w = 0, pw = 0;
-    if (t < n_test) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_test; t += gridDim.x * blockDim.x) {
+        unsigned long long wt = 0;
         for (int q = 0; q < 7; ++q) {
             const int32_t tb = nbr[7 * (size_t)t + q];
-            if (tb >= 0) w += rows_off[tb + 1] - rows_off[tb];
+            if (tb >= 0) wt += rows_off[tb + 1] - rows_off[tb];
         }
-        pw = w * nleaf[t];
+        w += wt;
+        pw += wt * nleaf[t];
     }
     for (int o = 32; o >= 1; o >>= 1) {
         w += __shfl_xor(w, o);
         pw += __shfl_xor(pw, o);
     }
-    if ((threadIdx.x & 63) == 0 && (w | pw)) {
-        atomicAdd(acc_reads, w);
-        atomicAdd(acc_pairs, pw);
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = w;
+        s_pw[threadIdx.x >> 6] = pw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        pw = s_pw[0] + s_pw[1] + s_pw[2] + s_pw[3];
+        if (w | pw) {
+            atomicAdd(acc_reads, w);
+            atomicAdd(acc_pairs, pw);
+        }
     }
 }
 
