@@ -207,12 +207,27 @@ __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict
         big[atomicAdd(&counters[big_slot], 1u)] = seg;
         return;
     }
+    // eight points per trip: the index loads, then the coordinate loads, are issued together (a cell is a chain of
+    // dependent gathers otherwise); the sums still run in cloud order
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (uint32_t j = s0; j < s1; ++j) {
-        const uint32_t v = vals[j];
-        sx += p[3 * (size_t)v];
-        sy += p[3 * (size_t)v + 1];
-        sz += p[3 * (size_t)v + 2];
+    for (uint32_t j = s0; j < s1; j += 8) {
+        uint32_t v[8];
+        float x[8], y[8], z[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = vals[min(j + u, s1 - 1u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = p[3 * (size_t)v[u]];
+            y[u] = p[3 * (size_t)v[u] + 1];
+            z[u] = p[3 * (size_t)v[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j + u < s1) {
+                sx += x[u];
+                sy += y[u];
+                sz += z[u];
+            }
     }
     const float cnt = (float)(s1 - s0);
     out[3 * (size_t)seg] = sx / cnt;
