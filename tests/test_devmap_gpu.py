@@ -454,3 +454,22 @@ def test_config5_scan_at_full_size(built):
         assert st[k] == so[k], (k, st[k], so[k])
     assert st["voxel_updates"] > 15_000_000
     _same(m, o, "1M rays @ 0.05 m")
+
+
+def test_unstructured_sequence_all_variants_of_the_pool(built):
+    """the other data set of the reference (data/sim_unstructured, 12 scans) through the three pool variants — BGK at
+    0.1 m, GP on every third point, BGK-L — each against its oracle restatement"""
+    import la3dm_amd
+    from oracle import oracle as O
+    cases = [(la3dm_amd.BGKOctoMap, O.OracleMap, dict(la3dm_amd.BGK_YAML), 1, 0.5),
+             (la3dm_amd.GPOctoMap, O.OracleGPMap, dict(la3dm_amd.GP_YAML), 3, 0.5),
+             (la3dm_amd.BGKLOctoMap, O.OracleLMap, dict(la3dm_amd.L_YAML), 1, 0.3)]
+    for cls, ocls, params, step, fr in cases:
+        m, o = cls(**params, device=0), ocls(**params)
+        assert m.is_device_resident()
+        for i in range(1, 13):
+            xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+            m.insert_pointcloud(xyz[::step], origin, 0.1, fr, 8.0)
+            o.insert_pointcloud(xyz[::step], origin, 0.1, fr, 8.0)
+        _same(m, o, cls.__name__)
+        assert m.leaves()["A"].size > 20000
