@@ -294,7 +294,8 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
                     &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->q_out, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
-                    &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node};
+                    &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node,
+                    &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
     void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp};
