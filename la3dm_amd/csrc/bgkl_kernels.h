@@ -74,6 +74,15 @@ struct BgklSplit {
     uint32_t threshold;
 };
 
+// Does a row at distance d enter a leaf's sums?  d < ell: the kernel is positive.  d >= ell: r >= 1, the kernel is <= 0
+// and cleaned to 0 — skipped.  d NaN or inf (a beam built from a NaN point of an unfiltered cloud): the reference's
+// dense formula yields NaN, the `< 0 -> 0` clean-up lets it through and it poisons ybar / kbar of every leaf that
+// meets the row (the kbar > 0.001 gate then rejects the update) — kept, with k = NaN.
+__device__ __forceinline__ bool bgkl_row_counts(float d, float ell) { return !(d >= ell) || d == __builtin_inff(); }
+__device__ __forceinline__ float bgkl_row_kernel(float d, float ell, float sf2) {
+    return (d - d == 0.0f) ? cov_sparse<true, 0>(d / ell, sf2) : __builtin_nanf("");
+}
+
 // leaf of this lane: false when the tile holds no leaves
 __device__ __forceinline__ bool bgkl_leaf(const BgklArgs &a, uint32_t task, int lane, uint32_t &blk, uint32_t &li, bool &active,
                                           float &px, float &py, float &pz) {
@@ -140,10 +149,10 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
                 const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j);       // x0 y0 z0 x1
                 const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j + 4);   // y1 z1 label -
                 const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-                const bool hit = active && d < a.ell;  // d >= ell  =>  d / ell >= 1  =>  the kernel is <= 0 and cleaned to 0
+                const bool hit = active && bgkl_row_counts(d, a.ell);
                 if (__ballot(hit) == 0ull) continue;
                 if (hit) {
-                    const float kv = cov_sparse<true, 0>(d / a.ell, a.sf2);
+                    const float kv = bgkl_row_kernel(d, a.ell, a.sf2);
                     ybar += kv * p1.z;
                     kbar += kv;
                 }
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
                     const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
                     const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
                     float kv = 0.0f, kyv = 0.0f;
-                    if (active && d < a.ell) {
-                        kv = cov_sparse<true, 0>(d / a.ell, a.sf2);
+                    if (active && bgkl_row_counts(d, a.ell)) {
+                        kv = bgkl_row_kernel(d, a.ell, a.sf2);
                         kyv = kv * p1.z;
                     }
                     s_k[j][lane] = kv;
@@ -252,12 +261,12 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
             const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
             if ((m >> lane) & 1ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mm.y, __builtin_amdgcn_mbcnt_lo(mm.x, 0));
-                s.vals[vb + off + rank] = cov_sparse<true, 0>(d / a.ell, a.sf2);
+                s.vals[vb + off + rank] = bgkl_row_kernel(d, a.ell, a.sf2);
             }
             off += (uint32_t)__popcll(m);
         } else {
             const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-            const unsigned long long m = __ballot(active && d < a.ell);
+            const unsigned long long m = __ballot(active && bgkl_row_counts(d, a.ell));
             if ((j & 63u) == 0u) {
                 boff = off;
                 if (lane == 0) s.batch_off[it * kLBatches + (j >> 6)] = off;

@@ -1,0 +1,55 @@
+"""Long differential fuzz of the device-resident pool against the oracle (not collected by pytest): seeded random
+scenes, map parameters and scan arguments for the BGK, GP and BGK-L variants, offsets far from the origin included.
+usage: python tests/manual/fuzz_pool.py [first_seed] [n_seeds]"""
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, la3dm_amd
+from oracle import oracle as O
+
+def same(m, o, tag):
+    a, b = m.leaves(), o.leaves()
+    ok = a["A"].size == b["A"].size and all((a[k] == b[k]).all() for k in ("block_key", "node_key", "state", "classified")) \
+        and (a["A"].view(np.uint32) == b["A"].view(np.uint32)).all() and (a["B"].view(np.uint32) == b["B"].view(np.uint32)).all()
+    if not ok:
+        print("MISMATCH", tag, a["A"].size, b["A"].size, flush=True)
+    return ok
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+bad, t0 = 0, time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    res = float(rng.choice([0.05, 0.1, 0.2, 0.25]))
+    depth = int(rng.choice([1, 2, 3, 4, 5]))
+    kind = int(rng.integers(0, 3))
+    common = dict(resolution=res, block_depth=depth, sf2=float(rng.choice([0.1, 1.0, 2.0])), free_thresh=0.3, occupied_thresh=0.7)
+    if kind == 1:
+        depth = min(depth, 3)
+        params = dict(common, block_depth=depth, ell=float(rng.choice([3.0, 5.0, 10.0])) * res, noise=0.01, l=100.0, min_var=0.001,
+                      max_var=1000.0, max_known_var=0.02)
+        m, o = la3dm_amd.GPOctoMap(**params, device=0), O.OracleGPMap(**params)
+    else:
+        params = dict(common, ell=float(rng.choice([1.5, 2.0, 3.0])) * res, var_thresh=float(rng.choice([0.05, 0.15, 100.0])),
+                      prior_A=0.001, prior_B=0.001)
+        m, o = (la3dm_amd.BGKLOctoMap(**params, device=0), O.OracleLMap(**params)) if kind == 2 else \
+               (la3dm_amd.BGKOctoMap(**params, device=0), O.OracleMap(**params))
+        if kind == 2:
+            m.set_option("bgkl_split_rows", int(rng.choice([0, 40, 4096])))
+    assert m.is_device_resident()
+    offset = rng.choice([0.0, 0.0, 37.3, -412.7, 5000.2]) * np.array([1, rng.choice([0, 1]), 0], np.float32)
+    for scan in range(int(rng.integers(1, 4))):
+        n = int(rng.integers(1, 60 if kind == 1 else 500))
+        origin = (offset + rng.uniform(-1, 1, 3)).astype(np.float32)
+        pts = (origin + rng.normal(0, 1.0, (n, 3)) * rng.uniform(0.2, 3.0)).astype(np.float32)
+        k = n // 4
+        pts[:k] = (np.round(pts[:k] / res) * res).astype(np.float32)
+        if rng.random() < 0.2:
+            pts[rng.integers(0, n)] = np.nan
+        ds = float(rng.choice([-1.0, res, 2 * res]))
+        fr = float(rng.choice([0.3, 0.5, 1.0])) * max(res * 4, 0.2)
+        mr = float(rng.choice([-1.0, 2.5, 6.0]))
+        m.insert_pointcloud(pts, origin, ds, fr, mr)
+        o.insert_pointcloud(pts, origin, ds, fr, mr)
+        if not same(m, o, f"seed {seed} kind {kind} scan {scan} {params} ds={ds} fr={fr} mr={mr} offset={offset.tolist()}"):
+            bad += 1
+            break
+print(f"seeds {first}..{first + count - 1}: {bad} mismatching, {time.time() - t0:.0f} s", flush=True)

@@ -150,3 +150,23 @@ def test_host_orchestrated_mode(built, depth):
     m.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
     o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
     _same(m, o, "host mode synthetic")
+
+
+@pytest.mark.parametrize("resident", [True, False])
+@pytest.mark.parametrize("split_rows", [0, 4096])
+def test_beam_built_from_a_nan_point(built, resident, split_rows):
+    """an unfiltered cloud (ds_resolution < 0) with a NaN point: its beam still owns a finite origin sample, so the
+    origin's block gets a row whose segment is NaN; the reference's dense kernel matrix then holds NaN (the `< 0 -> 0`
+    clean-up lets it through) and poisons ybar / kbar of every leaf that meets the row — the kbar > 0.001 gate rejects
+    those updates.  Found by tests/manual/fuzz_pool.py."""
+    import la3dm_amd
+    params = dict(la3dm_amd.L_YAML, block_depth=2, resolution=0.2, ell=0.3)
+    pts = np.array([[1.0, 0.2, 0.1], [np.nan, 0.0, 0.0], [0.3, 0.9, 0.2], [-0.8, 0.1, 0.3]], np.float32)
+    origin = np.array([0.05, 0.05, 0.05], np.float32)
+    m, o = _maps(params, resident=resident)
+    m.set_option("bgkl_split_rows", split_rows)
+    for _ in range(2):
+        m.insert_pointcloud(pts, origin, -1.0, 0.3, -1.0)
+        o.insert_pointcloud(pts, origin, -1.0, 0.3, -1.0)
+        _same(m, o, "nan beam")
+    assert 0 < int(m.leaves()["classified"].sum()) < m.leaves()["A"].size
