@@ -315,7 +315,7 @@ static int training_bbox(la3dm_devmap *dm) {
     hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
     hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)dm->xy.ptr, npts,
                        dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox);
+    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox, (const float *)dm->xy.ptr);
     DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
     return LA3DM_OK;
@@ -719,7 +719,10 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
     hipStream_t st = dm->ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
     int rc;
-    if (dm->n_xy == 0) {  // empty cloud, or every hit beyond max_range
+    bool no_bbox = false;  // a NaN coordinate in the first training point: the reference's bbox is NaN, no block is visited
+    for (int a = 0; a < 6 && dm->n_xy; ++a) no_bbox |= dm->h_bbox[a] != dm->h_bbox[a];
+    if (dm->n_xy == 0 || no_bbox) {  // empty cloud, every hit beyond max_range, or no candidate blocks
+        S.t_total = wall() - t0;
         if (stats_out) *stats_out = S;
         return LA3DM_OK;
     }

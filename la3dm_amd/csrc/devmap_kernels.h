@@ -115,8 +115,15 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
 }
 
 // decoded min/max for the host (bbox of the training set)
-__global__ void dm_minmax_decode(const uint32_t *mm, float *out) {
-    if (threadIdx.x < 6) out[threadIdx.x] = dec_f32(mm[threadIdx.x]);
+// bbox of the training set.  The reference (bbox(), bgkoctomap.cpp:464-484) reduces with `<`, which a NaN never wins:
+// NaN coordinates are ignored — except in the FIRST training point, which seeds the reduction and then never loses
+// (restated as a min / max chain from xy[0]): that axis' limits stay NaN, get_blocks_in_bbox makes no step and the
+// scan is a no-op.  `first` = xy[0] (x, y, z, label).
+__global__ void dm_minmax_decode(const uint32_t *mm, float *out, const float *first) {
+    if (threadIdx.x < 6) {
+        const float f = first[threadIdx.x % 3];
+        out[threadIdx.x] = f != f ? f : dec_f32(mm[threadIdx.x]);
+    }
 }
 
 __global__ void dm_grid_params(const uint32_t *mm, float inv, GridParams *gp) {

@@ -899,7 +899,7 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
         const float l = (float)sqrt((x - x0) * (x - x0) + (y - y0) * (y - y0) + (z - z0) * (z - z0));
         const float nx = (x - x0) / l, ny = (y - y0) / l, nz = (z - z0) / l;
         size_t w = frees.size();
-        const size_t room = 3 * ((size_t)(l / free_resolution) + 4);
+        const size_t room = 3 * ((l < 1.0e9f ? (size_t)(l / free_resolution) : 0) + 4);  // (false for a NaN range too)
         frees.resize(w + room);
         float *f = frees.data();
         f[w++] = x0;
@@ -1122,6 +1122,10 @@ bool BGKOctoMap::partition_and_pack(bool ungated) {
         }
         lo[0] = l0; lo[1] = l1; lo[2] = l2;
         hi[0] = h0; hi[1] = h1; hi[2] = h2;
+        // The reference's reduction uses `<`, which a NaN never wins: NaN coordinates are ignored, except in the first
+        // point, which seeds the reduction and never loses — that axis' limits are NaN and no candidate block is made.
+        for (int a = 0; a < 3; ++a)
+            if (xy[a] != xy[a]) lo[a] = hi[a] = xy[a];
     }
     std::vector<BlockHashKey> bbox_keys;
     for (float x = lo[0] - bs; x <= hi[0] + 2 * bs; x += bs)

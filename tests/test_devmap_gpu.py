@@ -473,3 +473,31 @@ def test_unstructured_sequence_all_variants_of_the_pool(built):
             o.insert_pointcloud(xyz[::step], origin, 0.1, fr, 8.0)
         _same(m, o, cls.__name__)
         assert m.leaves()["A"].size > 20000
+
+
+@pytest.mark.parametrize("variant", ["bgk", "gp", "bgkl"])
+def test_nan_in_the_first_point_of_an_unfiltered_cloud(built, variant):
+    """ds_resolution < 0 and a NaN in the first hit: it seeds the reference's bbox reduction (`<` never replaces a NaN),
+    the limits are NaN, get_blocks_in_bbox makes no step and the scan is a no-op — in the oracle, on the pool and in the
+    host-orchestrated mode (which used to size a buffer from the NaN range).  A NaN anywhere else is ignored.
+    Found by tests/manual/fuzz_pool.py."""
+    import la3dm_amd
+    from oracle import oracle as O
+    cls, ocls, params = {"bgk": (la3dm_amd.BGKOctoMap, O.OracleMap, la3dm_amd.BGK_YAML),
+                         "gp": (la3dm_amd.GPOctoMap, O.OracleGPMap, la3dm_amd.GP_YAML),
+                         "bgkl": (la3dm_amd.BGKLOctoMap, O.OracleLMap, la3dm_amd.L_YAML)}[variant]
+    pts = np.array([[np.nan, 0.0, 0.0], [1.0, 0.2, 0.1], [0.3, 0.9, 0.2], [-0.8, 0.1, 0.3], [0.4, -0.7, 0.6]], np.float32)
+    origin = np.array([0.05, 0.05, 0.05], np.float32)
+    for resident in (True, False):
+        m, o = cls(**params, device=0).set_device_resident(resident), ocls(**params)
+        m.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)
+        o.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)
+        assert m.block_count() == 0 and o.leaves()["A"].size == 0, (variant, resident)
+        later = np.ascontiguousarray(pts[[1, 0, 2, 3, 4]])                      # the NaN is no longer first: ignored
+        m.insert_pointcloud(later, origin, -1.0, 0.5, -1.0)
+        o.insert_pointcloud(later, origin, -1.0, 0.5, -1.0)
+        assert m.block_count() > 0
+        _same(m, o, f"{variant} resident={resident}")
+        m.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)                       # and a no-op again on a filled map
+        o.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)
+        _same(m, o, f"{variant} resident={resident} after the no-op")
