@@ -237,7 +237,18 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
             for (float z = lo[2] - bs; z <= hi[2] + 2 * bs; z += bs) keys.push_back(block_to_hash_key(x, y, z));
     lvst.n_bbox_blocks = keys.size();
     std::sort(keys.begin(), keys.end());
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<uint32_t> key_mult;  // how often the candidate loop produced each distinct key
+    {
+        size_t w = 0;
+        for (size_t i = 0; i < keys.size();) {
+            size_t j = i;
+            while (j < keys.size() && keys[j] == keys[i]) ++j;
+            keys[w++] = keys[i];
+            key_mult.push_back((uint32_t)(j - i));
+            i = j;
+        }
+        keys.resize(w);
+    }
 
     // bucket the samples: edge g, index floor((v + block_size/2) / g), stable counting sort
     const unsigned depth = (unsigned)get_block_depth();
@@ -246,14 +257,24 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
     const int reach = (int)std::ceil((double)OcTreeNode::ell / g);
     auto cidx = [&](float v) { return (int64_t)std::floor(((double)v + half) / g); };
     int64_t cmin[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, cmax[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+    // A sample with a non-finite coordinate (a hit at the sensor itself gives a beam without direction: 0 / 0) lies in
+    // no voxel's box and in no bucket; it keeps its place in `samples` (the rays refer to sample indices) but is not
+    // binned.
     std::vector<int64_t> cc(3 * ns);
-    for (size_t i = 0; i < ns; ++i)
+    std::vector<uint8_t> binned(ns, 0);
+    size_t n_binned = 0;
+    for (size_t i = 0; i < ns; ++i) {
+        if (!std::isfinite(samples[4 * i]) || !std::isfinite(samples[4 * i + 1]) || !std::isfinite(samples[4 * i + 2])) continue;
+        binned[i] = 1;
+        ++n_binned;
         for (int a = 0; a < 3; ++a) {
             const int64_t c = cidx(samples[4 * i + a]);
             cc[3 * i + a] = c;
             cmin[a] = std::min(cmin[a], c);
             cmax[a] = std::max(cmax[a], c);
         }
+    }
+    if (n_binned == 0) return false;
     size_t ncell = 1;
     for (int a = 0; a < 3; ++a) {
         cell_min[a] = (int32_t)cmin[a];
@@ -264,6 +285,7 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
     cell_off.assign(ncell + 1, 0u);
     std::vector<uint32_t> lin(ns);
     for (size_t i = 0; i < ns; ++i) {
+        if (!binned[i]) continue;
         lin[i] = (uint32_t)(((cc[3 * i + 2] - cmin[2]) * cell_dim[1] + (cc[3 * i + 1] - cmin[1])) * cell_dim[0] + (cc[3 * i] - cmin[0]));
         ++cell_off[lin[i] + 1];
     }
@@ -272,6 +294,7 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
     {
         std::vector<uint32_t> cur(cell_off.begin(), cell_off.end() - 1);
         for (size_t i = 0; i < ns; ++i) {
+            if (!binned[i]) continue;
             const uint32_t d = cur[lin[i]]++;
             const uint32_t oi = (uint32_t)i;
             sorted[4 * d] = samples[4 * i];
@@ -304,7 +327,13 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
         for (long i = 0; i < (long)missing.size(); ++i) made[(size_t)i] = new Block(hash_key_to_block(missing[(size_t)i]));
         for (size_t i = 0; i < missing.size(); ++i) block_arr.emplace(missing[i], made[i]);
     }
-    for (BlockHashKey k : keys) {
+    lv_all_blocks.clear();
+    lv_all_center.clear();
+    lv_all_cell0.clear();
+    lv_mult.clear();
+    lv_max_mult = 0;
+    for (size_t ki = 0; ki < keys.size(); ++ki) {
+        const BlockHashKey k = keys[ki];
         Block *blk = block_arr.find(k)->second;
         const point3f c = blk->get_center();
         // lowest bucket of the block: its lower corner is c - size/2, i.e. bucket floor((c - size/2 + size/2)/g)
@@ -314,11 +343,37 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
                       b0[2] + bpb - 1 + reach))
             continue;
         if (blk->node_arr == nullptr || blk->node_arr[depth - 1] == nullptr) continue;  // finest layer fully collapsed
-        lv_blocks.push_back(blk);
-        lv_center.insert(lv_center.end(), {c.x(), c.y(), c.z()});
-        lv_cell0.insert(lv_cell0.end(), {(int32_t)b0[0], (int32_t)b0[1], (int32_t)b0[2]});
+        lv_all_blocks.push_back(blk);
+        lv_all_center.insert(lv_all_center.end(), {c.x(), c.y(), c.z()});
+        lv_all_cell0.insert(lv_all_cell0.end(), {(int32_t)b0[0], (int32_t)b0[1], (int32_t)b0[2]});
+        lv_mult.push_back(key_mult[ki]);
+        lv_max_mult = std::max(lv_max_mult, key_mult[ki]);
     }
-    lvst.n_packed_blocks = lv_blocks.size();
+    lv_info.assign(lv_all_blocks.size(), 0);
+    lvst.n_packed_blocks = lv_all_blocks.size();
+    lvst.voxels = lv_all_blocks.size() * npb;
+    lvst.voxel_updates = 0;
+    const bool any = select_pass_lv(0);
+    lvst.t_partition = wall() - t1;
+    return any;
+}
+
+// blocks of visit number `pass` (0 = every packed block) and their node arrays as they are now
+bool BGKLVOctoMap::select_pass_lv(uint32_t pass) {
+    const unsigned depth = (unsigned)get_block_depth();
+    const size_t npb = (size_t)1 << (3 * (depth - 1));
+    lv_blocks.clear();
+    lv_center.clear();
+    lv_cell0.clear();
+    lv_pass_index.clear();
+    for (size_t b = 0; b < lv_all_blocks.size(); ++b) {
+        if (lv_mult[b] <= pass) continue;
+        if (lv_all_blocks[b]->node_arr == nullptr || lv_all_blocks[b]->node_arr[depth - 1] == nullptr) continue;
+        lv_blocks.push_back(lv_all_blocks[b]);
+        lv_center.insert(lv_center.end(), lv_all_center.begin() + 3 * b, lv_all_center.begin() + 3 * b + 3);
+        lv_cell0.insert(lv_cell0.end(), lv_all_cell0.begin() + 3 * b, lv_all_cell0.begin() + 3 * b + 3);
+        lv_pass_index.push_back((uint32_t)b);
+    }
     lv_alpha.resize(lv_blocks.size() * npb);
     lv_beta.resize(lv_blocks.size() * npb);
     lv_state.resize(lv_blocks.size() * npb);
@@ -332,8 +387,6 @@ bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const p
             lv_state[b * npb + i] = (uint8_t)lv_code(layer[i].get_state());
         }
     }
-    lvst.voxels = lv_blocks.size() * npb;
-    lvst.t_partition = wall() - t1;
     return !lv_blocks.empty();
 }
 
@@ -363,8 +416,8 @@ void BGKLVOctoMap::commit_lv() {
     const double t0 = wall();
     const unsigned depth = (unsigned)get_block_depth();
     const size_t npb = (size_t)1 << (3 * (depth - 1));
-    uint64_t updates = 0, info_blocks = 0;
-#pragma omp parallel for num_threads(16) schedule(dynamic, 4) reduction(+ : updates, info_blocks)
+    uint64_t updates = 0;
+#pragma omp parallel for num_threads(16) schedule(dynamic, 4) reduction(+ : updates)
     for (long bb = 0; bb < (long)lv_blocks.size(); ++bb) {
         const size_t b = (size_t)bb;
         OcTreeNode *layer = lv_blocks[b]->node_arr[depth - 1];
@@ -379,14 +432,24 @@ void BGKLVOctoMap::commit_lv() {
             layer[i].state = state_from_lv(st & 7u);
             ++updates;
         }
-        if (info) {
-            ++info_blocks;
-            if (OcTreeNode::original_size) lv_blocks[b]->prune();
-        }
+        if (info) lv_info[lv_pass_index[b]] = 1;
     }
-    lvst.voxel_updates = updates;
+    lvst.voxel_updates += updates;
+    lvst.t_commit += wall() - t0;
+}
+
+// after the last visit: prune the blocks that had information (bgklvoctomap.cpp:262-273)
+void BGKLVOctoMap::finish_lv() {
+    const double t0 = wall();
+    uint64_t info_blocks = 0;
+#pragma omp parallel for num_threads(16) schedule(dynamic, 4) reduction(+ : info_blocks)
+    for (long b = 0; b < (long)lv_all_blocks.size(); ++b) {
+        if (!lv_info[(size_t)b]) continue;
+        ++info_blocks;
+        if (OcTreeNode::original_size) lv_all_blocks[(size_t)b]->prune();
+    }
     lvst.n_info_blocks = info_blocks;
-    lvst.t_commit = wall() - t0;
+    lvst.t_commit += wall() - t0;
 }
 
 void BGKLVOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
@@ -394,12 +457,16 @@ void BGKLVOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, 
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKLVOctoMap::insert_pointcloud: no device context (there is no CPU path)");
     if (!prepare_lv(xyz, n, stride, origin, ds_resolution, free_res, max_range)) return;
-    const double t1 = wall();
-    la3dm_lv_scan s = packed_lv();
-    if (la3dm_bgklv_scan_host(ctx, &s, nullptr) != LA3DM_OK)
-        throw std::runtime_error(std::string("BGKLVOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
-    lvst.t_device = wall() - t1;
-    commit_lv();
+    for (uint32_t pass = 0; pass < lv_max_mult; ++pass) {
+        if (pass > 0 && !select_pass_lv(pass)) continue;  // repeats of the float-stepped candidate list
+        const double t1 = wall();
+        la3dm_lv_scan s = packed_lv();
+        if (la3dm_bgklv_scan_host(ctx, &s, nullptr) != LA3DM_OK)
+            throw std::runtime_error(std::string("BGKLVOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
+        lvst.t_device += wall() - t1;
+        commit_lv();
+    }
+    finish_lv();
     lvst.t_total = wall() - t0;
 }
 

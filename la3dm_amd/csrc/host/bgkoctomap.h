@@ -495,11 +495,13 @@ public:
     const std::vector<float> &lv_samples() const { return samples; }
     const std::vector<float> &lv_rays() const { return rays6; }
     /// split form used by the benchmark: prepare_lv packs (returns false if nothing to do), packed_lv exposes the
-    /// device-call arguments (host pointers), commit_lv writes the nodes and prunes
+    /// device-call arguments (host pointers), commit_lv writes the nodes and prunes (the split form runs the first visit
+    /// of every block only; insert_pointcloud also runs the repeats of the float-stepped candidate list)
     bool prepare_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution, float free_res,
                     float max_range);
     la3dm_lv_scan packed_lv();
     void commit_lv();
+    void finish_lv();
 
 private:
     void training_data_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
@@ -513,6 +515,17 @@ private:
     std::vector<int32_t> lv_cell0;
     std::vector<uint8_t> lv_state;
     std::vector<Block *> lv_blocks;
+    // A block index the float-stepped candidate loop produces k times is visited k times by the reference (the same
+    // samples, serially): lv_mult[b] = k; pass p re-packs and re-runs the blocks with k > p (lv_all_* keep the full
+    // list, lv_blocks / lv_center / lv_cell0 hold the current pass), the prune follows the last pass.
+    std::vector<Block *> lv_all_blocks;
+    std::vector<float> lv_all_center;
+    std::vector<int32_t> lv_all_cell0;
+    std::vector<uint32_t> lv_mult;
+    std::vector<uint8_t> lv_info;   // per entry of lv_all_blocks: some voxel had samples in its box (any pass)
+    std::vector<uint32_t> lv_pass_index;  // lv_blocks[i] == lv_all_blocks[lv_pass_index[i]]
+    uint32_t lv_max_mult = 0;
+    bool select_pass_lv(uint32_t pass);
     LVStats lvst;
 };
 

@@ -129,7 +129,7 @@ int la3dm_map_lv_packed(la3dm_map *m, la3dm_lv_scan *out) {
           return 0;)
 }
 int la3dm_map_lv_commit(la3dm_map *m) {
-    GUARD(la3dm::BGKLVOctoMap *lv = as_lv(m); if (!lv) throw std::runtime_error("not an LV map"); lv->commit_lv(); return 0;)
+    GUARD(la3dm::BGKLVOctoMap *lv = as_lv(m); if (!lv) throw std::runtime_error("not an LV map"); lv->commit_lv(); lv->finish_lv(); return 0;)
 }
 
 void la3dm_map_destroy(la3dm_map *m) {

@@ -15,18 +15,24 @@ def same(m, o, tag):
     return ok
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+degenerate = len(sys.argv) > 3 and sys.argv[3] == "degenerate"
 bad, t0 = 0, time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     res = float(rng.choice([0.05, 0.1, 0.2, 0.25]))
     depth = int(rng.choice([1, 2, 3, 4, 5]))
-    kind = int(rng.integers(0, 3))
+    kind = int(rng.integers(0, 4))
     common = dict(resolution=res, block_depth=depth, sf2=float(rng.choice([0.1, 1.0, 2.0])), free_thresh=0.3, occupied_thresh=0.7)
     if kind == 1:
         depth = min(depth, 3)
         params = dict(common, block_depth=depth, ell=float(rng.choice([3.0, 5.0, 10.0])) * res, noise=0.01, l=100.0, min_var=0.001,
                       max_var=1000.0, max_known_var=0.02)
         m, o = la3dm_amd.GPOctoMap(**params, device=0), O.OracleGPMap(**params)
+    elif kind == 3:
+        depth = max(depth, 2)
+        params = dict(common, block_depth=depth, ell=float(rng.choice([1.5, 2.0, 3.0])) * res, var_thresh=float(rng.choice([0.05, 0.2, 100.0])),
+                      prior_A=0.001, prior_B=0.001, original_size=bool(rng.integers(0, 2)), min_W=float(rng.choice([0.1, 1.0])))
+        m, o = la3dm_amd.BGKLVOctoMap(**params, device=0), O.OracleLVMap(**params)
     else:
         params = dict(common, ell=float(rng.choice([1.5, 2.0, 3.0])) * res, var_thresh=float(rng.choice([0.05, 0.15, 100.0])),
                       prior_A=0.001, prior_B=0.001)
@@ -34,19 +40,28 @@ for seed in range(first, first + count):
                (la3dm_amd.BGKOctoMap(**params, device=0), O.OracleMap(**params))
         if kind == 2:
             m.set_option("bgkl_split_rows", int(rng.choice([0, 40, 4096])))
-    assert m.is_device_resident()
+    if kind != 3:
+        assert m.is_device_resident()
+        if rng.random() < 0.25:
+            m.set_device_resident(False)
     offset = rng.choice([0.0, 0.0, 37.3, -412.7, 5000.2]) * np.array([1, rng.choice([0, 1]), 0], np.float32)
     for scan in range(int(rng.integers(1, 4))):
-        n = int(rng.integers(1, 60 if kind == 1 else 500))
+        n = int(rng.integers(1, 60 if kind == 1 else (120 if kind == 3 else 500)))
         origin = (offset + rng.uniform(-1, 1, 3)).astype(np.float32)
         pts = (origin + rng.normal(0, 1.0, (n, 3)) * rng.uniform(0.2, 3.0)).astype(np.float32)
         k = n // 4
         pts[:k] = (np.round(pts[:k] / res) * res).astype(np.float32)
         if rng.random() < 0.2:
             pts[rng.integers(0, n)] = np.nan
+        if degenerate and rng.random() < 0.3:
+            pts[rng.integers(0, n)] = origin                      # a hit at the sensor: zero-length beam
+        if degenerate and rng.random() < 0.2:
+            pts[rng.integers(0, n)] = pts[rng.integers(0, n)]     # duplicate hit
         ds = float(rng.choice([-1.0, res, 2 * res]))
         fr = float(rng.choice([0.3, 0.5, 1.0])) * max(res * 4, 0.2)
         mr = float(rng.choice([-1.0, 2.5, 6.0]))
+        if kind == 3:                                             # BGK-LV: filtered clouds with a range gate
+            ds, mr = res, float(rng.choice([2.5, 6.0, 8.0]))
         m.insert_pointcloud(pts, origin, ds, fr, mr)
         o.insert_pointcloud(pts, origin, ds, fr, mr)
         if not same(m, o, f"seed {seed} kind {kind} scan {scan} {params} ds={ds} fr={fr} mr={mr} offset={offset.tolist()}"):

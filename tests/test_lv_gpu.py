@@ -70,3 +70,24 @@ def test_lv_edge_cases(built):
     m.insert_pointcloud(pts, [0, 0, 1.0], 0.1, 0.1, 8.0)
     o.insert_pointcloud(pts, [0, 0, 1.0], 0.1, 0.1, 8.0)
     _compare(m, o, params, "clipped")
+
+
+def test_repeated_candidate_keys_and_a_hit_at_the_sensor(built):
+    """two findings of tests/manual/fuzz_pool.py: (1) the float-stepped candidate loop repeats a block index (0.4 m
+    blocks here; any block size far from the origin) and the reference then visits the block twice — the voxels get the
+    same rows twice; (2) a hit at the sensor itself has no direction (0 / 0): its beam's samples are NaN, lie in no
+    voxel's box and must not be binned (the host used to index the bucket grid with them)."""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(resolution=0.2, block_depth=2, sf2=1.0, ell=0.3, free_thresh=0.3, occupied_thresh=0.7, var_thresh=0.2,
+                  prior_A=0.001, prior_B=0.001, original_size=False, min_W=1.0)
+    rng = np.random.default_rng(77)
+    for case in range(4):
+        m, o = la3dm_amd.BGKLVOctoMap(**params, device=0), O.OracleLVMap(**params)
+        origin = rng.uniform(-1, 1, 3).astype(np.float32) + np.array([0.0, 0.0, 0.0] if case < 2 else [900.0, -350.0, 0.0], np.float32)
+        for scan in range(2):
+            pts = (origin + rng.normal(0, 1.2, (60, 3))).astype(np.float32)
+            pts[7] = origin                                            # a hit at the sensor
+            m.insert_pointcloud(pts, origin, 0.2, 0.24, 8.0)
+            o.insert_pointcloud(pts, origin, 0.2, 0.24, 8.0)
+            _compare(m, o, params, f"case {case} scan {scan}")
