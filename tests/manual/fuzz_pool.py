@@ -16,12 +16,15 @@ def same(m, o, tag):
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
 degenerate = len(sys.argv) > 3 and sys.argv[3] == "degenerate"
+big = len(sys.argv) > 3 and sys.argv[3] == "big"      # few seeds, large clouds, long sequences, BGK and BGK-L only
 bad, t0 = 0, time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     res = float(rng.choice([0.05, 0.1, 0.2, 0.25]))
     depth = int(rng.choice([1, 2, 3, 4, 5]))
     kind = int(rng.integers(0, 4))
+    if big:
+        kind = 2 * int(rng.integers(0, 2))
     common = dict(resolution=res, block_depth=depth, sf2=float(rng.choice([0.1, 1.0, 2.0])), free_thresh=0.3, occupied_thresh=0.7)
     if kind == 1:
         depth = min(depth, 3)
@@ -45,8 +48,10 @@ for seed in range(first, first + count):
         if rng.random() < 0.25:
             m.set_device_resident(False)
     offset = rng.choice([0.0, 0.0, 37.3, -412.7, 5000.2]) * np.array([1, rng.choice([0, 1]), 0], np.float32)
-    for scan in range(int(rng.integers(1, 4))):
+    for scan in range(int(rng.integers(4, 9)) if big else int(rng.integers(1, 4))):
         n = int(rng.integers(1, 60 if kind == 1 else (120 if kind == 3 else 500)))
+        if big:
+            n = int(rng.integers(1000, 5000))
         origin = (offset + rng.uniform(-1, 1, 3)).astype(np.float32)
         pts = (origin + rng.normal(0, 1.0, (n, 3)) * rng.uniform(0.2, 3.0)).astype(np.float32)
         k = n // 4
