@@ -72,4 +72,18 @@ for seed in range(first, first + count):
         if not same(m, o, f"seed {seed} kind {kind} scan {scan} {params} ds={ds} fr={fr} mr={mr} offset={offset.tolist()}"):
             bad += 1
             break
+    else:
+        if kind != 3:                                      # queries that run on the pool: bbox and the leaf export
+            lo, hi = m.get_bbox()
+            olo, ohi = o.get_bbox()
+            ok = (lo == olo).all() and (hi == ohi).all()
+            for state in ("occupied", "free"):
+                for original in (True, False):
+                    a, b = m.export_cells(state, original), o.export_cells(state, original)
+                    ra = np.concatenate([a["cells"], a["rgba"], a["level"][:, None].astype(np.float32)], axis=1)
+                    rb = np.concatenate([b["cells"], b["rgba"], b["level"][:, None].astype(np.float32)], axis=1)
+                    ok = ok and ra.shape == rb.shape and (ra[np.lexsort(ra.T[::-1])] == rb[np.lexsort(rb.T[::-1])]).all()
+            if not ok:
+                print("MISMATCH (bbox / export)", f"seed {seed} kind {kind} {params}", flush=True)
+                bad += 1
 print(f"seeds {first}..{first + count - 1}: {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
