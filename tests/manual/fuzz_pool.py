@@ -17,6 +17,7 @@ def same(m, o, tag):
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
 degenerate = len(sys.argv) > 3 and sys.argv[3] == "degenerate"
 big = len(sys.argv) > 3 and sys.argv[3] == "big"      # few seeds, large clouds, long sequences, BGK and BGK-L only
+gp_heavy = len(sys.argv) > 3 and sys.argv[3] == "gp"   # GP maps with hundreds of points per block (matrix-core paths)
 bad, t0 = 0, time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
@@ -25,9 +26,11 @@ for seed in range(first, first + count):
     kind = int(rng.integers(0, 4))
     if big:
         kind = 2 * int(rng.integers(0, 2))
+    if gp_heavy:
+        kind, depth = 1, int(rng.choice([3, 4]))
     common = dict(resolution=res, block_depth=depth, sf2=float(rng.choice([0.1, 1.0, 2.0])), free_thresh=0.3, occupied_thresh=0.7)
     if kind == 1:
-        depth = min(depth, 3)
+        depth = min(depth, 4 if gp_heavy else 3)
         params = dict(common, block_depth=depth, ell=float(rng.choice([3.0, 5.0, 10.0])) * res, noise=0.01, l=100.0, min_var=0.001,
                       max_var=1000.0, max_known_var=0.02)
         m, o = la3dm_amd.GPOctoMap(**params, device=0), O.OracleGPMap(**params)
@@ -52,6 +55,8 @@ for seed in range(first, first + count):
         n = int(rng.integers(1, 60 if kind == 1 else (120 if kind == 3 else 500)))
         if big:
             n = int(rng.integers(1000, 5000))
+        if gp_heavy:
+            n = int(rng.integers(200, 1500))
         origin = (offset + rng.uniform(-1, 1, 3)).astype(np.float32)
         pts = (origin + rng.normal(0, 1.0, (n, 3)) * rng.uniform(0.2, 3.0)).astype(np.float32)
         k = n // 4
