@@ -85,3 +85,16 @@ def test_bgklv_random(built):
             m.insert_pointcloud(pts, origin, res, fr, 8.0)
             o.insert_pointcloud(pts, origin, res, fr, 8.0)
             _same(m.leaves(), o.leaves(), f"lv case{case} scan{scan} {params} fr={fr}")
+
+
+def test_differential_fuzz_sample(built):
+    """a slice of tests/manual/fuzz_pool.py (all four variants, both map modes, offsets, NaN points, hits at the sensor,
+    duplicates, bbox and leaf export on the pool): every seed must match the oracle bit for bit"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "manual", "fuzz_pool.py"), "300", "25", "degenerate"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "seeds 300..324: 0 mismatching" in r.stdout, r.stdout[-2000:]
