@@ -20,6 +20,9 @@
 //    Noetic => Eigen 3.3.7 / PCL 1.10) and neither is installed here, and the
 //    reference ships no tests or golden vectors.  For those two boundaries this
 //    oracle restates the published algorithms and is  **parity unpinned**.
+//  * The ORDER in which a block's training points reach Ks*y differs by design: ascending index here, R-tree
+//    traversal order in the reference.  tests/test_oracle.py measures the effect with the reference's real tree
+//    (rtree.h in oracle/_ref): the fused posterior moves by <= 2e-7 (tolerance 1e-5) — the order only permutes fp32 sums.
 //
 // Conventions: all arithmetic that the reference does in float is done in float
 // here, every float->double promotion the reference performs is reproduced.
