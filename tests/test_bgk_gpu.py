@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 P_TOL = 1e-5
 
 
-def _maps(params):
+def _maps(params, omp=False):
     import la3dm_amd
     from oracle import oracle as O
     m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)   # this file: host-orchestrated mode
-    o = O.OracleMap(**params)                                                  # (tests/test_devmap_gpu.py: the default)
+    o = O.OracleMap(**params, omp=omp)                                         # (tests/test_devmap_gpu.py: the default)
     return m, o
 
 
@@ -147,7 +147,7 @@ def test_synthetic_scan_small(built):
     xyz, origin = la3dm_amd.synthetic_scan(20000)
     for depth in (3, 4):
         params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
-        m, o = _maps(params)
+        m, o = _maps(params, omp=True)       # (the oracle's OpenMP build: same code, the blocks are independent)
         m.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
         o.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
         _compare(m, o, params, f"synth d{depth}")

@@ -13,15 +13,17 @@ from conftest import pcd_path
 pytestmark = pytest.mark.gpu
 
 
-def _maps(params, gp=False):
+def _maps(params, gp=False, omp=False):
+    """device-resident map and its oracle (omp: the oracle's OpenMP build — same code, the blocks are independent —
+    for the cases whose single-thread restatement takes a minute)"""
     import la3dm_amd
     from oracle import oracle as O
     if gp:
         m = la3dm_amd.GPOctoMap(**params, device=0).set_device_resident(True)
-        o = O.OracleGPMap(**params)
+        o = O.OracleGPMap(**params, omp=omp)
     else:
         m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
-        o = O.OracleMap(**params)
+        o = O.OracleMap(**params, omp=omp)
     assert m.is_device_resident()
     return m, o
 
@@ -201,7 +203,7 @@ def test_synthetic_scan(built):
     xyz, origin = la3dm_amd.synthetic_scan(30000)
     for depth in (3, 4):
         params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
-        m, o = _maps(params)
+        m, o = _maps(params, omp=True)
         for _ in range(2):
             m.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
             o.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
@@ -278,7 +280,7 @@ def test_randomised_small_scenes(built):
                       var_thresh=float(rng.choice([0.05, 100.0])), prior_A=0.001, prior_B=0.001)
         md = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
         mh = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
-        o = O.OracleMap(**params)
+        o = O.OracleMap(**params, omp=True)
         for scan in range(3):
             n = int(rng.integers(1, 400))
             origin = rng.uniform(-1, 1, 3).astype(np.float32)
@@ -327,17 +329,17 @@ def test_voxel_grid_index_overflow_passthrough_and_depth5(built):
     from oracle import oracle as O
     rng = np.random.default_rng(17)
     params = dict(la3dm_amd.BGK_YAML)
-    m, o = _maps(params)
-    pts = (rng.uniform(-1, 1, (150, 3)) * np.array([110.0, 110.0, 30.0])).astype(np.float32)   # 2200 x 2200 x 600 cells
+    m, o = _maps(params, omp=True)
+    pts = (rng.uniform(-1, 1, (150, 3)) * np.array([55.0, 55.0, 15.0])).astype(np.float32)   # 2200 x 2200 x 600 cells of 5 cm
     origin = np.zeros(3, np.float32)
-    m.insert_pointcloud(pts, origin, 0.1, 2.0, -1.0)
-    o.insert_pointcloud(pts, origin, 0.1, 2.0, -1.0)
-    t, ref = m.training_data(), O.get_training_data(pts, origin, 0.1, 2.0, -1.0)
+    m.insert_pointcloud(pts, origin, 0.05, 2.0, -1.0)
+    o.insert_pointcloud(pts, origin, 0.05, 2.0, -1.0)
+    t, ref = m.training_data(), O.get_training_data(pts, origin, 0.05, 2.0, -1.0)
     assert t.shape == ref.shape and (t.view(np.uint32) == ref.view(np.uint32)).all()
     assert (t[:, 3] == 1).sum() == 150                      # nothing was merged: the filter passed the cloud through
     _same(m, o, "passthrough")
     params = dict(la3dm_amd.BGK_YAML, block_depth=5, resolution=0.05)
-    m, o = _maps(params)
+    m, o = _maps(params, omp=True)
     xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 3))
     for _ in range(2):
         m.insert_pointcloud(xyz[::5], origin, 0.05, 0.5, 5.0)
