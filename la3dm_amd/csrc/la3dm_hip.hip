@@ -63,6 +63,11 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
     ctx->p = *params;
     ctx->p.lut_xyz = nullptr;
     ctx->device = params->device;
+    {   // x / ell by reciprocal + one exact correction is the IEEE quotient unless ell's significand is all ones
+        uint32_t eb;
+        memcpy(&eb, &params->ell, 4);
+        ctx->inv_ell = (eb & 0x7FFFFFu) != 0x7FFFFFu ? 1.0f / params->ell : 0.0f;
+    }
     ctx->lut_count = params->lut_count;
     auto fail = [&](const char *what, hipError_t e) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -104,23 +109,37 @@ void la3dm_destroy(la3dm_ctx *ctx) {
 
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return LA3DM_ERR_ARG;
-    if (!strcmp(name, "bgk_variant")) {
+    auto bad_value = [&](const char *allowed) {
+        ctx->err = std::string("la3dm_set_option: ") + name + " must be " + allowed;
+        return LA3DM_ERR_ARG;
+    };
+    if (!strcmp(name, "bgk_variant")) {  // 0 = default (v9 where eligible), 5 = always the candidate-major kernel
+        if (value != 0 && value != 5 && value != 9) return bad_value("0, 5 or 9");
         ctx->opt_variant = value;
         return LA3DM_OK;
     }
+    if (!strcmp(name, "fifo_rows")) {
+        if (value != 8 && value != 11 && value != 14 && value != 16) return bad_value("8, 11, 14 or 16");
+        ctx->opt_fifo_rows = value;
+        return LA3DM_OK;
+    }
     if (!strcmp(name, "fast_trig")) {
+        if (value < 0 || value > 2) return bad_value("0, 1 or 2");
         ctx->opt_fast_trig = value;
         return LA3DM_OK;
     }
-    if (!strcmp(name, "waves_per_wg")) {
+    if (!strcmp(name, "waves_per_wg")) {  // launch bounds and LDS sizing exist for these three only
+        if (value != 1 && value != 2 && value != 4) return bad_value("1, 2 or 4");
         ctx->opt_waves = value;
         return LA3DM_OK;
     }
     if (!strcmp(name, "ablate")) {
+        if (value < 0 || value > 7) return bad_value("0..7");
         ctx->opt_ablate = value;
         return LA3DM_OK;
     }
     if (!strcmp(name, "remap")) {
+        if (value < 0 || value > 2) return bad_value("0, 1 or 2");
         ctx->opt_remap = value;
         return LA3DM_OK;
     }
@@ -195,6 +214,8 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.n_tasks = s->n_test_blk << tpb_shift;
     a.flags = s->flags | ((uint32_t)ctx->opt_ablate << 8);
     a.remap = (uint32_t)ctx->opt_remap;
+    a.depth = (uint32_t)ctx->p.block_depth;
+    a.inv_ell = ctx->inv_ell;
     a.sf2 = ctx->p.sf2;
     a.ell = ctx->p.ell;
     a.free_thresh = ctx->p.free_thresh;
@@ -218,7 +239,23 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
     default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, 0, stream, a); break;    \
     }
-    {
+    // per-leaf FIFO kernel (v9): gated update, labels promised to be 0 / 1, sf2 > 0 (its hit threshold assumes a positive
+    // kernel scale); everything else takes v5
+    const bool fifo = (s->flags & LA3DM_SCAN_LABELS_BINARY) && !(s->flags & LA3DM_SCAN_UPDATE_UNGATED) && ctx->p.sf2 > 0.0f &&
+                      ctx->opt_variant != 5;
+    if (fifo) {
+        grid = dim3(a.n_tasks);
+        block = dim3(kWave);
+        if (ctx->opt_fifo_rows == 8) {
+            LAUNCH_BGK(bgk_predict_fuse_v9, , 8)
+        } else if (ctx->opt_fifo_rows == 14) {
+            LAUNCH_BGK(bgk_predict_fuse_v9, , 14)
+        } else if (ctx->opt_fifo_rows == 16) {
+            LAUNCH_BGK(bgk_predict_fuse_v9, , 16)
+        } else {
+            LAUNCH_BGK(bgk_predict_fuse_v9, , 11)
+        }
+    } else {
         const int w = ctx->opt_waves;
         grid = dim3((a.n_tasks + w - 1) / w);
         block = dim3(w * kWave);
@@ -681,7 +718,7 @@ int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bit
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->h_diag_out.ptr, 0, 8, st));
     hipLaunchKernelGGL(sweep_check_kernel, dim3(4096), dim3(256), 0, st, what, lo_bits, hi_bits,
-                       (unsigned long long *)ctx->h_diag_out.ptr);
+                       (unsigned long long *)ctx->h_diag_out.ptr, ctx->p.ell, ctx->inv_ell, ctx->p.sf2);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long v = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->h_diag_out.ptr, 8, hipMemcpyDeviceToHost, st));
