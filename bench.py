@@ -47,7 +47,6 @@ def main():
     ap.add_argument("--resolution", type=float, default=0.1)
     ap.add_argument("--fast-trig", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--fifo-rows", type=int, default=0, help="v9: FIFO rows per round (8/12/16); 0 = library default")
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (kernel variant 3); 0 = library default")
     ap.add_argument("--remap", type=int, default=-1, help="workgroup->tile remap mode; -1 = library default")
     ap.add_argument("--workload", choices=["bgk", "gp", "lv", "l"], default="bgk",
@@ -157,7 +156,7 @@ def main():
         scan.alpha = alpha_t.data_ptr()
         scan.beta = beta_t.data_ptr()
         scan.state = state_t.data_ptr()
-        scan.flags = pk.flags            # LA3DM_SCAN_LABELS_BINARY for an insert_pointcloud scan
+        scan.flags = 0
         payloads.append(payload)
         scans.append(scan)
         keep.append((alpha_t, beta_t, state_t))
@@ -168,8 +167,6 @@ def main():
         m.set_option("fast_trig", args.fast_trig)
     if args.variant:
         m.set_option("bgk_variant", args.variant)
-    if args.fifo_rows:
-        m.set_option("fifo_rows", args.fifo_rows)
     if args.waves:
         m.set_option("waves_per_wg", args.waves)
     if args.remap >= 0:

@@ -49,9 +49,6 @@ enum { LA3DM_FREE = 0, LA3DM_OCCUPIED = 1, LA3DM_UNKNOWN = 2, LA3DM_PRUNED = 3 }
 /* la3dm_bgk_scan.flags */
 #define LA3DM_SCAN_UPDATE_UNGATED 0x1u /* insert_training_data semantics: update even when kbar == 0
                                           (src/bgkoctomap/bgkoctomap.cpp:179-185) */
-#define LA3DM_SCAN_LABELS_BINARY 0x2u  /* promise: every training label is exactly 0.0f or 1.0f (what insert_pointcloud
-                                          produces, bgkoctomap.cpp:398-416).  Lets la3dm_bgk_scan_* take the per-leaf FIFO
-                                          kernel; results are bit-identical with or without the flag. */
 
 /* Map-wide constants: the statics BGKOctoMap's constructor sets
  * (src/bgkoctomap/bgkoctomap.cpp:31-56) plus the voxel look-up table
@@ -129,8 +126,8 @@ void la3dm_destroy(la3dm_ctx *ctx);
 const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last create error */
 
 /* Options: "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial,
- * 2 = OCML; "bgk_variant" 0 = default (the per-leaf FIFO kernel v9 when the scan carries LA3DM_SCAN_LABELS_BINARY and is
- * gated, else the candidate-major kernel v5), 5 = v5 always; "fifo_rows" 8/11/14/16 (v9, default 11); "waves_per_wg" 1/2/4 (v5),
+ * 2 = OCML; "bgk_variant" is accepted and ignored (one implementation is built; the measurement history of the
+ * other variants is in DESIGN.md); "waves_per_wg" 1/2/4,
  * "remap" 0-2, "ablate" 0-7 (profiling); values outside these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
  * rows than this take the split path (default 4096, < 0 = never; results do not depend on it). */

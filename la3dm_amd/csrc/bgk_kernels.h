@@ -269,7 +269,7 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
 // ---------------------------------------------------------------------------
 // bgk_predict_fuse_v5 (the kernel; variants 1-4 and 6 of the measurement history in DESIGN.md are gone):
 // three tight phases per candidate round.
-//   B  test + push, branch free: four candidates per trip; hits of candidate j are written
+//   B  test + push, branch free: four candidates per trip (hit <=> d2 < kHitT); hits of candidate j are written
 //      to ring[tail + rank] (rank = mbcnt of the hit mask), misses to a per-lane scratch
 //      slot; every lane shifts its own hit bit into a 64-candidate history.
 //   C  dense evaluation: lane i evaluates ring[p + i] and writes {k, k*y} back in place.
@@ -283,6 +283,12 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
 // ---------------------------------------------------------------------------
 constexpr int kCand5 = 64;
 constexpr int kRing5 = 448;
+// 0.96778184f: the smallest fp32 T such that k(sqrt(d2)) == 0 (after the < 0 clamp) for EVERY fp32 d2 in [T, 1) —
+// and k <= 0 for every r >= 1 —, so a pair with d2 >= T adds +0 to both sums and can be dropped at the distance
+// test (4.8 % of the pairs inside the unit ball).  The sign of (a + b) does not depend on sf2 > 0.  Checked against the
+// oracle's kernel over all 1.68 M fp32 values of [0.9, 1) (tests/test_oracle.py) and against the device arithmetic by
+// la3dm_diag_sweep(what = 8) (tests/test_bgk_gpu.py).
+constexpr uint32_t kHitTBits = 0x3f77c08du;
 
 struct __attribute__((aligned(16))) WaveLds5 {
     float4 cand[kCand5 + 4];       // x/ell, y/ell, z/ell, label (+ padding slots)
@@ -329,11 +335,25 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
     const uint32_t key = a.leaf_key[li];
     const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
     const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs0 = (off4.x + cx) / a.ell, ys0 = (off4.y + cy) / a.ell, zs0 = (off4.z + cz) / a.ell;
+    const float xs0 = div_by_ell(off4.x + cx, a.ell, a.inv_ell), ys0 = div_by_ell(off4.y + cy, a.ell, a.inv_ell),
+                zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
     float A = a.alpha[li], B = a.beta[li];
 
-    const float lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
-    const float hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    // bounding box of the tile's leaf centres (only culls: any box that contains them is valid).  A full tile of
+    // finest-depth leaves is one 4x4x4 cube in LeafIterator order (descending index, bgkoctree.h:101-135): lane 0 holds
+    // the (+x,+y,+z) corner and lane 63 the (-x,-y,-z) one; anything else (pruned leaves, a short tile) reduces.
+    float lox, loy, loz, hix, hiy, hiz;
+    if (nl == (uint32_t)kWave && __ballot((key >> 16) + 1u != a.depth) == 0ull) {
+        lox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 63));
+        loy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 63));
+        loz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 63));
+        hix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 0));
+        hiy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 0));
+        hiz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 0));
+    } else {
+        lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
+        hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    }
     const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
 
     const bool ungated = (a.flags & 1u) != 0;
@@ -393,6 +413,7 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
         }
     }
 
+    const float hit_t = __uint_as_float(kHitTBits);
     bool more = true;
     while (more) {
         // pad the list to a multiple of four with points no leaf can reach
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
                 for (int u = 0; u < 4; ++u) {
                     const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
                     const float d2 = dx * dx + (dy * dy + dz * dz);
-                    const bool hit = d2 < 1.0f;  // k(r) <= 0 for every fp32 r >= 1
+                    const bool hit = d2 < hit_t;  // k(sqrt(d2)) == 0 for every fp32 d2 >= kHitT
                     const unsigned long long m = __ballot(hit);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
                     const uint32_t slot = hit ? tail + rank : (uint32_t)(kRing5 + lane);
@@ -505,298 +526,6 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
     }
 }
 
-// ---------------------------------------------------------------------------
-// bgk_predict_fuse_v9 — per-leaf FIFOs instead of a candidate-major pair ring (round 2).
-// Same tile / lane = leaf decomposition, same staged candidate list, same arithmetic and the same summation order
-// as v5 (results bit-identical); what changes is how a hit travels from the distance test to the ordered sums:
-//   B  test + push: hit <=> d2 < kHitT (every fp32 d2 >= kHitT has k(sqrt(d2)) == 0 — swept exhaustively, so the
-//      pair contributes nothing to either sum); a hit lane appends {d2 | label bit} to ITS OWN FIFO column
-//      fifo[slot][lane] (exec-masked ds_write_b32, conflict-free) — no ballot rank, no hit history.
-//   R  row compaction: the valid lanes of FIFO row s push their slot address into a dense list (one ballot +
-//      mbcnt per ROW, <= kS rows per round, instead of one per candidate).
-//   C  dense evaluation over the list, {d2 | label} -> {k | label} in place.
-//   D  ordered fuse: lane = leaf walks its own column (lane-contiguous reads), in candidate order.  The
-//      per-neighbour flush of Occupancy::update runs lazily per lane with flag arithmetic on fast fp32 ops only:
-//      with f = 1.0 where the entry is the lane's first hit of a new neighbour (else 0) and g = 1 - f,
-//          A = fma(ybar, f, A);  B = fma(kbar - ybar, f, B);  kbar = fma(kbar, g, k);  ybar = fma(ybar, g, k*y)
-//      reproduces `if (kbar > 0) { A += ybar; B += kbar - ybar; }` + restart exactly: ybar*f and kbar*g are exact,
-//      so every fma rounds once like the reference's add; a neighbour without hits adds +0 to A and B (no-op),
-//      which is also why the kbar > 0 gate needs no branch.  Labels must be 0 or 1 (LA3DM_SCAN_LABELS_BINARY):
-//      k * y is k or +0, carried as the sign bit of the FIFO entry (k >= +0 after the clamp).
-// LDS per wave (kS = 11): candidates 1 KB + FIFO 2.75 KB + list 1 KB = 4 928 B (8 waves per SIMD).
-// ---------------------------------------------------------------------------
-constexpr uint32_t kHitTBits = 0x3f77c08du;  // 0.96778184f: smallest fp32 T with k(sqrt(d2)) == 0 for all d2 in [T, 1)
-
-constexpr int kList9 = 512;  // entries of the dense list; a round with more pairs runs R + C in two chunks
-
-template <int kS>
-struct __attribute__((aligned(16))) WaveLds9 {
-    float4 cand[kCand5 + 4];
-    uint32_t fifo[kS * kWave];
-    uint16_t list[kList9];
-};
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int kTrig, int kS>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(kS <= 11 ? 8 : 7, 8))) void bgk_predict_fuse_v9(BgkArgs a) {
-    __shared__ WaveLds9<kS> L;
-    const int lane = threadIdx.x & 63;
-    uint32_t wg = blockIdx.x;
-    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
-    else if (a.remap == 2) {
-        const uint32_t G8 = gridDim.x & ~63u;
-        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
-    }
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg);
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const bool active = (uint32_t)lane < nl;
-    const uint32_t li = l0 + (active ? lane : 0);
-
-    uint32_t p0[7], cnt[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        const uint2 r = a.nbr_range[7 * blk + b];
-        p0[b] = r.x;
-        cnt[b] = r.y;
-    }
-    float4 q[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b)
-        q[b] = ((uint32_t)lane < cnt[b]) ? a.pts[p0[b] + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    const uint32_t key = a.leaf_key[li];
-    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
-    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
-    const float xs0 = div_by_ell(off4.x + cx, a.ell, a.inv_ell), ys0 = div_by_ell(off4.y + cy, a.ell, a.inv_ell),
-                zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
-    float A = a.alpha[li], B = a.beta[li];
-
-#pragma unroll
-    for (int s = 0; s < kS; ++s) L.fifo[s * kWave + lane] = 0u;  // invariant: the FIFO is all zero between rounds
-
-    // bounding box of the tile's leaf centres (only culls: any box that contains them is valid).  A full tile of
-    // finest-depth leaves is one 4x4x4 cube in LeafIterator order (descending index, bgkoctree.h:101-135): lane 0 holds
-    // the (+x,+y,+z) corner and lane 63 the (-x,-y,-z) one; anything else (pruned leaves, a short tile) reduces.
-    float lox, loy, loz, hix, hiy, hiz;
-    if (nl == (uint32_t)kWave && __ballot((key >> 16) + 1u != a.depth) == 0ull) {
-        lox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 63));
-        loy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 63));
-        loz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 63));
-        hix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 0));
-        hiy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 0));
-        hiz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 0));
-    } else {
-        lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);
-        hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
-    }
-    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
-
-    uint32_t anyk = 0;
-    uint32_t ncand = 0;
-    unsigned long long nbstart = 0;  // bit s: candidate slot s is the first of a new neighbour
-    int last_nb = -1;
-
-    auto stage = [&](const float4 &p, bool valid, int b) {
-        bool keep = false;
-        if (valid) {
-            const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
-            const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
-            const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
-            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
-        }
-        const unsigned long long m = __ballot(keep);
-        if (b != last_nb && m != 0ull) {
-            nbstart |= 1ull << ncand;
-            last_nb = b;
-        }
-        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        // the label travels as a sign bit: -0.0f for label 1, +0.0f for label 0
-        if (keep) L.cand[slot] = make_float4(p.x, p.y, p.z, p.w != 0.0f ? -0.0f : 0.0f);
-        ncand += (uint32_t)__popcll(m);
-    };
-
-    uint32_t it_b = 7, it_base = 0;
-    {
-        bool open = true;
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            if (!open || cnt[b] == 0) continue;
-            if (ncand + min(cnt[b], (uint32_t)kWave) <= (uint32_t)kCand5) {
-                stage(q[b], (uint32_t)lane < cnt[b], b);
-                if (cnt[b] > (uint32_t)kWave) {
-                    open = false;
-                    it_b = b;
-                    it_base = kWave;
-                }
-            } else {
-                open = false;
-                it_b = b;
-                it_base = 0;
-            }
-        }
-    }
-
-    const float hit_t = __uint_as_float(kHitTBits);
-    const uint32_t wbase = (uint32_t)lane * 4u;                    // byte address of this lane's column, row 0
-    const uint32_t wlimit = wbase + (uint32_t)(kS - 4) * 256u;     // above this a lane has < 4 free rows
-    const uint32_t wfull = wbase + (uint32_t)kS * 256u;            // the column is full
-
-    // bit s: row s of this lane's column starts a new neighbour.  D shifts one bit out per row, so after a round only
-    // bit 0 can be left: a flag set at a lane's final count when that count equals the round's row count — it then
-    // belongs to the lane's first row of the next round and is carried over.
-    uint32_t fm = 0;
-    f32x2 AB = {A, B};
-    f32x2 KY = {0.0f, 0.0f};  // (kbar, ybar) of the neighbour the lane is in
-    bool more = true;
-    while (more) {
-        if (lane < 4) L.cand[ncand + lane] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t nc4 = (a.flags & 0x200u) ? 0u : (ncand + 3u) & ~3u;  // 0x200: profiling ablation
-        uint32_t c = 0;
-        while (c < nc4) {
-            // ---- B: test + push into the lane's own FIFO column ----
-            uint32_t waddr = wbase;
-            auto test_push = [&](const float4 &p) {
-                const float dx = p.x - xs, dy = p.y - ys, dz = p.z - zs;
-                const float d2 = dx * dx + (dy * dy + dz * dz);
-                if (d2 < hit_t) {
-                    *(uint32_t *)((char *)L.fifo + waddr) = __float_as_uint(d2) | __float_as_uint(p.w);
-                    waddr += 256u;
-                }
-            };
-            auto mark_start = [&]() {  // the lane's next row opens a new neighbour
-                uint32_t bit = 1u << ((waddr - wbase) >> 8);
-                asm volatile("" : "+v"(bit));  // keep this off the common path (no speculation into selects)
-                fm |= bit;
-            };
-            while (c < nc4) {
-                if ((c & 3u) == 0u && __ballot(waddr > wlimit) == 0ull) {  // four candidates, every lane has room
-                    float4 t[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] = L.cand[c + u];
-                    const uint32_t sb = (uint32_t)(nbstart >> c) & 0xFu;
-                    if (sb == 0u) {  // the common group: no neighbour starts inside it
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) test_push(t[u]);
-                    } else {         // <= 7 groups per tile
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (sb & (1u << u)) mark_start();
-                            test_push(t[u]);
-                        }
-                    }
-                    c += 4;
-                } else {  // a column is nearly full: one candidate at a time until one is full
-                    if (__ballot(waddr >= wfull) != 0ull) break;
-                    const float4 t = L.cand[c];
-                    if ((nbstart >> c) & 1ull) mark_start();
-                    test_push(t);
-                    c += 1;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- R + C: rows -> dense list of slot addresses -> dense evaluation, {d2 | label} -> {k | label} in place
-            const uint32_t nrow = (waddr - wbase) >> 8;
-            uint32_t rows = 0;
-            {
-                uint32_t la = wbase;
-                uint32_t s = 0;
-                while (s < (uint32_t)kS) {
-                    uint32_t total = 0;
-                    for (; s < (uint32_t)kS && total <= (uint32_t)(kList9 - kWave); ++s) {
-                        const bool v = nrow > s;
-                        const unsigned long long m = __ballot(v);
-                        if (m == 0ull) {
-                            s = kS;
-                            break;
-                        }
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                        if (v) L.list[total + rank] = (uint16_t)la;
-                        la += 256u;
-                        total += (uint32_t)__popcll(m);
-                        ++rows;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t p = 0; p < ((a.flags & 0x100u) ? 0u : total); p += kWave) {  // 0x100: profiling ablation
-                        const uint32_t i = p + lane;
-                        if (i < total) {
-                            uint32_t *slot = (uint32_t *)((char *)L.fifo + L.list[i]);
-                            const uint32_t e = *slot;
-                            const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(e & 0x7FFFFFFFu)), a.sf2);
-                            *slot = (__float_as_uint(kv) & 0x7FFFFFFFu) | (e & 0x80000000u);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            // ---- D: ordered fuse down the lane's own column; rows are zeroed behind the read ----
-            for (uint32_t s = 0; s < rows; ++s) {
-                const uint32_t e = L.fifo[s * kWave + lane];
-                L.fifo[s * kWave + lane] = 0u;
-                if (a.flags & 0x400u) continue;  // 0x400: profiling ablation
-                const uint32_t kb = e & 0x7FFFFFFFu;
-                const uint32_t kyb = kb & (uint32_t)((int32_t)e >> 31);
-                const uint32_t fb = 0u - (fm & 1u);
-                fm >>= 1;
-                const float f = __uint_as_float(fb & 0x3F800000u);
-                const float gq = __uint_as_float(~fb & 0x3F800000u);
-                // f = 1: Occupancy::update of the finished neighbour (A += ybar; B += kbar - ybar), then restart the sums
-                const f32x2 upd = {KY.y, KY.x - KY.y};
-                const f32x2 ff = {f, f}, gg = {gq, gq};
-                const f32x2 in = {__uint_as_float(kb), __uint_as_float(kyb)};
-                AB = __builtin_elementwise_fma(upd, ff, AB);
-                KY = __builtin_elementwise_fma(KY, gg, in);
-                anyk |= kb;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        ncand = 0;
-        nbstart = 0;
-        // refill in order (rare: > 64 points in a block, or a crowded 7-neighbourhood)
-        more = false;
-        while (it_b < 7) {
-            const uint2 rr = a.nbr_range[7 * blk + it_b];
-            const uint32_t pp0 = rr.x, pc = rr.y;
-            if (it_base >= pc) {
-                ++it_b;
-                it_base = 0;
-                continue;
-            }
-            if (ncand != 0u) break;  // one 64-point chunk per refill round
-            const bool valid = it_base + lane < pc;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) p = a.pts[pp0 + it_base + lane];
-            stage(p, valid, (int)it_b);
-            it_base += kWave;
-            more = true;
-        }
-    }
-    // last neighbour's flush (bgkoctree_node.cpp:31-35)
-    A = AB.x + KY.y;
-    B = AB.y + (KY.x - KY.y);
-
-    if (active) {
-        if (anyk != 0u) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
-        } else {
-            a.state[li] = 0;
-        }
-    }
-}
-
 // exhaustive sweeps of the kernel's shortcuts against the IEEE operations:
 // counts fp32 inputs in [lo_bits, hi_bits] (as unsigned bit patterns) where they differ.
 __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatch, float ell,
@@ -811,7 +540,7 @@ __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits,
         else if (what == 2) ok = sqrt_cr(x) == sqrtf(x);
         else if (what == 4) ok = sqrtf(x) == (float)sqrt((double)x);
         else if (what == 5) ok = div_const(x, 2.0f * 3.1415926f, 0.159154952f) == x / (2.0f * 3.1415926f);
-        else if (what == 7) ok = div_const(x, ell, inv_ell) == x / ell && div_const(-x, ell, inv_ell) == -x / ell;
+        else if (what == 7) ok = div_by_ell(x, ell, inv_ell) == x / ell && div_by_ell(-x, ell, inv_ell) == -x / ell;
         else if (what == 8) ok = !(cov_sparse_fast<0>(sqrt_cr(x), sf2) > 0.0f);  // no support left at this d2
         else {  // sincos_cr vs the double-precision library functions rounded to float
             float s, c;

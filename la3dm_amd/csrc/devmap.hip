@@ -792,8 +792,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
 
     if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
-    // the front end labels hits 1 and free samples 0 (GP: +-1, its kernel ignores the flag)
-    return scan_training_set(dm, ctx->p.variant == 0 ? LA3DM_SCAN_LABELS_BINARY : 0u, t0, stats_out);
+    return scan_training_set(dm, 0u, t0, stats_out);
 }
 
 int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride, const float origin[3],

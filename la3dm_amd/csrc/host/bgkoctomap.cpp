@@ -1093,8 +1093,8 @@ inline AxisCand axis_candidates(float v, float size, float h) {
 }
 }  // namespace
 
-bool BGKOctoMap::partition_and_pack(bool ungated, bool binary_labels) {
-    scan_flags = (ungated ? LA3DM_SCAN_UPDATE_UNGATED : 0u) | (binary_labels ? LA3DM_SCAN_LABELS_BINARY : 0u);
+bool BGKOctoMap::partition_and_pack(bool ungated) {
+    scan_flags = ungated ? LA3DM_SCAN_UPDATE_UNGATED : 0u;
     passes.clear();
     prune_list.clear();
     train_xyzy.clear();
@@ -1454,7 +1454,7 @@ bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3
     }
     get_training_data(xyz, n, stride, origin, ds_resolution, free_res, max_range);
     stats.t_frontend = wall() - t0;
-    return partition_and_pack(false, variant == 0);  // get_training_data labels hits 1, free samples 0
+    return partition_and_pack(false);
 }
 
 bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated) {

@@ -412,7 +412,7 @@ public:
 protected:
     void get_training_data(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                            float free_resolution, float max_range);
-    bool partition_and_pack(bool ungated, bool binary_labels = false);
+    bool partition_and_pack(bool ungated);
     void refresh_pass(size_t p);
     void write_nodes(size_t p);
 

@@ -20,8 +20,7 @@ struct la3dm_ctx {
     float4 *d_lut = nullptr;
     uint32_t lut_count = 0;
     std::string err;
-    int opt_variant = 0;   // 0 default (v9 where eligible), 5 = candidate-major kernel only
-    int opt_fifo_rows = 11; // v9: FIFO rows per round (8 / 11 / 14 / 16); 11 keeps 8 waves per SIMD
+    int opt_variant = 0;   // unused (one BGK kernel is built)
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
     int opt_time_kernel = 0;

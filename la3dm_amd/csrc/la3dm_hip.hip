@@ -113,14 +113,8 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->err = std::string("la3dm_set_option: ") + name + " must be " + allowed;
         return LA3DM_ERR_ARG;
     };
-    if (!strcmp(name, "bgk_variant")) {  // 0 = default (v9 where eligible), 5 = always the candidate-major kernel
-        if (value != 0 && value != 5 && value != 9) return bad_value("0, 5 or 9");
+    if (!strcmp(name, "bgk_variant")) {  // accepted and ignored: one implementation is built
         ctx->opt_variant = value;
-        return LA3DM_OK;
-    }
-    if (!strcmp(name, "fifo_rows")) {
-        if (value != 8 && value != 11 && value != 14 && value != 16) return bad_value("8, 11, 14 or 16");
-        ctx->opt_fifo_rows = value;
         return LA3DM_OK;
     }
     if (!strcmp(name, "fast_trig")) {
@@ -239,23 +233,7 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
     default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, 0, stream, a); break;    \
     }
-    // per-leaf FIFO kernel (v9): gated update, labels promised to be 0 / 1, sf2 > 0 (its hit threshold assumes a positive
-    // kernel scale); everything else takes v5
-    const bool fifo = (s->flags & LA3DM_SCAN_LABELS_BINARY) && !(s->flags & LA3DM_SCAN_UPDATE_UNGATED) && ctx->p.sf2 > 0.0f &&
-                      ctx->opt_variant != 5;
-    if (fifo) {
-        grid = dim3(a.n_tasks);
-        block = dim3(kWave);
-        if (ctx->opt_fifo_rows == 8) {
-            LAUNCH_BGK(bgk_predict_fuse_v9, , 8)
-        } else if (ctx->opt_fifo_rows == 14) {
-            LAUNCH_BGK(bgk_predict_fuse_v9, , 14)
-        } else if (ctx->opt_fifo_rows == 16) {
-            LAUNCH_BGK(bgk_predict_fuse_v9, , 16)
-        } else {
-            LAUNCH_BGK(bgk_predict_fuse_v9, , 11)
-        }
-    } else {
+    {
         const int w = ctx->opt_waves;
         grid = dim3((a.n_tasks + w - 1) / w);
         block = dim3(w * kWave);

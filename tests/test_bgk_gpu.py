@@ -87,6 +87,26 @@ def test_device_primitives_bit_exact(built):
         assert np.abs(g - ref).max() <= 7e-8, op
 
 
+def test_hit_threshold_and_division_by_ell_exhaustive(built):
+    """two shortcuts of the predict kernel, checked over EVERY fp32 input of their ranges on the device:
+    (1) a pair is dropped at the distance test when d2 >= 0x3f77c08d (0.96778184) — the device's own k(sqrt(d2)) must be
+        0 for every fp32 d2 in [that, 1) and positive one ulp below it (for three kernel scales sf2);
+    (2) (LUT + centre) / ell by reciprocal + one exact FMA correction equals the IEEE division for every fp32 x with
+        |x| in [2^-10, 2^17] (map coordinates), for ell = 0.2 (the YAML value) and two awkward ones; an ell whose
+        significand is all ones falls back to the division itself."""
+    import la3dm_amd
+    T = np.uint32(0x3f77c08d).view(np.float32)
+    below = np.uint32(0x3f77c08c).view(np.float32)
+    last = np.uint32(0x3f7fffff).view(np.float32)
+    for sf2 in (1.0, 0.1, 37.5):
+        m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, sf2=sf2), device=0)
+        assert m.diag_sweep(8, T, last) == 0
+        assert m.diag_sweep(8, below, below) == 1
+    for ell in (0.2, 0.3, 1.9999998807907104, 0.1):      # the third one: significand all ones -> IEEE division path
+        m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, ell=ell), device=0)
+        assert m.diag_sweep(7, 2.0 ** -10, 2.0 ** 17) == 0, ell
+
+
 @pytest.mark.parametrize("depth", [3, 4])
 def test_config1_sim_structured_scan1(built, depth):
     """BASELINE config 1: sim_structured scan 1, bgkoctomap.yaml, max_range 8."""

@@ -255,3 +255,18 @@ def test_reference_rtree_gather_order_stays_within_the_tolerance(O):
     assert reordered > 50 and n_leaf > 5000       # the tree's order really differs from ascending index
     assert worst <= 1e-5, worst
     assert worst < 2e-6                           # in fact: a few ulps of the sums
+
+
+def test_kernel_support_ends_at_the_device_hit_threshold(built):
+    """the predict kernel drops a pair when d2 >= 0x3f77c08d: with the oracle's arithmetic (correctly rounded sqrt,
+    sin, cos; bgkinference.h:113-126) k(sqrt(d2)) is 0 for every one of the fp32 values of [that, 1) and positive one
+    ulp below — and the support does not depend on sf2 > 0."""
+    from oracle import oracle as O
+    lo, hi = int(np.float32(0.90).view(np.uint32)), int(np.float32(1.0).view(np.uint32))
+    d2 = np.arange(lo, hi, dtype=np.uint32).view(np.float32)
+    r = np.sqrt(d2)
+    assert r.dtype == np.float32
+    for sf2 in (1.0, 0.1, 37.5):
+        pos = O.kernel(r, sf2) > 0
+        assert int(d2[pos].max().view(np.uint32)) == 0x3f77c08c, sf2
+    assert (O.kernel(np.linspace(1.0, 4.0, 300001).astype(np.float32), 1.0) == 0).all()
