@@ -282,7 +282,7 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
 // LDS per wave: 64 candidates (1 KB) + 448-pair ring and scratch (4 KB).
 // ---------------------------------------------------------------------------
 constexpr int kCand5 = 64;
-constexpr int kRing5 = 448;
+constexpr int kRing5 = 432;  // with the 64 scratch slots and the zero entry the wave's LDS stays within 5 120 B (8 waves per SIMD)
 // 0.96778184f: the smallest fp32 T such that k(sqrt(d2)) == 0 (after the < 0 clamp) for EVERY fp32 d2 in [T, 1) —
 // and k <= 0 for every r >= 1 —, so a pair with d2 >= T adds +0 to both sums and can be dropped at the distance
 // test (4.8 % of the pairs inside the unit ball).  The sign of (a + b) does not depend on sf2 > 0.  Checked against the
@@ -292,11 +292,59 @@ constexpr uint32_t kHitTBits = 0x3f77c08du;
 
 struct __attribute__((aligned(16))) WaveLds5 {
     float4 cand[kCand5 + 4];       // x/ell, y/ell, z/ell, label (+ padding slots)
-    uint2 ring[kRing5 + kWave];    // {d2, candidate} -> {k, k*y}; last 64 = per-lane scratch
+    uint2 ring[kRing5 + kWave + 1];  // {d2, candidate} -> {k, k*y}; then 64 per-lane scratch slots and one {0, 0} entry
 };
 
+// The two loops that run once per staged candidate are written in gfx950 assembly: the compiler's versions carried
+// ~9 scalar and ~16 vector instructions per candidate in B (exec-mask juggling around the compaction, 64-bit history
+// shifts) and 6 + 13 in D; scalar instructions cost an issue slot like vector ones on this chip
+// (profiles/r02/valu_issue.txt), so the instruction count is the time.  Here B is 15 VALU + 2 SALU + 1 LDS and D's
+// gather 6 VALU + 2 SALU + 1 LDS per candidate (the ordered adds and the per-neighbour flush stay in C++).  No DPP / lane-select / transcendental / packed instruction is used, so none
+// of the gfx9 data hazards applies except gfx940's "VALU writes an SGPR / VCC -> a VALU reads it as an operand, carry or
+// mask: 2 wait states" — every v_cmp below is followed by two instructions that do not read its mask.  LDS returns
+// in order, so lgkmcnt(n) counts this block's own reads from the back of the queue.
+//
+// B, one candidate {X, Y, Z} (training point / ell), lane = leaf at (xs, ys, zs):
+//   d2 = dx*dx + (dy*dy + dz*dz) in the reference's association (bgkinference.h:88-93); hit <=> d2 < T;
+//   hit lanes write {d2, candidate index} to ring[tail + rank] (rank = mbcnt of the hit mask), the others to their
+//   scratch slot; the lane's hit bit is shifted into its history word (h = 2 h + hit: v_addc with the mask as carry).
+#define LA3DM_B_HEAD(A, X, Y)                               \
+    "v_sub_f32 " A ", " X ", %[xs]\n"                       \
+    "v_sub_f32 %[tb], " Y ", %[ys]\n"
+#define LA3DM_B_TAIL(A, Z)                                  \
+    "v_sub_f32 %[tc], " Z ", %[zs]\n"                       \
+    "v_mul_f32 " A ", " A ", " A "\n"                       \
+    "v_mul_f32 %[tb], %[tb], %[tb]\n"                       \
+    "v_mul_f32 %[tc], %[tc], %[tc]\n"                       \
+    "v_add_f32 %[tb], %[tb], %[tc]\n"                       \
+    "v_add_f32 " A ", " A ", %[tb]\n"                       \
+    "v_cmp_gt_f32 vcc, %[T], " A "\n"
+#define LA3DM_B_PUSH(A)                                     \
+    "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
+    "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
+    "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
+    "v_cndmask_b32 %[tr], %[scr], %[tr], vcc\n"             \
+    "ds_write2_b32 %[tr], " A ", %[idx] offset1:1\n"        \
+    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
+    "v_add_u32 %[idx], 1, %[idx]\n"                         \
+    "v_addc_co_u32 %[h], vcc, %[h], %[h], vcc\n"            \
+    "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
+// D, one candidate: the lane's hit bit leaves the history word at the top (oldest first); hit lanes read their
+// {k, k*y} at ring[roff + rank], the others the zero entry; E = the 64-bit register pair that receives it.
+#define LA3DM_D_CAND(E)                                     \
+    "v_cmp_gt_i32 vcc, 0, %[h]\n"                           \
+    "v_add_u32 %[h], %[h], %[h]\n"                          \
+    "s_nop 0\n"                                             \
+    "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
+    "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
+    "v_lshl_add_u32 %[tr], %[tr], 3, %[roff]\n"             \
+    "v_cndmask_b32 %[tr], %[zad], %[tr], vcc\n"             \
+    "ds_read_b64 " E ", %[tr]\n"                            \
+    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
+    "s_lshl3_add_u32 %[roff], %[st], %[roff]\n"
+
 template <int kTrig, int kWaves>
-__global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) {
+__global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(kWaves == 1 ? 8 : 4, 8))) void bgk_predict_fuse_v5(BgkArgs a) {
     __shared__ WaveLds5 s_lds[kWaves];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -339,11 +387,14 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
                 zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
     float A = a.alpha[li], B = a.beta[li];
 
-    // bounding box of the tile's leaf centres (only culls: any box that contains them is valid).  A full tile of
-    // finest-depth leaves is one 4x4x4 cube in LeafIterator order (descending index, bgkoctree.h:101-135): lane 0 holds
-    // the (+x,+y,+z) corner and lane 63 the (-x,-y,-z) one; anything else (pruned leaves, a short tile) reduces.
+    // bounding box of the tile's leaf centres (only culls: any box that contains them is valid).  64 finest-depth
+    // leaves with the indices 64 c + 63 ... 64 c (LeafIterator order is descending, bgkoctree.h:101-135) are one aligned
+    // 4x4x4 cube: lane 0 holds its (+x,+y,+z) corner and lane 63 the (-x,-y,-z) one.  Anything else — a short tile,
+    // coarse leaves, or 64 fine leaves that straddle two cubes of a partly pruned block — takes the reduction.
     float lox, loy, loz, hix, hiy, hiz;
-    if (nl == (uint32_t)kWave && __ballot((key >> 16) + 1u != a.depth) == 0ull) {
+    const uint32_t key_first = __builtin_amdgcn_readlane(key, 0), key_last = __builtin_amdgcn_readlane(key, 63);
+    if (nl == (uint32_t)kWave && (key_last & 63u) == 0u && key_first == key_last + 63u &&
+        __ballot((key >> 16) + 1u != a.depth) == 0ull) {
         lox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 63));
         loy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 63));
         loz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 63));
@@ -414,6 +465,11 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
     }
 
     const float hit_t = __uint_as_float(kHitTBits);
+    // LDS byte addresses (the low 32 bits of a generic pointer into LDS are the LDS offset)
+    const uint32_t ring_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&L.ring[0]);
+    const uint32_t scratch_addr = ring_base + 8u * (uint32_t)(kRing5 + lane);
+    const uint32_t zero_addr = ring_base + 8u * (uint32_t)(kRing5 + kWave);
+    if (lane == 0) L.ring[kRing5 + kWave] = make_uint2(0u, 0u);
     bool more = true;
     while (more) {
         // pad the list to a multiple of four with points no leaf can reach
@@ -423,28 +479,37 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
         const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
         uint32_t g = 0;
         while (g < ngroup) {
-            // ---- B: test + push ----
+            // ---- B: test + push (assembly, four candidates per trip) ----
             const uint32_t g0 = g;
-            uint32_t tail = 0;
-            unsigned long long hist = 0;
-            for (; g < ngroup && tail <= (uint32_t)(kRing5 - 4 * kWave); ++g) {
+            uint32_t tailb = ring_base;          // LDS byte address of ring[tail]
+            uint32_t hA = 0, hB = 0;             // hit history: candidates 0-31 of this round in hA, 32-63 in hB
+            uint32_t idx = 4 * g;                // candidate index, uniform, in a VGPR for the ring entry
+            auto b_trip = [&](uint32_t &hw) {
                 float4 t[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
-                    const float d2 = dx * dx + (dy * dy + dz * dz);
-                    const bool hit = d2 < hit_t;  // k(sqrt(d2)) == 0 for every fp32 d2 >= kHitT
-                    const unsigned long long m = __ballot(hit);
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                    const uint32_t slot = hit ? tail + rank : (uint32_t)(kRing5 + lane);
-                    L.ring[slot] = make_uint2(__float_as_uint(d2), 4 * g + u);
-                    tail += (uint32_t)__popcll(m);
-                    hist = (hist << 1) | (hit ? 1ull : 0ull);
-                }
-            }
+                // software-pipelined by hand: the first two instructions of the next candidate sit between a v_cmp and the
+                // first reader of its mask (the gfx940 two-wait-state rule); the last candidate pays an s_nop
+                float a0, a1, tb2, tc, tr;
+                uint32_t st;
+                asm volatile(LA3DM_B_HEAD("%[a0]", "%[x0]", "%[y0]") LA3DM_B_TAIL("%[a0]", "%[z0]")
+                             LA3DM_B_HEAD("%[a1]", "%[x1]", "%[y1]") LA3DM_B_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z1]")
+                             LA3DM_B_HEAD("%[a0]", "%[x2]", "%[y2]") LA3DM_B_PUSH("%[a1]") LA3DM_B_TAIL("%[a0]", "%[z2]")
+                             LA3DM_B_HEAD("%[a1]", "%[x3]", "%[y3]") LA3DM_B_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z3]")
+                             "s_nop 1\n" LA3DM_B_PUSH("%[a1]")
+                             : [h] "+v"(hw), [idx] "+v"(idx), [tail] "+s"(tailb), [a0] "=&v"(a0), [a1] "=&v"(a1), [tb] "=&v"(tb2),
+                               [tc] "=&v"(tc), [tr] "=&v"(tr), [st] "=&s"(st)
+                             : [xs] "v"(xs), [ys] "v"(ys), [zs] "v"(zs), [T] "s"(hit_t), [scr] "v"(scratch_addr), [x0] "v"(t[0].x),
+                               [y0] "v"(t[0].y), [z0] "v"(t[0].z), [x1] "v"(t[1].x), [y1] "v"(t[1].y), [z1] "v"(t[1].z),
+                               [x2] "v"(t[2].x), [y2] "v"(t[2].y), [z2] "v"(t[2].z), [x3] "v"(t[3].x), [y3] "v"(t[3].y),
+                               [z3] "v"(t[3].z)
+                             : "vcc", "memory");
+            };
+            const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRing5 - 4 * kWave);
+            for (; g < ngroup && tailb <= tail_cap && g - g0 < 8u; ++g) b_trip(hA);
+            for (; g < ngroup && tailb <= tail_cap; ++g) b_trip(hB);
             const uint32_t nstep = 4 * (g - g0);
+            const uint32_t tail = (tailb - ring_base) >> 3;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- C: dense evaluation, {d2, candidate} -> {k, k*y} in place ----
@@ -459,31 +524,44 @@ __global__ __launch_bounds__(kWaves *kWave) void bgk_predict_fuse_v5(BgkArgs a) 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // ---- D: ordered fuse, four candidates per trip (reads issued together) ----
-            uint32_t roff = 0;
+            // ---- D: ordered fuse, four candidates per trip; a trip with a neighbour start takes the C++ path ----
+            uint32_t roffb = ring_base;
             unsigned long long starts = nbstart >> (4 * g0);
-            unsigned long long h = nstep ? hist << (64u - nstep) : 0ull;  // oldest candidate in bit 63
+            // oldest candidate first: the first word (hA when the round has more than 32 candidates) is full; the last one
+            // holds nlast bits at its bottom
+            const uint32_t nlast = nstep > 32u ? nstep - 32u : nstep;
+            const uint32_t hlast = nlast ? (nstep > 32u ? hB : hA) << (32u - nlast) : 0u;
+            uint32_t hc = nstep > 32u ? hA : hlast;
             for (uint32_t s2 = 0; s2 < ((a.flags & 0x400u) ? 0u : nstep); s2 += 4) {  // 0x400: profiling ablation
+                if (s2 == 32u) hc = hlast;
                 const uint32_t sb = (uint32_t)starts & 0xFu;
                 starts >>= 4;
-                const uint32_t hh = (uint32_t)(h >> 32);
-                h <<= 4;
-                bool mine[4];
-                uint2 e[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    mine[u] = (hh & (0x80000000u >> u)) != 0u;
-                    const unsigned long long m = __ballot(mine[u]);
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                    e[u] = L.ring[roff + rank];  // in bounds for every lane; only `mine` lanes use it
-                    roff += (uint32_t)__popcll(m);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (sb & (1u << u)) flush_nb();  // uniform
-                    // adding +0.0 leaves a non-negative-zero accumulator unchanged
-                    ybar += mine[u] ? __uint_as_float(e[u].y) : 0.0f;
-                    kbar += mine[u] ? __uint_as_float(e[u].x) : 0.0f;
+                {
+                    // gather (assembly): the four entries land in fixed register pairs, all four reads are back at the end
+                    register float e0k asm("v56"), e0y asm("v57"), e1k asm("v58"), e1y asm("v59"), e2k asm("v60"), e2y asm("v61"),
+                        e3k asm("v62"), e3y asm("v63");
+                    float tr;
+                    uint32_t st;
+                    asm volatile(LA3DM_D_CAND("v[56:57]") LA3DM_D_CAND("v[58:59]") LA3DM_D_CAND("v[60:61]") LA3DM_D_CAND("v[62:63]")
+                                 "s_waitcnt lgkmcnt(0)\n"
+                                 : [h] "+v"(hc), [roff] "+s"(roffb), [tr] "=&v"(tr), [st] "=&s"(st), "=v"(e0k), "=v"(e0y), "=v"(e1k),
+                                   "=v"(e1y), "=v"(e2k), "=v"(e2y), "=v"(e3k), "=v"(e3y)
+                                 : [zad] "v"(zero_addr)
+                                 : "vcc", "memory");
+                    // ordered sums; Occupancy::update where a neighbour starts (uniform).  Adding the zero entry's +0.0
+                    // leaves a non-negative-zero accumulator unchanged.
+                    if (sb & 1u) flush_nb();
+                    ybar += e0y;
+                    kbar += e0k;
+                    if (sb & 2u) flush_nb();
+                    ybar += e1y;
+                    kbar += e1k;
+                    if (sb & 4u) flush_nb();
+                    ybar += e2y;
+                    kbar += e2k;
+                    if (sb & 8u) flush_nb();
+                    ybar += e3y;
+                    kbar += e3k;
                 }
             }
             __builtin_amdgcn_wave_barrier();
