@@ -60,6 +60,8 @@ def main():
                     help="N > 1: one leaf buffer, every all-gather finishes before the next kernel starts")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (device-resident insert_pointcloud) leg")
+    ap.add_argument("--no-big", action="store_true",
+                    help="skip the out-of-cache leg (configs[4]'s 1M-ray scan on this GPU: working set > the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-omp", dest="cpu_omp", action="store_false",
                     help="skip the all-core OpenMP run of the oracle (cpu_baseline_omp)")
     args = ap.parse_args()
@@ -237,18 +239,8 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_U / (dt / args.steps)
         achieved = b_alg / (k_ms * 1e-3) / 1e9
-        traffic = None
-        valu = None
-        tpath = os.path.join(ROOT, "profiles", "bgk_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                key = f"rays{args.rays}_d{args.depth}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                valu = tj.get(key, {}).get("valu_insts_per_launch")
-            except Exception:
-                traffic = None
+        counters = profiled_counters(f"rays{args.rays}_d{args.depth}_r{args.resolution}")
+        traffic = counters.get("hbm_bytes_per_launch") if counters else None
         out = {
             "metric": "voxel-updates/sec per scan (200k pts, 0.1 m res); HBM GB/s vs roofline",
             "value": value, "unit": "voxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,14 +267,27 @@ def main():
             "host": {"prepare_s": t_prepare, "frontend_s": st["t_frontend"], "partition_s": st["t_partition"],
                      "pack_s": st["t_pack"]},
         }
-        if valu is not None:
-            # the kernel is VALU-issue bound, not HBM bound: wave64 VALU instructions retire one per 4 cycles per
-            # SIMD; 256 CUs x 4 SIMDs at 2.4 GHz = 6.144e11 wave-instructions/s (PMC count from profiles/)
-            rate = valu / (k_ms * 1e-3)
-            out["roofline"]["valu_issue"] = {"achieved": rate, "peak": 6.144e11, "unit": "wave-instr/s",
-                                             "frac": rate / 6.144e11, "valu_insts_per_launch": valu}
+        if counters:
+            # Instruction-issue roofline (the kernel is issue bound, not HBM bound).  Peaks are MEASURED on this chip
+            # (profiles/r02/valu_issue.txt, scratch/ubench/valu_issue.hip): a SIMD issues one instruction of any kind per
+            # 2.2 cycles at best, and most VALU instructions of this kernel's mix occupy it for 4.1 cycles.
+            n_valu, n_salu, n_lds = (counters.get(k, 0) for k in ("valu_insts_per_launch", "salu_insts_per_launch", "lds_insts_per_launch"))
+            simds, clk = 1024, 2.4e9
+            rate = (n_valu + n_salu + n_lds) / (k_ms * 1e-3)
+            out["roofline"]["issue"] = {
+                "achieved": rate, "peak": simds * clk / 2.2, "unit": "wave-instr/s (VALU+SALU+LDS)",
+                "frac": rate / (simds * clk / 2.2), "valu_insts_per_launch": n_valu, "salu_insts_per_launch": n_salu,
+                "lds_insts_per_launch": n_lds,
+                "valu_only": {"achieved": n_valu / (k_ms * 1e-3), "peak_fast_class": simds * clk / 2.2,
+                              "peak_4cycle_class": simds * clk / 4.1},
+                "source": counters.get("source")}
+        else:
+            out["roofline"]["traffic_note"] = ("profiles/bgk_traffic.json has no entry stamped with this build's kernel source "
+                                               "hash for this workload: counters omitted (scratch/update_traffic.sh regenerates)")
         if world == 1 and not shard_mode and not args.no_e2e:
-            out["end_to_end"] = end_to_end(la3dm_amd, params, xyz, origin, args, U)
+            out["end_to_end"] = end_to_end(la3dm_amd, params, args)
+        if world == 1 and not args.no_big and args.rays == 200000:
+            out["roofline"]["out_of_cache"] = out_of_cache_leg(la3dm_amd, _lib, torch, dev)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(params, xyz, origin, args, U)
             if args.cpu_omp:
@@ -290,6 +295,30 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_source_hash():
+    """sha256 of the files the BGK kernel is built from: PMC numbers quoted from profiles/ are only valid for this build"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("bgk_kernels.h", "la3dm_hip.hip"):
+        with open(os.path.join(ROOT, "la3dm_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_counters(key):
+    """per-launch PMC counters of the dominant kernel for this workload, from profiles/bgk_traffic.json — refused unless
+    the entry was recorded with the kernel source this build was made from (scratch/update_traffic.sh stamps it)"""
+    tpath = os.path.join(ROOT, "profiles", "bgk_traffic.json")
+    try:
+        with open(tpath) as f:
+            e = json.load(f).get(key)
+    except Exception:
+        return None
+    if not e or e.get("kernel_sha") != kernel_source_hash():
+        return None
+    return e
 
 
 def side_bench(args, torch, la3dm_amd, _lib):
@@ -442,46 +471,109 @@ def l_bench(args, torch, la3dm_amd):
     print(json.dumps(out))
 
 
-def end_to_end(la3dm_amd, params, xyz, origin, args, U):
+SEQ_POSES = [None, (1.5, 0.5, 1.0), (-1.5, 1.0, 1.2), (0.5, -2.0, 0.9), (2.5, 2.0, 1.1)]   # sensor poses of the e2e sequence
+
+
+def e2e_sequence(la3dm_amd, rays):
+    return [la3dm_amd.synthetic_scan(rays, origin=p) for p in SEQ_POSES]
+
+
+def end_to_end(la3dm_amd, params, args):
     """Whole BGKOctoMap::insert_pointcloud calls in device-resident mode (front end, partition, predict + fuse,
-    write-back, prune on the GPU; the cloud is uploaded from host memory inside the timed region)."""
-    m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
-    m.insert_pointcloud(xyz, origin, args.resolution, 0.5, -1.0)  # warm-up: arenas, block creation
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        m.insert_pointcloud(xyz, origin, args.resolution, 0.5, -1.0)
-    dt = (time.perf_counter() - t0) / n
-    st = m.stats()
-    # the same calls with the cloud already resident in HBM (insert_pointcloud_device)
+    write-back, prune on the GPU; the cloud is uploaded from host memory inside the timed region), like for like with
+    the CPU leg (cpu_baseline_omp.sequence): scan 0 goes into a FRESH map (timed on its own: block creation and the first
+    growth of the device arenas are in it), then four more scans of the same room from other sensor poses follow into
+    the same map (distinct scans, no re-insertion)."""
     import torch
-    d_cloud = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).to("cuda:0")
+    scans = e2e_sequence(la3dm_amd, args.rays)
+    la3dm_amd.BGKOctoMap(**params, device=0).insert_pointcloud(*scans[0], args.resolution, 0.5, -1.0)   # library warm-up
     torch.cuda.synchronize()
-    m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, args.resolution, 0.5, -1.0)
+    m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+    times, updates = [], []
+    for xyz, origin in scans:
+        t0 = time.perf_counter()
+        m.insert_pointcloud(xyz, origin, args.resolution, 0.5, -1.0)
+        times.append(time.perf_counter() - t0)
+        updates.append(int(m.stats()["voxel_updates"]))
+    st = m.stats()
+    # the same sequence with the clouds already resident in HBM (insert_pointcloud_device), second fresh map
+    m2 = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(True)
+    d_clouds = [torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda:0") for x, _ in scans]
+    torch.cuda.synchronize()
+    times_dev = []
+    for d, (_, origin) in zip(d_clouds, scans):
+        t0 = time.perf_counter()
+        m2.insert_pointcloud_device(d.data_ptr(), d.shape[0], origin, args.resolution, 0.5, -1.0)
+        times_dev.append(time.perf_counter() - t0)
+    seq, seq_dev = float(np.mean(times[1:])), float(np.mean(times_dev[1:]))
+    return {"what": "BGKOctoMap.insert_pointcloud, device-resident map, host cloud -> updated pool in HBM (PCIe upload of the "
+                    "cloud included): scan 0 into a fresh map, then 4 distinct scans (other sensor poses) into the same map; "
+                    "*_device_cloud: the clouds already in HBM",
+            "first_insert_fresh_map_ms": times[0] * 1e3, "ms_per_insert": seq * 1e3,
+            "voxel_updates_per_s": float(np.mean(updates[1:])) / seq,
+            "first_insert_fresh_map_ms_device_cloud": times_dev[0] * 1e3, "ms_per_insert_device_cloud": seq_dev * 1e3,
+            "voxel_updates_per_s_device_cloud": float(np.mean(updates[1:])) / seq_dev,
+            "ms_each": [t * 1e3 for t in times], "voxel_updates_each": updates, "calls": len(scans),
+            "stages_s_last_call": {"frontend": st["t_frontend"], "partition": st["t_partition"],
+                                   "pack_kernel_commit_prune": st["t_pack"]}}
+
+
+def out_of_cache_leg(la3dm_amd, _lib, torch, dev):
+    """The same kernel on configs[4]'s scan (1M rays, 0.05 m, depth 3) on this one GPU: B_alg ~ 0.58 GB per launch and a
+    working set beyond the 256 MiB Infinity Cache, so achieved GB/s here is a genuine HBM-side figure (at configs[1] the
+    ~45 MB working set stays cache resident across the in-place steps)."""
+    params = dict(la3dm_amd.BGK_YAML, resolution=0.05, block_depth=3)
+    xyz, origin = la3dm_amd.synthetic_scan(1000000)
+    m = la3dm_amd.BGKOctoMap(**params, device=0)
+    assert m.prepare(xyz, origin, 0.05, 0.5, -1.0)
+    st, pk = m.stats(), m.packed()
+    U = int(st["voxel_updates"])
+    b_alg = 16 * int(st["train_reads"]) + 17 * U
+    keep = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+            (pk.train_xyzy, pk.train_off.view(np.int32), pk.nbr, pk.blk_center, pk.leaf_off.view(np.int32),
+             pk.leaf_key.view(np.int32), pk.alpha, pk.beta)]
+    state = torch.zeros(pk.n_leaf, dtype=torch.uint8, device=dev)
+    scan = _lib.BgkScan()
+    (scan.train_xyzy, scan.train_off, scan.nbr, scan.blk_center, scan.leaf_off, scan.leaf_key, scan.alpha,
+     scan.beta) = [t.data_ptr() for t in keep]
+    scan.state = state.data_ptr()
+    scan.n_train_pts, scan.n_train_blk, scan.n_test_blk, scan.n_leaf, scan.flags = pk.n_train_pts, pk.n_train_blk, pk.n_test_blk, pk.n_leaf, 0
+    H = _lib.hip()
+    stream = torch.cuda.current_stream().cuda_stream
+    steps = 10
+    for _ in range(2):
+        assert H.la3dm_bgk_scan_device(m.ctx(), C.byref(scan), stream, None) == 0
+    m.set_option("time_kernel", 1)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n):
-        m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, args.resolution, 0.5, -1.0)
-    dt_dev = (time.perf_counter() - t0) / n
-    return {"what": "BGKOctoMap.insert_pointcloud, device-resident map, host cloud -> updated pool in HBM "
-                    "(same scan re-inserted; PCIe upload of the cloud included); *_device_cloud: the cloud already in HBM",
-            "ms_per_insert": dt * 1e3, "voxel_updates_per_s": int(st["voxel_updates"]) / dt,
-            "ms_per_insert_device_cloud": dt_dev * 1e3, "voxel_updates_per_s_device_cloud": int(st["voxel_updates"]) / dt_dev,
-            "voxel_updates_per_scan": int(st["voxel_updates"]), "calls": n,
-            "stages_s": {"frontend": st["t_frontend"], "partition": st["t_partition"],
-                         "pack_kernel_commit_prune": st["t_pack"]}}
+    for _ in range(steps):
+        assert H.la3dm_bgk_scan_device(m.ctx(), C.byref(scan), stream, None) == 0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kt = np.zeros(steps + 8, np.float32)
+    nk = C.c_uint32()
+    H.la3dm_kernel_times(m.ctx(), kt.ctypes.data, kt.size, C.byref(nk))
+    m.set_option("time_kernel", 0)
+    k_ms = float(kt[:nk.value].mean())
+    ach = b_alg / (k_ms * 1e-3) / 1e9
+    return {"workload": "BGKOctoMap synthetic 1000000-ray scan, 0.05 m, block_depth 3 (configs[4] on one GPU)",
+            "voxel_updates_per_scan": U, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": k_ms, "ms_per_step": dt * 1e3,
+            "voxel_updates_per_s": U / dt, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "pair_evals_per_s": int(st["pair_evals"]) / (k_ms * 1e-3), "steps": steps}
 
 
 def cpu_baseline(params, xyz, origin, args, U, omp=False):
     """The CPU oracle (strict-fp32 restatement of the reference's insert_pointcloud) on the same
     scan, on this box's host cores.  Bounded: for the default 200k-ray scan one full
-    insert_pointcloud takes ~10-20 s on one core; larger workloads are subsampled by rays."""
+    insert_pointcloud takes ~10-20 s on one core; larger workloads are subsampled by rays.
+    The all-core leg also runs end_to_end's five-scan sequence into one fresh map (`sequence`)."""
     from oracle import oracle as O
     rays = xyz.shape[0]
     sample = xyz
-    desc = f"full {rays}-ray scan, 1 insert_pointcloud"
+    desc = f"full {rays}-ray scan, 1 insert_pointcloud into a fresh map"
     if rays > 250000 and not omp:
         sample = xyz[:: int(np.ceil(rays / 250000))]
-        desc = f"every {int(np.ceil(rays / 250000))}th ray of the scan ({sample.shape[0]} rays), 1 insert_pointcloud"
+        desc = f"every {int(np.ceil(rays / 250000))}th ray of the scan ({sample.shape[0]} rays), 1 insert_pointcloud into a fresh map"
     # single core: one insert (~6 s at the default workload); all cores: one warm-up + the median of five fresh maps
     runs = []
     for rep in range(6 if omp else 1):
@@ -500,11 +592,22 @@ def cpu_baseline(params, xyz, origin, args, U, omp=False):
             cpu = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         pass
-    return {"value": s["voxel_updates"] / s["t_predict"], "unit": "voxel-updates/s", "cores": cores, "kind": "port",
-            "sample": desc + "; value = leaves of test blocks / predict+fuse stage time",
-            "stage_s": {"frontend": s["t_frontend"], "partition": s["t_partition"], "predict_fuse": s["t_predict"],
-                        "prune": s["t_prune"], "insert_pointcloud": t},
-            "voxel_updates": s["voxel_updates"], "host_cpus": os.cpu_count(), "host_cpu_model": cpu}
+    out = {"value": s["voxel_updates"] / s["t_predict"], "unit": "voxel-updates/s", "cores": cores, "kind": "port",
+           "sample": desc + "; value = leaves of test blocks / predict+fuse stage time",
+           "stage_s": {"frontend": s["t_frontend"], "partition": s["t_partition"], "predict_fuse": s["t_predict"],
+                       "prune": s["t_prune"], "insert_pointcloud": t},
+           "voxel_updates": s["voxel_updates"], "host_cpus": os.cpu_count(), "host_cpu_model": cpu}
+    if omp and rays <= 250000 and not args.no_e2e:
+        import la3dm_amd
+        o = O.OracleMap(**params, omp=True)
+        ts = []
+        for sx, so in e2e_sequence(la3dm_amd, rays):
+            t0 = time.perf_counter()
+            o.insert_pointcloud(sx, so, args.resolution, 0.5, -1.0)
+            ts.append(time.perf_counter() - t0)
+        out["sequence"] = {"what": "end_to_end's five-scan sequence into one fresh oracle map, same host cores",
+                           "first_insert_fresh_map_s": ts[0], "s_per_insert": float(np.mean(ts[1:])), "s_each": ts}
+    return out
 
 
 if __name__ == "__main__":

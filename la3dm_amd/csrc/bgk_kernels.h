@@ -308,6 +308,12 @@ struct __attribute__((aligned(16))) WaveLds5 {
 //   d2 = dx*dx + (dy*dy + dz*dz) in the reference's association (bgkinference.h:88-93); hit <=> d2 < T;
 //   hit lanes write {d2, candidate index} to ring[tail + rank] (rank = mbcnt of the hit mask), the others to their
 //   scratch slot; the lane's hit bit is shifted into its history word (h = 2 h + hit: v_addc with the mask as carry).
+#ifndef LA3DM_ASM_B
+#define LA3DM_ASM_B 1
+#endif
+#ifndef LA3DM_ASM_D
+#define LA3DM_ASM_D 1
+#endif
 #define LA3DM_B_HEAD(A, X, Y)                               \
     "v_sub_f32 " A ", " X ", %[xs]\n"                       \
     "v_sub_f32 %[tb], " Y ", %[ys]\n"
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
                 float4 t[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
+#if LA3DM_ASM_B
                 // software-pipelined by hand: the first two instructions of the next candidate sit between a v_cmp and the
                 // first reader of its mask (the gfx940 two-wait-state rule); the last candidate pays an s_nop
                 float a0, a1, tb2, tc, tr;
@@ -503,7 +510,22 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
                                [y0] "v"(t[0].y), [z0] "v"(t[0].z), [x1] "v"(t[1].x), [y1] "v"(t[1].y), [z1] "v"(t[1].z),
                                [x2] "v"(t[2].x), [y2] "v"(t[2].y), [z2] "v"(t[2].z), [x3] "v"(t[3].x), [y3] "v"(t[3].y),
                                [z3] "v"(t[3].z)
-                             : "vcc", "memory");
+                             : "vcc", "scc", "memory");  // s_bcnt1 / s_lshl3_add write SCC
+#else
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
+                    const float d2 = dx * dx + (dy * dy + dz * dz);
+                    const bool hit = d2 < hit_t;
+                    const unsigned long long m = __ballot(hit);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    const uint32_t slot = hit ? ((tailb - ring_base) >> 3) + rank : (uint32_t)(kRing5 + lane);
+                    L.ring[slot] = make_uint2(__float_as_uint(d2), idx);
+                    tailb += 8u * (uint32_t)__popcll(m);
+                    idx += 1;
+                    hw = (hw << 1) | (hit ? 1u : 0u);
+                }
+#endif
             };
             const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRing5 - 4 * kWave);
             for (; g < ngroup && tailb <= tail_cap && g - g0 < 8u; ++g) b_trip(hA);
@@ -538,16 +560,39 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
                 starts >>= 4;
                 {
                     // gather (assembly): the four entries land in fixed register pairs, all four reads are back at the end
+#if LA3DM_ASM_D
                     register float e0k asm("v56"), e0y asm("v57"), e1k asm("v58"), e1y asm("v59"), e2k asm("v60"), e2y asm("v61"),
                         e3k asm("v62"), e3y asm("v63");
                     float tr;
                     uint32_t st;
+#else
+                    float e0k, e0y, e1k, e1y, e2k, e2y, e3k, e3y;
+#endif
+#if LA3DM_ASM_D
                     asm volatile(LA3DM_D_CAND("v[56:57]") LA3DM_D_CAND("v[58:59]") LA3DM_D_CAND("v[60:61]") LA3DM_D_CAND("v[62:63]")
                                  "s_waitcnt lgkmcnt(0)\n"
-                                 : [h] "+v"(hc), [roff] "+s"(roffb), [tr] "=&v"(tr), [st] "=&s"(st), "=v"(e0k), "=v"(e0y), "=v"(e1k),
-                                   "=v"(e1y), "=v"(e2k), "=v"(e2y), "=v"(e3k), "=v"(e3y)
+                                 : [h] "+v"(hc), [roff] "+s"(roffb), [tr] "=&v"(tr), [st] "=&s"(st), "=&v"(e0k), "=&v"(e0y), "=&v"(e1k),
+                                   "=&v"(e1y), "=&v"(e2k), "=&v"(e2y), "=&v"(e3k), "=&v"(e3y)  // early clobber: written before zad / h are dead
                                  : [zad] "v"(zero_addr)
-                                 : "vcc", "memory");
+                                 : "vcc", "scc", "memory");  // s_bcnt1 / s_lshl3_add write SCC
+#else
+                    {
+                        uint32_t roff = (roffb - ring_base) >> 3;
+                        float *ek[4] = {&e0k, &e1k, &e2k, &e3k}, *ey[4] = {&e0y, &e1y, &e2y, &e3y};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool mine = (hc & 0x80000000u) != 0u;
+                            hc <<= 1;
+                            const unsigned long long m = __ballot(mine);
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            const uint2 e = L.ring[mine ? roff + rank : (uint32_t)(kRing5 + kWave)];
+                            *ek[u] = __uint_as_float(e.x);
+                            *ey[u] = __uint_as_float(e.y);
+                            roff += (uint32_t)__popcll(m);
+                        }
+                        roffb = ring_base + 8u * roff;
+                    }
+#endif
                     // ordered sums; Occupancy::update where a neighbour starts (uniform).  Adding the zero entry's +0.0
                     // leaves a non-negative-zero accumulator unchanged.
                     if (sb & 1u) flush_nb();
@@ -594,12 +639,16 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
     }
 
     if (active) {
+        // the store addresses are formed here, from the leaf index, rather than carried through the kernel from the
+        // alpha / beta loads (two 64-bit pointers: the four VGPRs that would otherwise spill at 8 waves per SIMD)
+        uint32_t lw = li;
+        asm volatile("" : "+v"(lw));
         if (updated) {
-            a.alpha[li] = A;
-            a.beta[li] = B;
-            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+            a.alpha[lw] = A;
+            a.beta[lw] = B;
+            a.state[lw] = (uint8_t)(classify(A, B, a) | 0x80u);
         } else {
-            a.state[li] = 0;
+            a.state[lw] = 0;
         }
     }
 }

@@ -3,9 +3,11 @@ n rays on a Fibonacci sphere from (0,0,1), nearest hit + N(0, 0.01 m) range nois
 import numpy as np
 
 
-def synthetic_scan(n_rays, seed=1234, noise=0.01):
-    """-> (xyz float32 [n,3], origin float32 [3])"""
+def synthetic_scan(n_rays, seed=1234, noise=0.01, origin=None):
+    """-> (xyz float32 [n,3], origin float32 [3]).  `origin` moves the sensor inside the same room (the spheres only
+    depend on `seed` and keep clear of the default pose (0, 0, 1)); the default call is the BASELINE.md §4 scan."""
     rng = np.random.default_rng(seed)
+    sensor = np.array([0.0, 0.0, 1.0]) if origin is None else np.asarray(origin, np.float64)
     origin = np.array([0.0, 0.0, 1.0])
     centres, radii = [], []
     while len(centres) < 24:
@@ -17,6 +19,9 @@ def synthetic_scan(n_rays, seed=1234, noise=0.01):
         radii.append(r)
     centres = np.asarray(centres)
     radii = np.asarray(radii)
+    origin = sensor
+    if (np.linalg.norm(centres - origin, axis=1) < radii + 0.05).any():
+        raise ValueError("synthetic_scan: the sensor pose lies inside a sphere of the scene")
     i = np.arange(n_rays, dtype=np.float64) + 0.5
     z = 1.0 - 2.0 * i / n_rays
     phi = np.pi * (1.0 + 5.0 ** 0.5) * i
