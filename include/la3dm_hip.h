@@ -268,6 +268,18 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
  * {x, y, z, label} (host pointer) take the place of the front end's output; every leaf of every test block is updated
  * for every neighbour model (LA3DM_SCAN_UPDATE_UNGATED), then the test blocks are pruned. */
 int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats);
+/* Block-sharded insert across the GPUs of a node (BASELINE.json configs[4]; the loop that is sharded is the test-block
+ * loop of src/bgkoctomap/bgkoctomap.cpp:293-336).  Every rank holds a full replica of the map and is handed the SAME
+ * cloud; front end and partition run redundantly (cheaper than a broadcast), the test-block list is cut into `world`
+ * contiguous ranges of equal weight in candidate order, rank r predicts + fuses range r only, then ONE all-gather of the
+ * leaf payload (alpha | beta | state, 9 B per leaf, padded to the largest range) reassembles the updated leaves on
+ * every rank, and commit + prune run everywhere: after the call all replicas are identical to a single-GPU map, bit for
+ * bit.  The library has no communication dependency: `fn` is called once per pass with the DEVICE pointer of the payload
+ * ([world][bytes_per_rank]; slice `rank` is filled and the stream has been synchronised) and must return 0 after the
+ * all-gather has completed (ncclAllGather / torch.distributed.all_gather_into_tensor on it, then a stream sync).
+ * world = 1 switches sharding off.  Variants 0 (BGK) and 1 (GP). */
+typedef int (*la3dm_allgather_fn)(void *user, void *payload, uint64_t bytes_per_rank, uint32_t world);
+int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user);
 int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nodes_per_block);
 /* keys[n_blocks]; A, B, S [n_blocks * nodes_per_block], node order = depth-major (8^d - 1)/7 + index;
  * S: bits 0-2 State (FREE 0, OCCUPIED 1, UNKNOWN 2, PRUNED 3), bit 7 = classified */

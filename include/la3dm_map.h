@@ -82,6 +82,9 @@ la3dm_ctx *la3dm_map_ctx(la3dm_map *m);
  * start to finish on the GPU, the host blocks are a lazily refreshed mirror.  Switch while the map is empty.
  * insert_training_data and prepare/commit are refused in this mode. */
 int la3dm_map_set_device_resident(la3dm_map *m, int on);
+/* block-sharded insert_pointcloud over `world` replicas of the map, one per GPU (la3dm_devmap_set_shard, la3dm_hip.h);
+ * the map must be device resident; world = 1 switches it off */
+int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user);
 int la3dm_map_is_device_resident(const la3dm_map *m);
 
 int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out);

@@ -15,6 +15,9 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 HIP_SO = os.path.join(_CSRC, "libla3dm_hip.so")
 MAP_SO = os.path.join(_CSRC, "libla3dm_map.so")
 
+# la3dm_allgather_fn (include/la3dm_hip.h): int fn(void *user, void *payload, uint64_t bytes_per_rank, uint32_t world)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32)
+
 LEAF_UPDATED = 0x80
 SCAN_UPDATE_UNGATED = 0x1
 
@@ -72,7 +75,7 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_devmap_training_data", "la3dm_devmap_diag_add_repeat", "la3dm_bgkl_scan_host",
                "la3dm_bgkl_scan_device", "la3dm_diag_mfma_chain", "la3dm_devmap_search_host",
                "la3dm_devmap_export_cells", "la3dm_devmap_key_bounds",
-               "la3dm_devmap_insert_training_data_host"]
+               "la3dm_devmap_insert_training_data_host", "la3dm_devmap_set_shard"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud", "la3dm_map_insert_pointcloud_device",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
@@ -82,7 +85,7 @@ MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv",
                "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut",
                "la3dm_map_set_device_resident", "la3dm_map_is_device_resident", "la3dm_map_raycast",
                "la3dm_map_block_grid", "la3dm_map_create_l", "la3dm_map_l_training",
-               "la3dm_map_search_many", "la3dm_map_export_cells"]
+               "la3dm_map_search_many", "la3dm_map_export_cells", "la3dm_map_set_shard"]
 
 _hip = None
 _map = None
@@ -188,6 +191,8 @@ def maplib():
                                              C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         M.la3dm_map_raycast.restype = C.c_uint64
         M.la3dm_map_raycast.argtypes = [C.c_void_p, f32p, f32p] + [C.c_void_p] * 7 + [C.c_uint64]
+        M.la3dm_map_set_shard.restype = C.c_int
+        M.la3dm_map_set_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, ALLGATHER_FN, C.c_void_p]
         M.la3dm_map_set_device_resident.restype = C.c_int
         M.la3dm_map_set_device_resident.argtypes = [C.c_void_p, C.c_int]
         M.la3dm_map_is_device_resident.restype = C.c_int

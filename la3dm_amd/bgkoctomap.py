@@ -64,6 +64,23 @@ class BGKOctoMap:
     def is_device_resident(self):
         return bool(self._M.la3dm_map_is_device_resident(self._h))
 
+    def set_shard(self, rank, world, allgather):
+        """Block-sharded insert_pointcloud over `world` replicas of this map, one process per GPU (every process
+        inserts the same clouds): rank r predicts + fuses its contiguous range of the test blocks and
+        `allgather(payload_ptr, bytes_per_rank, world)` — called once per pass with the device pointer of the
+        [world][bytes_per_rank] leaf payload, slice `rank` filled — must complete an in-place all-gather before it
+        returns (la3dm_amd.sharding.torch_allgather builds one on torch.distributed).  world = 1 switches it off."""
+        def _cb(user, payload, bytes_per_rank, nranks):
+            try:
+                allgather(int(payload), int(bytes_per_rank), int(nranks))
+                return 0
+            except Exception as e:           # never let an exception cross the C boundary
+                self._shard_error = e
+                return 1
+        self._shard_cb = _lib.ALLGATHER_FN(_cb) if world > 1 else _lib.ALLGATHER_FN(0)
+        self._chk(self._M.la3dm_map_set_shard(self._h, rank, world, self._shard_cb, None))
+        return self
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._M.la3dm_map_destroy(self._h)

@@ -54,6 +54,12 @@ struct la3dm_devmap {
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
     Arena l_ray_idx, l_rays, l_rows, l_rows_off, l_rflag, l_rscan;  // BGKLOctoMap: beam of every sample, beam segments, training rows
+    // block-sharded insert (la3dm_devmap_set_shard)
+    uint32_t shard_rank = 0, shard_world = 1;
+    la3dm_allgather_fn shard_fn = nullptr;
+    void *shard_user = nullptr;
+    Arena shard_w, shard_cumw, shard_bounds, shard_payload;
+    uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
     uint32_t n_xy = 0;
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
     la3dm_devmap_stats stats;
@@ -295,9 +301,11 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->q_out, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node,
-                    &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan};
+                    &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan,
+                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds, &dm->shard_payload};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
+    if (dm->h_shard) (void)hipHostFree(dm->h_shard);
     void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -605,10 +613,27 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     S.n_passes = pass + 1;
     DM_RESERVE(dm->t_key1, 4ull * n_test);
     DM_RESERVE(dm->t_ent1, 4ull * n_test);
-    // heaviest test blocks first (the blocks are independent: order only balances the launch)
-    if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
-                         (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
-        return rc;
+    const bool sharded = dm->shard_world > 1;
+    const uint32_t world = dm->shard_world;
+    if (!sharded) {
+        // heaviest test blocks first (the blocks are independent: order only balances the launch)
+        if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
+                             (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
+            return rc;
+    } else {
+        // block-sharded: the list stays in candidate order (block indices x-major: neighbouring test blocks, which share
+        // training blocks, stay on one GPU's L2) and is cut into `world` contiguous ranges of equal weight
+        DM_TRY(hipMemcpyAsync(dm->t_key1.ptr, dm->t_key0.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
+        DM_TRY(hipMemcpyAsync(dm->t_ent1.ptr, dm->t_ent0.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
+        DM_RESERVE(dm->shard_w, 4ull * n_test);
+        DM_RESERVE(dm->shard_cumw, 4ull * n_test);
+        DM_RESERVE(dm->shard_bounds, 8ull * (world + 1));
+        hipLaunchKernelGGL(dm_shard_weight, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr, n_test,
+                           (uint32_t *)dm->shard_w.ptr);
+        if ((rc = exclusive_scan(dm, (const uint32_t *)dm->shard_w.ptr, (uint32_t *)dm->shard_cumw.ptr, n_test)) != LA3DM_OK) return rc;
+        hipLaunchKernelGGL(dm_shard_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_cumw.ptr,
+                           (const uint32_t *)dm->shard_w.ptr, n_test, world, (uint32_t *)dm->shard_bounds.ptr);
+    }
     DM_RESERVE(dm->t_blockkey, 8ull * n_test);
     DM_RESERVE(dm->t_center, 12ull * n_test);
     DM_RESERVE(dm->t_nbr, 28ull * n_test);
@@ -680,10 +705,48 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.beta = (float *)dm->leaf_beta.ptr;
     s.state = (uint8_t *)dm->leaf_state.ptr;
     s.flags = P.flags;
-    rc = ctx->p.variant == 1   ? la3dm_gp_scan_device(ctx, &s, st, nullptr)
-         : ctx->p.variant == 3 ? la3dm_bgkl_scan_device(ctx, &s, st, nullptr)
-                               : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
+    uint32_t chunk = 0;
+    if (sharded) {
+        // this rank's contiguous range of test blocks; leaf_off holds absolute leaf indices, so offsetting the per-block
+        // arrays is all the kernel needs
+        uint32_t *lb = (uint32_t *)dm->shard_bounds.ptr + (world + 1);
+        hipLaunchKernelGGL(dm_shard_leaf_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_bounds.ptr,
+                           (const uint32_t *)leaf_off, world, lb);
+        DM_TRY(hipMemcpyAsync(dm->h_shard, dm->shard_bounds.ptr, 8ull * (world + 1), hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));
+        const uint32_t *hb = dm->h_shard, *hl = dm->h_shard + (world + 1);
+        for (uint32_t q = 0; q < world; ++q) chunk = std::max(chunk, hl[q + 1] - hl[q]);
+        chunk = (chunk + 63u) & ~63u;
+        const uint32_t t0s = hb[dm->shard_rank], t1s = hb[dm->shard_rank + 1];
+        s.nbr += 7ull * t0s;
+        s.blk_center += 3ull * t0s;
+        s.leaf_off += t0s;
+        s.n_test_blk = t1s - t0s;
+    }
+    rc = LA3DM_OK;
+    if (s.n_test_blk)
+        rc = ctx->p.variant == 1   ? la3dm_gp_scan_device(ctx, &s, st, nullptr)
+             : ctx->p.variant == 3 ? la3dm_bgkl_scan_device(ctx, &s, st, nullptr)
+                                   : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
     if (rc != LA3DM_OK) return rc;
+    if (sharded && chunk) {
+        // one all-gather of the leaf payload (alpha, beta, state: 9 B per leaf) reassembles the updated leaves on every
+        // rank; commit and prune then run everywhere on identical data
+        const uint32_t *hl = dm->h_shard + (world + 1);
+        const uint32_t first = hl[dm->shard_rank], n_own = hl[dm->shard_rank + 1] - first;
+        DM_RESERVE(dm->shard_payload, 9ull * chunk * world);
+        uint8_t *payload = (uint8_t *)dm->shard_payload.ptr;
+        if (n_own)
+            hipLaunchKernelGGL(dm_shard_pack, dim3(cdiv(n_own, 256)), dim3(256), 0, st, (const float *)dm->leaf_alpha.ptr,
+                               (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr, first, n_own, chunk,
+                               payload + 9ull * chunk * dm->shard_rank);
+        DM_TRY(hipStreamSynchronize(st));  // the callback runs on the caller's streams: hand over a finished slice
+        const int xrc = dm->shard_fn(dm->shard_user, payload, 9ull * chunk, world);
+        if (xrc != 0) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed");
+        hipLaunchKernelGGL(dm_shard_unpack, dim3(std::min(cdiv(chunk, 256), 512u), world), dim3(256), 0, st, (const uint8_t *)payload,
+                           (const uint32_t *)dm->shard_bounds.ptr + (world + 1), world, dm->shard_rank, chunk,
+                           (float *)dm->leaf_alpha.ptr, (float *)dm->leaf_beta.ptr, (uint8_t *)dm->leaf_state.ptr);
+    }
     double tp2 = tp1;
     if (dm->stage_timing) {
         DM_TRY(hipStreamSynchronize(st));
@@ -774,6 +837,25 @@ int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, 
     int rc = training_bbox(dm);
     if (rc != LA3DM_OK) return rc;
     return scan_training_set(dm, LA3DM_SCAN_UPDATE_UNGATED, t0, stats_out);
+}
+
+int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
+    if (!dm) return LA3DM_ERR_ARG;
+    if (world == 0 || world > 1023 || rank >= world || (world > 1 && !fn))
+        return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_set_shard: need rank < world <= 1023 and a callback when world > 1");
+    if (world > 1 && dm->ctx->p.variant != 0 && dm->ctx->p.variant != 1)
+        return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_set_shard: block sharding is built for BGKOctoMap and GPOctoMap contexts");
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    if (dm->h_shard) {
+        (void)hipHostFree(dm->h_shard);
+        dm->h_shard = nullptr;
+    }
+    if (world > 1) DM_TRY(hipHostMalloc((void **)&dm->h_shard, 8ull * (world + 1)));
+    dm->shard_rank = rank;
+    dm->shard_world = world;
+    dm->shard_fn = world > 1 ? fn : nullptr;
+    dm->shard_user = user;
+    return LA3DM_OK;
 }
 
 int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],

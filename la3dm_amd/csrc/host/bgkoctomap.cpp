@@ -1440,6 +1440,11 @@ void BGKOctoMap::commit() {
     stats.t_prune = wall() - t1;
 }
 
+void BGKOctoMap::set_shard(uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
+    if (dmap == nullptr) throw std::runtime_error("set_shard: the map is not in device-resident mode");
+    if (la3dm_devmap_set_shard(dmap, rank, world, fn, user) != LA3DM_OK) throw std::runtime_error(la3dm_last_error(ctx));
+}
+
 bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                          float free_res, float max_range) {
     ensure_host_mode();

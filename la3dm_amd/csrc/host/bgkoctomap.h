@@ -330,6 +330,9 @@ public:
     void set_device_resident(bool on);
     void ensure_host_mode();
     bool is_device_resident() const { return dmap != nullptr; }
+    /// Block-sharded insert_pointcloud across `world` GPUs (one process per GPU, every process holds a replica of the map
+    /// and inserts the same clouds): see la3dm_devmap_set_shard in include/la3dm_hip.h.  Needs the device-resident mode.
+    void set_shard(uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user);
     void sync_mirror() const;
     void take_device_stats(const la3dm_devmap_stats &ds);
     /// training set (x, y, z, label) the device front end produced for the last scan

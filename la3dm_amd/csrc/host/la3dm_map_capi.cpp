@@ -206,6 +206,9 @@ int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap) {
 
 int la3dm_map_set_device_resident(la3dm_map *m, int on) { GUARD(m->map->set_device_resident(on != 0); return 0;) }
 int la3dm_map_is_device_resident(const la3dm_map *m) { return m->map->is_device_resident() ? 1 : 0; }
+int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
+    GUARD(m->map->set_shard(rank, world, fn, user); return 0;)
+}
 
 float la3dm_map_block_size(const la3dm_map *m) { return m->map->get_block_size(); }
 uint64_t la3dm_map_block_count(const la3dm_map *m) { return m->map->block_count(); }

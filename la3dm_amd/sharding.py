@@ -71,3 +71,42 @@ def reassemble(pk, gathered, world):
         pk.alpha[idx] = row[0:4 * n].view(np.float32)
         pk.beta[idx] = row[4 * cap:4 * cap + 4 * n].view(np.float32)
         pk.state[idx] = row[8 * cap:8 * cap + n]
+
+
+# ---- device-resident sharded insert (la3dm_devmap_set_shard): the all-gather callback on torch.distributed ----
+class _DeviceBytes:
+    """a raw device pointer as a __cuda_array_interface__ object, so torch can view it without a copy"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+def torch_allgather(dist, rank, device, stage_through_host=False):
+    """-> allgather(payload_ptr, bytes_per_rank, world) for BGKOctoMap.set_shard: ONE in-place all-gather of the leaf
+    payload (RCCL over xGMI when the process group's backend is "nccl").  stage_through_host: the gloo self-test on a
+    single GPU (all ranks on cuda:0) — the payload goes through host memory; never a measurement."""
+    import torch
+
+    def allgather(ptr, bytes_per_rank, world):
+        buf = torch.as_tensor(_DeviceBytes(ptr, bytes_per_rank * world), device=device)
+        mine = buf[rank * bytes_per_rank:(rank + 1) * bytes_per_rank]
+        if stage_through_host:
+            out = torch.empty(bytes_per_rank * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, mine.cpu())
+            buf.copy_(out)
+        else:
+            dist.all_gather_into_tensor(buf, mine)   # in place: the input is slice `rank` of the output
+        torch.cuda.synchronize(device)
+
+    return allgather
+
+
+def balanced_ranges(weights, world):
+    """host mirror of dm_shard_weight / dm_shard_bounds (devmap_kernels.h): cut the test-block list (candidate order)
+    into `world` contiguous ranges where the running weight (neighbourhood size + 16 per block) crosses q / world of the
+    total.  -> bounds [world + 1]"""
+    w = np.asarray(weights, np.uint64) + 16
+    cum = np.concatenate([[0], np.cumsum(w)[:-1]]).astype(np.uint64)          # exclusive
+    total = int(cum[-1] + w[-1]) if len(w) else 0
+    b = [int(np.searchsorted(cum, np.uint64(total * q // world), side="left")) for q in range(world)]
+    return np.array(b + [len(w)], np.int64)
