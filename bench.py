@@ -52,9 +52,11 @@ def main():
     ap.add_argument("--workload", choices=["bgk", "gp", "lv", "l"], default="bgk",
                     help="bgk = BASELINE configs[1] (default, the contract line); gp = configs[2] (GPOctoMap, 50k rays); "
                          "lv = configs[3] (BGKLV, sim_unstructured scan, 0.05 m), l = BGKLOctoMap insert (row f4) — single-GPU side benches")
-    ap.add_argument("--mode", choices=["scans", "shard"], default="scans",
-                    help="N>1 only. scans (default, weak scaling): one scan per GPU; shard (strong scaling, config-5 "
-                         "style): ONE scan, its test blocks dealt round-robin to the ranks (la3dm_amd/sharding.py)")
+    ap.add_argument("--mode", choices=["shard", "scans"], default="shard",
+                    help="N>1 only. shard (default, strong scaling, BASELINE configs[4]): ONE 1M-ray scan at 0.05 m, every rank "
+                         "holds a replica of the device-resident map, predicts + fuses its contiguous range of the test blocks, "
+                         "one RCCL all-gather of the leaf payload (la3dm_devmap_set_shard); scans (weak scaling): one 200k-ray "
+                         "scan per GPU through the hot-path kernel + an all-gather of its leaves (replicas)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): 1 skip k(r) evaluation, 2 skip tests")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one leaf buffer, every all-gather finishes before the next kernel starts")
@@ -97,10 +99,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.mode == "shard":
+            return sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest)
 
     # ---- build the workload (host side, untimed) -------------------------------------
     params = dict(la3dm_amd.BGK_YAML, resolution=args.resolution, block_depth=args.depth)
-    shard_mode = world > 1 and args.mode == "shard"
+    shard_mode = False     # (N > 1 default mode returns above; what follows is N = 1 and --mode scans)
     xyz, origin = la3dm_amd.synthetic_scan(args.rays, seed=1234 + (0 if shard_mode else rank))
     m = la3dm_amd.BGKOctoMap(**params, device=local_rank)
     t0 = time.perf_counter()
@@ -111,14 +115,6 @@ def main():
     pk = m.packed()
     U = int(st["voxel_updates"])
     b_alg = 16 * int(st["train_reads"]) + 17 * U
-    if shard_mode:
-        from la3dm_amd import sharding
-        full = pk
-        pk = sharding.Shard(full, rank, world)     # this rank's test blocks; training CSR replicated
-        U = pk.n_leaf
-        reads = sum(int(full.train_off[n + 1] - full.train_off[n]) for n in pk.nbr.ravel() if n >= 0)
-        b_alg = 16 * reads + 17 * U
-
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
@@ -254,8 +250,6 @@ def main():
                        "test_blocks": int(st["n_test_blocks"]), "train_blocks": int(st["n_train_blocks"]),
                        "voxel_updates_per_scan": U, "pair_evals_per_scan": int(st["pair_evals"]),
                        "parallelism": ("single GPU" if world == 1 else
-                                       "one scan, test blocks dealt round-robin to the ranks + RCCL all-gather of leaf "
-                                       "(alpha,beta,state)" if shard_mode else
                                        "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)") +
                                       (", gather of scan k under the kernel of scan k+1 (two leaf buffers)" if n_buf > 1 else ""),
                        "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
@@ -295,6 +289,79 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest):
+    """N > 1 default: BASELINE configs[4] — ONE synthetic 1M-ray scan at 0.05 m, block-sharded.  Every rank holds a
+    replica of the device-resident map and is handed the same cloud (resident in its HBM); a step is one whole
+    BGKOctoMap::insert_pointcloud: front end + partition redundantly on every GPU, predict + fuse of the rank's contiguous
+    range of test blocks, ONE all-gather of the leaf payload over RCCL, commit + prune everywhere.  Strong scaling: the
+    work per step is fixed, value = voxel updates of the timed steps / max-over-ranks time.  Rank 0 also times the same
+    steps unsharded on its own GPU beforehand so the line carries its own single-GPU reference."""
+    from la3dm_amd import sharding
+    rays, res = (1000000, 0.05) if args.rays == 200000 else (args.rays, args.resolution)
+    params = dict(la3dm_amd.BGK_YAML, resolution=res, block_depth=args.depth)
+    xyz, origin = la3dm_amd.synthetic_scan(rays)
+    d_cloud = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).to(dev)
+    cdev = torch.device("cpu") if selftest else dev
+
+    def run(m, steps, warm):
+        ups = 0
+        for _ in range(warm):
+            m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
+            ups += int(m.stats()["voxel_updates"])
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ups
+
+    # single-GPU reference: the same W + K inserts on an unsharded replica (all ranks do it, so every GPU is equally warm)
+    ref = la3dm_amd.BGKOctoMap(**params, device=local_rank)
+    dt1, ups1 = run(ref, args.steps, args.warmup)
+    del ref
+    m = la3dm_amd.BGKOctoMap(**params, device=local_rank)
+    m.set_shard(rank, world, sharding.torch_allgather(dist, rank, dev, stage_through_host=selftest))
+    m.set_option("time_kernel", 1)       # HIP events around the predict + fuse kernel of every insert (this rank's range)
+    dt, ups = run(m, args.steps, args.warmup)
+    from la3dm_amd import _lib
+    kt = np.zeros(args.steps + args.warmup + 8, np.float32)
+    nk = C.c_uint32()
+    _lib.hip().la3dm_kernel_times(m.ctx(), kt.ctypes.data, kt.size, C.byref(nk))
+    k_ms = float(kt[max(0, nk.value - args.steps):nk.value].mean()) if nk.value else float("nan")
+    tt = torch.tensor([dt, dt1], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, dt1 = float(tt[0].item()), float(tt[1].item())
+    st = m.stats()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "voxel-updates/sec per scan (200k pts, 0.1 m res); HBM GB/s vs roofline",
+            "value": ups / dt, "unit": "voxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BGKOctoMap synthetic {rays}-ray scan, {res} m res, block_depth {args.depth}, bgkoctomap.yaml "
+                                   "kernel params (configs[4]); a step = one device-resident insert_pointcloud of the scan "
+                                   "(re-inserted every step), cloud resident in HBM",
+                       "rays": rays, "resolution": res, "block_depth": args.depth,
+                       "parallelism": f"block-sharded over {world} GPUs: replicated map, contiguous equal-weight ranges of the "
+                                      "test blocks per rank, one RCCL all-gather of leaf (alpha,beta,state) per insert, "
+                                      "front end + partition + commit + prune redundant on every rank",
+                       "voxel_updates_last_step": int(st["voxel_updates"]), "test_blocks": int(st["n_test_blocks"]),
+                       "allgather_payload_bytes_per_rank_approx": 9 * int(st["voxel_updates"]) // world},
+            "roofline": {"bound": "hbm", "achieved": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9,
+                         "peak": 8000.0, "unit": "GB/s",
+                         "frac": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9 / 8000.0,
+                         "traffic": None, "kernel": "bgk_predict_fuse (rank 0's range of the last steps; algorithmic bytes of the "
+                                                    "scan / world: the ranges are cut to equal weight)", "kernel_ms": k_ms},
+            "single_gpu": {"what": "the same steps on one unsharded replica, measured in this run on every rank's own GPU (max)",
+                           "value": ups1 / dt1, "ms_per_step": dt1 / args.steps * 1e3},
+            "speedup_vs_single_gpu": (ups / dt) / (ups1 / dt1)}))
+    dist.destroy_process_group()
 
 
 def kernel_source_hash():
