@@ -253,14 +253,19 @@ typedef struct la3dm_devmap_stats {
     double t_frontend, t_partition, t_pack, t_kernel, t_commit, t_total; /* seconds, host clock at sync points */
 } la3dm_devmap_stats;
 
+/* The devmap keeps a pointer to `ctx`: destroy the devmap BEFORE the context (la3dm_destroy refuses — keeps the context
+ * alive and reports on stderr — while a devmap still points at it). */
 int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out);
 void la3dm_devmap_destroy(la3dm_devmap *dm);
 /* cloud: n points, `stride` floats apart (>= 3), host memory */
 int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride,
                                         const float origin[3], float ds_resolution, float free_resolution,
                                         float max_range, la3dm_devmap_stats *stats);
-/* cloud: n packed xyz triples in device memory; runs on the context's stream and returns after the last
- * kernel has been enqueued and the few scalar read-backs the launch sizes depend on */
+/* cloud: n packed xyz triples in device memory; runs on the context's OWN (non-blocking) stream and returns after the last
+ * kernel has been enqueued and the few scalar read-backs the launch sizes depend on.  That stream is not ordered against
+ * the stream that produced d_xyz: either the cloud is complete before the call (synchronise the producer), or record a
+ * hipEvent_t on the producing stream and hand it to la3dm_devmap_wait_event first — the insert then starts behind it. */
+int la3dm_devmap_wait_event(la3dm_devmap *dm, void *event /* hipEvent_t */);
 int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
                                           float ds_resolution, float free_resolution, float max_range,
                                           la3dm_devmap_stats *stats);

@@ -112,7 +112,10 @@ class BGKOctoMap:
 
     def insert_pointcloud_device(self, d_xyz, n, origin, ds_resolution, free_res=2.0, max_range=-1.0):
         """insert_pointcloud for a cloud already in HBM: d_xyz = device address of n packed float32 xyz triples on the
-        map's GPU (e.g. torch_tensor.data_ptr() of a contiguous (n, 3) float32 CUDA tensor); device-resident maps only."""
+        map's GPU (e.g. torch_tensor.data_ptr() of a contiguous (n, 3) float32 CUDA tensor); device-resident maps only.
+        The insert runs on the library's own stream: the cloud must be complete before the call — synchronise the stream
+        that produced it (torch.cuda.current_stream().synchronize()) or order the insert behind a hipEvent with
+        la3dm_devmap_wait_event (include/la3dm_hip.h)."""
         o = np.ascontiguousarray(origin, np.float32)
         self._chk(self._M.la3dm_map_insert_pointcloud_device(self._h, int(d_xyz), int(n), o, ds_resolution, free_res, max_range))
         return self

@@ -61,6 +61,7 @@ struct la3dm_devmap {
     Arena shard_w, shard_cumw, shard_bounds, shard_payload;
     uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
     uint32_t n_xy = 0;
+    bool poisoned = false;  // a failed insert whose block table could not be reconciled with the host's block count
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
     la3dm_devmap_stats stats;
 };
@@ -114,6 +115,17 @@ static int read_counters(la3dm_devmap *dm) {
     hipStream_t st = dm->ctx->stream;
     DM_TRY(hipMemcpyAsync(dm->h_cnt, dm->d_cnt, sizeof(uint32_t) * kCntWords, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
+    return LA3DM_OK;
+}
+
+// after the beam-count kernels: a beam that would not terminate, or more samples than the 32-bit offsets can index
+static int check_beam_counters(la3dm_devmap *dm) {
+    if (dm->h_cnt[kCntError] & kErrBeam)
+        return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: a beam does not terminate (infinite range, or free_resolution too small "
+                                          "against the range for fp32 stepping; set max_range / a larger free_resolution)");
+    const uint64_t total = (uint64_t)dm->h_cnt[kCntBeamTotal] | ((uint64_t)dm->h_cnt[kCntBeamTotal + 1] << 32);
+    if (total > 0x7FFFFFFFull)
+        return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: more than 2^31 beam samples in one scan (raise free_resolution or set max_range)");
     return LA3DM_OK;
 }
 
@@ -289,12 +301,14 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         la3dm_devmap_destroy(dm);
         return LA3DM_ERR_OOM;
     }
+    ctx->n_devmaps++;
     *out = dm;
     return LA3DM_OK;
 }
 
 void la3dm_devmap_destroy(la3dm_devmap *dm) {
     if (!dm) return;
+    dm->ctx->n_devmaps--;
     (void)hipSetDevice(dm->ctx->device);
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
@@ -369,12 +383,13 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     uint32_t *keep = (uint32_t *)dm->keep.ptr, *nfree = (uint32_t *)dm->nfree.ptr, *keep_off = (uint32_t *)dm->keep_off.ptr,
              *free_off = (uint32_t *)dm->free_off.ptr;
     if (ctx->p.variant == 3) {  // BGKLOctoMap: samples keep their beam, no second voxel filter
-        hipLaunchKernelGGL(dm_l_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree);
+        hipLaunchKernelGGL(dm_l_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
         if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
         if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
         hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, keep_off, keep, n_h, dm->d_cnt, (int)kCntKept);
         hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
         const uint32_t n_beams = dm->h_cnt[kCntKept], n_samples = dm->h_cnt[kCntFreeRaw];
         if (n_beams == 0) return LA3DM_OK;
         DM_RESERVE(dm->xy, 16ull * n_samples);
@@ -387,12 +402,13 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         S.n_frees = n_samples - n_beams;
         return training_bbox(dm);
     }
-    hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree);
+    hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
     if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
     if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, keep_off, keep, n_h, dm->d_cnt, (int)kCntKept);
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_kept = dm->h_cnt[kCntKept], n_free_raw = dm->h_cnt[kCntFreeRaw];
     if (n_kept == 0) return LA3DM_OK;
     DM_RESERVE(dm->xy, 16ull * ((size_t)n_kept + n_free_raw));
@@ -799,7 +815,22 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
     const uint32_t max_occ = P.max_occ;
     uint32_t n_test0 = 0;
     for (uint32_t pass = 0; pass < max_occ; ++pass)
-        if ((rc = run_pass(dm, P, pass, &n_test0)) != LA3DM_OK) return rc;
+        if ((rc = run_pass(dm, P, pass, &n_test0)) != LA3DM_OK) {
+            // run_pass is not failure-atomic: dm_table_insert may already have published new keys and bumped the device
+            // block counter when a later step (arena growth, a sort, the scan) fails.  Adopt the device counter so that the
+            // table, the pool (new blocks carry their default nodes) and the host agree again — the map stays usable, the
+            // scan is lost, as if the reference had thrown after creating its blocks.  If even that fails: poison.
+            const std::string why = dm->ctx->err;
+            uint32_t dev_blocks = 0;
+            if (hipStreamSynchronize(st) == hipSuccess &&
+                hipMemcpy(&dev_blocks, dm->d_cnt + kCntBlocks, 4, hipMemcpyDeviceToHost) == hipSuccess && dev_blocks <= dm->cap_blocks) {
+                if (dev_blocks > dm->n_blocks) dm->n_blocks = dev_blocks;
+            } else {
+                dm->poisoned = true;
+            }
+            dm->ctx->err = why;
+            return rc;
+        }
     if (max_occ > 1 && n_test0)
         hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test0, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot0.ptr, n_test0, dm->A, dm->B, dm->S, dm->npb, dm->depth);
@@ -839,6 +870,31 @@ int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, 
     return scan_training_set(dm, LA3DM_SCAN_UPDATE_UNGATED, t0, stats_out);
 }
 
+// Argument checks shared by the insert entry points.  The beam sampler walks `for (d = fr; d < l; d += fr)` on the GPU
+// (bgkoctomap.cpp:445-457): a free_resolution that is not a positive finite number would never terminate there (the
+// reference would run out of memory on the host instead), so it is rejected here; so are NaN resolutions / ranges and a
+// non-finite sensor origin.  Non-finite points of the cloud itself are dropped by the front end's range gate.
+static int check_scan_args(la3dm_devmap *dm, const float origin[3], float ds_resolution, float free_resolution, float max_range) {
+    if (dm->poisoned)
+        return dm_fail(dm, LA3DM_ERR_HIP, "devmap: an earlier insert failed in a way that left the block table unusable; destroy the map");
+    if (!(free_resolution > 0.0f) || !std::isfinite(free_resolution))
+        return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: free_resolution must be a positive finite number");
+    if (ds_resolution != ds_resolution || std::isinf(ds_resolution) || ds_resolution == 0.0f)
+        return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: ds_resolution must be finite and non-zero (negative = no voxel filter)");
+    if (max_range != max_range)
+        return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: max_range is NaN");
+    for (int i = 0; i < 3; ++i)
+        if (!std::isfinite(origin[i])) return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: the sensor origin is not finite");
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_wait_event(la3dm_devmap *dm, void *event) {
+    if (!dm || !event) return LA3DM_ERR_ARG;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    DM_TRY(hipStreamWaitEvent(dm->ctx->stream, (hipEvent_t)event, 0));
+    return LA3DM_OK;
+}
+
 int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
     if (!dm) return LA3DM_ERR_ARG;
     if (world == 0 || world > 1023 || rank >= world || (world > 1 && !fn))
@@ -863,6 +919,8 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
                                           la3dm_devmap_stats *stats_out) {
     if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
     la3dm_ctx *ctx = dm->ctx;
+    int rc;
+    if ((rc = check_scan_args(dm, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
     DM_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
@@ -870,7 +928,6 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     S.n_blocks = dm->n_blocks;
     dm->n_xy = 0;
     const double t0 = wall();
-    int rc;
     DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
 
     if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;

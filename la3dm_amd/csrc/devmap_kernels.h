@@ -46,7 +46,8 @@ enum DevCounter {
     kCntBig = 12,        // voxel-grid cells with more than kBigCell points
     kCntTrained = 13,    // blocks with training points that are in the candidate list
     kCntPairEvals = 14,  // 64-bit (words 14, 15): sum of neighbourhood points x leaves; kCntTrainReads likewise (10, 11)
-    kCntWords = 16
+    kCntBeamTotal = 16,  // 64-bit (words 16, 17): beam samples of the scan, summed without the 32-bit wrap of the offsets
+    kCntWords = 18
 };
 
 struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call
@@ -467,26 +468,45 @@ __device__ __forceinline__ float f32_sqrt_cr(float x) {  // correctly rounded (=
 }
 
 // number of free-space samples of one beam: the origin, every free_res, one sample free_res short of the hit
-__device__ __forceinline__ uint32_t beam_count(float l, float fr) {
+// A beam whose walk would not end is cut at kBeamCap samples and flagged (error bit 2): an infinite range, or a
+// free_resolution so small against the range that d += fr stops advancing in fp32 — the reference's host loop
+// (bgkoctomap.cpp:445-457) would spin or exhaust memory there; on the GPU it would hang the device.
+constexpr uint32_t kBeamCap = 1u << 22;
+constexpr uint32_t kErrBeam = 2u;
+__device__ __forceinline__ uint32_t beam_count(float l, float fr, uint32_t *counters) {
     uint32_t c = 1;
-    for (float d = fr; d < l; d += fr) ++c;
+    for (float d = fr; d < l && c < kBeamCap; d += fr) ++c;
+    if (c >= kBeamCap) {
+        atomicOr(&counters[kCntError], kErrBeam);
+        return 1;
+    }
     if (l > fr) ++c;
     return c;
 }
+// wave-reduced 64-bit total of the per-beam sample counts (the 32-bit offsets wrap silently above 2^32 samples)
+__device__ __forceinline__ void beam_total_add(uint32_t c, uint32_t *counters) {
+    unsigned long long t = c;
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(reinterpret_cast<unsigned long long *>(counters + kCntBeamTotal), t);
+}
 
 __global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
-                                                    uint32_t *nfree) {
+                                                    uint32_t *nfree, uint32_t *counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
-    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
-    const float s = dx * dx + dy * dy + dz * dz;
-    bool k = true;
-    // point3f::norm() > max_range in f64: sqrt((double)s) > R  <=>  s > R*R (R*R is exact in f64 and the
-    // gap between a float s and R*R is far above half an ulp of the f64 root)
-    if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);
-    keep[i] = k ? 1u : 0u;
-    nfree[i] = k ? beam_count(f32_sqrt_cr(s), a.free_res) : 0u;
+    uint32_t c = 0;
+    if (i < n) {
+        const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
+        const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+        const float s = dx * dx + dy * dy + dz * dz;
+        bool k = true;
+        // point3f::norm() > max_range in f64: sqrt((double)s) > R  <=>  s > R*R (R*R is exact in f64 and the
+        // gap between a float s and R*R is far above half an ulp of the f64 root)
+        if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);
+        keep[i] = k ? 1u : 0u;
+        c = k ? beam_count(f32_sqrt_cr(s), a.free_res, counters) : 0u;
+        nfree[i] = c;
+    }
+    beam_total_add(c, counters);
 }
 
 // hits that pass the gate -> xy (label 1) in order; their beam samples -> frees (xyz) in order
@@ -544,22 +564,28 @@ __device__ __forceinline__ LBeam l_beam(float x, float y, float z, const BeamArg
 }
 
 __global__ __launch_bounds__(256) void dm_l_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
-                                                      uint32_t *nsamp) {
+                                                      uint32_t *nsamp, uint32_t *counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
-    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
-    const float s = dx * dx + dy * dy + dz * dz;
-    bool k = true;
-    if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);  // see dm_beam_count
     uint32_t c = 0;
-    if (k) {
-        const LBeam b = l_beam(x, y, z, a);
-        c = 2;  // the re-projected hit and the origin sample
-        for (float d = b.l2 - a.free_res; d > 0.0f; d -= a.free_res) ++c;
+    if (i < n) {
+        const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
+        const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+        const float s = dx * dx + dy * dy + dz * dz;
+        bool k = true;
+        if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);  // see dm_beam_count
+        if (k) {
+            const LBeam b = l_beam(x, y, z, a);
+            c = 2;  // the re-projected hit and the origin sample
+            for (float d = b.l2 - a.free_res; d > 0.0f && c < kBeamCap; d -= a.free_res) ++c;
+            if (c >= kBeamCap) {  // see beam_count
+                atomicOr(&counters[kCntError], kErrBeam);
+                c = 2;
+            }
+        }
+        keep[i] = k ? 1u : 0u;
+        nsamp[i] = c;
     }
-    keep[i] = k ? 1u : 0u;
-    nsamp[i] = c;
+    beam_total_add(c, counters);
 }
 
 __global__ __launch_bounds__(256) void dm_l_beam_write(const float *__restrict__ hits, uint32_t n, BeamArgs a,

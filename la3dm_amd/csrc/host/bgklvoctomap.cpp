@@ -98,6 +98,7 @@ BGKLVOctoMap::BGKLVOctoMap(float resolution_, unsigned short block_depth_, float
 // near other hits) and samples along it (first sample = segment start) that carry the ray's index.
 void BGKLVOctoMap::training_data_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                                     float free_resolution, float max_range) {
+    bind();
     std::vector<float> packed(3 * n), hits;
     for (size_t i = 0; i < n; ++i) {
         packed[3 * i] = xyz[stride * i];
@@ -211,6 +212,7 @@ void BGKLVOctoMap::training_data_lv(const float *xyz, size_t n, size_t stride, c
 
 bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                               float free_res, float max_range) {
+    bind();
     lvst = LVStats();
     const double t0 = wall();
     if (ds_resolution > resolution) ds_resolution = resolution;
@@ -391,6 +393,7 @@ bool BGKLVOctoMap::select_pass_lv(uint32_t pass) {
 }
 
 la3dm_lv_scan BGKLVOctoMap::packed_lv() {
+    bind();
     la3dm_lv_scan s;
     std::memset(&s, 0, sizeof(s));
     s.samples = samples.data();
@@ -413,6 +416,7 @@ la3dm_lv_scan BGKLVOctoMap::packed_lv() {
 }
 
 void BGKLVOctoMap::commit_lv() {
+    bind();
     const double t0 = wall();
     const unsigned depth = (unsigned)get_block_depth();
     const size_t npb = (size_t)1 << (3 * (depth - 1));
@@ -454,6 +458,7 @@ void BGKLVOctoMap::finish_lv() {
 
 void BGKLVOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                                      float free_res, float max_range) {
+    bind();
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKLVOctoMap::insert_pointcloud: no device context (there is no CPU path)");
     if (!prepare_lv(xyz, n, stride, origin, ds_resolution, free_res, max_range)) return;

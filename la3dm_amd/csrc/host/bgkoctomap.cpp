@@ -326,6 +326,7 @@ OcTreeHashKey Block::get_node(unsigned short x, unsigned short y, unsigned short
 // ------------------------------------------------------------------ RayCaster
 BGKOctoMap::RayCaster::RayCaster(const BGKOctoMap *m, const point3f &start, const point3f &end_)
     : map(m), block(nullptr), n(0), lim(1 << (m->block_depth - 1)) {
+    m->bind();
     key = block_to_hash_key(start);
     block = map->search(key);
     if (block == nullptr) return;  // the walk only starts inside an existing block
@@ -448,6 +449,8 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
         OcTreeNode::init_B = OcTreeNode::min_ivar;
     }
 
+    capture_statics();
+
     la3dm_params p;
     std::memset(&p, 0, sizeof(p));
     p.variant = variant;
@@ -483,18 +486,75 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     }
 }
 
+const BGKOctoMap *BGKOctoMap::bound = nullptr;
+
+void BGKOctoMap::capture_statics() {
+    mine.resolution = Block::resolution;
+    mine.size = Block::size;
+    mine.key_loc_map = Block::key_loc_map;
+    mine.max_depth = OcTree::max_depth;
+    mine.sf2 = OcTreeNode::sf2;
+    mine.ell = OcTreeNode::ell;
+    mine.free_thresh = OcTreeNode::free_thresh;
+    mine.occupied_thresh = OcTreeNode::occupied_thresh;
+    mine.var_thresh = OcTreeNode::var_thresh;
+    mine.prior_A = OcTreeNode::prior_A;
+    mine.prior_B = OcTreeNode::prior_B;
+    mine.init_A = OcTreeNode::init_A;
+    mine.init_B = OcTreeNode::init_B;
+    mine.min_W = OcTreeNode::min_W;
+    mine.noise = OcTreeNode::noise;
+    mine.l = OcTreeNode::l;
+    mine.min_ivar = OcTreeNode::min_ivar;
+    mine.max_ivar = OcTreeNode::max_ivar;
+    mine.min_known_ivar = OcTreeNode::min_known_ivar;
+    mine.variant = OcTreeNode::variant;
+    mine.original_size = OcTreeNode::original_size;
+    bound = this;
+}
+
+// re-install this map's parameters into the process-global statics (no-op while this map is the bound one)
+void BGKOctoMap::bind() const {
+    if (bound == this) return;
+    Block::resolution = mine.resolution;
+    Block::size = mine.size;
+    Block::key_loc_map = mine.key_loc_map;
+    OcTree::max_depth = mine.max_depth;
+    OcTreeNode::sf2 = mine.sf2;
+    OcTreeNode::ell = mine.ell;
+    OcTreeNode::free_thresh = mine.free_thresh;
+    OcTreeNode::occupied_thresh = mine.occupied_thresh;
+    OcTreeNode::var_thresh = mine.var_thresh;
+    OcTreeNode::prior_A = mine.prior_A;
+    OcTreeNode::prior_B = mine.prior_B;
+    OcTreeNode::init_A = mine.init_A;
+    OcTreeNode::init_B = mine.init_B;
+    OcTreeNode::min_W = mine.min_W;
+    OcTreeNode::noise = mine.noise;
+    OcTreeNode::l = mine.l;
+    OcTreeNode::min_ivar = mine.min_ivar;
+    OcTreeNode::max_ivar = mine.max_ivar;
+    OcTreeNode::min_known_ivar = mine.min_known_ivar;
+    OcTreeNode::variant = mine.variant;
+    OcTreeNode::original_size = mine.original_size;
+    bound = this;
+}
+
 void BGKOctoMap::ensure_host_mode() {
     if (dmap != nullptr) set_device_resident(false);
 }
 
 BGKOctoMap::~BGKOctoMap() {
+    bind();  // the blocks' destructors read the layer count
     for (auto &kv : block_arr) delete kv.second;
+    bound = nullptr;
     la3dm_devmap_destroy(dmap);
     la3dm_destroy(ctx);
 }
 
 // ------------------------------------------------------------- device-resident mode
 void BGKOctoMap::set_device_resident(bool on) {
+    bind();
     if (on == (dmap != nullptr)) return;
     if (!on) {
         sync_mirror();
@@ -512,6 +572,7 @@ void BGKOctoMap::set_device_resident(bool on) {
 // Refresh the host mirror from the device pool: every block's nodes are overwritten with the device
 // state (alpha, beta, state, classified); PRUNED children keep their collapsed parents' leaf role.
 void BGKOctoMap::sync_mirror() const {
+    bind();
     if (dmap == nullptr || !mirror_dirty) return;
     uint32_t nb = 0, npb = 0;
     if (la3dm_devmap_block_count(dmap, &nb, &npb) != LA3DM_OK)
@@ -547,11 +608,13 @@ Block *BGKOctoMap::search(BlockHashKey key) const {
 }
 
 OcTreeNode BGKOctoMap::search(point3f p) const {
+    bind();
     Block *b = search(block_to_hash_key(p));
     return b == nullptr ? OcTreeNode() : OcTreeNode(b->search(p));
 }
 
 void BGKOctoMap::search_many(const float *xyz, size_t n, uint8_t *exists, float *A, float *B, uint8_t *state) const {
+    bind();
     if (dmap != nullptr) {
         if (la3dm_devmap_search_host(dmap, xyz, (uint32_t)n, exists, A, B, state) != LA3DM_OK)
             throw std::runtime_error(std::string("BGKOctoMap::search_many: ") + la3dm_last_error(ctx));
@@ -595,6 +658,7 @@ void height_map_color(double h, float *rgba) {
 }  // namespace
 
 size_t BGKOctoMap::export_cells(State state, bool original_size, float min_z, float max_z, Cells &out) const {
+    bind();
     if (state != State::OCCUPIED && state != State::FREE)
         throw std::runtime_error("BGKOctoMap::export_cells: state must be OCCUPIED or FREE");
     out.xyz_size.clear();
@@ -650,6 +714,7 @@ size_t BGKOctoMap::export_cells(State state, bool original_size, float min_z, fl
 }
 
 void BGKOctoMap::get_bbox(point3f &lim_min, point3f &lim_max) const {
+    bind();
     if (dmap != nullptr) {  // index box of the pool's keys; centre = (index - 524288) * size is monotone in the index
         lim_min = point3f(0, 0, 0);
         lim_max = point3f(0, 0, 0);
@@ -1362,6 +1427,7 @@ int BGKOctoMap::run_scan(la3dm_bgk_scan *s, la3dm_bgk_counters *c) {
 }
 
 la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
+    bind();
     la3dm_bgk_scan s;
     std::memset(&s, 0, sizeof(s));
     Pass &ps = passes.at(pass);
@@ -1419,6 +1485,7 @@ void BGKOctoMap::write_nodes(size_t p) {
 // candidate list (a float-stepping artefact, normally none) are replayed here one pass
 // after the other so that they see the previous pass's posterior, as the serial reference does.
 void BGKOctoMap::commit() {
+    bind();
     const double t0 = wall();
     if (!passes.empty()) write_nodes(0);
     for (size_t p = 1; p < passes.size(); ++p) {
@@ -1447,6 +1514,7 @@ void BGKOctoMap::set_shard(uint32_t rank, uint32_t world, la3dm_allgather_fn fn,
 
 bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                          float free_res, float max_range) {
+    bind();
     ensure_host_mode();
     stats = ScanStats();
     const double t0 = wall();
@@ -1463,6 +1531,7 @@ bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3
 }
 
 bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated) {
+    bind();
     ensure_host_mode();
     stats = ScanStats();
     xy.assign(xyzy, xyzy + 4 * n);
@@ -1489,6 +1558,7 @@ void BGKOctoMap::take_device_stats(const la3dm_devmap_stats &ds) {
 
 void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                                    float free_res, float max_range) {
+    bind();
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_pointcloud: no device context (there is no CPU path)");
     if (dmap != nullptr) {  // device-resident mode: the whole scan runs on the GPU
@@ -1518,6 +1588,7 @@ void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, co
 
 void BGKOctoMap::insert_pointcloud_device(const float *d_xyz, size_t n, const point3f &origin, float ds_resolution, float free_res,
                                           float max_range) {
+    bind();
     const double t0 = wall();
     if (dmap == nullptr) throw std::runtime_error("BGKOctoMap::insert_pointcloud_device: the map is not device resident");
     const float o[3] = {origin.x(), origin.y(), origin.z()};
@@ -1530,6 +1601,7 @@ void BGKOctoMap::insert_pointcloud_device(const float *d_xyz, size_t n, const po
 }
 
 void BGKOctoMap::insert_training_data(const GPPointCloud &cloud) {
+    bind();
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKOctoMap::insert_training_data: no device context (there is no CPU path)");
     std::vector<float> flat;

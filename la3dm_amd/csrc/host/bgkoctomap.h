@@ -382,6 +382,7 @@ public:
         OcTree::LeafIterator leaf_it, end_leaf;
     };
     LeafIterator begin_leaf() const {
+        bind();
         sync_mirror();
         return LeafIterator(this);
     }
@@ -394,6 +395,7 @@ public:
     /// device pool (no mirror refresh); otherwise from the host blocks.  exists[i] = the block exists.
     void search_many(const float *xyz, size_t n, uint8_t *exists, float *A, float *B, uint8_t *state) const;
     size_t block_count() const {
+        bind();
         sync_mirror();
         return block_arr.size();
     }
@@ -418,6 +420,32 @@ protected:
     bool partition_and_pack(bool ungated);
     void refresh_pass(size_t p);
     void write_nodes(size_t p);
+
+    // The reference keeps its map parameters in process-global statics (Block::resolution / size / key_loc_map,
+    // OcTree::max_depth, every OcTreeNode threshold: bgkoctomap.cpp:31-56) and so do the node / block classes here.
+    // Each map therefore remembers its own set and re-installs it (bind()) at the top of every public entry point, so
+    // several maps with different variants, depths or resolutions can be alive in one process.  Like the reference the
+    // maps of a process must be driven from one thread at a time, and a LeafIterator / RayCaster must be used up
+    // before another map is touched.
+    struct BoundStatics {
+        float resolution, size;
+        std::vector<point3f> key_loc_map;
+        unsigned short max_depth;
+        float sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B, init_A, init_B, min_W;
+        float noise, l, min_ivar, max_ivar, min_known_ivar;
+        int variant;
+        bool original_size;
+    };
+    BoundStatics mine;
+    static const BGKOctoMap *bound;
+    void capture_statics();
+
+public:
+    /// make this map's parameters the process-global ones (every public entry point does it; call it yourself before
+    /// using the static helpers block_to_hash_key / hash_key_to_block / get_extended_block with a particular map in mind)
+    void bind() const;
+
+protected:
 
     float resolution;
     float block_size;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -34,10 +35,10 @@ const char *la3dm_map_last_error(void) { return g_err.c_str(); }
 la3dm_map *la3dm_map_create(float resolution, int block_depth, float sf2, float ell, float free_thresh,
                             float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device) {
     try {
-        la3dm_map *m = new la3dm_map;
+        std::unique_ptr<la3dm_map> m(new la3dm_map);
         m->map = new BGKOctoMap(resolution, (unsigned short)block_depth, sf2, ell, free_thresh, occupied_thresh,
                                 var_thresh, prior_A, prior_B, device);
-        return m;
+        return m.release();
     } catch (const std::exception &e) {
         g_err = e.what();
         return nullptr;
@@ -48,10 +49,10 @@ la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, flo
                                float min_var, float max_var, float max_known_var, float free_thresh,
                                float occupied_thresh, int device) {
     try {
-        la3dm_map *m = new la3dm_map;
+        std::unique_ptr<la3dm_map> m(new la3dm_map);
         m->map = new la3dm::GPOctoMap(resolution, (unsigned short)block_depth, sf2, ell, noise, l, min_var, max_var,
                                       max_known_var, free_thresh, occupied_thresh, device);
-        return m;
+        return m.release();
     } catch (const std::exception &e) {
         g_err = e.what();
         return nullptr;
@@ -61,10 +62,10 @@ la3dm_map *la3dm_map_create_gp(float resolution, int block_depth, float sf2, flo
 la3dm_map *la3dm_map_create_l(float resolution, int block_depth, float sf2, float ell, float free_thresh,
                               float occupied_thresh, float var_thresh, float prior_A, float prior_B, int device) {
     try {
-        la3dm_map *m = new la3dm_map;
+        std::unique_ptr<la3dm_map> m(new la3dm_map);
         m->map = new la3dm::BGKLOctoMap(resolution, (unsigned short)block_depth, sf2, ell, free_thresh, occupied_thresh,
                                         var_thresh, prior_A, prior_B, device);
-        return m;
+        return m.release();
     } catch (const std::exception &e) {
         g_err = e.what();
         return nullptr;
@@ -85,10 +86,10 @@ la3dm_map *la3dm_map_create_lv(float resolution, int block_depth, float sf2, flo
                                float occupied_thresh, float var_thresh, float prior_A, float prior_B, int original_size,
                                float min_W, int device) {
     try {
-        la3dm_map *m = new la3dm_map;
+        std::unique_ptr<la3dm_map> m(new la3dm_map);
         m->map = new la3dm::BGKLVOctoMap(resolution, (unsigned short)block_depth, sf2, ell, free_thresh, occupied_thresh,
                                          var_thresh, prior_A, prior_B, original_size != 0, min_W, device);
-        return m;
+        return m.release();
     } catch (const std::exception &e) {
         g_err = e.what();
         return nullptr;
@@ -288,7 +289,8 @@ int la3dm_map_search(const la3dm_map *m, float x, float y, float z, float *A, fl
     return b != nullptr;
 }
 
-void la3dm_map_block_grid(const la3dm_map *, const float *c3, const float *p3, int32_t *idx3, int32_t *node_key, float *point3) {
+void la3dm_map_block_grid(const la3dm_map *m, const float *c3, const float *p3, int32_t *idx3, int32_t *node_key, float *point3) {
+    m->map->bind();
     la3dm::Block b(point3f(c3[0], c3[1], c3[2]));
     unsigned short x, y, z;
     b.get_index(point3f(p3[0], p3[1], p3[2]), x, y, z);
@@ -348,12 +350,17 @@ int la3dm_map_get_bbox(const la3dm_map *m, float *lo, float *hi) {
     return 0;
 }
 
-int64_t la3dm_map_block_to_hash_key(const la3dm_map *, float x, float y, float z) { return la3dm::block_to_hash_key(x, y, z); }
-void la3dm_map_hash_key_to_block(const la3dm_map *, int64_t key, float *out3) {
+int64_t la3dm_map_block_to_hash_key(const la3dm_map *m, float x, float y, float z) {
+    m->map->bind();
+    return la3dm::block_to_hash_key(x, y, z);
+}
+void la3dm_map_hash_key_to_block(const la3dm_map *m, int64_t key, float *out3) {
+    m->map->bind();
     const point3f c = la3dm::hash_key_to_block(key);
     out3[0] = c.x(); out3[1] = c.y(); out3[2] = c.z();
 }
-void la3dm_map_extended_block(const la3dm_map *, int64_t key, int64_t *out7) {
+void la3dm_map_extended_block(const la3dm_map *m, int64_t key, int64_t *out7) {
+    m->map->bind();
     const la3dm::ExtendedBlock e = la3dm::get_extended_block(key);
     for (int i = 0; i < 7; ++i) out7[i] = e[i];
 }

@@ -20,6 +20,7 @@ struct la3dm_ctx {
     float4 *d_lut = nullptr;
     uint32_t lut_count = 0;
     std::string err;
+    int n_devmaps = 0;     // live la3dm_devmap objects that point at this context (la3dm_destroy refuses while > 0)
     int opt_variant = 0;   // unused (one BGK kernel is built)
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML

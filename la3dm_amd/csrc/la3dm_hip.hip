@@ -91,6 +91,11 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
 
 void la3dm_destroy(la3dm_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->n_devmaps > 0) {  // a device-resident map still points at this context: freeing it now would leave it dangling
+        ctx->err = "la3dm_destroy: destroy the context's la3dm_devmap objects first (context kept alive)";
+        fprintf(stderr, "%s\n", ctx->err.c_str());
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_val, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,

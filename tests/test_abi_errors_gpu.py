@@ -99,3 +99,45 @@ def test_device_map_entry_points_reject_bad_arguments(built):
     before = m.block_count()
     m.insert_pointcloud(bad, origin, 0.1, 0.5, 8.0)
     assert m.block_count() == before
+
+
+def test_scan_arguments_that_would_hang_the_beam_sampler_are_rejected(built):
+    """the beam sampler's `for (d = fr; d < l; d += fr)` (bgkoctomap.cpp:445-457) runs on the GPU; arguments
+    that would make it spin are rejected at the ABI (or, when only the data decides, flagged by the kernel) instead of
+    hanging the device, and the map stays usable."""
+    import la3dm_amd
+    for make in (lambda: la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0), lambda: la3dm_amd.BGKLOctoMap(**la3dm_amd.L_YAML, device=0)):
+        m = make()
+        assert m.is_device_resident()
+        pts = np.array([[2.0, 0.3, 0.4], [1.5, -1.0, 0.2], [0.2, 2.5, 1.0]], np.float32)
+        for fr in (0.0, -0.5, float("nan"), float("inf")):
+            with pytest.raises(RuntimeError, match="free_resolution"):
+                m.insert_pointcloud(pts, [0, 0, 0.5], 0.1, fr, -1.0)
+        with pytest.raises(RuntimeError, match="ds_resolution"):
+            m.insert_pointcloud(pts, [0, 0, 0.5], float("nan"), 0.5, -1.0)
+        with pytest.raises(RuntimeError, match="origin"):
+            m.insert_pointcloud(pts, [0, float("inf"), 0.5], 0.1, 0.5, -1.0)
+        # data-dependent: an unfiltered cloud (ds < 0, no range gate) with an infinitely far hit, and a free_resolution
+        # far below the fp32 spacing at the beam's range (d += fr stops advancing)
+        with pytest.raises(RuntimeError, match="does not terminate"):
+            m.insert_pointcloud(pts, [0, 0, 0.5], -1.0, 1e-9, -1.0)
+        assert m.block_count() == 0
+        far = np.array([[np.inf, 0.0, 1.0]], np.float32)               # an infinite range: must come back, either way
+        try:
+            m.insert_pointcloud(far, [0, 0, 0.5], -1.0, 0.5, -1.0)
+        except RuntimeError as e:
+            assert "does not terminate" in str(e)
+        before = m.block_count()
+        m.insert_pointcloud(pts, [0, 0, 0.5], 0.1, 0.3, -1.0)          # the map is still usable
+        assert m.block_count() > before
+
+
+def test_set_option_validates_its_values(built):
+    import la3dm_amd
+    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+    for name, bad in (("waves_per_wg", 0), ("waves_per_wg", 3), ("waves_per_wg", 8), ("remap", 3), ("remap", -1), ("fast_trig", 5),
+                      ("ablate", 99)):
+        with pytest.raises(RuntimeError):
+            m.set_option(name, bad)
+    for name, ok in (("waves_per_wg", 2), ("waves_per_wg", 1), ("remap", 0), ("remap", 2), ("fast_trig", 0)):
+        m.set_option(name, ok)

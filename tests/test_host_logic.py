@@ -288,3 +288,28 @@ def test_synthetic_scan_generator(built):
     assert np.abs(xyz[:, :2]).max() < 10.2 and -0.1 < xyz[:, 2].min() and xyz[:, 2].max() < 5.1
     x2, _ = la3dm_amd.synthetic_scan(5000)
     assert (x2 == xyz).all()
+
+
+def test_two_live_maps_with_different_parameters_keep_their_own(built):
+    """ADVICE r01: the node / block parameters are process-global statics as in the reference (bgkoctomap.cpp:31-56);
+    every map re-installs its own set at each public entry point, so a second live map with another depth, resolution
+    or variant does not change the first one's hashing, leaf layout or classification."""
+    import la3dm_amd
+    a = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, resolution=0.1, block_depth=3), device=-1)
+    ka = a.block_to_hash_key(0.39, -0.41, 7.45)
+    lut_a = a.lut().copy()
+    b = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, resolution=0.25, block_depth=5), device=-1)   # now the bound one
+    kb = b.block_to_hash_key(0.39, -0.41, 7.45)
+    assert a.block_to_hash_key(0.39, -0.41, 7.45) == ka == 0x800017ffff80013          # SURVEY 9.3, depth 3 / 0.1 m
+    assert b.block_to_hash_key(0.39, -0.41, 7.45) == kb != ka
+    assert abs(a.get_block_size() - 0.4) < 1e-6 and abs(b.get_block_size() - 4.0) < 1e-6
+    assert (a.lut() == lut_a).all() and a.lut().shape[0] == 73 and b.lut().shape[0] == (8 ** 5 - 1) // 7
+    # interleaved host-orchestrated work on both maps
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, (200, 3)).astype(np.float32)
+    assert a.prepare(pts, [0, 0, 0.5], 0.1, 0.5, -1.0)
+    na = a.packed().n_leaf
+    assert b.prepare(pts, [0, 0, 0.5], 0.25, 0.5, -1.0)
+    assert a.packed().n_leaf == na
+    ca, cb = a.hash_key_to_block(ka), b.hash_key_to_block(kb)
+    assert abs(ca[2] - 7.6) < 1e-5 and abs(cb[2] - 8.0) < 1e-5
