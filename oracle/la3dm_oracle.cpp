@@ -270,8 +270,86 @@ bool block_prune(const Params &p, Block &b) {
 // the true value lies within ~1e-16 relative of a rounding tie).  This is
 // independent of which cosf/sinf variant glibc's ifunc selects on the host.
 // ---------------------------------------------------------------------------
-inline float cr_cosf(float t) { return (float)cos((double)t); }
-inline float cr_sinf(float t) { return (float)sin((double)t); }
+}  // namespace
+
+// ---- sensitivity switches (tests/test_oracle.py::test_eigen_packet_trig_and_pcl_sort_order_move_p_by) ----------------
+// The two boundaries where this oracle restates third-party code the image does not have can be restated in more than
+// one plausible way.  Default (0, 0): correctly rounded sinf/cosf, ascending cloud index inside a voxel-grid cell — what
+// the HIP path is bit-identical to.  Alternative (1, 1): what a ROS Noetic build of the reference most likely executes:
+//   trig 1       Eigen 3.3.7's SSE packet psin / pcos (Eigen/src/Core/arch/SSE/MathFunctions.h, the Cephes-derived
+//                sse_mathfun algorithm: scale by 4/pi, truncate, j = (j + 1) & ~1, three-term Cody-Waite reduction with
+//                separate multiply and add, degree-3 polynomials in z = x^2, no FMA) for EVERY element (Eigen uses libm
+//                for the last size % 4 elements of an array only);
+//   grid sort 1  pcl::VoxelGrid's std::sort over {idx, cloud_point_index} with operator< on idx alone (PCL 1.10
+//                voxel_grid.hpp): libstdc++'s introsort, so the order of the points inside a cell — the order of the fp32
+//                centroid sum — is whatever that unstable sort leaves.
+// Neither library is present, so the alternative is as unpinned as the default; the point of having both is to MEASURE
+// how far the choice moves the occupancy probability.
+int g_orc_trig_mode = 0;
+int g_orc_grid_sort_mode = 0;
+extern "C" void orc_set_modes(int trig, int grid_sort) {
+    g_orc_trig_mode = trig;
+    g_orc_grid_sort_mode = grid_sort;
+}
+
+namespace orc_eigen337 {
+static inline float from_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline uint32_t to_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline void reduce(float &x, float &y, int32_t &j) {
+    x = std::fabs(x);
+    y = x * 1.27323954473516f;        // cephes_FOPI = 4 / pi
+    j = (int32_t)y;                   // _mm_cvttps_epi32
+    j = (j + 1) & ~1;
+    y = (float)j;
+}
+static inline float poly(float x, bool use_sin) {
+    const float z = x * x;
+    if (!use_sin) {
+        float y = 2.443315711809948E-005f;
+        y = y * z + -1.388731625493765E-003f;   // pmadd without FMA: rounded multiply, rounded add
+        y = y * z + 4.166664568298827E-002f;
+        y = y * z;
+        y = y * z;
+        y = y - z * 0.5f;
+        return y + 1.0f;
+    }
+    float y2 = -1.9515295891E-4f;
+    y2 = y2 * z + 8.3321608736E-3f;
+    y2 = y2 * z + -1.6666654611E-1f;
+    y2 = y2 * z;
+    y2 = y2 * x;
+    return y2 + x;
+}
+float psin(float x0) {
+    uint32_t sign = to_bits(x0) & 0x80000000u;
+    float x, y;
+    int32_t j;
+    x = x0;
+    reduce(x, y, j);
+    sign ^= ((uint32_t)(j & 4)) << 29;
+    const bool use_sin = (j & 2) == 0;
+    x = x + y * -0.78515625f;
+    x = x + y * -2.4187564849853515625e-4f;
+    x = x + y * -3.77489497744594108e-8f;
+    return from_bits(to_bits(poly(x, use_sin)) ^ sign);
+}
+float pcos(float x0) {
+    float x = x0, y;
+    int32_t j;
+    reduce(x, y, j);
+    j -= 2;
+    const uint32_t sign = ((uint32_t)(~j & 4)) << 29;
+    const bool use_sin = (j & 2) == 0;
+    x = x + y * -0.78515625f;
+    x = x + y * -2.4187564849853515625e-4f;
+    x = x + y * -3.77489497744594108e-8f;
+    return from_bits(to_bits(poly(x, use_sin)) ^ sign);
+}
+}  // namespace orc_eigen337
+
+namespace {
+inline float cr_cosf(float t) { return g_orc_trig_mode ? orc_eigen337::pcos(t) : (float)cos((double)t); }
+inline float cr_sinf(float t) { return g_orc_trig_mode ? orc_eigen337::psin(t) : (float)sin((double)t); }
 
 inline float cov_sparse_elem(float r, float sf2) {
     float t = (r * 2.0f) * 3.1415926f;
@@ -431,8 +509,16 @@ void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
         iv.emplace_back((unsigned)idx, (unsigned)i);
     }
     // std::sort in PCL is not stable; equal-cell order is implementation defined.
-    // Restated as ascending cloud index inside a cell.
-    std::sort(iv.begin(), iv.end());
+    // Restated as ascending cloud index inside a cell — or, with the sensitivity switch, as what libstdc++'s introsort
+    // leaves when it compares idx only, like pcl::VoxelGrid's cloud_point_index_idx::operator<.
+    if (g_orc_grid_sort_mode) {
+        struct PclLess {
+            bool operator()(const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) const { return a.first < b.first; }
+        };
+        std::sort(iv.begin(), iv.end(), PclLess());
+    } else {
+        std::sort(iv.begin(), iv.end());
+    }
     size_t i = 0;
     while (i < iv.size()) {
         size_t j = i + 1;

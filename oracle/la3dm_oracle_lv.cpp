@@ -29,6 +29,12 @@
 #include <unordered_map>
 #include <vector>
 
+extern int g_orc_trig_mode, g_orc_grid_sort_mode;   // la3dm_oracle.cpp: the sensitivity switches (orc_set_modes)
+namespace orc_eigen337 {
+float psin(float x);
+float pcos(float x);
+}
+
 namespace {
 
 enum : uint8_t { LV_FREE = 0, LV_OCCUPIED = 1, LV_UNKNOWN = 2, LV_UNCERTAIN = 3, LV_PRUNED = 4 };
@@ -191,7 +197,14 @@ void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
         int c0 = (int)(std::floor(p.x * inv) - (float)lo[0]), c1 = (int)(std::floor(p.y * inv) - (float)lo[1]), c2 = (int)(std::floor(p.z * inv) - (float)lo[2]);
         iv.emplace_back((unsigned)(c0 + c1 * sp[0] + c2 * sp[0] * sp[1]), (unsigned)i);
     }
-    std::sort(iv.begin(), iv.end());
+    if (g_orc_grid_sort_mode) {  // pcl::VoxelGrid's unstable sort on idx alone (see la3dm_oracle.cpp)
+        struct PclLess {
+            bool operator()(const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) const { return a.first < b.first; }
+        };
+        std::sort(iv.begin(), iv.end(), PclLess());
+    } else {
+        std::sort(iv.begin(), iv.end());
+    }
     for (size_t i = 0; i < iv.size();) {
         size_t j = i;
         float sx = 0, sy = 0, sz = 0;
@@ -302,8 +315,8 @@ inline float seg_dist(V3 p, V3 p0, V3 p1) {
     V3 nearest = p0 + mulf(line_vec, (float)b);
     return (float)norm3(p - nearest);
 }
-inline float cr_cosf(float t) { return (float)cos((double)t); }
-inline float cr_sinf(float t) { return (float)sin((double)t); }
+inline float cr_cosf(float t) { return g_orc_trig_mode ? orc_eigen337::pcos(t) : (float)cos((double)t); }
+inline float cr_sinf(float t) { return g_orc_trig_mode ? orc_eigen337::psin(t) : (float)sin((double)t); }
 inline float cov_sparse_line(float d, float ell, float sf2) {
     float r = d / ell;
     if (r > 1.0) r = 1.0f;

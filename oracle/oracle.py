@@ -113,6 +113,7 @@ def _load(name):
     lib.orc_insert_training_data.argtypes = [C.c_void_p, f32p, C.c_int64]
     lib.orc_stats.argtypes = [C.c_void_p, f64p]
     lib.orc_num_threads.restype = C.c_int
+    lib.orc_set_modes.argtypes = [C.c_int, C.c_int]
     lib.orc_block_count.restype = C.c_int64
     lib.orc_block_count.argtypes = [C.c_void_p]
     lib.orc_leaf_count.restype = C.c_int64
@@ -454,3 +455,10 @@ def ref():
         R.ref_rtree_box_query.argtypes = [C.c_void_p, f32p, f32p, i32p, C.c_int]
         _ref = R
     return _ref
+
+
+def set_modes(trig=0, grid_sort=0, omp=False):
+    """sensitivity switches of the restatement (oracle/la3dm_oracle.cpp): trig 1 = Eigen 3.3.7 SSE packet psin / pcos
+    instead of correctly rounded sin / cos; grid_sort 1 = pcl::VoxelGrid's unstable std::sort on the cell index alone.
+    Process-global per library build; (0, 0) is the default every parity test uses."""
+    lib(omp).orc_set_modes(int(trig), int(grid_sort))

@@ -270,3 +270,58 @@ def test_kernel_support_ends_at_the_device_hit_threshold(built):
         pos = O.kernel(r, sf2) > 0
         assert int(d2[pos].max().view(np.uint32)) == 0x3f77c08c, sf2
     assert (O.kernel(np.linspace(1.0, 4.0, 300001).astype(np.float32), 1.0) == 0).all()
+
+
+def test_eigen_packet_trig_and_pcl_sort_order_move_p_by(built):
+    """how far do the two unpinned restatement choices move the result?  The oracle's defaults are
+    correctly rounded sin / cos (include/bgkoctomap/bgkinference.h:115-116 calls Eigen's array cos / sin) and ascending
+    cloud index inside a voxel-grid cell (src/bgkoctomap/bgkoctomap.cpp:425-430 calls pcl::VoxelGrid).  The alternative
+    restates what a ROS Noetic build most likely runs — Eigen 3.3.7's SSE packet psin / pcos and PCL's unstable std::sort
+    on the cell index — and the same scans go through both: configs[0] (sim_structured scan 1, 0.1 m, bgkoctomap.yaml)
+    after 1 insertion and after the 15 re-insertions of the sim_structured_long_term pattern.
+    The bounds asserted are what was measured (DESIGN.md section 4 quotes them): the choice stays inside the north star's
+    1e-5 for a single scan and does not after 15 fused ones — bit-identity with THIS oracle is therefore not bit-identity
+    with a particular build of la3dm, and 1e-5 against such a build holds per scan, not per long sequence."""
+    import la3dm_amd
+    from conftest import pcd_path
+    from oracle import oracle as O
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+
+    def run(trig, sort, n):
+        O.set_modes(trig, sort)
+        try:
+            o = O.OracleMap(**YAML)
+            for _ in range(n):
+                o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+            return o.leaves()
+        finally:
+            O.set_modes(0, 0)
+
+    report = {}
+    for n in (1, 15):
+        base = run(0, 0, n)
+        for tag, (trig, sort) in {"trig": (1, 0), "sort": (0, 1), "both": (1, 1)}.items():
+            alt = run(trig, sort, n)
+            if alt["block_key"].size != base["block_key"].size or (alt["node_key"] != base["node_key"]).any():
+                # pruning diverged (a state flipped): compare the leaves both maps have
+                ka = {(int(b), int(k)): i for i, (b, k) in enumerate(zip(alt["block_key"], alt["node_key"]))}
+                idx = [(j, ka[(int(b), int(k))]) for j, (b, k) in enumerate(zip(base["block_key"], base["node_key"])) if (int(b), int(k)) in ka]
+                jb, ja = np.array([i for i, _ in idx]), np.array([i for _, i in idx])
+            else:
+                jb = ja = np.arange(base["A"].size)
+            pb = base["A"][jb].astype(np.float64) / (base["A"][jb].astype(np.float64) + base["B"][jb])
+            pa = alt["A"][ja].astype(np.float64) / (alt["A"][ja].astype(np.float64) + alt["B"][ja])
+            d = np.abs(pa - pb)
+            report[(n, tag)] = (float(d.max()), int((alt["state"][ja] != base["state"][jb]).sum()),
+                                int(base["A"].size - jb.size), float((d > 1e-5).mean()))
+    print("max |dp|, state flips, unmatched leaves, fraction of leaves beyond 1e-5:", report)
+    # measured here (sim_structured scan 1, 43 100 leaves): 1 scan: trig 6.9e-6, sort 1.9e-5, both 2.0e-5;
+    # 15 fused scans: trig 4.9e-5, sort 2.5e-4, both 2.5e-4; no state flips, identical leaf sets; 0.12 % (1 scan) to 0.9 % (15 scans) of the leaves move by more than 1e-5
+    assert report[(1, "trig")][0] <= 1e-5                                   # the packet trig alone stays inside the north star's 1e-5
+    for tag in ("sort", "both"):
+        assert 1e-5 < report[(1, tag)][0] <= 5e-5, (tag, report[(1, tag)])  # PCL's cell order alone already exceeds it (rim voxels)
+    for tag in ("trig", "sort", "both"):
+        assert report[(15, tag)][0] <= 2e-3, (tag, report[(15, tag)])       # 15 fused scans: measured, documented, NOT <= 1e-5
+        for n in (1, 15):
+            assert report[(n, tag)][1] == 0 and report[(n, tag)][2] == 0     # ... yet no state and no leaf structure changes
+            assert report[(n, tag)][3] < 0.02
