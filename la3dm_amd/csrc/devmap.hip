@@ -61,6 +61,8 @@ struct la3dm_devmap {
     Arena shard_w, shard_cumw, shard_bounds, shard_payload;
     uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
     uint32_t n_xy = 0;
+    bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
+    uint32_t mailbox_seq = 0;
     bool poisoned = false;  // a failed insert whose block table could not be reconciled with the host's block count
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
     la3dm_devmap_stats stats;
@@ -113,8 +115,24 @@ static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, u
 
 static int read_counters(la3dm_devmap *dm) {
     hipStream_t st = dm->ctx->stream;
-    DM_TRY(hipMemcpyAsync(dm->h_cnt, dm->d_cnt, sizeof(uint32_t) * kCntWords, hipMemcpyDeviceToHost, st));
-    DM_TRY(hipStreamSynchronize(st));
+    if (!dm->mailbox) {
+        DM_TRY(hipMemcpyAsync(dm->h_cnt, dm->d_cnt, sizeof(uint32_t) * kCntWords, hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));
+        return LA3DM_OK;
+    }
+    const uint32_t seq = ++dm->mailbox_seq;
+    hipLaunchKernelGGL(dm_publish_counters, dim3(1), dim3(64), 0, st, (const uint32_t *)dm->d_cnt, (volatile uint32_t *)dm->h_cnt, seq);
+    DM_TRY(hipGetLastError());
+    volatile uint32_t *flag = dm->h_cnt + kCntWords;
+    const double t0 = wall();
+    for (uint32_t spin = 0; *flag != seq; ++spin) {
+        if ((spin & 0x3FFu) == 0x3FFu && wall() - t0 > 2.0) {  // something is wrong (a fault upstream): let HIP report it
+            DM_TRY(hipStreamSynchronize(st));
+            if (*flag != seq) return dm_fail(dm, LA3DM_ERR_HIP, "devmap: the counter mailbox was not written");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
     return LA3DM_OK;
 }
 
@@ -288,8 +306,12 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     }
     memset(&dm->stats, 0, sizeof(dm->stats));
     dm->stage_timing = getenv("LA3DM_TIMING") != nullptr;
+    {
+        const char *mb = getenv("LA3DM_MAILBOX");
+        dm->mailbox = !(mb && mb[0] == '0');
+    }
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
-              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
+              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2)) == hipSuccess &&
               hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 8) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
@@ -338,6 +360,10 @@ static int training_bbox(la3dm_devmap *dm) {
     hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)dm->xy.ptr, npts,
                        dm->d_mm);
     hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox, (const float *)dm->xy.ptr);
+    if (dm->mailbox) {  // the decoded box goes to the host with the counter block: one pinned-memory mailbox, no stream sync
+        DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
+        return read_counters(dm);
+    }
     DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
     DM_TRY(hipStreamSynchronize(st));
     return LA3DM_OK;

@@ -687,6 +687,21 @@ __global__ __launch_bounds__(256) void dm_l_test_stats(const int32_t *__restrict
     }
 }
 
+// read_counters without a stream synchronisation: the counter block goes straight to pinned host memory, followed by a
+// sequence number the host spins on (a D2H copy + hipStreamSynchronize costs ~20 us of driver latency per read-back,
+// seven times per scan; this is a few us).  The kernel runs after everything queued before it on the stream, so the host
+// seeing the sequence number is as good as a synchronisation for that work.
+__global__ void dm_publish_counters(const uint32_t *__restrict__ counters, volatile uint32_t *mailbox, uint32_t seq) {
+    const uint32_t i = threadIdx.x;
+    if (i < (uint32_t)kCntWords) mailbox[i] = counters[i];
+    __threadfence_system();
+    __syncthreads();
+    if (i == 0) {
+        mailbox[kCntWords] = seq;
+        __threadfence_system();
+    }
+}
+
 // total = off[n-1] + cnt[n-1] of an exclusive scan
 __global__ void dm_scan_total(const uint32_t *off, const uint32_t *cnt, uint32_t n, uint32_t *counters, int slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -7,4 +7,4 @@ xyz, origin = la3dm_amd.synthetic_scan(n)
 m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0).set_device_resident(True)
 for rep in range(reps):
     t0 = time.time(); m.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0); t1 = time.time()
-    print("insert %.4f" % (t1 - t0), flush=True)
+    print("insert %.6f" % (t1 - t0), flush=True)
