@@ -313,3 +313,50 @@ def test_two_live_maps_with_different_parameters_keep_their_own(built):
     assert a.packed().n_leaf == na
     ca, cb = a.hash_key_to_block(ka), b.hash_key_to_block(kb)
     assert abs(ca[2] - 7.6) < 1e-5 and abs(cb[2] - 8.0) < 1e-5
+
+
+def test_pcl_overload_compiles_and_runs_with_a_pcl_shaped_cloud(built, tmp_path):
+    """the PCL overload of insert_pointcloud (host/bgkoctomap.h, LA3DM_WITH_PCL — what the reference's nodes
+    call, include/bgkoctomap/bgkoctomap.h:82-84) was never compiled because PCL is not in the image.  A mock with
+    pcl::PointCloud<pcl::PointXYZ>'s shape (16-byte points in `.points`, size(), empty()) instantiates it here and drives
+    it through a bookkeeping-only map: the call must reach the map's own entry point with stride 4 (and fail there, for
+    lack of a device, with the library's message rather than anything about the cloud)."""
+    import subprocess
+    from conftest import ROOT
+    src = tmp_path / "pcl_mock.cpp"
+    src.write_text(r'''
+#define LA3DM_WITH_PCL 1
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+#include "la3dm_amd/csrc/host/bgkoctomap.h"
+namespace pcl {
+struct alignas(16) PointXYZ { float x, y, z, pad; };
+template <class P> struct PointCloud {
+    std::vector<P> points;
+    size_t size() const { return points.size(); }
+    bool empty() const { return points.empty(); }
+};
+}
+int main() {
+    static_assert(sizeof(pcl::PointXYZ) == 16, "PCL's PointXYZ is 16 bytes");
+    pcl::PointCloud<pcl::PointXYZ> cloud;
+    for (int i = 0; i < 100; ++i) cloud.points.push_back({1.0f + 0.01f * i, 0.5f, 0.25f, 0.0f});
+    la3dm::BGKOctoMap map(0.1f, 3, 1.0f, 0.2f, 0.3f, 0.7f, 100.0f, 0.001f, 0.001f, /*device=*/-1);
+    try {
+        map.insert_pointcloud(cloud, la3dm::point3f(0, 0, 0), 0.1f, 0.5f, -1.0f);
+    } catch (const std::exception &e) {
+        std::printf("threw: %s\n", e.what());
+        return std::strstr(e.what(), "no device context") ? 0 : 2;
+    }
+    return 3;
+}
+''')
+    exe = tmp_path / "pcl_mock"
+    csrc = os.path.join(ROOT, "la3dm_amd", "csrc")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", ROOT, str(src), "-o", str(exe), "-L", csrc, "-lla3dm_map", "-lla3dm_hip",
+                        f"-Wl,-rpath,{csrc}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
