@@ -436,7 +436,9 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
             const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
             const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
             const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
-            keep = (ex * ex + ey * ey + ez * ez) < 1.00001f;
+            // the distance to the box of the leaf centres bounds every leaf's distance from below: at or beyond the hit
+            // threshold (plus slack for the different rounding of this sum) no leaf can hit
+            keep = (ex * ex + ey * ey + ez * ez) < 0.96780f;
         }
         const unsigned long long m = __ballot(keep);
         if (b != last_nb && m != 0ull) {
@@ -527,9 +529,19 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
                 }
 #endif
             };
+            // one counter and one data-dependent exit per trip (the ring's head room) keep the scalar loop control short
             const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRing5 - 4 * kWave);
-            for (; g < ngroup && tailb <= tail_cap && g - g0 < 8u; ++g) b_trip(hA);
-            for (; g < ngroup && tailb <= tail_cap; ++g) b_trip(hB);
+            for (uint32_t left = min(ngroup - g, 8u); left != 0u; --left) {
+                b_trip(hA);
+                ++g;
+                if (tailb > tail_cap) break;
+            }
+            if (g - g0 == 8u && tailb <= tail_cap)
+                for (uint32_t left = ngroup - g; left != 0u; --left) {
+                    b_trip(hB);
+                    ++g;
+                    if (tailb > tail_cap) break;
+                }
             const uint32_t nstep = 4 * (g - g0);
             const uint32_t tail = (tailb - ring_base) >> 3;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -553,11 +565,10 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
             // holds nlast bits at its bottom
             const uint32_t nlast = nstep > 32u ? nstep - 32u : nstep;
             const uint32_t hlast = nlast ? (nstep > 32u ? hB : hA) << (32u - nlast) : 0u;
-            uint32_t hc = nstep > 32u ? hA : hlast;
-            for (uint32_t s2 = 0; s2 < ((a.flags & 0x400u) ? 0u : nstep); s2 += 4) {  // 0x400: profiling ablation
-                if (s2 == 32u) hc = hlast;
-                const uint32_t sb = (uint32_t)starts & 0xFu;
-                starts >>= 4;
+            auto d_trips = [&](uint32_t hc, uint32_t ntrip) {
+                for (; ntrip != 0u; --ntrip) {
+                    const uint32_t sb = (uint32_t)starts & 0xFu;
+                    starts >>= 4;
                 {
                     // gather (assembly): the four entries land in fixed register pairs, all four reads are back at the end
 #if LA3DM_ASM_D
@@ -608,6 +619,11 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
                     ybar += e3y;
                     kbar += e3k;
                 }
+                }
+            };
+            if (!(a.flags & 0x400u)) {  // 0x400: profiling ablation
+                if (nstep > 32u) d_trips(hA, 8u);
+                d_trips(hlast, nlast >> 2);
             }
             __builtin_amdgcn_wave_barrier();
         }
