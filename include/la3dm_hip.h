@@ -235,9 +235,9 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
  *   E   la3dm_bgk_scan_device / la3dm_gp_scan_device / la3dm_bgkl_scan_device (above)
  *   f3  leaf enumeration (bgkoctree.h:62-147), node write-back, OcTree::prune (bgkoctree.cpp:101-148)
  * Only the cloud goes in; the host reads nodes back on demand (la3dm_devmap_download).  Results are
- * bit-identical to the host-orchestrated path.  Works for variant 0 (BGK), 1 (GP) and 3 (BGK-L: the front end of
- * src/bgkloctomap/bgkloctomap.cpp:300-381 and the training rows of :141-170 take the place of f1 / the gather)
- * contexts. */
+ * bit-identical to the host-orchestrated path.  Works for variant 0 (BGK), 1 (GP), 3 (BGK-L: the front end of
+ * src/bgkloctomap/bgkloctomap.cpp:300-381 and the training rows of :141-170 take the place of f1 / the gather) and 2
+ * (BGK-LV, see la3dm_devmap_lv_stats below) contexts. */
 typedef struct la3dm_devmap la3dm_devmap;
 
 typedef struct la3dm_devmap_stats {
@@ -273,6 +273,32 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
  * {x, y, z, label} (host pointer) take the place of the front end's output; every leaf of every test block is updated
  * for every neighbour model (LA3DM_SCAN_UPDATE_UNGATED), then the test blocks are pruned. */
 int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats);
+/* BGKLVOctoMap (variant 2) on the device-resident pool: la3dm_devmap_insert_pointcloud_{host,device} run
+ * BGKLVOctoMap::insert_pointcloud (src/bgklvoctomap/bgklvoctomap.cpp:89-285) start to finish on the GPU — voxel filter of
+ * the hits, ray shortening and the downward-ray filter (:303-423), free segments and their samples (:439-462), the
+ * candidate blocks of the bounding box (all created, :105-135), the gather grid that stands in for the R-tree, the
+ * per-voxel kernel in place on the pool (once per repeat of a candidate key), prune of the blocks that had information
+ * (:262-273, only with original_size).  The pool stores the host enum of the states (PRUNED 3, UNCERTAIN 4), so
+ * la3dm_devmap_download / _search_host / _key_bounds serve this variant unchanged. */
+typedef struct la3dm_devmap_lv_stats {
+    uint64_t n_hits;           /* hit samples */
+    uint64_t n_rays;           /* free segments */
+    uint64_t n_samples;        /* hit + segment samples */
+    uint64_t n_bbox_blocks;    /* entries of the candidate list */
+    uint64_t n_packed_blocks;  /* blocks with a sample within reach */
+    uint64_t voxels;           /* base-resolution voxels of the packed blocks */
+    uint64_t voxel_updates;    /* Occupancy::update calls (all passes) */
+    uint64_t n_info_blocks;    /* blocks that had information (pruned afterwards) */
+    uint64_t n_blocks;         /* blocks in the pool after the scan */
+    double t_frontend, t_total; /* seconds; t_frontend = everything before the first voxel kernel */
+} la3dm_devmap_lv_stats;
+int la3dm_devmap_lv_stats_get(la3dm_devmap *dm, la3dm_devmap_lv_stats *out);
+/* BGKLVOctoMap's constructor argument original_size (prune after the scan): default 1 */
+int la3dm_devmap_lv_set_original_size(la3dm_devmap *dm, int original_size);
+/* samples {x, y, z, ray (-1 = hit)} and segments {start xyz, end xyz} of the last scan (host buffers; NULL = counts only) */
+int la3dm_devmap_lv_training(la3dm_devmap *dm, float *samples4, uint32_t cap_samples, float *rays6, uint32_t cap_rays,
+                             uint32_t *n_samples, uint32_t *n_rays);
+
 /* Block-sharded insert across the GPUs of a node (BASELINE.json configs[4]; the loop that is sharded is the test-block
  * loop of src/bgkoctomap/bgkoctomap.cpp:293-336).  Every rank holds a full replica of the map and is handed the SAME
  * cloud; front end and partition run redundantly (cheaper than a broadcast), the test-block list is cut into `world`

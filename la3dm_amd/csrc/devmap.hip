@@ -16,6 +16,7 @@
 
 #include "la3dm_ctx.h"
 #include "devmap_kernels.h"
+#include "devmap_lv_kernels.h"
 
 using namespace la3dm_dev;
 
@@ -54,6 +55,13 @@ struct la3dm_devmap {
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
     Arena l_ray_idx, l_rays, l_rows, l_rows_off, l_rflag, l_rscan;  // BGKLOctoMap: beam of every sample, beam segments, training rows
+    // BGKLVOctoMap (variant 2): beams, samples, segments, gather grid, packed blocks
+    Arena lv_rng, lv_flags, lv_seg, lv_nsamp, lv_nray, lv_samp_off, lv_ray_off, lv_samples, lv_rays, lv_sorted, lv_cell_off;
+    Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
+    int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
+    uint32_t lv_n_samples = 0, lv_n_rays = 0;
+    bool lv_original_size = true;
+    la3dm_devmap_lv_stats lv_stats;
     // block-sharded insert (la3dm_devmap_set_shard)
     uint32_t shard_rank = 0, shard_world = 1;
     la3dm_allgather_fn shard_fn = nullptr;
@@ -282,8 +290,8 @@ extern "C" {
 int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     if (!ctx || !out) return LA3DM_ERR_ARG;
     *out = nullptr;
-    if (ctx->p.variant != 0 && ctx->p.variant != 1 && ctx->p.variant != 3) {
-        ctx->err = "la3dm_devmap_create: the device-resident map supports variant 0 (BGK), 1 (GP) and 3 (BGK-L)";
+    if (ctx->p.variant < 0 || ctx->p.variant > 3) {
+        ctx->err = "la3dm_devmap_create: the device-resident map supports variant 0 (BGK), 1 (GP), 2 (BGK-LV) and 3 (BGK-L)";
         return LA3DM_ERR_ARG;
     }
     if (ctx->p.block_depth > 5) {  // dm_prune stages 3 bytes per node of a block in LDS
@@ -317,7 +325,8 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
               hipMalloc((void **)&dm->d_gp, sizeof(GridParams)) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_gp, sizeof(GridParams)) == hipSuccess &&
-              hipMemset(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords) == hipSuccess;
+              hipMemset(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords) == hipSuccess &&
+              (ctx->p.variant != 2 || (hipMalloc((void **)&dm->d_lvmm, 32) == hipSuccess && hipHostMalloc((void **)&dm->h_lvmm, 32) == hipSuccess));
     if (!ok) {
         ctx->err = "la3dm_devmap_create: allocation failed";
         la3dm_devmap_destroy(dm);
@@ -338,10 +347,15 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node,
                     &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan,
-                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds, &dm->shard_payload};
+                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds, &dm->shard_payload,
+                    &dm->lv_rng, &dm->lv_flags, &dm->lv_seg, &dm->lv_nsamp, &dm->lv_nray, &dm->lv_samp_off, &dm->lv_ray_off, &dm->lv_samples,
+                    &dm->lv_rays, &dm->lv_sorted, &dm->lv_cell_off, &dm->lv_axis, &dm->lv_keys, &dm->lv_mult, &dm->lv_flag, &dm->lv_pos,
+                    &dm->lv_slot, &dm->lv_center, &dm->lv_cell0, &dm->lv_pslot, &dm->lv_pmult, &dm->lv_info, &dm->lv_prune};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
     if (dm->h_shard) (void)hipHostFree(dm->h_shard);
+    if (dm->d_lvmm) (void)hipFree(dm->d_lvmm);
+    if (dm->h_lvmm) (void)hipHostFree(dm->h_lvmm);
     void *dev[] = {dm->A, dm->B, dm->S, dm->blk_key, dm->tab_key, dm->tab_val, dm->d_cnt, dm->d_mm, dm->d_bbox, dm->d_gp};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -896,6 +910,248 @@ int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, 
     return scan_training_set(dm, LA3DM_SCAN_UPDATE_UNGATED, t0, stats_out);
 }
 
+// ---- BGKLVOctoMap::insert_pointcloud on the pool (src/bgklvoctomap/bgklvoctomap.cpp:89-285; kernels and the map of
+// the stages in devmap_lv_kernels.h).  The pool stores the host's State enum (PRUNED 3, UNCERTAIN 4), so download,
+// search and prune are the BGK ones.  Read-backs: hit-grid cell count, beam totals, sample bbox, bucket bounds,
+// packed-block count, counters at the end.
+static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3], float ds_resolution,
+                     float free_resolution, float max_range, double t0) {
+    la3dm_ctx *ctx = dm->ctx;
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_lv_stats &L = dm->lv_stats;
+    memset(&L, 0, sizeof(L));
+    dm->lv_n_samples = dm->lv_n_rays = 0;
+    int rc;
+    if (ds_resolution > ctx->p.resolution) ds_resolution = ctx->p.resolution;  // bgklvoctomap.cpp:95-96
+    // hits: voxel-grid filter (or the cloud itself)
+    const float *d_hits = d_xyz;
+    uint32_t nh = n;
+    if (!(ds_resolution < 0)) {
+        if ((rc = voxel_grid(dm, d_xyz, n, ds_resolution, dm->hits, &nh)) != LA3DM_OK) return rc;
+        d_hits = (const float *)dm->hits.ptr;
+    }
+    if (nh == 0) return LA3DM_OK;
+    LvBeamArgs ba;
+    ba.ox = origin[0]; ba.oy = origin[1]; ba.oz = origin[2];
+    ba.max_range = max_range;
+    ba.free_res = free_resolution;
+    ba.offset = (double)ctx->p.ell * pow(2, 0.5);
+    ba.influence = (double)ctx->p.ell;
+    DM_RESERVE(dm->lv_rng, 8ull * nh);
+    DM_RESERVE(dm->lv_flags, nh);
+    DM_RESERVE(dm->lv_seg, 24ull * nh);
+    DM_RESERVE(dm->lv_nsamp, 4ull * nh);
+    DM_RESERVE(dm->lv_nray, 4ull * nh);
+    DM_RESERVE(dm->lv_samp_off, 4ull * nh);
+    DM_RESERVE(dm->lv_ray_off, 4ull * nh);
+    uint32_t *nsamp = (uint32_t *)dm->lv_nsamp.ptr, *nray = (uint32_t *)dm->lv_nray.ptr;
+    uint32_t *samp_off = (uint32_t *)dm->lv_samp_off.ptr, *ray_off = (uint32_t *)dm->lv_ray_off.ptr;
+    hipLaunchKernelGGL(dm_lv_ranges, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (double *)dm->lv_rng.ptr);
+    hipLaunchKernelGGL(dm_lv_beams, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+                       (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
+    if ((rc = exclusive_scan(dm, nsamp, samp_off, nh)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, nray, ray_off, nh)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, samp_off, nsamp, nh, dm->d_cnt, (int)kCntFreeRaw);
+    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, ray_off, nray, nh, dm->d_cnt, (int)kCntKept);
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
+    const uint32_t ns = dm->h_cnt[kCntFreeRaw], n_rays = dm->h_cnt[kCntKept];
+    L.n_rays = n_rays;
+    L.n_samples = ns;
+    if (ns == 0) return LA3DM_OK;
+    DM_RESERVE(dm->lv_samples, 16ull * ns);
+    DM_RESERVE(dm->lv_rays, 32ull * (n_rays ? n_rays : 1));
+    float4 *samples = (float4 *)dm->lv_samples.ptr;
+    hipLaunchKernelGGL(dm_lv_emit, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (const uint8_t *)dm->lv_flags.ptr,
+                       (const float *)dm->lv_seg.ptr, (const uint32_t *)samp_off, (const uint32_t *)ray_off, samples,
+                       (float4 *)dm->lv_rays.ptr);
+    dm->lv_n_samples = ns;
+    dm->lv_n_rays = n_rays;
+    L.n_hits = dm->h_cnt[kCntTrained];
+    // bounding box of ALL samples (std::min / std::max chains from samples[0]: bgklvoctomap.cpp:105-112)
+    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(ns, 1024), 512)), dim3(256), 0, st, (const float *)samples, ns, dm->d_mm);
+    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox, (const float *)samples);
+    // bucket bounds of the finite samples
+    const int depth = ctx->p.block_depth;
+    const float bs = dm->block_size;
+    const double g = depth >= 3 ? 4.0 * (double)ctx->p.resolution : (double)bs;
+    const double half = 0.5 * (double)bs;
+    {
+        const int32_t init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
+        DM_TRY(hipMemcpyAsync(dm->d_lvmm, init, 32, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(dm_lv_cell_bounds, dim3(cdiv(ns, 256)), dim3(256), 0, st, (const float4 *)samples, ns, half, g, dm->d_lvmm, dm->d_cnt);
+    DM_TRY(hipMemcpyAsync(dm->h_lvmm, dm->d_lvmm, 32, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    if (dm->h_cnt[kCntError] & kErrLvExtent) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): sample coordinates beyond the gather grid's index range");
+    for (int a = 0; a < 6; ++a)
+        if (dm->h_bbox[a] != dm->h_bbox[a]) return LA3DM_OK;  // NaN box (first sample not finite): no candidate block, as on the host
+    const uint32_t n_binned = (uint32_t)dm->h_lvmm[6];
+    if (n_binned == 0) return LA3DM_OK;
+    LvGridArgs ga;
+    ga.g = g;
+    ga.half = half;
+    size_t ncell = 1;
+    for (int a = 0; a < 3; ++a) {
+        ga.cmin[a] = dm->h_lvmm[a];
+        ga.cdim[a] = dm->h_lvmm[3 + a] - dm->h_lvmm[a] + 1;
+        ncell *= (size_t)ga.cdim[a];
+    }
+    if (ncell > ((size_t)1 << 28)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): scan extent too large for the dense gather grid");
+    // candidate blocks: per-axis float-stepped sequences (host, a few dozen values), distinct indices + multiplicities
+    std::vector<int32_t> ax_idx[3];
+    std::vector<uint32_t> ax_mult[3];
+    uint32_t max_mult = 1;
+    size_t n_cand = 1, n_bbox = 1;
+    for (int a = 0; a < 3; ++a) {
+        std::vector<int> seq = axis_sequence(dm->h_bbox[a], dm->h_bbox[3 + a], bs);
+        if (seq.empty() || seq.size() > (1u << 20)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: degenerate training-set extent");
+        n_bbox *= seq.size();
+        std::sort(seq.begin(), seq.end());
+        uint32_t mm = 1;
+        for (size_t i = 0; i < seq.size();) {
+            size_t j = i;
+            while (j < seq.size() && seq[j] == seq[i]) ++j;
+            ax_idx[a].push_back(seq[i]);
+            ax_mult[a].push_back((uint32_t)(j - i));
+            mm = std::max(mm, (uint32_t)(j - i));
+            i = j;
+        }
+        max_mult *= mm;
+        n_cand *= ax_idx[a].size();
+    }
+    if (n_cand > (1u << 26)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): more than 2^26 candidate blocks (set max_range)");
+    L.n_bbox_blocks = n_bbox;
+    // gather grid: stable sort of the samples by bucket, CSR over the dense grid
+    DM_RESERVE(dm->k0, 4ull * ns);
+    DM_RESERVE(dm->k1, 4ull * ns);
+    DM_RESERVE(dm->v0, 4ull * ns);
+    DM_RESERVE(dm->v1, 4ull * ns);
+    DM_RESERVE(dm->lv_sorted, 16ull * ns);
+    DM_RESERVE(dm->lv_cell_off, 4ull * (ncell + 1));
+    uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
+    hipLaunchKernelGGL(dm_lv_cell_keys, dim3(cdiv(ns, 256)), dim3(256), 0, st, (const float4 *)samples, ns, ga, (uint32_t)ncell, k0, v0);
+    int key_bits = 1;
+    while (((size_t)1 << key_bits) <= ncell) ++key_bits;
+    if ((rc = sort_pairs(dm, k0, k1, v0, v1, ns, key_bits)) != LA3DM_OK) return rc;
+    hipLaunchKernelGGL(dm_lv_sorted, dim3(cdiv(ns, 256)), dim3(256), 0, st, (const float4 *)samples, (const uint32_t *)v1, ns, (float4 *)dm->lv_sorted.ptr);
+    hipLaunchKernelGGL(dm_lv_cell_off, dim3(cdiv((uint32_t)ncell + 1, 256)), dim3(256), 0, st, (const uint32_t *)k1, ns, (uint32_t)ncell,
+                       (uint32_t *)dm->lv_cell_off.ptr);
+    // candidates: keys (ascending), multiplicities, "has a sample within reach"; every candidate block is created
+    {
+        size_t bytes = 0;
+        for (int a = 0; a < 3; ++a) bytes += 8 * ax_idx[a].size();
+        DM_RESERVE(dm->lv_axis, bytes);
+    }
+    LvCandArgs ca;
+    {
+        uint8_t *base = (uint8_t *)dm->lv_axis.ptr;
+        size_t o = 0;
+        for (int a = 0; a < 3; ++a) {
+            const size_t m = ax_idx[a].size();
+            DM_TRY(hipMemcpyAsync(base + o, ax_idx[a].data(), 4 * m, hipMemcpyHostToDevice, st));
+            ca.idx[a] = (const int32_t *)(base + o);
+            o += 4 * m;
+            DM_TRY(hipMemcpyAsync(base + o, ax_mult[a].data(), 4 * m, hipMemcpyHostToDevice, st));
+            ca.mult[a] = (const uint32_t *)(base + o);
+            o += 4 * m;
+            ca.n[a] = (uint32_t)m;
+            ca.cmin[a] = ga.cmin[a];
+            ca.cdim[a] = ga.cdim[a];
+        }
+        DM_TRY(hipStreamSynchronize(st));  // the host vectors go out of use only after the copies
+    }
+    ca.block_size = bs;
+    ca.g = g;
+    ca.reach = (int32_t)std::ceil((double)ctx->p.ell / g);
+    ca.bpb = depth >= 3 ? (1 << (depth - 3)) : 1;
+    const uint32_t nc = (uint32_t)n_cand;
+    DM_RESERVE(dm->lv_keys, 8ull * nc);
+    DM_RESERVE(dm->lv_mult, 4ull * nc);
+    DM_RESERVE(dm->lv_flag, 4ull * nc);
+    DM_RESERVE(dm->lv_pos, 4ull * nc);
+    DM_RESERVE(dm->lv_slot, 4ull * nc);
+    hipLaunchKernelGGL(dm_lv_candidates, dim3(cdiv(nc, 256)), dim3(256), 0, st, ca, nc, (const uint32_t *)dm->lv_cell_off.ptr,
+                       (long long *)dm->lv_keys.ptr, (uint32_t *)dm->lv_mult.ptr, (uint32_t *)dm->lv_flag.ptr);
+    if ((rc = grow_pool(dm, (size_t)dm->n_blocks + nc)) != LA3DM_OK) return rc;
+    if ((rc = grow_table(dm, (size_t)dm->n_blocks + nc)) != LA3DM_OK) return rc;
+    {
+        const uint32_t two[2] = {nc, dm->n_blocks};
+        DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntTest, &two[0], 4, hipMemcpyHostToDevice, st));
+        DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntBlocks, &two[1], 4, hipMemcpyHostToDevice, st));
+        DM_TRY(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(nc, 256)), dim3(256), 0, st, (const long long *)dm->lv_keys.ptr, dm->d_cnt, dm->tab_key,
+                       dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key, (uint32_t *)dm->lv_slot.ptr);
+    hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)nc * dm->npb, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S, dm->n_blocks,
+                       (const uint32_t *)(dm->d_cnt + kCntBlocks), dm->npb, dm->init_A, dm->init_B);
+    if ((rc = exclusive_scan(dm, (const uint32_t *)dm->lv_flag.ptr, (uint32_t *)dm->lv_pos.ptr, nc)) != LA3DM_OK) return rc;
+    DM_RESERVE(dm->lv_center, 12ull * nc);
+    DM_RESERVE(dm->lv_cell0, 12ull * nc);
+    DM_RESERVE(dm->lv_pslot, 4ull * nc);
+    DM_RESERVE(dm->lv_pmult, 4ull * nc);
+    DM_RESERVE(dm->lv_info, 4ull * nc);
+    DM_RESERVE(dm->lv_prune, 4ull * nc);
+    DM_TRY(hipMemsetAsync(dm->lv_info.ptr, 0, 4ull * nc, st));
+    hipLaunchKernelGGL(dm_lv_pack, dim3(cdiv(nc, 256)), dim3(256), 0, st, (const long long *)dm->lv_keys.ptr, (const uint32_t *)dm->lv_mult.ptr,
+                       (const uint32_t *)dm->lv_flag.ptr, (const uint32_t *)dm->lv_pos.ptr, (const uint32_t *)dm->lv_slot.ptr, nc, bs, g,
+                       (float *)dm->lv_center.ptr, (int32_t *)dm->lv_cell0.ptr, (uint32_t *)dm->lv_pslot.ptr, (uint32_t *)dm->lv_pmult.ptr,
+                       dm->d_cnt);
+    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntLeaves, 0, 4, st));  // counts the voxel updates of all passes
+    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGeo, 0, 4, st));     // counts the blocks with information
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    dm->n_blocks = dm->h_cnt[kCntBlocks];
+    const uint32_t n_packed = dm->h_cnt[kCntTest];
+    L.n_packed_blocks = n_packed;
+    L.voxels = (uint64_t)n_packed << (3 * (depth - 1));
+    const double t1 = wall();
+    if (n_packed) {
+        la3dm_lv_pool_scan ps;
+        memset(&ps, 0, sizeof(ps));
+        ps.samples = (const float *)samples;
+        ps.sorted = (const float *)dm->lv_sorted.ptr;
+        ps.rays = (const float *)dm->lv_rays.ptr;
+        ps.cell_off = (const uint32_t *)dm->lv_cell_off.ptr;
+        for (int a = 0; a < 3; ++a) {
+            ps.cell_min[a] = ga.cmin[a];
+            ps.cell_dim[a] = ga.cdim[a];
+        }
+        ps.n_blk = n_packed;
+        ps.blk_center = (const float *)dm->lv_center.ptr;
+        ps.blk_cell0 = (const int32_t *)dm->lv_cell0.ptr;
+        ps.blk_slot = (const uint32_t *)dm->lv_pslot.ptr;
+        ps.blk_mult = (const uint32_t *)dm->lv_pmult.ptr;
+        ps.A = dm->A;
+        ps.B = dm->B;
+        ps.S = dm->S;
+        ps.npb = dm->npb;
+        ps.upd_counter = dm->d_cnt + kCntLeaves;
+        const uint32_t layer_n = 1u << (3 * (depth - 1)), layer_off = dm->npb - layer_n;
+        for (uint32_t pass = 0; pass < max_mult; ++pass) {  // a key the float-stepped loop repeats is visited again, serially
+            ps.pass = pass;
+            if ((rc = la3dm_bgklv_pool_scan_device(ctx, &ps, st)) != LA3DM_OK) return rc;
+            hipLaunchKernelGGL(dm_lv_finish, dim3(cdiv(n_packed, 4)), dim3(256), 0, st, (const uint32_t *)dm->lv_pslot.ptr,
+                               (const uint32_t *)dm->lv_pmult.ptr, n_packed, pass, dm->S, dm->npb, layer_off, layer_n,
+                               (uint32_t *)dm->lv_info.ptr);
+        }
+        hipLaunchKernelGGL(dm_lv_prune_list, dim3(cdiv(n_packed, 256)), dim3(256), 0, st, (const uint32_t *)dm->lv_pslot.ptr,
+                           (const uint32_t *)dm->lv_info.ptr, n_packed, (uint32_t *)dm->lv_prune.ptr, dm->d_cnt);
+        if (dm->lv_original_size)
+            hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_packed, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
+                               (const uint32_t *)dm->lv_prune.ptr, n_packed, dm->A, dm->B, dm->S, dm->npb, dm->depth);
+        DM_TRY(hipGetLastError());
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        L.voxel_updates = dm->h_cnt[kCntLeaves];
+        L.n_info_blocks = dm->h_cnt[kCntGeo];
+    }
+    L.n_blocks = dm->n_blocks;
+    L.t_frontend = t1 - t0;
+    L.t_total = wall() - t0;
+    return LA3DM_OK;
+}
+
 // Argument checks shared by the insert entry points.  The beam sampler walks `for (d = fr; d < l; d += fr)` on the GPU
 // (bgkoctomap.cpp:445-457): a free_resolution that is not a positive finite number would never terminate there (the
 // reference would run out of memory on the host instead), so it is rejected here; so are NaN resolutions / ranges and a
@@ -911,6 +1167,55 @@ static int check_scan_args(la3dm_devmap *dm, const float origin[3], float ds_res
         return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: max_range is NaN");
     for (int i = 0; i < 3; ++i)
         if (!std::isfinite(origin[i])) return dm_fail(dm, LA3DM_ERR_ARG, "insert_pointcloud: the sensor origin is not finite");
+    return LA3DM_OK;
+}
+
+// after a failed BGK-LV insert: the candidate blocks may already be in the table (see scan_training_set)
+static void lv_recover(la3dm_devmap *dm) {
+    const std::string why = dm->ctx->err;
+    uint32_t dev_blocks = 0;
+    if (hipStreamSynchronize(dm->ctx->stream) == hipSuccess &&
+        hipMemcpy(&dev_blocks, dm->d_cnt + kCntBlocks, 4, hipMemcpyDeviceToHost) == hipSuccess && dev_blocks <= dm->cap_blocks) {
+        if (dev_blocks > dm->n_blocks) dm->n_blocks = dev_blocks;
+    } else {
+        dm->poisoned = true;
+    }
+    dm->ctx->err = why;
+}
+
+int la3dm_devmap_lv_stats_get(la3dm_devmap *dm, la3dm_devmap_lv_stats *out) {
+    if (!dm || !out) return LA3DM_ERR_ARG;
+    *out = dm->lv_stats;
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_lv_set_original_size(la3dm_devmap *dm, int original_size) {
+    if (!dm) return LA3DM_ERR_ARG;
+    dm->lv_original_size = original_size != 0;
+    return LA3DM_OK;
+}
+
+int la3dm_devmap_lv_training(la3dm_devmap *dm, float *samples4, uint32_t cap_samples, float *rays6, uint32_t cap_rays,
+                             uint32_t *n_samples, uint32_t *n_rays) {
+    if (!dm) return LA3DM_ERR_ARG;
+    if (n_samples) *n_samples = dm->lv_n_samples;
+    if (n_rays) *n_rays = dm->lv_n_rays;
+    if (!samples4 && !rays6) return LA3DM_OK;
+    if ((samples4 && cap_samples < dm->lv_n_samples) || (rays6 && cap_rays < dm->lv_n_rays)) return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_lv_training: buffer too small");
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    if (samples4 && dm->lv_n_samples)
+        DM_TRY(hipMemcpyAsync(samples4, dm->lv_samples.ptr, 16ull * dm->lv_n_samples, hipMemcpyDeviceToHost, st));
+    std::vector<float> r8;
+    if (rays6 && dm->lv_n_rays) {
+        r8.resize(8ull * dm->lv_n_rays);
+        DM_TRY(hipMemcpyAsync(r8.data(), dm->lv_rays.ptr, 32ull * dm->lv_n_rays, hipMemcpyDeviceToHost, st));
+    }
+    DM_TRY(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < (rays6 ? dm->lv_n_rays : 0u); ++i) {
+        rays6[6 * i] = r8[8 * i]; rays6[6 * i + 1] = r8[8 * i + 1]; rays6[6 * i + 2] = r8[8 * i + 2];
+        rays6[6 * i + 3] = r8[8 * i + 4]; rays6[6 * i + 4] = r8[8 * i + 5]; rays6[6 * i + 5] = r8[8 * i + 6];
+    }
     return LA3DM_OK;
 }
 
@@ -955,6 +1260,13 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     dm->n_xy = 0;
     const double t0 = wall();
     DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+    if (ctx->p.variant == 2) {
+        rc = lv_insert(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range, t0);
+        if (rc != LA3DM_OK) lv_recover(dm);
+        S.n_blocks = dm->n_blocks;
+        if (stats_out) *stats_out = S;
+        return rc;
+    }
 
     if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
     return scan_training_set(dm, 0u, t0, stats_out);

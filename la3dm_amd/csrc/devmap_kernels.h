@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slo
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + wv;
     const int lane = threadIdx.x & 63;
-    if (t >= n_test) return;
+    if (t >= n_test || slot[t] == 0xFFFFFFFFu) return;  // (0xFFFFFFFF: an entry the caller masked out)
     uint8_t *sS = dm_prune_smem + wv * prune_lds_stride(npb);
     uint16_t *src = (uint16_t *)(sS + ((npb + 1u) & ~1u));
     const size_t base = (size_t)slot[t] * npb;

@@ -90,6 +90,7 @@ BGKLVOctoMap::BGKLVOctoMap(float resolution_, unsigned short block_depth_, float
                  }(),
                  device) {
     if (block_depth_ > 6) throw std::runtime_error("BGKLVOctoMap: block_depth > 6 is not supported (16-bit layer index)");
+    if (dmap != nullptr) la3dm_devmap_lv_set_original_size(dmap, original_size ? 1 : 0);
     std::memset(cell_min, 0, sizeof(cell_min));
     std::memset(cell_dim, 0, sizeof(cell_dim));
 }
@@ -213,6 +214,8 @@ void BGKLVOctoMap::training_data_lv(const float *xyz, size_t n, size_t stride, c
 bool BGKLVOctoMap::prepare_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                               float free_res, float max_range) {
     bind();
+    ensure_host_mode();   // the split form is host-orchestrated (one download of the pool)
+    device_training_stale = false;
     lvst = LVStats();
     const double t0 = wall();
     if (ds_resolution > resolution) ds_resolution = resolution;
@@ -392,6 +395,17 @@ bool BGKLVOctoMap::select_pass_lv(uint32_t pass) {
     return !lv_blocks.empty();
 }
 
+void BGKLVOctoMap::fetch_device_training() const {
+    if (!device_training_stale || dmap == nullptr) return;
+    uint32_t ns = 0, nr = 0;
+    la3dm_devmap_lv_training(dmap, nullptr, 0, nullptr, 0, &ns, &nr);
+    samples.assign(4 * (size_t)ns, 0.0f);
+    rays6.assign(6 * (size_t)nr, 0.0f);
+    if (la3dm_devmap_lv_training(dmap, samples.data(), ns, rays6.data(), nr, &ns, &nr) != LA3DM_OK)
+        throw std::runtime_error(std::string("BGKLVOctoMap: ") + la3dm_last_error(ctx));
+    device_training_stale = false;
+}
+
 la3dm_lv_scan BGKLVOctoMap::packed_lv() {
     bind();
     la3dm_lv_scan s;
@@ -461,6 +475,22 @@ void BGKLVOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, 
     bind();
     const double t0 = wall();
     if (ctx == nullptr) throw std::runtime_error("BGKLVOctoMap::insert_pointcloud: no device context (there is no CPU path)");
+    if (dmap != nullptr) {  // device-resident mode: the whole call runs on the GPU (devmap.hip lv_insert)
+        lvst = LVStats();
+        if (n > 0xFFFFFFFFull) throw std::runtime_error("BGKLVOctoMap::insert_pointcloud: more than 2^32 - 1 points");
+        const float o[3] = {origin.x(), origin.y(), origin.z()};
+        const int rc = la3dm_devmap_insert_pointcloud_host(dmap, xyz, (uint32_t)n, (uint32_t)stride, o, ds_resolution, free_res, max_range, nullptr);
+        la3dm_devmap_lv_stats ds;
+        la3dm_devmap_lv_stats_get(dmap, &ds);
+        lvst.n_hits = ds.n_hits; lvst.n_rays = ds.n_rays; lvst.n_samples = ds.n_samples; lvst.n_bbox_blocks = ds.n_bbox_blocks;
+        lvst.n_packed_blocks = ds.n_packed_blocks; lvst.n_info_blocks = ds.n_info_blocks; lvst.voxels = ds.voxels;
+        lvst.voxel_updates = ds.voxel_updates; lvst.t_frontend = ds.t_frontend; lvst.t_total = wall() - t0;
+        lvst.t_device = ds.t_total - ds.t_frontend;
+        mirror_dirty = true;
+        device_training_stale = true;
+        if (rc != LA3DM_OK) throw std::runtime_error(std::string("BGKLVOctoMap::insert_pointcloud: ") + la3dm_last_error(ctx));
+        return;
+    }
     if (!prepare_lv(xyz, n, stride, origin, ds_resolution, free_res, max_range)) return;
     for (uint32_t pass = 0; pass < lv_max_mult; ++pass) {
         if (pass > 0 && !select_pass_lv(pass)) continue;  // repeats of the float-stepped candidate list

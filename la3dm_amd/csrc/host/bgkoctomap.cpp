@@ -481,7 +481,7 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     // start to finish on the GPU (insert_training_data too).  The split prepare()/commit() form moves the map back to
     // the host-orchestrated mode on its own (ensure_host_mode).  LA3DM_DEVICE_RESIDENT=0 keeps the host mode.
     const char *env = getenv("LA3DM_DEVICE_RESIDENT");
-    if ((variant == 0 || variant == 1 || variant == 3) && block_depth <= 5 && !(env && env[0] == '0')) {
+    if (variant >= 0 && variant <= 3 && block_depth <= 5 && !(env && env[0] == '0')) {
         if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK) dmap = nullptr;
     }
 }

@@ -523,8 +523,14 @@ public:
     };
     const LVStats &lv_stats() const { return lvst; }
     /// training samples (x, y, z, ray index or -1) and segments (6 floats) of the last scan
-    const std::vector<float> &lv_samples() const { return samples; }
-    const std::vector<float> &lv_rays() const { return rays6; }
+    const std::vector<float> &lv_samples() const {
+        fetch_device_training();
+        return samples;
+    }
+    const std::vector<float> &lv_rays() const {
+        fetch_device_training();
+        return rays6;
+    }
     /// split form used by the benchmark: prepare_lv packs (returns false if nothing to do), packed_lv exposes the
     /// device-call arguments (host pointers), commit_lv writes the nodes and prunes (the split form runs the first visit
     /// of every block only; insert_pointcloud also runs the repeats of the float-stepped candidate list)
@@ -537,9 +543,12 @@ public:
 private:
     void training_data_lv(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                           float free_resolution, float max_range);
-    std::vector<float> samples;   // x, y, z, ray
+    void fetch_device_training() const;   // device-resident mode: samples / segments of the last scan come from the GPU on demand
+    mutable bool device_training_stale = false;
+    mutable std::vector<float> samples;   // x, y, z, ray
     std::vector<float> sorted;    // x, y, z, original index bits
-    std::vector<float> rays8, rays6;
+    std::vector<float> rays8;
+    mutable std::vector<float> rays6;
     std::vector<uint32_t> cell_off;
     int32_t cell_min[3], cell_dim[3];
     std::vector<float> lv_center, lv_alpha, lv_beta;

@@ -68,3 +68,19 @@ static inline int arena_reserve(la3dm_ctx *ctx, Arena &a, size_t bytes) {
     return LA3DM_OK;
 }
 
+
+// ---- internal (devmap.hip -> la3dm_hip.hip): the BGKLV voxel kernel run in place on the device-resident block pool ----
+struct la3dm_lv_pool_scan {
+    const float *samples, *sorted, *rays;  // as la3dm_lv_scan (device pointers)
+    const uint32_t *cell_off;
+    int32_t cell_min[3], cell_dim[3];
+    uint32_t n_blk;
+    const float *blk_center;
+    const int32_t *blk_cell0;
+    const uint32_t *blk_slot, *blk_mult;   // pool slot and candidate-key multiplicity of every packed block
+    float *A, *B;                          // the pool
+    uint8_t *S;
+    uint32_t npb, pass;
+    uint32_t *upd_counter;                 // += nodes updated
+};
+int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hipStream_t stream);

@@ -22,6 +22,75 @@ using namespace la3dm_dev;
 
 static thread_local std::string g_create_error;
 
+// the part of LvArgs that only depends on the map's parameters and the number of packed blocks
+static void lv_fill_args(la3dm_ctx *ctx, LvArgs &a, uint32_t n_blk) {
+    const int d = ctx->p.block_depth;
+    memset(&a, 0, sizeof(a));
+    a.lut = ctx->d_lut;
+    a.lut_base = 0;
+    for (int k = 0; k + 1 < d; ++k) a.lut_base += 1u << (3 * k);
+    a.nodes_per_blk = 1u << (3 * (d - 1));
+    const uint32_t cubes = (a.nodes_per_blk + kWave - 1) / kWave;  // 8^(d-3) for d >= 3, else 1
+    a.cubes_shift = 0;
+    while ((1u << a.cubes_shift) < cubes) ++a.cubes_shift;
+    a.cubes_bits = a.cubes_shift / 3;
+    a.n_tasks = n_blk << a.cubes_shift;
+    const double g = d >= 3 ? 4.0 * (double)ctx->p.resolution : (double)((float)pow(2, d - 1) * ctx->p.resolution);
+    a.reach = (int)ceil((double)ctx->p.ell / g);
+    a.sf2 = ctx->p.sf2;
+    a.ell = ctx->p.ell;
+    a.free_thresh = ctx->p.free_thresh;
+    a.occupied_thresh = ctx->p.occupied_thresh;
+    a.var_thresh = ctx->p.var_thresh;
+    a.min_W = ctx->p.min_W;
+}
+
+int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hipStream_t stream) {
+    if (!ctx || !s) return LA3DM_ERR_ARG;
+    if (s->n_blk == 0) return LA3DM_OK;
+    if (ctx->p.variant != 2) {
+        ctx->err = "la3dm_bgklv_pool_scan: the context was not created with variant = 2 (BGKLVOctoMap)";
+        return LA3DM_ERR_ARG;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LvArgs a;
+    lv_fill_args(ctx, a, s->n_blk);
+    a.samples = (const float4 *)s->samples;
+    a.sorted = (const float4 *)s->sorted;
+    a.rays = (const float4 *)s->rays;
+    a.cell_off = s->cell_off;
+    a.blk_center = s->blk_center;
+    a.blk_cell0 = s->blk_cell0;
+    a.alpha = s->A;
+    a.beta = s->B;
+    a.state = s->S;
+    for (int i = 0; i < 3; ++i) {
+        a.cell_min[i] = s->cell_min[i];
+        a.cell_dim[i] = s->cell_dim[i];
+    }
+    a.blk_slot = s->blk_slot;
+    a.blk_mult = s->blk_mult;
+    a.upd_counter = s->upd_counter;
+    a.npb = s->npb;
+    a.layer_off = a.lut_base;  // the pool is depth-major like the LUT: the finest layer starts at (8^(d-1) - 1) / 7
+    a.pass = s->pass;
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (ctx->opt_time_kernel) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> p;
+            HIP_TRY(ctx, hipEventCreate(&p.first));
+            HIP_TRY(ctx, hipEventCreate(&p.second));
+            ctx->ev_pool.push_back(p);
+        }
+        ev = &ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
+    }
+    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(a.n_tasks), dim3(kLvWaves * kWave), 0, stream, a);
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return LA3DM_OK;
+}
+
 extern "C" {
 
 int la3dm_device_count(void) {
@@ -468,9 +537,8 @@ int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream
     }
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int d = ctx->p.block_depth;
     LvArgs a;
-    memset(&a, 0, sizeof(a));
+    lv_fill_args(ctx, a, s->n_blk);
     a.samples = (const float4 *)s->samples;
     a.sorted = (const float4 *)s->sorted;
     a.rays = (const float4 *)s->rays;
@@ -480,27 +548,10 @@ int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream
     a.alpha = s->alpha;
     a.beta = s->beta;
     a.state = s->state;
-    a.lut = ctx->d_lut;
     for (int i = 0; i < 3; ++i) {
         a.cell_min[i] = s->cell_min[i];
         a.cell_dim[i] = s->cell_dim[i];
     }
-    a.lut_base = 0;
-    for (int k = 0; k + 1 < d; ++k) a.lut_base += 1u << (3 * k);
-    a.nodes_per_blk = 1u << (3 * (d - 1));
-    const uint32_t cubes = (a.nodes_per_blk + kWave - 1) / kWave;  // 8^(d-3) for d >= 3, else 1
-    a.cubes_shift = 0;
-    while ((1u << a.cubes_shift) < cubes) ++a.cubes_shift;
-    a.cubes_bits = a.cubes_shift / 3;
-    a.n_tasks = s->n_blk << a.cubes_shift;
-    const double g = d >= 3 ? 4.0 * (double)ctx->p.resolution : (double)((float)pow(2, d - 1) * ctx->p.resolution);
-    a.reach = (int)ceil((double)ctx->p.ell / g);
-    a.sf2 = ctx->p.sf2;
-    a.ell = ctx->p.ell;
-    a.free_thresh = ctx->p.free_thresh;
-    a.occupied_thresh = ctx->p.occupied_thresh;
-    a.var_thresh = ctx->p.var_thresh;
-    a.min_W = ctx->p.min_W;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (ctx->opt_time_kernel) {
         if (ctx->ev_used == ctx->ev_pool.size()) {

@@ -43,7 +43,20 @@ struct LvArgs {
     uint32_t n_tasks;
     int32_t reach;           // r = ceil(ell / g)
     float sf2, ell, free_thresh, occupied_thresh, var_thresh, min_W;
+    // pool mode (device-resident map, devmap.hip lv_insert): the node arrays are the block pool itself — block b lives at
+    // blk_slot[b] * npb + layer_off, the state byte carries the HOST enum (PRUNED 3, UNCERTAIN 4) under the classified bit,
+    // a voxel that saw samples gets bit 6 until dm_lv_finish clears it, blocks whose candidate key repeats fewer than
+    // pass + 1 times sit the pass out, and updates are counted into *upd_counter.
+    const uint32_t *blk_slot;   // nullptr = packed mode (the la3dm_lv_scan arrays)
+    const uint32_t *blk_mult;
+    uint32_t *upd_counter;
+    uint32_t npb, layer_off, pass;
 };
+
+// LV state code <-> the host enum stored in the pool (State::PRUNED = 3, State::UNCERTAIN = 4; la3dm_lv_scan uses the
+// reference's numbering UNCERTAIN 3, PRUNED 4: src/bgklvoctomap/bgklvoctree_node.h:11-13)
+__device__ __forceinline__ uint8_t lv_from_pool(uint8_t s) { s &= 7u; return s == 3u ? 4u : (s == 4u ? 3u : s); }
+__device__ __forceinline__ uint8_t lv_to_pool(uint8_t s) { return s == 3u ? 4u : (s == 4u ? 3u : s); }
 
 // point3f::norm(): double sqrt of a float sum, narrowed where the reference stores it in a float matrix
 __device__ __forceinline__ float norm3f(float x, float y, float z) { return (float)sqrt((double)(x * x + y * y + z * z)); }
@@ -114,8 +127,12 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     const uint32_t cube = task & ((1u << a.cubes_shift) - 1u);
     const uint32_t node = cube * kWave + lane;
     const bool in_range = node < a.nodes_per_blk;
-    const size_t ni = (size_t)blk * a.nodes_per_blk + (in_range ? node : 0);
-    const uint8_t st_in = in_range ? a.state[ni] : (uint8_t)4;
+    const bool pool = a.blk_slot != nullptr;
+    if (pool && a.blk_mult[blk] <= a.pass) return;  // (uniform) this block's key repeats fewer times than the pass number
+    const size_t ni = pool ? (size_t)a.blk_slot[blk] * a.npb + a.layer_off + (in_range ? node : 0)
+                           : (size_t)blk * a.nodes_per_blk + (in_range ? node : 0);
+    const uint8_t st_raw = in_range ? a.state[ni] : (uint8_t)4;
+    const uint8_t st_in = !in_range ? (uint8_t)4 : (pool ? lv_from_pool(st_raw) : st_raw);
     const bool active = st_in != 4;
     const float4 off4 = a.lut[a.lut_base + (in_range ? node : 0)];
     const float cx = off4.x + a.blk_center[3 * blk + 0], cy = off4.y + a.blk_center[3 * blk + 1],
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     const float thx = wave_max_dpp(active ? hix : -inf), thy = wave_max_dpp(active ? hiy : -inf), thz = wave_max_dpp(active ? hiz : -inf);
     __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
     if (!(tlx <= thx)) {  // no base-resolution leaf in this cube (uniform over the workgroup)
-        if (wave == 0 && in_range) a.state[ni] = 0;
+        if (wave == 0 && in_range && !pool) a.state[ni] = 0;
         return;
     }
     // bucket of this cube: the octree index interleaves (x, y, z) bits, coarsest first
@@ -237,7 +254,9 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
 #pragma unroll
     for (int v = 1; v < kLvWaves; ++v) info |= L.info[v][lane] != 0u;
     uint8_t out = info ? 0x40u : 0u;
+    bool updated = false;
     if (active && info && kbar > 0.001f) {  // bgklvoctomap.cpp:236-238
+        updated = true;
         float A = a.alpha[ni], B = a.beta[ni];
         A += ybar;
         B += kbar - ybar;
@@ -248,9 +267,16 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
         else st = prob > a.occupied_thresh ? 1 : (prob < a.free_thresh ? 0 : 2);
         a.alpha[ni] = A;
         a.beta[ni] = B;
-        out |= (uint8_t)(0x80u | st);
+        out |= (uint8_t)(0x80u | (pool ? lv_to_pool(st) : st));
     }
-    a.state[ni] = out;
+    if (!pool) {
+        a.state[ni] = out;
+        return;
+    }
+    // pool: an untouched node keeps its byte (state + classified), plus the transient "saw samples" bit
+    a.state[ni] = updated ? out : (uint8_t)(st_raw | (out & 0x40u));
+    const unsigned long long um = __ballot(updated);
+    if (lane == 0 && um) atomicAdd(a.upd_counter, (uint32_t)__popcll(um));
 }
 
 }  // namespace la3dm_dev

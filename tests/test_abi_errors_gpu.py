@@ -65,8 +65,10 @@ def test_device_map_entry_points_reject_bad_arguments(built):
     from la3dm_amd import _lib
     H = _lib.hip()
     dm = C.c_void_p()
-    lv = la3dm_amd.BGKLVOctoMap(**la3dm_amd.LV_YAML, device=0)
-    assert H.la3dm_devmap_create(lv.ctx(), C.byref(dm)) == ERR_ARG and "variant 0" in _err(H, lv.ctx()) and not dm.value
+    lv6 = la3dm_amd.BGKLVOctoMap(**dict(la3dm_amd.LV_YAML, block_depth=6), device=0)       # deeper than the pool supports
+    assert not lv6.is_device_resident()
+    assert H.la3dm_devmap_create(lv6.ctx(), C.byref(dm)) == ERR_ARG and "block_depth" in _err(H, lv6.ctx()) and not dm.value
+    assert la3dm_amd.BGKLVOctoMap(**la3dm_amd.LV_YAML, device=0).is_device_resident()        # BGK-LV lives on the pool too
     deep = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, block_depth=6), device=0)
     assert not deep.is_device_resident()                  # the class falls back to the host-orchestrated mode
     assert H.la3dm_devmap_create(deep.ctx(), C.byref(dm)) == ERR_ARG and "block_depth" in _err(H, deep.ctx())
