@@ -57,6 +57,7 @@ struct la3dm_devmap {
     Arena l_ray_idx, l_rays, l_rows, l_rows_off, l_rflag, l_rscan;  // BGKLOctoMap: beam of every sample, beam segments, training rows
     // BGKLVOctoMap (variant 2): beams, samples, segments, gather grid, packed blocks
     Arena lv_rng, lv_flags, lv_seg, lv_nsamp, lv_nray, lv_samp_off, lv_ray_off, lv_samples, lv_rays, lv_sorted, lv_cell_off;
+    Arena lv_beam, lv_mask;
     Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
     int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
     uint32_t lv_n_samples = 0, lv_n_rays = 0;
@@ -350,7 +351,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds, &dm->shard_payload,
                     &dm->lv_rng, &dm->lv_flags, &dm->lv_seg, &dm->lv_nsamp, &dm->lv_nray, &dm->lv_samp_off, &dm->lv_ray_off, &dm->lv_samples,
                     &dm->lv_rays, &dm->lv_sorted, &dm->lv_cell_off, &dm->lv_axis, &dm->lv_keys, &dm->lv_mult, &dm->lv_flag, &dm->lv_pos,
-                    &dm->lv_slot, &dm->lv_center, &dm->lv_cell0, &dm->lv_pslot, &dm->lv_pmult, &dm->lv_info, &dm->lv_prune};
+                    &dm->lv_slot, &dm->lv_center, &dm->lv_cell0, &dm->lv_pslot, &dm->lv_pmult, &dm->lv_info, &dm->lv_prune, &dm->lv_beam, &dm->lv_mask};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
     if (dm->h_shard) (void)hipHostFree(dm->h_shard);
@@ -947,8 +948,21 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     uint32_t *nsamp = (uint32_t *)dm->lv_nsamp.ptr, *nray = (uint32_t *)dm->lv_nray.ptr;
     uint32_t *samp_off = (uint32_t *)dm->lv_samp_off.ptr, *ray_off = (uint32_t *)dm->lv_ray_off.ptr;
     hipLaunchKernelGGL(dm_lv_ranges, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (double *)dm->lv_rng.ptr);
-    hipLaunchKernelGGL(dm_lv_beams, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
-                       (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
+    if (nh <= 32768u) {  // membership of the "nearby" gather for all (beam, hit) pairs at once, then the ordered walk over the set bits
+        const uint32_t nw = cdiv(nh, 64);
+        DM_RESERVE(dm->lv_beam, sizeof(LvBeam) * (size_t)nh);
+        DM_RESERVE(dm->lv_mask, 8ull * nh * nw);
+        hipLaunchKernelGGL(dm_lv_beam_init, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (LvBeam *)dm->lv_beam.ptr);
+        hipLaunchKernelGGL(dm_lv_nearby, dim3(nw, nh), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+                           (const LvBeam *)dm->lv_beam.ptr, (unsigned long long *)dm->lv_mask.ptr);
+        const int lds_hits = 12ull * nh <= 60000 ? 1 : 0;   // the hit list in LDS (2 workgroups per CU still fit)
+        hipLaunchKernelGGL(dm_lv_beams_walk, dim3(cdiv(nh, 64)), dim3(64), lds_hits ? 12 * nh : 0, st, d_hits, nh, ba,
+                           (const LvBeam *)dm->lv_beam.ptr, (const unsigned long long *)dm->lv_mask.ptr, nw, (uint8_t *)dm->lv_flags.ptr,
+                           (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt, lds_hits);
+    } else {
+        hipLaunchKernelGGL(dm_lv_beams, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+                           (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
+    }
     if ((rc = exclusive_scan(dm, nsamp, samp_off, nh)) != LA3DM_OK) return rc;
     if ((rc = exclusive_scan(dm, nray, ray_off, nh)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, samp_off, nsamp, nh, dm->d_cnt, (int)kCntFreeRaw);

@@ -118,6 +118,145 @@ __global__ __launch_bounds__(64) void dm_lv_beams(const float *__restrict__ hits
     if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(hm));  // hit samples of the scan
 }
 
+// ---- the same beam computation in two parallel-friendly steps (used while the nh x nh bit matrix fits: nh <= 32768) ----
+// dm_lv_beams walks all nh hits per beam in one lane: nh / 64 waves of nh iterations with three f64 square roots each —
+// 0.7 ms for a 3 000-hit scan on a chip that then sits 95 % idle.  The membership test of the "nearby" gather depends
+// only on the beam's INITIAL length and end point, so it runs for all (beam, hit) pairs at once (one wave per beam and
+// 64 hits, the ballot is the row's mask word); the order-dependent shortening then only visits the set bits.
+struct LvBeam {
+    double l0;
+    float ex, ey, ez;   // initial free_endpt
+    float nx, ny, nz;
+    float pz;
+    uint32_t fl;
+};
+__global__ __launch_bounds__(256) void dm_lv_beam_init(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, LvBeam *__restrict__ beams) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nh) return;
+    const float px = hits[3 * (size_t)h], py = hits[3 * (size_t)h + 1], pz = hits[3 * (size_t)h + 2];
+    const float ox = a.ox, oy = a.oy, oz = a.oz;
+    double l = lv_norm(px - ox, py - oy, pz - oz);
+    LvBeam b;
+    b.nx = (float)((px - ox) / l);
+    b.ny = (float)((py - oy) / l);
+    b.nz = (float)((pz - oz) / l);
+    b.fl = 0;
+    if (a.max_range > 0) {
+        if (l < a.max_range) {
+            l = (float)sqrt((double)((px - ox) * (px - ox) + (py - oy) * (py - oy) + (pz - oz) * (pz - oz)));
+            l = l - a.offset;
+            b.fl |= kLvBeamHit;
+        } else {
+            l = a.max_range - a.offset;
+        }
+    }
+    b.l0 = l;
+    b.ex = (float)(ox + b.nx * l);
+    b.ey = (float)(oy + b.ny * l);
+    b.ez = (float)(oz + b.nz * l);
+    b.pz = pz;
+    beams[h] = b;
+}
+// grid (ceil(nh / 64), nh), 64 threads: mask[h * nw + w] bit j <=> hit 64 w + j is "nearby" for beam h AND within `influence`
+// of the beam's line
+__global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
+                                                  const LvBeam *__restrict__ beams, unsigned long long *__restrict__ mask) {
+    const uint32_t h = blockIdx.y, q = blockIdx.x * 64u + threadIdx.x;
+    const LvBeam b = beams[h];
+    bool near = false;
+    if (q < nh) {
+        const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
+        const double dist2 = rng[q];
+        const bool high = (double)b.pz > (a.offset + (double)a.oz);
+        if (!(a.max_range > 0 && dist2 > a.max_range) && !(high && (double)qz < (double)a.oz + a.influence)) {
+            const double dist1 = lv_norm(b.ex - qx, b.ey - qy, b.ez - qz);
+            near = dist1 < a.influence || (dist1 < b.l0 && dist2 < b.l0);
+            if (near) {
+                // the distance from the hit to the beam's line does not depend on the running length either: only hits
+                // within `influence` of the line can shorten the beam, the ordered walk just gates them on b <= l^2
+                const float ox = a.ox, oy = a.oy, oz = a.oz;
+                const float lvx = b.ex - ox, lvy = b.ey - oy, lvz = b.ez - oz;
+                const double lvn = lv_norm(lvx, lvy, lvz);
+                const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
+                const double bb = (double)(vx * lvx + vy * lvy + vz * lvz);
+                const float t = (float)(bb / (lvn * lvn));
+                const float mx = ox + lvx * t, my = oy + lvy * t, mz = oz + lvz * t;
+                near = lv_norm(qx - mx, qy - my, qz - mz) < a.influence;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(near);
+    if (threadIdx.x == 0) mask[(size_t)h * gridDim.x + blockIdx.x] = m;
+}
+__global__ __launch_bounds__(64) void dm_lv_beams_walk(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
+                                                      const LvBeam *__restrict__ beams, const unsigned long long *__restrict__ mask,
+                                                      uint32_t nw, uint8_t *__restrict__ flags, float *__restrict__ seg,
+                                                      uint32_t *__restrict__ nsamp, uint32_t *__restrict__ nray, uint32_t *counters,
+                                                      int lds_hits) {
+    // the walk reads one hit per set bit, each read depending on the previous bit: with the hit list staged in LDS
+    // (lds_hits != 0: it fits) that is an LDS latency per step instead of a trip to L2
+    extern __shared__ float lv_walk_hits[];
+    if (lds_hits) {
+        for (uint32_t i = threadIdx.x; i < 3u * nh; i += blockDim.x) lv_walk_hits[i] = hits[i];
+        __syncthreads();
+    }
+    const float *hp = lds_hits ? lv_walk_hits : hits;
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0;
+    bool is_hit = false;
+    if (h < nh) {
+        const LvBeam bm = beams[h];
+        const float ox = a.ox, oy = a.oy, oz = a.oz;
+        const float nx = bm.nx, ny = bm.ny, nz = bm.nz;
+        double l = bm.l0;
+        uint32_t fl = bm.fl;
+        float npz = bm.pz;
+        const float lvx = bm.ex - ox, lvy = bm.ey - oy, lvz = bm.ez - oz;
+        const double lvn = lv_norm(lvx, lvy, lvz);
+        for (uint32_t w = 0; w < nw; ++w) {
+            unsigned long long m = mask[(size_t)h * nw + w];
+            while (m) {
+                const uint32_t q = 64u * w + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const float qx = hp[3 * (size_t)q], qy = hp[3 * (size_t)q + 1], qz = hp[3 * (size_t)q + 2];
+                const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
+                const double b = (double)(vx * lvx + vy * lvy + vz * lvz);
+                if (b > l * l) continue;   // (the distance-to-the-line test is already in the mask)
+                npz = qz;
+                l = b / lvn;
+            }
+        }
+        if (l < a.max_range / 5.0 && l / (a.offset - (double)npz) > 0) {  // downward rays close to the sensor
+            fl |= kLvBeamSkip;
+        } else {
+            const float fex = (float)(ox + nx * l), fey = (float)(oy + ny * l), fez = (float)(oz + nz * l);
+            float fox = fex, foy = fey, foz = fez;
+            if (l > a.influence * 1.0) {
+                fox = (float)(ox + nx * a.influence * 1.0);
+                foy = (float)(oy + ny * a.influence * 1.0);
+                foz = (float)(oz + nz * a.influence * 1.0);
+            }
+            float *s = seg + 6 * (size_t)h;
+            s[0] = fox; s[1] = foy; s[2] = foz; s[3] = fex; s[4] = fey; s[5] = fez;
+            const float len = (float)sqrt((double)((fex - fox) * (fex - fox) + (fey - foy) * (fey - foy) + (fez - foz) * (fez - foz)));
+            c = 1;
+            for (float d = len; d > 0.0 && c < kBeamCap; d -= a.free_res) ++c;
+            if (c >= kBeamCap) {
+                atomicOr(&counters[kCntError], kErrBeam);
+                c = 1;
+            }
+        }
+        flags[h] = (uint8_t)fl;
+        nray[h] = (fl & kLvBeamSkip) ? 0u : 1u;
+        c += (fl & kLvBeamHit) ? 1u : 0u;
+        nsamp[h] = c;
+        is_hit = (fl & kLvBeamHit) != 0u;
+    }
+    beam_total_add(c, counters);
+    const unsigned long long hm = __ballot(is_hit);
+    if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(hm));
+}
+
 // samples {x, y, z, ray as float (-1 = hit)} and segments {start, first sample index bits | end, 0} in beam order
 __global__ __launch_bounds__(256) void dm_lv_emit(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
                                                  const uint8_t *__restrict__ flags, const float *__restrict__ seg,
@@ -155,19 +294,33 @@ constexpr uint32_t kErrLvExtent = 4u;
 __global__ __launch_bounds__(256) void dm_lv_cell_bounds(const float4 *__restrict__ samples, uint32_t ns, double half, double g,
                                                         int32_t *mm, uint32_t *counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    const float4 s = samples[i];
-    if (!isfinite(s.x) || !isfinite(s.y) || !isfinite(s.z)) return;
-    const long long c[3] = {lv_cidx(s.x, half, g), lv_cidx(s.y, half, g), lv_cidx(s.z, half, g)};
-    for (int a = 0; a < 3; ++a) {
-        if (c[a] < -(1ll << 30) || c[a] > (1ll << 30)) {
-            atomicOr(&counters[kCntError], kErrLvExtent);
-            return;
+    int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    bool ok = false;
+    if (i < ns) {
+        const float4 s = samples[i];
+        if (isfinite(s.x) && isfinite(s.y) && isfinite(s.z)) {
+            const long long c[3] = {lv_cidx(s.x, half, g), lv_cidx(s.y, half, g), lv_cidx(s.z, half, g)};
+            ok = true;
+            for (int a = 0; a < 3; ++a) ok &= c[a] >= -(1ll << 30) && c[a] <= (1ll << 30);
+            if (!ok) atomicOr(&counters[kCntError], kErrLvExtent);
+            else
+                for (int a = 0; a < 3; ++a) lo[a] = hi[a] = (int32_t)c[a];
         }
-        atomicMin(&mm[a], (int32_t)c[a]);
-        atomicMax(&mm[3 + a], (int32_t)c[a]);
     }
-    atomicAdd((uint32_t *)&mm[6], 1u);
+    // one set of atomics per wave
+    for (int o = 32; o >= 1; o >>= 1)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+        }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&mm[a], lo[a]);
+            atomicMax(&mm[3 + a], hi[a]);
+        }
+        atomicAdd((uint32_t *)&mm[6], (uint32_t)__popcll(m));
+    }
 }
 // key = linear bucket index (x fastest), ncell for a sample that is not binned (non-finite: it keeps its place in
 // `samples` — the rays refer to sample indices — but lies in no voxel's box)
