@@ -75,7 +75,8 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_devmap_training_data", "la3dm_devmap_diag_add_repeat", "la3dm_bgkl_scan_host",
                "la3dm_bgkl_scan_device", "la3dm_diag_mfma_chain", "la3dm_devmap_search_host",
                "la3dm_devmap_export_cells", "la3dm_devmap_key_bounds",
-               "la3dm_devmap_insert_training_data_host", "la3dm_devmap_set_shard", "la3dm_devmap_wait_event"]
+               "la3dm_devmap_insert_training_data_host", "la3dm_devmap_set_shard", "la3dm_devmap_wait_event",
+               "la3dm_devmap_lv_stats_get", "la3dm_devmap_lv_set_original_size", "la3dm_devmap_lv_training"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud", "la3dm_map_insert_pointcloud_device",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
