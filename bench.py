@@ -365,18 +365,20 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
 
 
 def kernel_source_hash():
-    """sha256 of the files the BGK kernel is built from: PMC numbers quoted from profiles/ are only valid for this build"""
+    """sha256 of the file the BGK kernel is built from (the launch side is covered by the waves-per-launch check in
+    profiled_counters): PMC numbers quoted from profiles/ are only valid for this kernel"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("bgk_kernels.h", "la3dm_hip.hip"):
+    for f in ("bgk_kernels.h",):
         with open(os.path.join(ROOT, "la3dm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def profiled_counters(key):
+def profiled_counters(key, tiles=None):
     """per-launch PMC counters of the dominant kernel for this workload, from profiles/bgk_traffic.json — refused unless
-    the entry was recorded with the kernel source this build was made from (scratch/update_traffic.sh stamps it)"""
+    the entry was recorded with the kernel source this build was made from (scratch/update_traffic.sh stamps it) and, when
+    the caller knows it, with the number of waves this run launches"""
     tpath = os.path.join(ROOT, "profiles", "bgk_traffic.json")
     try:
         with open(tpath) as f:
@@ -384,6 +386,8 @@ def profiled_counters(key):
     except Exception:
         return None
     if not e or e.get("kernel_sha") != kernel_source_hash():
+        return None
+    if tiles is not None and e.get("waves_per_launch") is not None and int(e["waves_per_launch"]) != int(tiles):
         return None
     return e
 

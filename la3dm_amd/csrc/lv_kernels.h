@@ -51,6 +51,15 @@ struct LvArgs {
     const uint32_t *blk_mult;
     uint32_t *upd_counter;
     uint32_t npb, layer_off, pass;
+    float inv_ell;              // RN(1 / ell) or 0 (bgk_kernels.h div_by_ell)
+    // work plan (bgklv_plan_kernel): workgroup -> cube, and the row scratch of the cubes that are split over workgroups
+    uint32_t *sub_task;         // nullptr: workgroup = cube, nothing is split
+    uint32_t *task_first, *task_nsub, *task_row0, *split_list;
+    uint32_t *plan_totals;      // [0] workgroups, [1] scratch rows, [2] split cubes
+    float *rows;                // [row][64 voxels] k
+    uint8_t *row_y;             // 1 = the row's sample is a hit (y = 1)
+    uint32_t *sub_rows;         // per workgroup: rows written
+    unsigned long long *sub_info;   // per workgroup: voxels that saw a sample in their box
 };
 
 // LV state code <-> the host enum stored in the pool (State::PRUNED = 3, State::UNCERTAIN = 4; la3dm_lv_scan uses the
@@ -61,7 +70,8 @@ __device__ __forceinline__ uint8_t lv_to_pool(uint8_t s) { return s == 3u ? 4u :
 // point3f::norm(): double sqrt of a float sum, narrowed where the reference stores it in a float matrix
 __device__ __forceinline__ float norm3f(float x, float y, float z) { return (float)sqrt((double)(x * x + y * y + z * z)); }
 
-// include/bgklvoctomap/bgklvinference.h:104-131
+// include/bgklvoctomap/bgklvinference.h:104-131, as the reference writes it (double sqrt / double division).  Only the
+// numerics test uses this form; the kernel evaluates lv_seg_point + lv_kernel_at below, which return the same bits.
 __device__ __forceinline__ float seg_dist_dev(float px, float py, float pz, float ax, float ay, float az, float bx, float by,
                                               float bz) {
     const float lx = bx - ax, ly = by - ay, lz = bz - az;
@@ -83,6 +93,37 @@ __device__ __forceinline__ float cov_sparse_line_dev(float d, float ell, float s
     return cov_sparse<false, 0>(r, sf2);
 }
 
+// The same function in fp32 only.  (float)sqrt((double)x) == sqrtf(x) for every fp32 x and (float)((double)a / (double)b)
+// == a / b for fp32 a, b with a normal quotient: rounding an exact square root / quotient to 53 bits and then to 24 is
+// the same as rounding it to 24 bits at once whenever the wide format has at least 2 * 24 + 2 bits (Figueroa, "When is
+// double rounding innocuous?", 1995); la3dm_diag_sweep(what = 4) checks the square root for all 2^31 non-negative fp32
+// inputs on the device, what = 9 a few billion quotients, and a quotient below 2^-100 takes the double division.
+// Returns the point of the segment a + t (b - a), t in [0, 1], the distance is measured to; l = b - a.
+__device__ __forceinline__ void lv_seg_point(float px, float py, float pz, float ax, float ay, float az, float bx, float by, float bz,
+                                             float lx, float ly, float lz, float &qx, float &qy, float &qz) {
+    const float vx = px - ax, vy = py - ay, vz = pz - az;
+    const float c1 = vx * lx + vy * ly + vz * lz;
+    const float c2 = lx * lx + ly * ly + lz * lz;
+    qx = ax; qy = ay; qz = az;
+    if (c1 <= 0.0f) return;
+    if (c2 <= c1) {
+        qx = bx; qy = by; qz = bz;
+        return;
+    }
+    float b = c1 / c2;
+    if (b < 0x1p-100f) b = (float)((double)c1 / (double)c2);
+    qx = ax + lx * b; qy = ay + ly * b; qz = az + lz * b;
+}
+// covSparseLine at distance |p - q| (bgklvinference.h:143-156: r = min(d / ell, 1), no clamp of negative values)
+__device__ __forceinline__ float lv_kernel_at(float px, float py, float pz, float qx, float qy, float qz, float ell, float inv_ell,
+                                              float sf2) {
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    float r = div_by_ell(d, ell, inv_ell);
+    if (r > 1.0f) r = 1.0f;
+    return cov_sparse_fast<0, false>(r, sf2);
+}
+
 // src/bgklvoctomap/bgklvoctree_node.cpp:29-63
 __device__ __forceinline__ float lv_prob_dev(float A, float B, float min_W) {
     const float W = (A + B < min_W) ? min_W : A + B;
@@ -95,60 +136,68 @@ __device__ __forceinline__ float lv_var_dev(float A, float B, float min_W, float
     return (float)((double)(A / W) * (a * a) + (double)((W - A - B) / W) * (b * b) + (double)(B / W) * (c * c));
 }
 
+// A staged sample.  type (p.w): 0 = hit, 1 = first sample of its ray, 2 = later sample of a ray, + 4 = the ray's segment
+// is shorter than 0.1 mm (point_to_line_dist then measures to the segment start).  The segment direction l = end - start
+// rides in the w components.
 struct __attribute__((aligned(16))) LvCand {
-    float4 p;     // sample position, w: 0 = hit, 1 = first sample of its ray, 2 = later sample
-    float4 prev;  // previous sample of the same ray (type 2)
-    float4 r0;    // segment start (= the ray's first sample)
-    float4 r1;    // segment end
+    float4 p;     // sample position, type
+    float4 prev;  // previous sample of the same ray (type 2), l.x
+    float4 r0;    // segment start (= the ray's first sample), l.y
+    float4 r1;    // segment end, l.z
 };
 
-// One workgroup of kLvWaves waves per cube.  Every wave stages its own 64 samples of a bucket (ordered compaction
-// across the waves through LDS), then the staged candidates are evaluated kLvWaves at a time — wave w takes
-// candidates w, w + kLvWaves, ... of a 64-candidate round, lane = voxel, and writes {k or +0, k * y or +0} into a
-// dense [candidate][voxel] tile — and wave 0 adds the tile row by row: the cube next to the sensor, which sees every
-// beam, spreads its distance / kernel evaluations over the CU's four SIMDs while the two running sums keep the
-// gather order (adding +0 leaves a sum that started at +0 unchanged: it can never be -0).
+// One workgroup of kLvWaves waves per cube, or per sub-task of a cube.  The samples the cube has to look at are the
+// concatenation, z-major, of the buckets around its own (the "stream"); the workgroup walks its part of the stream 512
+// positions at a time: every wave stages its own 64 samples (lane = sample: locate the bucket, load, cull against the
+// cube's +-ell box, ordered compaction across the waves through LDS), then the staged candidates are evaluated kLvWaves
+// at a time — wave w takes candidates w, w + kLvWaves, ... of a 64-candidate round, lane = voxel, and writes k (or +0)
+// into a dense [candidate][voxel] tile — and wave 0 adds the tile row by row: the evaluations spread over the CU's four
+// SIMDs while the two running sums keep the gather order (adding +0 leaves a sum that started at +0 unchanged: it can
+// never be -0; k * y with y in {0, 1} is k or a zero).
+//
+// A cube next to the sensor sees every beam: one workgroup for it would run ten times longer than the rest of the grid
+// together.  bgklv_plan_kernel therefore cuts a cube whose stream is longer than kLvChunk into sub-tasks of kLvChunk
+// stream positions; the sub-tasks of such a cube write their tile rows to a scratch array instead of adding them, and
+// bgklv_split_add_kernel adds the rows of all sub-tasks in stream order — the same additions in the same order.
 constexpr int kLvWaves = 8;
+constexpr uint32_t kLvChunk = 1024;
+constexpr uint32_t kLvGroup = 64;   // buckets whose ranges are resident in LDS at a time
 
 struct LvLds {
     LvCand cand[kLvWaves * kWave];
     float k[kWave][kWave];
-    float ky[kWave][kWave];
+    uint32_t yflag[kWave];
     uint32_t cnt[kLvWaves];
-    uint32_t info[kLvWaves][kWave];
+    unsigned long long info[kLvWaves];
+    uint32_t g_c0[kLvGroup];
+    uint32_t g_incl[kLvGroup];
 };
 
-__global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) {
-    __shared__ LvLds L;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t task = blockIdx.x;
-    if (task >= a.n_tasks) return;
-    const uint32_t blk = task >> a.cubes_shift;
-    const uint32_t cube = task & ((1u << a.cubes_shift) - 1u);
-    const uint32_t node = cube * kWave + lane;
-    const bool in_range = node < a.nodes_per_blk;
-    const bool pool = a.blk_slot != nullptr;
-    if (pool && a.blk_mult[blk] <= a.pass) return;  // (uniform) this block's key repeats fewer times than the pass number
-    const size_t ni = pool ? (size_t)a.blk_slot[blk] * a.npb + a.layer_off + (in_range ? node : 0)
-                           : (size_t)blk * a.nodes_per_blk + (in_range ? node : 0);
-    const uint8_t st_raw = in_range ? a.state[ni] : (uint8_t)4;
-    const uint8_t st_in = !in_range ? (uint8_t)4 : (pool ? lv_from_pool(st_raw) : st_raw);
-    const bool active = st_in != 4;
-    const float4 off4 = a.lut[a.lut_base + (in_range ? node : 0)];
-    const float cx = off4.x + a.blk_center[3 * blk + 0], cy = off4.y + a.blk_center[3 * blk + 1],
-                cz = off4.z + a.blk_center[3 * blk + 2];
-    // the voxel's closed query box (bgklvoctomap.cpp:162-166)
-    const float lox = cx - a.ell, loy = cy - a.ell, loz = cz - a.ell;
-    const float hix = cx + a.ell, hiy = cy + a.ell, hiz = cz + a.ell;
-    const float inf = __builtin_inff();
-    const float tlx = wave_min_dpp(active ? lox : inf), tly = wave_min_dpp(active ? loy : inf), tlz = wave_min_dpp(active ? loz : inf);
-    const float thx = wave_max_dpp(active ? hix : -inf), thy = wave_max_dpp(active ? hiy : -inf), thz = wave_max_dpp(active ? hiz : -inf);
-    __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
-    if (!(tlx <= thx)) {  // no base-resolution leaf in this cube (uniform over the workgroup)
-        if (wave == 0 && in_range && !pool) a.state[ni] = 0;
-        return;
-    }
-    // bucket of this cube: the octree index interleaves (x, y, z) bits, coarsest first
+struct LvTask {
+    uint32_t blk, cube, node;
+    bool in_range, pool, active;
+    size_t ni;
+    uint8_t st_raw;
+    float cx, cy, cz;
+};
+
+__device__ __forceinline__ LvTask lv_task(const LvArgs &a, uint32_t task, int lane) {
+    LvTask t;
+    t.blk = task >> a.cubes_shift;
+    t.cube = task & ((1u << a.cubes_shift) - 1u);
+    t.node = t.cube * kWave + lane;
+    t.in_range = t.node < a.nodes_per_blk;
+    t.pool = a.blk_slot != nullptr;
+    t.ni = t.pool ? (size_t)a.blk_slot[t.blk] * a.npb + a.layer_off + (t.in_range ? t.node : 0)
+                  : (size_t)t.blk * a.nodes_per_blk + (t.in_range ? t.node : 0);
+    t.st_raw = t.in_range ? a.state[t.ni] : (uint8_t)4;
+    const uint8_t st_in = !t.in_range ? (uint8_t)4 : (t.pool ? lv_from_pool(t.st_raw) : t.st_raw);
+    t.active = st_in != 4;
+    return t;
+}
+
+// bucket coordinates (relative to the gather grid) of a cube: the octree index interleaves (x, y, z) bits, coarsest first
+__device__ __forceinline__ void lv_cube_cell(const LvArgs &a, uint32_t blk, uint32_t cube, int &gx, int &gy, int &gz) {
     int bxc = 0, byc = 0, bzc = 0;
     for (uint32_t lvl = 0; lvl < a.cubes_bits; ++lvl) {
         const uint32_t sh = 3u * (a.cubes_bits - 1u - lvl);
@@ -157,107 +206,78 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
         byc = (byc << 1) | (int)((oct >> 1) & 1u);
         bzc = (bzc << 1) | (int)(oct & 1u);
     }
-    const int gx = a.blk_cell0[3 * blk + 0] + bxc - a.cell_min[0], gy = a.blk_cell0[3 * blk + 1] + byc - a.cell_min[1],
-              gz = a.blk_cell0[3 * blk + 2] + bzc - a.cell_min[2];
+    gx = a.blk_cell0[3 * blk + 0] + bxc - a.cell_min[0];
+    gy = a.blk_cell0[3 * blk + 1] + byc - a.cell_min[1];
+    gz = a.blk_cell0[3 * blk + 2] + bzc - a.cell_min[2];
+}
 
-    float ybar = 0.0f, kbar = 0.0f;
-    bool info = false;
-    for (int dz = -a.reach; dz <= a.reach; ++dz)
-        for (int dy = -a.reach; dy <= a.reach; ++dy)
-            for (int dx = -a.reach; dx <= a.reach; ++dx) {
-                const int x = gx + dx, y = gy + dy, z = gz + dz;
-                if (x < 0 || y < 0 || z < 0 || x >= a.cell_dim[0] || y >= a.cell_dim[1] || z >= a.cell_dim[2]) continue;
-                const uint32_t cell = ((uint32_t)z * a.cell_dim[1] + (uint32_t)y) * a.cell_dim[0] + (uint32_t)x;
-                const uint32_t c0 = a.cell_off[cell], c1 = a.cell_off[cell + 1];
-                for (uint32_t base = c0; base < c1; base += kLvWaves * kWave) {
-                    // stage: lane = sample, wave w takes samples [base + 64 w, base + 64 w + 64)
-                    const uint32_t si = base + (uint32_t)wave * kWave + lane;
-                    bool keep = false;
-                    LvCand c;
-                    if (si < c1) {
-                        const float4 s = a.sorted[si];
-                        keep = !(tlx > s.x || s.x > thx || tly > s.y || s.y > thy || tlz > s.z || s.z > thz);
-                        if (keep) {
-                            const uint32_t orig = __float_as_uint(s.w);
-                            const float4 so = a.samples[orig];
-                            const int ray = (int)so.w;
-                            c.p = make_float4(s.x, s.y, s.z, 0.0f);
-                            c.prev = c.r0 = c.r1 = c.p;
-                            if (ray >= 0) {
-                                const float4 ra = a.rays[2 * ray], rb = a.rays[2 * ray + 1];
-                                const uint32_t first = __float_as_uint(ra.w);
-                                c.r0 = ra;
-                                c.r1 = rb;
-                                c.p.w = orig == first ? 1.0f : 2.0f;
-                                if (orig != first) c.prev = a.samples[orig - 1];
-                            }
-                        }
-                    }
-                    const unsigned long long m = __ballot(keep);
-                    const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                    if (lane == 0) L.cnt[wave] = (uint32_t)__popcll(m);
-                    __syncthreads();
-                    uint32_t before = 0, total = 0;
+// sample range of bucket number j (z-major in the (2 reach + 1)^3 neighbourhood of (gx, gy, gz)); empty outside the grid
+__device__ __forceinline__ void lv_bucket_range(const LvArgs &a, int gx, int gy, int gz, uint32_t j, uint32_t nb, uint32_t &c0,
+                                                uint32_t &c1) {
+    c0 = c1 = 0;
+    if (j >= nb) return;
+    const uint32_t w = 2u * (uint32_t)a.reach + 1u;
+    const int dx = (int)(j % w) - a.reach, dy = (int)((j / w) % w) - a.reach, dz = (int)(j / (w * w)) - a.reach;
+    const int x = gx + dx, y = gy + dy, z = gz + dz;
+    if (x < 0 || y < 0 || z < 0 || x >= a.cell_dim[0] || y >= a.cell_dim[1] || z >= a.cell_dim[2]) return;
+    const uint32_t cell = ((uint32_t)z * a.cell_dim[1] + (uint32_t)y) * a.cell_dim[0] + (uint32_t)x;
+    c0 = a.cell_off[cell];
+    c1 = a.cell_off[cell + 1];
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
-                    for (int v = 0; v < kLvWaves; ++v) {
-                        const uint32_t cv = L.cnt[v];
-                        before += v < wave ? cv : 0u;
-                        total += cv;
-                    }
-                    if (keep) L.cand[before + slot] = c;
-                    __syncthreads();
-                    // rounds of 64 staged candidates: evaluate (all waves), then add in order (wave 0)
-                    for (uint32_t r0 = 0; r0 < total; r0 += kWave) {
-                        const uint32_t nr = min(total - r0, (uint32_t)kWave);
-                        for (uint32_t j = wave; j < nr; j += kLvWaves) {
-                            const LvCand &cd = L.cand[r0 + j];
-                            const float4 p = cd.p;
-                            const bool inb = active && !(lox > p.x || p.x > hix || loy > p.y || p.y > hiy || loz > p.z || p.z > hiz);
-                            float kv = 0.0f, kyv = 0.0f;
-                            if (__any(inb)) {
-                                bool count = inb;
-                                float ax = p.x, ay = p.y, az = p.z, bx = p.x, by = p.y, bz = p.z, yv = 1.0f;
-                                if (p.w != 0.0f) {  // a ray sample (uniform): is it this ray's lowest-index sample in my box?
-                                    const float4 q0 = cd.r0, q1 = cd.r1, pv = cd.prev;
-                                    ax = q0.x; ay = q0.y; az = q0.z; bx = q1.x; by = q1.y; bz = q1.z;
-                                    yv = 0.0f;
-                                    if (p.w == 2.0f) {
-                                        const bool first_in = !(lox > q0.x || q0.x > hix || loy > q0.y || q0.y > hiy || loz > q0.z || q0.z > hiz);
-                                        const bool prev_in = !(lox > pv.x || pv.x > hix || loy > pv.y || pv.y > hiy || loz > pv.z || pv.z > hiz);
-                                        count = inb && !first_in && !prev_in;
-                                    }
-                                }
-                                info |= inb;
-                                if (count) {
-                                    const float d = seg_dist_dev(cx, cy, cz, ax, ay, az, bx, by, bz);
-                                    kv = cov_sparse_line_dev(d, a.ell, a.sf2);
-                                    kyv = kv * yv;
-                                }
-                            }
-                            L.k[j][lane] = kv;
-                            L.ky[j][lane] = kyv;
-                        }
-                        __syncthreads();
-                        if (wave == 0) {
-                            for (uint32_t j = 0; j < nr; ++j) {
-                                ybar += L.ky[j][lane];
-                                kbar += L.k[j][lane];
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
-            }
-    L.info[wave][lane] = info ? 1u : 0u;
-    __syncthreads();
-    if (wave != 0 || !in_range) return;
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, kWave);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Work plan, one wave per cube: cubes without a base-resolution leaf or (pool mode) without a sample in reach get no
+// workgroup; the others ceil(stream / kLvChunk).  Workgroup numbers, scratch rows and the list of split cubes are handed
+// out with atomics — their order is irrelevant, every cube's result is a function of its own rows alone.
+// totals: [0] workgroups, [1] scratch rows, [2] split cubes.
+__global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (task >= a.n_tasks) return;
+    const LvTask t = lv_task(a, task, lane);
+    uint32_t nsub = 0, stream = 0;
+    if (__any(t.active)) {
+        int gx, gy, gz;
+        lv_cube_cell(a, t.blk, t.cube, gx, gy, gz);
+        const uint32_t w = 2u * (uint32_t)a.reach + 1u, nb = w * w * w;
+        for (uint32_t j = lane; j < nb; j += kWave) {
+            uint32_t c0, c1;
+            lv_bucket_range(a, gx, gy, gz, j, nb, c0, c1);
+            stream += c1 - c0;
+        }
 #pragma unroll
-    for (int v = 1; v < kLvWaves; ++v) info |= L.info[v][lane] != 0u;
+        for (int d = 32; d > 0; d >>= 1) stream += (uint32_t)__shfl_xor((int)stream, d, kWave);
+        nsub = (stream + kLvChunk - 1) / kLvChunk;
+    }
+    if (!t.pool && nsub == 0) nsub = 1;   // packed mode: the workgroup still clears the cube's status bytes
+    if (lane != 0) return;
+    a.task_nsub[task] = nsub;
+    if (nsub == 0) return;
+    const uint32_t first = atomicAdd(a.plan_totals + 0, nsub);
+    a.task_first[task] = first;
+    for (uint32_t s = 0; s < nsub; ++s) a.sub_task[first + s] = task;
+    if (nsub > 1) {
+        a.task_row0[task] = atomicAdd(a.plan_totals + 1, stream);
+        a.split_list[atomicAdd(a.plan_totals + 2, 1u)] = task;
+    }
+}
+
+// fold the voxel's sums into its node (bgklvoctomap.cpp:236-238 + LV Occupancy); wave 0 of the workgroup that owns the sums
+__device__ __forceinline__ void lv_commit(const LvArgs &a, const LvTask &t, float ybar, float kbar, bool info) {
+    if (!t.in_range) return;
     uint8_t out = info ? 0x40u : 0u;
     bool updated = false;
-    if (active && info && kbar > 0.001f) {  // bgklvoctomap.cpp:236-238
+    if (t.active && info && kbar > 0.001f) {
         updated = true;
-        float A = a.alpha[ni], B = a.beta[ni];
+        float A = a.alpha[t.ni], B = a.beta[t.ni];
         A += ybar;
         B += kbar - ybar;
         const float prob = lv_prob_dev(A, B, a.min_W);
@@ -265,18 +285,238 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
         uint8_t st;
         if (var > a.var_thresh) st = 3;
         else st = prob > a.occupied_thresh ? 1 : (prob < a.free_thresh ? 0 : 2);
-        a.alpha[ni] = A;
-        a.beta[ni] = B;
-        out |= (uint8_t)(0x80u | (pool ? lv_to_pool(st) : st));
+        a.alpha[t.ni] = A;
+        a.beta[t.ni] = B;
+        out |= (uint8_t)(0x80u | (t.pool ? lv_to_pool(st) : st));
     }
-    if (!pool) {
-        a.state[ni] = out;
+    if (!t.pool) {
+        a.state[t.ni] = out;
         return;
     }
     // pool: an untouched node keeps its byte (state + classified), plus the transient "saw samples" bit
-    a.state[ni] = updated ? out : (uint8_t)(st_raw | (out & 0x40u));
+    a.state[t.ni] = updated ? out : (uint8_t)(t.st_raw | (out & 0x40u));
     const unsigned long long um = __ballot(updated);
-    if (lane == 0 && um) atomicAdd(a.upd_counter, (uint32_t)__popcll(um));
+    if ((threadIdx.x & 63) == 0 && um) atomicAdd(a.upd_counter, (uint32_t)__popcll(um));
+}
+
+__global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) {
+    __shared__ LvLds L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t task = blockIdx.x, sub = 0, nsub = 1;
+    if (a.sub_task) {
+        task = a.sub_task[blockIdx.x];
+        sub = blockIdx.x - a.task_first[task];
+        nsub = a.task_nsub[task];
+    }
+    if (task >= a.n_tasks) return;
+    const LvTask t = lv_task(a, task, lane);
+    if (t.pool && a.blk_mult[t.blk] <= a.pass) return;  // (uniform) this block's key repeats fewer times than the pass number
+    const bool active = t.active;
+    const float4 off4 = a.lut[a.lut_base + (t.in_range ? t.node : 0)];
+    const float cx = off4.x + a.blk_center[3 * t.blk + 0], cy = off4.y + a.blk_center[3 * t.blk + 1],
+                cz = off4.z + a.blk_center[3 * t.blk + 2];
+    // the voxel's closed query box (bgklvoctomap.cpp:162-166)
+    const float lox = cx - a.ell, loy = cy - a.ell, loz = cz - a.ell;
+    const float hix = cx + a.ell, hiy = cy + a.ell, hiz = cz + a.ell;
+    const float inf = __builtin_inff();
+    const float tlx = wave_min_dpp(active ? lox : inf), tly = wave_min_dpp(active ? loy : inf), tlz = wave_min_dpp(active ? loz : inf);
+    const float thx = wave_max_dpp(active ? hix : -inf), thy = wave_max_dpp(active ? hiy : -inf), thz = wave_max_dpp(active ? hiz : -inf);
+    __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
+    if (!(tlx <= thx)) {  // no base-resolution leaf in this cube (uniform over the workgroup)
+        if (wave == 0 && t.in_range && !t.pool) a.state[t.ni] = 0;
+        return;
+    }
+    int gx, gy, gz;
+    lv_cube_cell(a, t.blk, t.cube, gx, gy, gz);
+    const bool split = nsub > 1;
+    const uint32_t lo = split ? sub * kLvChunk : 0u, hi = split ? lo + kLvChunk : 0xFFFFFFFFu;
+    const size_t row0 = split ? (size_t)a.task_row0[task] + lo : 0;
+    const uint32_t wdt = 2u * (uint32_t)a.reach + 1u, nb = wdt * wdt * wdt;
+
+    float ybar = 0.0f, kbar = 0.0f;
+    bool info = false;
+    uint32_t n_rows = 0;   // candidates staged so far (split: rows written)
+    uint32_t pos0 = 0;     // stream position of the bucket group's first sample
+    for (uint32_t g0 = 0; g0 < nb && pos0 < hi; g0 += kLvGroup) {
+        // ranges of the group's buckets (every wave computes them, wave 0 publishes them)
+        uint32_t c0, c1;
+        lv_bucket_range(a, gx, gy, gz, g0 + lane, nb, c0, c1);
+        const uint32_t incl = wave_incl_scan_u32(c1 - c0, lane);
+        const uint32_t gtotal = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (wave == 0) {
+            L.g_c0[lane] = c0 - (incl - (c1 - c0));   // sample index = g_c0[j] + position inside the group
+            L.g_incl[lane] = incl;
+        }
+        __syncthreads();
+        const uint32_t s0 = lo > pos0 ? lo - pos0 : 0u, s1 = min(hi - pos0, gtotal);   // my part of the group, group-relative
+        for (uint32_t base = s0; base < s1; base += kLvWaves * kWave) {
+            // stage: lane = stream position, wave w takes [base + 64 w, base + 64 w + 64)
+            const uint32_t q = base + (uint32_t)wave * kWave + lane;
+            bool keep = false;
+            LvCand c;
+            if (q < s1) {
+                uint32_t j = 0;   // first bucket whose inclusive count exceeds q
+#pragma unroll
+                for (uint32_t step = kLvGroup / 2; step > 0; step >>= 1)
+                    if (L.g_incl[j + step - 1] <= q) j += step;
+                const uint32_t si = L.g_c0[j] + q;
+                const float4 s = a.sorted[si];
+                keep = !(tlx > s.x || s.x > thx || tly > s.y || s.y > thy || tlz > s.z || s.z > thz);
+                if (keep) {
+                    const uint32_t orig = __float_as_uint(s.w);
+                    const float4 so = a.samples[orig];
+                    const int ray = (int)so.w;
+                    c.p = make_float4(s.x, s.y, s.z, 0.0f);
+                    c.prev = c.r0 = c.r1 = c.p;
+                    if (ray >= 0) {
+                        const float4 ra = a.rays[2 * ray], rb = a.rays[2 * ray + 1];
+                        const uint32_t first = __float_as_uint(ra.w);
+                        const float lx = rb.x - ra.x, ly = rb.y - ra.y, lz = rb.z - ra.z;
+                        float type = orig == first ? 1.0f : 2.0f;
+                        if (sqrtf(lx * lx + ly * ly + lz * lz) < 0.0001f) type += 4.0f;
+                        float4 pv = c.p;
+                        if (orig != first) pv = a.samples[orig - 1];
+                        c.p.w = type;
+                        c.prev = make_float4(pv.x, pv.y, pv.z, lx);
+                        c.r0 = make_float4(ra.x, ra.y, ra.z, ly);
+                        c.r1 = make_float4(rb.x, rb.y, rb.z, lz);
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (lane == 0) L.cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int v = 0; v < kLvWaves; ++v) {
+                const uint32_t cv = L.cnt[v];
+                before += v < wave ? cv : 0u;
+                total += cv;
+            }
+            if (keep) L.cand[before + slot] = c;
+            __syncthreads();
+            // rounds of 64 staged candidates: evaluate (all waves), then add in order (wave 0) or write the rows out
+            for (uint32_t r0 = 0; r0 < total; r0 += kWave) {
+                const uint32_t nr = min(total - r0, (uint32_t)kWave);
+                for (uint32_t j = wave; j < nr; j += kLvWaves) {
+                    const LvCand &cd = L.cand[r0 + j];
+                    const float4 p = cd.p;
+                    const int type = __builtin_amdgcn_readfirstlane((int)p.w);
+                    const bool inb = active && !(lox > p.x || p.x > hix || loy > p.y || p.y > hiy || loz > p.z || p.z > hiz);
+                    float kv = 0.0f;
+                    if (__any(inb)) {
+                        bool count = inb;
+                        float qx = p.x, qy = p.y, qz = p.z;   // a hit: the distance to the sample itself
+                        if (type != 0) {  // a ray sample: is it this ray's lowest-index sample in my box?
+                            const float4 q0 = cd.r0, q1 = cd.r1, pv = cd.prev;
+                            if ((type & 3) == 2) {
+                                const bool first_in = !(lox > q0.x || q0.x > hix || loy > q0.y || q0.y > hiy || loz > q0.z || q0.z > hiz);
+                                const bool prev_in = !(lox > pv.x || pv.x > hix || loy > pv.y || pv.y > hiy || loz > pv.z || pv.z > hiz);
+                                count = inb && !first_in && !prev_in;
+                            }
+                            qx = q0.x; qy = q0.y; qz = q0.z;
+                            if (!(type & 4) && __any(count))
+                                lv_seg_point(cx, cy, cz, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, pv.w, q0.w, q1.w, qx, qy, qz);
+                        }
+                        info |= inb;
+                        if (count) kv = lv_kernel_at(cx, cy, cz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
+                    }
+                    const uint32_t yf = type == 0 ? 1u : 0u;
+                    if (split) {
+                        const size_t row = row0 + n_rows + r0 + j;
+                        a.rows[row * kWave + lane] = kv;
+                        if (lane == 0) a.row_y[row] = (uint8_t)yf;
+                    } else {
+                        L.k[j][lane] = kv;
+                        if (lane == 0) L.yflag[j] = yf;
+                    }
+                }
+                if (!split) {
+                    __syncthreads();
+                    if (wave == 0) {
+                        for (uint32_t j = 0; j < nr; ++j) {
+                            const float kv = L.k[j][lane];
+                            ybar += L.yflag[j] ? kv : 0.0f;
+                            kbar += kv;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            n_rows += total;
+        }
+        pos0 += gtotal;
+        __syncthreads();   // the group's ranges are read until here
+    }
+    const unsigned long long im = __ballot(info);
+    if (lane == 0) L.info[wave] = im;
+    __syncthreads();
+    if (wave != 0) return;
+    unsigned long long all = 0;
+#pragma unroll
+    for (int v = 0; v < kLvWaves; ++v) all |= L.info[v];
+    if (split) {
+        if (lane == 0) {
+            a.sub_rows[blockIdx.x] = n_rows;
+            a.sub_info[blockIdx.x] = all;
+        }
+        return;
+    }
+    lv_commit(a, t, ybar, kbar, (all >> lane) & 1ull);
+}
+
+// The rows of a split cube, added in stream order: sub-task after sub-task, row after row.  The eight waves fetch 128
+// rows at a time (the next tile is in flight while wave 0 adds the current one).
+constexpr uint32_t kLvAddRows = 128;
+struct LvAddLds {
+    float k[kLvAddRows][kWave];
+    uint32_t yflag[kLvAddRows];
+};
+
+__global__ __launch_bounds__(kLvWaves *kWave) void bgklv_split_add_kernel(LvArgs a) {
+    __shared__ LvAddLds L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t task = a.split_list[blockIdx.x];
+    const LvTask t = lv_task(a, task, lane);
+    if (t.pool && a.blk_mult[t.blk] <= a.pass) return;
+    const uint32_t first = a.task_first[task], nsub = a.task_nsub[task];
+    const size_t row0 = a.task_row0[task];
+    constexpr uint32_t kPer = kLvAddRows / kLvWaves;   // rows per wave and tile
+    float ybar = 0.0f, kbar = 0.0f;
+    unsigned long long info = 0;
+    float reg[kPer];
+    for (uint32_t s = 0; s < nsub; ++s) {
+        const uint32_t n = a.sub_rows[first + s];
+        info |= a.sub_info[first + s];
+        const size_t base = row0 + (size_t)s * kLvChunk;
+        auto fetch = [&](uint32_t r0) {
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; ++i) {
+                const uint32_t r = r0 + (uint32_t)wave + i * kLvWaves;
+                reg[i] = r < n ? a.rows[(base + r) * kWave + lane] : 0.0f;
+            }
+        };
+        if (n) fetch(0);
+        for (uint32_t r0 = 0; r0 < n; r0 += kLvAddRows) {
+            const uint32_t nr = min(n - r0, kLvAddRows);
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; ++i) L.k[wave + i * kLvWaves][lane] = reg[i];
+            if (threadIdx.x < nr) L.yflag[threadIdx.x] = a.row_y[base + r0 + threadIdx.x];
+            __syncthreads();
+            if (r0 + kLvAddRows < n) fetch(r0 + kLvAddRows);
+            if (wave == 0) {
+                for (uint32_t j = 0; j < nr; ++j) {
+                    const float kv = L.k[j][lane];
+                    ybar += L.yflag[j] ? kv : 0.0f;
+                    kbar += kv;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (wave != 0) return;
+    lv_commit(a, t, ybar, kbar, (info >> lane) & 1ull);
 }
 
 }  // namespace la3dm_dev

@@ -38,7 +38,7 @@ if fuse:
     import bench
     mean = lambda c: sum(fuse[c]) / len(fuse[c]) if fuse.get(c) else None
     fetch_kb, write_kb = mean("FETCH_SIZE"), mean("WRITE_SIZE")
-    entry = {"kernel": "bgk_predict_fuse_v5<0,1>", "round": 2, "kernel_sha": bench.kernel_source_hash(),
+    entry = {"kernel": "bgk_predict_fuse_v5<0,1>", "round": 2, "kernel_sha": bench.kernel_source_hash(),  # bgk_kernels.h
              "source": "profiles/r02/bench_pmc_summary.txt (scratch/update_traffic.sh)",
              "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
              "raw_bytes_per_launch": (fetch_kb + write_kb) * 1024 if fetch_kb and write_kb else None,
