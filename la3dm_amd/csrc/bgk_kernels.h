@@ -252,7 +252,7 @@ __device__ __forceinline__ float sqrt_cr(float x) {
 
 // covSparse elementwise (bgkinference.h:115-125) with the two constant divisions done by
 // div_const; bit-identical to cov_sparse<true, kTrig> (tests sweep the divisions exhaustively).
-template <int kTrig>
+template <int kTrig, bool kClamp = true>
 __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     const float t = (r * 2.0f) * 3.1415926f;
     float s, c;
@@ -262,7 +262,7 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     const float a = div_const((2.0f + c) * (1.0f - r), 3.0f, 0.333333343f);
     const float b = div_const(s, 2.0f * 3.1415926f, 0.159154952f);
     float k = (a + b) * sf2;
-    if (k < 0.0f) k = 0.0f;
+    if (kClamp && k < 0.0f) k = 0.0f;
     return k;
 }
 
@@ -685,6 +685,20 @@ __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits,
         else if (what == 5) ok = div_const(x, 2.0f * 3.1415926f, 0.159154952f) == x / (2.0f * 3.1415926f);
         else if (what == 7) ok = div_by_ell(x, ell, inv_ell) == x / ell && div_by_ell(-x, ell, inv_ell) == -x / ell;
         else if (what == 8) ok = !(cov_sparse_fast<0>(sqrt_cr(x), sf2) > 0.0f);  // no support left at this d2
+        else if (what == 9) {  // fp32 quotient == the double quotient narrowed (lv_kernels.h lv_seg_point): x against 8 hashed divisors
+            ok = true;
+            uint32_t h = (lo_bits + (uint32_t)i) * 2654435761u + 0x9E3779B9u;
+            for (int rep = 0; rep < 8; ++rep) {
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+                // a divisor in [x, 4097 x): the projection parameter c1 / c2 lies in (0, 1)
+                const float y = x * (1.0f + (float)(h & 0xFFFFFFu) * 0x1p-12f);
+                const float q = x / y;
+                if (q >= 0x1p-100f) ok = ok && q == (float)((double)x / (double)y);
+                const float y2 = __uint_as_float(0x30000000u + (h & 0x1FFFFFFFu));  // any magnitude in [2^-31, 2^32)
+                const float q2 = x / y2;
+                if (q2 >= 0x1p-100f && q2 < 0x1p100f) ok = ok && q2 == (float)((double)x / (double)y2);
+            }
+        }
         else {  // sincos_cr vs the double-precision library functions rounded to float
             float s, c;
             sincos_cr(x, s, c);

@@ -1115,6 +1115,31 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
                        dm->d_cnt);
     DM_TRY(hipMemsetAsync(dm->d_cnt + kCntLeaves, 0, 4, st));  // counts the voxel updates of all passes
     DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGeo, 0, 4, st));     // counts the blocks with information
+    // work plan of the voxel kernel for at most nc packed blocks (the kernel itself stops at the packed count, which is
+    // still on the device): its totals come back with the counters below
+    la3dm_lv_pool_scan ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.n_samples = ns;
+    ps.samples = (const float *)samples;
+    ps.sorted = (const float *)dm->lv_sorted.ptr;
+    ps.rays = (const float *)dm->lv_rays.ptr;
+    ps.cell_off = (const uint32_t *)dm->lv_cell_off.ptr;
+    for (int a = 0; a < 3; ++a) {
+        ps.cell_min[a] = ga.cmin[a];
+        ps.cell_dim[a] = ga.cdim[a];
+    }
+    ps.blk_center = (const float *)dm->lv_center.ptr;
+    ps.blk_cell0 = (const int32_t *)dm->lv_cell0.ptr;
+    ps.blk_slot = (const uint32_t *)dm->lv_pslot.ptr;
+    ps.blk_mult = (const uint32_t *)dm->lv_pmult.ptr;
+    ps.A = dm->A;
+    ps.B = dm->B;
+    ps.S = dm->S;
+    ps.npb = dm->npb;
+    ps.upd_counter = dm->d_cnt + kCntLeaves;
+    ps.n_blk = ps.plan_n_blk = nc;
+    ps.n_blk_dev = dm->d_cnt + kCntTest;
+    if ((rc = la3dm_bgklv_pool_plan_device(ctx, &ps, dm->d_cnt + kCntLvPlan, st)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     dm->n_blocks = dm->h_cnt[kCntBlocks];
     const uint32_t n_packed = dm->h_cnt[kCntTest];
@@ -1122,26 +1147,8 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     L.voxels = (uint64_t)n_packed << (3 * (depth - 1));
     const double t1 = wall();
     if (n_packed) {
-        la3dm_lv_pool_scan ps;
-        memset(&ps, 0, sizeof(ps));
-        ps.samples = (const float *)samples;
-        ps.sorted = (const float *)dm->lv_sorted.ptr;
-        ps.rays = (const float *)dm->lv_rays.ptr;
-        ps.cell_off = (const uint32_t *)dm->lv_cell_off.ptr;
-        for (int a = 0; a < 3; ++a) {
-            ps.cell_min[a] = ga.cmin[a];
-            ps.cell_dim[a] = ga.cdim[a];
-        }
         ps.n_blk = n_packed;
-        ps.blk_center = (const float *)dm->lv_center.ptr;
-        ps.blk_cell0 = (const int32_t *)dm->lv_cell0.ptr;
-        ps.blk_slot = (const uint32_t *)dm->lv_pslot.ptr;
-        ps.blk_mult = (const uint32_t *)dm->lv_pmult.ptr;
-        ps.A = dm->A;
-        ps.B = dm->B;
-        ps.S = dm->S;
-        ps.npb = dm->npb;
-        ps.upd_counter = dm->d_cnt + kCntLeaves;
+        for (int a = 0; a < 3; ++a) ps.plan_totals[a] = dm->h_cnt[kCntLvPlan + a];
         const uint32_t layer_n = 1u << (3 * (depth - 1)), layer_off = dm->npb - layer_n;
         for (uint32_t pass = 0; pass < max_mult; ++pass) {  // a key the float-stepped loop repeats is visited again, serially
             ps.pass = pass;

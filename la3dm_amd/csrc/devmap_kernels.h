@@ -47,7 +47,8 @@ enum DevCounter {
     kCntTrained = 13,    // blocks with training points that are in the candidate list
     kCntPairEvals = 14,  // 64-bit (words 14, 15): sum of neighbourhood points x leaves; kCntTrainReads likewise (10, 11)
     kCntBeamTotal = 16,  // 64-bit (words 16, 17): beam samples of the scan, summed without the 32-bit wrap of the offsets
-    kCntWords = 18
+    kCntLvPlan = 18,     // BGK-LV work plan (words 18-20): workgroups, scratch rows, split cubes
+    kCntWords = 21
 };
 
 struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call

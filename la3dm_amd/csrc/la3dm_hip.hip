@@ -39,21 +39,77 @@ static void lv_fill_args(la3dm_ctx *ctx, LvArgs &a, uint32_t n_blk) {
     a.reach = (int)ceil((double)ctx->p.ell / g);
     a.sf2 = ctx->p.sf2;
     a.ell = ctx->p.ell;
+    a.inv_ell = ctx->inv_ell;
     a.free_thresh = ctx->p.free_thresh;
     a.occupied_thresh = ctx->p.occupied_thresh;
     a.var_thresh = ctx->p.var_thresh;
     a.min_W = ctx->p.min_W;
 }
 
-int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hipStream_t stream) {
+// ---- BGK-LV work plan (lv_kernels.h bgklv_plan_kernel): which cube gets how many workgroups ----
+static void lv_plan_layout(la3dm_ctx *ctx, LvArgs &a, uint32_t n_tasks) {
+    a.sub_task = (uint32_t *)ctx->lvp_sub_task.ptr;
+    a.task_first = (uint32_t *)ctx->lvp_task.ptr;
+    a.task_nsub = a.task_first + n_tasks;
+    a.task_row0 = a.task_nsub + n_tasks;
+    a.split_list = a.task_row0 + n_tasks;
+}
+// Reserves the plan arrays, points `a` at them and launches the plan kernel; the three totals (workgroups, scratch rows,
+// split cubes) land in totals_dev (zeroed here), for the caller to read back.
+static int lv_plan_launch(la3dm_ctx *ctx, LvArgs &a, uint32_t n_samples, uint32_t *totals_dev, hipStream_t stream) {
+    const uint64_t w = 2ull * (uint64_t)a.reach + 1ull, nb = w * w * w;
+    const uint64_t max_subs = (uint64_t)a.n_tasks + nb * (uint64_t)n_samples / kLvChunk + 1;   // sum of ceil(stream / chunk)
+    if (max_subs > 0x7FFFFFFFull) {
+        ctx->err = "lv scan: too many cubes x samples for the work plan";
+        return LA3DM_ERR_ARG;
+    }
+    int rc;
+    if ((rc = arena_reserve(ctx, ctx->lvp_sub_task, 4 * max_subs)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->lvp_task, 16ull * a.n_tasks)) != LA3DM_OK) return rc;
+    lv_plan_layout(ctx, a, a.n_tasks);
+    a.plan_totals = totals_dev;
+    HIP_TRY(ctx, hipMemsetAsync(totals_dev, 0, 12, stream));
+    hipLaunchKernelGGL(bgklv_plan_kernel, dim3((a.n_tasks + 3) / 4), dim3(256), 0, stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return LA3DM_OK;
+}
+
+// the voxel kernel over the planned workgroups + the ordered adds of the split cubes (totals: as read back from the plan)
+static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[3], hipStream_t stream) {
+    const uint32_t n_subs = totals[0], n_rows = totals[1], n_split = totals[2];
+    if (n_subs == 0) return LA3DM_OK;
+    int rc;
+    if ((rc = arena_reserve(ctx, ctx->lvp_rows, 256ull * (n_rows ? n_rows : 1))) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->lvp_row_y, n_rows ? n_rows : 1)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->lvp_sub_out, 12ull * n_subs)) != LA3DM_OK) return rc;
+    a.rows = (float *)ctx->lvp_rows.ptr;
+    a.row_y = (uint8_t *)ctx->lvp_row_y.ptr;
+    a.sub_info = (unsigned long long *)ctx->lvp_sub_out.ptr;
+    a.sub_rows = (uint32_t *)(a.sub_info + n_subs);
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (ctx->opt_time_kernel) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            std::pair<hipEvent_t, hipEvent_t> p;
+            HIP_TRY(ctx, hipEventCreate(&p.first));
+            HIP_TRY(ctx, hipEventCreate(&p.second));
+            ctx->ev_pool.push_back(p);
+        }
+        ev = &ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
+    }
+    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
+    if (n_split) hipLaunchKernelGGL(bgklv_split_add_kernel, dim3(n_split), dim3(kLvWaves * kWave), 0, stream, a);
+    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return LA3DM_OK;
+}
+
+static int lv_pool_args(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, LvArgs &a) {
     if (!ctx || !s) return LA3DM_ERR_ARG;
-    if (s->n_blk == 0) return LA3DM_OK;
     if (ctx->p.variant != 2) {
         ctx->err = "la3dm_bgklv_pool_scan: the context was not created with variant = 2 (BGKLVOctoMap)";
         return LA3DM_ERR_ARG;
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LvArgs a;
     lv_fill_args(ctx, a, s->n_blk);
     a.samples = (const float4 *)s->samples;
     a.sorted = (const float4 *)s->sorted;
@@ -74,21 +130,28 @@ int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hi
     a.npb = s->npb;
     a.layer_off = a.lut_base;  // the pool is depth-major like the LUT: the finest layer starts at (8^(d-1) - 1) / 7
     a.pass = s->pass;
-    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
-    if (ctx->opt_time_kernel) {
-        if (ctx->ev_used == ctx->ev_pool.size()) {
-            std::pair<hipEvent_t, hipEvent_t> p;
-            HIP_TRY(ctx, hipEventCreate(&p.first));
-            HIP_TRY(ctx, hipEventCreate(&p.second));
-            ctx->ev_pool.push_back(p);
-        }
-        ev = &ctx->ev_pool[ctx->ev_used++];
-        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
-    }
-    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(a.n_tasks), dim3(kLvWaves * kWave), 0, stream, a);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
-    HIP_TRY(ctx, hipGetLastError());
+    a.n_blk_dev = s->n_blk_dev;
     return LA3DM_OK;
+}
+
+int la3dm_bgklv_pool_plan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, uint32_t *totals_dev, hipStream_t stream) {
+    if (!s || s->n_blk == 0) return LA3DM_OK;
+    LvArgs a;
+    int rc = lv_pool_args(ctx, s, a);
+    if (rc != LA3DM_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lv_plan_launch(ctx, a, s->n_samples, totals_dev, stream);
+}
+
+int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hipStream_t stream) {
+    if (!s || s->n_blk == 0) return LA3DM_OK;
+    LvArgs a;
+    int rc = lv_pool_args(ctx, s, a);
+    if (rc != LA3DM_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the plan arrays are where la3dm_bgklv_pool_plan_device left them
+    lv_plan_layout(ctx, a, (s->plan_n_blk ? s->plan_n_blk : s->n_blk) << a.cubes_shift);
+    return lv_run_planned(ctx, a, s->plan_totals, stream);
 }
 
 extern "C" {
@@ -168,7 +231,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_val, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
-                    &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
+                    &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_row_y, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
@@ -552,21 +615,14 @@ int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream
         a.cell_min[i] = s->cell_min[i];
         a.cell_dim[i] = s->cell_dim[i];
     }
-    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
-    if (ctx->opt_time_kernel) {
-        if (ctx->ev_used == ctx->ev_pool.size()) {
-            std::pair<hipEvent_t, hipEvent_t> p;
-            HIP_TRY(ctx, hipEventCreate(&p.first));
-            HIP_TRY(ctx, hipEventCreate(&p.second));
-            ctx->ev_pool.push_back(p);
-        }
-        ev = &ctx->ev_pool[ctx->ev_used++];
-        HIP_TRY(ctx, hipEventRecord(ev->first, stream));
-    }
-    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(a.n_tasks), dim3(kLvWaves * kWave), 0, stream, a);
-    if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
-    HIP_TRY(ctx, hipGetLastError());
-    if (out) out->n_tiles = a.n_tasks;
+    int rc = arena_reserve(ctx, ctx->lvp_totals, 16);
+    if (rc != LA3DM_OK) return rc;
+    if ((rc = lv_plan_launch(ctx, a, s->n_samples, (uint32_t *)ctx->lvp_totals.ptr, stream)) != LA3DM_OK) return rc;
+    uint32_t totals[3] = {0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(totals, ctx->lvp_totals.ptr, 12, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if ((rc = lv_run_planned(ctx, a, totals, stream)) != LA3DM_OK) return rc;
+    if (out) out->n_tiles = totals[0];
     return LA3DM_OK;
 }
 

@@ -56,6 +56,7 @@ struct LvArgs {
     uint32_t *sub_task;         // nullptr: workgroup = cube, nothing is split
     uint32_t *task_first, *task_nsub, *task_row0, *split_list;
     uint32_t *plan_totals;      // [0] workgroups, [1] scratch rows, [2] split cubes
+    const uint32_t *n_blk_dev;  // plan kernel: number of packed blocks when it is still on the device (else n_tasks counts)
     float *rows;                // [row][64 voxels] k
     uint8_t *row_y;             // 1 = the row's sample is a hit (y = 1)
     uint32_t *sub_rows;         // per workgroup: rows written
@@ -241,7 +242,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 __global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (task >= a.n_tasks) return;
+    if (task >= (a.n_blk_dev ? *a.n_blk_dev << a.cubes_shift : a.n_tasks)) return;
     const LvTask t = lv_task(a, task, lane);
     uint32_t nsub = 0, stream = 0;
     if (__any(t.active)) {

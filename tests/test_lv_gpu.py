@@ -91,3 +91,33 @@ def test_repeated_candidate_keys_and_a_hit_at_the_sensor(built):
             m.insert_pointcloud(pts, origin, 0.2, 0.24, 8.0)
             o.insert_pointcloud(pts, origin, 0.2, 0.24, 8.0)
             _compare(m, o, params, f"case {case} scan {scan}")
+
+
+def test_fp32_line_distance_matches_the_reference_double_steps(built):
+    """the voxel kernel takes point_to_line_dist's square roots and its c1 / c2 division in fp32 (lv_kernels.h
+    lv_seg_point / lv_kernel_at); the reference widens to double for both and narrows the result
+    (bgklvinference.h:104-131).  Same bits: every non-negative fp32 square root, and 8 x 2 hashed divisors for each
+    of 2^28 dividends."""
+    import la3dm_amd
+    m = la3dm_amd.BGKLVOctoMap(**la3dm_amd.LV_YAML, device=0)
+    assert m.diag_sweep(4, 0.0, np.float32(np.finfo(np.float32).max)) == 0
+    assert m.diag_sweep(9, 2.0 ** -20, 2.0 ** 12) == 0
+
+
+@pytest.mark.parametrize("ell,depth,both_modes", [(0.5, 3, True), (0.9, 4, False)])
+def test_lv_wide_kernel_several_bucket_groups(built, ell, depth, both_modes):
+    """ell > 4 voxels: the gather neighbourhood is 5^3 / 7^3 buckets (more than one group of 64 bucket ranges in the
+    voxel kernel), every cube's stream is long and most cubes are split over workgroups"""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.LV_YAML, resolution=0.1, block_depth=depth, ell=ell)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", 2))
+    o = O.OracleLVMap(**params)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+    for resident in ((True, False) if both_modes else (True,)):
+        m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+        if not resident:
+            m.set_device_resident(False)
+        m.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        ea, eb = _compare(m, o, params, f"ell {ell} resident {resident}")
+        assert ea == 1.0 and eb == 1.0
