@@ -69,7 +69,7 @@ static int lv_plan_launch(la3dm_ctx *ctx, LvArgs &a, uint32_t n_samples, uint32_
     lv_plan_layout(ctx, a, a.n_tasks);
     a.plan_totals = totals_dev;
     HIP_TRY(ctx, hipMemsetAsync(totals_dev, 0, 12, stream));
-    hipLaunchKernelGGL(bgklv_plan_kernel, dim3((a.n_tasks + 3) / 4), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(bgklv_plan_kernel, dim3((a.n_tasks + 4 * kLvPlanPerWave - 1) / (4 * kLvPlanPerWave)), dim3(256), 0, stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return LA3DM_OK;
 }
@@ -80,12 +80,12 @@ static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[3], h
     if (n_subs == 0) return LA3DM_OK;
     int rc;
     if ((rc = arena_reserve(ctx, ctx->lvp_rows, 256ull * (n_rows ? n_rows : 1))) != LA3DM_OK) return rc;
-    if ((rc = arena_reserve(ctx, ctx->lvp_row_y, n_rows ? n_rows : 1)) != LA3DM_OK) return rc;
-    if ((rc = arena_reserve(ctx, ctx->lvp_sub_out, 12ull * n_subs)) != LA3DM_OK) return rc;
+    constexpr size_t kWords = kLvChunk / kWave;
+    if ((rc = arena_reserve(ctx, ctx->lvp_sub_out, 8ull * (2 * kWords + 1) * n_subs)) != LA3DM_OK) return rc;
     a.rows = (float *)ctx->lvp_rows.ptr;
-    a.row_y = (uint8_t *)ctx->lvp_row_y.ptr;
     a.sub_info = (unsigned long long *)ctx->lvp_sub_out.ptr;
-    a.sub_rows = (uint32_t *)(a.sub_info + n_subs);
+    a.sub_nz = a.sub_info + n_subs;
+    a.sub_y = a.sub_nz + kWords * n_subs;
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (ctx->opt_time_kernel) {
         if (ctx->ev_used == ctx->ev_pool.size()) {

@@ -57,9 +57,9 @@ struct LvArgs {
     uint32_t *task_first, *task_nsub, *task_row0, *split_list;
     uint32_t *plan_totals;      // [0] workgroups, [1] scratch rows, [2] split cubes
     const uint32_t *n_blk_dev;  // plan kernel: number of packed blocks when it is still on the device (else n_tasks counts)
-    float *rows;                // [row][64 voxels] k
-    uint8_t *row_y;             // 1 = the row's sample is a hit (y = 1)
-    uint32_t *sub_rows;         // per workgroup: rows written
+    float *rows;                // [row slot][64 voxels] k; only rows with a non-zero k are written
+    unsigned long long *sub_nz; // per workgroup: kLvChunk bits, row slot written
+    unsigned long long *sub_y;  // per workgroup: kLvChunk bits, the row's sample is a hit (y = 1)
     unsigned long long *sub_info;   // per workgroup: voxels that saw a sample in their box
 };
 
@@ -167,9 +167,12 @@ constexpr uint32_t kLvGroup = 64;   // buckets whose ranges are resident in LDS 
 struct LvLds {
     LvCand cand[kLvWaves * kWave];
     float k[kWave][kWave];
-    uint32_t yflag[kWave];
+    unsigned long long y_round[2];               // rows of the current round that are hits with a non-zero k (by round parity)
+    unsigned long long nz_map[kLvChunk / kWave];  // split cube: the same per staged candidate of the sub-task
+    unsigned long long y_map[kLvChunk / kWave];
     uint32_t cnt[kLvWaves];
     unsigned long long info[kLvWaves];
+    float ybar[kWave];
     uint32_t g_c0[kLvGroup];
     uint32_t g_incl[kLvGroup];
 };
@@ -235,39 +238,94 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-// Work plan, one wave per cube: cubes without a base-resolution leaf or (pool mode) without a sample in reach get no
-// workgroup; the others ceil(stream / kLvChunk).  Workgroup numbers, scratch rows and the list of split cubes are handed
-// out with atomics — their order is irrelevant, every cube's result is a function of its own rows alone.
-// totals: [0] workgroups, [1] scratch rows, [2] split cubes.
-__global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (task >= (a.n_blk_dev ? *a.n_blk_dev << a.cubes_shift : a.n_tasks)) return;
-    const LvTask t = lv_task(a, task, lane);
-    uint32_t nsub = 0, stream = 0;
-    if (__any(t.active)) {
-        int gx, gy, gz;
-        lv_cube_cell(a, t.blk, t.cube, gx, gy, gz);
-        const uint32_t w = 2u * (uint32_t)a.reach + 1u, nb = w * w * w;
-        for (uint32_t j = lane; j < nb; j += kWave) {
-            uint32_t c0, c1;
-            lv_bucket_range(a, gx, gy, gz, j, nb, c0, c1);
-            stream += c1 - c0;
+// The rows of a [row][voxel] tile whose bit is set in m, added to acc in row order: the row numbers come out of the mask
+// on the scalar unit, eight LDS reads are in flight at a time (one read per dependent add would cost the LDS latency per
+// row).  Skipped rows are rows of zeros, or rows that add +0 to this sum: x + 0 = x for every sum that started at +0.
+__device__ __forceinline__ float lv_add_rows(const float (*k)[kWave], unsigned long long m, int lane, float acc) {
+    while (m) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = m ? __builtin_ctzll(m) : 0;
+            v[i] = m ? k[j][lane] : 0.0f;
+            m &= m - 1ull;
         }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) stream += (uint32_t)__shfl_xor((int)stream, d, kWave);
-        nsub = (stream + kLvChunk - 1) / kLvChunk;
+        for (int i = 0; i < 8; ++i) acc += v[i];
     }
-    if (!t.pool && nsub == 0) nsub = 1;   // packed mode: the workgroup still clears the cube's status bytes
-    if (lane != 0) return;
-    a.task_nsub[task] = nsub;
-    if (nsub == 0) return;
-    const uint32_t first = atomicAdd(a.plan_totals + 0, nsub);
+    return acc;
+}
+
+// rows [0, n16) of a tile added to acc in row order, n16 a multiple of 16 (the rows past the last real one hold zeros):
+// constant LDS offsets, 16 reads in flight — a fifth of the masked walk's cost per row, so the sum over all rows (most
+// of them non-zero) goes this way and only the sparse hit rows use the mask.
+__device__ __forceinline__ float lv_add_dense(const float (*k)[kWave], uint32_t n16, int lane, float acc) {
+    for (uint32_t j = 0; j < n16; j += 16) {
+        float v[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) v[i] = k[j + i][lane];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) acc += v[i];
+    }
+    return acc;
+}
+
+// Work plan: cubes without a base-resolution leaf or (pool mode) without a sample in reach get no workgroup; the others
+// ceil(stream / kLvChunk).  A wave looks at 16 cubes one after the other (lane = voxel for the status bytes, lane = bucket
+// for the stream length) and then hands out workgroup numbers, scratch rows and list places for all of them with one
+// atomic each — their order is irrelevant, every cube's result is a function of its own rows alone.
+// totals: [0] workgroups, [1] scratch rows, [2] split cubes.
+constexpr uint32_t kLvPlanPerWave = 16;
+__global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_tasks = a.n_blk_dev ? *a.n_blk_dev << a.cubes_shift : a.n_tasks;
+    const uint32_t task0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kLvPlanPerWave;
+    if (task0 >= n_tasks) return;
+    const uint32_t w = 2u * (uint32_t)a.reach + 1u, nb = w * w * w;
+    uint32_t my_nsub = 0, my_stream = 0;   // lane i: cube task0 + i
+    for (uint32_t i = 0; i < kLvPlanPerWave && task0 + i < n_tasks; ++i) {
+        const LvTask t = lv_task(a, task0 + i, lane);
+        uint32_t nsub = 0, stream = 0;
+        if (__any(t.active)) {
+            int gx, gy, gz;
+            lv_cube_cell(a, t.blk, t.cube, gx, gy, gz);
+            for (uint32_t j = lane; j < nb; j += kWave) {
+                uint32_t c0, c1;
+                lv_bucket_range(a, gx, gy, gz, j, nb, c0, c1);
+                stream += c1 - c0;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) stream += (uint32_t)__shfl_xor((int)stream, d, kWave);
+            nsub = (stream + kLvChunk - 1) / kLvChunk;
+        }
+        if (!t.pool && nsub == 0) nsub = 1;   // packed mode: the workgroup still clears the cube's status bytes
+        if (lane == (int)i) {
+            my_nsub = nsub;
+            my_stream = nsub > 1 ? stream : 0u;
+        }
+    }
+    const bool is_split = my_nsub > 1;
+    const uint32_t sub_incl = wave_incl_scan_u32(my_nsub, lane), row_incl = wave_incl_scan_u32(my_stream, lane);
+    const unsigned long long sm = __ballot(is_split);
+    uint32_t base_sub = 0, base_row = 0, base_split = 0;
+    if (lane == kWave - 1) {
+        if (sub_incl) base_sub = atomicAdd(a.plan_totals + 0, sub_incl);
+        if (row_incl) base_row = atomicAdd(a.plan_totals + 1, row_incl);
+        if (sm) base_split = atomicAdd(a.plan_totals + 2, (uint32_t)__popcll(sm));
+    }
+    base_sub = (uint32_t)__shfl((int)base_sub, kWave - 1, kWave);
+    base_row = (uint32_t)__shfl((int)base_row, kWave - 1, kWave);
+    base_split = (uint32_t)__shfl((int)base_split, kWave - 1, kWave);
+    if (lane >= (int)kLvPlanPerWave || task0 + lane >= n_tasks) return;
+    const uint32_t task = task0 + lane;
+    a.task_nsub[task] = my_nsub;
+    if (my_nsub == 0) return;
+    const uint32_t first = base_sub + sub_incl - my_nsub;
     a.task_first[task] = first;
-    for (uint32_t s = 0; s < nsub; ++s) a.sub_task[first + s] = task;
-    if (nsub > 1) {
-        a.task_row0[task] = atomicAdd(a.plan_totals + 1, stream);
-        a.split_list[atomicAdd(a.plan_totals + 2, 1u)] = task;
+    for (uint32_t s2 = 0; s2 < my_nsub; ++s2) a.sub_task[first + s2] = task;
+    if (is_split) {
+        a.task_row0[task] = base_row + row_incl - my_stream;
+        a.split_list[base_split + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = task;
     }
 }
 
@@ -322,6 +380,8 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     const float inf = __builtin_inff();
     const float tlx = wave_min_dpp(active ? lox : inf), tly = wave_min_dpp(active ? loy : inf), tlz = wave_min_dpp(active ? loz : inf);
     const float thx = wave_max_dpp(active ? hix : -inf), thy = wave_max_dpp(active ? hiy : -inf), thz = wave_max_dpp(active ? hiz : -inf);
+    if (threadIdx.x < 2) L.y_round[threadIdx.x] = 0ull;
+    if (threadIdx.x < kLvChunk / kWave) L.nz_map[threadIdx.x] = L.y_map[threadIdx.x] = 0ull;
     __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
     if (!(tlx <= thx)) {  // no base-resolution leaf in this cube (uniform over the workgroup)
         if (wave == 0 && t.in_range && !t.pool) a.state[t.ni] = 0;
@@ -334,9 +394,10 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     const size_t row0 = split ? (size_t)a.task_row0[task] + lo : 0;
     const uint32_t wdt = 2u * (uint32_t)a.reach + 1u, nb = wdt * wdt * wdt;
 
-    float ybar = 0.0f, kbar = 0.0f;
+    float ybar = 0.0f, kbar = 0.0f;   // kbar lives in wave 0, ybar in wave 1
     bool info = false;
-    uint32_t n_rows = 0;   // candidates staged so far (split: rows written)
+    uint32_t n_rows = 0;   // candidates staged so far (split: the next row slot)
+    uint32_t rnd = 0;
     uint32_t pos0 = 0;     // stream position of the bucket group's first sample
     for (uint32_t g0 = 0; g0 < nb && pos0 < hi; g0 += kLvGroup) {
         // ranges of the group's buckets (every wave computes them, wave 0 publishes them)
@@ -397,10 +458,16 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
             }
             if (keep) L.cand[before + slot] = c;
             __syncthreads();
-            // rounds of 64 staged candidates: evaluate (all waves), then add in order (wave 0) or write the rows out
+            // rounds of 64 staged candidates: evaluate (all waves), then add in order (wave 0: k, wave 1: k y) or write the
+            // non-zero rows out
             for (uint32_t r0 = 0; r0 < total; r0 += kWave) {
                 const uint32_t nr = min(total - r0, (uint32_t)kWave);
-                for (uint32_t j = wave; j < nr; j += kLvWaves) {
+                const uint32_t nr16 = split ? nr : (nr + 15u) & ~15u;
+                for (uint32_t j = wave; j < nr16; j += kLvWaves) {
+                    if (j >= nr) {   // zero rows up to the next multiple of 16 for the dense add
+                        L.k[j][lane] = 0.0f;
+                        continue;
+                    }
                     const LvCand &cd = L.cand[r0 + j];
                     const float4 p = cd.p;
                     const int type = __builtin_amdgcn_readfirstlane((int)p.w);
@@ -423,26 +490,29 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
                         info |= inb;
                         if (count) kv = lv_kernel_at(cx, cy, cz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
                     }
-                    const uint32_t yf = type == 0 ? 1u : 0u;
-                    if (split) {
-                        const size_t row = row0 + n_rows + r0 + j;
-                        a.rows[row * kWave + lane] = kv;
-                        if (lane == 0) a.row_y[row] = (uint8_t)yf;
-                    } else {
+                    const bool nz = __any(kv != 0.0f);
+                    if (!split) {
                         L.k[j][lane] = kv;
-                        if (lane == 0) L.yflag[j] = yf;
+                        if (type == 0 && nz && lane == 0) atomicOr(&L.y_round[rnd & 1u], 1ull << j);
+                        continue;
+                    }
+                    if (!nz) continue;   // a row of zeros adds nothing to either sum: not written, not read
+                    const uint32_t slot = n_rows + r0 + j;
+                    a.rows[(row0 + slot) * kWave + lane] = kv;
+                    if (lane == 0) {
+                        atomicOr(&L.nz_map[slot >> 6], 1ull << (slot & 63u));
+                        if (type == 0) atomicOr(&L.y_map[slot >> 6], 1ull << (slot & 63u));
                     }
                 }
                 if (!split) {
                     __syncthreads();
-                    if (wave == 0) {
-                        for (uint32_t j = 0; j < nr; ++j) {
-                            const float kv = L.k[j][lane];
-                            ybar += L.yflag[j] ? kv : 0.0f;
-                            kbar += kv;
-                        }
-                    }
+                    if (wave == 0) kbar = lv_add_dense(L.k, nr16, lane, kbar);
+                    if (wave == 1) ybar = lv_add_rows(L.k, L.y_round[rnd & 1u], lane, ybar);
+                    // the other parity's masks: last read in the previous round's add phase, next set after this round's
+                    // second barrier
+                    if (threadIdx.x == 2 * kWave) L.y_round[(rnd + 1u) & 1u] = 0ull;
                     __syncthreads();
+                    ++rnd;
                 }
             }
             n_rows += total;
@@ -452,27 +522,37 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     }
     const unsigned long long im = __ballot(info);
     if (lane == 0) L.info[wave] = im;
+    if (wave == 1) L.ybar[lane] = ybar;
     __syncthreads();
     if (wave != 0) return;
     unsigned long long all = 0;
 #pragma unroll
     for (int v = 0; v < kLvWaves; ++v) all |= L.info[v];
     if (split) {
-        if (lane == 0) {
-            a.sub_rows[blockIdx.x] = n_rows;
-            a.sub_info[blockIdx.x] = all;
+        constexpr uint32_t kWords = kLvChunk / kWave;
+        if (lane < (int)kWords) {
+            a.sub_nz[(size_t)blockIdx.x * kWords + lane] = L.nz_map[lane];
+            a.sub_y[(size_t)blockIdx.x * kWords + lane] = L.y_map[lane];
         }
+        if (lane == 0) a.sub_info[blockIdx.x] = all;
         return;
     }
-    lv_commit(a, t, ybar, kbar, (all >> lane) & 1ull);
+    lv_commit(a, t, L.ybar[lane], kbar, (all >> lane) & 1ull);
 }
 
-// The rows of a split cube, added in stream order: sub-task after sub-task, row after row.  The eight waves fetch 128
-// rows at a time (the next tile is in flight while wave 0 adds the current one).
+// The rows of a split cube, added in stream order: sub-task after sub-task, row after row (rows of zeros were not
+// written and are not read).  Per sub-task the set bits of its row map become a list of row slots; the eight waves fetch
+// the listed rows 128 at a time, 16 B per lane, three tiles ahead of the one wave 0 adds into the k sum and wave 1 (hit
+// rows only) into the k y sum — the rows come from other CUs' stores, ~2 us away, and one tile in flight would leave the
+// adder waiting for memory most of the time.
 constexpr uint32_t kLvAddRows = 128;
+constexpr int kLvAddDepth = 3;
 struct LvAddLds {
     float k[kLvAddRows][kWave];
-    uint32_t yflag[kLvAddRows];
+    uint16_t slot[kLvChunk];
+    uint8_t hit[kLvChunk];
+    uint32_t word_off[kLvChunk / kWave + 1];
+    float ybar[kWave];
 };
 
 __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_split_add_kernel(LvArgs a) {
@@ -483,41 +563,75 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_split_add_kernel(LvArgs
     if (t.pool && a.blk_mult[t.blk] <= a.pass) return;
     const uint32_t first = a.task_first[task], nsub = a.task_nsub[task];
     const size_t row0 = a.task_row0[task];
-    constexpr uint32_t kPer = kLvAddRows / kLvWaves;   // rows per wave and tile
-    float ybar = 0.0f, kbar = 0.0f;
+    constexpr uint32_t kWords = kLvChunk / kWave;
+    constexpr uint32_t kRowsPerLoad = kLvWaves * kWave / 16;   // 32 rows per load instruction of the workgroup
+    constexpr uint32_t kLoads = kLvAddRows / kRowsPerLoad;     // 4
+    const uint32_t my_row = threadIdx.x >> 4, my_quad = threadIdx.x & 15u;
+    float ybar = 0.0f, kbar = 0.0f;                     // kbar lives in wave 0, ybar in wave 1
     unsigned long long info = 0;
-    float reg[kPer];
+    float4 reg[kLvAddDepth][kLoads];
     for (uint32_t s = 0; s < nsub; ++s) {
-        const uint32_t n = a.sub_rows[first + s];
         info |= a.sub_info[first + s];
-        const size_t base = row0 + (size_t)s * kLvChunk;
-        auto fetch = [&](uint32_t r0) {
-#pragma unroll
-            for (uint32_t i = 0; i < kPer; ++i) {
-                const uint32_t r = r0 + (uint32_t)wave + i * kLvWaves;
-                reg[i] = r < n ? a.rows[(base + r) * kWave + lane] : 0.0f;
+        const unsigned long long *nzw = a.sub_nz + (size_t)(first + s) * kWords, *yw = a.sub_y + (size_t)(first + s) * kWords;
+        // row list of the sub-task: slot numbers of the set bits, ascending
+        if (wave == 0) {
+            const uint32_t c = lane < (int)kWords ? (uint32_t)__popcll(nzw[lane]) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(c, lane);
+            if (lane < (int)kWords) L.word_off[lane + 1] = incl;
+            if (lane == 0) L.word_off[0] = 0;
+        }
+        __syncthreads();
+        const uint32_t n = L.word_off[kWords];
+        for (uint32_t b = threadIdx.x; b < kLvChunk; b += kLvWaves * kWave) {
+            const unsigned long long wd = nzw[b >> 6];
+            if ((wd >> (b & 63u)) & 1ull) {
+                const uint32_t pos = L.word_off[b >> 6] + (uint32_t)__popcll(wd & ((1ull << (b & 63u)) - 1ull));
+                L.slot[pos] = (uint16_t)b;
+                L.hit[pos] = (uint8_t)((yw[b >> 6] >> (b & 63u)) & 1ull);
             }
+        }
+        __syncthreads();
+        const float4 *rows4 = (const float4 *)(a.rows + (row0 + (size_t)s * kLvChunk) * kWave);
+        auto fetch = [&](float4 (&r)[kLoads], uint32_t r0) {
+            uint32_t sl[kLoads];
+#pragma unroll
+            for (uint32_t i = 0; i < kLoads; ++i) {
+                const uint32_t row = r0 + my_row + i * kRowsPerLoad;
+                sl[i] = row < n ? (uint32_t)L.slot[row] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kLoads; ++i)
+                r[i] = sl[i] != 0xFFFFFFFFu ? rows4[(size_t)sl[i] * 16 + my_quad] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         };
-        if (n) fetch(0);
-        for (uint32_t r0 = 0; r0 < n; r0 += kLvAddRows) {
+        auto tile = [&](float4 (&r)[kLoads], uint32_t r0) {   // r holds tile r0; afterwards the tile kLvAddDepth tiles on
             const uint32_t nr = min(n - r0, kLvAddRows);
 #pragma unroll
-            for (uint32_t i = 0; i < kPer; ++i) L.k[wave + i * kLvWaves][lane] = reg[i];
-            if (threadIdx.x < nr) L.yflag[threadIdx.x] = a.row_y[base + r0 + threadIdx.x];
+            for (uint32_t i = 0; i < kLoads; ++i) *(float4 *)&L.k[my_row + i * kRowsPerLoad][4 * my_quad] = r[i];
             __syncthreads();
-            if (r0 + kLvAddRows < n) fetch(r0 + kLvAddRows);
+            if (r0 + kLvAddDepth * kLvAddRows < n) fetch(r, r0 + kLvAddDepth * kLvAddRows);
             if (wave == 0) {
-                for (uint32_t j = 0; j < nr; ++j) {
-                    const float kv = L.k[j][lane];
-                    ybar += L.yflag[j] ? kv : 0.0f;
-                    kbar += kv;
-                }
+                kbar = lv_add_dense(L.k, (nr + 15u) & ~15u, lane, kbar);   // fetch() zero-fills the tile past the last row
+            } else if (wave == 1) {
+                const unsigned long long m0 = __ballot((uint32_t)lane < nr && L.hit[r0 + lane]);
+                const unsigned long long m1 = __ballot(64u + (uint32_t)lane < nr && L.hit[r0 + 64 + lane]);
+                ybar = lv_add_rows(L.k, m0, lane, ybar);
+                ybar = lv_add_rows(L.k + kWave, m1, lane, ybar);
             }
             __syncthreads();
+        };
+#pragma unroll
+        for (int d = 0; d < kLvAddDepth; ++d)
+            if ((uint32_t)d * kLvAddRows < n) fetch(reg[d], (uint32_t)d * kLvAddRows);
+        for (uint32_t r0 = 0; r0 < n; r0 += kLvAddDepth * kLvAddRows) {
+#pragma unroll
+            for (int d = 0; d < kLvAddDepth; ++d)
+                if (r0 + (uint32_t)d * kLvAddRows < n) tile(reg[d], r0 + (uint32_t)d * kLvAddRows);
         }
     }
+    if (wave == 1) L.ybar[lane] = ybar;
+    __syncthreads();
     if (wave != 0) return;
-    lv_commit(a, t, ybar, kbar, (info >> lane) & 1ull);
+    lv_commit(a, t, L.ybar[lane], kbar, (info >> lane) & 1ull);
 }
 
 }  // namespace la3dm_dev
