@@ -16,6 +16,8 @@
 
 #include "la3dm_ctx.h"
 #include "devmap_kernels.h"
+#include "devmap_scan.h"
+#include "devmap_sort.h"
 #include "devmap_lv_kernels.h"
 
 using namespace la3dm_dev;
@@ -45,12 +47,18 @@ struct la3dm_devmap {
     uint32_t *tab_val = nullptr;
     // small fixed buffers
     uint32_t *d_cnt = nullptr, *h_cnt = nullptr;  // counters (device / pinned host)
-    uint32_t *d_mm = nullptr;
+    uint32_t *d_mm = nullptr;   // [0..5] encoded min / max, [6] arrival counter of the min/max launches
     float *d_bbox = nullptr, *h_bbox = nullptr;
     GridParams *d_gp = nullptr, *h_gp = nullptr;
     // arenas (grow only)
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
     Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big, chunk_desc;
+    Arena scan_status;            // devmap_scan.h: per-tile status words + 2 tickets, zero between launches
+    size_t scan_tiles = 0;
+    Arena radix_state, radix_tmp; // devmap_sort.h: histogram + tickets + two status arrays (zero between sorts); ping-pong buffers
+    size_t radix_tiles = 0;
+    uint32_t radix_seq = 0;       // sorts so far: which of the two histograms is current
+    bool own_sort = true;         // LA3DM_OWN_SORT=0: rocPRIM's radix sort instead (A/B)
     Arena train, grid, axis_tab, m_code, q_out;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
@@ -102,23 +110,117 @@ static int sort_pairs_cfg(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_ou
     return LA3DM_OK;
 }
 
-// Stable sort of (key, value) pairs on the low `end_bit` key bits.  rocPRIM's default hands anything up to 2^20
-// items to its merge sort (log2(n / 1024) partition + merge launch pairs, whatever end_bit says); Onesweep is one
-// launch (+ two state resets) per 8 key bits, so it is the shorter chain above 2^18 items (measured: membership
-// sort of ~5.6e5 pairs 210 -> 170 us; for 4e4 pairs even a 16-bit key sorts faster through the merge path).
+// Stable sort of (key, value) pairs on the low `end_bit` key bits: devmap_sort.h (one histogram launch + one launch per
+// 8 key bits; the input arrays are left as they are).  rocPRIM's sort (LA3DM_OWN_SORT=0) is kept for comparison: above
+// 2^18 items its Onesweep costs three launches per pass, below that its merge sort log2(n / 1024) launch pairs.
 static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
                       uint32_t n, int end_bit) {
     if (n == 0) return LA3DM_OK;
-    return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit);
+    if (!dm->own_sort || end_bit > 32 || end_bit < 1) return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit);
+    hipStream_t st = dm->ctx->stream;
+    const uint32_t n_pass = ((uint32_t)end_bit + 7u) / 8u, tiles = cdiv(n, kRsTile);
+    if (tiles > dm->radix_tiles) {
+        const size_t want = std::max<size_t>(2 * (size_t)tiles, 1024);
+        DM_TRY(hipStreamSynchronize(st));
+        const size_t bytes = 8192 + 64 + 2 * want * 1024;
+        DM_RESERVE(dm->radix_state, bytes);
+        DM_TRY(hipMemsetAsync(dm->radix_state.ptr, 0, bytes, st));   // on the sorts' own stream
+        dm->radix_tiles = want;
+    }
+    RadixState rs;   // layout: two histograms (this sort's, the next sort's), tickets, two status arrays
+    uint32_t *base = (uint32_t *)dm->radix_state.ptr;
+    rs.hist = base + 1024 * (dm->radix_seq & 1u);
+    rs.hist_next = base + 1024 * ((dm->radix_seq + 1u) & 1u);
+    ++dm->radix_seq;
+    rs.ticket = base + 2048;
+    rs.status[0] = base + 2048 + 16;
+    rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
+    DM_RESERVE(dm->radix_tmp, 8ull * n);
+    uint32_t *tk = (uint32_t *)dm->radix_tmp.ptr, *tv = tk + n;
+    hipLaunchKernelGGL(dm_radix_hist, dim3(std::min<uint32_t>(cdiv(n, 4 * kRsThreads), 512u)), dim3(kRsThreads), 0, st, k_in, n, n_pass, rs);
+    const uint32_t *sk = k_in, *sv = v_in;
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        const bool to_out = ((n_pass - 1u - p) & 1u) == 0u;   // the last pass lands in the output arrays
+        RadixArgs a;
+        a.k_in = sk;
+        a.v_in = sv;
+        a.k_out = to_out ? k_out : tk;
+        a.v_out = to_out ? v_out : tv;
+        a.n = n;
+        a.n_pass = n_pass;
+        a.pass = p;
+        a.counters = dm->d_cnt;
+        a.err_slot = (int)kCntError;
+        hipLaunchKernelGGL(dm_radix_pass, dim3(tiles), dim3(kRsThreads), 0, st, a, rs);
+        sk = a.k_out;
+        sv = a.v_out;
+    }
+    DM_TRY(hipGetLastError());
+    return LA3DM_OK;
 }
 
-static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, uint32_t n) {
-    if (n == 0) return LA3DM_OK;
-    hipStream_t st = dm->ctx->stream;
-    size_t tmp = 0;
-    DM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, st));
-    DM_RESERVE(dm->cub_tmp, tmp);
-    DM_TRY(hipcub::DeviceScan::ExclusiveSum(dm->cub_tmp.ptr, tmp, in, out, (int)n, st));
+// state of the single-launch scan (devmap_scan.h) for up to n elements
+static int scan_state(la3dm_devmap *dm, uint32_t n, ScanState &ss) {
+    const size_t tiles = ((size_t)n + kScanTile - 1) / kScanTile;
+    if (tiles > dm->scan_tiles) {
+        const size_t want = std::max<size_t>(2 * tiles, 4096);
+        DM_TRY(hipStreamSynchronize(dm->ctx->stream));
+        DM_RESERVE(dm->scan_status, 8 * want + 16);
+        DM_TRY(hipMemsetAsync(dm->scan_status.ptr, 0, 8 * want + 16, dm->ctx->stream));   // on the scans' own stream
+        dm->scan_tiles = want;
+    }
+    ss.ticket = (uint32_t *)dm->scan_status.ptr;
+    ss.status = (unsigned long long *)((uint8_t *)dm->scan_status.ptr + 16);
+    return LA3DM_OK;
+}
+
+// out[i] = in[0] + ... + in[i-1]; total_slot >= 0: the sum of all n also goes to d_cnt[total_slot]
+static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, uint32_t n, int total_slot = -1) {
+    if (n == 0) {
+        if (total_slot >= 0) DM_TRY(hipMemsetAsync(dm->d_cnt + total_slot, 0, 4, dm->ctx->stream));
+        return LA3DM_OK;
+    }
+    ScanState ss;
+    int rc = scan_state(dm, n, ss);
+    if (rc != LA3DM_OK) return rc;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.out = out;
+    a.n = n;
+    a.counters = dm->d_cnt;
+    a.total_slot = total_slot;
+    a.zero_slot = -1;
+    a.err_slot = (int)kCntError;
+    hipLaunchKernelGGL(dm_scan_lb<false>, dim3(cdiv(n, kScanTile)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
+    DM_TRY(hipGetLastError());
+    return LA3DM_OK;
+}
+
+// Segments of a sorted key array (invalid keys last), one launch: head flags, their exclusive scan, the segment starts
+// (+ keys), d_cnt[seg_slot] = segments, d_cnt[valid_slot] = valid keys, seg_start[segments] = valid keys;
+// zero_slot >= 0: d_cnt[zero_slot] = 0 on the way.
+static int scan_heads(la3dm_devmap *dm, const uint32_t *keys, uint32_t n, uint32_t *flag, uint32_t *scan, uint32_t *seg_start,
+                      uint32_t *seg_key, int seg_slot, int valid_slot, int zero_slot = -1) {
+    ScanState ss;
+    int rc = scan_state(dm, n, ss);
+    if (rc != LA3DM_OK) return rc;
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = keys;
+    a.out = scan;
+    a.n = n;
+    a.counters = dm->d_cnt;
+    a.total_slot = -1;
+    a.flag = flag;
+    a.seg_start = seg_start;
+    a.seg_key = seg_key;
+    a.seg_slot = seg_slot;
+    a.valid_slot = valid_slot;
+    a.zero_slot = zero_slot;
+    a.err_slot = (int)kCntError;
+    hipLaunchKernelGGL(dm_scan_lb<true>, dim3(cdiv(n, kScanTile)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
+    DM_TRY(hipGetLastError());
     return LA3DM_OK;
 }
 
@@ -141,6 +243,10 @@ static int read_counters(la3dm_devmap *dm) {
             break;
         }
         __builtin_ia32_pause();
+    }
+    if (dm->h_cnt[kCntError] & (kScanErrStuck | kRsErrStuck)) {
+        dm->poisoned = true;
+        return dm_fail(dm, LA3DM_ERR_HIP, "devmap: a prefix-sum launch found its state in use (internal error)");
     }
     return LA3DM_OK;
 }
@@ -174,21 +280,18 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     DM_RESERVE(dm->seg_start, 4ull * (n + 1));
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
     uint32_t *flag = (uint32_t *)dm->flag.ptr, *scan = (uint32_t *)dm->scan.ptr, *seg_start = (uint32_t *)dm->seg_start.ptr;
-    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), 512)), dim3(256), 0, st, d_in, n, dm->d_mm);
-    hipLaunchKernelGGL(dm_grid_params, dim3(1), dim3(64), 0, st, dm->d_mm, inv, dm->d_gp);
+    {
+        MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6};
+        hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), 512)), dim3(256), 0, st, d_in, n, dm->d_mm, fin);
+    }
     hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
     int rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
     if (rc != LA3DM_OK) return rc;
-    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGridValid, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(dm_heads, dim3(cdiv(n, 256)), dim3(256), 0, st, k1, n, flag, dm->d_cnt, (int)kCntGridValid);
-    rc = exclusive_scan(dm, flag, scan, n);
+    rc = scan_heads(dm, k1, n, flag, scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid, (int)kCntBig);
     if (rc != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_seg_starts, dim3(cdiv(n, 256)), dim3(256), 0, st, k1, flag, scan, n, seg_start, (uint32_t *)nullptr,
-                       dm->d_cnt, (int)kCntGridSegs, (int)kCntGridValid);
-    DM_TRY(hipMemcpyAsync(dm->h_gp, dm->d_gp, sizeof(GridParams), hipMemcpyDeviceToHost, st));
     rc = read_counters(dm);
     if (rc != LA3DM_OK) return rc;
+    memcpy(dm->h_gp, dm->h_cnt + kCntGrid, sizeof(GridParams));
     if (dm->h_gp->passthrough) {  // index space overflows int32: PCL returns the cloud unfiltered
         DM_RESERVE(out, 12ull * n);
         DM_TRY(hipMemcpyAsync(out.ptr, d_in, 12ull * n, hipMemcpyDeviceToDevice, st));
@@ -200,7 +303,6 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     if (nseg) {
         // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
         DM_RESERVE(dm->big, 4ull * (n / kBigCell + 1));
-        DM_TRY(hipMemsetAsync(dm->d_cnt + kCntBig, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(nseg, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
                            (int)kCntGridSegs, (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
         const uint32_t nchunk = n / kChunk;
@@ -318,6 +420,8 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     {
         const char *mb = getenv("LA3DM_MAILBOX");
         dm->mailbox = !(mb && mb[0] == '0');
+        const char *os = getenv("LA3DM_OWN_SORT");
+        dm->own_sort = !(os && os[0] == '0');
     }
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2)) == hipSuccess &&
@@ -344,7 +448,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
     (void)hipSetDevice(dm->ctx->device);
     Arena *all[] = {&dm->cloud, &dm->hits, &dm->keep, &dm->nfree, &dm->keep_off, &dm->free_off, &dm->frees_raw, &dm->frees_ds,
                     &dm->xy, &dm->k0, &dm->k1, &dm->v0, &dm->v1, &dm->flag, &dm->scan, &dm->seg_start, &dm->seg_key,
-                    &dm->cub_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->q_out, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
+                    &dm->cub_tmp, &dm->scan_status, &dm->radix_state, &dm->radix_tmp, &dm->big, &dm->chunk_desc, &dm->train, &dm->grid, &dm->axis_tab, &dm->m_code, &dm->q_out, &dm->c_flag, &dm->c_weight, &dm->c_scan, &dm->t_key0,
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node,
                     &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan,
@@ -371,16 +475,12 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
 static int training_bbox(la3dm_devmap *dm) {
     hipStream_t st = dm->ctx->stream;
     const uint32_t npts = dm->n_xy;
-    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
+    MinmaxFin fin = {2, 0.0f, nullptr, (const float *)dm->xy.ptr, dm->d_cnt, dm->d_mm + 6};
     hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)dm->xy.ptr, npts,
-                       dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox, (const float *)dm->xy.ptr);
-    if (dm->mailbox) {  // the decoded box goes to the host with the counter block: one pinned-memory mailbox, no stream sync
-        DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
-        return read_counters(dm);
-    }
-    DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
-    DM_TRY(hipStreamSynchronize(st));
+                       dm->d_mm, fin);
+    int rc = read_counters(dm);   // the box comes back with the counter block
+    if (rc != LA3DM_OK) return rc;
+    memcpy(dm->h_bbox, dm->h_cnt + kCntBbox, sizeof(float) * 6);
     return LA3DM_OK;
 }
 
@@ -425,10 +525,8 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
              *free_off = (uint32_t *)dm->free_off.ptr;
     if (ctx->p.variant == 3) {  // BGKLOctoMap: samples keep their beam, no second voxel filter
         hipLaunchKernelGGL(dm_l_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
-        if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
-        if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
-        hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, keep_off, keep, n_h, dm->d_cnt, (int)kCntKept);
-        hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
+        if ((rc = exclusive_scan(dm, keep, keep_off, n_h, (int)kCntKept)) != LA3DM_OK) return rc;
+        if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
         if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
         const uint32_t n_beams = dm->h_cnt[kCntKept], n_samples = dm->h_cnt[kCntFreeRaw];
@@ -444,10 +542,8 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         return training_bbox(dm);
     }
     hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
-    if ((rc = exclusive_scan(dm, keep, keep_off, n_h)) != LA3DM_OK) return rc;
-    if ((rc = exclusive_scan(dm, nfree, free_off, n_h)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, keep_off, keep, n_h, dm->d_cnt, (int)kCntKept);
-    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, free_off, nfree, n_h, dm->d_cnt, (int)kCntFreeRaw);
+    if ((rc = exclusive_scan(dm, keep, keep_off, n_h, (int)kCntKept)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_kept = dm->h_cnt[kCntKept], n_free_raw = dm->h_cnt[kCntFreeRaw];
@@ -575,8 +671,7 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->m_code, 16ull * npts);
     hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, xy, npts, pa, m_cnt,
                        (int4 *)dm->m_code.ptr);
-    if ((rc = exclusive_scan(dm, m_cnt, m_off, npts)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, m_off, m_cnt, npts, dm->d_cnt, (int)kCntMembers);
+    if ((rc = exclusive_scan(dm, m_cnt, m_off, npts, (int)kCntMembers)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_mem = dm->h_cnt[kCntMembers];
     DM_RESERVE(dm->k0, 4ull * n_mem);
@@ -595,11 +690,7 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->seg_key, 4ull * (n_mem + 1));
     uint32_t *sflag = (uint32_t *)dm->c_flag.ptr, *sscan = (uint32_t *)dm->c_scan.ptr;
     uint32_t *train_off = (uint32_t *)dm->seg_start.ptr, *seg_key = (uint32_t *)dm->seg_key.ptr;
-    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGridValid, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(dm_heads, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, k1, n_mem, sflag, dm->d_cnt, (int)kCntGridValid);
-    if ((rc = exclusive_scan(dm, sflag, sscan, n_mem)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_seg_starts, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, k1, sflag, sscan, n_mem, train_off, seg_key,
-                       dm->d_cnt, (int)kCntGeo, (int)kCntGridValid);
+    if ((rc = scan_heads(dm, k1, n_mem, sflag, sscan, train_off, seg_key, (int)kCntGeo, (int)kCntGridValid)) != LA3DM_OK) return rc;
     if (ctx->p.variant == 3) {  // training rows: hits as degenerate segments, every beam once per block
         DM_RESERVE(dm->l_rflag, 4ull * n_mem);
         DM_RESERVE(dm->l_rscan, 4ull * n_mem);
@@ -674,8 +765,13 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     const uint32_t world = dm->shard_world;
     if (!sharded) {
         // heaviest test blocks first (the blocks are independent: order only balances the launch)
-        if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
-                             (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
+        if (n_test <= kSortSmallMax) {
+            uint32_t N = 2;
+            while (N < n_test) N <<= 1;
+            hipLaunchKernelGGL(dm_sort_small, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->t_key0.ptr, (const uint32_t *)dm->t_ent0.ptr,
+                               n_test, N, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent1.ptr);
+        } else if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
+                                    (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
             return rc;
     } else {
         // block-sharded: the list stays in candidate order (block indices x-major: neighbouring test blocks, which share
@@ -701,7 +797,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     // blocks: find or create (bgkoctomap.cpp:298-305)
     if ((rc = grow_pool(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
     if ((rc = grow_table(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
-    DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntBlocks, &dm->n_blocks, 4, hipMemcpyHostToDevice, st));
+    // (d_cnt[kCntBlocks] holds the pool's block count since dm_begin; the passes keep it current)
     hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const long long *)dm->t_blockkey.ptr,
                        dm->d_cnt, dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key,
                        (uint32_t *)dm->t_slot.ptr);
@@ -719,7 +815,6 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     DM_RESERVE(dm->leaf_node, 4 * max_leaves);
     DM_RESERVE(dm->leaf_state, max_leaves);
     uint32_t *nleaf = (uint32_t *)dm->nleaf.ptr, *leaf_off = (uint32_t *)dm->leaf_off.ptr;
-    DM_TRY(hipMemsetAsync(nleaf + n_test, 0, 4, st));
     hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                        (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
@@ -729,8 +824,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     else
         hipLaunchKernelGGL(dm_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
                            (const uint32_t *)nleaf, n_test, dm->d_cnt);
-    if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, leaf_off, nleaf, n_test + 1, dm->d_cnt, (int)kCntLeaves);
+    if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1, (int)kCntLeaves)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                        (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                        (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
@@ -897,7 +991,7 @@ int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, 
     S.n_blocks = dm->n_blocks;
     dm->n_xy = 0;
     const double t0 = wall();
-    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+    hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, st, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);
     if (n == 0) {  // bgkoctomap.cpp:83-84
         if (stats_out) *stats_out = S;
         return LA3DM_OK;
@@ -963,10 +1057,8 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         hipLaunchKernelGGL(dm_lv_beams, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
                            (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
     }
-    if ((rc = exclusive_scan(dm, nsamp, samp_off, nh)) != LA3DM_OK) return rc;
-    if ((rc = exclusive_scan(dm, nray, ray_off, nh)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, samp_off, nsamp, nh, dm->d_cnt, (int)kCntFreeRaw);
-    hipLaunchKernelGGL(dm_scan_total, dim3(1), dim3(64), 0, st, ray_off, nray, nh, dm->d_cnt, (int)kCntKept);
+    if ((rc = exclusive_scan(dm, nsamp, samp_off, nh, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, nray, ray_off, nh, (int)kCntKept)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t ns = dm->h_cnt[kCntFreeRaw], n_rays = dm->h_cnt[kCntKept];
@@ -983,9 +1075,10 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     dm->lv_n_rays = n_rays;
     L.n_hits = dm->h_cnt[kCntTrained];
     // bounding box of ALL samples (std::min / std::max chains from samples[0]: bgklvoctomap.cpp:105-112)
-    hipLaunchKernelGGL(dm_minmax_init, dim3(1), dim3(64), 0, st, dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(ns, 1024), 512)), dim3(256), 0, st, (const float *)samples, ns, dm->d_mm);
-    hipLaunchKernelGGL(dm_minmax_decode, dim3(1), dim3(64), 0, st, dm->d_mm, dm->d_bbox, (const float *)samples);
+    {
+        MinmaxFin fin = {2, 0.0f, nullptr, (const float *)samples, dm->d_cnt, dm->d_mm + 6};
+        hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(ns, 1024), 512)), dim3(256), 0, st, (const float *)samples, ns, dm->d_mm, fin);
+    }
     // bucket bounds of the finite samples
     const int depth = ctx->p.block_depth;
     const float bs = dm->block_size;
@@ -997,8 +1090,8 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     }
     hipLaunchKernelGGL(dm_lv_cell_bounds, dim3(cdiv(ns, 256)), dim3(256), 0, st, (const float4 *)samples, ns, half, g, dm->d_lvmm, dm->d_cnt);
     DM_TRY(hipMemcpyAsync(dm->h_lvmm, dm->d_lvmm, 32, hipMemcpyDeviceToHost, st));
-    DM_TRY(hipMemcpyAsync(dm->h_bbox, dm->d_bbox, sizeof(float) * 6, hipMemcpyDeviceToHost, st));
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    memcpy(dm->h_bbox, dm->h_cnt + kCntBbox, sizeof(float) * 6);
     if (dm->h_cnt[kCntError] & kErrLvExtent) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): sample coordinates beyond the gather grid's index range");
     for (int a = 0; a < 6; ++a)
         if (dm->h_bbox[a] != dm->h_bbox[a]) return LA3DM_OK;  // NaN box (first sample not finite): no candidate block, as on the host
@@ -1088,15 +1181,9 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     DM_RESERVE(dm->lv_pos, 4ull * nc);
     DM_RESERVE(dm->lv_slot, 4ull * nc);
     hipLaunchKernelGGL(dm_lv_candidates, dim3(cdiv(nc, 256)), dim3(256), 0, st, ca, nc, (const uint32_t *)dm->lv_cell_off.ptr,
-                       (long long *)dm->lv_keys.ptr, (uint32_t *)dm->lv_mult.ptr, (uint32_t *)dm->lv_flag.ptr);
+                       (long long *)dm->lv_keys.ptr, (uint32_t *)dm->lv_mult.ptr, (uint32_t *)dm->lv_flag.ptr, dm->d_cnt);
     if ((rc = grow_pool(dm, (size_t)dm->n_blocks + nc)) != LA3DM_OK) return rc;
     if ((rc = grow_table(dm, (size_t)dm->n_blocks + nc)) != LA3DM_OK) return rc;
-    {
-        const uint32_t two[2] = {nc, dm->n_blocks};
-        DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntTest, &two[0], 4, hipMemcpyHostToDevice, st));
-        DM_TRY(hipMemcpyAsync(dm->d_cnt + kCntBlocks, &two[1], 4, hipMemcpyHostToDevice, st));
-        DM_TRY(hipStreamSynchronize(st));
-    }
     hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(nc, 256)), dim3(256), 0, st, (const long long *)dm->lv_keys.ptr, dm->d_cnt, dm->tab_key,
                        dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key, (uint32_t *)dm->lv_slot.ptr);
     hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)nc * dm->npb, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S, dm->n_blocks,
@@ -1280,7 +1367,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     S.n_blocks = dm->n_blocks;
     dm->n_xy = 0;
     const double t0 = wall();
-    DM_TRY(hipMemsetAsync(dm->d_cnt, 0, sizeof(uint32_t) * kCntWords, st));
+    hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, st, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);
     if (ctx->p.variant == 2) {
         rc = lv_insert(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range, t0);
         if (rc != LA3DM_OK) lv_recover(dm);

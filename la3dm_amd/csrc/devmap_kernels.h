@@ -48,7 +48,9 @@ enum DevCounter {
     kCntPairEvals = 14,  // 64-bit (words 14, 15): sum of neighbourhood points x leaves; kCntTrainReads likewise (10, 11)
     kCntBeamTotal = 16,  // 64-bit (words 16, 17): beam samples of the scan, summed without the 32-bit wrap of the offsets
     kCntLvPlan = 18,     // BGK-LV work plan (words 18-20): workgroups, scratch rows, split cubes
-    kCntWords = 21
+    kCntGrid = 21,       // GridParams of the last voxel-filter call (10 words), for the host
+    kCntBbox = 31,       // training-set box (6 floats as bits), for the host
+    kCntWords = 37
 };
 
 struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call
@@ -78,9 +80,27 @@ __global__ void dm_minmax_init(uint32_t *mm) {
     else if (threadIdx.x < 6) mm[threadIdx.x] = 0u;
 }
 
+// What the LAST workgroup of a min/max launch does with the result (it then resets mm and the arrival counter, so that
+// neither a reset launch before nor a one-thread launch after the reduction is needed):
+//   mode 1: the voxel filter's GridParams (-> gp for the kernels, counters[kCntGrid..] for the host)
+//   mode 2: the training set's box (-> counters[kCntBbox..]).  The reference (bbox(), bgkoctomap.cpp:464-484) reduces
+//           with `<`, which a NaN never wins: NaN coordinates are ignored — except in the FIRST training point, which
+//           seeds the reduction and then never loses (restated as a min / max chain from xy[0]): that axis' limits stay
+//           NaN, get_blocks_in_bbox makes no step and the scan is a no-op.  `first` = xy[0] (x, y, z, label).
+struct MinmaxFin {
+    int mode;
+    float inv;
+    GridParams *gp;
+    const float *first;
+    uint32_t *counters;
+    uint32_t *done;      // zero between launches
+};
+__device__ void grid_params_from(const uint32_t *mmv, float inv, GridParams &g);
+
 template <int kStride>
-__global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, uint32_t n, uint32_t *mm) {
+__global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, uint32_t n, uint32_t *mm, MinmaxFin fin) {
     __shared__ float red[4][6];
+    __shared__ uint32_t s_last;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float x = p[(size_t)kStride * i], y = p[(size_t)kStride * i + 1], z = p[(size_t)kStride * i + 2];
@@ -108,29 +128,42 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
         const int a = threadIdx.x;
         float v = red[0][a];
         for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+        // (returning atomics: the arrival count below must not overtake them; no fence — a release fence writes the
+        // whole L2 back, which doubled this kernel's time after a producer of tens of MB)
+        uint32_t prev = 0;
         if (a < 3) {
-            if (v != INFINITY) atomicMin(&mm[a], enc_f32(v));
+            if (v != INFINITY) prev = atomicMin(&mm[a], enc_f32(v));
         } else {
-            if (v != -INFINITY) atomicMax(&mm[a], enc_f32(v));
+            if (v != -INFINITY) prev = atomicMax(&mm[a], enc_f32(v));
+        }
+        asm volatile("" ::"v"(prev));
+    }
+    if (fin.mode == 0) return;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(fin.done, 1u) + 1u == gridDim.x ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    uint32_t mmv[6];
+    for (int a = 0; a < 6; ++a) {
+        mmv[a] = __hip_atomic_load(&mm[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mm[a] = a < 3 ? 0xFFFFFFFFu : 0u;
+    }
+    *fin.done = 0u;
+    if (fin.mode == 1) {
+        GridParams g;
+        grid_params_from(mmv, fin.inv, g);
+        *fin.gp = g;
+        const int *gi = (const int *)&g;
+        for (int k = 0; k < (int)(sizeof(GridParams) / 4); ++k) fin.counters[kCntGrid + k] = (uint32_t)gi[k];
+    } else {
+        for (int a = 0; a < 6; ++a) {
+            const float f = fin.first[a % 3];
+            fin.counters[kCntBbox + a] = __float_as_uint(f != f ? f : dec_f32(mmv[a]));
         }
     }
 }
 
-// decoded min/max for the host (bbox of the training set)
-// bbox of the training set.  The reference (bbox(), bgkoctomap.cpp:464-484) reduces with `<`, which a NaN never wins:
-// NaN coordinates are ignored — except in the FIRST training point, which seeds the reduction and then never loses
-// (restated as a min / max chain from xy[0]): that axis' limits stay NaN, get_blocks_in_bbox makes no step and the
-// scan is a no-op.  `first` = xy[0] (x, y, z, label).
-__global__ void dm_minmax_decode(const uint32_t *mm, float *out, const float *first) {
-    if (threadIdx.x < 6) {
-        const float f = first[threadIdx.x % 3];
-        out[threadIdx.x] = f != f ? f : dec_f32(mm[threadIdx.x]);
-    }
-}
-
-__global__ void dm_grid_params(const uint32_t *mm, float inv, GridParams *gp) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    GridParams g;
+__device__ void grid_params_from(const uint32_t *mm, float inv, GridParams &g) {
     g.passthrough = 0;
     g.empty = mm[0] == 0xFFFFFFFFu && mm[3] == 0u;
     float mn[3], mx[3];
@@ -141,7 +174,6 @@ __global__ void dm_grid_params(const uint32_t *mm, float inv, GridParams *gp) {
     if (g.empty) {
         for (int a = 0; a < 3; ++a) g.lo[a] = 0, g.span[a] = 1;
         g.m1 = g.m2 = 1;
-        *gp = g;
         return;
     }
     const long long ex = (long long)((mx[0] - mn[0]) * inv) + 1, ey = (long long)((mx[1] - mn[1]) * inv) + 1,
@@ -153,7 +185,47 @@ __global__ void dm_grid_params(const uint32_t *mm, float inv, GridParams *gp) {
     }
     g.m1 = g.span[0];
     g.m2 = g.span[0] * g.span[1];
-    *gp = g;
+}
+
+// Stable ascending sort of n <= 4096 (key, value) pairs in ONE workgroup: a bitonic network over (key << 32 | position)
+// in LDS (the library sort is 7-9 dependent launches whatever n is; a pass's test-block list has a few hundred to a
+// few thousand entries).  N = n rounded up to a power of two.
+constexpr uint32_t kSortSmallMax = 4096;
+__global__ __launch_bounds__(1024) void dm_sort_small(const uint32_t *__restrict__ k_in, const uint32_t *__restrict__ v_in, uint32_t n,
+                                                     uint32_t N, uint32_t *__restrict__ k_out, uint32_t *__restrict__ v_out) {
+    __shared__ unsigned long long e[kSortSmallMax];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < N; i += 1024) e[i] = i < n ? ((unsigned long long)k_in[i] << 32) | i : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < N; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = e[i], y = e[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        e[i] = y;
+                        e[l] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned long long x = e[i];
+        k_out[i] = (uint32_t)(x >> 32);
+        v_out[i] = v_in[(uint32_t)x];
+    }
+}
+
+// start of an insert: the counter block is zero except the pool's block count, the min/max words are at their identities
+__global__ void dm_begin(uint32_t *counters, uint32_t n_blocks, uint32_t *mm, uint32_t *done) {
+    const uint32_t i = threadIdx.x;
+    if (i < (uint32_t)kCntWords) counters[i] = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
+    if (i < 3) mm[i] = 0xFFFFFFFFu;
+    else if (i < 6) mm[i] = 0u;
+    if (i == 6) *done = 0u;
 }
 
 // cell index of every point (kInvalidCell for non-finite points), value = cloud index
@@ -1126,6 +1198,7 @@ __global__ __launch_bounds__(256) void dm_leaves(const uint32_t *__restrict__ sl
                                                 float *alpha, float *beta, uint32_t *leaf_node) {
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) nleaf[counters[kCntTest]] = 0;   // the scan runs over n_test + 1 counts
     if (t >= counters[kCntTest]) return;
     const size_t base = (size_t)slot[t] * npb;
     const uint8_t *Sb = S + base;

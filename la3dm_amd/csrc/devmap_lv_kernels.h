@@ -375,9 +375,10 @@ struct LvCandArgs {
 };
 __global__ __launch_bounds__(256) void dm_lv_candidates(LvCandArgs a, uint32_t n_cand, const uint32_t *__restrict__ cell_off,
                                                        long long *__restrict__ keys, uint32_t *__restrict__ mult,
-                                                       uint32_t *__restrict__ flag) {
+                                                       uint32_t *__restrict__ flag, uint32_t *counters) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_cand) return;
+    if (t == 0) counters[kCntTest] = n_cand;   // dm_table_insert takes its key count from there
     const uint32_t iz = t % a.n[2], iy = (t / a.n[2]) % a.n[1], ix = t / (a.n[2] * a.n[1]);
     const long long kx = a.idx[0][ix], ky = a.idx[1][iy], kz = a.idx[2][iz];
     keys[t] = (kx << 40) | (ky << 20) | kz;

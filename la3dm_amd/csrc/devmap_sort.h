@@ -1,0 +1,220 @@
+// devmap_sort.h — stable LSD radix sort of (key, value) pairs, 8 bits per pass, ONE launch per pass plus one histogram
+// launch per sort, for the device-resident map's front end (devmap.hip).
+//
+// Why not the library sort: rocPRIM's Onesweep costs three dependent launches per pass (two state resets + the pass)
+// and its merge-sort fallback 7-9 for the sizes that occur here; each dependent launch is ≈ 4.7 us on this GPU whatever it
+// does, and a scan runs three sorts.  Same algorithm family (Onesweep: chained per-digit prefix with decoupled
+// look-back), but the state cleans itself: the histogram launch clears status array 0, every pass clears the rows of
+// the status array the NEXT pass uses, the last workgroup of a pass resets the tickets (and, in the last pass, the
+// histogram).  Everything is zero between sorts.
+//
+// Stability (the voxel filter's fp32 centroid sums depend on it): a tile is 4 waves x 16 rows x 64 lanes of consecutive
+// items, ranked row by row inside a wave (ballot matching), wave after wave, tile after tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace la3dm_dev {
+
+constexpr uint32_t kRsThreads = 256, kRsWaves = 4, kRsRows = 16, kRsTile = kRsThreads * kRsRows;   // 4096 items per tile
+constexpr uint32_t kRsErrStuck = 16u;
+constexpr int kRsLook = 16;   // predecessor tiles whose status words are in flight at a time
+
+struct RadixState {
+    uint32_t *hist;       // [4][256] digit counts of the sort in flight (zero before its histogram launch)
+    uint32_t *hist_next;  // [4][256] the histogram of the NEXT sort: the histogram launch clears it
+    uint32_t *status[2];  // [tiles][256] per array: bits 31..30 = 0 empty / 1 tile count / 2 inclusive prefix, low 30 bits = value
+    uint32_t *ticket;     // [0] next tile, [1] tiles finished (sorts of more than kRsResident tiles only)
+};
+
+struct RadixArgs {
+    const uint32_t *k_in, *v_in;
+    uint32_t *k_out, *v_out;
+    uint32_t n, n_pass, pass;
+    uint32_t *counters;
+    int err_slot;
+};
+
+// Tiles take their number from the workgroup id while all of a sort's workgroups fit on the chip at once (256 CUs x 4
+// workgroups of 38 KB LDS): no workgroup can then wait for one that has no slot.  Larger sorts draw tickets.  Every
+// device-scope atomic with a returned value costs a ~2.5 us round trip, and a pass is a chain of them: ticket, look-back,
+// arrival count — the resident form has only the look-back left.
+constexpr uint32_t kRsResident = 1024;
+
+__device__ __forceinline__ uint32_t rs_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rs_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// exclusive prefix over the 256 threads' values (one per thread)
+__device__ __forceinline__ uint32_t rs_scan256(uint32_t v, uint32_t tid, uint32_t *s_part) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)(tid & 63u) >= d) incl += o;
+    }
+    __syncthreads();
+    if ((tid & 63u) == 63u) s_part[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) off += s_part[w];
+    return off + incl - v;
+}
+
+// digit counts of all passes in one sweep over the keys.  Also clears status array 0 for the first pass and the next
+// sort's histogram.
+__global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__restrict__ keys, uint32_t n, uint32_t n_pass, RadixState st) {
+    __shared__ uint32_t h[4][256];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t p = 0; p < 4; ++p) h[p][tid] = 0;
+    const uint32_t n_tiles = (n + kRsTile - 1) / kRsTile;
+    for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n_tiles * 256u; i += gridDim.x * kRsThreads) st.status[0][i] = 0u;
+    if (blockIdx.x == 0)
+        for (uint32_t p = 0; p < 4; ++p) st.hist_next[p * 256u + tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n; i += gridDim.x * kRsThreads) {
+        const uint32_t k = keys[i];
+        const unsigned long long act = __ballot(true);
+        for (uint32_t p = 0; p < n_pass; ++p) {
+            // the high digits of grid-cell keys are the same for whole waves: one add instead of 64 colliding LDS atomics
+            const uint32_t d = (k >> (8u * p)) & 255u, d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            if (__ballot(d == d0) == act) {
+                if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&h[p][d0], (uint32_t)__popcll(act));
+            } else {
+                atomicAdd(&h[p][d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        const uint32_t c = h[p][tid];
+        if (c) atomicAdd(&st.hist[p * 256u + tid], c);
+    }
+}
+
+__global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixState st) {
+    __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
+    __shared__ uint32_t s_wcnt[kRsWaves][256];
+    __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64];
+    __shared__ uint32_t s_tile, s_last;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = 8u * a.pass;
+    const bool tickets = n_tiles > kRsResident;
+    uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
+    if (tickets && tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
+#pragma unroll
+    for (uint32_t w = 0; w < kRsWaves; ++w) s_wcnt[w][tid] = 0u;
+    const uint32_t total_d = st.hist[a.pass * 256u + tid];   // keys with digit tid in this pass (written by the histogram launch)
+    __syncthreads();
+    const uint32_t tile = tickets ? s_tile : blockIdx.x;
+    other[tile * 256u + tid] = 0u;   // my row of the array the next pass (or the next sort's second pass) uses
+    auto finish = [&]() {   // ticket form only: the last workgroup out resets the two counters
+        if (!tickets) return;
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(st.ticket + 1, 1u) + 1u == n_tiles ? 1u : 0u;
+        __syncthreads();
+        if (s_last && tid < 2) st.ticket[tid] = 0u;
+    };
+    // every key has the same digit in this pass (the top byte of grid-cell keys, mostly): the pass is a copy
+    if (__syncthreads_or(total_d == a.n)) {
+        const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
+        for (uint32_t j = tid; j < in_tile; j += kRsThreads) {
+            a.k_out[tile * kRsTile + j] = a.k_in[tile * kRsTile + j];
+            a.v_out[tile * kRsTile + j] = a.v_in[tile * kRsTile + j];
+        }
+        finish();
+        return;
+    }
+    // ---- load: wave w holds items [tile * 4096 + w * 1024, + 1024), row r = 64 consecutive items
+    const uint32_t i0 = tile * kRsTile + wave * (kRsRows * 64u) + lane;
+    uint32_t key[kRsRows], val[kRsRows], rank[kRsRows];
+#pragma unroll
+    for (uint32_t r = 0; r < kRsRows; ++r) {
+        const uint32_t i = i0 + r * 64u;
+        key[r] = i < a.n ? a.k_in[i] : 0xFFFFFFFFu;
+        val[r] = i < a.n ? a.v_in[i] : 0u;
+    }
+    const uint32_t digit_base = rs_scan256(total_d, tid, s_part);   // first output position of digit tid
+    // ---- rank inside the wave, row after row: peers = lanes of the row with my digit
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    volatile uint32_t *wc = s_wcnt[wave];
+#pragma unroll
+    for (uint32_t r = 0; r < kRsRows; ++r) {
+        const bool valid = i0 + r * 64u < a.n;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t prev = wc[d];
+        rank[r] = prev + (uint32_t)__popcll(peers & lt);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt) == 0ull) wc[d] = prev + (uint32_t)__popcll(peers);   // the lowest peer
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- per digit (thread = digit): count in the tile, wave offsets, tile-local start
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kRsWaves; ++w) {
+        const uint32_t c = s_wcnt[w][tid];
+        s_wcnt[w][tid] = cnt;   // exclusive over the waves
+        cnt += c;
+    }
+    // ---- chained prefix over the tiles, one digit per thread, kRsLook predecessors in flight (all tiles of a front-end
+    // sort are resident at once and publish their counts together: a tile walks back over most of its predecessors)
+    uint32_t excl = 0;
+    if (tile == 0) {
+        rs_st(&status[tid], (2u << 30) | cnt);
+    } else {
+        rs_st(&status[tile * 256u + tid], (1u << 30) | cnt);
+    }
+    s_start[tid] = rs_scan256(cnt, tid, s_part);
+    if (tile != 0) {
+        bool done = false;
+        for (int idx = (int)tile - 1; !done; idx -= kRsLook) {
+            uint32_t s[kRsLook];
+#pragma unroll
+            for (int u = 0; u < kRsLook; ++u) s[u] = idx - u >= 0 ? rs_ld(&status[(uint32_t)(idx - u) * 256u + tid]) : (2u << 30);
+#pragma unroll
+            for (int u = 0; u < kRsLook; ++u) {
+                if (done) break;
+                for (uint32_t spins = 0; (s[u] >> 30) == 0u; ++spins) {
+                    s[u] = rs_ld(&status[(uint32_t)(idx - u) * 256u + tid]);
+                    if (spins > (1u << 22)) {   // seconds: the state was not clean when the sort began — give up, flag it
+                        atomicOr(&a.counters[a.err_slot], kRsErrStuck);
+                        s[u] = 2u << 30;
+                    }
+                }
+                excl += s[u] & 0x3FFFFFFFu;
+                done = (s[u] >> 30) == 2u;
+            }
+        }
+        rs_st(&status[tile * 256u + tid], (2u << 30) | (excl + cnt));
+    }
+    s_gbase[tid] = digit_base + excl;
+    __syncthreads();
+    // ---- reorder through LDS, then write runs of equal digits
+#pragma unroll
+    for (uint32_t r = 0; r < kRsRows; ++r) {
+        if (i0 + r * 64u < a.n) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = s_start[d] + s_wcnt[wave][d] + rank[r];
+            s_key[pos] = key[r];
+            s_val[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
+    for (uint32_t j = tid; j < in_tile; j += kRsThreads) {
+        const uint32_t k = s_key[j], d = (k >> shift) & 255u;
+        const uint32_t g = s_gbase[d] + (j - s_start[d]);
+        a.k_out[g] = k;
+        a.v_out[g] = s_val[j];
+    }
+    finish();
+}
+
+}  // namespace la3dm_dev
