@@ -443,8 +443,8 @@ __device__ __forceinline__ float bcast_half(float v, int half) {
 
 __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__restrict__ L, const float4 *__restrict__ x,
                                               const float *__restrict__ al, const int N, const float tx, const float ty,
-                                              const float tz, float *__restrict__ vg, const int lane, float &mj_out,
-                                              float &ss_out) {
+                                              const float tz, float *__restrict__ vg, float *lds, const int lane,
+                                              float &mj_out, float &ss_out) {
     const int c = lane & 31, h = lane >> 5;
     const float t0x = __shfl(tx, c), t0y = __shfl(ty, c), t0z = __shfl(tz, c);
     const float t1x = __shfl(tx, 32 + c), t1y = __shfl(ty, 32 + c), t1z = __shfl(tz, 32 + c);
@@ -454,6 +454,34 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
         const int R0 = 32 * K;
         f32x16 C0, C1;
         float alv[16];
+        // the diagonal tile L[K][K] (used after the MFMAs): fetched like the A tiles, in flight during the kernel evaluations
+        float (*s_d)[36] = reinterpret_cast<float (*)[36]>(lds + 2 * 32 * 36);
+        float4 gd[4];
+        {
+            const int trow_ = lane >> 3, tcol_ = 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = R0 + 8 * i + trow_, col = R0 + tcol_;
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < N) {
+                    if (col + 3 < N) {
+                        __builtin_memcpy(&q, L + (size_t)row * N + col, 16);
+                    } else {   // the last block row: the tile sticks out of the matrix
+                        const float *p = L + (size_t)row * N;
+                        q.x = col < N ? p[col] : 0.f;
+                        q.y = col + 1 < N ? p[col + 1] : 0.f;
+                        q.z = col + 2 < N ? p[col + 2] : 0.f;
+                    }
+                } else {   // padded row: identity
+                    const int rr = 8 * i + trow_;
+                    q.x = rr == tcol_ ? 1.f : 0.f;
+                    q.y = rr == tcol_ + 1 ? 1.f : 0.f;
+                    q.z = rr == tcol_ + 2 ? 1.f : 0.f;
+                    q.w = rr == tcol_ + 3 ? 1.f : 0.f;
+                }
+                gd[i] = q;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // Ks(k, j) = k(x_k, xs_j) in accumulator layout
             const int row = R0 + 8 * (r >> 2) + 4 * h + (r & 3);
@@ -478,27 +506,69 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 mj1 = bcast_half(mj1, hh);
             }
         }
-        // off-diagonal blocks on the matrix cores: C -= L[K][J] V[J].  The operands of block J + 1 are fetched
-        // while the 32 MFMAs of block J run (one memory round trip per block instead of one per k-pair).
         {
-            const int arow = R0 + c;
-            const bool avalid = arow < N;
-            const float *Lrow = L + (size_t)(avalid ? arow : 0) * N;
+            const int trow_ = lane >> 3, tcol_ = 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&s_d[8 * i + trow_][tcol_]) = gd[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // off-diagonal blocks on the matrix cores: C -= L[K][J] V[J].  The A operand wants lane c = row R0 + c, i.e. 32
+        // different rows (cache lines) per load if it is read straight from the row-major factor — the address unit then
+        // spends ~32 cycles per load and bounds the kernel.  The 32 x 32 tile is fetched as four coalesced 16-byte loads
+        // per lane instead (8 rows x 128 B per instruction), negated, passed through LDS ([row][36], two buffers) and
+        // read back in operand layout.  Tile J + 2 is in flight and tile J + 1 in LDS while the 32 MFMAs of block J run.
+        {
+            float (*s_t)[32][36] = reinterpret_cast<float (*)[32][36]>(lds);
+            const int trow = lane >> 3, tcol = 4 * (lane & 7);
+            float4 g[4];
             float av[16];
             float2 bv[16];
-            auto fetch = [&](int J, float (&A_)[16], float2 (&B_)[16]) {
+            auto load_tile = [&](int J) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = R0 + 8 * i + trow;
+                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < N) __builtin_memcpy(&q, L + (size_t)row * N + 32 * J + tcol, 16);   // 4-byte aligned
+                    g[i] = q;
+                }
+            };
+            auto store_tile = [&](int buf) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4 *>(&s_t[buf][8 * i + trow][tcol]) = make_float4(-g[i].x, -g[i].y, -g[i].z, -g[i].w);
+            };
+            auto read_ops = [&](int J, int buf, float (&A_)[16], float2 (&B_)[16]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 q = *reinterpret_cast<const float4 *>(&s_t[buf][c][4 * i]);
+                    A_[2 * i] = h ? q.y : q.x;
+                    A_[2 * i + 1] = h ? q.w : q.z;
+                }
 #pragma unroll
                 for (int m2 = 0; m2 < 16; ++m2) {
                     const int kcol = 32 * J + 2 * m2 + h;
-                    A_[m2] = avalid ? -Lrow[kcol] : 0.0f;
                     B_[m2] = *reinterpret_cast<const float2 *>(vg + (size_t)kcol * kWave + 2 * c);
                 }
             };
-            if (K > 0) fetch(0, av, bv);
+            if (K > 0) {
+                load_tile(0);
+                store_tile(0);
+                if (K > 1) load_tile(1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                read_ops(0, 0, av, bv);
+            }
             for (int J = 0; J < K; ++J) {
                 float an[16];
                 float2 bn[16];
-                if (J + 1 < K) fetch(J + 1, an, bn);
+                if (J + 1 < K) {
+                    store_tile((J + 1) & 1);   // g holds tile J + 1; buffer (J + 1) & 1 was last read for block J - 1
+                    if (J + 2 < K) load_tile(J + 2);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    read_ops(J + 1, (J + 1) & 1, an, bn);
+                }
 #pragma unroll
                 for (int m2 = 0; m2 < 16; ++m2) {
                     C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m2], bv[m2].x, C0, 0, 0, 0);
@@ -524,15 +594,21 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 const int r = 4 * G + j;
                 const int row = R0 + r;
                 const bool valid = row < N;  // wave-uniform
-                const float *Ld = L + (size_t)(valid ? row : 0) * N + R0;
+                // row r of the diagonal tile from LDS, four entries per (broadcast) read; a padded row is a row of the identity
+                float lrow[32];
+#pragma unroll
+                for (int w4 = 0; w4 <= r / 4; ++w4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(&s_d[r][4 * w4]);
+                    lrow[4 * w4] = q.x; lrow[4 * w4 + 1] = q.y; lrow[4 * w4 + 2] = q.z; lrow[4 * w4 + 3] = q.w;
+                }
                 float acc0 = C0[base + j], acc1 = C1[base + j];
 #pragma unroll
                 for (int w = 0; w < r; ++w) {
-                    const float lw = valid ? Ld[w] : 0.0f;
+                    const float lw = lrow[w];
                     acc0 = __builtin_fmaf(-lw, vb0[w], acc0);
                     acc1 = __builtin_fmaf(-lw, vb1[w], acc1);
                 }
-                const float d = valid ? Ld[r] : 1.0f;
+                const float d = lrow[r];
                 const float v0 = acc0 / d, v1 = acc1 / d;
                 vb0[r] = v0;  // right in the owning half; the other half is repaired after the group
                 vb1[r] = v1;
@@ -637,7 +713,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
         } else {
-            gp_solve_mfma(a, L, x, al, N, tx, ty, tz, vg, lane, mj, ss);
+            gp_solve_mfma(a, L, x, al, N, tx, ty, tz, vg, s_vraw, lane, mj, ss);   // (its tile staging reuses the LDS of the small path)
         }
         const float var = a.sf2 - ss;
         gp_node_update_dev(a, m_ivar, ivar, state, mj, var);
