@@ -95,7 +95,9 @@ def torch_allgather(dist, rank, device, stage_through_host=False):
             dist.all_gather_into_tensor(out, mine.cpu())
             buf.copy_(out)
         else:
-            dist.all_gather_into_tensor(buf, mine)   # in place: the input is slice `rank` of the output
+            # (the input is slice `rank` of the output; a private copy of it — a few MB — keeps the call clear of any
+            # in-place / aliasing rule of the backend)
+            dist.all_gather_into_tensor(buf, mine.clone())
         torch.cuda.synchronize(device)
 
     return allgather
