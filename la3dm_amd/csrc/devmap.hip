@@ -54,7 +54,8 @@ struct la3dm_devmap {
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
     Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big, chunk_desc;
     Arena scan_status;            // devmap_scan.h: per-tile status words + 2 tickets, zero between launches
-    size_t scan_tiles = 0;
+    size_t scan_tiles = 0, scan_dirty[2] = {0, 0};   // status entries in use per array
+    uint32_t scan_seq = 0;
     Arena radix_state, radix_tmp; // devmap_sort.h: histogram + tickets + two status arrays (zero between sorts); ping-pong buffers
     size_t radix_tiles = 0;
     uint32_t radix_seq = 0;       // sorts so far: which of the two histograms is current
@@ -97,6 +98,10 @@ static int dm_fail(la3dm_devmap *dm, int code, const std::string &msg) {
     return code;
 }
 
+// Workgroups of a launch that ends in atomics on a handful of addresses (min/max words, arrival counters): a device-scope
+// atomic on one address costs ~25 ns per workgroup, serialised — 512 workgroups spent 12 us on them, whatever the data.
+constexpr uint32_t kMinmaxWgs = 128;
+
 // ---- library plumbing: device-wide sort / scan (rocPRIM through hipCUB) ---------------------------------
 template <size_t kMergeLimit>
 static int sort_pairs_cfg(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
@@ -122,22 +127,22 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
     if (tiles > dm->radix_tiles) {
         const size_t want = std::max<size_t>(2 * (size_t)tiles, 1024);
         DM_TRY(hipStreamSynchronize(st));
-        const size_t bytes = 8192 + 64 + 2 * want * 1024;
+        const size_t bytes = 2 * 4096 * kRsHistCopies + 64 + 2 * want * 1024;
         DM_RESERVE(dm->radix_state, bytes);
         DM_TRY(hipMemsetAsync(dm->radix_state.ptr, 0, bytes, st));   // on the sorts' own stream
         dm->radix_tiles = want;
     }
     RadixState rs;   // layout: two histograms (this sort's, the next sort's), tickets, two status arrays
     uint32_t *base = (uint32_t *)dm->radix_state.ptr;
-    rs.hist = base + 1024 * (dm->radix_seq & 1u);
-    rs.hist_next = base + 1024 * ((dm->radix_seq + 1u) & 1u);
+    rs.hist = base + 1024 * kRsHistCopies * (dm->radix_seq & 1u);
+    rs.hist_next = base + 1024 * kRsHistCopies * ((dm->radix_seq + 1u) & 1u);
     ++dm->radix_seq;
-    rs.ticket = base + 2048;
-    rs.status[0] = base + 2048 + 16;
+    rs.ticket = base + 2048 * kRsHistCopies;
+    rs.status[0] = base + 2048 * kRsHistCopies + 16;
     rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
     DM_RESERVE(dm->radix_tmp, 8ull * n);
     uint32_t *tk = (uint32_t *)dm->radix_tmp.ptr, *tv = tk + n;
-    hipLaunchKernelGGL(dm_radix_hist, dim3(std::min<uint32_t>(cdiv(n, 4 * kRsThreads), 512u)), dim3(kRsThreads), 0, st, k_in, n, n_pass, rs);
+    hipLaunchKernelGGL(dm_radix_hist, dim3(std::max<uint32_t>(std::min<uint32_t>(cdiv(n, 4 * kRsThreads), 512u), kRsHistCopies)), dim3(kRsThreads), 0, st, k_in, n, n_pass, rs);
     const uint32_t *sk = k_in, *sv = v_in;
     for (uint32_t p = 0; p < n_pass; ++p) {
         const bool to_out = ((n_pass - 1u - p) & 1u) == 0u;   // the last pass lands in the output arrays
@@ -165,12 +170,22 @@ static int scan_state(la3dm_devmap *dm, uint32_t n, ScanState &ss) {
     if (tiles > dm->scan_tiles) {
         const size_t want = std::max<size_t>(2 * tiles, 4096);
         DM_TRY(hipStreamSynchronize(dm->ctx->stream));
-        DM_RESERVE(dm->scan_status, 8 * want + 16);
-        DM_TRY(hipMemsetAsync(dm->scan_status.ptr, 0, 8 * want + 16, dm->ctx->stream));   // on the scans' own stream
+        DM_RESERVE(dm->scan_status, 16 * want + 16);
+        DM_TRY(hipMemsetAsync(dm->scan_status.ptr, 0, 16 * want + 16, dm->ctx->stream));   // on the scans' own stream
         dm->scan_tiles = want;
+        dm->scan_dirty[0] = dm->scan_dirty[1] = 0;
     }
+    // layout: tickets, status array 0, status array 1.  The arrays alternate from launch to launch; a launch clears the
+    // used part of the other array (written two launches ago), so the array a launch starts on is all zero.
     ss.ticket = (uint32_t *)dm->scan_status.ptr;
-    ss.status = (unsigned long long *)((uint8_t *)dm->scan_status.ptr + 16);
+    unsigned long long *base = (unsigned long long *)((uint8_t *)dm->scan_status.ptr + 16);
+    const uint32_t cur = dm->scan_seq & 1u;
+    ss.status = base + (size_t)cur * dm->scan_tiles;
+    ss.other = base + (size_t)(cur ^ 1u) * dm->scan_tiles;
+    ss.other_n = (uint32_t)dm->scan_dirty[cur ^ 1u];
+    dm->scan_dirty[cur ^ 1u] = 0;
+    dm->scan_dirty[cur] = tiles;
+    ++dm->scan_seq;
     return LA3DM_OK;
 }
 
@@ -266,7 +281,8 @@ static int check_beam_counters(la3dm_devmap *dm) {
 // written to `out` (reserved here) and its point count returned.  One read-back (cell count).
 // key_bits: number of low key bits that can differ between cells (32 = unknown); must satisfy
 // cell count <= 2^key_bits - 1 so that the all-ones key of a non-finite point still sorts behind every cell.
-static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out, int key_bits = 32) {
+static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out, int key_bits = 32,
+                      bool params_ready = false) {
     hipStream_t st = dm->ctx->stream;
     *n_out = 0;
     if (n == 0) return LA3DM_OK;
@@ -280,9 +296,9 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     DM_RESERVE(dm->seg_start, 4ull * (n + 1));
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
     uint32_t *flag = (uint32_t *)dm->flag.ptr, *scan = (uint32_t *)dm->scan.ptr, *seg_start = (uint32_t *)dm->seg_start.ptr;
-    {
-        MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6};
-        hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), 512)), dim3(256), 0, st, d_in, n, dm->d_mm, fin);
+    if (!params_ready) {   // (the producer of d_in may have reduced its box and left the GridParams already)
+        MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
+        hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), kMinmaxWgs)), dim3(256), 0, st, d_in, n, dm->d_mm, fin);
     }
     hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
     int rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
@@ -425,7 +441,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     }
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2)) == hipSuccess &&
-              hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 8) == hipSuccess &&
+              hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 16) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
               hipMalloc((void **)&dm->d_gp, sizeof(GridParams)) == hipSuccess &&
@@ -472,12 +488,14 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
 
 // bbox of the training set in dm->xy (bbox(), bgkoctomap.cpp:464-484) -> dm->h_bbox; get_blocks_in_bbox walks it on
 // the host.  One synchronisation.
-static int training_bbox(la3dm_devmap *dm) {
+static int training_bbox(la3dm_devmap *dm, bool reduced = false) {
     hipStream_t st = dm->ctx->stream;
     const uint32_t npts = dm->n_xy;
-    MinmaxFin fin = {2, 0.0f, nullptr, (const float *)dm->xy.ptr, dm->d_cnt, dm->d_mm + 6};
-    hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), 512)), dim3(256), 0, st, (const float *)dm->xy.ptr, npts,
-                       dm->d_mm, fin);
+    if (!reduced) {   // (the front end's own kernels may have reduced the box while writing the set)
+        MinmaxFin fin = {2, 0.0f, nullptr, (const float *)dm->xy.ptr, dm->d_cnt, dm->d_mm + 6, nullptr};
+        hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), kMinmaxWgs)), dim3(256), 0, st, (const float *)dm->xy.ptr,
+                           npts, dm->d_mm, fin);
+    }
     int rc = read_counters(dm);   // the box comes back with the counter block
     if (rc != LA3DM_OK) return rc;
     memcpy(dm->h_bbox, dm->h_cnt + kCntBbox, sizeof(float) * 6);
@@ -551,23 +569,34 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     DM_RESERVE(dm->xy, 16ull * ((size_t)n_kept + n_free_raw));
     DM_RESERVE(dm->frees_raw, 12ull * n_free_raw);
     float4 *xy = (float4 *)dm->xy.ptr;
-    hipLaunchKernelGGL(dm_beam_write, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, keep_off, free_off, xy,
-                       (float *)dm->frees_raw.ptr);
+    // the beam kernel also reduces the box of the free samples (-> GridParams of the second voxel filter, finished by its
+    // last workgroup) and the box of the kept hits (d_mm[8..13]); dm_append_frees then completes the training set's box
+    uint32_t *mm_hits = dm->d_mm + 8;
+    {
+        MinmaxFin fin = {1, ds_resolution < 0 ? 1.0f : 1.0f / ds_resolution, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
+        hipLaunchKernelGGL(dm_beam_write, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep, keep_off,
+                           free_off, xy, (float *)dm->frees_raw.ptr, dm->d_mm, fin, mm_hits);
+    }
     const float *d_frees = (const float *)dm->frees_raw.ptr;
     uint32_t n_f = n_free_raw;
     if (!(ds_resolution < 0)) {
-        if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f, free_key_bits)) != LA3DM_OK) return rc;
+        if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f, free_key_bits, true)) != LA3DM_OK) return rc;
         d_frees = (const float *)dm->frees_ds.ptr;
     }
     const float free_label = ctx->p.variant == 1 ? -1.0f : 0.0f;  // bgkoctomap.cpp:415 / gpoctomap.cpp:399
-    if (n_f)
-        hipLaunchKernelGGL(dm_append_frees, dim3(cdiv(n_f, 256)), dim3(256), 0, st, d_frees, n_f, n_kept, free_label, xy);
+    bool box_reduced = false;
+    if (n_f) {
+        MinmaxFin fin = {2, 0.0f, nullptr, (const float *)xy, dm->d_cnt, dm->d_mm + 6, mm_hits};
+        hipLaunchKernelGGL(dm_append_frees, dim3(std::min<uint32_t>(cdiv(n_f, 256), kMinmaxWgs)), dim3(256), 0, st, d_frees, n_f, n_kept, free_label,
+                           xy, dm->d_mm, fin);
+        box_reduced = true;
+    }
     const uint32_t npts = n_kept + n_f;
     dm->n_xy = npts;
     S.n_hits = n_kept;
     S.n_frees = n_f;
 
-    return training_bbox(dm);
+    return training_bbox(dm, box_reduced);
 }
 
 // Host-side facts of the scan in flight, shared by the partition and the passes.
@@ -679,8 +708,9 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->v0, 4ull * n_mem);
     DM_RESERVE(dm->v1, 4ull * n_mem);
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
+    DM_RESERVE(dm->grid, 4ull * ncid);
     hipLaunchKernelGGL(dm_members_write, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const int4 *)dm->m_code.ptr, npts, pa, m_off,
-                       k0, v0, dm->d_cnt);
+                       k0, v0, dm->d_cnt, (int32_t *)dm->grid.ptr, (uint32_t)ncid);
     int bits = 1;
     while ((1ull << bits) < ncid) ++bits;
     if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;
@@ -709,8 +739,6 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
         DM_RESERVE(dm->train, 16ull * n_mem);
         hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, v1, n_mem, (float4 *)dm->train.ptr);
     }
-    DM_RESERVE(dm->grid, 4ull * ncid);
-    DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
     hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
     // the segment count is only needed on the host by the GP launches; the BGK path reads it (and the error flag)
     // together with the test-block count of the first pass
@@ -1076,8 +1104,8 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     L.n_hits = dm->h_cnt[kCntTrained];
     // bounding box of ALL samples (std::min / std::max chains from samples[0]: bgklvoctomap.cpp:105-112)
     {
-        MinmaxFin fin = {2, 0.0f, nullptr, (const float *)samples, dm->d_cnt, dm->d_mm + 6};
-        hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(ns, 1024), 512)), dim3(256), 0, st, (const float *)samples, ns, dm->d_mm, fin);
+        MinmaxFin fin = {2, 0.0f, nullptr, (const float *)samples, dm->d_cnt, dm->d_mm + 6, nullptr};
+        hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(ns, 1024), kMinmaxWgs)), dim3(256), 0, st, (const float *)samples, ns, dm->d_mm, fin);
     }
     // bucket bounds of the finite samples
     const int depth = ctx->p.block_depth;

@@ -94,20 +94,20 @@ struct MinmaxFin {
     const float *first;
     uint32_t *counters;
     uint32_t *done;      // zero between launches
+    uint32_t *mm_extra;  // mode 2: a second encoded box to unite with (and reset), or nullptr
 };
 __device__ void grid_params_from(const uint32_t *mmv, float inv, GridParams &g);
+__device__ __forceinline__ void box_add(float mn[3], float mx[3], float x, float y, float z) {   // dm_minmax's rule: finite points only
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) return;
+    mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+    mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+}
 
-template <int kStride>
-__global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, uint32_t n, uint32_t *mm, MinmaxFin fin) {
-    __shared__ float red[4][6];
-    __shared__ uint32_t s_last;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float x = p[(size_t)kStride * i], y = p[(size_t)kStride * i + 1], z = p[(size_t)kStride * i + 2];
-        if (!finite3(x, y, z)) continue;
-        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
-        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
-    }
+// Workgroup part of a min/max reduction (256 threads, every thread of the workgroup calls it): per-thread min/max ->
+// one atomic per value per workgroup on mm -> (fin.mode != 0) the last workgroup of the launch finishes the result.
+// red: [4][6] floats of LDS, s_last: one word of LDS.
+__device__ __forceinline__ void minmax_wg(float mn[3], float mx[3], uint32_t *mm, const MinmaxFin &fin, float (*red)[6],
+                                          uint32_t *s_last) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o >= 1; o >>= 1) {
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
         }
     }
     const int wv = threadIdx.x >> 6;
+    __syncthreads();   // (red may still be read from an earlier call)
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -140,13 +141,20 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
     }
     if (fin.mode == 0) return;
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(fin.done, 1u) + 1u == gridDim.x ? 1u : 0u;
+    if (threadIdx.x == 0) *s_last = atomicAdd(fin.done, 1u) + 1u == gridDim.x ? 1u : 0u;
     __syncthreads();
-    if (!s_last || threadIdx.x != 0) return;
+    if (!*s_last || threadIdx.x != 0) return;
     uint32_t mmv[6];
     for (int a = 0; a < 6; ++a) {
         mmv[a] = __hip_atomic_load(&mm[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mm[a] = a < 3 ? 0xFFFFFFFFu : 0u;
+    }
+    if (fin.mm_extra) {   // a second box, complete since an earlier launch: the union of the two
+        for (int a = 0; a < 6; ++a) {
+            const uint32_t e = fin.mm_extra[a];
+            mmv[a] = a < 3 ? min(mmv[a], e) : max(mmv[a], e);
+            fin.mm_extra[a] = a < 3 ? 0xFFFFFFFFu : 0u;
+        }
     }
     *fin.done = 0u;
     if (fin.mode == 1) {
@@ -161,6 +169,20 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
             fin.counters[kCntBbox + a] = __float_as_uint(f != f ? f : dec_f32(mmv[a]));
         }
     }
+}
+
+template <int kStride>
+__global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, uint32_t n, uint32_t *mm, MinmaxFin fin) {
+    __shared__ float red[4][6];
+    __shared__ uint32_t s_last;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = p[(size_t)kStride * i], y = p[(size_t)kStride * i + 1], z = p[(size_t)kStride * i + 2];
+        if (!finite3(x, y, z)) continue;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+    minmax_wg(mn, mx, mm, fin, red, &s_last);
 }
 
 __device__ void grid_params_from(const uint32_t *mm, float inv, GridParams &g) {
@@ -223,8 +245,8 @@ __global__ __launch_bounds__(1024) void dm_sort_small(const uint32_t *__restrict
 __global__ void dm_begin(uint32_t *counters, uint32_t n_blocks, uint32_t *mm, uint32_t *done) {
     const uint32_t i = threadIdx.x;
     if (i < (uint32_t)kCntWords) counters[i] = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
-    if (i < 3) mm[i] = 0xFFFFFFFFu;
-    else if (i < 6) mm[i] = 0u;
+    if (i < 3) mm[i] = mm[8 + i] = 0xFFFFFFFFu;   // mm[8..13]: the second box (kept hits) of the fused front end
+    else if (i < 6) mm[i] = mm[8 + i] = 0u;
     if (i == 6) *done = 0u;
 }
 
@@ -557,10 +579,19 @@ __device__ __forceinline__ uint32_t beam_count(float l, float fr, uint32_t *coun
     return c;
 }
 // wave-reduced 64-bit total of the per-beam sample counts (the 32-bit offsets wrap silently above 2^32 samples)
+// (one atomic per workgroup of up to 256 threads, all of which call this: every atomic on this one address costs ~25 ns,
+// serialised)
 __device__ __forceinline__ void beam_total_add(uint32_t c, uint32_t *counters) {
+    __shared__ unsigned long long s_t[4];
     unsigned long long t = c;
     for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-    if ((threadIdx.x & 63) == 0 && t) atomicAdd(reinterpret_cast<unsigned long long *>(counters + kCntBeamTotal), t);
+    if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        for (uint32_t w = 0; w < (blockDim.x + 63u) >> 6 && w < 4u; ++w) all += s_t[w];
+        if (all) atomicAdd(reinterpret_cast<unsigned long long *>(counters + kCntBeamTotal), all);
+    }
 }
 
 __global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
@@ -583,28 +614,47 @@ __global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ h
 }
 
 // hits that pass the gate -> xy (label 1) in order; their beam samples -> frees (xyz) in order
+// Also reduces, on the way, the box of the free samples it writes (the second voxel filter's grid: its min/max launch
+// and one-thread parameter launch are gone) and the box of the kept hits (half of the training set's box).
 __global__ __launch_bounds__(256) void dm_beam_write(const float *__restrict__ hits, uint32_t n, BeamArgs a,
                                                     const uint32_t *__restrict__ keep,
                                                     const uint32_t *__restrict__ keep_off,
-                                                    const uint32_t *__restrict__ free_off, float4 *xy, float *frees) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !keep[i]) return;
-    const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
-    xy[keep_off[i]] = make_float4(x, y, z, 1.0f);
-    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
-    const float l = f32_sqrt_cr(dx * dx + dy * dy + dz * dz);
-    const float nx = dx / l, ny = dy / l, nz = dz / l;
-    float *f = frees + 3 * (size_t)free_off[i];
-    f[0] = a.ox; f[1] = a.oy; f[2] = a.oz;
-    f += 3;
-    for (float d = a.free_res; d < l; d += a.free_res) {
-        f[0] = a.ox + nx * d; f[1] = a.oy + ny * d; f[2] = a.oz + nz * d;
+                                                    const uint32_t *__restrict__ free_off, float4 *xy, float *frees,
+                                                    uint32_t *mm_frees, MinmaxFin fin_frees, uint32_t *mm_hits) {
+    __shared__ float red[4][6];
+    __shared__ uint32_t s_last;
+    float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float hmn[3] = {INFINITY, INFINITY, INFINITY}, hmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!keep[i]) continue;
+        const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
+        xy[keep_off[i]] = make_float4(x, y, z, 1.0f);
+        box_add(hmn, hmx, x, y, z);
+        const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+        const float l = f32_sqrt_cr(dx * dx + dy * dy + dz * dz);
+        const float nx = dx / l, ny = dy / l, nz = dz / l;
+        float *f = frees + 3 * (size_t)free_off[i];
+        f[0] = a.ox; f[1] = a.oy; f[2] = a.oz;
+        box_add(fmn, fmx, a.ox, a.oy, a.oz);
         f += 3;
+        for (float d = a.free_res; d < l; d += a.free_res) {
+            const float sx = a.ox + nx * d, sy = a.oy + ny * d, sz = a.oz + nz * d;
+            f[0] = sx; f[1] = sy; f[2] = sz;
+            box_add(fmn, fmx, sx, sy, sz);
+            f += 3;
+        }
+        if (l > a.free_res) {
+            const float d = l - a.free_res;
+            const float sx = a.ox + nx * d, sy = a.oy + ny * d, sz = a.oz + nz * d;
+            f[0] = sx; f[1] = sy; f[2] = sz;
+            box_add(fmn, fmx, sx, sy, sz);
+        }
     }
-    if (l > a.free_res) {
-        const float d = l - a.free_res;
-        f[0] = a.ox + nx * d; f[1] = a.oy + ny * d; f[2] = a.oz + nz * d;
-    }
+    if (!mm_frees) return;   // (uniform) the unfused form
+    MinmaxFin none = fin_frees;
+    none.mode = 0;
+    minmax_wg(hmn, hmx, mm_hits, none, red, &s_last);
+    minmax_wg(fmn, fmx, mm_frees, fin_frees, red, &s_last);
 }
 
 // ---- BGKLOctoMap front end (src/bgkloctomap/bgkloctomap.cpp:300-343, beam_sample :359-381): a hit is re-projected
@@ -782,10 +832,17 @@ __global__ void dm_scan_total(const uint32_t *off, const uint32_t *cnt, uint32_t
 }
 
 __global__ __launch_bounds__(256) void dm_append_frees(const float *__restrict__ pts, uint32_t n, uint32_t base, float label,
-                                                      float4 *xy) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    xy[base + i] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], label);
+                                                      float4 *xy, uint32_t *mm, MinmaxFin fin) {
+    __shared__ float red[4][6];
+    __shared__ uint32_t s_last;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+        xy[base + i] = make_float4(x, y, z, label);
+        box_add(mn, mx, x, y, z);
+    }
+    if (!mm) return;   // (uniform) the unfused form
+    minmax_wg(mn, mx, mm, fin, red, &s_last);   // mode 2 with mm_extra = the kept hits' box: the training set's box
 }
 
 // ---- partition (stage B..D) -----------------------------------------------------------------------------
@@ -843,8 +900,10 @@ __global__ __launch_bounds__(256) void dm_members_count(const float4 *__restrict
 
 __global__ __launch_bounds__(256) void dm_members_write(const int4 *__restrict__ code, uint32_t n, PartArgs a,
                                                        const uint32_t *__restrict__ off, uint32_t *keys, uint32_t *vals,
-                                                       uint32_t *counters) {
+                                                       uint32_t *counters, int32_t *grid, uint32_t ncid) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (also: grid[cid] = -1 for dm_geo_fill, which runs two launches later — a memset launch less)
+    for (uint32_t c = i; c < ncid; c += gridDim.x * blockDim.x) grid[c] = -1;
     if (i >= n) return;
     const int4 cd = code[i];
     const int nx = cd.w & 3, ny = (cd.w >> 2) & 3, nz = (cd.w >> 4) & 3;

@@ -9,7 +9,8 @@
 //   mode heads : in = keys sorted ascending with the invalid key (0xFFFFFFFF) last; flag[i] = valid key that differs from
 //                its predecessor; seg_start[k] = position of the k-th flagged element (+ seg_key[k] = its key),
 //                seg_start[n_seg] = number of valid keys, counters[seg_slot] = n_seg, counters[valid_slot] = valid keys
-// The per-tile status words and the two tickets are zero between launches: the last workgroup to finish clears them.
+// Two status arrays alternate between launches; a launch clears what the launch before the previous one left in the array
+// the next launch will use.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,8 +22,15 @@ constexpr uint32_t kScanInvalid = 0xFFFFFFFFu;
 
 struct ScanState {
     unsigned long long *status;  // per tile: bits 63..62 = 0 empty / 1 tile aggregate / 2 inclusive prefix; low 32 bits = value
-    uint32_t *ticket;            // [0] next tile number, [1] workgroups finished
+    unsigned long long *other;   // the status array of the NEXT launch: this launch clears its other_n used entries
+    uint32_t other_n;
+    uint32_t *ticket;            // [0] next tile number, [1] workgroups finished (launches of more than kScanResident tiles only)
 };
+// Tiles take their number from the workgroup id while all workgroups of the launch fit on the chip at once; larger
+// launches draw tickets.  A device-scope atomic on ONE address costs ~25 ns per workgroup, serialised (measured: 390
+// workgroups x (ticket + arrival count) = 20 us of a 23 us scan), so the resident form has none: the status arrays
+// alternate between launches and are cleaned by the launch in between.
+constexpr uint32_t kScanResident = 1024;
 
 struct ScanArgs {
     const uint32_t *in;
@@ -55,9 +63,13 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
     __shared__ uint32_t s_tile, s_wave[kScanThreads / 64], s_excl, s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (a.n + kScanTile - 1) / kScanTile;
-    if (tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
-    __syncthreads();
-    const uint32_t tile = s_tile;
+    const bool tickets = n_tiles > kScanResident;
+    if (tickets) {
+        if (tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
+        __syncthreads();
+    }
+    const uint32_t tile = tickets ? s_tile : blockIdx.x;
+    for (uint32_t e = blockIdx.x * kScanThreads + tid; e < st.other_n; e += gridDim.x * kScanThreads) st.other[e] = 0ull;
     const uint32_t i0 = tile * kScanTile + tid * kScanItems;
     // ---- items
     uint32_t raw[kScanItems], v[kScanItems];
@@ -165,14 +177,12 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
         run += v[u];
     }
     if (tile == 0 && tid == 0 && a.zero_slot >= 0) a.counters[a.zero_slot] = 0;
-    // ---- the last workgroup out clears the state for the next launch
+    // ---- ticket form: the last workgroup out resets the two counters
+    if (!tickets) return;
     __syncthreads();
     if (tid == 0) s_last = atomicAdd(st.ticket + 1, 1u) + 1u == n_tiles ? 1u : 0u;
     __syncthreads();
-    if (s_last) {
-        for (uint32_t t = tid; t < n_tiles; t += kScanThreads) st.status[t] = 0ull;
-        if (tid < 2) st.ticket[tid] = 0u;
-    }
+    if (s_last && tid < 2) st.ticket[tid] = 0u;
 }
 
 }  // namespace la3dm_dev

@@ -18,11 +18,14 @@ namespace la3dm_dev {
 
 constexpr uint32_t kRsThreads = 256, kRsWaves = 4, kRsRows = 16, kRsTile = kRsThreads * kRsRows;   // 4096 items per tile
 constexpr uint32_t kRsErrStuck = 16u;
-constexpr int kRsLook = 16;   // predecessor tiles whose status words are in flight at a time
+constexpr int kRsLook = 16;
+constexpr uint32_t kRsHistCopies = 8;   // predecessor tiles whose status words are in flight at a time
 
 struct RadixState {
-    uint32_t *hist;       // [4][256] digit counts of the sort in flight (zero before its histogram launch)
-    uint32_t *hist_next;  // [4][256] the histogram of the NEXT sort: the histogram launch clears it
+    uint32_t *hist;       // [kRsHistCopies][4][256] digit counts of the sort in flight (zero before its histogram launch):
+                          // workgroup b of the histogram launch adds into copy b % kRsHistCopies (an atomic on one
+                          // address costs ~25 ns per workgroup, serialised), the passes add the copies up
+    uint32_t *hist_next;  // the histogram of the NEXT sort: the histogram launch clears it
     uint32_t *status[2];  // [tiles][256] per array: bits 31..30 = 0 empty / 1 tile count / 2 inclusive prefix, low 30 bits = value
     uint32_t *ticket;     // [0] next tile, [1] tiles finished (sorts of more than kRsResident tiles only)
 };
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
     for (uint32_t p = 0; p < 4; ++p) h[p][tid] = 0;
     const uint32_t n_tiles = (n + kRsTile - 1) / kRsTile;
     for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n_tiles * 256u; i += gridDim.x * kRsThreads) st.status[0][i] = 0u;
-    if (blockIdx.x == 0)
-        for (uint32_t p = 0; p < 4; ++p) st.hist_next[p * 256u + tid] = 0u;
+    if (blockIdx.x < kRsHistCopies)
+        for (uint32_t p = 0; p < 4; ++p) st.hist_next[(blockIdx.x * 4u + p) * 256u + tid] = 0u;
     __syncthreads();
     for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n; i += gridDim.x * kRsThreads) {
         const uint32_t k = keys[i];
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
     __syncthreads();
     for (uint32_t p = 0; p < n_pass; ++p) {
         const uint32_t c = h[p][tid];
-        if (c) atomicAdd(&st.hist[p * 256u + tid], c);
+        if (c) atomicAdd(&st.hist[((blockIdx.x % kRsHistCopies) * 4u + p) * 256u + tid], c);
     }
 }
 
@@ -103,7 +106,9 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
     if (tickets && tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
 #pragma unroll
     for (uint32_t w = 0; w < kRsWaves; ++w) s_wcnt[w][tid] = 0u;
-    const uint32_t total_d = st.hist[a.pass * 256u + tid];   // keys with digit tid in this pass (written by the histogram launch)
+    uint32_t total_d = 0;   // keys with digit tid in this pass (written by the histogram launch)
+#pragma unroll
+    for (uint32_t cpy = 0; cpy < kRsHistCopies; ++cpy) total_d += st.hist[(cpy * 4u + a.pass) * 256u + tid];
     __syncthreads();
     const uint32_t tile = tickets ? s_tile : blockIdx.x;
     other[tile * 256u + tid] = 0u;   // my row of the array the next pass (or the next sort's second pass) uses
