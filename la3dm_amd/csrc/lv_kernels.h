@@ -279,8 +279,7 @@ constexpr uint32_t kLvPlanPerWave = 16;
 __global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t n_tasks = a.n_blk_dev ? *a.n_blk_dev << a.cubes_shift : a.n_tasks;
-    const uint32_t task0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kLvPlanPerWave;
-    if (task0 >= n_tasks) return;
+    const uint32_t task0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kLvPlanPerWave;   // (may lie beyond n_tasks: the wave idles)
     const uint32_t w = 2u * (uint32_t)a.reach + 1u, nb = w * w * w;
     uint32_t my_nsub = 0, my_stream = 0;   // lane i: cube task0 + i
     for (uint32_t i = 0; i < kLvPlanPerWave && task0 + i < n_tasks; ++i) {
@@ -307,15 +306,28 @@ __global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
     const bool is_split = my_nsub > 1;
     const uint32_t sub_incl = wave_incl_scan_u32(my_nsub, lane), row_incl = wave_incl_scan_u32(my_stream, lane);
     const unsigned long long sm = __ballot(is_split);
-    uint32_t base_sub = 0, base_row = 0, base_split = 0;
+    // one atomic per total and WORKGROUP (an atomic on one address costs ~25 ns per caller, serialised: per wave they
+    // were two thirds of this kernel's time): the four waves' totals meet in LDS, thread 0 draws, the waves take their parts
+    __shared__ uint32_t s_tot[4][3], s_base[3];
+    const uint32_t wave = threadIdx.x >> 6;
     if (lane == kWave - 1) {
-        if (sub_incl) base_sub = atomicAdd(a.plan_totals + 0, sub_incl);
-        if (row_incl) base_row = atomicAdd(a.plan_totals + 1, row_incl);
-        if (sm) base_split = atomicAdd(a.plan_totals + 2, (uint32_t)__popcll(sm));
+        s_tot[wave][0] = sub_incl;
+        s_tot[wave][1] = row_incl;
+        s_tot[wave][2] = (uint32_t)__popcll(sm);
     }
-    base_sub = (uint32_t)__shfl((int)base_sub, kWave - 1, kWave);
-    base_row = (uint32_t)__shfl((int)base_row, kWave - 1, kWave);
-    base_split = (uint32_t)__shfl((int)base_split, kWave - 1, kWave);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t t = 0;
+        for (uint32_t v = 0; v < 4; ++v) t += s_tot[v][threadIdx.x];
+        s_base[threadIdx.x] = t ? atomicAdd(a.plan_totals + threadIdx.x, t) : 0u;
+    }
+    __syncthreads();
+    uint32_t base_sub = s_base[0], base_row = s_base[1], base_split = s_base[2];
+    for (uint32_t v = 0; v < wave; ++v) {
+        base_sub += s_tot[v][0];
+        base_row += s_tot[v][1];
+        base_split += s_tot[v][2];
+    }
     if (lane >= (int)kLvPlanPerWave || task0 + lane >= n_tasks) return;
     const uint32_t task = task0 + lane;
     a.task_nsub[task] = my_nsub;
