@@ -338,6 +338,15 @@ int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint
  * the voxel-grid kernel uses for runs of identical samples, out_loop = the plain sequential fp32 loop */
 int la3dm_devmap_diag_add_repeat(la3dm_ctx *ctx, const float *s, const float *x, const uint32_t *m, uint32_t n,
                                  float *out_fast, float *out_loop);
+/* Test hooks for the device-resident front end's own scan / sort primitives (la3dm_amd/csrc/devmap_scan.h,
+ * devmap_sort.h), run on the map's stream and self-cleaning state; host arrays in and out.
+ * scan, mode 0: out[i] = in[0] + ... + in[i-1], aux[0] = total.
+ * scan, mode 1: in = keys sorted ascending, 0xFFFFFFFF = invalid (last); out = exclusive scan of the head flags,
+ *               aux = {segments, valid keys, seg_start[0 .. segments]} (room for n + 3 words).
+ * sort: stable, on the low `bits` bits of the keys. */
+int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *aux);
+int la3dm_devmap_diag_sort(la3dm_devmap *dm, const uint32_t *keys, const uint32_t *vals, uint32_t n, int bits,
+                           uint32_t *keys_out, uint32_t *vals_out);
 
 #ifdef __cplusplus
 }

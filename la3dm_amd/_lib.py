@@ -76,7 +76,8 @@ HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_des
                "la3dm_bgkl_scan_device", "la3dm_diag_mfma_chain", "la3dm_devmap_search_host",
                "la3dm_devmap_export_cells", "la3dm_devmap_key_bounds",
                "la3dm_devmap_insert_training_data_host", "la3dm_devmap_set_shard", "la3dm_devmap_wait_event",
-               "la3dm_devmap_lv_stats_get", "la3dm_devmap_lv_set_original_size", "la3dm_devmap_lv_training"]
+               "la3dm_devmap_lv_stats_get", "la3dm_devmap_lv_set_original_size", "la3dm_devmap_lv_training",
+               "la3dm_devmap_diag_scan", "la3dm_devmap_diag_sort"]
 MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv", "la3dm_map_lv_training",
                "la3dm_map_lv_stats", "la3dm_map_lv_prepare", "la3dm_map_lv_packed", "la3dm_map_lv_commit", "la3dm_map_destroy", "la3dm_map_last_error", "la3dm_map_insert_pointcloud", "la3dm_map_insert_pointcloud_device",
                "la3dm_map_insert_training_data", "la3dm_map_prepare", "la3dm_map_prepare_training_data",
@@ -147,6 +148,10 @@ def hip():
         L.la3dm_devmap_download.restype = C.c_int
         L.la3dm_devmap_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.la3dm_devmap_diag_add_repeat.restype = C.c_int
+        L.la3dm_devmap_diag_scan.restype = C.c_int
+        L.la3dm_devmap_diag_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.la3dm_devmap_diag_sort.restype = C.c_int
+        L.la3dm_devmap_diag_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.la3dm_devmap_diag_add_repeat.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2
         L.la3dm_devmap_search_host.restype = C.c_int
         L.la3dm_devmap_search_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 4

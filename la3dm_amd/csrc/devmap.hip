@@ -3,14 +3,15 @@
 // The host only sizes launches (a handful of scalar read-backs per scan) and walks the float-stepped
 // candidate loops of get_blocks_in_bbox (a few dozen iterations per axis).  No CPU fallback.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
-#include <cstring>
+#include <cstring>   // (before rocPRIM: one of its iterator headers calls memset unqualified)
+
+#include <rocprim/rocprim.hpp>
+
 #include <string>
 #include <vector>
 
@@ -1581,6 +1582,56 @@ int la3dm_devmap_diag_add_repeat(la3dm_ctx *ctx, const float *s, const float *x,
         ctx->err = std::string("la3dm_devmap_diag_add_repeat: ") + hipGetErrorString(e);
         return LA3DM_ERR_HIP;
     }
+    return LA3DM_OK;
+}
+
+// Test hooks for the front end's own primitives (devmap_scan.h, devmap_sort.h), on the map's stream and state.
+// mode 0: out[i] = sum of in[0..i), aux[0] = total.  mode 1: in = sorted keys (0xFFFFFFFF = invalid, last): out = exclusive
+// scan of the head flags, aux = {segments, valid keys, seg_start[0..segments]} (aux holds n + 3 words).
+int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *aux) {
+    if (!dm || !in || !out || !aux || n == 0 || (mode != 0 && mode != 1)) return LA3DM_ERR_ARG;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    DM_RESERVE(dm->k0, 4ull * n);
+    DM_RESERVE(dm->k1, 4ull * n);
+    DM_RESERVE(dm->seg_start, 4ull * (n + 1));
+    DM_TRY(hipMemcpyAsync(dm->k0.ptr, in, 4ull * n, hipMemcpyHostToDevice, st));
+    int rc;
+    if (mode == 0) rc = exclusive_scan(dm, (const uint32_t *)dm->k0.ptr, (uint32_t *)dm->k1.ptr, n, (int)kCntMembers);
+    else rc = scan_heads(dm, (const uint32_t *)dm->k0.ptr, n, nullptr, (uint32_t *)dm->k1.ptr, (uint32_t *)dm->seg_start.ptr, nullptr,
+                         (int)kCntGridSegs, (int)kCntGridValid);
+    if (rc != LA3DM_OK) return rc;
+    DM_TRY(hipMemcpyAsync(out, dm->k1.ptr, 4ull * n, hipMemcpyDeviceToHost, st));
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    DM_TRY(hipStreamSynchronize(st));
+    if (mode == 0) {
+        aux[0] = dm->h_cnt[kCntMembers];
+    } else {
+        aux[0] = dm->h_cnt[kCntGridSegs];
+        aux[1] = dm->h_cnt[kCntGridValid];
+        DM_TRY(hipMemcpy(aux + 2, dm->seg_start.ptr, 4ull * (aux[0] + 1), hipMemcpyDeviceToHost));
+    }
+    return LA3DM_OK;
+}
+
+// stable sort of (keys, vals) on the low `bits` key bits through sort_pairs (the in-house radix sort unless LA3DM_OWN_SORT=0)
+int la3dm_devmap_diag_sort(la3dm_devmap *dm, const uint32_t *keys, const uint32_t *vals, uint32_t n, int bits, uint32_t *keys_out,
+                           uint32_t *vals_out) {
+    if (!dm || !keys || !vals || !keys_out || !vals_out || n == 0 || bits < 1 || bits > 32) return LA3DM_ERR_ARG;
+    DM_TRY(hipSetDevice(dm->ctx->device));
+    hipStream_t st = dm->ctx->stream;
+    DM_RESERVE(dm->k0, 4ull * n);
+    DM_RESERVE(dm->k1, 4ull * n);
+    DM_RESERVE(dm->v0, 4ull * n);
+    DM_RESERVE(dm->v1, 4ull * n);
+    DM_TRY(hipMemcpyAsync(dm->k0.ptr, keys, 4ull * n, hipMemcpyHostToDevice, st));
+    DM_TRY(hipMemcpyAsync(dm->v0.ptr, vals, 4ull * n, hipMemcpyHostToDevice, st));
+    int rc = sort_pairs(dm, (const uint32_t *)dm->k0.ptr, (uint32_t *)dm->k1.ptr, (const uint32_t *)dm->v0.ptr, (uint32_t *)dm->v1.ptr, n, bits);
+    if (rc != LA3DM_OK) return rc;
+    DM_TRY(hipMemcpyAsync(keys_out, dm->k1.ptr, 4ull * n, hipMemcpyDeviceToHost, st));
+    DM_TRY(hipMemcpyAsync(vals_out, dm->v1.ptr, 4ull * n, hipMemcpyDeviceToHost, st));
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;   // (carries the "stuck" error bit of the look-back loops)
+    DM_TRY(hipStreamSynchronize(st));
     return LA3DM_OK;
 }
 
