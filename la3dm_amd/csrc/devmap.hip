@@ -337,7 +337,9 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
 static int grow_pool(la3dm_devmap *dm, size_t want_blocks) {
     if (want_blocks <= dm->cap_blocks) return LA3DM_OK;
     hipStream_t st = dm->ctx->stream;
-    size_t cap = std::max<size_t>(want_blocks + want_blocks / 2, 4096);
+    // a regrow copies the pool and synchronises: the first allocation leaves room for a few scans' worth of new blocks
+    // (9 bytes per node: 164 k blocks of 73 nodes are 108 MB), later ones double
+    size_t cap = std::max<size_t>((dm->cap_blocks ? 2 : 4) * want_blocks, 4096);
     float *A = nullptr, *B = nullptr;
     uint8_t *S = nullptr;
     long long *bk = nullptr;

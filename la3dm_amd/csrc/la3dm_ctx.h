@@ -58,7 +58,7 @@ static inline int arena_reserve(la3dm_ctx *ctx, Arena &a, size_t bytes) {
         a.ptr = nullptr;
         a.cap = 0;
     }
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = bytes + bytes / 2 + 256;   // 50 % head room: a regrow is a device-wide free + malloc (hundreds of us)
     hipError_t e = hipMalloc(&a.ptr, want);
     if (e != hipSuccess) {
         ctx->err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
