@@ -106,13 +106,13 @@ constexpr uint32_t kMinmaxWgs = 128;
 // ---- library plumbing: device-wide sort / scan (rocPRIM through hipCUB) ---------------------------------
 template <size_t kMergeLimit>
 static int sort_pairs_cfg(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
-                          uint32_t n, int end_bit) {
+                          uint32_t n, int end_bit, int begin_bit = 0) {
     hipStream_t st = dm->ctx->stream;
     size_t tmp = 0;
     using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, kMergeLimit>;
-    DM_TRY(rocprim::radix_sort_pairs<sort_config>(nullptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, (unsigned)end_bit, st));
+    DM_TRY(rocprim::radix_sort_pairs<sort_config>(nullptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
     DM_RESERVE(dm->cub_tmp, tmp);
-    DM_TRY(rocprim::radix_sort_pairs<sort_config>(dm->cub_tmp.ptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, (unsigned)end_bit, st));
+    DM_TRY(rocprim::radix_sort_pairs<sort_config>(dm->cub_tmp.ptr, tmp, k_in, k_out, v_in, v_out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
     return LA3DM_OK;
 }
 
@@ -120,11 +120,12 @@ static int sort_pairs_cfg(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_ou
 // 8 key bits; the input arrays are left as they are).  rocPRIM's sort (LA3DM_OWN_SORT=0) is kept for comparison: above
 // 2^18 items its Onesweep costs three launches per pass, below that its merge sort log2(n / 1024) launch pairs.
 static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
-                      uint32_t n, int end_bit) {
+                      uint32_t n, int end_bit, int begin_bit = 0) {
     if (n == 0) return LA3DM_OK;
-    if (!dm->own_sort || end_bit > 32 || end_bit < 1) return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit);
+    if (!dm->own_sort || end_bit > 32 || end_bit <= begin_bit || begin_bit < 0)
+        return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit, begin_bit);
     hipStream_t st = dm->ctx->stream;
-    const uint32_t n_pass = ((uint32_t)end_bit + 7u) / 8u, tiles = cdiv(n, kRsTile);
+    const uint32_t n_pass = ((uint32_t)(end_bit - begin_bit) + 7u) / 8u, tiles = cdiv(n, kRsTile);
     if (tiles > dm->radix_tiles) {
         const size_t want = std::max<size_t>(2 * (size_t)tiles, 1024);
         DM_TRY(hipStreamSynchronize(st));
@@ -143,7 +144,7 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
     rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
     DM_RESERVE(dm->radix_tmp, 8ull * n);
     uint32_t *tk = (uint32_t *)dm->radix_tmp.ptr, *tv = tk + n;
-    hipLaunchKernelGGL(dm_radix_hist, dim3(std::max<uint32_t>(std::min<uint32_t>(cdiv(n, 4 * kRsThreads), 512u), kRsHistCopies)), dim3(kRsThreads), 0, st, k_in, n, n_pass, rs);
+    hipLaunchKernelGGL(dm_radix_hist, dim3(std::max<uint32_t>(std::min<uint32_t>(cdiv(n, 4 * kRsThreads), 512u), kRsHistCopies)), dim3(kRsThreads), 0, st, k_in, n, n_pass, (uint32_t)begin_bit, rs);
     const uint32_t *sk = k_in, *sv = v_in;
     for (uint32_t p = 0; p < n_pass; ++p) {
         const bool to_out = ((n_pass - 1u - p) & 1u) == 0u;   // the last pass lands in the output arrays
@@ -155,6 +156,7 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         a.n = n;
         a.n_pass = n_pass;
         a.pass = p;
+        a.begin_bit = (uint32_t)begin_bit;
         a.counters = dm->d_cnt;
         a.err_slot = (int)kCntError;
         hipLaunchKernelGGL(dm_radix_pass, dim3(tiles), dim3(kRsThreads), 0, st, a, rs);
@@ -802,7 +804,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
             hipLaunchKernelGGL(dm_sort_small, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->t_key0.ptr, (const uint32_t *)dm->t_ent0.ptr,
                                n_test, N, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent1.ptr);
         } else if ((rc = sort_pairs(dm, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (uint32_t *)dm->t_ent0.ptr,
-                                    (uint32_t *)dm->t_ent1.ptr, n_test, 32)) != LA3DM_OK)
+                                    (uint32_t *)dm->t_ent1.ptr, n_test, 32, 24)) != LA3DM_OK)   // the weight class
             return rc;
     } else {
         // block-sharded: the list stays in candidate order (block indices x-major: neighbouring test blocks, which share

@@ -209,6 +209,15 @@ __device__ void grid_params_from(const uint32_t *mm, float inv, GridParams &g) {
     g.m2 = g.span[0] * g.span[1];
 }
 
+// Sort key of a test block: heaviest first only balances the predict launch (the blocks are independent, the leaves are
+// committed by node index), so the order need not be exact — one radix pass on a weight class in the top byte (16 points
+// per class, everything above 4 080 points in class 255) instead of four on the weight; the weight rides in the low bits.
+__host__ __device__ __forceinline__ uint32_t test_key(uint32_t weight) {
+    const uint32_t cls = weight >> 4 > 255u ? 255u : weight >> 4;
+    return ((255u - cls) << 24) | (weight > 0xFFFFFFu ? 0xFFFFFFu : weight);
+}
+__host__ __device__ __forceinline__ uint32_t test_key_weight(uint32_t key) { return key & 0xFFFFFFu; }
+
 // Stable ascending sort of n <= 4096 (key, value) pairs in ONE workgroup: a bitonic network over (key << 32 | position)
 // in LDS (the library sort is 7-9 dependent launches whatever n is; a pass's test-block list has a few hundred to a
 // few thousand entries).  N = n rounded up to a power of two.
@@ -945,7 +954,7 @@ __global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ 
 // weight of a test block for the balance = its neighbourhood size (what the kernel streams) + a constant per tile
 __global__ void dm_shard_weight(const uint32_t *__restrict__ t_key, uint32_t n_test, uint32_t *__restrict__ w) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_test) w[t] = (0xFFFFFFFFu - t_key[t]) + 16u;
+    if (t < n_test) w[t] = test_key_weight(t_key[t]) + 16u;
 }
 // bounds[q] = first test block of rank q (q = 0..world): the list is cut where the running weight crosses q/world of
 // the total — contiguous ranges of the candidate order (x-major block index order: spatially coherent), equal work
@@ -1003,7 +1012,7 @@ __global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict_
     unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
     unsigned long long w = 0, pw = 0;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_test; t += gridDim.x * blockDim.x) {
-        const unsigned long long wt = 0xFFFFFFFFu - t_key[t];  // the sort key of the test list is ~weight
+        const unsigned long long wt = test_key_weight(t_key[t]);
         w += wt;
         pw += wt * nleaf[t];
     }
@@ -1086,7 +1095,7 @@ __global__ __launch_bounds__(256) void dm_test_compact(const uint32_t *__restric
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
     if (flag[e]) {
-        t_key[scan[e]] = 0xFFFFFFFFu - weight[e];
+        t_key[scan[e]] = test_key(weight[e]);
         t_entry[scan[e]] = e;
     }
     if (e + 1 == n_entries) counters[kCntTest] = scan[e] + flag[e];

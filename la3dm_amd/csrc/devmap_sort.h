@@ -34,6 +34,7 @@ struct RadixArgs {
     const uint32_t *k_in, *v_in;
     uint32_t *k_out, *v_out;
     uint32_t n, n_pass, pass;
+    uint32_t begin_bit;   // pass p sorts on key bits [begin_bit + 8 p, + 8)
     uint32_t *counters;
     int err_slot;
 };
@@ -65,7 +66,8 @@ __device__ __forceinline__ uint32_t rs_scan256(uint32_t v, uint32_t tid, uint32_
 
 // digit counts of all passes in one sweep over the keys.  Also clears status array 0 for the first pass and the next
 // sort's histogram.
-__global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__restrict__ keys, uint32_t n, uint32_t n_pass, RadixState st) {
+__global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__restrict__ keys, uint32_t n, uint32_t n_pass, uint32_t begin_bit,
+                                                           RadixState st) {
     __shared__ uint32_t h[4][256];
     const uint32_t tid = threadIdx.x;
     for (uint32_t p = 0; p < 4; ++p) h[p][tid] = 0;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
         const unsigned long long act = __ballot(true);
         for (uint32_t p = 0; p < n_pass; ++p) {
             // the high digits of grid-cell keys are the same for whole waves: one add instead of 64 colliding LDS atomics
-            const uint32_t d = (k >> (8u * p)) & 255u, d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            const uint32_t d = (k >> (begin_bit + 8u * p)) & 255u, d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
             if (__ballot(d == d0) == act) {
                 if ((tid & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&h[p][d0], (uint32_t)__popcll(act));
             } else {
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
     __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64];
     __shared__ uint32_t s_tile, s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = 8u * a.pass;
+    const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = a.begin_bit + 8u * a.pass;
     const bool tickets = n_tiles > kRsResident;
     uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
     if (tickets && tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
