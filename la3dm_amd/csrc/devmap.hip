@@ -60,6 +60,7 @@ struct la3dm_devmap {
     Arena radix_state, radix_tmp; // devmap_sort.h: histogram + tickets + two status arrays (zero between sorts); ping-pong buffers
     size_t radix_tiles = 0;
     uint32_t radix_seq = 0;       // sorts so far: which of the two histograms is current
+    std::vector<uint8_t> lv_axis_host;   // BGK-LV: staging of the per-axis candidate tables (kept until the next insert)
     bool own_sort = true;         // LA3DM_OWN_SORT=0: rocPRIM's radix sort instead (A/B)
     Arena train, grid, axis_tab, m_code, q_out;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
@@ -1117,14 +1118,12 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     const float bs = dm->block_size;
     const double g = depth >= 3 ? 4.0 * (double)ctx->p.resolution : (double)bs;
     const double half = 0.5 * (double)bs;
-    {
-        const int32_t init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
-        DM_TRY(hipMemcpyAsync(dm->d_lvmm, init, 32, hipMemcpyHostToDevice, st));
-    }
-    hipLaunchKernelGGL(dm_lv_cell_bounds, dim3(cdiv(ns, 256)), dim3(256), 0, st, (const float4 *)samples, ns, half, g, dm->d_lvmm, dm->d_cnt);
-    DM_TRY(hipMemcpyAsync(dm->h_lvmm, dm->d_lvmm, 32, hipMemcpyDeviceToHost, st));
+    // (the bounds live in the counter block — initialised by dm_begin, read back with it)
+    hipLaunchKernelGGL(dm_lv_cell_bounds, dim3(std::min<uint32_t>(cdiv(ns, 256), kMinmaxWgs)), dim3(256), 0, st, (const float4 *)samples, ns, half, g,
+                       (int32_t *)(dm->d_cnt + kCntLvmm), dm->d_cnt);
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     memcpy(dm->h_bbox, dm->h_cnt + kCntBbox, sizeof(float) * 6);
+    memcpy(dm->h_lvmm, dm->h_cnt + kCntLvmm, 28);
     if (dm->h_cnt[kCntError] & kErrLvExtent) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): sample coordinates beyond the gather grid's index range");
     for (int a = 0; a < 6; ++a)
         if (dm->h_bbox[a] != dm->h_bbox[a]) return LA3DM_OK;  // NaN box (first sample not finite): no candidate block, as on the host
@@ -1187,21 +1186,25 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     }
     LvCandArgs ca;
     {
-        uint8_t *base = (uint8_t *)dm->lv_axis.ptr;
+        // one upload from a staging vector that lives as long as the map (no synchronisation for the host buffers' sake)
+        size_t bytes = 0;
+        for (int a = 0; a < 3; ++a) bytes += 8 * ax_idx[a].size();
+        dm->lv_axis_host.resize(bytes);
+        uint8_t *base = (uint8_t *)dm->lv_axis.ptr, *hb = dm->lv_axis_host.data();
         size_t o = 0;
         for (int a = 0; a < 3; ++a) {
             const size_t m = ax_idx[a].size();
-            DM_TRY(hipMemcpyAsync(base + o, ax_idx[a].data(), 4 * m, hipMemcpyHostToDevice, st));
+            memcpy(hb + o, ax_idx[a].data(), 4 * m);
             ca.idx[a] = (const int32_t *)(base + o);
             o += 4 * m;
-            DM_TRY(hipMemcpyAsync(base + o, ax_mult[a].data(), 4 * m, hipMemcpyHostToDevice, st));
+            memcpy(hb + o, ax_mult[a].data(), 4 * m);
             ca.mult[a] = (const uint32_t *)(base + o);
             o += 4 * m;
             ca.n[a] = (uint32_t)m;
             ca.cmin[a] = ga.cmin[a];
             ca.cdim[a] = ga.cdim[a];
         }
-        DM_TRY(hipStreamSynchronize(st));  // the host vectors go out of use only after the copies
+        DM_TRY(hipMemcpyAsync(base, hb, bytes, hipMemcpyHostToDevice, st));
     }
     ca.block_size = bs;
     ca.g = g;
@@ -1228,13 +1231,12 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     DM_RESERVE(dm->lv_pmult, 4ull * nc);
     DM_RESERVE(dm->lv_info, 4ull * nc);
     DM_RESERVE(dm->lv_prune, 4ull * nc);
-    DM_TRY(hipMemsetAsync(dm->lv_info.ptr, 0, 4ull * nc, st));
     hipLaunchKernelGGL(dm_lv_pack, dim3(cdiv(nc, 256)), dim3(256), 0, st, (const long long *)dm->lv_keys.ptr, (const uint32_t *)dm->lv_mult.ptr,
                        (const uint32_t *)dm->lv_flag.ptr, (const uint32_t *)dm->lv_pos.ptr, (const uint32_t *)dm->lv_slot.ptr, nc, bs, g,
                        (float *)dm->lv_center.ptr, (int32_t *)dm->lv_cell0.ptr, (uint32_t *)dm->lv_pslot.ptr, (uint32_t *)dm->lv_pmult.ptr,
-                       dm->d_cnt);
-    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntLeaves, 0, 4, st));  // counts the voxel updates of all passes
-    DM_TRY(hipMemsetAsync(dm->d_cnt + kCntGeo, 0, 4, st));     // counts the blocks with information
+                       dm->d_cnt, (uint32_t *)dm->lv_info.ptr);
+    // (d_cnt[kCntLeaves] counts the voxel updates of all passes, d_cnt[kCntGeo] the blocks with information: zero since
+    // dm_begin, nothing before this point of a BGK-LV insert touches them)
     // work plan of the voxel kernel for at most nc packed blocks (the kernel itself stops at the packed count, which is
     // still on the device): its totals come back with the counters below
     la3dm_lv_pool_scan ps;

@@ -50,7 +50,8 @@ enum DevCounter {
     kCntLvPlan = 18,     // BGK-LV work plan (words 18-20): workgroups, scratch rows, split cubes
     kCntGrid = 21,       // GridParams of the last voxel-filter call (10 words), for the host
     kCntBbox = 31,       // training-set box (6 floats as bits), for the host
-    kCntWords = 37
+    kCntLvmm = 37,       // BGK-LV: bucket bounds of the finite samples (3 min, 3 max as int32) + their count
+    kCntWords = 44
 };
 
 struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call
@@ -253,7 +254,12 @@ __global__ __launch_bounds__(1024) void dm_sort_small(const uint32_t *__restrict
 // start of an insert: the counter block is zero except the pool's block count, the min/max words are at their identities
 __global__ void dm_begin(uint32_t *counters, uint32_t n_blocks, uint32_t *mm, uint32_t *done) {
     const uint32_t i = threadIdx.x;
-    if (i < (uint32_t)kCntWords) counters[i] = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
+    if (i < (uint32_t)kCntWords) {
+        uint32_t v = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
+        if (i >= (uint32_t)kCntLvmm && i < (uint32_t)kCntLvmm + 3u) v = 0x7FFFFFFFu;        // INT32_MAX
+        else if (i >= (uint32_t)kCntLvmm + 3u && i < (uint32_t)kCntLvmm + 6u) v = 0x80000000u;   // INT32_MIN
+        counters[i] = v;
+    }
     if (i < 3) mm[i] = mm[8 + i] = 0xFFFFFFFFu;   // mm[8..13]: the second box (kept hits) of the fused front end
     else if (i < 6) mm[i] = mm[8 + i] = 0u;
     if (i == 6) *done = 0u;

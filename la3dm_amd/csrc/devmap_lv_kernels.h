@@ -293,33 +293,58 @@ __device__ __forceinline__ long long lv_cidx(float v, double half, double g) { r
 constexpr uint32_t kErrLvExtent = 4u;
 __global__ __launch_bounds__(256) void dm_lv_cell_bounds(const float4 *__restrict__ samples, uint32_t ns, double half, double g,
                                                         int32_t *mm, uint32_t *counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int32_t s_lo[4][3], s_hi[4][3];
+    __shared__ uint32_t s_n[4];
     int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-    bool ok = false;
-    if (i < ns) {
+    uint32_t n_ok = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
         const float4 s = samples[i];
         if (isfinite(s.x) && isfinite(s.y) && isfinite(s.z)) {
             const long long c[3] = {lv_cidx(s.x, half, g), lv_cidx(s.y, half, g), lv_cidx(s.z, half, g)};
-            ok = true;
+            bool ok = true;
             for (int a = 0; a < 3; ++a) ok &= c[a] >= -(1ll << 30) && c[a] <= (1ll << 30);
             if (!ok) atomicOr(&counters[kCntError], kErrLvExtent);
-            else
-                for (int a = 0; a < 3; ++a) lo[a] = hi[a] = (int32_t)c[a];
+            else {
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = min(lo[a], (int32_t)c[a]);
+                    hi[a] = max(hi[a], (int32_t)c[a]);
+                }
+                ++n_ok;
+            }
         }
     }
-    // one set of atomics per wave
-    for (int o = 32; o >= 1; o >>= 1)
+    // one set of atomics per workgroup, at most 128 workgroups (an atomic on one address costs ~25 ns per caller, serialised)
+    for (int o = 32; o >= 1; o >>= 1) {
         for (int a = 0; a < 3; ++a) {
             lo[a] = min(lo[a], __shfl_xor(lo[a], o));
             hi[a] = max(hi[a], __shfl_xor(hi[a], o));
         }
-    const unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m) {
+        n_ok += __shfl_xor(n_ok, o);
+    }
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&mm[a], lo[a]);
-            atomicMax(&mm[3 + a], hi[a]);
+            s_lo[wv][a] = lo[a];
+            s_hi[wv][a] = hi[a];
         }
-        atomicAdd((uint32_t *)&mm[6], (uint32_t)__popcll(m));
+        s_n[wv] = n_ok;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (int w = 0; w < 4; ++w) n += s_n[w];
+        if (n) {
+            for (int a = 0; a < 3; ++a) {
+                int32_t l = s_lo[0][a], h = s_hi[0][a];
+                for (int w = 1; w < 4; ++w) {
+                    l = min(l, s_lo[w][a]);
+                    h = max(h, s_hi[w][a]);
+                }
+                atomicMin(&mm[a], l);
+                atomicMax(&mm[3 + a], h);
+            }
+            atomicAdd((uint32_t *)&mm[6], n);
+        }
     }
 }
 // key = linear bucket index (x fastest), ncell for a sample that is not binned (non-finite: it keeps its place in
@@ -410,9 +435,10 @@ __global__ __launch_bounds__(256) void dm_lv_pack(const long long *__restrict__ 
                                                  const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
                                                  const uint32_t *__restrict__ slot, uint32_t n_cand, float block_size, double g,
                                                  float *__restrict__ center, int32_t *__restrict__ cell0, uint32_t *__restrict__ p_slot,
-                                                 uint32_t *__restrict__ p_mult, uint32_t *counters) {
+                                                 uint32_t *__restrict__ p_mult, uint32_t *counters, uint32_t *__restrict__ info) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_cand) return;
+    info[t] = 0u;   // "had information" flags of the packed blocks (at most n_cand of them)
     if (t == n_cand - 1) counters[kCntTest] = pos[t] + flag[t];
     if (!flag[t]) return;
     const uint32_t w = pos[t];

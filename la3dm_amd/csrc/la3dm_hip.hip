@@ -55,8 +55,8 @@ static void lv_plan_layout(la3dm_ctx *ctx, LvArgs &a, uint32_t n_tasks) {
     a.split_list = a.task_row0 + n_tasks;
 }
 // Reserves the plan arrays, points `a` at them and launches the plan kernel; the three totals (workgroups, scratch rows,
-// split cubes) land in totals_dev (zeroed here), for the caller to read back.
-static int lv_plan_launch(la3dm_ctx *ctx, LvArgs &a, uint32_t n_samples, uint32_t *totals_dev, hipStream_t stream) {
+// split cubes) land in totals_dev (zeroed here unless the caller vouches for them), for the caller to read back.
+static int lv_plan_launch(la3dm_ctx *ctx, LvArgs &a, uint32_t n_samples, uint32_t *totals_dev, hipStream_t stream, bool zero_totals = true) {
     const uint64_t w = 2ull * (uint64_t)a.reach + 1ull, nb = w * w * w;
     const uint64_t max_subs = (uint64_t)a.n_tasks + nb * (uint64_t)n_samples / kLvChunk + 1;   // sum of ceil(stream / chunk)
     if (max_subs > 0x7FFFFFFFull) {
@@ -68,7 +68,7 @@ static int lv_plan_launch(la3dm_ctx *ctx, LvArgs &a, uint32_t n_samples, uint32_
     if ((rc = arena_reserve(ctx, ctx->lvp_task, 16ull * a.n_tasks)) != LA3DM_OK) return rc;
     lv_plan_layout(ctx, a, a.n_tasks);
     a.plan_totals = totals_dev;
-    HIP_TRY(ctx, hipMemsetAsync(totals_dev, 0, 12, stream));
+    if (zero_totals) HIP_TRY(ctx, hipMemsetAsync(totals_dev, 0, 12, stream));
     hipLaunchKernelGGL(bgklv_plan_kernel, dim3((a.n_tasks + 4 * kLvPlanPerWave - 1) / (4 * kLvPlanPerWave)), dim3(256), 0, stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return LA3DM_OK;
@@ -140,7 +140,7 @@ int la3dm_bgklv_pool_plan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, ui
     int rc = lv_pool_args(ctx, s, a);
     if (rc != LA3DM_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return lv_plan_launch(ctx, a, s->n_samples, totals_dev, stream);
+    return lv_plan_launch(ctx, a, s->n_samples, totals_dev, stream, false);   // the caller's counter block is zero at this point
 }
 
 int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hipStream_t stream) {
