@@ -643,7 +643,11 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
 // chain still runs over i ascending — the oracle's order.  Rows of L are loaded with coalesced vector
 // loads (lane = column) and broadcast with v_readlane; v lives in LDS [row][lane].  Blocks with more than 64
 // rows go through gp_solve_mfma (above).
-constexpr int kGpLdsRows = 64;  // blocks up to one wave of rows are solved in LDS; larger ones on the matrix cores
+constexpr int kGpLdsRows = 64;  // rows of v the LDS path can hold (one wave of columns of L)
+#ifndef LA3DM_GP_MFMA_MIN_N
+#define LA3DM_GP_MFMA_MIN_N 65
+#endif
+constexpr int kGpMfmaMinN = LA3DM_GP_MFMA_MIN_N;  // blocks with at least this many points are solved on the matrix cores
 
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void gp_predict_fuse_kernel(GpArgs a) {
     extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: sized per launch, LDS is the occupancy limiter
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const float4 *x = a.pts + r.x;
         const float *al = a.alpha_k + r.x;
         float mj = 0.0f, ss = 0.0f;
-        if (N <= kWave) {
+        if (N < kGpMfmaMinN) {
             // fast path: a row of L fits one register (lane = column)
             for (int k0 = 0; k0 < N; k0 += 4) {
                 float Lr[4], acc[4], ks[4];

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -489,7 +490,7 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     a.n_train_blk = s->n_train_blk;
     a.vmax = 0;
     a.vscratch = nullptr;
-    if (max_n > (uint32_t)kGpLdsRows) {
+    if (max_n >= (uint32_t)kGpMfmaMinN) {
         a.vmax = max_n;
         if ((rc = arena_reserve(ctx, ctx->gp_v, sizeof(float) * (size_t)a.n_tasks * max_n * kWave)) != LA3DM_OK) return rc;
         a.vscratch = (float *)ctx->gp_v.ptr;
@@ -544,7 +545,9 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     }
     {
         const uint32_t rows = max_n < (uint32_t)kGpLdsRows ? (max_n ? max_n : 1u) : (uint32_t)kGpLdsRows;
-        hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), rows * kWave * sizeof(float), stream, a);
+        size_t lds = rows * kWave * sizeof(float);
+        if (max_n >= (uint32_t)kGpMfmaMinN) lds = std::max<size_t>(lds, 3 * 32 * 36 * sizeof(float));   // gp_solve_mfma's three tile buffers
+        hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), lds, stream, a);
     }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
     HIP_TRY(ctx, hipGetLastError());
