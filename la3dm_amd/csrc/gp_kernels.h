@@ -129,8 +129,14 @@ __device__ __forceinline__ float rl(float v, int lane_idx) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx));
 }
 
-__global__ __launch_bounds__(kWave) void gp_train_kernel(GpArgs a) {
-    __shared__ float s_tile[2][32][kTrT];
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void gp_train_kernel(GpArgs a) {
+    // MFMA operand tiles of L (rows x 32 columns of an earlier block column), fetched as four coalesced 16-byte loads per
+    // lane and passed through LDS: read straight from the row-major factor, lane c = row c touches 32 cache lines per load
+    // and the wave waits a memory round trip per k-pair (this kernel was latency bound: 9.6 ms for 4 726 blocks).
+    // The accumulator -> [row][col] transposes (s_tile) happen after the operand loop and share the space.
+    __shared__ __attribute__((aligned(16))) float s_lds[3 * 32 * 36];
+    float (*s_op)[32][36] = reinterpret_cast<float (*)[32][36]>(s_lds);
+    float (*s_tile)[32][kTrT] = reinterpret_cast<float (*)[32][kTrT]>(s_lds);
     const uint32_t b = blockIdx.x;
     const uint32_t p0 = a.train_off[b];
     const int N = (int)(a.train_off[b + 1] - p0);
@@ -166,6 +172,29 @@ __global__ __launch_bounds__(kWave) void gp_train_kernel(GpArgs a) {
         for (int r = 0; r < 16; ++r) s_tile[t][8 * (r >> 2) + 4 * h + (r & 3)][c] = C[r];
     };
 
+    const int trow = lane >> 3, tcol = 4 * (lane & 7);
+    auto load_tile = [&](float4 (&g)[4], int R, int T, bool on) {   // rows R .. R + 31, columns 32 T .. 32 T + 31 (all < N)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = R + 8 * i + trow;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on && row < N) __builtin_memcpy(&q, L + (size_t)row * N + 32 * T + tcol, 16);   // 4-byte aligned
+            g[i] = q;
+        }
+    };
+    auto store_tile = [&](int t, const float4 (&g)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&s_op[t][8 * i + trow][tcol]) = g[i];
+    };
+    auto read_ops = [&](int t, float (&o)[16]) {   // operand layout: lane (c, h) holds tile[c][2 m2 + h]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 q = *reinterpret_cast<const float4 *>(&s_op[t][c][4 * i]);
+            o[2 * i] = h ? q.y : q.x;
+            o[2 * i + 1] = h ? q.w : q.z;
+        }
+    };
+
     for (int J = 0; J < nblk; ++J) {
         const int RJ = 32 * J;
         // ---------------- diagonal block ----------------
@@ -174,12 +203,19 @@ __global__ __launch_bounds__(kWave) void gp_train_kernel(GpArgs a) {
             f32x16 C;
             kblock(RJ, RJ, C);
             const int arow = RJ + c;
-            const float *Lrow = L + (size_t)(arow < N ? arow : 0) * N;
-            for (int T = 0; T < J; ++T) {
-#pragma unroll 4
-                for (int m2 = 0; m2 < 16; ++m2) {
-                    const float lv = arow < N ? Lrow[32 * T + 2 * m2 + h] : 0.0f;
-                    C = __builtin_amdgcn_mfma_f32_32x32x2f32(-lv, lv, C, 0, 0, 0);
+            {
+                float4 g[4];
+                if (J > 0) load_tile(g, RJ, 0, true);
+                for (int T = 0; T < J; ++T) {
+                    float lv[16];
+                    store_tile(0, g);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    read_ops(0, lv);
+                    if (T + 1 < J) load_tile(g, RJ, T + 1, true);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int m2 = 0; m2 < 16; ++m2) C = __builtin_amdgcn_mfma_f32_32x32x2f32(-lv[m2], lv[m2], C, 0, 0, 0);
                 }
             }
             to_tile(C, 0);
@@ -215,18 +251,32 @@ __global__ __launch_bounds__(kWave) void gp_train_kernel(GpArgs a) {
                 for (int r = 0; r < 16; ++r) C1[r] = 0.0f;
             }
             {
-                const int r0 = RI0 + c, r1 = RI1 + c, rb = RJ + c;
-                const float *A0 = L + (size_t)(r0 < N ? r0 : 0) * N, *A1 = L + (size_t)(two && r1 < N ? r1 : 0) * N;
-                const float *Bp = L + (size_t)(rb < N ? rb : 0) * N;
+                float4 g0[4], g1[4], gb[4];
+                if (J > 0) {
+                    load_tile(g0, RI0, 0, true);
+                    load_tile(g1, RI1, 0, two);
+                    load_tile(gb, RJ, 0, true);
+                }
                 for (int T = 0; T < J; ++T) {
-#pragma unroll 4
+                    float a0[16], a1[16], bv[16];
+                    store_tile(0, g0);
+                    store_tile(1, g1);
+                    store_tile(2, gb);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    read_ops(0, a0);
+                    read_ops(1, a1);
+                    read_ops(2, bv);
+                    if (T + 1 < J) {   // the next tiles are in flight while this block's 32 MFMAs run
+                        load_tile(g0, RI0, T + 1, true);
+                        load_tile(g1, RI1, T + 1, two);
+                        load_tile(gb, RJ, T + 1, true);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
                     for (int m2 = 0; m2 < 16; ++m2) {
-                        const int kc = 32 * T + 2 * m2 + h;
-                        const float bv = rb < N ? Bp[kc] : 0.0f;
-                        const float a0 = r0 < N ? -A0[kc] : 0.0f;
-                        const float a1 = (two && r1 < N) ? -A1[kc] : 0.0f;
-                        C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, C0, 0, 0, 0);
-                        C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, C1, 0, 0, 0);
+                        C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0[m2], bv[m2], C0, 0, 0, 0);
+                        C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1[m2], bv[m2], C1, 0, 0, 0);
                     }
                 }
             }
