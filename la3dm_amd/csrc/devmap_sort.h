@@ -39,11 +39,11 @@ struct RadixArgs {
     int err_slot;
 };
 
-// Tiles take their number from the workgroup id while all of a sort's workgroups fit on the chip at once (256 CUs x 4
-// workgroups of 38 KB LDS): no workgroup can then wait for one that has no slot.  Larger sorts draw tickets.  Every
+// Tiles take their number from the workgroup id while all of a sort's workgroups fit on the chip at once (256 CUs x 3
+// workgroups at 159 VGPRs = 768): no workgroup can then wait for one that has no slot.  Larger sorts draw tickets.  Every
 // device-scope atomic with a returned value costs a ~2.5 us round trip, and a pass is a chain of them: ticket, look-back,
 // arrival count — the resident form has only the look-back left.
-constexpr uint32_t kRsResident = 1024;
+constexpr uint32_t kRsResident = 512;
 
 __device__ __forceinline__ uint32_t rs_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rs_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

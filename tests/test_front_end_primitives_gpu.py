@@ -23,7 +23,7 @@ def devmap(built):
     H.la3dm_devmap_destroy(dm)
 
 
-SIZES = [1, 2, 63, 64, 65, 4095, 4096, 4097, 12345, 262144, 1000003, 4096 * 1024 + 17, 6_000_011, 7, 4096 * 1024, 5]
+SIZES = [1, 2, 63, 64, 65, 4095, 4096, 4097, 12345, 262144, 1000003, 4096 * 512, 4096 * 512 + 1, 3_000_001, 4096 * 1024 + 17, 6_000_011, 7, 4096 * 1024, 5]
 
 
 def test_exclusive_scan(devmap):
