@@ -2,7 +2,8 @@
 //
 // Reference (CPU):
 //   BGKLInference::predict        include/bgkloctomap/bgklinference.h:80-88
-//   point_to_line_dist            include/bgkloctomap/bgklinference.h:104-140   (== seg_dist_dev, lv_kernels.h)
+//   point_to_line_dist            include/bgkloctomap/bgklinference.h:104-140   (== seg_dist_dev, lv_kernels.h; evaluated by
+//                                 its fp32 twin seg_dist_f32, same bits: see there)
 //   covSparseLine                 include/bgkloctomap/bgklinference.h:186-200   (d / ell, formula, `< 0 -> 0`)
 //   7-neighbour update loop       src/bgkloctomap/bgkloctomap.cpp:206-231       (gate: kbar > 0.001)
 //   Occupancy::update             src/bgkloctomap/bgkloctree_node.cpp:31-44     (same node as BGKOctoMap)
@@ -34,6 +35,7 @@ struct BgklArgs {
     uint32_t tpb_shift;
     uint32_t n_tasks;
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
+    float inv_ell;   // RN(1 / ell) or 0 (bgk_kernels.h div_by_ell)
 };
 
 // Split path for the tiles around the sensor.  Every beam crosses the sensor's block, so a 200 k-ray scan hands a
@@ -79,8 +81,8 @@ struct BgklSplit {
 // dense formula yields NaN, the `< 0 -> 0` clean-up lets it through and it poisons ybar / kbar of every leaf that
 // meets the row (the kbar > 0.001 gate then rejects the update) — kept, with k = NaN.
 __device__ __forceinline__ bool bgkl_row_counts(float d, float ell) { return !(d >= ell) || d == __builtin_inff(); }
-__device__ __forceinline__ float bgkl_row_kernel(float d, float ell, float sf2) {
-    return (d - d == 0.0f) ? cov_sparse<true, 0>(d / ell, sf2) : __builtin_nanf("");
+__device__ __forceinline__ float bgkl_row_kernel(float d, float ell, float inv_ell, float sf2) {
+    return (d - d == 0.0f) ? cov_sparse_fast<0, true>(div_by_ell(d, ell, inv_ell), sf2) : __builtin_nanf("");
 }
 
 // leaf of this lane: false when the tile holds no leaves
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
             for (uint32_t j = r0; j < r1; ++j) {
                 const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j);       // x0 y0 z0 x1
                 const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j + 4);   // y1 z1 label -
-                const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
                 const bool hit = active && bgkl_row_counts(d, a.ell);
                 if (__ballot(hit) == 0ull) continue;
                 if (hit) {
-                    const float kv = bgkl_row_kernel(d, a.ell, a.sf2);
+                    const float kv = bgkl_row_kernel(d, a.ell, a.inv_ell, a.sf2);
                     ybar += kv * p1.z;
                     kbar += kv;
                 }
@@ -166,10 +168,10 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
                     const size_t row = (size_t)q + j;
                     const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * row);
                     const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
-                    const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                    const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
                     float kv = 0.0f, kyv = 0.0f;
                     if (active && bgkl_row_counts(d, a.ell)) {
-                        kv = bgkl_row_kernel(d, a.ell, a.sf2);
+                        kv = bgkl_row_kernel(d, a.ell, a.inv_ell, a.sf2);
                         kyv = kv * p1.z;
                     }
                     s_k[j][lane] = kv;
@@ -258,14 +260,14 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
             const uint2 mm = *reinterpret_cast<const uint2 *>(rec + j);  // wave-uniform
             const unsigned long long m = ((unsigned long long)mm.y << 32) | mm.x;
             if (m == 0ull) continue;
-            const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+            const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
             if ((m >> lane) & 1ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mm.y, __builtin_amdgcn_mbcnt_lo(mm.x, 0));
-                s.vals[vb + off + rank] = bgkl_row_kernel(d, a.ell, a.sf2);
+                s.vals[vb + off + rank] = bgkl_row_kernel(d, a.ell, a.inv_ell, a.sf2);
             }
             off += (uint32_t)__popcll(m);
         } else {
-            const float d = seg_dist_dev(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+            const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
             const unsigned long long m = __ballot(active && bgkl_row_counts(d, a.ell));
             if ((j & 63u) == 0u) {
                 boff = off;

@@ -661,6 +661,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     a.n_tasks = s->n_test_blk << tpb_shift;
     a.sf2 = ctx->p.sf2;
     a.ell = ctx->p.ell;
+    a.inv_ell = ctx->inv_ell;
     a.free_thresh = ctx->p.free_thresh;
     a.occupied_thresh = ctx->p.occupied_thresh;
     a.var_thresh = ctx->p.var_thresh;

@@ -115,6 +115,15 @@ __device__ __forceinline__ void lv_seg_point(float px, float py, float pz, float
     if (b < 0x1p-100f) b = (float)((double)c1 / (double)c2);
     qx = ax + lx * b; qy = ay + ly * b; qz = az + lz * b;
 }
+// point_to_line_dist as one fp32 function (the segment's direction recomputed per call): the same bits as seg_dist_dev
+__device__ __forceinline__ float seg_dist_f32(float px, float py, float pz, float ax, float ay, float az, float bx, float by, float bz) {
+    const float lx = bx - ax, ly = by - ay, lz = bz - az;
+    float qx = ax, qy = ay, qz = az;
+    if (!(sqrtf(lx * lx + ly * ly + lz * lz) < 0.0001f)) lv_seg_point(px, py, pz, ax, ay, az, bx, by, bz, lx, ly, lz, qx, qy, qz);
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
 // covSparseLine at distance |p - q| (bgklvinference.h:143-156: r = min(d / ell, 1), no clamp of negative values)
 __device__ __forceinline__ float lv_kernel_at(float px, float py, float pz, float qx, float qy, float qz, float ell, float inv_ell,
                                               float sf2) {

@@ -102,6 +102,8 @@ def test_fp32_line_distance_matches_the_reference_double_steps(built):
     m = la3dm_amd.BGKLVOctoMap(**la3dm_amd.LV_YAML, device=0)
     assert m.diag_sweep(4, 0.0, np.float32(np.finfo(np.float32).max)) == 0
     assert m.diag_sweep(9, 2.0 ** -20, 2.0 ** 12) == 0
+    # d / ell by reciprocal + one exact correction, also for the tiny distances of a voxel centre next to a sample
+    assert m.diag_sweep(7, 2.0 ** -80, 2.0 ** 6) == 0
 
 
 @pytest.mark.parametrize("ell,depth,both_modes", [(0.5, 3, True), (0.9, 4, False)])
