@@ -1270,7 +1270,8 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     const double t1 = wall();
     if (n_packed) {
         ps.n_blk = n_packed;
-        for (int a = 0; a < 3; ++a) ps.plan_totals[a] = dm->h_cnt[kCntLvPlan + a];
+        for (int a = 0; a < 4; ++a) ps.plan_totals[a] = dm->h_cnt[kCntLvPlan + a];
+        ps.plan_totals_dev = dm->d_cnt + kCntLvPlan;
         const uint32_t layer_n = 1u << (3 * (depth - 1)), layer_off = dm->npb - layer_n;
         for (uint32_t pass = 0; pass < max_mult; ++pass) {  // a key the float-stepped loop repeats is visited again, serially
             ps.pass = pass;

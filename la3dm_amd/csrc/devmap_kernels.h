@@ -47,11 +47,11 @@ enum DevCounter {
     kCntTrained = 13,    // blocks with training points that are in the candidate list
     kCntPairEvals = 14,  // 64-bit (words 14, 15): sum of neighbourhood points x leaves; kCntTrainReads likewise (10, 11)
     kCntBeamTotal = 16,  // 64-bit (words 16, 17): beam samples of the scan, summed without the 32-bit wrap of the offsets
-    kCntLvPlan = 18,     // BGK-LV work plan (words 18-20): workgroups, scratch rows, split cubes
+    kCntLvPlan = 44,     // BGK-LV work plan (4 words): workgroups of split cubes, scratch rows, split cubes, other workgroups
     kCntGrid = 21,       // GridParams of the last voxel-filter call (10 words), for the host
     kCntBbox = 31,       // training-set box (6 floats as bits), for the host
     kCntLvmm = 37,       // BGK-LV: bucket bounds of the finite samples (3 min, 3 max as int32) + their count
-    kCntWords = 44
+    kCntWords = 48
 };
 
 struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call

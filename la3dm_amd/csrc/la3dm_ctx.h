@@ -36,7 +36,7 @@ struct la3dm_ctx {
     Arena gp_loff, gp_totals, gp_L, gp_alpha, gp_v;
     Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_val, l_item_hits, l_bdesc, l_vals;
     Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;
-    Arena lvp_sub_task, lvp_task, lvp_totals, lvp_rows, lvp_row_y, lvp_sub_out;  // BGK-LV work plan + row scratch of split cubes
+    Arena lvp_sub_task, lvp_task, lvp_totals, lvp_rows, lvp_row_y, lvp_sub_out, lvp_cand;  // BGK-LV work plan + row scratch of split cubes
     // staging (host-pointer path)
     Arena h_train, h_train_off, h_nbr, h_center, h_leaf_off, h_leaf_key, h_alpha, h_beta, h_state, h_diag_in,
         h_diag_out;
@@ -86,7 +86,9 @@ struct la3dm_lv_pool_scan {
     uint32_t n_samples;
     uint32_t plan_n_blk;                   // block count the plan arrays were laid out for (>= n_blk)
     const uint32_t *n_blk_dev;             // plan only: the packed block count, still on the device (nullptr: n_blk)
-    uint32_t plan_totals[3];               // read back from the plan: workgroups, scratch rows, split cubes
+    uint32_t plan_totals[4];               // read back from the plan: workgroups of split cubes, scratch rows, split cubes,
+                                           // workgroups of the other cubes
+    uint32_t *plan_totals_dev;             // where the plan left them on the device (the voxel kernel reads [0])
 };
 // plan once per scan (totals_dev: 3 words the caller reads back into plan_totals), then one scan per pass
 int la3dm_bgklv_pool_plan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, uint32_t *totals_dev, hipStream_t stream);

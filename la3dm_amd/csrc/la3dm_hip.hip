@@ -48,7 +48,13 @@ static void lv_fill_args(la3dm_ctx *ctx, LvArgs &a, uint32_t n_blk) {
 }
 
 // ---- BGK-LV work plan (lv_kernels.h bgklv_plan_kernel): which cube gets how many workgroups ----
-static void lv_plan_layout(la3dm_ctx *ctx, LvArgs &a, uint32_t n_tasks) {
+// upper bound of the workgroups a plan can hand out: sum over the cubes of ceil(stream / chunk)
+static uint64_t lv_max_subs(const LvArgs &a, uint32_t n_tasks, uint32_t n_samples) {
+    const uint64_t w = 2ull * (uint64_t)a.reach + 1ull, nb = w * w * w;
+    return (uint64_t)n_tasks + nb * (uint64_t)n_samples / kLvChunk + 1;
+}
+static void lv_plan_layout(la3dm_ctx *ctx, LvArgs &a, uint32_t n_tasks, uint32_t n_samples) {
+    a.max_subs = (uint32_t)lv_max_subs(a, n_tasks, n_samples);
     a.sub_task = (uint32_t *)ctx->lvp_sub_task.ptr;
     a.task_first = (uint32_t *)ctx->lvp_task.ptr;
     a.task_nsub = a.task_first + n_tasks;
@@ -58,30 +64,34 @@ static void lv_plan_layout(la3dm_ctx *ctx, LvArgs &a, uint32_t n_tasks) {
 // Reserves the plan arrays, points `a` at them and launches the plan kernel; the three totals (workgroups, scratch rows,
 // split cubes) land in totals_dev (zeroed here unless the caller vouches for them), for the caller to read back.
 static int lv_plan_launch(la3dm_ctx *ctx, LvArgs &a, uint32_t n_samples, uint32_t *totals_dev, hipStream_t stream, bool zero_totals = true) {
-    const uint64_t w = 2ull * (uint64_t)a.reach + 1ull, nb = w * w * w;
-    const uint64_t max_subs = (uint64_t)a.n_tasks + nb * (uint64_t)n_samples / kLvChunk + 1;   // sum of ceil(stream / chunk)
-    if (max_subs > 0x7FFFFFFFull) {
+    const uint64_t max_subs = lv_max_subs(a, a.n_tasks, n_samples);
+    if (max_subs > 0x3FFFFFFFull) {
         ctx->err = "lv scan: too many cubes x samples for the work plan";
         return LA3DM_ERR_ARG;
     }
     int rc;
-    if ((rc = arena_reserve(ctx, ctx->lvp_sub_task, 4 * max_subs)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->lvp_sub_task, 8 * max_subs)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->lvp_task, 16ull * a.n_tasks)) != LA3DM_OK) return rc;
-    lv_plan_layout(ctx, a, a.n_tasks);
+    if ((rc = arena_reserve(ctx, ctx->lvp_cand, sizeof(LvCand) * (size_t)(n_samples ? n_samples : 1))) != LA3DM_OK) return rc;
+    a.cand = (LvCand *)ctx->lvp_cand.ptr;
+    a.n_samples = n_samples;
+    if (n_samples) hipLaunchKernelGGL(bgklv_cand_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, stream, a);
+    lv_plan_layout(ctx, a, a.n_tasks, n_samples);
     a.plan_totals = totals_dev;
-    if (zero_totals) HIP_TRY(ctx, hipMemsetAsync(totals_dev, 0, 12, stream));
+    if (zero_totals) HIP_TRY(ctx, hipMemsetAsync(totals_dev, 0, 16, stream));
     hipLaunchKernelGGL(bgklv_plan_kernel, dim3((a.n_tasks + 4 * kLvPlanPerWave - 1) / (4 * kLvPlanPerWave)), dim3(256), 0, stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return LA3DM_OK;
 }
 
 // the voxel kernel over the planned workgroups + the ordered adds of the split cubes (totals: as read back from the plan)
-static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[3], hipStream_t stream) {
-    const uint32_t n_subs = totals[0], n_rows = totals[1], n_split = totals[2];
+static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[4], hipStream_t stream) {
+    const uint32_t n_heavy = totals[0], n_rows = totals[1], n_split = totals[2], n_subs = totals[0] + totals[3];
     if (n_subs == 0) return LA3DM_OK;
     int rc;
     if ((rc = arena_reserve(ctx, ctx->lvp_rows, 256ull * (n_rows ? n_rows : 1))) != LA3DM_OK) return rc;
     constexpr size_t kWords = kLvChunk / kWave;
+    (void)n_heavy;
     if ((rc = arena_reserve(ctx, ctx->lvp_sub_out, 8ull * (2 * kWords + 1) * n_subs)) != LA3DM_OK) return rc;
     a.rows = (float *)ctx->lvp_rows.ptr;
     a.sub_info = (unsigned long long *)ctx->lvp_sub_out.ptr;
@@ -151,7 +161,10 @@ int la3dm_bgklv_pool_scan_device(la3dm_ctx *ctx, const la3dm_lv_pool_scan *s, hi
     if (rc != LA3DM_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the plan arrays are where la3dm_bgklv_pool_plan_device left them
-    lv_plan_layout(ctx, a, (s->plan_n_blk ? s->plan_n_blk : s->n_blk) << a.cubes_shift);
+    lv_plan_layout(ctx, a, (s->plan_n_blk ? s->plan_n_blk : s->n_blk) << a.cubes_shift, s->n_samples);
+    a.plan_totals = s->plan_totals_dev;
+    a.cand = (LvCand *)ctx->lvp_cand.ptr;   // built by the plan step
+    a.n_samples = s->n_samples;
     return lv_run_planned(ctx, a, s->plan_totals, stream);
 }
 
@@ -232,7 +245,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_val, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
-                    &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_row_y, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
+                    &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_row_y, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
         if (a->ptr) (void)hipFree(a->ptr);
@@ -621,11 +634,11 @@ int la3dm_bgklv_scan_device(la3dm_ctx *ctx, const la3dm_lv_scan *s, void *stream
     int rc = arena_reserve(ctx, ctx->lvp_totals, 16);
     if (rc != LA3DM_OK) return rc;
     if ((rc = lv_plan_launch(ctx, a, s->n_samples, (uint32_t *)ctx->lvp_totals.ptr, stream)) != LA3DM_OK) return rc;
-    uint32_t totals[3] = {0, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(totals, ctx->lvp_totals.ptr, 12, hipMemcpyDeviceToHost, stream));
+    uint32_t totals[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(totals, ctx->lvp_totals.ptr, 16, hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if ((rc = lv_run_planned(ctx, a, totals, stream)) != LA3DM_OK) return rc;
-    if (out) out->n_tiles = totals[0];
+    if (out) out->n_tiles = totals[0] + totals[3];
     return LA3DM_OK;
 }
 

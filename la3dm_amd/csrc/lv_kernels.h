@@ -52,10 +52,13 @@ struct LvArgs {
     uint32_t *upd_counter;
     uint32_t npb, layer_off, pass;
     float inv_ell;              // RN(1 / ell) or 0 (bgk_kernels.h div_by_ell)
+    struct LvCand *cand;        // [n_samples] in bucket order: everything the voxel kernel needs of a sample (bgklv_cand_kernel)
+    uint32_t n_samples;
     // work plan (bgklv_plan_kernel): workgroup -> cube, and the row scratch of the cubes that are split over workgroups
-    uint32_t *sub_task;         // nullptr: workgroup = cube, nothing is split
+    uint32_t *sub_task;         // workgroup -> cube: [0, max_subs) the sub-tasks of split cubes, [max_subs, 2 max_subs) the other cubes
+    uint32_t max_subs;
     uint32_t *task_first, *task_nsub, *task_row0, *split_list;
-    uint32_t *plan_totals;      // [0] workgroups, [1] scratch rows, [2] split cubes
+    uint32_t *plan_totals;      // [0] workgroups of split cubes, [1] scratch rows, [2] split cubes, [3] workgroups of the other cubes
     const uint32_t *n_blk_dev;  // plan kernel: number of packed blocks when it is still on the device (else n_tasks counts)
     float *rows;                // [row slot][64 voxels] k; only rows with a non-zero k are written
     unsigned long long *sub_nz; // per workgroup: kLvChunk bits, row slot written
@@ -170,7 +173,7 @@ struct __attribute__((aligned(16))) LvCand {
 // stream positions; the sub-tasks of such a cube write their tile rows to a scratch array instead of adding them, and
 // bgklv_split_add_kernel adds the rows of all sub-tasks in stream order — the same additions in the same order.
 constexpr int kLvWaves = 8;
-constexpr uint32_t kLvChunk = 1024;
+constexpr uint32_t kLvChunk = 512;
 constexpr uint32_t kLvGroup = 64;   // buckets whose ranges are resident in LDS at a time
 
 struct LvLds {
@@ -279,11 +282,38 @@ __device__ __forceinline__ float lv_add_dense(const float (*k)[kWave], uint32_t 
     return acc;
 }
 
+// The voxel kernel's view of the samples, in bucket order, one 64-byte record each (built once per scan): position and
+// type, the previous sample of the same ray, the ray's segment and its direction.
+__global__ __launch_bounds__(256) void bgklv_cand_kernel(LvArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_samples) return;
+    const float4 s = a.sorted[i];
+    const uint32_t orig = __float_as_uint(s.w);
+    LvCand c;
+    c.p = make_float4(s.x, s.y, s.z, 0.0f);
+    c.prev = c.r0 = c.r1 = c.p;
+    const int ray = orig < a.n_samples ? (int)a.samples[orig].w : -1;
+    if (ray >= 0) {
+        const float4 ra = a.rays[2 * ray], rb = a.rays[2 * ray + 1];
+        const uint32_t first = __float_as_uint(ra.w);
+        const float lx = rb.x - ra.x, ly = rb.y - ra.y, lz = rb.z - ra.z;
+        float type = orig == first ? 1.0f : 2.0f;
+        if (sqrtf(lx * lx + ly * ly + lz * lz) < 0.0001f) type += 4.0f;
+        float4 pv = c.p;
+        if (orig != first) pv = a.samples[orig - 1];
+        c.p.w = type;
+        c.prev = make_float4(pv.x, pv.y, pv.z, lx);
+        c.r0 = make_float4(ra.x, ra.y, ra.z, ly);
+        c.r1 = make_float4(rb.x, rb.y, rb.z, lz);
+    }
+    a.cand[i] = c;
+}
+
 // Work plan: cubes without a base-resolution leaf or (pool mode) without a sample in reach get no workgroup; the others
 // ceil(stream / kLvChunk).  A wave looks at 16 cubes one after the other (lane = voxel for the status bytes, lane = bucket
 // for the stream length) and then hands out workgroup numbers, scratch rows and list places for all of them with one
 // atomic each — their order is irrelevant, every cube's result is a function of its own rows alone.
-// totals: [0] workgroups, [1] scratch rows, [2] split cubes.
+// totals: [0] workgroups of split cubes, [1] scratch rows, [2] split cubes, [3] workgroups of the other cubes.
 constexpr uint32_t kLvPlanPerWave = 16;
 __global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
     const int lane = threadIdx.x & 63;
@@ -317,36 +347,45 @@ __global__ __launch_bounds__(256) void bgklv_plan_kernel(LvArgs a) {
     const unsigned long long sm = __ballot(is_split);
     // one atomic per total and WORKGROUP (an atomic on one address costs ~25 ns per caller, serialised: per wave they
     // were two thirds of this kernel's time): the four waves' totals meet in LDS, thread 0 draws, the waves take their parts
-    __shared__ uint32_t s_tot[4][3], s_base[3];
+    __shared__ uint32_t s_tot[4][4], s_base[4];
     const uint32_t wave = threadIdx.x >> 6;
+    // the sub-tasks of split cubes are numbered first: a launch hands its workgroups out in order, and a split cube's
+    // workgroup runs several times longer than the average one — started last, it was the launch's tail
+    const uint32_t heavy_incl = wave_incl_scan_u32(is_split ? my_nsub : 0u, lane);
+    const uint32_t light_incl = wave_incl_scan_u32(my_nsub == 1u ? 1u : 0u, lane);
     if (lane == kWave - 1) {
-        s_tot[wave][0] = sub_incl;
+        s_tot[wave][0] = heavy_incl;
         s_tot[wave][1] = row_incl;
         s_tot[wave][2] = (uint32_t)__popcll(sm);
+        s_tot[wave][3] = light_incl;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         uint32_t t = 0;
         for (uint32_t v = 0; v < 4; ++v) t += s_tot[v][threadIdx.x];
         s_base[threadIdx.x] = t ? atomicAdd(a.plan_totals + threadIdx.x, t) : 0u;
     }
     __syncthreads();
-    uint32_t base_sub = s_base[0], base_row = s_base[1], base_split = s_base[2];
+    uint32_t base_heavy = s_base[0], base_row = s_base[1], base_split = s_base[2], base_light = s_base[3];
     for (uint32_t v = 0; v < wave; ++v) {
-        base_sub += s_tot[v][0];
+        base_heavy += s_tot[v][0];
         base_row += s_tot[v][1];
         base_split += s_tot[v][2];
+        base_light += s_tot[v][3];
     }
+    (void)sub_incl;
     if (lane >= (int)kLvPlanPerWave || task0 + lane >= n_tasks) return;
     const uint32_t task = task0 + lane;
     a.task_nsub[task] = my_nsub;
     if (my_nsub == 0) return;
-    const uint32_t first = base_sub + sub_incl - my_nsub;
-    a.task_first[task] = first;
-    for (uint32_t s2 = 0; s2 < my_nsub; ++s2) a.sub_task[first + s2] = task;
     if (is_split) {
+        const uint32_t first = base_heavy + heavy_incl - my_nsub;
+        a.task_first[task] = first;
+        for (uint32_t s2 = 0; s2 < my_nsub; ++s2) a.sub_task[first + s2] = task;
         a.task_row0[task] = base_row + row_incl - my_stream;
         a.split_list[base_split + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))] = task;
+    } else {
+        a.sub_task[a.max_subs + base_light + light_incl - 1u] = task;
     }
 }
 
@@ -384,9 +423,14 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t task = blockIdx.x, sub = 0, nsub = 1;
     if (a.sub_task) {
-        task = a.sub_task[blockIdx.x];
-        sub = blockIdx.x - a.task_first[task];
-        nsub = a.task_nsub[task];
+        const uint32_t n_heavy = a.plan_totals[0];
+        if (blockIdx.x < n_heavy) {
+            task = a.sub_task[blockIdx.x];
+            sub = blockIdx.x - a.task_first[task];
+            nsub = a.task_nsub[task];
+        } else {
+            task = a.sub_task[a.max_subs + (blockIdx.x - n_heavy)];
+        }
     }
     if (task >= a.n_tasks) return;
     const LvTask t = lv_task(a, task, lane);
@@ -401,6 +445,11 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
     const float inf = __builtin_inff();
     const float tlx = wave_min_dpp(active ? lox : inf), tly = wave_min_dpp(active ? loy : inf), tlz = wave_min_dpp(active ? loz : inf);
     const float thx = wave_max_dpp(active ? hix : -inf), thy = wave_max_dpp(active ? hiy : -inf), thz = wave_max_dpp(active ? hiz : -inf);
+    // the intersection of the active voxels' boxes: a later sample of a ray whose previous sample, or whose ray's first
+    // sample, lies in there is nobody's lowest-index sample in the box — it adds no row; and the voxels' "saw a sample"
+    // flags do not need it either: that previous / first sample is itself in this cube's stream and in every box
+    const float clx = wave_max_dpp(active ? lox : -inf), cly = wave_max_dpp(active ? loy : -inf), clz = wave_max_dpp(active ? loz : -inf);
+    const float chx = wave_min_dpp(active ? hix : inf), chy = wave_min_dpp(active ? hiy : inf), chz = wave_min_dpp(active ? hiz : inf);
     if (threadIdx.x < 2) L.y_round[threadIdx.x] = 0ull;
     if (threadIdx.x < kLvChunk / kWave) L.nz_map[threadIdx.x] = L.y_map[threadIdx.x] = 0ull;
     __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
@@ -443,27 +492,12 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
                 for (uint32_t step = kLvGroup / 2; step > 0; step >>= 1)
                     if (L.g_incl[j + step - 1] <= q) j += step;
                 const uint32_t si = L.g_c0[j] + q;
-                const float4 s = a.sorted[si];
-                keep = !(tlx > s.x || s.x > thx || tly > s.y || s.y > thy || tlz > s.z || s.z > thz);
-                if (keep) {
-                    const uint32_t orig = __float_as_uint(s.w);
-                    const float4 so = a.samples[orig];
-                    const int ray = (int)so.w;
-                    c.p = make_float4(s.x, s.y, s.z, 0.0f);
-                    c.prev = c.r0 = c.r1 = c.p;
-                    if (ray >= 0) {
-                        const float4 ra = a.rays[2 * ray], rb = a.rays[2 * ray + 1];
-                        const uint32_t first = __float_as_uint(ra.w);
-                        const float lx = rb.x - ra.x, ly = rb.y - ra.y, lz = rb.z - ra.z;
-                        float type = orig == first ? 1.0f : 2.0f;
-                        if (sqrtf(lx * lx + ly * ly + lz * lz) < 0.0001f) type += 4.0f;
-                        float4 pv = c.p;
-                        if (orig != first) pv = a.samples[orig - 1];
-                        c.p.w = type;
-                        c.prev = make_float4(pv.x, pv.y, pv.z, lx);
-                        c.r0 = make_float4(ra.x, ra.y, ra.z, ly);
-                        c.r1 = make_float4(rb.x, rb.y, rb.z, lz);
-                    }
+                c = a.cand[si];   // one 64-byte record (was: sorted -> samples -> rays -> previous sample, four dependent loads)
+                keep = !(tlx > c.p.x || c.p.x > thx || tly > c.p.y || c.p.y > thy || tlz > c.p.z || c.p.z > thz);
+                if (keep && ((int)c.p.w & 3) == 2) {
+                    const bool prev_core = !(clx > c.prev.x || c.prev.x > chx || cly > c.prev.y || c.prev.y > chy || clz > c.prev.z || c.prev.z > chz);
+                    const bool first_core = !(clx > c.r0.x || c.r0.x > chx || cly > c.r0.y || c.r0.y > chy || clz > c.r0.z || c.r0.z > chz);
+                    if (prev_core || first_core) keep = false;
                 }
             }
             const unsigned long long m = __ballot(keep);
