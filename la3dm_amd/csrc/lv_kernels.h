@@ -179,7 +179,8 @@ constexpr uint32_t kLvGroup = 64;   // buckets whose ranges are resident in LDS 
 struct LvLds {
     LvCand cand[kLvWaves * kWave];
     float k[kWave][kWave];
-    unsigned long long y_round[2];               // rows of the current round that are hits with a non-zero k (by round parity)
+    unsigned long long y_round[2];               // rows of the current round that are hits with a counted voxel (by round parity)
+    unsigned long long cmask[kWave];             // per candidate of the round: the voxels that count it
     unsigned long long nz_map[kLvChunk / kWave];  // split cube: the same per staged candidate of the sub-task
     unsigned long long y_map[kLvChunk / kWave];
     uint32_t cnt[kLvWaves];
@@ -309,6 +310,27 @@ __global__ __launch_bounds__(256) void bgklv_cand_kernel(LvArgs a) {
     a.cand[i] = c;
 }
 
+// position of the r-th set bit (r = 0: the lowest) of a 64-bit mask that has more than r bits set
+__device__ __forceinline__ uint32_t lv_nth_bit(unsigned long long m, uint32_t r) {
+    uint32_t x = (uint32_t)m, pos = 0;
+    const uint32_t c0 = (uint32_t)__popc(x);
+    if (r >= c0) {
+        r -= c0;
+        x = (uint32_t)(m >> 32);
+        pos = 32;
+    }
+#pragma unroll
+    for (uint32_t w = 16; w >= 1; w >>= 1) {
+        const uint32_t c = (uint32_t)__popc(x & ((1u << w) - 1u));
+        if (r >= c) {
+            r -= c;
+            x >>= w;
+            pos += w;
+        }
+    }
+    return pos;
+}
+
 // Work plan: cubes without a base-resolution leaf or (pool mode) without a sample in reach get no workgroup; the others
 // ceil(stream / kLvChunk).  A wave looks at 16 cubes one after the other (lane = voxel for the status bytes, lane = bucket
 // for the stream length) and then hands out workgroup numbers, scratch rows and list places for all of them with one
@@ -418,7 +440,7 @@ __device__ __forceinline__ void lv_commit(const LvArgs &a, const LvTask &t, floa
     if ((threadIdx.x & 63) == 0 && um) atomicAdd(a.upd_counter, (uint32_t)__popcll(um));
 }
 
-__global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) {
+__global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void bgklv_voxel_kernel(LvArgs a) {
     __shared__ LvLds L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t task = blockIdx.x, sub = 0, nsub = 1;
@@ -513,62 +535,97 @@ __global__ __launch_bounds__(kLvWaves *kWave) void bgklv_voxel_kernel(LvArgs a) 
             }
             if (keep) L.cand[before + slot] = c;
             __syncthreads();
-            // rounds of 64 staged candidates: evaluate (all waves), then add in order (wave 0: k, wave 1: k y) or write the
-            // non-zero rows out
+            // Rounds of 64 staged candidates.  (T) every wave tests eight candidates against the 64 voxels (lane = voxel):
+            // which voxels count it — as a hit in the box, or as its ray's lowest-index sample in the box.  (E) the counting
+            // (candidate, voxel) pairs — one in eight or so — are enumerated densely, lane = pair, and only they pay for the
+            // segment projection and the kernel; the values land in a [candidate][voxel] tile of zeros.  (A) wave 0 adds
+            // the tile's rows in order into the k sums, wave 1 the hit rows into the k y sums — or, for a split cube, the
+            // rows with a counting voxel go out to the scratch array.
             for (uint32_t r0 = 0; r0 < total; r0 += kWave) {
                 const uint32_t nr = min(total - r0, (uint32_t)kWave);
                 const uint32_t nr16 = split ? nr : (nr + 15u) & ~15u;
-                for (uint32_t j = wave; j < nr16; j += kLvWaves) {
-                    if (j >= nr) {   // zero rows up to the next multiple of 16 for the dense add
-                        L.k[j][lane] = 0.0f;
-                        continue;
-                    }
-                    const LvCand &cd = L.cand[r0 + j];
-                    const float4 p = cd.p;
-                    const int type = __builtin_amdgcn_readfirstlane((int)p.w);
-                    const bool inb = active && !(lox > p.x || p.x > hix || loy > p.y || p.y > hiy || loz > p.z || p.z > hiz);
-                    float kv = 0.0f;
-                    if (__any(inb)) {
+                // ---- T
+                for (uint32_t j = wave; j < kWave; j += kLvWaves) {
+                    unsigned long long cm = 0ull;
+                    int type = 0;
+                    if (j < nr) {
+                        const LvCand &cd = L.cand[r0 + j];
+                        const float4 p = cd.p;
+                        type = __builtin_amdgcn_readfirstlane((int)p.w);
+                        const bool inb = active && !(lox > p.x || p.x > hix || loy > p.y || p.y > hiy || loz > p.z || p.z > hiz);
                         bool count = inb;
-                        float qx = p.x, qy = p.y, qz = p.z;   // a hit: the distance to the sample itself
-                        if (type != 0) {  // a ray sample: is it this ray's lowest-index sample in my box?
-                            const float4 q0 = cd.r0, q1 = cd.r1, pv = cd.prev;
-                            if ((type & 3) == 2) {
-                                const bool first_in = !(lox > q0.x || q0.x > hix || loy > q0.y || q0.y > hiy || loz > q0.z || q0.z > hiz);
-                                const bool prev_in = !(lox > pv.x || pv.x > hix || loy > pv.y || pv.y > hiy || loz > pv.z || pv.z > hiz);
-                                count = inb && !first_in && !prev_in;
-                            }
-                            qx = q0.x; qy = q0.y; qz = q0.z;
-                            if (!(type & 4) && __any(count))
-                                lv_seg_point(cx, cy, cz, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, pv.w, q0.w, q1.w, qx, qy, qz);
+                        if ((type & 3) == 2 && __any(inb)) {  // a later sample of a ray: is it the ray's lowest-index sample in my box?
+                            const float4 q0 = cd.r0, pv = cd.prev;
+                            const bool first_in = !(lox > q0.x || q0.x > hix || loy > q0.y || q0.y > hiy || loz > q0.z || q0.z > hiz);
+                            const bool prev_in = !(lox > pv.x || pv.x > hix || loy > pv.y || pv.y > hiy || loz > pv.z || pv.z > hiz);
+                            count = inb && !first_in && !prev_in;
                         }
                         info |= inb;
-                        if (count) kv = lv_kernel_at(cx, cy, cz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
+                        cm = __ballot(count);
                     }
-                    const bool nz = __any(kv != 0.0f);
-                    if (!split) {
-                        L.k[j][lane] = kv;
-                        if (type == 0 && nz && lane == 0) atomicOr(&L.y_round[rnd & 1u], 1ull << j);
-                        continue;
-                    }
-                    if (!nz) continue;   // a row of zeros adds nothing to either sum: not written, not read
-                    const uint32_t slot = n_rows + r0 + j;
-                    a.rows[(row0 + slot) * kWave + lane] = kv;
+                    if (j < nr16) L.k[j][lane] = 0.0f;
                     if (lane == 0) {
-                        atomicOr(&L.nz_map[slot >> 6], 1ull << (slot & 63u));
-                        if (type == 0) atomicOr(&L.y_map[slot >> 6], 1ull << (slot & 63u));
+                        L.cmask[j] = cm;
+                        if (cm != 0ull && type == 0 && !split) atomicOr(&L.y_round[rnd & 1u], 1ull << j);
                     }
                 }
+                __syncthreads();
+                // ---- E
+                {
+                    const unsigned long long mine = L.cmask[lane];                     // lane = candidate
+                    const uint32_t cj = (uint32_t)__popcll(mine);
+                    const uint32_t incl = wave_incl_scan_u32(cj, lane);
+                    const uint32_t excl = incl - cj;
+                    const uint32_t n_pairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    for (uint32_t e = (uint32_t)wave * kWave + lane; e - lane < n_pairs; e += kLvWaves * kWave) {
+                        const bool valid = e < n_pairs;
+                        // the candidate of pair e: the last one whose exclusive count is <= e
+                        uint32_t jc = 0;
+#pragma unroll
+                        for (uint32_t step = 32; step >= 1; step >>= 1) {
+                            const uint32_t t2 = (uint32_t)__shfl((int)excl, (int)(jc + step), kWave);
+                            if (t2 <= e) jc += step;
+                        }
+                        const unsigned long long cmj = valid ? L.cmask[jc] : 1ull;
+                        const uint32_t ex_j = (uint32_t)__shfl((int)excl, (int)jc, kWave);
+                        const uint32_t vox = lv_nth_bit(cmj, valid ? e - ex_j : 0u);
+                        const float vx = __shfl(cx, (int)vox, kWave), vy = __shfl(cy, (int)vox, kWave), vz = __shfl(cz, (int)vox, kWave);
+                        if (valid) {
+                            const LvCand &cd = L.cand[r0 + jc];
+                            const float4 p = cd.p;
+                            const int ty = (int)p.w;
+                            float qx = p.x, qy = p.y, qz = p.z;   // a hit: the distance to the sample itself
+                            if (ty != 0) {
+                                const float4 q0 = cd.r0, q1 = cd.r1;
+                                const float lx = cd.prev.w;
+                                qx = q0.x; qy = q0.y; qz = q0.z;
+                                if (!(ty & 4)) lv_seg_point(vx, vy, vz, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lx, q0.w, q1.w, qx, qy, qz);
+                            }
+                            L.k[jc][vox] = lv_kernel_at(vx, vy, vz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- A
                 if (!split) {
-                    __syncthreads();
                     if (wave == 0) kbar = lv_add_dense(L.k, nr16, lane, kbar);
                     if (wave == 1) ybar = lv_add_rows(L.k, L.y_round[rnd & 1u], lane, ybar);
                     // the other parity's masks: last read in the previous round's add phase, next set after this round's
-                    // second barrier
+                    // last barrier
                     if (threadIdx.x == 2 * kWave) L.y_round[(rnd + 1u) & 1u] = 0ull;
-                    __syncthreads();
                     ++rnd;
+                } else {
+                    for (uint32_t j = wave; j < nr; j += kLvWaves) {
+                        if (L.cmask[j] == 0ull) continue;   // a row of zeros adds nothing to either sum: not written, not read
+                        const uint32_t slot = n_rows + r0 + j;
+                        a.rows[(row0 + slot) * kWave + lane] = L.k[j][lane];
+                        if (lane == 0) {
+                            atomicOr(&L.nz_map[slot >> 6], 1ull << (slot & 63u));
+                            if ((int)L.cand[r0 + j].p.w == 0) atomicOr(&L.y_map[slot >> 6], 1ull << (slot & 63u));
+                        }
+                    }
                 }
+                __syncthreads();
             }
             n_rows += total;
         }
