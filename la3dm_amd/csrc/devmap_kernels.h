@@ -76,11 +76,6 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 }
 
 // ---- min / max of the finite points; mm[0..2] = enc(min), mm[3..5] = enc(max) --------------------------
-__global__ void dm_minmax_init(uint32_t *mm) {
-    if (threadIdx.x < 3) mm[threadIdx.x] = 0xFFFFFFFFu;
-    else if (threadIdx.x < 6) mm[threadIdx.x] = 0u;
-}
-
 // What the LAST workgroup of a min/max launch does with the result (it then resets mm and the arrival counter, so that
 // neither a reset launch before nor a one-thread launch after the reduction is needed):
 //   mode 1: the voxel filter's GridParams (-> gp for the kernels, counters[kCntGrid..] for the host)
@@ -280,34 +275,6 @@ __global__ __launch_bounds__(256) void dm_grid_cells(const float *__restrict__ p
     }
     keys[i] = cell;
     vals[i] = i;
-}
-
-// head flags of a sorted key array (invalid keys sort last); also records the number of valid entries
-__global__ __launch_bounds__(256) void dm_heads(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *flag,
-                                               uint32_t *counters, int valid_slot) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    const bool valid = k != kInvalidCell;
-    flag[i] = (valid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-    if (valid && (i + 1 == n || keys[i + 1] == kInvalidCell)) counters[valid_slot] = i + 1;
-}
-
-// seg_start[seg] = first sorted position of segment seg; seg_key[seg] = its key; also the total
-__global__ __launch_bounds__(256) void dm_seg_starts(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ flag,
-                                                    const uint32_t *__restrict__ scan, uint32_t n, uint32_t *seg_start,
-                                                    uint32_t *seg_key, uint32_t *counters, int seg_slot, int valid_slot) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag[i]) {
-        seg_start[scan[i]] = i;
-        if (seg_key) seg_key[scan[i]] = keys[i];
-    }
-    if (i + 1 == n) {
-        const uint32_t nseg = scan[i] + flag[i];
-        counters[seg_slot] = nseg;
-        seg_start[nseg] = counters[valid_slot];  // written by dm_heads (earlier launch)
-    }
 }
 
 // Centroid of one voxel-grid cell: fp32 sums in cloud order (the sort is stable, values ascend inside a
@@ -838,12 +805,6 @@ __global__ void dm_publish_counters(const uint32_t *__restrict__ counters, volat
         mailbox[kCntWords] = seq;
         __threadfence_system();
     }
-}
-
-// total = off[n-1] + cnt[n-1] of an exclusive scan
-__global__ void dm_scan_total(const uint32_t *off, const uint32_t *cnt, uint32_t n, uint32_t *counters, int slot) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    counters[slot] = n ? off[n - 1] + cnt[n - 1] : 0u;
 }
 
 __global__ __launch_bounds__(256) void dm_append_frees(const float *__restrict__ pts, uint32_t n, uint32_t base, float label,
