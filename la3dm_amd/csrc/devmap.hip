@@ -54,10 +54,10 @@ struct la3dm_devmap {
     // arenas (grow only)
     Arena cloud, hits, keep, nfree, keep_off, free_off, frees_raw, frees_ds, xy;
     Arena k0, k1, v0, v1, flag, scan, seg_start, seg_key, cub_tmp, big, chunk_desc;
-    Arena scan_status;            // devmap_scan.h: per-tile status words + 2 tickets, zero between launches
+    Arena scan_status;            // devmap_scan.h: two arrays of per-tile status words, zero between launches
     size_t scan_tiles = 0, scan_dirty[2] = {0, 0};   // status entries in use per array
     uint32_t scan_seq = 0;
-    Arena radix_state, radix_tmp; // devmap_sort.h: histogram + tickets + two status arrays (zero between sorts); ping-pong buffers
+    Arena radix_state, radix_tmp; // devmap_sort.h: histograms + two status arrays (zero between sorts); ping-pong buffers
     size_t radix_tiles = 0;
     uint32_t radix_seq = 0;       // sorts so far: which of the two histograms is current
     std::vector<uint8_t> lv_axis_host;   // BGK-LV: staging of the per-axis candidate tables (kept until the next insert)
@@ -135,12 +135,11 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         DM_TRY(hipMemsetAsync(dm->radix_state.ptr, 0, bytes, st));   // on the sorts' own stream
         dm->radix_tiles = want;
     }
-    RadixState rs;   // layout: two histograms (this sort's, the next sort's), tickets, two status arrays
+    RadixState rs;   // layout: two histograms (this sort's, the next sort's), 16 spare words, two status arrays
     uint32_t *base = (uint32_t *)dm->radix_state.ptr;
     rs.hist = base + 1024 * kRsHistCopies * (dm->radix_seq & 1u);
     rs.hist_next = base + 1024 * kRsHistCopies * ((dm->radix_seq + 1u) & 1u);
     ++dm->radix_seq;
-    rs.ticket = base + 2048 * kRsHistCopies;
     rs.status[0] = base + 2048 * kRsHistCopies + 16;
     rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
     DM_RESERVE(dm->radix_tmp, 8ull * n);
@@ -160,7 +159,7 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         a.begin_bit = (uint32_t)begin_bit;
         a.counters = dm->d_cnt;
         a.err_slot = (int)kCntError;
-        hipLaunchKernelGGL(dm_radix_pass, dim3(tiles), dim3(kRsThreads), 0, st, a, rs);
+        hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, kRsResident)), dim3(kRsThreads), 0, st, a, rs);
         sk = a.k_out;
         sv = a.v_out;
     }
@@ -179,9 +178,8 @@ static int scan_state(la3dm_devmap *dm, uint32_t n, ScanState &ss) {
         dm->scan_tiles = want;
         dm->scan_dirty[0] = dm->scan_dirty[1] = 0;
     }
-    // layout: tickets, status array 0, status array 1.  The arrays alternate from launch to launch; a launch clears the
+    // layout: 16 spare bytes, status array 0, status array 1.  The arrays alternate from launch to launch; a launch clears the
     // used part of the other array (written two launches ago), so the array a launch starts on is all zero.
-    ss.ticket = (uint32_t *)dm->scan_status.ptr;
     unsigned long long *base = (unsigned long long *)((uint8_t *)dm->scan_status.ptr + 16);
     const uint32_t cur = dm->scan_seq & 1u;
     ss.status = base + (size_t)cur * dm->scan_tiles;
@@ -211,7 +209,7 @@ static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, u
     a.total_slot = total_slot;
     a.zero_slot = -1;
     a.err_slot = (int)kCntError;
-    hipLaunchKernelGGL(dm_scan_lb<false>, dim3(cdiv(n, kScanTile)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
+    hipLaunchKernelGGL(dm_scan_lb<false>, dim3(std::min<uint32_t>(cdiv(n, kScanTile), kScanResident)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
     DM_TRY(hipGetLastError());
     return LA3DM_OK;
 }
@@ -238,7 +236,7 @@ static int scan_heads(la3dm_devmap *dm, const uint32_t *keys, uint32_t n, uint32
     a.valid_slot = valid_slot;
     a.zero_slot = zero_slot;
     a.err_slot = (int)kCntError;
-    hipLaunchKernelGGL(dm_scan_lb<true>, dim3(cdiv(n, kScanTile)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
+    hipLaunchKernelGGL(dm_scan_lb<true>, dim3(std::min<uint32_t>(cdiv(n, kScanTile), kScanResident)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
     DM_TRY(hipGetLastError());
     return LA3DM_OK;
 }

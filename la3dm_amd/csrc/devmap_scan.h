@@ -24,12 +24,12 @@ struct ScanState {
     unsigned long long *status;  // per tile: bits 63..62 = 0 empty / 1 tile aggregate / 2 inclusive prefix; low 32 bits = value
     unsigned long long *other;   // the status array of the NEXT launch: this launch clears its other_n used entries
     uint32_t other_n;
-    uint32_t *ticket;            // [0] next tile number, [1] workgroups finished (launches of more than kScanResident tiles only)
 };
-// Tiles take their number from the workgroup id while all workgroups of the launch fit on the chip at once; larger
-// launches draw tickets.  A device-scope atomic on ONE address costs ~25 ns per workgroup, serialised (measured: 390
-// workgroups x (ticket + arrival count) = 20 us of a 23 us scan), so the resident form has none: the status arrays
-// alternate between launches and are cleaned by the launch in between.
+// A launch has at most kScanResident workgroups (what the chip holds at once); workgroup b takes the tiles b, b + G,
+// b + 2 G, ... in this order, and workgroups are handed out in order, so a tile only ever waits for tiles of workgroups
+// that started before its own — no ticket, no arrival counter: a device-scope atomic on ONE address costs ~25 ns per workgroup, serialised (measured: 390 workgroups x
+// (ticket + arrival count) = 20 us of a 23 us scan).  The status arrays alternate between launches and are cleaned by
+// the launch in between.
 constexpr uint32_t kScanResident = 1024;
 
 struct ScanArgs {
@@ -60,16 +60,11 @@ __device__ __forceinline__ void scan_st(unsigned long long *p, unsigned long lon
 
 template <bool kHeads>
 __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState st) {
-    __shared__ uint32_t s_tile, s_wave[kScanThreads / 64], s_excl, s_last;
+    __shared__ uint32_t s_wave[kScanThreads / 64], s_excl;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (a.n + kScanTile - 1) / kScanTile;
-    const bool tickets = n_tiles > kScanResident;
-    if (tickets) {
-        if (tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
-        __syncthreads();
-    }
-    const uint32_t tile = tickets ? s_tile : blockIdx.x;
     for (uint32_t e = blockIdx.x * kScanThreads + tid; e < st.other_n; e += gridDim.x * kScanThreads) st.other[e] = 0ull;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint32_t i0 = tile * kScanTile + tid * kScanItems;
     // ---- items
     uint32_t raw[kScanItems], v[kScanItems];
@@ -177,12 +172,8 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
         run += v[u];
     }
     if (tile == 0 && tid == 0 && a.zero_slot >= 0) a.counters[a.zero_slot] = 0;
-    // ---- ticket form: the last workgroup out resets the two counters
-    if (!tickets) return;
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(st.ticket + 1, 1u) + 1u == n_tiles ? 1u : 0u;
-    __syncthreads();
-    if (s_last && tid < 2) st.ticket[tid] = 0u;
+    __syncthreads();   // s_wave / s_excl are reused by the next tile
+    }
 }
 
 }  // namespace la3dm_dev

@@ -4,9 +4,8 @@
 // Why not the library sort: rocPRIM's Onesweep costs three dependent launches per pass (two state resets + the pass)
 // and its merge-sort fallback 7-9 for the sizes that occur here; each dependent launch is ≈ 4.7 us on this GPU whatever it
 // does, and a scan runs three sorts.  Same algorithm family (Onesweep: chained per-digit prefix with decoupled
-// look-back), but the state cleans itself: the histogram launch clears status array 0, every pass clears the rows of
-// the status array the NEXT pass uses, the last workgroup of a pass resets the tickets (and, in the last pass, the
-// histogram).  Everything is zero between sorts.
+// look-back), but the state cleans itself: the histogram launch clears status array 0 and the next sort's histogram,
+// every pass clears the rows of the status array the NEXT pass uses.  Everything is zero between sorts.
 //
 // Stability (the voxel filter's fp32 centroid sums depend on it): a tile is 4 waves x 16 rows x 64 lanes of consecutive
 // items, ranked row by row inside a wave (ballot matching), wave after wave, tile after tile.
@@ -27,7 +26,6 @@ struct RadixState {
                           // address costs ~25 ns per workgroup, serialised), the passes add the copies up
     uint32_t *hist_next;  // the histogram of the NEXT sort: the histogram launch clears it
     uint32_t *status[2];  // [tiles][256] per array: bits 31..30 = 0 empty / 1 tile count / 2 inclusive prefix, low 30 bits = value
-    uint32_t *ticket;     // [0] next tile, [1] tiles finished (sorts of more than kRsResident tiles only)
 };
 
 struct RadixArgs {
@@ -39,11 +37,11 @@ struct RadixArgs {
     int err_slot;
 };
 
-// Tiles take their number from the workgroup id while all of a sort's workgroups fit on the chip at once (256 CUs x 3
-// workgroups at 159 VGPRs = 768): no workgroup can then wait for one that has no slot.  Larger sorts draw tickets.  Every
-// device-scope atomic with a returned value costs a ~2.5 us round trip, and a pass is a chain of them: ticket, look-back,
-// arrival count — the resident form has only the look-back left.
-constexpr uint32_t kRsResident = 512;
+// A pass has at most kRsResident workgroups (what the chip holds at once: 256 CUs x 3 workgroups at 159 VGPRs); workgroup
+// b takes the tiles b, b + G, b + 2 G, ... in this order, and workgroups are handed out in order, so a tile only ever
+// waits for tiles of workgroups that started before its own.  No ticket and no arrival counter: every device-scope atomic with a returned value is
+// a ~2.5 us round trip, and on ONE address they serialise at ~25 ns per workgroup.
+constexpr uint32_t kRsResident = 768;
 
 __device__ __forceinline__ uint32_t rs_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rs_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -100,37 +98,28 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
     __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
     __shared__ uint32_t s_wcnt[kRsWaves][256];
     __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64];
-    __shared__ uint32_t s_tile, s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = a.begin_bit + 8u * a.pass;
-    const bool tickets = n_tiles > kRsResident;
     uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
-    if (tickets && tid == 0) s_tile = atomicAdd(st.ticket, 1u);   // tiles in arrival order: a predecessor is always running or done
-#pragma unroll
-    for (uint32_t w = 0; w < kRsWaves; ++w) s_wcnt[w][tid] = 0u;
     uint32_t total_d = 0;   // keys with digit tid in this pass (written by the histogram launch)
 #pragma unroll
     for (uint32_t cpy = 0; cpy < kRsHistCopies; ++cpy) total_d += st.hist[(cpy * 4u + a.pass) * 256u + tid];
-    __syncthreads();
-    const uint32_t tile = tickets ? s_tile : blockIdx.x;
-    other[tile * 256u + tid] = 0u;   // my row of the array the next pass (or the next sort's second pass) uses
-    auto finish = [&]() {   // ticket form only: the last workgroup out resets the two counters
-        if (!tickets) return;
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(st.ticket + 1, 1u) + 1u == n_tiles ? 1u : 0u;
-        __syncthreads();
-        if (s_last && tid < 2) st.ticket[tid] = 0u;
-    };
     // every key has the same digit in this pass (the top byte of grid-cell keys, mostly): the pass is a copy
-    if (__syncthreads_or(total_d == a.n)) {
+    const bool copy_pass = __syncthreads_or(total_d == a.n) != 0;
+    const uint32_t digit_base = rs_scan256(total_d, tid, s_part);   // first output position of digit tid
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    other[tile * 256u + tid] = 0u;   // my row of the array the next pass (or the next sort's second pass) uses
+    if (copy_pass) {
         const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
         for (uint32_t j = tid; j < in_tile; j += kRsThreads) {
             a.k_out[tile * kRsTile + j] = a.k_in[tile * kRsTile + j];
             a.v_out[tile * kRsTile + j] = a.v_in[tile * kRsTile + j];
         }
-        finish();
-        return;
+        continue;
     }
+#pragma unroll
+    for (uint32_t w = 0; w < kRsWaves; ++w) s_wcnt[w][tid] = 0u;
+    __syncthreads();
     // ---- load: wave w holds items [tile * 4096 + w * 1024, + 1024), row r = 64 consecutive items
     const uint32_t i0 = tile * kRsTile + wave * (kRsRows * 64u) + lane;
     uint32_t key[kRsRows], val[kRsRows], rank[kRsRows];
@@ -140,7 +129,6 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
         key[r] = i < a.n ? a.k_in[i] : 0xFFFFFFFFu;
         val[r] = i < a.n ? a.v_in[i] : 0u;
     }
-    const uint32_t digit_base = rs_scan256(total_d, tid, s_part);   // first output position of digit tid
     // ---- rank inside the wave, row after row: peers = lanes of the row with my digit
     const unsigned long long lt = (1ull << lane) - 1ull;
     volatile uint32_t *wc = s_wcnt[wave];
@@ -221,7 +209,8 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
         a.k_out[g] = k;
         a.v_out[g] = s_val[j];
     }
-    finish();
+    __syncthreads();   // the LDS arrays are reused by the next tile
+    }
 }
 
 }  // namespace la3dm_dev
