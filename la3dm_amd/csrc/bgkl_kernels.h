@@ -57,8 +57,8 @@ struct BgklArgs {
 constexpr int kLItemRows = 256;
 constexpr int kLBatch = 64;
 constexpr int kLBatches = kLItemRows / kLBatch;
-constexpr int kLProducers = 7;
-constexpr int kLRowsPerProducer = (kLBatch + kLProducers - 1) / kLProducers;  // 10
+constexpr int kLProducers = 14;   // + two consumer waves = a 1024-thread workgroup
+constexpr int kLRowsPerProducer = (kLBatch + kLProducers - 1) / kLProducers;  // 5
 
 struct BgklSplit {
     uint32_t *task_item;          // [2 * n_tasks] {first item or 0xFFFFFFFF, index in split_list}
@@ -303,9 +303,10 @@ __global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {
     s.bdesc[q] = d;
 }
 
-__global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(BgklArgs a, BgklSplit s) {
+__global__ __launch_bounds__(kWave *(2 + kLProducers)) void bgkl_split_fuse(BgklArgs a, BgklSplit s) {
     __shared__ float s_k[2][kLBatch][kWave];   // k of (row, leaf), +0 where the leaf is out of reach
-    __shared__ float s_ky[2][kLBatch][kWave];  // k * label
+    __shared__ float s_lab[2][kLBatch];        // label of the row (1 = hit, 0 = beam): k * label is k or a zero
+    __shared__ float s_y[kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t h = blockIdx.x / 7u, b = blockIdx.x % 7u;
     const uint32_t it0 = s.nb_first[8 * h + b], it1 = s.nb_first[8 * h + b + 1];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(Bgkl
     const uint32_t q0 = it0 * kLBatches;
     const int nb = (int)((it1 - it0) * kLBatches);  // batches of this chain (the last item may end with empty ones)
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    const int pw = wave - 1;
+    const int pw = wave - 2;   // wave 0 adds the k rows, wave 1 the k * label rows (hit rows only), waves 2.. produce
 
     // producer state: row records of the batch two trips ahead (lane k holds row pw + 7 k; asked for on one trip,
     // used on the next), values of the batch one trip ahead (asked for on one trip, written to LDS on the next)
@@ -325,13 +326,27 @@ __global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(Bgkl
 
     for (int i = -3; i < nb; ++i) {
         if (wave == 0) {
-            // ---- consumer: batch i, in row order ----
+            // ---- consumer of k: batch i, in row order (constant LDS offsets, 16 reads in flight) ----
             if (i >= 0) {
                 const int buf = i & 1;
 #pragma unroll 16
-                for (int r = 0; r < kLBatch; ++r) {
-                    ybar += s_ky[buf][r][lane];
-                    kbar += s_k[buf][r][lane];
+                for (int r = 0; r < kLBatch; ++r) kbar += s_k[buf][r][lane];
+            }
+        } else if (wave == 1) {
+            // ---- consumer of k * label: only the hit rows add something (x + 0 = x for a sum that started at +0) ----
+            if (i >= 0) {
+                const int buf = i & 1;
+                unsigned long long m = __ballot(s_lab[buf][lane] != 0.0f);
+                while (m) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = m ? __builtin_ctzll(m) : 0;
+                        v[u] = m ? s_k[buf][r][lane] : 0.0f;
+                        m &= m - 1ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ybar += v[u];
                 }
             }
         } else {
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(Bgkl
                     const int r = pw + kLProducers * k;
                     if (r < kLBatch) {
                         s_k[buf][r][lane] = val[k];
-                        s_ky[buf][r][lane] = val[k] * lab[k];  // k * label, rounded once as in the row-serial kernel
+                        if (lane == 0) s_lab[buf][r] = lab[k];
                     }
                 }
             }
@@ -363,10 +378,8 @@ __global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(Bgkl
                         const uint32_t mlo = __builtin_amdgcn_readlane(rec.x, k), mhi = __builtin_amdgcn_readlane(rec.y, k);
                         const uint32_t woff = __builtin_amdgcn_readlane(rec.w, k);
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
-                        if ((((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u) {
-                            v = s.vals[v0 + woff + rank];
-                            l = __uint_as_float(__builtin_amdgcn_readlane(rec.z, k));
-                        }
+                        l = __uint_as_float(__builtin_amdgcn_readlane(rec.z, k));   // the row's label (uniform)
+                        if ((((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u) v = s.vals[v0 + woff + rank];
                     }
                     val[k] = v;
                     lab[k] = l;
@@ -386,7 +399,9 @@ __global__ __launch_bounds__(kWave *(1 + kLProducers)) void bgkl_split_fuse(Bgkl
         }
         __syncthreads();
     }
-    if (wave == 0) s.part[((size_t)h * 7u + b) * kWave + lane] = make_float2(ybar, kbar);
+    if (wave == 1) s_y[lane] = ybar;
+    __syncthreads();
+    if (wave == 0) s.part[((size_t)h * 7u + b) * kWave + lane] = make_float2(s_y[lane], kbar);
 }
 
 __global__ __launch_bounds__(kWave) void bgkl_split_apply(BgklArgs a, BgklSplit s) {

@@ -735,7 +735,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         sp.vals = (float *)ctx->l_vals.ptr;
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
         hipLaunchKernelGGL(bgkl_split_eval<true>, dim3(n_items), dim3(kWave), 0, stream, a, sp);
-        hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (1 + kLProducers)), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_apply, dim3(n_split), dim3(kWave), 0, stream, a, sp);
         HIP_TRY(ctx, hipGetLastError());
     }
