@@ -57,6 +57,7 @@ struct BgklArgs {
 constexpr int kLItemRows = 256;
 constexpr int kLBatch = 64;
 constexpr int kLBatches = kLItemRows / kLBatch;
+constexpr uint32_t kLItemVals = kLItemRows * kWave;   // value slots of an item (every row x every leaf)
 constexpr int kLProducers = 14;   // + two consumer waves = a 1024-thread workgroup
 constexpr int kLRowsPerProducer = (kLBatch + kLProducers - 1) / kLProducers;  // 5
 
@@ -268,7 +269,11 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
             off += (uint32_t)__popcll(m);
         } else {
             const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-            const unsigned long long m = __ballot(active && bgkl_row_counts(d, a.ell));
+            const bool hit = active && bgkl_row_counts(d, a.ell);
+            const unsigned long long m = __ballot(hit);
+            // the hit lanes' distances, in (row, lane) order, in the item's own slots: bgkl_split_kernelize turns them into
+            // kernel values in place, at full lane utilisation (the second distance pass over all rows is gone)
+            if (hit) s.vals[(size_t)it * kLItemVals + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = d;
             if ((j & 63u) == 0u) {
                 boff = off;
                 if (lane == 0) s.batch_off[it * kLBatches + (j >> 6)] = off;
@@ -282,8 +287,16 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
     }
     if (!kWrite && lane == 0) {
         s.item_hits[it] = off;
-        s.item_val[it] = atomicAdd(reinterpret_cast<unsigned long long *>(s.counters + 2), (unsigned long long)off);
+        s.item_val[it] = (unsigned long long)it * kLItemVals;
     }
+}
+
+// distances -> kernel values, in place, dense
+__global__ __launch_bounds__(256) void bgkl_split_kernelize(BgklArgs a, BgklSplit s) {
+    const uint32_t it = blockIdx.x;
+    const uint32_t n = s.item_hits[it];
+    float *v = s.vals + (size_t)it * kLItemVals;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v[i] = bgkl_row_kernel(v[i], a.ell, a.inv_ell, a.sf2);
 }
 
 __global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {
@@ -369,7 +382,8 @@ __global__ __launch_bounds__(kWave *(2 + kLProducers)) void bgkl_split_fuse(Bgkl
             if (i + 2 >= 0 && i + 2 < nb) {
                 const uint4 D = s.bdesc[q0 + (uint32_t)(i + 2)];
                 const uint32_t nr = __builtin_amdgcn_readfirstlane(D.w & 0xFFFFu);
-                const unsigned long long v0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(D.y) << 32) | __builtin_amdgcn_readfirstlane(D.x);
+                const unsigned long long v0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(D.y) << 32) |
+                                              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(D.x);   // (readfirstlane returns int)
 #pragma unroll
                 for (int k = 0; k < kLRowsPerProducer; ++k) {
                     const uint32_t r = (uint32_t)(pw + kLProducers * k);

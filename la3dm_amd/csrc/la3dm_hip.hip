@@ -704,7 +704,6 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         hipLaunchKernelGGL(bgkl_predict_fuse_kernel<1>, dim3(a.n_tasks), dim3(kWave), 0, stream, a, (const uint32_t *)sp.task_item);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t head[2] = {0, 0};  // items, split tiles
-    unsigned long long n_vals = 0;
     if (split) {
         HIP_TRY(ctx, hipMemcpyAsync(head, sp.counters, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -727,21 +726,20 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         sp.bdesc = (uint4 *)ctx->l_bdesc.ptr;
         sp.nb_first = (uint32_t *)ctx->l_nb_first.ptr;
         sp.part = (float2 *)ctx->l_part.ptr;
+        // every item owns kLItemVals value slots (64 KB): no read-back of the hit total, no second distance pass
+        if ((rc = arena_reserve(ctx, ctx->l_vals, sizeof(float) * (size_t)n_items * kLItemVals)) != LA3DM_OK) return rc;
+        sp.vals = (float *)ctx->l_vals.ptr;
         hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_eval<false>, dim3(n_items), dim3(kWave), 0, stream, a, sp);
-        HIP_TRY(ctx, hipMemcpyAsync(&n_vals, sp.counters + 2, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(ctx, hipStreamSynchronize(stream));
-        if ((rc = arena_reserve(ctx, ctx->l_vals, sizeof(float) * (size_t)(n_vals + 1))) != LA3DM_OK) return rc;
-        sp.vals = (float *)ctx->l_vals.ptr;
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
-        hipLaunchKernelGGL(bgkl_split_eval<true>, dim3(n_items), dim3(kWave), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_kernelize, dim3(n_items), dim3(256), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_apply, dim3(n_split), dim3(kWave), 0, stream, a, sp);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (out) {
         out->n_tiles = a.n_tasks;
-        out->scratch_bytes = sizeof(uint4) * (size_t)n_items * kLItemRows + sizeof(float) * (size_t)n_vals;
+        out->scratch_bytes = sizeof(uint4) * (size_t)n_items * kLItemRows + sizeof(float) * (size_t)n_items * kLItemVals;
     }
     return LA3DM_OK;
 }
