@@ -496,14 +496,11 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                                               const float tz, float *__restrict__ vg, float *lds, const int lane,
                                               float &mj_out, float &ss_out) {
     const int c = lane & 31, h = lane >> 5;
-    const float t0x = __shfl(tx, c), t0y = __shfl(ty, c), t0z = __shfl(tz, c);
-    const float t1x = __shfl(tx, 32 + c), t1y = __shfl(ty, 32 + c), t1z = __shfl(tz, 32 + c);
-    float mj0 = 0.0f, mj1 = 0.0f, ss0 = 0.0f, ss1 = 0.0f;
+    float mj = 0.0f, ss = 0.0f;   // lane = leaf: the two chains of this lane's column
     const int nblk = (N + 31) >> 5;
     for (int K = 0; K < nblk; ++K) {
         const int R0 = 32 * K;
         f32x16 C0, C1;
-        float alv[16];
         // the diagonal tile L[K][K] (used after the MFMAs): fetched like the A tiles, in flight during the kernel evaluations
         float (*s_d)[36] = reinterpret_cast<float (*)[36]>(lds + 2 * 32 * 36);
         float4 gd[4];
@@ -532,28 +529,30 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 gd[i] = q;
             }
         }
+        {
+            // Ks(k, j) = k(x_k, xs_j) with lane = leaf j, the 32 rows of the block in registers (training points and alpha
+            // are wave-uniform: scalar loads), m = Ks^T alpha continued row by row; then into accumulator layout
+            float ks[32];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // Ks(k, j) = k(x_k, xs_j) in accumulator layout
-            const int row = R0 + 8 * (r >> 2) + 4 * h + (r & 3);
-            const bool valid = row < N;
-            const float4 xr = valid ? x[row] : make_float4(0.f, 0.f, 0.f, 0.f);
-            C0[r] = valid ? matern3_fast(xr.x, xr.y, xr.z, t0x, t0y, t0z, a.sf2) : 0.0f;
-            C1[r] = valid ? matern3_fast(xr.x, xr.y, xr.z, t1x, t1y, t1z, a.sf2) : 0.0f;
-            alv[r] = valid ? al[row] : 0.0f;
-        }
+            for (int r = 0; r < 32; ++r) {
+                // no branch per row (the 32 evaluations interleave): a padded row evaluates the last point and is zeroed
+                const int row = R0 + r, rowc = min(row, N - 1);
+                const bool valid = row < N;   // wave-uniform
+                const float4 xr = x[rowc];
+                const float kv = matern3_fast(xr.x, xr.y, xr.z, tx, ty, tz, a.sf2);
+                const float av_ = al[rowc];
+                ks[r] = valid ? kv : 0.0f;
+                mj = __builtin_fmaf(ks[r], valid ? av_ : 0.0f, mj);
+            }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // m = Ks^T alpha, rows in order: 4 rows in half 0, 4 rows in half 1, ...
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (h == hh) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        mj0 = __builtin_fmaf(C0[4 * g + j], alv[4 * g + j], mj0);
-                        mj1 = __builtin_fmaf(C1[4 * g + j], alv[4 * g + j], mj1);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ks[8 * g + j]), __float_as_uint(ks[8 * g + 4 + j]),
+                                                                     false, false);
+                    C0[4 * g + j] = __uint_as_float(sw[0]);   // rows 8g + 4h + j of leaf c
+                    C1[4 * g + j] = __uint_as_float(sw[1]);   // ... of leaf 32 + c
                 }
-                mj0 = bcast_half(mj0, hh);  // both halves continue from the owner's value
-                mj1 = bcast_half(mj1, hh);
             }
         }
         {
@@ -633,58 +632,42 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 }
             }
         }
-        // diagonal block: rows in order, four at a time in alternating half-waves
-        float vb0[32], vb1[32];
+        // diagonal block: back to lane = leaf (the same swap), rows in order
+        float cc[32], vb[32];
 #pragma unroll
-        for (int G = 0; G < 8; ++G) {
-            const int hh = G & 1, base = 4 * (G >> 1);
-            float n0[4], n1[4];
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int r = 4 * G + j;
-                const int row = R0 + r;
-                const bool valid = row < N;  // wave-uniform
-                // row r of the diagonal tile from LDS, four entries per (broadcast) read; a padded row is a row of the identity
-                float lrow[32];
-#pragma unroll
-                for (int w4 = 0; w4 <= r / 4; ++w4) {
-                    const float4 q = *reinterpret_cast<const float4 *>(&s_d[r][4 * w4]);
-                    lrow[4 * w4] = q.x; lrow[4 * w4 + 1] = q.y; lrow[4 * w4 + 2] = q.z; lrow[4 * w4 + 3] = q.w;
-                }
-                float acc0 = C0[base + j], acc1 = C1[base + j];
-#pragma unroll
-                for (int w = 0; w < r; ++w) {
-                    const float lw = lrow[w];
-                    acc0 = __builtin_fmaf(-lw, vb0[w], acc0);
-                    acc1 = __builtin_fmaf(-lw, vb1[w], acc1);
-                }
-                const float d = lrow[r];
-                const float v0 = acc0 / d, v1 = acc1 / d;
-                vb0[r] = v0;  // right in the owning half; the other half is repaired after the group
-                vb1[r] = v1;
-                n0[j] = v0;
-                n1[j] = v1;
-                if (h == hh) {
-                    ss0 = __builtin_fmaf(v0, v0, ss0);
-                    ss1 = __builtin_fmaf(v1, v1, ss1);
-                    if (valid) *reinterpret_cast<float2 *>(vg + (size_t)row * kWave + 2 * c) = make_float2(v0, v1);
-                }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(C0[4 * g + j]), __float_as_uint(C1[4 * g + j]), false, false);
+                cc[8 * g + j] = __uint_as_float(sw[0]);
+                cc[8 * g + 4 + j] = __uint_as_float(sw[1]);
             }
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                vb0[4 * G + j] = bcast_half(n0[j], hh);
-                vb1[4 * G + j] = bcast_half(n1[j], hh);
+        for (int r = 0; r < 32; ++r) {
+            const int row = R0 + r;
+            // row r of the diagonal tile from LDS, four entries per (broadcast) read; a padded row is a row of the identity
+            float lrow[32];
+#pragma unroll
+            for (int w4 = 0; w4 <= r / 4; ++w4) {
+                const float4 q = *reinterpret_cast<const float4 *>(&s_d[r][4 * w4]);
+                lrow[4 * w4] = q.x; lrow[4 * w4 + 1] = q.y; lrow[4 * w4 + 2] = q.z; lrow[4 * w4 + 3] = q.w;
             }
-            ss0 = bcast_half(ss0, hh);
-            ss1 = bcast_half(ss1, hh);
+            float acc = cc[r];
+#pragma unroll
+            for (int w = 0; w < r; ++w) acc = __builtin_fmaf(-lrow[w], vb[w], acc);
+            const float v = acc / lrow[r];
+            vb[r] = v;
+            ss = __builtin_fmaf(v, v, ss);
+            vg[(size_t)row * kWave + 2 * c + h] = v;   // B operand layout: (leaf c, leaf 32 + c) adjacent; vmax is whole blocks
         }
         // V[K] is read back as MFMA B operands by the other lanes of this wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    mj_out = h == 0 ? mj0 : mj1;  // every chain value is present in both half-waves
-    ss_out = h == 0 ? ss0 : ss1;
+    mj_out = mj;
+    ss_out = ss;
 }
 
 // GPRegressor::predict + BCM fusion: one wave64 per leaf tile, lane = leaf (test point).

@@ -504,8 +504,8 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     a.vmax = 0;
     a.vscratch = nullptr;
     if (max_n >= (uint32_t)kGpMfmaMinN) {
-        a.vmax = max_n;
-        if ((rc = arena_reserve(ctx, ctx->gp_v, sizeof(float) * (size_t)a.n_tasks * max_n * kWave)) != LA3DM_OK) return rc;
+        a.vmax = (max_n + 31u) & ~31u;   // whole 32-row blocks: the solve stores its padded rows too
+        if ((rc = arena_reserve(ctx, ctx->gp_v, sizeof(float) * (size_t)a.n_tasks * a.vmax * kWave)) != LA3DM_OK) return rc;
         a.vscratch = (float *)ctx->gp_v.ptr;
     }
     a.pts = (const float4 *)ctx->pts_scaled.ptr;
