@@ -491,6 +491,13 @@ __device__ __forceinline__ float bcast_half(float v, int half) {
     return __uint_as_float(half ? r[1] : r[0]);
 }
 
+// LDS written by some lanes of a wave and read by others: the LDS queue of a wave is in order, so only the compiler has to
+// keep the order.  (A release fence, even at wavefront scope, also waits for every global load in flight — in the
+// tile loop that is the prefetch of the tile after next: the loop ran at memory latency.)
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+#ifndef LA3DM_GP_EXP_V
+#define LA3DM_GP_EXP_V 0
+#endif
 __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__restrict__ L, const float4 *__restrict__ x,
                                               const float *__restrict__ al, const int N, const float tx, const float ty,
                                               const float tz, float *__restrict__ vg, float *lds, const int lane,
@@ -539,7 +546,7 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 const int row = R0 + r, rowc = min(row, N - 1);
                 const bool valid = row < N;   // wave-uniform
                 const float4 xr = x[rowc];
-                const float kv = matern3_fast(xr.x, xr.y, xr.z, tx, ty, tz, a.sf2);
+                const float kv = LA3DM_GP_EXP_V == 4 ? xr.x * tx + xr.y : matern3_fast(xr.x, xr.y, xr.z, tx, ty, tz, a.sf2);
                 const float av_ = al[rowc];
                 ks[r] = valid ? kv : 0.0f;
                 mj = __builtin_fmaf(ks[r], valid ? av_ : 0.0f, mj);
@@ -559,7 +566,7 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
             const int trow_ = lane >> 3, tcol_ = 4 * (lane & 7);
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&s_d[8 * i + trow_][tcol_]) = gd[i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            lds_order();
             __builtin_amdgcn_wave_barrier();
         }
         // off-diagonal blocks on the matrix cores: C -= L[K][J] V[J].  The A operand wants lane c = row R0 + c, i.e. 32
@@ -571,64 +578,97 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
             float (*s_t)[32][36] = reinterpret_cast<float (*)[32][36]>(lds);
             const int trow = lane >> 3, tcol = 4 * (lane & 7);
             float4 g[4];
-            float av[16];
-            float2 bv[16];
-            auto load_tile = [&](int J) {
+            // per-lane element offsets of the four tile rows (rows beyond N re-read the last row: those accumulator rows are
+            // zeroed before the diagonal solve) and of the B operand inside a 32-row slab of V; the bases stay scalar
+            uint32_t loff[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = R0 + 8 * i + trow;
-                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row < N) __builtin_memcpy(&q, L + (size_t)row * N + 32 * J + tcol, 16);   // 4-byte aligned
-                    g[i] = q;
-                }
+            for (int i = 0; i < 4; ++i) loff[i] = (uint32_t)min(R0 + 8 * i + trow, N - 1) * (uint32_t)N + (uint32_t)tcol;
+            const uint32_t boff = (uint32_t)h * kWave + 2u * (uint32_t)c;
+            auto load_tile = [&](int J) {
+                const float *Lb = L + 32 * J;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_memcpy(&g[i], Lb + loff[i], 16);   // 4-byte aligned
             };
+            // LDS copy of a tile: row r holds its even columns at [r][0..15] and its odd columns at [r][16..31], so that lane
+            // (c, h) finds its 16 operand values (columns 2 m2 + h) contiguous; the sign of the update sits in V (stored
+            // negated), the tile goes through unchanged
             auto store_tile = [&](int buf) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4 *>(&s_t[buf][8 * i + trow][tcol]) = make_float4(-g[i].x, -g[i].y, -g[i].z, -g[i].w);
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<float2 *>(&s_t[buf][8 * i + trow][tcol >> 1]) = make_float2(g[i].x, g[i].z);
+                    *reinterpret_cast<float2 *>(&s_t[buf][8 * i + trow][16 + (tcol >> 1)]) = make_float2(g[i].y, g[i].w);
+                }
             };
-            auto read_ops = [&](int J, int buf, float (&A_)[16], float2 (&B_)[16]) {
+            // operands of half a tile (8 MFMA steps): the A values from the LDS copy of the tile, the B values from V
+            auto read_half = [&](int J, int buf, int s, float (&A_)[8], float2 (&B_)[8]) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 q = *reinterpret_cast<const float4 *>(&s_t[buf][c][4 * i]);
-                    A_[2 * i] = h ? q.y : q.x;
-                    A_[2 * i + 1] = h ? q.w : q.z;
+                for (int i = 0; i < 2; ++i) {
+                    const float4 q = *reinterpret_cast<const float4 *>(&s_t[buf][c][16 * h + 8 * s + 4 * i]);
+                    A_[4 * i] = q.x; A_[4 * i + 1] = q.y; A_[4 * i + 2] = q.z; A_[4 * i + 3] = q.w;
                 }
+                const float *Vb = vg + (size_t)(LA3DM_GP_EXP_V ? 0 : 32 * J) * kWave;
 #pragma unroll
-                for (int m2 = 0; m2 < 16; ++m2) {
-                    const int kcol = 32 * J + 2 * m2 + h;
-                    B_[m2] = *reinterpret_cast<const float2 *>(vg + (size_t)kcol * kWave + 2 * c);
-                }
+                for (int m = 0; m < 8; ++m) B_[m] = *reinterpret_cast<const float2 *>(Vb + (boff + 2u * (8 * s + m) * kWave));
             };
             if (K > 0) {
+                // One register set per half tile and no second copy: the operands of tile J + 1's first half are fetched
+                // into the registers of tile J's first half as soon as its 16 MFMAs are issued, and arrive while the second
+                // half's 16 run (with a full second operand set the kernel sat at 256 VGPRs and the allocator started
+                // copying prefetched registers around, each copy a wait for the memory round trip).
+                float a0[8], a1[8];
+                float2 b0[8], b1[8];
+                // The tile registers live inside one iteration only (fetch at the top, LDS store at the bottom, two tiles
+                // ahead of the one whose MFMAs run): carried around the loop edge they were split and copied by the
+                // allocator, each copy a wait for the fetch just issued.
                 load_tile(0);
                 store_tile(0);
-                if (K > 1) load_tile(1);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (K > 1) {
+                    load_tile(1);
+                    store_tile(1);
+                }
+                lds_order();
                 __builtin_amdgcn_wave_barrier();
-                read_ops(0, 0, av, bv);
-            }
-            for (int J = 0; J < K; ++J) {
-                float an[16];
-                float2 bn[16];
-                if (J + 1 < K) {
-                    store_tile((J + 1) & 1);   // g holds tile J + 1; buffer (J + 1) & 1 was last read for block J - 1
-                    if (J + 2 < K) load_tile(J + 2);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    read_ops(J + 1, (J + 1) & 1, an, bn);
-                }
+                read_half(0, 0, 0, a0, b0);
+                read_half(0, 0, 1, a1, b1);
+                // steady state without branches (so that the waits count exactly the loads in flight): the last tile's
+                // MFMAs are peeled off, the tile fetch is clamped (it re-reads tile K - 1 at the end, into a free buffer)
+                for (int J = 0; J + 1 < K; ++J) {
+                    load_tile(min(J + 2, K - 1));
 #pragma unroll
-                for (int m2 = 0; m2 < 16; ++m2) {
-                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m2], bv[m2].x, C0, 0, 0, 0);
-                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m2], bv[m2].y, C1, 0, 0, 0);
-                }
-                if (J + 1 < K) {
-#pragma unroll
-                    for (int m2 = 0; m2 < 16; ++m2) {
-                        av[m2] = an[m2];
-                        bv[m2] = bn[m2];
+                    for (int m = 0; m < 8; ++m) {
+                        C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m].x, C0, 0, 0, 0);
+                        C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m].y, C1, 0, 0, 0);
                     }
+                    read_half(J + 1, (J + 1) & 1, 0, a0, b0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m].x, C0, 0, 0, 0);
+                        C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m].y, C1, 0, 0, 0);
+                    }
+                    read_half(J + 1, (J + 1) & 1, 1, a1, b1);
+                    store_tile(J & 1);   // buffer J & 1 held tile J: its operands were read during iteration J - 1
+                    // the order of the above, spelled out for the scheduler (it otherwise issues all 32 MFMAs first and
+                    // fetches the next operands when they are already needed)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // tile J + 2: 4 VMEM reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMA (first half of tile J)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // A of tile J + 1, first half: 2 DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);    // B of tile J + 1, first half: 8 VMEM reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMA (second half)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);    // tile J + 2 into LDS: 8 DS writes
+                    lds_order();
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m].x, C0, 0, 0, 0);
+                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m].y, C1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m].x, C0, 0, 0, 0);
+                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m].y, C1, 0, 0, 0);
                 }
             }
         }
@@ -643,6 +683,10 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
                 cc[8 * g + 4 + j] = __uint_as_float(sw[1]);
             }
         }
+        if (R0 + 32 > N) {   // the padded rows of the last block solve to 0 (their A rows were not zero)
+#pragma unroll
+            for (int r = 1; r < 32; ++r) cc[r] = R0 + r < N ? cc[r] : 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const int row = R0 + r;
@@ -655,11 +699,11 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
             }
             float acc = cc[r];
 #pragma unroll
-            for (int w = 0; w < r; ++w) acc = __builtin_fmaf(-lrow[w], vb[w], acc);
+            for (int w = 0; w < (LA3DM_GP_EXP_V == 3 ? 0 : r); ++w) acc = __builtin_fmaf(-lrow[w], vb[w], acc);
             const float v = acc / lrow[r];
             vb[r] = v;
             ss = __builtin_fmaf(v, v, ss);
-            vg[(size_t)row * kWave + 2 * c + h] = v;   // B operand layout: (leaf c, leaf 32 + c) adjacent; vmax is whole blocks
+            vg[(size_t)row * kWave + 2 * c + h] = -v;   // B operand layout: (leaf c, leaf 32 + c) adjacent, negated (C -= L V as C += L (-V): the same FMA bits); vmax is whole blocks
         }
         // V[K] is read back as MFMA B operands by the other lanes of this wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
