@@ -150,20 +150,28 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // K(i, j) for the 32 x 32 block (RI, RJ) in accumulator layout: rows 8g + 4h + j, column c; the padding
     // beyond N is the identity so that padded rows factor to d = 1 and contribute nothing
     auto kblock = [&](int RI, int RJ, f32x16 &C) {
+        // every point is fetched before anything is evaluated (indices clamped, no branch per row: with one the 16 rows
+        // were 16 dependent memory round trips)
         const int col = RJ + c;
-        const float4 xc = col < N ? x[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 xc = x[min(col, N - 1)];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = RI + 8 * (r >> 2) + 4 * h + (r & 3);
-            float kv = 0.0f;
-            if (row < N && col < N) {
-                const float4 xr = x[row];
-                kv = matern3_fast(xr.x, xr.y, xr.z, xc.x, xc.y, xc.z, a.sf2);
-                if (row == col) kv = kv + a.noise;
-            } else if (row == col) {
-                kv = 1.0f;
+        for (int q = 0; q < 2; ++q) {
+            float4 xr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = 8 * q + u;
+                xr[u] = x[min(RI + 8 * (r >> 2) + 4 * h + (r & 3), N - 1)];
             }
-            C[r] = kv;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = 8 * q + u;
+                const int row = RI + 8 * (r >> 2) + 4 * h + (r & 3);
+                float kv = matern3_fast(xr[u].x, xr[u].y, xr[u].z, xc.x, xc.y, xc.z, a.sf2);
+                const bool in = row < N && col < N;
+                if (row == col) kv = in ? kv + a.noise : 1.0f;
+                else kv = in ? kv : 0.0f;
+                C[r] = kv;
+            }
         }
     };
     // accumulator layout -> tile[row][col]
