@@ -83,6 +83,8 @@ struct la3dm_devmap {
     uint32_t n_xy = 0;
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
     uint32_t mailbox_seq = 0;
+    uint32_t scan_resident = kScanResident, radix_resident = kRsResident;   // workgroups the chip holds at once (create)
+    uint32_t mailbox_pending = 0;   // sequence number a queued kernel will publish itself (0: none — read_counters launches the publisher)
     bool poisoned = false;  // a failed insert whose block table could not be reconciled with the host's block count
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
     la3dm_devmap_stats stats;
@@ -159,12 +161,21 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         a.begin_bit = (uint32_t)begin_bit;
         a.counters = dm->d_cnt;
         a.err_slot = (int)kCntError;
-        hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, kRsResident)), dim3(kRsThreads), 0, st, a, rs);
+        hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(kRsThreads), 0, st, a, rs);
         sk = a.k_out;
         sv = a.v_out;
     }
     DM_TRY(hipGetLastError());
     return LA3DM_OK;
+}
+
+// The kernel about to be launched publishes the counter block itself (dm_publish_lane) under a fresh sequence number.
+static void publish_with(la3dm_devmap *dm, volatile uint32_t *&mailbox, uint32_t &seq) {
+    if (!dm->mailbox) return;   // (copy + synchronise mode: read_counters does it all)
+    static const bool off = getenv("LA3DM_PUBLISH_IN_KERNEL") && atoi(getenv("LA3DM_PUBLISH_IN_KERNEL")) == 0;
+    if (off) return;
+    seq = dm->mailbox_pending = ++dm->mailbox_seq;
+    mailbox = (volatile uint32_t *)dm->h_cnt;
 }
 
 // state of the single-launch scan (devmap_scan.h) for up to n elements
@@ -192,7 +203,8 @@ static int scan_state(la3dm_devmap *dm, uint32_t n, ScanState &ss) {
 }
 
 // out[i] = in[0] + ... + in[i-1]; total_slot >= 0: the sum of all n also goes to d_cnt[total_slot]
-static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, uint32_t n, int total_slot = -1) {
+// publish: the launch also sends the counter block to the host's mailbox (the next read_counters only waits for it)
+static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, uint32_t n, int total_slot = -1, bool publish = false) {
     if (n == 0) {
         if (total_slot >= 0) DM_TRY(hipMemsetAsync(dm->d_cnt + total_slot, 0, 4, dm->ctx->stream));
         return LA3DM_OK;
@@ -209,7 +221,8 @@ static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, u
     a.total_slot = total_slot;
     a.zero_slot = -1;
     a.err_slot = (int)kCntError;
-    hipLaunchKernelGGL(dm_scan_lb<false>, dim3(std::min<uint32_t>(cdiv(n, kScanTile), kScanResident)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
+    if (publish && total_slot >= 0) publish_with(dm, a.mailbox, a.mailbox_seq);
+    hipLaunchKernelGGL(dm_scan_lb<false>, dim3(std::min<uint32_t>(cdiv(n, kScanTile), dm->scan_resident)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
     DM_TRY(hipGetLastError());
     return LA3DM_OK;
 }
@@ -218,7 +231,7 @@ static int exclusive_scan(la3dm_devmap *dm, const uint32_t *in, uint32_t *out, u
 // (+ keys), d_cnt[seg_slot] = segments, d_cnt[valid_slot] = valid keys, seg_start[segments] = valid keys;
 // zero_slot >= 0: d_cnt[zero_slot] = 0 on the way.
 static int scan_heads(la3dm_devmap *dm, const uint32_t *keys, uint32_t n, uint32_t *flag, uint32_t *scan, uint32_t *seg_start,
-                      uint32_t *seg_key, int seg_slot, int valid_slot, int zero_slot = -1) {
+                      uint32_t *seg_key, int seg_slot, int valid_slot, int zero_slot = -1, bool publish = false) {
     ScanState ss;
     int rc = scan_state(dm, n, ss);
     if (rc != LA3DM_OK) return rc;
@@ -236,7 +249,8 @@ static int scan_heads(la3dm_devmap *dm, const uint32_t *keys, uint32_t n, uint32
     a.valid_slot = valid_slot;
     a.zero_slot = zero_slot;
     a.err_slot = (int)kCntError;
-    hipLaunchKernelGGL(dm_scan_lb<true>, dim3(std::min<uint32_t>(cdiv(n, kScanTile), kScanResident)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
+    if (publish) publish_with(dm, a.mailbox, a.mailbox_seq);
+    hipLaunchKernelGGL(dm_scan_lb<true>, dim3(std::min<uint32_t>(cdiv(n, kScanTile), dm->scan_resident)), dim3(kScanThreads), 0, dm->ctx->stream, a, ss);
     DM_TRY(hipGetLastError());
     return LA3DM_OK;
 }
@@ -248,9 +262,13 @@ static int read_counters(la3dm_devmap *dm) {
         DM_TRY(hipStreamSynchronize(st));
         return LA3DM_OK;
     }
-    const uint32_t seq = ++dm->mailbox_seq;
-    hipLaunchKernelGGL(dm_publish_counters, dim3(1), dim3(64), 0, st, (const uint32_t *)dm->d_cnt, (volatile uint32_t *)dm->h_cnt, seq);
-    DM_TRY(hipGetLastError());
+    uint32_t seq = dm->mailbox_pending;
+    dm->mailbox_pending = 0;
+    if (!seq) {
+        seq = ++dm->mailbox_seq;
+        hipLaunchKernelGGL(dm_publish_counters, dim3(1), dim3(64), 0, st, (const uint32_t *)dm->d_cnt, (volatile uint32_t *)dm->h_cnt, seq);
+        DM_TRY(hipGetLastError());
+    }
     volatile uint32_t *flag = dm->h_cnt + kCntWords;
     const double t0 = wall();
     for (uint32_t spin = 0; *flag != seq; ++spin) {
@@ -263,7 +281,11 @@ static int read_counters(la3dm_devmap *dm) {
     }
     if (dm->h_cnt[kCntError] & (kScanErrStuck | kRsErrStuck)) {
         dm->poisoned = true;
-        return dm_fail(dm, LA3DM_ERR_HIP, "devmap: a prefix-sum launch found its state in use (internal error)");
+        if (getenv("LA3DM_DEBUG_CNT")) {
+            for (int w = 0; w < (int)kCntWords; ++w) fprintf(stderr, "cnt[%d]=%u ", w, dm->h_cnt[w]);
+            fprintf(stderr, "\n");
+        }
+        return dm_fail(dm, LA3DM_ERR_HIP, "devmap: a prefix-sum launch found its state in use (internal error; flags " + std::to_string(dm->h_cnt[kCntError]) + ")");
     }
     return LA3DM_OK;
 }
@@ -305,33 +327,32 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
     int rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
     if (rc != LA3DM_OK) return rc;
-    rc = scan_heads(dm, k1, n, flag, scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid, (int)kCntBig);
+    rc = scan_heads(dm, k1, n, flag, scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid, (int)kCntBig, true);
     if (rc != LA3DM_OK) return rc;
+    // The centroid kernels take the cell count from the counter block and are sized for the worst case (every point its
+    // own cell), so they are queued before the host waits for the counters: the wait and the next launches' latency overlap
+    // with them.  (A pass-through grid lets them write junk that the copy below replaces.)
+    DM_RESERVE(out, 12ull * n);
+    // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
+    DM_RESERVE(dm->big, 4ull * (n / kBigCell + 1));
+    hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntGridSegs,
+                       (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
+    const uint32_t nchunk = n / kChunk;
+    DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
+    if (nchunk)
+        hipLaunchKernelGGL(dm_big_chunks, dim3(nchunk), dim3(64), 0, st, d_in, v1, flag, scan, dm->d_cnt, (int)kCntGridValid,
+                           (uint4 *)dm->chunk_desc.ptr);
+    hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
+                       (const uint32_t *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
     rc = read_counters(dm);
     if (rc != LA3DM_OK) return rc;
     memcpy(dm->h_gp, dm->h_cnt + kCntGrid, sizeof(GridParams));
     if (dm->h_gp->passthrough) {  // index space overflows int32: PCL returns the cloud unfiltered
-        DM_RESERVE(out, 12ull * n);
         DM_TRY(hipMemcpyAsync(out.ptr, d_in, 12ull * n, hipMemcpyDeviceToDevice, st));
         *n_out = n;
         return LA3DM_OK;
     }
-    const uint32_t nseg = dm->h_cnt[kCntGridSegs];
-    DM_RESERVE(out, 12ull * nseg);
-    if (nseg) {
-        // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
-        DM_RESERVE(dm->big, 4ull * (n / kBigCell + 1));
-        hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(nseg, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
-                           (int)kCntGridSegs, (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
-        const uint32_t nchunk = n / kChunk;
-        DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
-        if (nchunk)
-            hipLaunchKernelGGL(dm_big_chunks, dim3(nchunk), dim3(64), 0, st, d_in, v1, flag, scan, dm->d_cnt, (int)kCntGridValid,
-                               (uint4 *)dm->chunk_desc.ptr);
-        hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
-                           (const uint32_t *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
-    }
-    *n_out = nseg;
+    *n_out = dm->h_cnt[kCntGridSegs];
     return LA3DM_OK;
 }
 
@@ -424,6 +445,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     la3dm_devmap *dm = new la3dm_devmap;
     dm->ctx = ctx;
+    ctx->n_devmaps++;   // (la3dm_devmap_destroy, also the failure paths' clean-up, counts it down)
     dm->depth = (uint32_t)ctx->p.block_depth;
     dm->npb = npb_of(ctx->p.block_depth);
     dm->ncell = 1u << (3 * (dm->depth - 1));
@@ -457,7 +479,23 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         la3dm_devmap_destroy(dm);
         return LA3DM_ERR_OOM;
     }
-    ctx->n_devmaps++;
+    {
+        // The single-launch scan and the radix passes hand tiles to at most as many workgroups as the chip holds at once
+        // (a workgroup waits for tiles of workgroups that started before it): the bound comes from the occupancy of the
+        // kernels as compiled, not from a constant that a change of their register count would silently falsify.
+        int cus = 0, b0 = 0, b1 = 0, b2 = 0;   // (hipGetDeviceProperties would cost tens of ms here)
+        ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0 &&
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, dm_scan_lb<false>, (int)kScanThreads, 0) == hipSuccess &&
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, dm_scan_lb<true>, (int)kScanThreads, 0) == hipSuccess &&
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, dm_radix_pass, (int)kRsThreads, 0) == hipSuccess && b0 > 0 && b1 > 0 && b2 > 0;
+        if (!ok) {
+            ctx->err = "la3dm_devmap_create: occupancy query failed";
+            la3dm_devmap_destroy(dm);
+            return LA3DM_ERR_HIP;
+        }
+        dm->scan_resident = std::min<uint32_t>(kScanResident, (uint32_t)std::min(b0, b1) * (uint32_t)cus);
+        dm->radix_resident = std::min<uint32_t>(kRsResident, (uint32_t)b2 * (uint32_t)cus);
+    }
     *out = dm;
     return LA3DM_OK;
 }
@@ -497,6 +535,7 @@ static int training_bbox(la3dm_devmap *dm, bool reduced = false) {
     const uint32_t npts = dm->n_xy;
     if (!reduced) {   // (the front end's own kernels may have reduced the box while writing the set)
         MinmaxFin fin = {2, 0.0f, nullptr, (const float *)dm->xy.ptr, dm->d_cnt, dm->d_mm + 6, nullptr};
+        publish_with(dm, fin.mailbox, fin.mailbox_seq);
         hipLaunchKernelGGL(dm_minmax<4>, dim3(std::min<uint32_t>(cdiv(npts, 1024), kMinmaxWgs)), dim3(256), 0, st, (const float *)dm->xy.ptr,
                            npts, dm->d_mm, fin);
     }
@@ -548,7 +587,7 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     if (ctx->p.variant == 3) {  // BGKLOctoMap: samples keep their beam, no second voxel filter
         hipLaunchKernelGGL(dm_l_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
         if ((rc = exclusive_scan(dm, keep, keep_off, n_h, (int)kCntKept)) != LA3DM_OK) return rc;
-        if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
+        if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw, true)) != LA3DM_OK) return rc;
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
         if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
         const uint32_t n_beams = dm->h_cnt[kCntKept], n_samples = dm->h_cnt[kCntFreeRaw];
@@ -565,7 +604,7 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     }
     hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
     if ((rc = exclusive_scan(dm, keep, keep_off, n_h, (int)kCntKept)) != LA3DM_OK) return rc;
-    if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw, true)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_kept = dm->h_cnt[kCntKept], n_free_raw = dm->h_cnt[kCntFreeRaw];
@@ -591,6 +630,7 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     bool box_reduced = false;
     if (n_f) {
         MinmaxFin fin = {2, 0.0f, nullptr, (const float *)xy, dm->d_cnt, dm->d_mm + 6, mm_hits};
+        publish_with(dm, fin.mailbox, fin.mailbox_seq);   // training_bbox only waits
         hipLaunchKernelGGL(dm_append_frees, dim3(std::min<uint32_t>(cdiv(n_f, 256), kMinmaxWgs)), dim3(256), 0, st, d_frees, n_f, n_kept, free_label,
                            xy, dm->d_mm, fin);
         box_reduced = true;
@@ -704,7 +744,7 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->m_code, 16ull * npts);
     hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, xy, npts, pa, m_cnt,
                        (int4 *)dm->m_code.ptr);
-    if ((rc = exclusive_scan(dm, m_cnt, m_off, npts, (int)kCntMembers)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, m_cnt, m_off, npts, (int)kCntMembers, true)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_mem = dm->h_cnt[kCntMembers];
     DM_RESERVE(dm->k0, 4ull * n_mem);
@@ -1090,7 +1130,7 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
                            (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
     }
     if ((rc = exclusive_scan(dm, nsamp, samp_off, nh, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
-    if ((rc = exclusive_scan(dm, nray, ray_off, nh, (int)kCntKept)) != LA3DM_OK) return rc;
+    if ((rc = exclusive_scan(dm, nray, ray_off, nh, (int)kCntKept, true)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if ((rc = check_beam_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t ns = dm->h_cnt[kCntFreeRaw], n_rays = dm->h_cnt[kCntKept];

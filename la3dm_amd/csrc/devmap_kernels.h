@@ -91,12 +91,30 @@ struct MinmaxFin {
     uint32_t *counters;
     uint32_t *done;      // zero between launches
     uint32_t *mm_extra;  // mode 2: a second encoded box to unite with (and reset), or nullptr
+    volatile uint32_t *mailbox;   // mode 2: the finishing thread also publishes the counter block (dm_publish_lane), or nullptr
+    uint32_t mailbox_seq;
 };
 __device__ void grid_params_from(const uint32_t *mmv, float inv, GridParams &g);
 __device__ __forceinline__ void box_add(float mn[3], float mx[3], float x, float y, float z) {   // dm_minmax's rule: finite points only
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) return;
     mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
     mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+}
+
+// The counter block to the host's mailbox from ONE thread of a kernel that has just written the last counters the host is
+// waiting for (instead of a dm_publish_counters launch behind it: a dependent dispatch costs ~4.7 us whatever it does).
+// What earlier kernels wrote is visible at kernel start, what this thread wrote is visible to itself; counters that
+// other threads of the same launch are still writing (error bits of a look-back loop, a zeroed slot) are not waited for
+// — the host reads those after a later, real publish.
+__device__ __forceinline__ void dm_publish_lane(const uint32_t *counters, volatile uint32_t *mailbox, uint32_t seq) {
+    uint32_t v[kCntWords];
+#pragma unroll
+    for (int w = 0; w < (int)kCntWords; ++w) v[w] = __hip_atomic_load(&counters[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int w = 0; w < (int)kCntWords; ++w) mailbox[w] = v[w];
+    __threadfence_system();
+    mailbox[kCntWords] = seq;
+    __threadfence_system();
 }
 
 // Workgroup part of a min/max reduction (256 threads, every thread of the workgroup calls it): per-thread min/max ->
@@ -164,6 +182,7 @@ __device__ __forceinline__ void minmax_wg(float mn[3], float mx[3], uint32_t *mm
             const float f = fin.first[a % 3];
             fin.counters[kCntBbox + a] = __float_as_uint(f != f ? f : dec_f32(mmv[a]));
         }
+        if (fin.mailbox) dm_publish_lane(fin.counters, fin.mailbox, fin.mailbox_seq);
     }
 }
 

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "devmap_kernels.h"   // the counter block (dm_publish_lane)
+
 namespace la3dm_dev {
 
 constexpr uint32_t kScanThreads = 512, kScanItems = 8, kScanTile = kScanThreads * kScanItems;
@@ -45,6 +47,8 @@ struct ScanArgs {
     int seg_slot, valid_slot;
     int zero_slot;        // counters[zero_slot] = 0 as a side effect (< 0: none)
     int err_slot;         // counters[err_slot] |= kScanErrStuck if a predecessor tile never reports (dirty state)
+    volatile uint32_t *mailbox;   // the thread that writes the total / closes the segment list also publishes the counter block
+    uint32_t mailbox_seq;         //   to the host (dm_publish_lane in devmap_kernels.h), or nullptr
 };
 constexpr uint32_t kScanErrStuck = 8u;
 
@@ -60,7 +64,8 @@ __device__ __forceinline__ void scan_st(unsigned long long *p, unsigned long lon
 
 template <bool kHeads>
 __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState st) {
-    __shared__ uint32_t s_wave[kScanThreads / 64], s_excl;
+    __shared__ uint32_t s_wave[kScanThreads / 64], s_excl, s_pub;
+    if (threadIdx.x == 0) s_pub = 0u;   // (two barriers lie between this and the first writer)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (a.n + kScanTile - 1) / kScanTile;
     for (uint32_t e = blockIdx.x * kScanThreads + tid; e < st.other_n; e += gridDim.x * kScanThreads) st.other[e] = 0ull;
@@ -160,19 +165,39 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
                     a.counters[a.valid_slot] = i + 1;
                     a.counters[a.seg_slot] = n_seg;
                     a.seg_start[n_seg] = i + 1;
+                    if (a.mailbox) s_pub = 1u;
                 } else if (i == 0 && raw[u] == kScanInvalid) {
                     a.counters[a.valid_slot] = 0;
                     a.counters[a.seg_slot] = 0;
                     a.seg_start[0] = 0;
+                    if (a.mailbox) s_pub = 1u;
                 }
             } else if (i + 1 == a.n && a.total_slot >= 0) {
                 a.counters[a.total_slot] = run + v[u];
+                if (a.mailbox) s_pub = 1u;
             }
         }
         run += v[u];
     }
     if (tile == 0 && tid == 0 && a.zero_slot >= 0) a.counters[a.zero_slot] = 0;
     __syncthreads();   // s_wave / s_excl are reused by the next tile
+    // The workgroup whose thread wrote the total / closed the segment list sends the counter block to the host's mailbox
+    // (instead of a dm_publish_counters launch behind this one: a dependent dispatch costs ~4.7 us whatever it does).  One
+    // wave, one word per lane — in the writing thread alone the 48 words cost 25 VGPRs, and this kernel must keep its
+    // occupancy (the launch relies on all its workgroups being resident).  What earlier kernels wrote is visible since
+    // the launch began, what this workgroup wrote since the barrier; counters other workgroups of this launch are still
+    // writing (the stuck bit, a zeroed slot) are read by the host after a later, real publish.
+    if (a.mailbox && s_pub) {
+        if (wave == 0) {
+            if (tid < (uint32_t)kCntWords) a.mailbox[tid] = __hip_atomic_load(&a.counters[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            if (tid == 0) {
+                a.mailbox[kCntWords] = a.mailbox_seq;
+                __threadfence_system();
+                s_pub = 0u;
+            }
+        }
+    }
     }
 }
 
