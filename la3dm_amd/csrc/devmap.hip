@@ -817,9 +817,10 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     ca.pass = pass;
     hipLaunchKernelGGL(dm_candidates, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
                        (const uint32_t *)train_off, n_entries, c_flag, c_weight);
-    if ((rc = exclusive_scan(dm, c_flag, c_scan, n_entries)) != LA3DM_OK) return rc;
     DM_RESERVE(dm->t_key0, 4ull * n_entries);
     DM_RESERVE(dm->t_ent0, 4ull * n_entries);
+    // (the scan's total is the test-block count: it publishes the counters, the compaction runs while the host waits)
+    if ((rc = exclusive_scan(dm, c_flag, c_scan, n_entries, (int)kCntTest, true)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
                        (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;

@@ -101,20 +101,24 @@ __device__ __forceinline__ void box_add(float mn[3], float mx[3], float x, float
     mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
 }
 
-// The counter block to the host's mailbox from ONE thread of a kernel that has just written the last counters the host is
+// The counter block to the host's mailbox from the first wave of a workgroup that has just written the last counters the host is
 // waiting for (instead of a dm_publish_counters launch behind it: a dependent dispatch costs ~4.7 us whatever it does).
-// What earlier kernels wrote is visible at kernel start, what this thread wrote is visible to itself; counters that
+// What earlier kernels wrote is visible at kernel start, what this workgroup wrote before its last barrier too; counters that
 // other threads of the same launch are still writing (error bits of a look-back loop, a zeroed slot) are not waited for
 // — the host reads those after a later, real publish.
-__device__ __forceinline__ void dm_publish_lane(const uint32_t *counters, volatile uint32_t *mailbox, uint32_t seq) {
-    uint32_t v[kCntWords];
-#pragma unroll
-    for (int w = 0; w < (int)kCntWords; ++w) v[w] = __hip_atomic_load(&counters[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int w = 0; w < (int)kCntWords; ++w) mailbox[w] = v[w];
-    __threadfence_system();
-    mailbox[kCntWords] = seq;
-    __threadfence_system();
+// The mailbox is pinned host memory (uncached on the device side): its words must be on their way before the sequence
+// number, nothing else has to be — a system-scope release fence here would also write back every dirty line the kernel
+// left in the L2 (measured in dm_append_frees, right behind tens of MB of samples: 13 -> 36 us).  Stores of a wave
+// retire through vmcnt on gfx9, and writes to the host leave through one ordered path.
+__device__ __forceinline__ void dm_mailbox_order() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void dm_publish_wave(const uint32_t *counters, volatile uint32_t *mailbox, uint32_t seq) {
+    if (threadIdx.x >= 64u) return;   // the first wave of the workgroup: one word per lane (one coalesced write to the host;
+                                      // word by word from one thread the 48 writes took 25 us)
+    if (threadIdx.x < (uint32_t)kCntWords)
+        mailbox[threadIdx.x] = __hip_atomic_load(&counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dm_mailbox_order();
+    if (threadIdx.x == 0) mailbox[kCntWords] = seq;
 }
 
 // Workgroup part of a min/max reduction (256 threads, every thread of the workgroup calls it): per-thread min/max ->
@@ -157,7 +161,8 @@ __device__ __forceinline__ void minmax_wg(float mn[3], float mx[3], uint32_t *mm
     __syncthreads();
     if (threadIdx.x == 0) *s_last = atomicAdd(fin.done, 1u) + 1u == gridDim.x ? 1u : 0u;
     __syncthreads();
-    if (!*s_last || threadIdx.x != 0) return;
+    if (!*s_last) return;
+    if (threadIdx.x == 0) {
     uint32_t mmv[6];
     for (int a = 0; a < 6; ++a) {
         mmv[a] = __hip_atomic_load(&mm[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -182,7 +187,11 @@ __device__ __forceinline__ void minmax_wg(float mn[3], float mx[3], uint32_t *mm
             const float f = fin.first[a % 3];
             fin.counters[kCntBbox + a] = __float_as_uint(f != f ? f : dec_f32(mmv[a]));
         }
-        if (fin.mailbox) dm_publish_lane(fin.counters, fin.mailbox, fin.mailbox_seq);
+    }
+    }
+    if (fin.mode == 2 && fin.mailbox) {   // (uniform over the workgroup) the counter block to the host, one word per lane
+        __syncthreads();
+        dm_publish_wave(fin.counters, fin.mailbox, fin.mailbox_seq);
     }
 }
 

@@ -188,15 +188,8 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
     // the launch began, what this workgroup wrote since the barrier; counters other workgroups of this launch are still
     // writing (the stuck bit, a zeroed slot) are read by the host after a later, real publish.
     if (a.mailbox && s_pub) {
-        if (wave == 0) {
-            if (tid < (uint32_t)kCntWords) a.mailbox[tid] = __hip_atomic_load(&a.counters[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            if (tid == 0) {
-                a.mailbox[kCntWords] = a.mailbox_seq;
-                __threadfence_system();
-                s_pub = 0u;
-            }
-        }
+        dm_publish_wave(a.counters, a.mailbox, a.mailbox_seq);
+        if (tid == 0) s_pub = 0u;
     }
     }
 }
