@@ -63,13 +63,12 @@ constexpr int kLRowsPerProducer = (kLBatch + kLProducers - 1) / kLProducers;  //
 
 struct BgklSplit {
     uint32_t *task_item;          // [2 * n_tasks] {first item or 0xFFFFFFFF, index in split_list}
-    uint32_t *counters;           // [0] items, [1] split tiles, [2..3] hit values (64-bit)
+    uint32_t *counters;           // [0] items, [1] split tiles
     uint32_t *split_list;         // [split tiles] tile
     uint32_t *nb_first;           // [split tiles * 8] first item of neighbour slot b; [7] = end
     uint4 *item_desc;             // {tile, neighbour slot, row begin, row end}
     uint4 *rowrec;                // [items * kLItemRows] {mask lo, mask hi, label, hits before the row inside its batch}
     uint32_t *batch_off;          // [items * kLBatches] hits before the batch inside its item
-    unsigned long long *item_val; // [items] first value of the item
     uint32_t *item_hits;          // [items]
     uint4 *bdesc;                 // [items * kLBatches] {value index lo, hi, values, rows | slot << 16}
     float *vals;
@@ -239,7 +238,8 @@ __global__ void bgkl_split_items(BgklArgs a, BgklSplit s) {
     s.nb_first[8 * h + 7] = it;
 }
 
-template <bool kWrite>
+// One wave per item (tile x neighbour x <= kLItemRows rows), lane = leaf: the distance test of every row, the hit masks
+// and labels as row records, and the hit lanes' distances in (row, lane) order in the item's own value slots.
 __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s) {
     const int lane = threadIdx.x;
     const uint32_t it = blockIdx.x;
@@ -250,45 +250,30 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
     if (!bgkl_leaf(a, dsc.x, lane, blk, li, active, px, py, pz)) return;  // (split tiles always hold leaves)
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(dsc.z), nrows = __builtin_amdgcn_readfirstlane(dsc.w) - r0;
     uint4 *rec = s.rowrec + (size_t)it * kLItemRows;
-    const unsigned long long vb = kWrite ? s.item_val[it] : 0ull;
+    float *vals = s.vals + (size_t)it * kLItemVals;
     uint32_t off = 0, boff = 0;
     uint4 mine = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t j = 0; j < nrows; ++j) {
         const size_t row = (size_t)r0 + j;
         const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * row);
         const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
-        if (kWrite) {
-            const uint2 mm = *reinterpret_cast<const uint2 *>(rec + j);  // wave-uniform
-            const unsigned long long m = ((unsigned long long)mm.y << 32) | mm.x;
-            if (m == 0ull) continue;
-            const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-            if ((m >> lane) & 1ull) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mm.y, __builtin_amdgcn_mbcnt_lo(mm.x, 0));
-                s.vals[vb + off + rank] = bgkl_row_kernel(d, a.ell, a.inv_ell, a.sf2);
-            }
-            off += (uint32_t)__popcll(m);
-        } else {
-            const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-            const bool hit = active && bgkl_row_counts(d, a.ell);
-            const unsigned long long m = __ballot(hit);
-            // the hit lanes' distances, in (row, lane) order, in the item's own slots: bgkl_split_kernelize turns them into
-            // kernel values in place, at full lane utilisation (the second distance pass over all rows is gone)
-            if (hit) s.vals[(size_t)it * kLItemVals + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = d;
-            if ((j & 63u) == 0u) {
-                boff = off;
-                if (lane == 0) s.batch_off[it * kLBatches + (j >> 6)] = off;
-            }
-            if ((uint32_t)lane == (j & 63u)) mine = make_uint4((uint32_t)m, (uint32_t)(m >> 32), __float_as_uint(p1.z), off - boff);
-            off += (uint32_t)__popcll(m);
-            if ((j & 63u) == 63u || j + 1 == nrows) {
-                if ((uint32_t)lane <= (j & 63u)) rec[(j & ~63u) + lane] = mine;
-            }
+        const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+        const bool hit = active && bgkl_row_counts(d, a.ell);
+        const unsigned long long m = __ballot(hit);
+        // bgkl_split_kernelize turns the distances into kernel values in place, at full lane utilisation (a second
+        // distance pass over all rows that wrote the values was 1.0 ms of a 200 k-ray insert)
+        if (hit) vals[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = d;
+        if ((j & 63u) == 0u) {
+            boff = off;
+            if (lane == 0) s.batch_off[it * kLBatches + (j >> 6)] = off;
+        }
+        if ((uint32_t)lane == (j & 63u)) mine = make_uint4((uint32_t)m, (uint32_t)(m >> 32), __float_as_uint(p1.z), off - boff);
+        off += (uint32_t)__popcll(m);
+        if ((j & 63u) == 63u || j + 1 == nrows) {
+            if ((uint32_t)lane <= (j & 63u)) rec[(j & ~63u) + lane] = mine;
         }
     }
-    if (!kWrite && lane == 0) {
-        s.item_hits[it] = off;
-        s.item_val[it] = (unsigned long long)it * kLItemVals;
-    }
+    if (lane == 0) s.item_hits[it] = off;
 }
 
 // distances -> kernel values, in place, dense
@@ -310,7 +295,7 @@ __global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {
         const uint32_t nr = min(nrows - k * kLBatch, (uint32_t)kLBatch);
         const uint32_t o0 = s.batch_off[q];
         const uint32_t o1 = ((k + 1) * kLBatch < nrows) ? s.batch_off[q + 1] : s.item_hits[it];
-        const unsigned long long v = s.item_val[it] + o0;
+        const unsigned long long v = (unsigned long long)it * kLItemVals + o0;   // the item's own value slots
         d = make_uint4((uint32_t)v, (uint32_t)(v >> 32), o1 - o0, nr | (dsc.y << 16));
     }
     s.bdesc[q] = d;

@@ -1643,9 +1643,11 @@ int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint3
     DM_RESERVE(dm->seg_start, 4ull * (n + 1));
     DM_TRY(hipMemcpyAsync(dm->k0.ptr, in, 4ull * n, hipMemcpyHostToDevice, st));
     int rc;
-    if (mode == 0) rc = exclusive_scan(dm, (const uint32_t *)dm->k0.ptr, (uint32_t *)dm->k1.ptr, n, (int)kCntMembers);
+    // (publishing launches, as in insert_pointcloud: the mailbox may arrive before the copy below has finished — hence the
+    // synchronisation after read_counters)
+    if (mode == 0) rc = exclusive_scan(dm, (const uint32_t *)dm->k0.ptr, (uint32_t *)dm->k1.ptr, n, (int)kCntMembers, true);
     else rc = scan_heads(dm, (const uint32_t *)dm->k0.ptr, n, nullptr, (uint32_t *)dm->k1.ptr, (uint32_t *)dm->seg_start.ptr, nullptr,
-                         (int)kCntGridSegs, (int)kCntGridValid);
+                         (int)kCntGridSegs, (int)kCntGridValid, -1, true);
     if (rc != LA3DM_OK) return rc;
     DM_TRY(hipMemcpyAsync(out, dm->k1.ptr, 4ull * n, hipMemcpyDeviceToHost, st));
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;

@@ -243,7 +243,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_val, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
+    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
@@ -713,7 +713,6 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         if ((rc = arena_reserve(ctx, ctx->l_item_desc, sizeof(uint4) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_rowrec, sizeof(uint4) * (size_t)n_items * kLItemRows)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_batch_off, sizeof(uint32_t) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;
-        if ((rc = arena_reserve(ctx, ctx->l_item_val, sizeof(unsigned long long) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_item_hits, sizeof(uint32_t) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_bdesc, sizeof(uint4) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_nb_first, sizeof(uint32_t) * 8 * (size_t)n_split)) != LA3DM_OK) return rc;
@@ -721,7 +720,6 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         sp.item_desc = (uint4 *)ctx->l_item_desc.ptr;
         sp.rowrec = (uint4 *)ctx->l_rowrec.ptr;
         sp.batch_off = (uint32_t *)ctx->l_batch_off.ptr;
-        sp.item_val = (unsigned long long *)ctx->l_item_val.ptr;
         sp.item_hits = (uint32_t *)ctx->l_item_hits.ptr;
         sp.bdesc = (uint4 *)ctx->l_bdesc.ptr;
         sp.nb_first = (uint32_t *)ctx->l_nb_first.ptr;
@@ -730,7 +728,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         if ((rc = arena_reserve(ctx, ctx->l_vals, sizeof(float) * (size_t)n_items * kLItemVals)) != LA3DM_OK) return rc;
         sp.vals = (float *)ctx->l_vals.ptr;
         hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
-        hipLaunchKernelGGL(bgkl_split_eval<false>, dim3(n_items), dim3(kWave), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_eval, dim3(n_items), dim3(kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
         hipLaunchKernelGGL(bgkl_split_kernelize, dim3(n_items), dim3(256), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
