@@ -603,8 +603,9 @@ __device__ __forceinline__ void gp_solve_mfma(const GpArgs &a, const float *__re
             auto store_tile = [&](int buf) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    *reinterpret_cast<float2 *>(&s_t[buf][8 * i + trow][tcol >> 1]) = make_float2(g[i].x, g[i].z);
-                    *reinterpret_cast<float2 *>(&s_t[buf][8 * i + trow][16 + (tcol >> 1)]) = make_float2(g[i].y, g[i].w);
+                    float *r_ = &s_t[buf][8 * i + trow][tcol >> 1];   // (scalar stores: ds_write2_b32 takes x and z where they are)
+                    r_[0] = g[i].x; r_[1] = g[i].z;
+                    r_[16] = g[i].y; r_[17] = g[i].w;
                 }
             };
             // operands of half a tile (8 MFMA steps): the A values from the LDS copy of the tile, the B values from V
