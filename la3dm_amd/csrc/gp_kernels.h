@@ -503,6 +503,9 @@ __device__ __forceinline__ float bcast_half(float v, int half) {
 // keep the order.  (A release fence, even at wavefront scope, also waits for every global load in flight — in the
 // tile loop that is the prefetch of the tile after next: the loop ran at memory latency.)
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+// Timing experiments (WRONG results, never built by default): -DLA3DM_GP_EXP_V=1 reads every B operand from V's first slab
+// (what the kernel costs when V is cache-hot), 3 also drops the diagonal solve's FMA chains, 4 also replaces the kernel
+// evaluation by one FMA.  They located the time of DESIGN.md 3.3 (tile loop vs evaluation vs solve).
 #ifndef LA3DM_GP_EXP_V
 #define LA3DM_GP_EXP_V 0
 #endif

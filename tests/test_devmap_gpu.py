@@ -5,6 +5,7 @@ Bar: every stage is integer / order work or strict-fp32 arithmetic in the refere
 training set, the block/leaf structure and every node (alpha, beta, state, classified) must be BIT-IDENTICAL
 to the CPU oracle — no tolerance anywhere in this file.
 """
+import os
 import numpy as np
 import pytest
 
@@ -503,3 +504,35 @@ def test_nan_in_the_first_point_of_an_unfiltered_cloud(built, variant):
         m.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)                       # and a no-op again on a filled map
         o.insert_pointcloud(pts, origin, -1.0, 0.5, -1.0)
         _same(m, o, f"{variant} resident={resident} after the no-op")
+
+
+_SWITCH_SCRIPT = r"""
+import sys, os, zlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, la3dm_amd
+from conftest import pcd_path
+m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+for i in (1, 2):
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+    m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+lv = m.leaves()
+print("CHK", lv["A"].size, zlib.crc32(lv["A"].tobytes()), zlib.crc32(lv["B"].tobytes()), zlib.crc32(lv["state"].tobytes()),
+      zlib.crc32(lv["block_key"].tobytes()))
+"""
+
+
+@pytest.mark.parametrize("switch", ["LA3DM_MAILBOX", "LA3DM_PUBLISH_IN_KERNEL", "LA3DM_OWN_SORT"])
+def test_fallback_switches_give_the_same_map(built, switch):
+    """the A/B switches of the front end (copy + sync read-backs, a publish launch per read-back instead of the producing
+    kernel's own mailbox write, rocPRIM's sort instead of devmap_sort.h) read their environment once per process: a child
+    process per mode, two fused scans, every leaf equal to the default mode's"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("CHK")][-1]
+
+    assert run({switch: "0"}) == run({})
