@@ -9,11 +9,12 @@
 //   Occupancy::update             src/bgkloctomap/bgkloctree_node.cpp:31-44     (same node as BGKOctoMap)
 //
 // Training rows are 8 floats {x0, y0, z0, x1, y1, z1, label, 0}: hits are degenerate segments with label 1,
-// each beam that has a sample inside the block contributes its segment once with label 0.  One workgroup = one
-// leaf tile, lane = leaf; the rows of a neighbour are evaluated eight at a time (one per wave, mixed f32/f64 segment
-// distance on every lane, k(d / ell) where the leaf is within ell) into a dense LDS tile and added in row order by
-// wave 0, so the results are bit-identical to the CPU restatement.  Tiles with very many rows (the blocks around
-// the sensor on large scans) take the split path further down.
+// each beam that has a sample inside the block contributes its segment once with label 0.  bgkl_rows_prepare adds what
+// the line distance needs from the segment alone (direction, squared length, the "shorter than 0.1 mm" decision).  One
+// wave (or eight, on small scans) = one leaf tile, lane = leaf: the rows of the seven neighbours in order, squared
+// point-to-segment distance on every lane, hit <=> d^2 below the exact threshold of `d < ell`, k(sqrt(d^2) / ell) for the
+// hits, the two running sums in row order — bit-identical to the CPU restatement.  Tiles with very many rows (the
+// blocks around the sensor on large scans) take the split path further down.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,7 +22,8 @@
 namespace la3dm_dev {
 
 struct BgklArgs {
-    const float *rows;           // 8 floats per row, grouped by training block
+    const float *rows;           // 8 floats per row, grouped by training block (the ABI's layout: input of bgkl_rows_prepare)
+    const float4 *rowx;          // 3 float4 per row {x0 y0 z0 x1 | y1 z1 label degenerate | lx ly lz |l|^2} (bgkl_rows_prepare)
     const uint32_t *row_off;     // CSR over training blocks
     const int32_t *nbr;          // [n_test_blk * 7] training block or -1, ExtendedBlock order
     const float *blk_center;
@@ -36,6 +38,7 @@ struct BgklArgs {
     uint32_t n_tasks;
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
     float inv_ell;   // RN(1 / ell) or 0 (bgk_kernels.h div_by_ell)
+    float hit_d2;    // the smallest fp32 t with sqrtf(t) >= ell: d >= ell <=> d^2 >= hit_d2 for d = sqrtf(d^2) (host, exact)
 };
 
 // Split path for the tiles around the sensor.  Every beam crosses the sensor's block, so a 200 k-ray scan hands a
@@ -45,14 +48,15 @@ struct BgklArgs {
 //   bgkl_split_mark    per tile: row total, item count, first item, index in the list of split tiles (atomic
 //                      bumps; the order of items and tiles is free, every tile is independent)
 //   bgkl_split_items   item descriptors {tile, neighbour, row range}, first item of each (tile, neighbour)
-//   bgkl_split_eval<0> one wave per item: distance test, per row {hit mask, label, running hit count}
+//   bgkl_split_eval    one wave per item: distance test, per row {hit mask, label, running hit count}; the hit lanes'
+//                      squared distances in (row, lane) order in the item's own value slots
 //   bgkl_split_bdesc   per 64-row batch: where its values live
-//   bgkl_split_eval<1> same rows again: k(d / ell) of the hit lanes, written in (row, lane) order
+//   bgkl_split_kernelize  squared distances -> k(d / ell), in place, dense
 //   bgkl_split_fuse    one workgroup per (split tile, neighbour) — the seven (ybar, kbar) pairs of a tile are
-//                      independent chains.  Seven producer waves expand the next 64-row batch into dense
-//                      [row][leaf] tiles in LDS ({k or +0}, {k * label or +0}; loads issued one trip ahead, row
-//                      records two trips ahead) while wave 0 adds the current batch row by row: 2 LDS reads +
-//                      2 adds per row on the serial chain -> same sums as the row-serial kernel, bit for bit
+//                      independent chains.  Fourteen producer waves expand the next 64-row batch into a dense
+//                      [row][leaf] tile of k in LDS (+0 where the leaf is out of reach) while one consumer wave adds the
+//                      current batch's k row by row and a second one the k * label rows (hit rows only) — the same
+//                      sums as the row-serial kernel, bit for bit
 //   bgkl_split_apply   per split tile: the gated update of (alpha, beta) in ExtendedBlock order + state
 constexpr int kLItemRows = 256;
 constexpr int kLBatch = 64;
@@ -80,9 +84,48 @@ struct BgklSplit {
 // and cleaned to 0 — skipped.  d NaN or inf (a beam built from a NaN point of an unfiltered cloud): the reference's
 // dense formula yields NaN, the `< 0 -> 0` clean-up lets it through and it poisons ybar / kbar of every leaf that
 // meets the row (the kbar > 0.001 gate then rejects the update) — kept, with k = NaN.
-__device__ __forceinline__ bool bgkl_row_counts(float d, float ell) { return !(d >= ell) || d == __builtin_inff(); }
+__device__ __forceinline__ bool bgkl_row_counts(float d2, float hit_d2) { return !(d2 >= hit_d2) || d2 == __builtin_inff(); }
 __device__ __forceinline__ float bgkl_row_kernel(float d, float ell, float inv_ell, float sf2) {
     return (d - d == 0.0f) ? cov_sparse_fast<0, true>(div_by_ell(d, ell, inv_ell), sf2) : __builtin_nanf("");
+}
+
+// What point_to_line_dist computes from the segment alone — its direction l = b - a, |l|^2 and the "shorter than 0.1 mm"
+// decision — once per row instead of once per (row, leaf): the same fp32 expressions as seg_dist_f32 (lv_kernels.h), so the
+// same bits.  A third of that function's instructions were these wave-uniform terms (there is no scalar float unit to
+// hoist them to).
+__global__ __launch_bounds__(256) void bgkl_rows_prepare(const float *__restrict__ rows, uint32_t n_rows, float4 *__restrict__ rowx) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows) return;
+    const float4 p0 = *reinterpret_cast<const float4 *>(rows + 8 * (size_t)j);       // x0 y0 z0 x1
+    const float4 p1 = *reinterpret_cast<const float4 *>(rows + 8 * (size_t)j + 4);   // y1 z1 label -
+    const float lx = p0.w - p0.x, ly = p1.x - p0.y, lz = p1.y - p0.z;
+    const float c2 = lx * lx + ly * ly + lz * lz;
+    const bool degenerate = sqrtf(c2) < 0.0001f;
+    rowx[3 * (size_t)j] = p0;
+    rowx[3 * (size_t)j + 1] = make_float4(p1.x, p1.y, p1.z, degenerate ? 1.0f : 0.0f);
+    rowx[3 * (size_t)j + 2] = make_float4(lx, ly, lz, c2);
+}
+
+// Squared distance from p to the row's segment: seg_dist_f32 without its final square root (the callers compare d^2 with
+// hit_d2 and take the root of the hits only) and with the row's own terms read instead of recomputed.  q1.w != 0 (wave-
+// uniform): the distance is measured to the segment's start.
+__device__ __forceinline__ float bgkl_seg_d2(float px, float py, float pz, const float4 q0, const float4 q1, const float4 q2) {
+    float qx = q0.x, qy = q0.y, qz = q0.z;
+    if (q1.w == 0.0f) {   // lv_seg_point (lv_kernels.h), c2 = q2.w
+        const float vx = px - q0.x, vy = py - q0.y, vz = pz - q0.z;
+        const float c1 = vx * q2.x + vy * q2.y + vz * q2.z;
+        if (!(c1 <= 0.0f)) {
+            if (q2.w <= c1) {
+                qx = q0.w; qy = q1.x; qz = q1.y;
+            } else {
+                float b = c1 / q2.w;
+                if (b < 0x1p-100f) b = (float)((double)c1 / (double)q2.w);
+                qx = q0.x + q2.x * b; qy = q0.y + q2.y * b; qz = q0.z + q2.z * b;
+            }
+        }
+    }
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    return dx * dx + dy * dy + dz * dz;
 }
 
 // leaf of this lane: false when the tile holds no leaves
@@ -148,14 +191,13 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
         float ybar = 0.0f, kbar = 0.0f;
         if constexpr (kW == 1) {  // one wave: rows in order, straight into the sums
             for (uint32_t j = r0; j < r1; ++j) {
-                const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j);       // x0 y0 z0 x1
-                const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * (size_t)j + 4);   // y1 z1 label -
-                const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-                const bool hit = active && bgkl_row_counts(d, a.ell);
+                const float4 q0 = a.rowx[3 * (size_t)j], q1 = a.rowx[3 * (size_t)j + 1], q2 = a.rowx[3 * (size_t)j + 2];
+                const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
+                const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
                 if (__ballot(hit) == 0ull) continue;
                 if (hit) {
-                    const float kv = bgkl_row_kernel(d, a.ell, a.inv_ell, a.sf2);
-                    ybar += kv * p1.z;
+                    const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+                    ybar += kv * q1.z;
                     kbar += kv;
                 }
             }
@@ -166,13 +208,12 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
                 const uint32_t nr = min(r1 - q, (uint32_t)kWave);
                 for (uint32_t j = wave; j < nr; j += kW) {
                     const size_t row = (size_t)q + j;
-                    const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * row);
-                    const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
-                    const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
+                    const float4 q0 = a.rowx[3 * row], q1 = a.rowx[3 * row + 1], q2 = a.rowx[3 * row + 2];
+                    const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
                     float kv = 0.0f, kyv = 0.0f;
-                    if (active && bgkl_row_counts(d, a.ell)) {
-                        kv = bgkl_row_kernel(d, a.ell, a.inv_ell, a.sf2);
-                        kyv = kv * p1.z;
+                    if (active && bgkl_row_counts(d2, a.hit_d2)) {
+                        kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+                        kyv = kv * q1.z;
                     }
                     s_k[j][lane] = kv;
                     s_ky[j][lane] = kyv;
@@ -239,7 +280,7 @@ __global__ void bgkl_split_items(BgklArgs a, BgklSplit s) {
 }
 
 // One wave per item (tile x neighbour x <= kLItemRows rows), lane = leaf: the distance test of every row, the hit masks
-// and labels as row records, and the hit lanes' distances in (row, lane) order in the item's own value slots.
+// and labels as row records, and the hit lanes' squared distances in (row, lane) order in the item's own value slots.
 __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s) {
     const int lane = threadIdx.x;
     const uint32_t it = blockIdx.x;
@@ -255,14 +296,14 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
     uint4 mine = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t j = 0; j < nrows; ++j) {
         const size_t row = (size_t)r0 + j;
-        const float4 p0 = *reinterpret_cast<const float4 *>(a.rows + 8 * row);
-        const float4 p1 = *reinterpret_cast<const float4 *>(a.rows + 8 * row + 4);
-        const float d = seg_dist_f32(px, py, pz, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y);
-        const bool hit = active && bgkl_row_counts(d, a.ell);
+        const float4 q0 = a.rowx[3 * row], q1 = a.rowx[3 * row + 1], q2 = a.rowx[3 * row + 2];
+        const float4 p1 = q1;
+        const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
+        const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
         const unsigned long long m = __ballot(hit);
-        // bgkl_split_kernelize turns the distances into kernel values in place, at full lane utilisation (a second
+        // bgkl_split_kernelize turns the squared distances into kernel values in place, at full lane utilisation (a second
         // distance pass over all rows that wrote the values was 1.0 ms of a 200 k-ray insert)
-        if (hit) vals[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = d;
+        if (hit) vals[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = d2;
         if ((j & 63u) == 0u) {
             boff = off;
             if (lane == 0) s.batch_off[it * kLBatches + (j >> 6)] = off;
@@ -276,12 +317,12 @@ __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s
     if (lane == 0) s.item_hits[it] = off;
 }
 
-// distances -> kernel values, in place, dense
+// squared distances -> kernel values, in place, dense
 __global__ __launch_bounds__(256) void bgkl_split_kernelize(BgklArgs a, BgklSplit s) {
     const uint32_t it = blockIdx.x;
     const uint32_t n = s.item_hits[it];
     float *v = s.vals + (size_t)it * kLItemVals;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v[i] = bgkl_row_kernel(v[i], a.ell, a.inv_ell, a.sf2);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v[i] = bgkl_row_kernel(sqrtf(v[i]), a.ell, a.inv_ell, a.sf2);
 }
 
 __global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {

@@ -243,7 +243,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals,
+    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
@@ -678,6 +678,19 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     a.free_thresh = ctx->p.free_thresh;
     a.occupied_thresh = ctx->p.occupied_thresh;
     a.var_thresh = ctx->p.var_thresh;
+    {
+        // d >= ell for d = sqrtf(d2)  <=>  d2 >= hit_d2, the smallest fp32 whose (correctly rounded, monotone) root reaches ell
+        const float ell = ctx->p.ell;
+        float t = ell * ell;
+        while (t > 0.0f && sqrtf(t) >= ell) t = nextafterf(t, 0.0f);
+        while (!(sqrtf(t) >= ell) && t < INFINITY) t = nextafterf(t, INFINITY);
+        a.hit_d2 = t;
+    }
+    // the rows' own terms of the line distance, once per row
+    if ((rc = arena_reserve(ctx, ctx->l_rowx, sizeof(float4) * 3 * (size_t)s->n_train_pts)) != LA3DM_OK) return rc;
+    a.rowx = (const float4 *)ctx->l_rowx.ptr;
+    if (s->n_train_pts)
+        hipLaunchKernelGGL(bgkl_rows_prepare, dim3((s->n_train_pts + 255) / 256), dim3(256), 0, stream, a.rows, s->n_train_pts, (float4 *)ctx->l_rowx.ptr);
     // tiles with more than `bgkl_split_rows` rows take the split path (bgkl_kernels.h); the others run while
     // the host waits for the item count
     BgklSplit sp;
@@ -737,7 +750,8 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     }
     if (out) {
         out->n_tiles = a.n_tasks;
-        out->scratch_bytes = sizeof(uint4) * (size_t)n_items * kLItemRows + sizeof(float) * (size_t)n_items * kLItemVals;
+        out->scratch_bytes = sizeof(uint4) * (size_t)n_items * kLItemRows + sizeof(float) * (size_t)n_items * kLItemVals +
+                             sizeof(float4) * 3 * (size_t)s->n_train_pts;
     }
     return LA3DM_OK;
 }
