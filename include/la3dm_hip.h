@@ -130,7 +130,9 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
  * other variants is in DESIGN.md); "waves_per_wg" 1/2/4,
  * "remap" 0-2, "ablate" 0-7 (profiling); values outside these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
- * rows than this take the split path (default 4096, < 0 = never; results do not depend on it). */
+ * rows than this take the split path (default 4096, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
+ * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
+ * 0 = the replay expands them itself (results do not depend on it). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */
@@ -220,8 +222,8 @@ int la3dm_diag_mfma_chain(la3dm_ctx *ctx, const float *A, const float *B, int K,
  * Same la3dm_bgk_scan layout, except that train_xyzy holds ROWS OF 8 FLOATS {x0,y0,z0, x1,y1,z1, label, 0}
  * (hits = degenerate segments with label 1; one row per beam and block with label 0), n_train_pts = number of
  * rows and train_off is the CSR over training blocks in rows.  The device form enqueues on `stream`; it waits for
- * the stream once (item count) and, when some tile exceeds "bgkl_split_rows", a second time (value count) to size
- * the scratch of the split path — set the option < 0 for a call that never blocks. */
+ * the stream once (item count) to size the scratch of the split path — set "bgkl_split_rows" < 0 for a call that never
+ * blocks. */
 int la3dm_bgkl_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_counters *out);
 int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream, la3dm_bgk_counters *out);
 

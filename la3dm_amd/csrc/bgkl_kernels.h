@@ -77,6 +77,8 @@ struct BgklSplit {
     uint4 *bdesc;                 // [items * kLBatches] {value index lo, hi, values, rows | slot << 16}
     float *vals;
     float2 *part;                 // [split tiles * 7 * 64] (ybar, kbar) of one neighbour
+    float4 *dense;                // [items * kLItemRows / 4 * 64] k of rows 4g .. 4g + 3 for lane = leaf, +0 where out of reach (bgkl_split_expand)
+    unsigned long long *labmask;  // [items * kLBatches] bit r: row r of the batch has label 1
     uint32_t threshold;
 };
 
@@ -442,6 +444,151 @@ __global__ __launch_bounds__(kWave *(2 + kLProducers)) void bgkl_split_fuse(Bgkl
     if (wave == 1) s_y[lane] = ybar;
     __syncthreads();
     if (wave == 0) s.part[((size_t)h * 7u + b) * kWave + lane] = make_float2(s_y[lane], kbar);
+}
+
+constexpr int kLBatchVec = kLBatch / 4 * kWave;    // float4s of a batch: 16 groups x 64 lanes
+
+// The replay with the expansion taken out of it.  bgkl_split_fuse above expands the compact values of a (tile,
+// neighbour) chain into dense LDS tiles inside the one workgroup that also adds them, so the sensor block's chain (10^5
+// rows) is bounded by that workgroup's producers (~900 cycles per 64 rows; 1.9 ms of a 200 k-ray insert).  The expansion
+// has no order to keep: bgkl_split_expand does it for all items at once, into global memory — per 64-row batch 16 groups
+// of 4 rows, a float4 per lane {k of rows 4g .. 4g + 3 for this leaf, +0 where the leaf is out of reach or the row does
+// not exist} — and bgkl_split_add keeps the shape of the replay (producers -> LDS -> two consumer waves, one barrier per
+// batch) with producers that only copy: 16 KB per batch, fetched kLAddDepth batches ahead (one wave alone cannot keep
+// enough loads in flight to stream a chain at memory latency).
+// grid (kLBatches, items), 256 threads = one 64-row batch: the row records first (one per lane), then every wave asks for
+// the values of its 16 rows at once, the tile is assembled in LDS and leaves as 16 KB of coalesced float4 stores
+__global__ __launch_bounds__(256) void bgkl_split_expand(BgklSplit s) {
+    __shared__ uint4 s_rec[kLBatch];
+    __shared__ float s_t[kLBatch / 4][kWave][4];
+    const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
+    const uint32_t it = blockIdx.y, bt = blockIdx.x;
+    const uint4 dsc = s.item_desc[it];
+    const uint32_t nrows = dsc.w - dsc.z;
+    if (bt * (uint32_t)kLBatch >= nrows) return;   // (uniform) a batch without rows is never read
+    if (u == 0) {
+        const uint32_t j = bt * (uint32_t)kLBatch + (uint32_t)lane;
+        const uint4 R = j < nrows ? s.rowrec[(size_t)it * kLItemRows + j] : make_uint4(0u, 0u, 0u, 0u);
+        s_rec[lane] = R;
+        const unsigned long long m = __ballot(j < nrows && __uint_as_float(R.z) != 0.0f);   // rows with label 1
+        if (lane == 0) s.labmask[(size_t)it * kLBatches + bt] = m;
+    }
+    __syncthreads();
+    const float *v = s.vals + (size_t)it * kLItemVals + s.batch_off[it * kLBatches + bt];
+    float val[kLBatch / 4];
+#pragma unroll
+    for (int k = 0; k < kLBatch / 4; ++k) {   // row 4k + u of the batch (a row past the end has an empty mask)
+        const uint4 R = s_rec[4 * k + u];
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane(R.x), mhi = __builtin_amdgcn_readfirstlane(R.y);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0));
+        val[k] = 0.0f;
+        if ((((lane < 32 ? mlo : mhi) >> (lane & 31)) & 1u) != 0u) val[k] = v[(uint32_t)__builtin_amdgcn_readfirstlane(R.w) + rank];
+    }
+#pragma unroll
+    for (int k = 0; k < kLBatch / 4; ++k) s_t[k][lane][u] = val[k];
+    __syncthreads();
+    float4 *out = s.dense + ((size_t)it * kLBatches + bt) * kLBatchVec;
+    const float4 *t = reinterpret_cast<const float4 *>(&s_t[0][0][0]);
+#pragma unroll
+    for (int q = 0; q < kLBatchVec / 256; ++q) out[threadIdx.x + 256 * q] = t[threadIdx.x + 256 * q];
+}
+
+constexpr int kLAddDepth = 4;   // batches in flight per producer lane (measured: fewer copy waves or one wave that adds straight from
+                                // global memory cannot keep enough loads in flight to stream a chain at memory latency)
+
+__global__ __launch_bounds__(kWave *(2 + kLProducers)) void bgkl_split_add(BgklArgs a, BgklSplit s) {
+    __shared__ float4 s_k[2][kLBatchVec];   // {k of 4 rows} of (group, leaf), +0 where the leaf is out of reach
+    __shared__ float s_y[kWave];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t h = blockIdx.x / 7u, b = blockIdx.x % 7u;
+    const uint32_t it0 = s.nb_first[8 * h + b], it1 = s.nb_first[8 * h + b + 1];
+    if (it0 == it1) return;  // no trained model in this slot (uniform over the workgroup)
+    const uint4 last = s.item_desc[it1 - 1];
+    // batches of this chain that hold rows: the items are consecutive in the dense array, 4 batches each, all full but the last
+    const int nb = (int)((it1 - it0 - 1) * kLBatches + (last.w - last.z + (uint32_t)kLBatch - 1u) / (uint32_t)kLBatch);
+    const float4 *in = s.dense + (size_t)it0 * (kLItemRows / 4) * kWave;
+    const unsigned long long *lm = s.labmask + (size_t)it0 * kLBatches;
+    const int pw = wave - 2;   // wave 0 adds the k rows, wave 1 the rows with label 1, waves 2.. copy
+    const bool two = pw >= 0 && pw < 16 - kLProducers;   // 16 chunks of 64 float4 per batch over 14 copy waves
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The ring of batches in flight: four slots as named variables (as arrays, even with compile-time indices, they were
+    // placed in scratch memory and every access waited for it).  Slot u holds the batches = u (mod 4); a depth of 8 measured no faster (the
+    // consumer's 64 dependent adds per batch and the barrier set the pace: ~870 cycles per batch).
+    float4 ra0 = zero, rb0 = zero, ra1 = zero, rb1 = zero, ra2 = zero, rb2 = zero, ra3 = zero, rb3 = zero;
+    unsigned long long mk0 = 0ull, mk1 = 0ull, mk2 = 0ull, mk3 = 0ull;
+#define LA3DM_L_FETCH(bt_, RA, RB, MK)                                                                      \
+    do {                                                                                                    \
+        const int fb_ = (bt_);                                                                              \
+        if (wave == 1) {                                                                                    \
+            MK = fb_ < nb ? lm[fb_] : 0ull;                                                                 \
+        } else if (wave >= 2) {                                                                             \
+            RA = zero;                                                                                      \
+            RB = zero;                                                                                      \
+            if (fb_ < nb) {                                                                                 \
+                RA = in[(size_t)fb_ * kLBatchVec + pw * kWave + lane];                                      \
+                if (two) RB = in[(size_t)fb_ * kLBatchVec + (kLProducers + pw) * kWave + lane];             \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+    // one trip: consumers batch bt (its mask in MKP, the slot of bt), producers batch bt + 1 (slot RA / RB) into LDS and
+    // batch bt + 1 + depth asked for
+#define LA3DM_L_TRIP(u_, RA, RB, MK, MKP)                                                                   \
+    do {                                                                                                    \
+        const int bt = i + (u_), nxt = bt + 1;                                                              \
+        if (wave == 0) {                                                                                    \
+            if (bt >= 0 && bt < nb) {                                                                       \
+                const float4 *t = s_k[bt & 1] + lane;                                                       \
+                _Pragma("unroll") for (int g = 0; g < kLBatch / 4; ++g) {                                   \
+                    const float4 q = t[g * kWave];                                                          \
+                    acc += q.x;                                                                             \
+                    acc += q.y;                                                                             \
+                    acc += q.z;                                                                             \
+                    acc += q.w;                                                                             \
+                }                                                                                           \
+            }                                                                                               \
+        } else if (wave == 1) {                                                                             \
+            if (bt >= 0 && bt < nb) {                                                                       \
+                const unsigned long long m = MKP; /* uniform */                                             \
+                if (m != 0ull) {                                                                            \
+                    const float4 *t = s_k[bt & 1] + lane;                                                   \
+                    for (int g = 0; g < kLBatch / 4; ++g) {                                                 \
+                        const uint32_t bits = (uint32_t)(m >> (4 * g)) & 15u; /* uniform */                 \
+                        if (bits == 0u) continue;                                                           \
+                        const float4 q = t[g * kWave];                                                      \
+                        if (bits & 1u) acc += q.x;                                                          \
+                        if (bits & 2u) acc += q.y;                                                          \
+                        if (bits & 4u) acc += q.z;                                                          \
+                        if (bits & 8u) acc += q.w;                                                          \
+                    }                                                                                       \
+                }                                                                                           \
+            }                                                                                               \
+            if (bt >= 0) LA3DM_L_FETCH(bt + kLAddDepth, RA, RB, MKP);                                       \
+        } else {                                                                                            \
+            if (nxt < nb) {                                                                                 \
+                float4 *t = s_k[nxt & 1];                                                                   \
+                t[pw * kWave + lane] = RA;                                                                  \
+                if (two) t[(kLProducers + pw) * kWave + lane] = RB;                                         \
+            }                                                                                               \
+            LA3DM_L_FETCH(nxt + kLAddDepth, RA, RB, MK);                                                    \
+        }                                                                                                   \
+        __syncthreads();                                                                                    \
+    } while (0)
+    LA3DM_L_FETCH(0, ra0, rb0, mk0);
+    LA3DM_L_FETCH(1, ra1, rb1, mk1);
+    LA3DM_L_FETCH(2, ra2, rb2, mk2);
+    LA3DM_L_FETCH(3, ra3, rb3, mk3);
+    float acc = 0.0f;
+    for (int i = -1; i < nb; i += kLAddDepth) {   // bt = i + u is = u - 1 (mod 4): its mask sits in slot (u + 3) % 4
+        LA3DM_L_TRIP(0, ra0, rb0, mk0, mk3);
+        LA3DM_L_TRIP(1, ra1, rb1, mk1, mk0);
+        LA3DM_L_TRIP(2, ra2, rb2, mk2, mk1);
+        LA3DM_L_TRIP(3, ra3, rb3, mk3, mk2);
+    }
+#undef LA3DM_L_TRIP
+#undef LA3DM_L_FETCH
+    if (wave == 1) s_y[lane] = acc;
+    __syncthreads();
+    if (wave == 0) s.part[((size_t)h * 7u + b) * kWave + lane] = make_float2(s_y[lane], acc);
 }
 
 __global__ __launch_bounds__(kWave) void bgkl_split_apply(BgklArgs a, BgklSplit s) {

@@ -27,6 +27,7 @@ struct la3dm_ctx {
     int opt_time_kernel = 0;
     int opt_waves = 1;  // waves per workgroup (variant 3)
     int opt_remap = 2;
+    int opt_l_dense_add = 1;      // BGK-L split tiles: 1 = expansion for all items at once + two-wave ordered add, 0 = producer / consumer workgroup
     int opt_l_split_rows = 4096;  // BGK-L: tiles with more rows than this are split over waves (< 0: never)
     int opt_ablate = 0;  // profiling only: 1 skip kernel evaluation, 2 skip the candidate tests
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
@@ -34,7 +35,7 @@ struct la3dm_ctx {
     // scratch (device-pointer path)
     Arena pts_scaled, nbr_range;
     Arena gp_loff, gp_totals, gp_L, gp_alpha, gp_v;
-    Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx;
+    Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask;
     Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;
     Arena lvp_sub_task, lvp_task, lvp_totals, lvp_rows, lvp_sub_out, lvp_cand;  // BGK-LV work plan + row scratch of split cubes
     // staging (host-pointer path)

@@ -243,7 +243,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx,
+    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
@@ -290,6 +290,11 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
     }
     if (!strcmp(name, "bgkl_split_rows")) {
         ctx->opt_l_split_rows = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "bgkl_dense_add")) {
+        if (value < 0 || value > 1) return bad_value("0 or 1");
+        ctx->opt_l_dense_add = value;
         return LA3DM_OK;
     }
     if (!strcmp(name, "time_kernel")) {
@@ -744,7 +749,17 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         hipLaunchKernelGGL(bgkl_split_eval, dim3(n_items), dim3(kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
         hipLaunchKernelGGL(bgkl_split_kernelize, dim3(n_items), dim3(256), 0, stream, a, sp);
-        hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
+        if (ctx->opt_l_dense_add) {
+            // the replay's expansion done for all items at once, the ordered part left to two waves per chain
+            if ((rc = arena_reserve(ctx, ctx->l_dense, sizeof(float) * (size_t)n_items * kLItemVals)) != LA3DM_OK) return rc;
+            if ((rc = arena_reserve(ctx, ctx->l_labmask, sizeof(unsigned long long) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;
+            sp.dense = (float4 *)ctx->l_dense.ptr;
+            sp.labmask = (unsigned long long *)ctx->l_labmask.ptr;
+            hipLaunchKernelGGL(bgkl_split_expand, dim3(kLBatches, n_items), dim3(256), 0, stream, sp);
+            hipLaunchKernelGGL(bgkl_split_add, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
+        } else {
+            hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
+        }
         hipLaunchKernelGGL(bgkl_split_apply, dim3(n_split), dim3(kWave), 0, stream, a, sp);
         HIP_TRY(ctx, hipGetLastError());
     }

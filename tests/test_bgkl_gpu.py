@@ -93,14 +93,16 @@ def test_edge_cases(built):
     _same(m, o, "dups")
 
 
-@pytest.mark.parametrize("rows,depth", [(0, 3), (0, 4), (300, 3), (70, 4)])
-def test_split_tiles(built, rows, depth):
+@pytest.mark.parametrize("rows,depth,dense", [(0, 3, 1), (0, 4, 1), (300, 3, 1), (70, 4, 1), (0, 3, 0), (70, 4, 0)])
+def test_split_tiles(built, rows, depth, dense):
     """tiles with more than `bgkl_split_rows` rows run the split path (distance test / kernel evaluation spread over
-    waves, ordered replay of the sums): same bits as the row-serial kernel and the oracle, whatever the threshold"""
+    waves, ordered replay of the sums): same bits as the row-serial kernel and the oracle, whatever the threshold and
+    in both forms of the replay (rows expanded for all items at once + copy-only replay / expansion inside the replay)"""
     import la3dm_amd
     params = dict(la3dm_amd.L_YAML, block_depth=depth)
     m, o = _maps(params)
     m.set_option("bgkl_split_rows", rows)
+    m.set_option("bgkl_dense_add", dense)
     for i in (1, 2, 3):
         xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
         m.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
