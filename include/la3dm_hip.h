@@ -130,7 +130,7 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
  * other variants is in DESIGN.md); "waves_per_wg" 1/2/4,
  * "remap" 0-2, "ablate" 0-7 (profiling); values outside these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
- * rows than this take the split path (default 4096, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
+ * rows than this take the split path (default 2048, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
  * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
  * 0 = the replay expands them itself (results do not depend on it). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
