@@ -1054,6 +1054,7 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
 // BGKOctoMap::insert_training_data (bgkoctomap.cpp:82-212) on the pool: n labelled points {x, y, z, label} (host
 // pointer) instead of a scan; every leaf of every test block is updated for every neighbour model (no kbar gate).
 int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats_out) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || (n && !xyzy)) return LA3DM_ERR_ARG;
     la3dm_ctx *ctx = dm->ctx;
     if (ctx->p.variant == 3) return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_insert_training_data: a BGK-L map needs beams, not labelled points");
@@ -1380,6 +1381,7 @@ int la3dm_devmap_lv_set_original_size(la3dm_devmap *dm, int original_size) {
 
 int la3dm_devmap_lv_training(la3dm_devmap *dm, float *samples4, uint32_t cap_samples, float *rays6, uint32_t cap_rays,
                              uint32_t *n_samples, uint32_t *n_rays) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm) return LA3DM_ERR_ARG;
     if (n_samples) *n_samples = dm->lv_n_samples;
     if (n_rays) *n_rays = dm->lv_n_rays;
@@ -1431,6 +1433,7 @@ int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3d
 int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3],
                                           float ds_resolution, float free_resolution, float max_range,
                                           la3dm_devmap_stats *stats_out) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || !origin || (n && !d_xyz)) return LA3DM_ERR_ARG;
     la3dm_ctx *ctx = dm->ctx;
     int rc;
@@ -1458,6 +1461,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
 int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride, const float origin[3],
                                         float ds_resolution, float free_resolution, float max_range,
                                         la3dm_devmap_stats *stats_out) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || (n && !xyz) || stride < 3) return LA3DM_ERR_ARG;
     DM_TRY(hipSetDevice(dm->ctx->device));
     DM_RESERVE(dm->cloud, 12ull * n);
@@ -1480,6 +1484,7 @@ int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nod
 }
 
 int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, uint8_t *S) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm) return LA3DM_ERR_ARG;
     if (dm->n_blocks == 0) return LA3DM_OK;
     if (!keys || !A || !B || !S) return LA3DM_ERR_ARG;
@@ -1496,6 +1501,7 @@ int la3dm_devmap_download(la3dm_devmap *dm, int64_t *keys, float *A, float *B, u
 
 int la3dm_devmap_search_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint8_t *exists, float *A, float *B,
                              uint8_t *state) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || (n && (!xyz || !exists || !A || !B || !state))) return LA3DM_ERR_ARG;
     if (n == 0) return LA3DM_OK;
     DM_TRY(hipSetDevice(dm->ctx->device));
@@ -1526,6 +1532,7 @@ int la3dm_devmap_search_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uin
 }
 
 int la3dm_devmap_key_bounds(la3dm_devmap *dm, int32_t lo[3], int32_t hi[3]) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || !lo || !hi) return LA3DM_ERR_ARG;
     if (dm->n_blocks == 0) return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_key_bounds: the map holds no blocks");
     DM_TRY(hipSetDevice(dm->ctx->device));
@@ -1547,6 +1554,7 @@ int la3dm_devmap_key_bounds(la3dm_devmap *dm, int32_t lo[3], int32_t hi[3]) {
 
 int la3dm_devmap_export_cells(la3dm_devmap *dm, int state, int original_size, float min_z, float max_z, float *cells,
                               float *rgba, int32_t *level, uint64_t cap, uint64_t *count) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || !count || (state != 0 && state != 1)) return LA3DM_ERR_ARG;
     *count = 0;
     if (dm->n_blocks == 0) return LA3DM_OK;
@@ -1635,6 +1643,7 @@ int la3dm_devmap_diag_add_repeat(la3dm_ctx *ctx, const float *s, const float *x,
 // mode 0: out[i] = sum of in[0..i), aux[0] = total.  mode 1: in = sorted keys (0xFFFFFFFF = invalid, last): out = exclusive
 // scan of the head flags, aux = {segments, valid keys, seg_start[0..segments]} (aux holds n + 3 words).
 int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *aux) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || !in || !out || !aux || n == 0 || (mode != 0 && mode != 1)) return LA3DM_ERR_ARG;
     DM_TRY(hipSetDevice(dm->ctx->device));
     hipStream_t st = dm->ctx->stream;
@@ -1665,6 +1674,7 @@ int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint3
 // stable sort of (keys, vals) on the low `bits` key bits through sort_pairs (the in-house radix sort unless LA3DM_OWN_SORT=0)
 int la3dm_devmap_diag_sort(la3dm_devmap *dm, const uint32_t *keys, const uint32_t *vals, uint32_t n, int bits, uint32_t *keys_out,
                            uint32_t *vals_out) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || !keys || !vals || !keys_out || !vals_out || n == 0 || bits < 1 || bits > 32) return LA3DM_ERR_ARG;
     DM_TRY(hipSetDevice(dm->ctx->device));
     hipStream_t st = dm->ctx->stream;
@@ -1684,6 +1694,7 @@ int la3dm_devmap_diag_sort(la3dm_devmap *dm, const uint32_t *keys, const uint32_
 }
 
 int la3dm_devmap_training_data(la3dm_devmap *dm, float *xyzy, uint32_t cap, uint32_t *n) {
+    if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
     if (!dm || !n) return LA3DM_ERR_ARG;
     *n = dm->n_xy;
     if (!xyzy || cap < dm->n_xy) return dm->n_xy ? LA3DM_ERR_ARG : LA3DM_OK;
