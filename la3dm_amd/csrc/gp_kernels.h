@@ -738,13 +738,22 @@ constexpr int kGpLdsRows = 64;  // rows of v the LDS path can hold (one wave of 
 #endif
 constexpr int kGpMfmaMinN = LA3DM_GP_MFMA_MIN_N;  // blocks with at least this many points are solved on the matrix cores
 
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void gp_predict_fuse_kernel(GpArgs a) {
-    extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: sized per launch, LDS is the occupancy limiter
+// Two launches share this body: the tiles whose seven neighbours all hold fewer than kGpMfmaMinN points (kMixed = false: no
+// matrix-core code in the kernel, so no 256-VGPR budget and no spills in the four-row loop — with both paths in one kernel
+// the small path of configs[2] ran 7 % slower after the large path had grown) and the tiles with at least one large
+// neighbour (kMixed = true).  Every tile is taken by exactly one of them.
+template <bool kMixed>
+__device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_vraw) {
     float (*s_v)[kWave] = reinterpret_cast<float (*)[kWave]>(s_vraw);
     const int lane = threadIdx.x;
     const uint32_t task = blockIdx.x;
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.tpb_shift;
+    {
+        bool large = false;
+        for (int nb = 0; nb < 7; ++nb) large = large || (int)a.nbr_range[7 * blk + nb].y >= kGpMfmaMinN;
+        if (large != kMixed) return;   // (uniform)
+    }
     const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
     const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
     const uint32_t l1 = a.leaf_off[blk + 1];
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const float4 *x = a.pts + r.x;
         const float *al = a.alpha_k + r.x;
         float mj = 0.0f, ss = 0.0f;
-        if (N < kGpMfmaMinN) {
+        if (!kMixed || N < kGpMfmaMinN) {
             // fast path: a row of L fits one register (lane = column)
             for (int k0 = 0; k0 < N; k0 += 4) {
                 float Lr[4], acc[4], ks[4];
@@ -805,7 +814,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     }
                 }
             }
-        } else {
+        } else if constexpr (kMixed) {
             gp_solve_mfma(a, L, x, al, N, tx, ty, tz, vg, s_vraw, lane, mj, ss);   // (its tile staging reuses the LDS of the small path)
         }
         const float var = a.sf2 - ss;
@@ -821,6 +830,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             a.state[li] = 0;
         }
     }
+}
+
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void gp_predict_fuse_kernel(GpArgs a) {
+    extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64] or the tile staging: sized per launch
+    gp_predict_fuse_body<true>(a, s_vraw);
+}
+__global__ __launch_bounds__(kWave) void gp_predict_fuse_small_kernel(GpArgs a) {
+    extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: LDS is the occupancy limiter
+    gp_predict_fuse_body<false>(a, s_vraw);
 }
 
 // Test hook for the property gp_solve_mfma / gp_train_kernel rely on: D = A B through v_mfma_f32_32x32x2_f32

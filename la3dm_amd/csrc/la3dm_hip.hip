@@ -563,9 +563,12 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     }
     {
         const uint32_t rows = max_n < (uint32_t)kGpLdsRows ? (max_n ? max_n : 1u) : (uint32_t)kGpLdsRows;
-        size_t lds = rows * kWave * sizeof(float);
-        if (max_n >= (uint32_t)kGpMfmaMinN) lds = std::max<size_t>(lds, 3 * 32 * 36 * sizeof(float));   // gp_solve_mfma's three tile buffers
-        hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave), lds, stream, a);
+        const size_t lds = rows * kWave * sizeof(float);
+        // tiles without a large neighbour; then (if there is any large block) the tiles with one — every tile once
+        hipLaunchKernelGGL(gp_predict_fuse_small_kernel, dim3(a.n_tasks), dim3(kWave), lds, stream, a);
+        if (max_n >= (uint32_t)kGpMfmaMinN)
+            hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave),
+                               std::max<size_t>(lds, 3 * 32 * 36 * sizeof(float)) /* gp_solve_mfma's three tile buffers */, stream, a);
     }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
     HIP_TRY(ctx, hipGetLastError());
