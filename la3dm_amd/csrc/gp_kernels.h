@@ -36,6 +36,8 @@ struct GpArgs {
     uint8_t *state;
     const float4 *lut;
     float *vscratch;            // [n_tasks][vmax][64] when a block exceeds the LDS capacity, else null
+    const uint32_t *order;      // large training blocks, largest first (gp_factor_offsets)
+    const unsigned long long *totals;   // [0] sum N^2, [1] max N, [2] large blocks
     uint32_t n_test_blk, tpb_shift, n_tasks, n_train_blk;
     uint32_t vmax;              // rows of v per task in vscratch
     float scale;                // (float)(1.73205 / ell)
@@ -76,10 +78,16 @@ __global__ void gp_prepare(const float4 *__restrict__ in, float4 *__restrict__ o
 }
 
 // exclusive scan of N_b^2 (one workgroup; n_train_blk is a few 10^4) + max N_b
+// + the large blocks (gp_train_kernel's: one wave each, run time ~ N^3) listed largest first: the launch takes them in this
+// order, so the longest factorisations start at once instead of wherever their index puts them (totals[2] = their number)
 __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32_t n_blk,
-                                  unsigned long long *__restrict__ l_off, unsigned long long *__restrict__ totals) {
+                                  unsigned long long *__restrict__ l_off, unsigned long long *__restrict__ totals,
+                                  uint32_t *__restrict__ order) {
     __shared__ unsigned long long s_sum[256];
     __shared__ uint32_t s_max[256];
+    __shared__ uint32_t s_cls[64];   // large blocks per size class (32-row blocks, capped)
+    if (threadIdx.x < 64) s_cls[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_blk + 255u) / 256u;
     const uint32_t b0 = tid * per, b1 = min(n_blk, b0 + per);
@@ -89,6 +97,7 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
         const unsigned long long n = train_off[b + 1] - train_off[b];
         sum += n * n;
         mx = max(mx, (uint32_t)n);
+        if (n > (unsigned long long)kGpTrainLdsMaxN) atomicAdd(&s_cls[min(63u, (uint32_t)((n + 31) >> 5))], 1u);
     }
     s_sum[tid] = sum;
     s_max[tid] = mx;
@@ -104,6 +113,13 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
         }
         totals[0] = run;
         totals[1] = m;
+        uint32_t first = 0;   // class c starts behind all larger classes
+        for (int c = 63; c >= 0; --c) {
+            const uint32_t k = s_cls[c];
+            s_cls[c] = first;
+            first += k;
+        }
+        totals[2] = first;
     }
     __syncthreads();
     unsigned long long run = s_sum[tid];
@@ -111,6 +127,7 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
         const unsigned long long n = train_off[b + 1] - train_off[b];
         l_off[b] = run;
         run += n * n;
+        if (n > (unsigned long long)kGpTrainLdsMaxN) order[atomicAdd(&s_cls[min(63u, (uint32_t)((n + 31) >> 5))], 1u)] = b;
     }
 }
 
@@ -137,7 +154,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     __shared__ __attribute__((aligned(16))) float s_lds[3 * 32 * 36];
     float (*s_op)[32][36] = reinterpret_cast<float (*)[32][36]>(s_lds);
     float (*s_tile)[32][kTrT] = reinterpret_cast<float (*)[32][kTrT]>(s_lds);
-    const uint32_t b = blockIdx.x;
+    if (blockIdx.x >= (uint32_t)a.totals[2]) return;   // (the launch has one workgroup per training block; the large ones are listed)
+    const uint32_t b = a.order[blockIdx.x];            // largest first
     const uint32_t p0 = a.train_off[b];
     const int N = (int)(a.train_off[b + 1] - p0);
     if (N <= kGpTrainLdsMaxN) return;  // small blocks: gp_train_wave_kernel

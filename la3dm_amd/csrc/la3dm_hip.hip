@@ -244,7 +244,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask,
-                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
+                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
@@ -482,10 +482,11 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     if ((rc = arena_reserve(ctx, ctx->pts_scaled, sizeof(float4) * npts)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->nbr_range, sizeof(uint2) * 7 * (size_t)s->n_test_blk)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_loff, sizeof(unsigned long long) * nblk)) != LA3DM_OK) return rc;
-    if ((rc = arena_reserve(ctx, ctx->gp_totals, 16)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->gp_totals, 24)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->gp_order, sizeof(uint32_t) * nblk)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_alpha, sizeof(float) * npts)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(gp_factor_offsets, dim3(1), dim3(256), 0, stream, s->train_off, s->n_train_blk,
-                       (unsigned long long *)ctx->gp_loff.ptr, (unsigned long long *)ctx->gp_totals.ptr);
+                       (unsigned long long *)ctx->gp_loff.ptr, (unsigned long long *)ctx->gp_totals.ptr, (uint32_t *)ctx->gp_order.ptr);
     unsigned long long sum_n2 = s->train_sum_n2;
     uint32_t max_n = s->train_max_n;
     if (sum_n2 == 0 || max_n == 0) {  // no hints: one synchronisation to size the factor arena
@@ -518,6 +519,8 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     a.nbr_range = (const uint2 *)ctx->nbr_range.ptr;
     a.nbr = s->nbr;
     a.l_off = (const unsigned long long *)ctx->gp_loff.ptr;
+    a.order = (const uint32_t *)ctx->gp_order.ptr;
+    a.totals = (const unsigned long long *)ctx->gp_totals.ptr;
     a.Lmat = (float *)ctx->gp_L.ptr;
     a.alpha_k = (float *)ctx->gp_alpha.ptr;
     a.blk_center = s->blk_center;
