@@ -52,11 +52,13 @@ struct BgklArgs {
 //                      squared distances in (row, lane) order in the item's own value slots
 //   bgkl_split_bdesc   per 64-row batch: where its values live
 //   bgkl_split_kernelize  squared distances -> k(d / ell), in place, dense
-//   bgkl_split_fuse    one workgroup per (split tile, neighbour) — the seven (ybar, kbar) pairs of a tile are
-//                      independent chains.  Fourteen producer waves expand the next 64-row batch into a dense
-//                      [row][leaf] tile of k in LDS (+0 where the leaf is out of reach) while one consumer wave adds the
-//                      current batch's k row by row and a second one the k * label rows (hit rows only) — the same
-//                      sums as the row-serial kernel, bit for bit
+//   bgkl_split_expand  (default form of the replay) compact values -> dense {k of 4 rows per leaf} tiles, all items at once
+//   bgkl_split_add     one workgroup per (split tile, neighbour) — the seven (ybar, kbar) pairs of a tile are
+//                      independent chains.  Fourteen copy waves bring the next 64-row batches of the dense tiles into
+//                      LDS (four batches in flight) while one consumer wave adds the current batch's k row by row and a
+//                      second one the rows with label 1 — the same sums as the row-serial kernel, bit for bit
+//   bgkl_split_fuse    (option bgkl_dense_add = 0) the same replay with producers that expand the compact values
+//                      themselves: 64 KB less scratch per item, the sensor block's chain 1.7x slower
 //   bgkl_split_apply   per split tile: the gated update of (alpha, beta) in ExtendedBlock order + state
 constexpr int kLItemRows = 256;
 constexpr int kLBatch = 64;
