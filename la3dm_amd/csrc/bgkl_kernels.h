@@ -458,13 +458,13 @@ constexpr int kLBatchVec = kLBatch / 4 * kWave;    // float4s of a batch: 16 gro
 // not exist} — and bgkl_split_add keeps the shape of the replay (producers -> LDS -> two consumer waves, one barrier per
 // batch) with producers that only copy: 16 KB per batch, fetched kLAddDepth batches ahead (one wave alone cannot keep
 // enough loads in flight to stream a chain at memory latency).
-// grid (kLBatches, items), 256 threads = one 64-row batch: the row records first (one per lane), then every wave asks for
+// grid kLBatches * items, 256 threads = one 64-row batch: the row records first (one per lane), then every wave asks for
 // the values of its 16 rows at once, the tile is assembled in LDS and leaves as 16 KB of coalesced float4 stores
 __global__ __launch_bounds__(256) void bgkl_split_expand(BgklSplit s) {
     __shared__ uint4 s_rec[kLBatch];
     __shared__ float s_t[kLBatch / 4][kWave][4];
     const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
-    const uint32_t it = blockIdx.y, bt = blockIdx.x;
+    const uint32_t it = blockIdx.x / (uint32_t)kLBatches, bt = blockIdx.x % (uint32_t)kLBatches;   // (one grid dimension: items can exceed 65535)
     const uint4 dsc = s.item_desc[it];
     const uint32_t nrows = dsc.w - dsc.z;
     if (bt * (uint32_t)kLBatch >= nrows) return;   // (uniform) a batch without rows is never read

@@ -761,7 +761,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
             if ((rc = arena_reserve(ctx, ctx->l_labmask, sizeof(unsigned long long) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;
             sp.dense = (float4 *)ctx->l_dense.ptr;
             sp.labmask = (unsigned long long *)ctx->l_labmask.ptr;
-            hipLaunchKernelGGL(bgkl_split_expand, dim3(kLBatches, n_items), dim3(256), 0, stream, sp);
+            hipLaunchKernelGGL(bgkl_split_expand, dim3(n_items * kLBatches), dim3(256), 0, stream, sp);
             hipLaunchKernelGGL(bgkl_split_add, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
         } else {
             hipLaunchKernelGGL(bgkl_split_fuse, dim3(n_split * 7), dim3(kWave * (2 + kLProducers)), 0, stream, a, sp);
