@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--resolution", type=float, default=0.1)
     ap.add_argument("--fast-trig", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--sum", type=int, default=-1, choices=[-1, 0, 1],
+                    help="BGK accumulate mode: 0 = the reference's fp32 order (bit-identical), 1 = order-free double accumulators; -1 = default")
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (kernel variant 3); 0 = library default")
     ap.add_argument("--remap", type=int, default=-1, help="workgroup->tile remap mode; -1 = library default")
     ap.add_argument("--workload", choices=["bgk", "gp", "lv", "l"], default="bgk",
@@ -163,8 +164,8 @@ def main():
     ctx = m.ctx()
     if args.fast_trig:
         m.set_option("fast_trig", args.fast_trig)
-    if args.variant:
-        m.set_option("bgk_variant", args.variant)
+    if args.sum >= 0:
+        m.set_option("bgk_sum", args.sum)
     if args.waves:
         m.set_option("waves_per_wg", args.waves)
     if args.remap >= 0:
@@ -253,7 +254,7 @@ def main():
                                        "1 scan per GPU + RCCL all-gather of leaf (alpha,beta,state)") +
                                       (", gather of scan k under the kernel of scan k+1 (two leaf buffers)" if n_buf > 1 else ""),
                        "trig": ["correctly-rounded", "f32-poly", "ocml"][args.fast_trig],
-                       "kernel_variant": args.variant, "waves_per_wg": args.waves, "remap": args.remap},
+                       "bgk_sum": args.sum, "waves_per_wg": args.waves, "remap": args.remap},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "bgk_predict_fuse", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,

@@ -43,6 +43,7 @@ struct BgkArgs {
     uint8_t *state;
     const float4 *lut;          // voxel LUT, depth-major, w unused
     const uint2 *nbr_range;     // [n_test_blk * 7] {first point, count} of each neighbour model (resolved by the prescale launch)
+    const uint32_t *blk_desc;   // [n_test_blk * 16] flat view of the 7 neighbour ranges for bgk_predict_fuse_r (see bgk_prepare)
     uint32_t n_test_blk;
     uint32_t tpb_shift;         // log2(tiles per test block)
     uint32_t n_tasks;           // n_test_blk << tpb_shift
@@ -185,10 +186,39 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
 
 // Same launch shape, second job: resolve nbr[t][b] -> {train_off[nb], count} once per scan, so that
 // the predict kernel's prologue needs one dependent memory round trip less per tile.
+// Third job (blk_desc != nullptr): the same seven ranges of a test block as ONE flat index space [0, M) — the
+// concatenation of the neighbours' points in ExtendedBlock order — for the kernel that stages 64 points per trip whatever
+// neighbour they belong to: words 0-6 = first point of neighbour b minus the flat index where b starts (flat index +
+// this = point index, modulo 2^32), words 8-14 = flat index where neighbour b ends (word 14 = M), word 7 = bit b set
+// when neighbour b has a trained model, word 15 = 0.
 __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell,
                             const int32_t *__restrict__ nbr, const uint32_t *__restrict__ train_off,
-                            uint2 *__restrict__ nbr_range, uint32_t n_nbr) {
+                            uint2 *__restrict__ nbr_range, uint32_t n_nbr, uint32_t *__restrict__ blk_desc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk_desc && i < n_nbr / 7u) {
+        uint32_t d[16];
+        uint32_t pre = 0, trained = 0;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const int tb = nbr[7 * i + b];
+            uint32_t first = 0, cnt = 0;
+            if (tb >= 0) {
+                first = train_off[tb];
+                cnt = train_off[tb + 1] - first;
+            }
+            d[b] = first - pre;
+            pre += cnt;
+            d[8 + b] = pre;
+            trained |= (cnt ? 1u : 0u) << b;
+        }
+        d[7] = trained;
+        d[15] = 0;
+        uint4 *o = (uint4 *)(blk_desc + 16 * (size_t)i);
+        o[0] = make_uint4(d[0], d[1], d[2], d[3]);
+        o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        o[2] = make_uint4(d[8], d[9], d[10], d[11]);
+        o[3] = make_uint4(d[12], d[13], d[14], d[15]);
+    }
     if (i < n) {
         const float4 p = in[i];
         out[i] = make_float4(p.x / ell, p.y / ell, p.z / ell, p.w);
@@ -660,6 +690,272 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
         uint32_t lw = li;
         asm volatile("" : "+v"(lw));
         if (updated) {
+            a.alpha[lw] = A;
+            a.beta[lw] = B;
+            a.state[lw] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[lw] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bgk_predict_fuse_r (round 3) — the same pairs and the same kernel values as bgk_predict_fuse_v5, but the two sums
+// per leaf are formed WITHOUT the reference's summation order: every evaluated pair adds {k, k*y} to the leaf's pair of
+// DOUBLE accumulators in LDS (ds_add_f64 — measured 32 cycles per wave instruction on gfx950, against 770 for
+// ds_add_f32: the f32 LDS float atomic is not a hardware path here, the f64 one is), and the epilogue rounds
+// alpha + sum(k*y) and beta + (sum(k) - sum(k*y)) to fp32 once.  A double sum of <= a few thousand fp32 terms is exact to
+// 2^-53 relative whatever the order, so the result does not depend on the order of the pairs (it is the correctly
+// rounded value of what the reference's fp32 chain approximates) and differs from the ordered kernel / the CPU
+// restatement by a few fp32 ulps of alpha, beta: |dp| <= ~2e-7, against the 1e-5 the north star asks for.  The 7
+// neighbours are not kept apart: Occupancy::update (bgkoctree_node.cpp:31-35) adds ybar and kbar - ybar per neighbour
+// with kbar > 0; k >= 0 everywhere, so "some neighbour had kbar > 0" is "sum(k) > 0", and a neighbour with kbar = 0
+// adds +0.
+//
+// What that removes from v5: phase D (the ordered replay: ~400 VALU + 180 SALU + 43 LDS per tile), the hit history,
+// the per-neighbour bookkeeping of the staging, the write-back of {k, k*y} to the ring.  What else is new here:
+//   * staging walks ONE flat index space over the 7 neighbours' points (bgk_prepare's blk_desc): 64 points per trip
+//     whatever neighbour they belong to (v5: one trip per neighbour at ~20 % lane utilisation), neighbour selection
+//     by a compare/select chain against the descriptor's prefix sums;
+//   * the ring is a queue: a C round evaluates full 64-entry batches only and moves the remainder (< 64 entries)
+//     to the front, so every batch but the tile's last runs at full lane utilisation;
+//   * hit lanes write under exec = hit mask (no scratch slots, 24 instead of 32 LDS cycles per write).
+// LDS per wave: 68 candidates (1 088 B) + 2 x 64 double accumulators (1 024 B) + 376-entry ring (3 008 B) = 5 120 B.
+// ---------------------------------------------------------------------------
+constexpr int kRingR = 376;
+struct __attribute__((aligned(16))) WaveLdsR {
+    float4 cand[kCand5 + 4];
+    double acc_k[kWave];
+    double acc_y[kWave];
+    uint2 ring[kRingR];  // {d2, (lane << 13) | (candidate << 4)}
+};
+#define LA3DM_RB_PUSH(A)                                    \
+    "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
+    "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
+    "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
+    "s_mov_b64 exec, vcc\n"                                 \
+    "ds_write2_b32 %[tr], " A ", %[idx] offset1:1\n"        \
+    "s_mov_b64 exec, -1\n"                                  \
+    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
+    "v_add_u32 %[idx], 16, %[idx]\n"                        \
+    "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
+
+template <int kTrig>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_r(BgkArgs a) {
+    __shared__ WaveLdsR L;
+    const uint32_t lane = threadIdx.x;
+    uint32_t wg = blockIdx.x;
+    if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
+    else if (a.remap == 2) {
+        const uint32_t G8 = gridDim.x & ~63u;
+        if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
+    }
+    const uint32_t task = __builtin_amdgcn_readfirstlane(wg);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const bool active = lane < nl;
+    const uint32_t li = l0 + (active ? lane : 0);
+
+    // flat view of the 7 neighbour ranges
+    const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
+    uint32_t adj[7], pend[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        adj[b] = dsc[b];
+        pend[b] = dsc[8 + b];
+    }
+    const uint32_t M = pend[6];
+    // neighbour of flat index f by six compares into six SGPR pairs and a select chain over the offsets (held in VGPRs: a
+    // v_cndmask may read one scalar operand, and the mask is one).  In assembly: the compiler turns the C++ select
+    // chain into an index chain plus a lookup in a scratch-memory copy of adj[], and its vcc-based pairs need a
+    // wait state each (gfx940: VALU writes vcc -> VALU reads it as a mask).
+    uint32_t adjv[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        adjv[b] = adj[b];
+        asm volatile("" : "+v"(adjv[b]));
+    }
+    auto load_chunk = [&](uint32_t cb) {
+        const uint32_t f = cb + lane;
+        uint32_t ad;
+        unsigned long long m1, m2, m3, m4, m5, m6;
+        asm("v_cmp_le_u32 %[m1], %[e0], %[f]\n"
+            "v_cmp_le_u32 %[m2], %[e1], %[f]\n"
+            "v_cmp_le_u32 %[m3], %[e2], %[f]\n"
+            "v_cmp_le_u32 %[m4], %[e3], %[f]\n"
+            "v_cmp_le_u32 %[m5], %[e4], %[f]\n"
+            "v_cmp_le_u32 %[m6], %[e5], %[f]\n"
+            "v_cndmask_b32 %[ad], %[a0], %[a1], %[m1]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a2], %[m2]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a3], %[m3]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a4], %[m4]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a5], %[m5]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a6], %[m6]\n"
+            : [ad] "=&v"(ad), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [m6] "=&s"(m6)
+            : [f] "v"(f), [e0] "s"(pend[0]), [e1] "s"(pend[1]), [e2] "s"(pend[2]), [e3] "s"(pend[3]), [e4] "s"(pend[4]),
+              [e5] "s"(pend[5]), [a0] "v"(adjv[0]), [a1] "v"(adjv[1]), [a2] "v"(adjv[2]), [a3] "v"(adjv[3]), [a4] "v"(adjv[4]),
+              [a5] "v"(adjv[5]), [a6] "v"(adjv[6]));
+        // lanes past the end hold a point no leaf can reach
+        return f < M ? a.pts[f + ad] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+    };
+    const float4 q0 = load_chunk(0);
+    float4 q1 = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+    if (M > (uint32_t)kWave) q1 = load_chunk(kWave);
+
+    const uint32_t key = a.leaf_key[li];
+    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs0 = div_by_ell(off4.x + cx, a.ell, a.inv_ell), ys0 = div_by_ell(off4.y + cy, a.ell, a.inv_ell),
+                zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
+    float A = a.alpha[li], B = a.beta[li];
+    L.acc_k[lane] = 0.0;
+    L.acc_y[lane] = 0.0;
+
+    // bounding box of the tile's leaf centres: as in bgk_predict_fuse_v5
+    float lox, loy, loz, hix, hiy, hiz;
+    const uint32_t key_first = __builtin_amdgcn_readlane(key, 0), key_last = __builtin_amdgcn_readlane(key, 63);
+    if (nl == (uint32_t)kWave && (key_last & 63u) == 0u && key_first == key_last + 63u &&
+        __ballot((key >> 16) + 1u != a.depth) == 0ull) {
+        lox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 63));
+        loy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 63));
+        loz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 63));
+        hix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs0), 0));
+        hiy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ys0), 0));
+        hiz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zs0), 0));
+    } else {
+        lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);  // inactive lanes hold leaf 0's position
+        hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
+    }
+    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
+
+    uint32_t ncand = 0;
+    auto stage = [&](const float4 &p) {
+        const float ex = fmaxf(fmaxf(lox - p.x, p.x - hix), 0.0f);
+        const float ey = fmaxf(fmaxf(loy - p.y, p.y - hiy), 0.0f);
+        const float ez = fmaxf(fmaxf(loz - p.z, p.z - hiz), 0.0f);
+        // as in v5: at or beyond the hit threshold (plus slack for the rounding of this sum) from the box of the leaf
+        // centres no leaf can hit; the filler points of lanes past the end fail it too
+        const bool keep = (ex * ex + ey * ey + ez * ez) < 0.96780f;
+        const unsigned long long m = __ballot(keep);
+        const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (keep) L.cand[slot] = p;
+        ncand += (uint32_t)__popcll(m);
+    };
+
+    const float hit_t = __uint_as_float(kHitTBits);
+    const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
+    const uint32_t acc_base = (uint32_t)(uintptr_t)&L.acc_k[0];
+    const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRingR - 4 * kWave);
+    uint32_t tailb = ring_base;  // LDS byte address of the ring's first free entry
+
+    // C: lane evaluates ring entry i and adds {k, k * y} to the leaf's accumulators
+    auto c_eval = [&](uint32_t i) {
+        const uint2 e = L.ring[i];
+        const float y = *(const float *)((const char *)&L.cand[0] + ((e.y & 0x3F0u) + 12u));
+        const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(e.x)), a.sf2);
+        const double kd = (double)kv, yd = (double)(kv * y);
+        const uint32_t ad = acc_base + (e.y >> 10);
+        asm volatile("ds_add_f64 %0, %1\n"
+                     "ds_add_f64 %0, %2 offset:512\n"
+                     :
+                     : "v"(ad), "v"(kd), "v"(yd)
+                     : "memory");
+    };
+
+    uint32_t cb = 0;  // flat index of the next chunk of training points
+    for (;;) {
+        // A: stage chunks while the worst case still fits the 64-entry candidate list
+        while (cb < M) {
+            const uint32_t n = min(M - cb, (uint32_t)kWave);
+            if (ncand + n > (uint32_t)kCand5) break;
+            if (cb == 0u) stage(q0);
+            else if (cb == (uint32_t)kWave) stage(q1);
+            else stage(load_chunk(cb));
+            cb += kWave;
+        }
+        // pad the list to a multiple of four with points no leaf can reach (the constant is made here: kept live across
+        // the rounds it costs four VGPRs, i.e. a spill at 64)
+        if (lane < 4u) {
+            float big;
+            asm volatile("v_mov_b32 %0, 0x5e268890" : "=v"(big));
+            L.cand[ncand + lane] = make_float4(big, big, big, 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
+        uint32_t g = 0;
+        while (g < ngroup) {
+            // ---- B: test + push (assembly, four candidates per trip; see LA3DM_B_HEAD / _TAIL above) ----
+            uint32_t idx = (lane << 13) | (g << 6);  // candidate 4 g in bits 4-9
+            for (uint32_t left = ngroup - g; left != 0u; --left) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
+                float a0, a1, tb2, tc, tr;
+                uint32_t st;
+                asm volatile(LA3DM_B_HEAD("%[a0]", "%[x0]", "%[y0]") LA3DM_B_TAIL("%[a0]", "%[z0]")
+                             LA3DM_B_HEAD("%[a1]", "%[x1]", "%[y1]") LA3DM_RB_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z1]")
+                             LA3DM_B_HEAD("%[a0]", "%[x2]", "%[y2]") LA3DM_RB_PUSH("%[a1]") LA3DM_B_TAIL("%[a0]", "%[z2]")
+                             LA3DM_B_HEAD("%[a1]", "%[x3]", "%[y3]") LA3DM_RB_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z3]")
+                             "s_nop 1\n" LA3DM_RB_PUSH("%[a1]")
+                             : [idx] "+v"(idx), [tail] "+s"(tailb), [a0] "=&v"(a0), [a1] "=&v"(a1), [tb] "=&v"(tb2), [tc] "=&v"(tc),
+                               [tr] "=&v"(tr), [st] "=&s"(st)
+                             : [xs] "v"(xs), [ys] "v"(ys), [zs] "v"(zs), [T] "s"(hit_t), [x0] "v"(t[0].x), [y0] "v"(t[0].y),
+                               [z0] "v"(t[0].z), [x1] "v"(t[1].x), [y1] "v"(t[1].y), [z1] "v"(t[1].z), [x2] "v"(t[2].x),
+                               [y2] "v"(t[2].y), [z2] "v"(t[2].z), [x3] "v"(t[3].x), [y3] "v"(t[3].y), [z3] "v"(t[3].z)
+                             : "vcc", "scc", "memory");
+                ++g;
+                if (tailb > tail_cap) break;
+            }
+            if (tailb > tail_cap) {
+                // ---- C: the full batches; the remainder moves to the front of the ring ----
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t tail = (tailb - ring_base) >> 3;
+                const uint32_t nfull = tail & ~63u, rem = tail & 63u;
+                if (!(a.flags & 0x100u))  // 0x100: profiling ablation
+                    for (uint32_t p = 0; p < nfull; p += kWave) c_eval(p + lane);
+                uint2 e = make_uint2(0u, 0u);
+                if (lane < rem) e = L.ring[nfull + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < rem) L.ring[lane] = e;
+                tailb = ring_base + 8u * rem;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // the ring's entries name their candidate by its slot in L.cand (the label is read from there): everything
+        // is evaluated before the next round of candidates overwrites the list — the tile's last batch, or the last
+        // batch of a round of a tile with more than 64 candidates, is the only one that may be partly filled
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const uint32_t tail = (tailb - ring_base) >> 3;
+            if (!(a.flags & 0x100u))
+                for (uint32_t p = 0; p < tail; p += kWave)
+                    if (p + lane < tail) c_eval(p + lane);
+            tailb = ring_base;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        ncand = 0;
+        if (cb >= M) break;
+    }
+
+    if (active) {
+        const double K = L.acc_k[lane], Y = L.acc_y[lane];
+        const bool updated = K > 0.0 || (a.flags & 1u) != 0u;  // flag 1: insert_training_data, update() runs unconditionally
+        uint32_t lw = li;
+        asm volatile("" : "+v"(lw));
+        if (updated) {
+            A = (float)((double)A + Y);
+            B = (float)((double)B + (K - Y));
             a.alpha[lw] = A;
             a.beta[lw] = B;
             a.state[lw] = (uint8_t)(classify(A, B, a) | 0x80u);

@@ -21,7 +21,8 @@ struct la3dm_ctx {
     uint32_t lut_count = 0;
     std::string err;
     int n_devmaps = 0;     // live la3dm_devmap objects that point at this context (la3dm_destroy refuses while > 0)
-    int opt_variant = 0;   // unused (one BGK kernel is built)
+    int opt_bgk_sum = 0;   // BGK accumulate mode: 0 = the reference's fp32 summation order (bgk_predict_fuse_v5, bit-identical to the
+                           // CPU restatement), 1 = order-free double accumulators (bgk_predict_fuse_r, |dp| <= ~2e-7)
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
     int opt_time_kernel = 0;
@@ -33,7 +34,7 @@ struct la3dm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
-    Arena pts_scaled, nbr_range;
+    Arena pts_scaled, nbr_range, blk_desc;
     Arena gp_loff, gp_totals, gp_order, gp_L, gp_alpha, gp_v;
     Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask;
     Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;

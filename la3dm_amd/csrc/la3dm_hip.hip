@@ -244,7 +244,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask,
-                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
+                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->blk_desc, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
@@ -264,8 +264,9 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->err = std::string("la3dm_set_option: ") + name + " must be " + allowed;
         return LA3DM_ERR_ARG;
     };
-    if (!strcmp(name, "bgk_variant")) {  // accepted and ignored: one implementation is built
-        ctx->opt_variant = value;
+    if (!strcmp(name, "bgk_sum")) {  // 0 = the reference's fp32 summation order, 1 = order-free double accumulators
+        if (value < 0 || value > 1) return bad_value("0 or 1");
+        ctx->opt_bgk_sum = value;
         return LA3DM_OK;
     }
     if (!strcmp(name, "fast_trig")) {
@@ -334,12 +335,18 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     if (rc != LA3DM_OK) return rc;
     rc = arena_reserve(ctx, ctx->nbr_range, sizeof(uint2) * 7 * (size_t)s->n_test_blk);
     if (rc != LA3DM_OK) return rc;
+    const bool sum_f64 = ctx->opt_bgk_sum == 1;
+    if (sum_f64) {
+        rc = arena_reserve(ctx, ctx->blk_desc, sizeof(uint32_t) * 16 * (size_t)s->n_test_blk);
+        if (rc != LA3DM_OK) return rc;
+    }
     {
         const uint32_t n_nbr = 7u * s->n_test_blk;
         const uint32_t n_thr = s->n_train_pts > n_nbr ? s->n_train_pts : n_nbr;
         dim3 g((n_thr + 255) / 256), b(256);
         hipLaunchKernelGGL(bgk_prepare, g, b, 0, stream, (const float4 *)s->train_xyzy, (float4 *)ctx->pts_scaled.ptr,
-                           s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, (uint2 *)ctx->nbr_range.ptr, n_nbr);
+                           s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, (uint2 *)ctx->nbr_range.ptr, n_nbr,
+                           sum_f64 ? (uint32_t *)ctx->blk_desc.ptr : (uint32_t *)nullptr);
     }
 
     // 2. predict + fuse
@@ -359,6 +366,7 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.state = s->state;
     a.lut = ctx->d_lut;
     a.nbr_range = (const uint2 *)ctx->nbr_range.ptr;
+    a.blk_desc = (const uint32_t *)ctx->blk_desc.ptr;
     a.n_test_blk = s->n_test_blk;
     a.tpb_shift = tpb_shift;
     a.n_tasks = s->n_test_blk << tpb_shift;
@@ -389,7 +397,11 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
     default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, 0, stream, a); break;    \
     }
-    {
+    if (sum_f64) {
+        grid = dim3(a.n_tasks);
+        block = dim3(kWave);
+        LAUNCH_BGK(bgk_predict_fuse_r)
+    } else {
         const int w = ctx->opt_waves;
         grid = dim3((a.n_tasks + w - 1) / w);
         block = dim3(w * kWave);
