@@ -44,6 +44,8 @@ struct BgkArgs {
     const float4 *lut;          // voxel LUT, depth-major, w unused
     const uint2 *nbr_range;     // [n_test_blk * 7] {first point, count} of each neighbour model (resolved by the prescale launch)
     const uint32_t *blk_desc;   // [n_test_blk * 16] flat view of the 7 neighbour ranges for bgk_predict_fuse_r (see bgk_prepare)
+    const uint32_t *label_seq;  // == seq when this scan has a label other than 0 / 1 (written by bgk_prepare)
+    uint32_t seq;               // number of this scan
     uint32_t n_test_blk;
     uint32_t tpb_shift;         // log2(tiles per test block)
     uint32_t n_tasks;           // n_test_blk << tpb_shift
@@ -110,32 +112,53 @@ __device__ __forceinline__ void sincos_0_2pi(float t, float &s, float &c) {
 // This is what the oracle's cr_sinf/cr_cosf compute (double libm rounded to float).
 // f64 FMA runs at half the f32 rate on gfx950 (78.6 TF); ~20 f64 ops per pair.
 // ---------------------------------------------------------------------------
+// v_fma_f64 with the addend (a constant) in an SGPR pair: the compiler's own choice for a Horner chain on constants is
+// v_fmac_f64 + a v_mov_b64 of the constant into the accumulator per step (10 extra 4-cycle instructions per sin/cos
+// pair), and 14 constants in VGPR pairs do not fit the 64-VGPR budget of 8 waves per SIMD.
+__device__ __forceinline__ double fma64_sc(double a, double b, double c_const) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_const));
+    return r;
+}
+__device__ __forceinline__ double fma64_sb(double a, double b_const, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_const), "v"(c));
+    return r;
+}
 __device__ __forceinline__ void sincos_cr(float t, float &s, float &c) {
-    const float kf = __builtin_rintf(t * 0.636619772f);
+    // quadrant by the magic-number trick: the low mantissa bits of u hold q = rint(t * 2 / pi) (0 <= q <= 4)
+    const float u = __builtin_fmaf(t, 0.636619772f, 12582912.0f);
+    const float kf = u - 12582912.0f;
     const double k = (double)kf;
     const double PIO2_HI = 1.57079632673412561417e+00;  // first 33 bits of pi/2
     const double PIO2_LO = 6.07710050650619224932e-11;  // pi/2 - PIO2_HI
-    double y = __builtin_fma(-k, PIO2_HI, (double)t);   // exact
-    y = __builtin_fma(-k, PIO2_LO, y);
+    double y = fma64_sb(k, -PIO2_HI, (double)t);        // exact
+    y = fma64_sb(k, -PIO2_LO, y);
     const double z = y * y;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-    const double sy = __builtin_fma(z * y, ps, y);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
-    const double cy = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    // the two Horner chains alternate: a dependent f64 pair back to back costs a wait state
+    double ps = fma64_sc(z, __builtin_bit_cast(double, 0x3de5d93a5acfd57cull) /* 1.58969099521155010221e-10 */, -2.50507602534068634195e-08);
+    double pc = fma64_sc(z, __builtin_bit_cast(double, 0xbda8fae9be8838d4ull) /* -1.13596475577881948265e-11 */, 2.08757232129817482790e-09);
+    const double zy = z * y;
+    const double zz = z * z;
+    ps = fma64_sc(z, ps, 2.75573137070700676789e-06);
+    pc = fma64_sc(z, pc, -2.75573143513906633035e-07);
+    ps = fma64_sc(z, ps, -1.98412698298579493134e-04);
+    pc = fma64_sc(z, pc, 2.48015872894767294178e-05);
+    ps = fma64_sc(z, ps, 8.33333333332248946124e-03);
+    pc = fma64_sc(z, pc, -1.38888888888741095749e-03);
+    const double hz = __builtin_fma(z, -0.5, 1.0);
+    ps = fma64_sc(z, ps, -1.66666666666666324348e-01);
+    pc = fma64_sc(z, pc, 4.16666666666666019037e-02);
+    const double sy = __builtin_fma(zy, ps, y);
+    const double cy = __builtin_fma(zz, pc, hz);
     const float sf = (float)sy, cf = (float)cy;
-    const int q = (int)kf;
-    const float ss = (q & 1) ? cf : sf;
-    const float cc = (q & 1) ? sf : cf;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
+    // sin(y + q pi/2), cos(y + q pi/2): swap on bit 0 of q, sin negative for q in {2, 3}, cos negative for q in {1, 2}
+    const uint32_t q = __float_as_uint(u);
+    const uint32_t q31 = q << 31, q30 = q << 30;       // bit 0 / bit 1 of q at the sign position
+    const bool odd = (int32_t)q31 < 0;
+    const uint32_t ss = __float_as_uint(odd ? cf : sf), cc = __float_as_uint(odd ? sf : cf);
+    s = __uint_as_float(ss ^ (q30 & 0x80000000u));
+    c = __uint_as_float(cc ^ ((q30 ^ q31) & 0x80000000u));
 }
 
 // correctly rounded x / d for a compile-time constant d (|x| far from the subnormal range):
@@ -193,7 +216,8 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
 // when neighbour b has a trained model, word 15 = 0.
 __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell,
                             const int32_t *__restrict__ nbr, const uint32_t *__restrict__ train_off,
-                            uint2 *__restrict__ nbr_range, uint32_t n_nbr, uint32_t *__restrict__ blk_desc) {
+                            uint2 *__restrict__ nbr_range, uint32_t n_nbr, uint32_t *__restrict__ blk_desc,
+                            uint32_t *__restrict__ label_seq, uint32_t seq) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blk_desc && i < n_nbr / 7u) {
         uint32_t d[16];
@@ -222,6 +246,7 @@ __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ 
     if (i < n) {
         const float4 p = in[i];
         out[i] = make_float4(p.x / ell, p.y / ell, p.z / ell, p.w);
+        if (label_seq && !(p.w == 0.0f || p.w == 1.0f)) *label_seq = seq;  // (same value from every writer)
     }
     if (i < n_nbr) {
         const int tb = nbr[i];
@@ -272,12 +297,15 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // correctly rounded sqrt for x in {0} U [2^-100, 2^100]: hardware estimate (<= 1 ulp) plus the
 // standard one-ulp residual fix-up (no denormal pre-scaling: d2 is 0 or >= ~1e-15 here).
 __device__ __forceinline__ float sqrt_cr(float x) {
+    // s = hardware estimate (within 1 ulp); sm / sp its neighbours.  RN(sqrt x) is sm when sm * s >= x, sp when
+    // sp * s < x, else s: with em = sm * s - x and ep = sp * s - x (one FMA each; an exact zero comes out as +0) that is
+    // bits(sm) + [em < 0] + [ep < 0], the two flags being the sign bits — no compare / select pairs (each needs a wait
+    // state on gfx940).  x = 0: s = 0, sm is a NaN pattern with the sign set (em = NaN keeps it), ep = +0: result 0.
     const float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
-    const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
-    float r = em <= 0.0f ? sm : s;
-    r = ep > 0.0f ? sp : r;
-    return r;
+    const uint32_t smb = __float_as_uint(s) - 1u;
+    const float sm = __uint_as_float(smb), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float em = __builtin_fmaf(sm, s, -x), ep = __builtin_fmaf(sp, s, -x);
+    return __uint_as_float(smb + (__float_as_uint(em) >> 31) + (__float_as_uint(ep) >> 31));
 }
 
 // covSparse elementwise (bgkinference.h:115-125) with the two constant divisions done by
@@ -292,7 +320,7 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     const float a = div_const((2.0f + c) * (1.0f - r), 3.0f, 0.333333343f);
     const float b = div_const(s, 2.0f * 3.1415926f, 0.159154952f);
     float k = (a + b) * sf2;
-    if (kClamp && k < 0.0f) k = 0.0f;
+    if (kClamp) k = fmaxf(k, 0.0f);  // k is never NaN here; (-0 -> +0 adds the same to every sum)
     return k;
 }
 
@@ -723,22 +751,50 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
 // LDS per wave: 68 candidates (1 088 B) + 2 x 64 double accumulators (1 024 B) + 376-entry ring (3 008 B) = 5 120 B.
 // ---------------------------------------------------------------------------
 constexpr int kRingR = 376;
+constexpr int kCandPad = kCand5 + 4;
 struct __attribute__((aligned(16))) WaveLdsR {
-    float4 cand[kCand5 + 4];
-    double acc_k[kWave];
-    double acc_y[kWave];
-    uint2 ring[kRingR];  // {d2, (lane << 13) | (candidate << 4)}
+    float cx[kCandPad], cy[kCandPad], cz[kCandPad], cw[kCandPad];  // candidates, one array per component (B reads four at a time)
+    double acc0[kWave];  // binary labels: sum(k) over the label-0 pairs;  any labels: sum(k)
+    double acc1[kWave];  // binary labels: sum(k) over the label-1 pairs;  any labels: sum(k * y)
+    uint2 ring[kRingR];  // {d2, (lane << 13) | (candidate << 2)}
 };
-#define LA3DM_RB_PUSH(A)                                    \
+// B, four candidates per trip, PACKED fp32: a VALU instruction occupies the SIMD for ~4 cycles whatever it is
+// (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0 in this kernel), so v_pk_add / v_pk_mul_f32 — two candidates per
+// instruction — halve the cost of the distance: 8 packed instructions per PAIR of candidates
+//   (dx, dy, dz)(A,B) = (X, Y, Z)(A,B) - (xs, ys, zs);  d2 = dx*dx + (dy*dy + dz*dz)   (bgkinference.h:88-93, same association)
+// against 8 per candidate.  The leaf's coordinates are broadcast to both halves by op_sel; the two pairs of a trip
+// alternate so that no packed instruction reads the result of the one before it (one wait state).  Registers are fixed
+// (v40-v63): the halves of a packed result feed v_cmp and ds_write separately.
+//   v[52:55] X of the four candidates, v[56:59] Y, v[60:63] Z;  pair 0 -> d2 in v40, v41;  pair 1 -> v46, v47
+// Push of one candidate (5 VALU + 4 SALU + 1 LDS): hit mask in vcc; the scalar popcount and the next entry word sit
+// between the v_cmp and the first VALU reader of vcc (gfx940: two wait states); hit lanes write {d2, entry word} at
+// ring[tail + rank] under exec = hit mask.
+#define LA3DM_RP_LOAD                                                                     \
+    "ds_read_b128 v[52:55], %[ca]\n"                                                     \
+    "ds_read_b128 v[56:59], %[ca] offset:272\n"                                          \
+    "ds_read_b128 v[60:63], %[ca] offset:544\n"                                          \
+    "s_waitcnt lgkmcnt(0)\n"
+#define LA3DM_RP_SUB(DX, DY, DZ, X, Y, Z)                                                 \
+    "v_pk_add_f32 " DX ", " X ", %[xy] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"      \
+    "v_pk_add_f32 " DY ", " Y ", %[xy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n" \
+    "v_pk_add_f32 " DZ ", " Z ", %[zz] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define LA3DM_RP_SQ(DX, DY, DZ)                                                           \
+    "v_pk_mul_f32 " DX ", " DX ", " DX "\n"                                              \
+    "v_pk_mul_f32 " DY ", " DY ", " DY "\n"                                              \
+    "v_pk_mul_f32 " DZ ", " DZ ", " DZ "\n"
+#define LA3DM_RP_PUSH(D, I, IN)                             \
+    "v_cmp_gt_f32 vcc, %[T], " D "\n"                       \
+    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
+    "v_add_u32 " IN ", 4, " I "\n"                          \
     "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
     "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
     "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
     "s_mov_b64 exec, vcc\n"                                 \
-    "ds_write2_b32 %[tr], " A ", %[idx] offset1:1\n"        \
+    "ds_write2_b32 %[tr], " D ", " I " offset1:1\n"         \
     "s_mov_b64 exec, -1\n"                                  \
-    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
-    "v_add_u32 %[idx], 16, %[idx]\n"                        \
     "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
+
+typedef float la3dm_v2f __attribute__((ext_vector_type(2)));
 
 template <int kTrig>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_r(BgkArgs a) {
@@ -760,6 +816,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
     const bool active = lane < nl;
     const uint32_t li = l0 + (active ? lane : 0);
+    // every label of this scan is 0 or 1 (bgk_prepare stamps label_seq with the scan's number when it meets another
+    // value): a pair then adds k to ONE accumulator, chosen by its label
+    const bool binary = a.label_seq[0] != a.seq;
 
     // flat view of the 7 neighbour ranges
     const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
@@ -813,8 +872,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const float xs0 = div_by_ell(off4.x + cx, a.ell, a.inv_ell), ys0 = div_by_ell(off4.y + cy, a.ell, a.inv_ell),
                 zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
     float A = a.alpha[li], B = a.beta[li];
-    L.acc_k[lane] = 0.0;
-    L.acc_y[lane] = 0.0;
+    L.acc0[lane] = 0.0;
+    L.acc1[lane] = 0.0;
 
     // bounding box of the tile's leaf centres: as in bgk_predict_fuse_v5
     float lox, loy, loz, hix, hiy, hiz;
@@ -831,7 +890,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         lox = wave_min_dpp(xs0), loy = wave_min_dpp(ys0), loz = wave_min_dpp(zs0);  // inactive lanes hold leaf 0's position
         hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
     }
-    const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
+    // the leaf's coordinates as packed operands: (xs, ys) and (zs, -); NaN never matches (inactive lanes)
+    la3dm_v2f xy, zz;
+    xy.x = active ? xs0 : __builtin_nanf("");
+    xy.y = ys0;
+    zz.x = zs0;
+    zz.y = 0.0f;
 
     uint32_t ncand = 0;
     auto stage = [&](const float4 &p) {
@@ -843,28 +907,43 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const bool keep = (ex * ex + ey * ey + ez * ez) < 0.96780f;
         const unsigned long long m = __ballot(keep);
         const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (keep) L.cand[slot] = p;
+        if (keep) {
+            L.cx[slot] = p.x;
+            L.cy[slot] = p.y;
+            L.cz[slot] = p.z;
+            L.cw[slot] = p.w;
+        }
         ncand += (uint32_t)__popcll(m);
     };
 
     const float hit_t = __uint_as_float(kHitTBits);
     const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
-    const uint32_t acc_base = (uint32_t)(uintptr_t)&L.acc_k[0];
+    const uint32_t acc_base = (uint32_t)(uintptr_t)&L.acc0[0];
+    const uint32_t cw_base = (uint32_t)(uintptr_t)&L.cw[0];
     const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRingR - 4 * kWave);
     uint32_t tailb = ring_base;  // LDS byte address of the ring's first free entry
 
-    // C: lane evaluates ring entry i and adds {k, k * y} to the leaf's accumulators
+    // C: lane evaluates ring entry i and adds k (and k * y) to the leaf's accumulators
     auto c_eval = [&](uint32_t i) {
         const uint2 e = L.ring[i];
-        const float y = *(const float *)((const char *)&L.cand[0] + ((e.y & 0x3F0u) + 12u));
+        float y;
+        asm volatile("ds_read_b32 %0, %1\n" : "=v"(y) : "v"(cw_base + (e.y & 0xFCu)) : "memory");
         const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(e.x)), a.sf2);
-        const double kd = (double)kv, yd = (double)(kv * y);
-        const uint32_t ad = acc_base + (e.y >> 10);
-        asm volatile("ds_add_f64 %0, %1\n"
-                     "ds_add_f64 %0, %2 offset:512\n"
-                     :
-                     : "v"(ad), "v"(kd), "v"(yd)
-                     : "memory");
+        const double kd = (double)kv;
+        uint32_t ad = acc_base + (e.y >> 10);
+        if (a.flags & 0x800u) ad = acc_base + 8u * lane;  // profiling ablation: conflict-free accumulate (results invalid)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (binary) {
+            ad += (__float_as_uint(y) >> 20) & 0x200u;  // 1.0f -> acc1 (512 bytes up), 0.0f -> acc0
+            asm volatile("ds_add_f64 %0, %1\n" : : "v"(ad), "v"(kd) : "memory");
+        } else {
+            const double yd = (double)(kv * y);
+            asm volatile("ds_add_f64 %0, %1\n"
+                         "ds_add_f64 %0, %2 offset:512\n"
+                         :
+                         : "v"(ad), "v"(kd), "v"(yd)
+                         : "memory");
+        }
     };
 
     uint32_t cb = 0;  // flat index of the next chunk of training points
@@ -878,38 +957,44 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             else stage(load_chunk(cb));
             cb += kWave;
         }
-        // pad the list to a multiple of four with points no leaf can reach (the constant is made here: kept live across
-        // the rounds it costs four VGPRs, i.e. a spill at 64)
+        // pad the list to a multiple of four with points no leaf can reach
         if (lane < 4u) {
             float big;
             asm volatile("v_mov_b32 %0, 0x5e268890" : "=v"(big));
-            L.cand[ncand + lane] = make_float4(big, big, big, 0.0f);
+            L.cx[ncand + lane] = big;
+            L.cy[ncand + lane] = big;
+            L.cz[ncand + lane] = big;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
         uint32_t g = 0;
         while (g < ngroup) {
-            // ---- B: test + push (assembly, four candidates per trip; see LA3DM_B_HEAD / _TAIL above) ----
-            uint32_t idx = (lane << 13) | (g << 6);  // candidate 4 g in bits 4-9
+            // ---- B: test + push ----
+            uint32_t i0 = (lane << 13) | (g << 4);  // entry word of candidate 4 g: candidate * 4 in bits 2-7
+            uint32_t ca = 16u * g;                  // LDS byte address of cx[4 g] (the struct sits at LDS address 0)
             for (uint32_t left = ngroup - g; left != 0u; --left) {
-                float4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
-                float a0, a1, tb2, tc, tr;
-                uint32_t st;
-                asm volatile(LA3DM_B_HEAD("%[a0]", "%[x0]", "%[y0]") LA3DM_B_TAIL("%[a0]", "%[z0]")
-                             LA3DM_B_HEAD("%[a1]", "%[x1]", "%[y1]") LA3DM_RB_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z1]")
-                             LA3DM_B_HEAD("%[a0]", "%[x2]", "%[y2]") LA3DM_RB_PUSH("%[a1]") LA3DM_B_TAIL("%[a0]", "%[z2]")
-                             LA3DM_B_HEAD("%[a1]", "%[x3]", "%[y3]") LA3DM_RB_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z3]")
-                             "s_nop 1\n" LA3DM_RB_PUSH("%[a1]")
-                             : [idx] "+v"(idx), [tail] "+s"(tailb), [a0] "=&v"(a0), [a1] "=&v"(a1), [tb] "=&v"(tb2), [tc] "=&v"(tc),
-                               [tr] "=&v"(tr), [st] "=&s"(st)
-                             : [xs] "v"(xs), [ys] "v"(ys), [zs] "v"(zs), [T] "s"(hit_t), [x0] "v"(t[0].x), [y0] "v"(t[0].y),
-                               [z0] "v"(t[0].z), [x1] "v"(t[1].x), [y1] "v"(t[1].y), [z1] "v"(t[1].z), [x2] "v"(t[2].x),
-                               [y2] "v"(t[2].y), [z2] "v"(t[2].z), [x3] "v"(t[3].x), [y3] "v"(t[3].y), [z3] "v"(t[3].z)
-                             : "vcc", "scc", "memory");
+                uint32_t i1, st;
+                float tr;
+                asm volatile(LA3DM_RP_LOAD
+                             LA3DM_RP_SUB("v[40:41]", "v[42:43]", "v[44:45]", "v[52:53]", "v[56:57]", "v[60:61]")
+                             LA3DM_RP_SUB("v[46:47]", "v[48:49]", "v[50:51]", "v[54:55]", "v[58:59]", "v[62:63]")
+                             LA3DM_RP_SQ("v[40:41]", "v[42:43]", "v[44:45]")
+                             LA3DM_RP_SQ("v[46:47]", "v[48:49]", "v[50:51]")
+                             "v_pk_add_f32 v[42:43], v[42:43], v[44:45]\n"
+                             "v_pk_add_f32 v[48:49], v[48:49], v[50:51]\n"
+                             "s_nop 0\n"
+                             "v_pk_add_f32 v[40:41], v[40:41], v[42:43]\n"
+                             "v_pk_add_f32 v[46:47], v[46:47], v[48:49]\n"
+                             "s_nop 0\n"
+                             LA3DM_RP_PUSH("v40", "%[i0]", "%[i1]") LA3DM_RP_PUSH("v41", "%[i1]", "%[i0]")
+                             LA3DM_RP_PUSH("v46", "%[i0]", "%[i1]") LA3DM_RP_PUSH("v47", "%[i1]", "%[i0]")
+                             : [i0] "+v"(i0), [i1] "=&v"(i1), [tail] "+s"(tailb), [tr] "=&v"(tr), [st] "=&s"(st)
+                             : [xy] "v"(xy), [zz] "v"(zz), [T] "s"(hit_t), [ca] "v"(ca)
+                             : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+                               "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
                 ++g;
+                ca += 16u;
                 if (tailb > tail_cap) break;
             }
             if (tailb > tail_cap) {
@@ -930,7 +1015,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // the ring's entries name their candidate by its slot in L.cand (the label is read from there): everything
+        // the ring's entries name their candidate by its slot in the list (the label is read from there): everything
         // is evaluated before the next round of candidates overwrites the list — the tile's last batch, or the last
         // batch of a round of a tile with more than 64 candidates, is the only one that may be partly filled
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -949,7 +1034,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     }
 
     if (active) {
-        const double K = L.acc_k[lane], Y = L.acc_y[lane];
+        const double s0 = L.acc0[lane], s1 = L.acc1[lane];
+        const double K = binary ? s0 + s1 : s0, Y = s1;
         const bool updated = K > 0.0 || (a.flags & 1u) != 0u;  // flag 1: insert_training_data, update() runs unconditionally
         uint32_t lw = li;
         asm volatile("" : "+v"(lw));

@@ -34,7 +34,8 @@ struct la3dm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
-    Arena pts_scaled, nbr_range, blk_desc;
+    Arena pts_scaled, nbr_range, blk_desc, label_seq;
+    uint32_t scan_seq = 0;  // la3dm_bgk_scan_device calls so far (BgkArgs::seq)
     Arena gp_loff, gp_totals, gp_order, gp_L, gp_alpha, gp_v;
     Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask;
     Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;

@@ -244,7 +244,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask,
-                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->blk_desc, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
+                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->blk_desc, &ctx->label_seq, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
@@ -280,7 +280,7 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         return LA3DM_OK;
     }
     if (!strcmp(name, "ablate")) {
-        if (value < 0 || value > 7) return bad_value("0..7");
+        if (value < 0 || value > 31) return bad_value("0..31");
         ctx->opt_ablate = value;
         return LA3DM_OK;
     }
@@ -339,6 +339,13 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     if (sum_f64) {
         rc = arena_reserve(ctx, ctx->blk_desc, sizeof(uint32_t) * 16 * (size_t)s->n_test_blk);
         if (rc != LA3DM_OK) return rc;
+        if (!ctx->label_seq.ptr) {
+            rc = arena_reserve(ctx, ctx->label_seq, sizeof(uint32_t));
+            if (rc != LA3DM_OK) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->label_seq.ptr, 0, sizeof(uint32_t), stream));
+            ctx->scan_seq = 0;
+        }
+        if (++ctx->scan_seq == 0u) ctx->scan_seq = 1u;  // 0 is the cleared state
     }
     {
         const uint32_t n_nbr = 7u * s->n_test_blk;
@@ -346,7 +353,8 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
         dim3 g((n_thr + 255) / 256), b(256);
         hipLaunchKernelGGL(bgk_prepare, g, b, 0, stream, (const float4 *)s->train_xyzy, (float4 *)ctx->pts_scaled.ptr,
                            s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, (uint2 *)ctx->nbr_range.ptr, n_nbr,
-                           sum_f64 ? (uint32_t *)ctx->blk_desc.ptr : (uint32_t *)nullptr);
+                           sum_f64 ? (uint32_t *)ctx->blk_desc.ptr : (uint32_t *)nullptr,
+                           sum_f64 ? (uint32_t *)ctx->label_seq.ptr : (uint32_t *)nullptr, ctx->scan_seq);
     }
 
     // 2. predict + fuse
@@ -367,6 +375,8 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.lut = ctx->d_lut;
     a.nbr_range = (const uint2 *)ctx->nbr_range.ptr;
     a.blk_desc = (const uint32_t *)ctx->blk_desc.ptr;
+    a.label_seq = (const uint32_t *)ctx->label_seq.ptr;
+    a.seq = ctx->scan_seq;
     a.n_test_blk = s->n_test_blk;
     a.tpb_shift = tpb_shift;
     a.n_tasks = s->n_test_blk << tpb_shift;

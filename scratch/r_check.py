@@ -53,7 +53,7 @@ if __name__ == "__main__":
     compare("sim_structured_1 d4", xyz, origin, 0.1, 4, fr=0.5, mr=8.0)
     xyz, origin = la3dm_amd.synthetic_scan(200000, seed=1234)
     m, pk = compare("synthetic 200k d3", xyz, origin, 0.1, 3, reps=10)
-    for ab in (1, 2):
+    for ab in (1, 2, 8, 16):
         _, t = run(m, pk, 1, 5, opts=(("ablate", ab),))
         print(f"  f64-sum ablate {ab}: {np.median(t):.4f} ms")
     m.set_option("ablate", 0)

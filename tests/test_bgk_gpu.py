@@ -107,6 +107,17 @@ def test_hit_threshold_and_division_by_ell_exhaustive(built):
         assert m.diag_sweep(7, 2.0 ** -10, 2.0 ** 17) == 0, ell
 
 
+def test_sqrt_and_sincos_correctly_rounded_exhaustive(built):
+    """the evaluation phase's own square root (hardware estimate + sign-bit fix-up, no compare / select) against the
+    IEEE sqrtf for 0 and EVERY fp32 d2 in [2^-100, 4], and its sin / cos (f64 minimax kernels, quadrant by the magic-number trick,
+    signs by xor) against the double library functions rounded once, for EVERY fp32 t in [0, 2 pi]"""
+    import la3dm_amd
+    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+    assert m.diag_sweep(2, 0.0, 0.0) == 0
+    assert m.diag_sweep(2, 2.0 ** -100, 4.0) == 0       # (d2 is 0 or >= ~1e-15 in the kernel: no denormal pre-scaling)
+    assert m.diag_sweep(3, 0.0, 6.2831855) == 0
+
+
 @pytest.mark.parametrize("depth", [3, 4])
 def test_config1_sim_structured_scan1(built, depth):
     """BASELINE config 1: sim_structured scan 1, bgkoctomap.yaml, max_range 8."""
