@@ -21,8 +21,9 @@ struct la3dm_ctx {
     uint32_t lut_count = 0;
     std::string err;
     int n_devmaps = 0;     // live la3dm_devmap objects that point at this context (la3dm_destroy refuses while > 0)
-    int opt_bgk_sum = 0;   // BGK accumulate mode: 0 = the reference's fp32 summation order (bgk_predict_fuse_v5, bit-identical to the
-                           // CPU restatement), 1 = order-free double accumulators (bgk_predict_fuse_r, |dp| <= ~2e-7)
+    int opt_bgk_sum = 1;   // BGK accumulate mode: 1 (default) = order-free double accumulators (bgk_predict_fuse_r: the correctly rounded
+                           // sums, |dp| <= ~4e-7 from the reference's fp32 chains), 0 = the reference's fp32 summation order
+                           // (bgk_predict_fuse_v5, bit-identical to the CPU restatement); env LA3DM_BGK_SUM sets the default
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
     int opt_time_kernel = 0;

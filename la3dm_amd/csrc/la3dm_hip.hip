@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -215,6 +216,9 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
         ctx->inv_ell = (eb & 0x7FFFFFu) != 0x7FFFFFu ? 1.0f / params->ell : 0.0f;
     }
     ctx->lut_count = params->lut_count;
+    if (const char *ev = getenv("LA3DM_BGK_SUM")) {  // default accumulate mode of new contexts (la3dm_set_option "bgk_sum" overrides)
+        if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_sum = ev[0] - '0';
+    }
     auto fail = [&](const char *what, hipError_t e) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(e);
         delete ctx;

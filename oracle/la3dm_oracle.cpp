@@ -291,6 +291,16 @@ extern "C" void orc_set_modes(int trig, int grid_sort) {
     g_orc_trig_mode = trig;
     g_orc_grid_sort_mode = grid_sort;
 }
+// Summation switch of the BGK update loop (variant 0), the counterpart of the device's order-free accumulate mode
+// (la3dm_set_option "bgk_sum" 1, bgk_kernels.h bgk_predict_fuse_r):
+//   0  the reference: fp32 running sums per neighbour in training-point order (bgkinference.h:76-78), one
+//      Occupancy::update per neighbour with kbar > 0 (bgkoctomap.cpp:314-335) — default, what every parity test uses;
+//   1  the same pairs and the same fp32 kernel values k and products k * y, summed in DOUBLE over all 7 neighbours, and
+//      alpha + sum(k y), beta + (sum(k) - sum(k y)) rounded to fp32 once; update() runs when sum(k) > 0 (k >= 0, so that
+//      is "some neighbour had kbar > 0").  A double sum of a few thousand fp32 terms does not depend on their order
+//      (up to 2^-53 relative), so this is the value the reference's fp32 chains approximate.
+int g_orc_sum_mode = 0;
+extern "C" void orc_set_sum_mode(int mode) { g_orc_sum_mode = mode; }
 
 namespace orc_eigen337 {
 static inline float from_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
@@ -382,6 +392,30 @@ void bgk_predict(float sf2, float ell, const float *xs, int M, const float *x, c
         }
         ybar[i] = yb;
         kbar[i] = kb;
+    }
+}
+
+// sum mode 1 (see orc_set_sum_mode): the same k and k * y, added to double accumulators
+void bgk_predict_acc(float sf2, float ell, const float *xs, int M, const float *x, const float *y, int N, double *ysum,
+                     double *ksum) {
+    std::vector<float> xsn((size_t)M * 3), xn((size_t)N * 3);
+    for (int i = 0; i < M * 3; ++i) xsn[i] = xs[i] / ell;
+    for (int i = 0; i < N * 3; ++i) xn[i] = x[i] / ell;
+    for (int i = 0; i < M; ++i) {
+        double yb = 0.0, kb = 0.0;
+        for (int j = 0; j < N; ++j) {
+            float dx = xn[3 * j + 0] - xsn[3 * i + 0];
+            float dy = xn[3 * j + 1] - xsn[3 * i + 1];
+            float dz = xn[3 * j + 2] - xsn[3 * i + 2];
+            float d2 = dx * dx + (dy * dy + dz * dz);
+            float r = sqrtf(d2);
+            float k = cov_sparse_elem(r, sf2);
+            float ky = k * y[j];
+            yb += (double)ky;
+            kb += (double)k;
+        }
+        ysum[i] += yb;
+        ksum[i] += kb;
     }
 }
 
@@ -869,6 +903,8 @@ void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr, boo
         extended_block_from_center(p, block->center,
                                    block_to_hash_key(p, block->center.x, block->center.y, block->center.z), eb);
         std::vector<float> bx, by, ybar(M), kbar(M);
+        const bool sum64 = g_orc_sum_mode == 1 && p.variant == 0;
+        std::vector<double> ysum(sum64 ? M : 0, 0.0), ksum(sum64 ? M : 0, 0.0);
         for (int k = 0; k < 7; ++k) {
             auto it = bgk_arr.find(eb[k]);
             if (it == bgk_arr.end()) continue;
@@ -902,6 +938,10 @@ void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr, boo
                 }
                 continue;
             }
+            if (sum64) {
+                bgk_predict_acc(p.sf2, p.ell, xs.data(), M, bx.data(), by.data(), N, ysum.data(), ksum.data());
+                continue;
+            }
             bgk_predict(p.sf2, p.ell, xs.data(), M, bx.data(), by.data(), N, ybar.data(), kbar.data());
             for (int j = 0; j < M; ++j) {
                 Node &node = block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF];
@@ -911,6 +951,18 @@ void insert_xy(Map &m, const std::vector<XY> &xy, const LData *ld = nullptr, boo
                 }
             }
         }
+        if (sum64)
+            for (int j = 0; j < M; ++j) {
+                Node &node = block->layer[leaf_keys[j] >> 16][leaf_keys[j] & 0xFFFF];
+                if (ksum[j] > 0.0 || ungated) {
+                    const float A1 = (float)((double)node.A + ysum[j]);
+                    const float B1 = (float)((double)node.B + (ksum[j] - ysum[j]));
+                    node.A = A1;
+                    node.B = B1;
+                    node_update(p, node, 0.0f, 0.0f);  // + 0 leaves A, B as they are; state and classified as in update()
+                    calls_ += 1;
+                }
+            }
     };
     // first occurrences: independent blocks, parallel like the reference's omp loop
 #ifdef _OPENMP

@@ -1,0 +1,178 @@
+"""The library's DEFAULT BGK accumulate mode (la3dm_set_option "bgk_sum" 1, bgk_kernels.h bgk_predict_fuse_r): every
+evaluated pair adds its fp32 kernel value k (and k * y) to double accumulators in LDS, alpha / beta are rounded once.
+Same pairs and the same k as the ordered kernel; only the reference's fp32 SUMMATION ORDER
+(include/bgkoctomap/bgkinference.h:76-78, src/bgkoctomap/bgkoctomap.cpp:314-335) is given up.
+
+Checked against two oracles on every BASELINE config the mode applies to:
+  * the restatement in ITS double-sum mode (oracle.set_sum_mode(1)): same leaf structure, same states and `classified`,
+    alpha / beta within ONE fp32 ulp (a double sum of fp32 terms depends on the order only in its last bit, which
+    survives the final rounding with probability ~2^-29) and >= 99.99 % bit-equal;
+  * the restatement in the reference's order (the default): same leaf structure, |dp| <= 1e-5 (the north-star
+    tolerance; observed <= 5e-7), states equal except where p sits within 1e-6 of a threshold.
+"""
+import numpy as np
+import pytest
+
+from conftest import pcd_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def _prob(lv):
+    a = lv["A"].astype(np.float64)
+    return a / (a + lv["B"])
+
+
+def _check(m, o64, o32, tag, params):
+    a, b, c = m.leaves(), o64.leaves(), o32.leaves()
+    for ref, name in ((b, "double-sum oracle"), (c, "reference-order oracle")):
+        assert a["block_key"].size == ref["block_key"].size, (tag, name)
+        assert (a["block_key"] == ref["block_key"]).all() and (a["node_key"] == ref["node_key"]).all(), (tag, name)
+        assert (a["classified"] == ref["classified"]).all(), (tag, name)
+    # against the double-sum restatement: one ulp, states identical
+    for k in ("A", "B"):
+        u = _ulps(a[k], b[k])
+        assert u.max() <= 1, (tag, k, int(u.max()))
+        assert (u == 0).mean() >= 0.9999, (tag, k, float((u == 0).mean()))
+    far = (a["state"] != b["state"])
+    if far.any():      # only where the 1-ulp difference straddles a threshold
+        p = _prob(a)[far]
+        d = np.minimum(np.abs(p - params["free_thresh"]), np.abs(p - params["occupied_thresh"]))
+        assert (d < 1e-6).all(), (tag, int(far.sum()))
+    # against the reference's summation order: the north-star tolerance
+    dp = np.abs(_prob(a) - _prob(c))
+    assert dp.max() <= 1e-5, (tag, float(dp.max()))
+    flips = a["state"] != c["state"]
+    if flips.any():
+        p = _prob(c)[flips]
+        d = np.minimum(np.abs(p - params["free_thresh"]), np.abs(p - params["occupied_thresh"]))
+        v = np.abs(c["A"][flips] * 0 + 1)   # (variance-threshold flips are not expected at these priors)
+        assert (d < 1e-6).all(), (tag, int(flips.sum()), v.size)
+    return float(dp.max())
+
+
+@pytest.fixture()
+def oracles():
+    from oracle import oracle as O
+    yield O
+    O.set_sum_mode(0)
+    O.set_sum_mode(0, omp=True)
+
+
+def _maps(la3dm_amd, O, params, omp=False):
+    m = la3dm_amd.BGKOctoMap(**params, device=0)
+    m.set_option("bgk_sum", 1)
+    assert m.is_device_resident()
+    return m, O.OracleMap(**params, omp=omp), O.OracleMap(**params, omp=omp)
+
+
+def _insert_both(O, o64, o32, omp, *args):
+    O.set_sum_mode(1, omp=omp)
+    o64.insert_pointcloud(*args)
+    O.set_sum_mode(0, omp=omp)
+    o32.insert_pointcloud(*args)
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_config0_sim_structured_scan1(built, oracles, depth):
+    import la3dm_amd
+    O = oracles
+    params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+    m, o64, o32 = _maps(la3dm_amd, O, params)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    _insert_both(O, o64, o32, False, xyz, origin, 0.1, 0.5, 8.0)
+    _check(m, o64, o32, f"configs[0] depth {depth}", params)
+
+
+def test_twelve_scans_and_fifteen_reinsertions(built, oracles):
+    """posterior accumulation, pruning and re-testing of collapsed parents in the default mode: the 12 sim_structured
+    scans fused, then scan 1 re-inserted 15 times (sim_structured_long_term) — the differences do not accumulate past
+    the tolerance"""
+    import la3dm_amd
+    O = oracles
+    params = dict(la3dm_amd.BGK_YAML)
+    m, o64, o32 = _maps(la3dm_amd, O, params)
+    for i in range(1, 13):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        _insert_both(O, o64, o32, False, xyz, origin, 0.1, 0.5, 8.0)
+    _check(m, o64, o32, "12 scans", params)
+    m, o64, o32 = _maps(la3dm_amd, O, params)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    for _ in range(15):
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        _insert_both(O, o64, o32, False, xyz, origin, 0.1, 0.5, 8.0)
+    _check(m, o64, o32, "15 re-insertions", params)
+
+
+@pytest.mark.parametrize("depth,inserts", [(3, 2), (4, 1)])
+def test_config1_bgk_200k_rays(built, oracles, depth, inserts):
+    """configs[1] at full size; the second insert at depth 3 meets the pruned map"""
+    import la3dm_amd
+    O = oracles
+    params = dict(la3dm_amd.BGK_YAML, resolution=0.1, block_depth=depth)
+    xyz, origin = la3dm_amd.synthetic_scan(200000)
+    m, o64, o32 = _maps(la3dm_amd, O, params, omp=True)
+    for _ in range(inserts):
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, -1.0)
+        _insert_both(O, o64, o32, True, xyz, origin, 0.1, 0.5, -1.0)
+    assert m.leaves()["A"].size > 1_500_000
+    _check(m, o64, o32, f"configs[1] depth {depth}", params)
+
+
+def test_config4_scan_1m_rays(built, oracles):
+    """configs[4]'s scan (1 M rays, 0.05 m) on one GPU, default mode, against both restatements (OpenMP build)"""
+    import la3dm_amd
+    O = oracles
+    params = dict(la3dm_amd.BGK_YAML, resolution=0.05, block_depth=3)
+    xyz, origin = la3dm_amd.synthetic_scan(1000000)
+    m, o64, o32 = _maps(la3dm_amd, O, params, omp=True)
+    m.insert_pointcloud(xyz, origin, 0.05, 0.5, -1.0)
+    _insert_both(O, o64, o32, True, xyz, origin, 0.05, 0.5, -1.0)
+    assert m.leaves()["A"].size > 5_000_000
+    _check(m, o64, o32, "configs[4] scan", params)
+
+
+def test_training_data_with_real_valued_labels(built, oracles):
+    """insert_training_data (bgkoctomap.cpp:82-212) with labels that are not 0 / 1: the kernel falls back from one
+    accumulator per label to sum(k), sum(k * y), and update() runs for every test voxel (ungated)"""
+    import la3dm_amd
+    O = oracles
+    params = dict(la3dm_amd.BGK_YAML)
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-2.0, 2.0, (6000, 3)).astype(np.float32)
+    for labels in (rng.uniform(0.0, 1.0, 6000).astype(np.float32), (rng.uniform(0, 1, 6000) > 0.6).astype(np.float32)):
+        xyzy = np.concatenate([pts, labels[:, None]], axis=1).astype(np.float32)
+        m, o64, o32 = _maps(la3dm_amd, O, params)
+        m.insert_training_data(xyzy)
+        O.set_sum_mode(1)
+        o64.insert_training_data(xyzy)
+        O.set_sum_mode(0)
+        o32.insert_training_data(xyzy)
+        _check(m, o64, o32, "training data", params)
+
+
+def test_both_modes_agree_and_default_is_the_order_free_one(built, monkeypatch):
+    """la3dm_create takes the default from LA3DM_BGK_SUM (conftest pins 0 for the bit-identity suites); without it the
+    default is 1; the two modes give the same leaf structure on a pruned two-scan map"""
+    import la3dm_amd
+    monkeypatch.delenv("LA3DM_BGK_SUM", raising=False)
+    xyz, origin = la3dm_amd.synthetic_scan(20000)
+    out = []
+    for mode in (None, 0):
+        m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+        if mode is not None:
+            m.set_option("bgk_sum", mode)
+        for pose in (None, (1.0, 0.5, 1.0)):
+            x, o = la3dm_amd.synthetic_scan(20000, origin=pose)
+            m.insert_pointcloud(x, o, 0.1, 0.5, -1.0)
+        out.append(m.leaves())
+    a, b = out
+    assert (a["block_key"] == b["block_key"]).all() and (a["node_key"] == b["node_key"]).all()
+    assert (a["A"] != b["A"]).any()          # the default really is the other kernel
+    assert np.abs(_prob(a) - _prob(b)).max() <= 1e-5

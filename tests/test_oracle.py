@@ -325,3 +325,29 @@ def test_eigen_packet_trig_and_pcl_sort_order_move_p_by(built):
         for n in (1, 15):
             assert report[(n, tag)][1] == 0 and report[(n, tag)][2] == 0     # ... yet no state and no leaf structure changes
             assert report[(n, tag)][3] < 0.02
+
+
+def test_double_sum_mode_of_the_restatement_stays_within_the_tolerance(built):
+    """oracle.set_sum_mode(1) — double accumulators over all 7 neighbours, alpha / beta rounded once, the counterpart of the
+    device's default accumulate mode — against the reference's fp32 summation order (bgkinference.h:76-78,
+    bgkoctomap.cpp:314-335) on configs[0] and on 15 fused re-insertions: same leaf structure and states, |dp| <= 1e-6."""
+    from oracle import oracle as O
+    import la3dm_amd
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    try:
+        for reps, bound in ((1, 1e-6), (15, 2e-6)):
+            a, b = O.OracleMap(**O.BGK_YAML), O.OracleMap(**O.BGK_YAML)
+            for _ in range(reps):
+                O.set_sum_mode(0)
+                a.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+                O.set_sum_mode(1)
+                b.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+            la, lb = a.leaves(), b.leaves()
+            assert (la["block_key"] == lb["block_key"]).all() and (la["node_key"] == lb["node_key"]).all()
+            assert (la["state"] == lb["state"]).all() and (la["classified"] == lb["classified"]).all()
+            pa = la["A"].astype(np.float64) / (la["A"].astype(np.float64) + la["B"])
+            pb = lb["A"].astype(np.float64) / (lb["A"].astype(np.float64) + lb["B"])
+            assert np.abs(pa - pb).max() <= bound, (reps, float(np.abs(pa - pb).max()))
+            assert (la["A"] != lb["A"]).any()
+    finally:
+        O.set_sum_mode(0)
