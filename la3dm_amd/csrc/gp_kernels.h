@@ -8,7 +8,7 @@
 //   update loop             src/gpoctomap/gpoctomap.cpp:306-319 (unconditional, ExtendedBlock order)
 //
 // Numerics: every inner product is an fp32 FMA chain in ascending index order — exactly the order
-// the oracle uses and, as measured on MI355X (scratch/mfma/mfma_order.hip), the order
+// the oracle uses and, as measured on MI355X (tools/mfma/mfma_order.hip), the order
 // v_mfma_f32_32x32x2_f32 accumulates in — so the results are bit-identical to the CPU restatement
 // whether a chain runs on the VALU or on the matrix cores; exp() is the correctly rounded single-precision value
 // (f64 library exp rounded once).  Eigen's own LLT/GEMV/packet-exp orders are unpinned.
@@ -500,7 +500,7 @@ __device__ __forceinline__ float matern3_fast(float ax, float ay, float az, floa
 // v = L^-1 Ks for training blocks with N > 64 on the matrix cores, bit-identical to the FMA chains.
 //
 // v_mfma_f32_32x32x2_f32 accumulates D = C + A B as a chain of fp32 FMAs over k ascending (measured: 0 mismatches
-// against fmaf chains, scratch/mfma/mfma_order.hip), so a blocked forward substitution whose off-diagonal updates
+// against fmaf chains, tools/mfma/mfma_order.hip), so a blocked forward substitution whose off-diagonal updates
 //      C[K] = Ks[K] - sum_{J<K} L[K][J] V[J]            (J ascending, k ascending inside a block)
 // run on MFMA reproduces  acc = fma(-L_ki, v_i, acc), i = 0..k-1  of the oracle exactly; the 32 x 32 diagonal
 // blocks continue each chain on the VALU.  Layout: one wave handles the tile's 64 leaves as two 32-column

@@ -32,13 +32,26 @@ def _last_json(out):
 
 def test_single_gpu_line(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--rays", "50000",
-                        "--no-cpu-omp"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-omp"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k != "LA3DM_BGK_SUM"})
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    for k in KEYS + ("cpu_baseline", "end_to_end"):
+    for k in KEYS + ("cpu_baseline", "end_to_end", "gp", "lv", "bgkl"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1 and d["value"] > 0 and d["dtype"] == "f32"
+    assert d["scaling"] == "none"
     rf = d["roofline"]
+    # the line is quoted on the library's default accumulate mode and carries the other one next to it
+    assert d["config"]["bgk_sum"] == 1 and rf["kernel"] == "bgk_predict_fuse_r"
+    assert rf["ordered"]["kernel"] == "bgk_predict_fuse_v5" and rf["ordered"]["kernel_ms"] > rf["kernel_ms"] > 0
+    # every other BASELINE config rides on the same line, each with a roofline and a CPU leg of its own
+    for depth in ("depth3", "depth4"):
+        g = d["gp"][depth]
+        assert g["ms_per_step"] > 0 and g["roofline"]["bound"] == "mfma" and g["roofline"]["kernel_ms"] > 0 and g["flops_per_step"] > 0
+    assert d["gp"]["depth3"]["cpu_baseline"]["value"] > 0 and d["gp"]["depth3"]["max_N"] < d["gp"]["depth4"]["max_N"]
+    assert d["lv"]["sequence_ms"] > 0 and d["lv"]["voxel_kernel_ms_sum"] > 0 and d["lv"]["cpu_baseline"]["value"] > 0
+    assert d["lv"]["synthetic_50k"]["roofline"]["kernel_ms"] > 0
+    assert d["bgkl"]["ms_per_step"] > 0 and d["bgkl"]["cpu_baseline"]["value"] > 0
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["kernel_ms"] > 0 and rf["algorithmic_bytes_per_launch"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
@@ -69,7 +82,7 @@ def test_two_ranks_self_test(built, mode, scaling):
         assert d["roofline"]["kernel_ms"] > 0
 
 
-@pytest.mark.parametrize("workload,extra", [("gp", ["--rays", "20000"]), ("lv", []), ("l", ["--rays", "20000"])])
+@pytest.mark.parametrize("workload,extra", [("gp", []), ("lv", []), ("l", [])])
 def test_side_benches(built, workload, extra):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
                         "--no-cpu"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)

@@ -1,5 +1,5 @@
 """bgk_sum = 1 (order-free double accumulators) against bgk_sum = 0 (the reference's order): same packed scan, same
-initial alpha / beta; prints the differences and the kernel times.  gpurun -- python scratch/r_check.py"""
+initial alpha / beta; prints the differences and the kernel times.  gpurun -- python tools/check/r_check.py"""
 import ctypes as C
 import os
 import sys

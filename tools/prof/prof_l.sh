@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_l; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python scratch/l_timing.py ${1:-200000} ${2:-2048} > $OUT/log.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python tools/prof/l_timing.py ${1:-200000} ${2:-2048} > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob
 for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):

@@ -2,7 +2,7 @@
 // phases (round 3): masked writes, many lanes to one address, ds_add_f32 with same-address conflicts, strided b128
 // reads.  Same conventions as valu_issue.hip: W waves per SIMD resident, cycles per wave-instruction per SIMD at the
 // nominal 2.4 GHz.
-// build: hipcc --offload-arch=gfx950 -O2 scratch/ubench/lds_issue.hip -o scratch/_out/lds_issue
+// build: hipcc --offload-arch=gfx950 -O2 tools/ubench/lds_issue.hip -o tools/_out/lds_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

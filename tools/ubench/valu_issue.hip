@@ -7,7 +7,7 @@
 //   cyc = issue cycles per wave-instruction per SIMD = t * f_clk * 1024 / (waves * instructions per wave)
 // with f_clk measured in the same launch from s_memtime (shader clock ticks) against the HIP-event wall time.
 //
-// build: hipcc --offload-arch=gfx950 -O2 scratch/ubench/valu_issue.hip -o scratch/_out/valu_issue
+// build: hipcc --offload-arch=gfx950 -O2 tools/ubench/valu_issue.hip -o tools/_out/valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
