@@ -24,38 +24,19 @@ def _maps(params, omp=False):
 
 
 def _compare(m, o, params, tag="", nscan=1):
+    """bit identity, like every other parity file (the correctly rounded trig and the reference's summation order make
+    alpha / beta / state / classified equal to the restatement's to the last bit through la3dm_bgk_scan_host as well)"""
     a, b = m.leaves(), o.leaves()
     assert a["block_key"].size == b["block_key"].size, tag
-    assert (a["block_key"] == b["block_key"]).all(), tag
-    assert (a["node_key"] == b["node_key"]).all(), tag
-    assert (a["loc"] == b["loc"]).all(), tag          # bit-exact positions
-    assert (a["size"] == b["size"]).all(), tag
-    # `classified` (= "update() ran") may differ only for leaves whose whole evidence is one
-    # rim pair whose kernel value rounds to +tiny on one side and to <= 0 (clamped) on the other
-    cm = a["classified"] != b["classified"]
-    if cm.any():
-        tiny = (np.abs(a["A"] - params["prior_A"]) < 1e-6) & (np.abs(a["B"] - params["prior_B"]) < 1e-6) & \
-               (np.abs(b["A"] - params["prior_A"]) < 1e-6) & (np.abs(b["B"] - params["prior_B"]) < 1e-6)
-        assert (tiny | ~cm).all(), (tag, int(cm.sum()))
-        assert cm.mean() < 1e-3, (tag, cm.mean())
-    # alpha/beta: the sums run in the reference's order and the kernel values are bit-identical
-    # (correctly rounded sin/cos on both sides), so they normally agree exactly; the bound allows
-    # the ~1e-7 of pairs where a double-rounded sin/cos differs in the last place
-    tol = 1e-5 * np.maximum(b["A"], b["B"]) + 2e-7 * nscan
-    assert (np.abs(a["A"] - b["A"]) <= tol).all(), tag
-    assert (np.abs(a["B"] - b["B"]) <= tol).all(), tag
+    for k in ("block_key", "node_key", "loc", "size", "state", "classified"):
+        assert (a[k] == b[k]).all(), (tag, k, int((a[k] != b[k]).sum()))
+    for k in ("A", "B"):
+        bad = a[k].view(np.uint32) != b[k].view(np.uint32)
+        assert not bad.any(), (tag, k, int(bad.sum()), float(np.abs(a[k] - b[k]).max()))
     pa = a["A"].astype(np.float64) / (a["A"].astype(np.float64) + a["B"])
     pb = b["A"].astype(np.float64) / (b["A"].astype(np.float64) + b["B"])
     err = np.abs(pa - pb).max()
-    assert err <= P_TOL, (tag, err)
-    # states may differ only next to a threshold
-    diff = a["state"] != b["state"]
-    if diff.any():
-        near = (np.abs(pb - params["free_thresh"]) < 1e-4) | (np.abs(pb - params["occupied_thresh"]) < 1e-4)
-        s = b["A"].astype(np.float64) + b["B"]
-        var = b["A"] * b["B"] / (s * s * (s + 1))
-        near |= np.abs(var - params["var_thresh"]) < 1e-4 * params["var_thresh"]
-        assert (near | ~diff).all(), (tag, int(diff.sum()))
+    assert err <= P_TOL, (tag, err)          # the north-star tolerance, written out (observed: 0)
     return err
 
 
@@ -278,3 +259,37 @@ def test_block_sharded_scan_through_the_kernel(built):
         assert (a[k] == b[k]).all(), k
     for k in ("A", "B"):
         assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), k
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_against_the_likely_reference_build(built, mode):
+    """The real parity risk: a ROS-Noetic build of la3dm most plausibly evaluates sin / cos with
+    Eigen 3.3.7's SSE packet psin / pcos (include/bgkoctomap/bgkinference.h:115-116) and orders a voxel-grid cell's points by
+    pcl::VoxelGrid's unstable std::sort (src/bgkoctomap/bgkoctomap.cpp:419-431) — oracle.set_modes(1, 1).  The HIP path (both
+    accumulate modes) against THAT restatement, single scans: identical leaf structure and states, max |dp| <= 2.5e-5 and
+    >= 99.8 % of the leaves within the north star's 1e-5.  A regression guard for the table in DESIGN.md, not a claim of
+    bit identity with any build."""
+    import la3dm_amd
+    from oracle import oracle as O
+    cases = [("configs[0]", la3dm_amd.load_pcd(pcd_path("sim_structured", 1)), 8.0, False),
+             ("configs[1] 50 k-ray cut", la3dm_amd.synthetic_scan(50000), -1.0, True)]
+    for tag, (xyz, origin), max_range, omp in cases:
+        params = dict(la3dm_amd.BGK_YAML)
+        m = la3dm_amd.BGKOctoMap(**params, device=0)
+        m.set_option("bgk_sum", mode)
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, max_range)
+        O.set_modes(1, 1, omp=omp)
+        try:
+            o = O.OracleMap(**params, omp=omp)
+            o.insert_pointcloud(xyz, origin, 0.1, 0.5, max_range)
+        finally:
+            O.set_modes(0, 0, omp=omp)
+        a, b = m.leaves(), o.leaves()
+        assert a["block_key"].size == b["block_key"].size, tag
+        for k in ("block_key", "node_key", "state", "classified"):
+            assert (a[k] == b[k]).all(), (tag, k, int((a[k] != b[k]).sum()))
+        pa = a["A"].astype(np.float64) / (a["A"].astype(np.float64) + a["B"])
+        pb = b["A"].astype(np.float64) / (b["A"].astype(np.float64) + b["B"])
+        d = np.abs(pa - pb)
+        assert d.max() <= 2.5e-5, (tag, float(d.max()))
+        assert (d <= 1e-5).mean() >= 0.998, (tag, float((d <= 1e-5).mean()))
