@@ -92,6 +92,14 @@ uint64_t la3dm_map_training_size(const la3dm_map *m);
 int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap);
 
 float la3dm_map_block_size(const la3dm_map *m);
+float la3dm_map_resolution(const la3dm_map *m);
+int la3dm_map_block_depth(const la3dm_map *m);
+/* BGKOctoMap::set_resolution / set_block_depth (reference src/bgkoctomap/bgkoctomap.cpp:66-80, and the same pair of the
+ * GP / BGK-L / BGK-LV classes): re-derive block size and voxel LUT, rebuild the device context.  Legal on an EMPTY map
+ * only — the reference applies them under existing blocks and silently corrupts the map; here that is an error (-1,
+ * la3dm_map_last_error).  Options set through la3dm_set_option return to their defaults. */
+int la3dm_map_set_resolution(la3dm_map *m, float resolution);
+int la3dm_map_set_block_depth(la3dm_map *m, int block_depth);
 uint64_t la3dm_map_block_count(const la3dm_map *m);
 uint64_t la3dm_map_leaf_count(const la3dm_map *m);
 /* all leaves, blocks by ascending hash key, leaves in LeafIterator order */

@@ -87,7 +87,8 @@ MAP_SYMBOLS = ["la3dm_map_create", "la3dm_map_create_gp", "la3dm_map_create_lv",
                "la3dm_map_hash_key_to_block", "la3dm_map_extended_block", "la3dm_map_lut",
                "la3dm_map_set_device_resident", "la3dm_map_is_device_resident", "la3dm_map_raycast",
                "la3dm_map_block_grid", "la3dm_map_create_l", "la3dm_map_l_training",
-               "la3dm_map_search_many", "la3dm_map_export_cells", "la3dm_map_set_shard"]
+               "la3dm_map_search_many", "la3dm_map_export_cells", "la3dm_map_set_shard", "la3dm_map_resolution",
+               "la3dm_map_block_depth", "la3dm_map_set_resolution", "la3dm_map_set_block_depth"]
 
 _hip = None
 _map = None
@@ -226,6 +227,11 @@ def maplib():
         M.la3dm_map_training_data.argtypes = [C.c_void_p, f32p, C.c_uint64]
         M.la3dm_map_block_size.restype = C.c_float
         M.la3dm_map_block_size.argtypes = [C.c_void_p]
+        M.la3dm_map_resolution.restype = C.c_float
+        M.la3dm_map_resolution.argtypes = [C.c_void_p]
+        M.la3dm_map_block_depth.argtypes = [C.c_void_p]
+        M.la3dm_map_set_resolution.argtypes = [C.c_void_p, C.c_float]
+        M.la3dm_map_set_block_depth.argtypes = [C.c_void_p, C.c_int]
         M.la3dm_map_block_count.restype = C.c_uint64
         M.la3dm_map_block_count.argtypes = [C.c_void_p]
         M.la3dm_map_leaf_count.restype = C.c_uint64

@@ -93,10 +93,22 @@ class BGKOctoMap:
 
     # -- reference API ------------------------------------------------------
     def get_resolution(self):
-        return self.resolution
+        return self._M.la3dm_map_resolution(self._h)
 
     def get_block_depth(self):
-        return self.block_depth
+        return self._M.la3dm_map_block_depth(self._h)
+
+    def set_resolution(self, resolution):
+        """BGKOctoMap::set_resolution (reference src/bgkoctomap/bgkoctomap.cpp:66-72): empty maps only (RuntimeError otherwise)"""
+        self._chk(self._M.la3dm_map_set_resolution(self._h, float(resolution)))
+        self.resolution = self.get_resolution()
+        return self
+
+    def set_block_depth(self, block_depth):
+        """BGKOctoMap::set_block_depth (reference src/bgkoctomap/bgkoctomap.cpp:74-80): empty maps only (RuntimeError otherwise)"""
+        self._chk(self._M.la3dm_map_set_block_depth(self._h, int(block_depth)))
+        self.block_depth = self.get_block_depth()
+        return self
 
     def get_block_size(self):
         return self._M.la3dm_map_block_size(self._h)

@@ -142,6 +142,7 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
     rs.hist = base + 1024 * kRsHistCopies * (dm->radix_seq & 1u);
     rs.hist_next = base + 1024 * kRsHistCopies * ((dm->radix_seq + 1u) & 1u);
     ++dm->radix_seq;
+    rs.ticket = base + 2048 * kRsHistCopies;   // (the 16 spare words)
     rs.status[0] = base + 2048 * kRsHistCopies + 16;
     rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
     DM_RESERVE(dm->radix_tmp, 8ull * n);
@@ -161,6 +162,7 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         a.begin_bit = (uint32_t)begin_bit;
         a.counters = dm->d_cnt;
         a.err_slot = (int)kCntError;
+        a.use_ticket = tiles > dm->radix_resident ? 1u : 0u;
         hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(kRsThreads), 0, st, a, rs);
         sk = a.k_out;
         sv = a.v_out;
@@ -196,6 +198,9 @@ static int scan_state(la3dm_devmap *dm, uint32_t n, ScanState &ss) {
     ss.status = base + (size_t)cur * dm->scan_tiles;
     ss.other = base + (size_t)(cur ^ 1u) * dm->scan_tiles;
     ss.other_n = (uint32_t)dm->scan_dirty[cur ^ 1u];
+    uint32_t *tickets = (uint32_t *)dm->scan_status.ptr;   // (the 16 spare bytes: one ticket per status array)
+    ss.ticket = tiles > dm->scan_resident ? tickets + cur : nullptr;
+    ss.ticket_other = tickets + (cur ^ 1u);
     dm->scan_dirty[cur ^ 1u] = 0;
     dm->scan_dirty[cur] = tiles;
     ++dm->scan_seq;
@@ -495,6 +500,9 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         }
         dm->scan_resident = std::min<uint32_t>(kScanResident, (uint32_t)std::min(b0, b1) * (uint32_t)cus);
         dm->radix_resident = std::min<uint32_t>(kRsResident, (uint32_t)b2 * (uint32_t)cus);
+        // test hook: a handful of workgroups per launch forces the multi-round (ticket) form of the scan / sort on small inputs
+        if (const char *ev = getenv("LA3DM_SCAN_RESIDENT")) dm->scan_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->scan_resident));
+        if (const char *ev = getenv("LA3DM_RADIX_RESIDENT")) dm->radix_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->radix_resident));
     }
     *out = dm;
     return LA3DM_OK;

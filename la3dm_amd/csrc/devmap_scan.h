@@ -26,11 +26,20 @@ struct ScanState {
     unsigned long long *status;  // per tile: bits 63..62 = 0 empty / 1 tile aggregate / 2 inclusive prefix; low 32 bits = value
     unsigned long long *other;   // the status array of the NEXT launch: this launch clears its other_n used entries
     uint32_t other_n;
+    uint32_t *ticket;            // nullptr: workgroup b takes the tiles b, b + G, ... (every tile of the launch has its own
+                                 // workgroup); else the tiles are handed out through this counter (zero at launch)
+    uint32_t *ticket_other;      // the ticket of the next launch: cleared here
 };
-// A launch has at most kScanResident workgroups (what the chip holds at once); workgroup b takes the tiles b, b + G,
-// b + 2 G, ... in this order, and workgroups are handed out in order, so a tile only ever waits for tiles of workgroups
-// that started before its own — no ticket, no arrival counter: a device-scope atomic on ONE address costs ~25 ns per workgroup, serialised (measured: 390 workgroups x
-// (ticket + arrival count) = 20 us of a 23 us scan).  The status arrays alternate between launches and are cleaned by
+// A launch has at most kScanResident workgroups.  With one workgroup per tile (n <= resident x 4096 elements — every
+// front-end scan up to ~4 M elements) tile b belongs to workgroup b and only ever waits for tiles of workgroups with
+// a lower index: the dispatcher hands workgroups out in index order per XCD, so the lowest unfinished tile always
+// belongs to a workgroup that is running or can be dispatched as soon as a slot frees, whatever else occupies the GPU —
+// no ticket, no arrival counter (a device-scope atomic on ONE address costs ~25 ns per workgroup, serialised: 390
+// workgroups x (ticket + arrival count) were 20 us of a 23 us scan).  A launch with MORE tiles than workgroups cannot
+// assign tiles by index: a workgroup in its second round would wait for a first-round tile whose workgroup may never
+// be dispatched while the resident ones spin (the occupancy bound only holds on an exclusively owned, unmasked GPU —
+// ADVICE r02).  Such launches hand their tiles out through an atomic ticket: a tile's predecessors then belong to
+// workgroups that have already started.  The status arrays (and tickets) alternate between launches and are cleaned by
 // the launch in between.
 constexpr uint32_t kScanResident = 1024;
 
@@ -64,12 +73,20 @@ __device__ __forceinline__ void scan_st(unsigned long long *p, unsigned long lon
 
 template <bool kHeads>
 __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState st) {
-    __shared__ uint32_t s_wave[kScanThreads / 64], s_excl, s_pub;
+    __shared__ uint32_t s_wave[kScanThreads / 64], s_excl, s_pub, s_tile;
     if (threadIdx.x == 0) s_pub = 0u;   // (two barriers lie between this and the first writer)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (a.n + kScanTile - 1) / kScanTile;
     for (uint32_t e = blockIdx.x * kScanThreads + tid; e < st.other_n; e += gridDim.x * kScanThreads) st.other[e] = 0ull;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (blockIdx.x == 0 && tid == 0 && st.ticket_other) *st.ticket_other = 0u;
+    auto next_tile = [&](uint32_t prev) -> uint32_t {
+        if (!st.ticket) return prev + gridDim.x;
+        __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(st.ticket, 1u);
+        __syncthreads();
+        return s_tile;
+    };
+    for (uint32_t tile = st.ticket ? next_tile(0u) : blockIdx.x; tile < n_tiles; tile = next_tile(tile)) {
     const uint32_t i0 = tile * kScanTile + tid * kScanItems;
     // ---- items
     uint32_t raw[kScanItems], v[kScanItems];

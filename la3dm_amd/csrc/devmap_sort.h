@@ -26,6 +26,8 @@ struct RadixState {
                           // address costs ~25 ns per workgroup, serialised), the passes add the copies up
     uint32_t *hist_next;  // the histogram of the NEXT sort: the histogram launch clears it
     uint32_t *status[2];  // [tiles][256] per array: bits 31..30 = 0 empty / 1 tile count / 2 inclusive prefix, low 30 bits = value
+    uint32_t *ticket;     // [4] one tile ticket per pass (cleared by the histogram launch); used when a pass has more tiles
+                          // than workgroups (devmap_scan.h explains why index-assigned tiles are only safe for one round)
 };
 
 struct RadixArgs {
@@ -35,6 +37,7 @@ struct RadixArgs {
     uint32_t begin_bit;   // pass p sorts on key bits [begin_bit + 8 p, + 8)
     uint32_t *counters;
     int err_slot;
+    uint32_t use_ticket;  // tiles > workgroups of the launch
 };
 
 // A pass has at most kRsResident workgroups (what the chip holds at once: 256 CUs x 3 workgroups at 159 VGPRs); workgroup
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
     for (uint32_t p = 0; p < 4; ++p) h[p][tid] = 0;
     const uint32_t n_tiles = (n + kRsTile - 1) / kRsTile;
     for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n_tiles * 256u; i += gridDim.x * kRsThreads) st.status[0][i] = 0u;
+    if (blockIdx.x == 0 && tid < 4u) st.ticket[tid] = 0u;
     if (blockIdx.x < kRsHistCopies)
         for (uint32_t p = 0; p < 4; ++p) st.hist_next[(blockIdx.x * 4u + p) * 256u + tid] = 0u;
     __syncthreads();
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
 __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixState st) {
     __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
     __shared__ uint32_t s_wcnt[kRsWaves][256];
-    __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64];
+    __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64], s_tile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = a.begin_bit + 8u * a.pass;
     uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
@@ -107,7 +111,14 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
     // every key has the same digit in this pass (the top byte of grid-cell keys, mostly): the pass is a copy
     const bool copy_pass = __syncthreads_or(total_d == a.n) != 0;
     const uint32_t digit_base = rs_scan256(total_d, tid, s_part);   // first output position of digit tid
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    auto next_tile = [&](uint32_t prev) -> uint32_t {
+        if (!a.use_ticket) return prev + gridDim.x;
+        __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(&st.ticket[a.pass], 1u);
+        __syncthreads();
+        return s_tile;
+    };
+    for (uint32_t tile = a.use_ticket ? next_tile(0u) : blockIdx.x; tile < n_tiles; tile = next_tile(tile)) {
     other[tile * 256u + tid] = 0u;   // my row of the array the next pass (or the next sort's second pass) uses
     if (copy_pass) {
         const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);

@@ -451,7 +451,7 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
 
     capture_statics();
 
-    la3dm_params p;
+    la3dm_params &p = create_params;
     std::memset(&p, 0, sizeof(p));
     p.variant = variant;
     p.noise = OcTreeNode::noise;
@@ -460,8 +460,6 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     p.max_ivar = OcTreeNode::max_ivar;
     p.min_known_ivar = OcTreeNode::min_known_ivar;
     p.min_W = OcTreeNode::min_W;
-    p.resolution = resolution;
-    p.block_depth = block_depth;
     p.sf2 = sf2;
     p.ell = ell;
     p.free_thresh = free_thresh;
@@ -470,10 +468,17 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     p.prior_A = prior_A;
     p.prior_B = prior_B;
     p.device = device;
+    create_context();
+}
+
+void BGKOctoMap::create_context() {
+    la3dm_params &p = create_params;
+    p.resolution = resolution;
+    p.block_depth = block_depth;
     p.lut_xyz = &Block::key_loc_map[0].x();
     p.lut_count = (uint32_t)Block::key_loc_map.size();
     static_assert(sizeof(point3f) == 12, "LUT is handed to the device as packed xyz");
-    if (device < 0) return;  // bookkeeping-only map (tests of the host logic): inserting throws
+    if (p.device < 0) return;  // bookkeeping-only map (tests of the host logic): inserting throws
     int rc = la3dm_create(&p, &ctx);
     if (rc != LA3DM_OK)
         throw std::runtime_error(std::string("BGKOctoMap: GPU context creation failed: ") + la3dm_last_error(nullptr));
@@ -483,6 +488,44 @@ BGKOctoMap::BGKOctoMap(int variant_, float resolution_, unsigned short block_dep
     const char *env = getenv("LA3DM_DEVICE_RESIDENT");
     if (variant >= 0 && variant <= 3 && block_depth <= 5 && !(env && env[0] == '0')) {
         if (la3dm_devmap_create(ctx, &dmap) != LA3DM_OK) dmap = nullptr;
+    }
+}
+
+void BGKOctoMap::set_resolution(float r) { reconfigure(r, block_depth); }
+void BGKOctoMap::set_block_depth(unsigned short d) { reconfigure(resolution, d); }
+
+// reference bgkoctomap.cpp:66-80: resolution / block_depth, Block::resolution, Block::size, Block::key_loc_map,
+// OcTree::max_depth — on an empty map (see the header)
+void BGKOctoMap::reconfigure(float r, unsigned short d) {
+    bind();
+    if (!(r > 0.0f) || !std::isfinite(r)) throw std::invalid_argument("set_resolution: resolution must be positive and finite");
+    if (d < 1 || d > 6) throw std::invalid_argument("set_block_depth: block_depth must be in 1..6 (16-bit in-block keys)");
+    bool empty = block_arr.empty();
+    if (dmap != nullptr) {
+        uint32_t nb = 0, npb = 0;
+        if (la3dm_devmap_block_count(dmap, &nb, &npb) != LA3DM_OK || nb != 0) empty = false;
+    }
+    if (!empty)
+        throw std::logic_error("set_resolution / set_block_depth: the map already holds blocks (the reference re-derives the "
+                               "block size and the voxel LUT under them and corrupts the map; build a new map instead)");
+    const bool was_resident = dmap != nullptr;
+    la3dm_devmap_destroy(dmap);
+    dmap = nullptr;
+    la3dm_destroy(ctx);
+    ctx = nullptr;
+    resolution = r;
+    block_depth = d;
+    block_size = (float)pow(2, block_depth - 1) * resolution;
+    Block::resolution = resolution;
+    Block::size = block_size;
+    Block::key_loc_map = init_key_loc_map(resolution, block_depth);
+    OcTree::max_depth = block_depth;
+    capture_statics();
+    passes.clear();
+    create_context();
+    if (!was_resident && dmap != nullptr) {  // the map had been moved to the host-orchestrated mode: keep it there
+        la3dm_devmap_destroy(dmap);
+        dmap = nullptr;
     }
 }
 

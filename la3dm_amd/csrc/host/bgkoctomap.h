@@ -270,6 +270,14 @@ public:
     float get_resolution() const { return resolution; }
     float get_block_depth() const { return block_depth; }
     float get_block_size() const { return block_size; }
+    /// reference bgkoctomap.cpp:66-80 (the same pair in gpoctomap.cpp:55-69, bgkloctomap.cpp:67-81, bgklvoctomap.cpp:73-87):
+    /// re-derive the block size and the voxel LUT for a new resolution / block depth.  The reference does this under
+    /// whatever blocks the map already holds (their octrees keep the old depth, their centres the old block size — a
+    /// filled map is silently corrupted); here it is legal on an EMPTY map only and throws std::logic_error otherwise.
+    /// The device context (LUT, kernels' block depth) and the device-resident pool are rebuilt; options set through
+    /// la3dm_set_option return to their defaults.
+    void set_resolution(float resolution);
+    void set_block_depth(unsigned short max_depth);
 
     /// One scan. xyz: n points, `stride` floats between consecutive points (3 for packed
     /// xyz, 4 for PCL's PointXYZ).  Mirrors insert_pointcloud(const PCLPointCloud&, ...)
@@ -454,6 +462,9 @@ protected:
     la3dm_ctx *ctx;
     la3dm_devmap *dmap = nullptr;
     mutable bool mirror_dirty = false;
+    la3dm_params create_params;   // what the context was created with (lut_xyz is re-pointed on use)
+    void create_context();        // la3dm_create + the device-resident pool from create_params and the current statics
+    void reconfigure(float resolution, unsigned short depth);
 
     // per-scan buffers (capacity reused across scans)
     std::vector<float> xy;               // training set: x,y,z,label

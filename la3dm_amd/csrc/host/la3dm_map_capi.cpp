@@ -212,6 +212,13 @@ int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allga
 }
 
 float la3dm_map_block_size(const la3dm_map *m) { return m->map->get_block_size(); }
+float la3dm_map_resolution(const la3dm_map *m) { return m->map->get_resolution(); }
+int la3dm_map_block_depth(const la3dm_map *m) { return (int)m->map->get_block_depth(); }
+int la3dm_map_set_resolution(la3dm_map *m, float resolution) { GUARD(m->map->set_resolution(resolution); return 0;) }
+int la3dm_map_set_block_depth(la3dm_map *m, int block_depth) {
+    GUARD(if (block_depth < 0 || block_depth > 65535) throw std::invalid_argument("set_block_depth: out of range");
+          m->map->set_block_depth((unsigned short)block_depth); return 0;)
+}
 uint64_t la3dm_map_block_count(const la3dm_map *m) { return m->map->block_count(); }
 
 uint64_t la3dm_map_leaf_count(const la3dm_map *m) {

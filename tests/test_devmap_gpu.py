@@ -536,3 +536,35 @@ def test_fallback_switches_give_the_same_map(built, switch):
         return [l for l in r.stdout.splitlines() if l.startswith("CHK")][-1]
 
     assert run({switch: "0"}) == run({})
+
+
+@pytest.mark.parametrize("cls", ["BGKOctoMap", "GPOctoMap", "BGKLOctoMap", "BGKLVOctoMap"])
+def test_insert_after_set_resolution_and_set_block_depth(built, cls):
+    """set_resolution / set_block_depth (reference src/bgkoctomap/bgkoctomap.cpp:66-80 and the GP / BGK-L / BGK-LV twins)
+    rebuild the LUT, the device context and the pool: an insert afterwards is bit-identical to a map constructed with
+    those values, in both map modes; once the map holds blocks the calls raise."""
+    import la3dm_amd
+    yaml = {"BGKOctoMap": la3dm_amd.BGK_YAML, "GPOctoMap": la3dm_amd.GP_YAML, "BGKLOctoMap": la3dm_amd.L_YAML,
+            "BGKLVOctoMap": la3dm_amd.LV_YAML}[cls]
+    K = getattr(la3dm_amd, cls)
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    res, depth, fr = (0.1, 4, 0.5) if cls != "BGKLVOctoMap" else (0.1, 4, 0.3)
+    for resident in (True, False):
+        a = K(**dict(yaml, resolution=0.2, block_depth=3), device=0)
+        a.set_device_resident(resident)
+        a.set_resolution(res).set_block_depth(depth)
+        assert a.is_device_resident() == resident
+        b = K(**dict(yaml, resolution=res, block_depth=depth), device=0)
+        b.set_device_resident(resident)
+        for m in (a, b):
+            m.insert_pointcloud(xyz, origin, res, fr, 8.0)
+        la, lb = a.leaves(), b.leaves()
+        assert la["A"].size == lb["A"].size > 1000
+        for k in ("block_key", "node_key", "state", "classified"):
+            assert (la[k] == lb[k]).all(), (cls, resident, k)
+        for k in ("A", "B"):
+            assert (la[k].view(np.uint32) == lb[k].view(np.uint32)).all(), (cls, resident, k)
+        with pytest.raises(RuntimeError):
+            a.set_block_depth(3)
+        with pytest.raises(RuntimeError):
+            a.set_resolution(0.3)

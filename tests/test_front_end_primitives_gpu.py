@@ -11,14 +11,25 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def devmap(built):
+@pytest.fixture(scope="module", params=["occupancy", "4 workgroups"])
+def devmap(built, request):
+    """second run: LA3DM_SCAN_RESIDENT / LA3DM_RADIX_RESIDENT = 4 caps every launch at four workgroups, so every input
+    beyond four tiles takes the multi-round form — tiles handed out through the atomic ticket (index-assigned
+    tiles are only deadlock-free while every tile has its own workgroup)"""
+    import os
     import la3dm_amd
     from la3dm_amd import _lib
-    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)     # only for its context
-    H = _lib.hip()
-    dm = C.c_void_p()
-    assert H.la3dm_devmap_create(m.ctx(), C.byref(dm)) == 0
+    forced = request.param != "occupancy"
+    if forced:
+        os.environ["LA3DM_SCAN_RESIDENT"] = os.environ["LA3DM_RADIX_RESIDENT"] = "4"
+    try:
+        m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)     # only for its context
+        H = _lib.hip()
+        dm = C.c_void_p()
+        assert H.la3dm_devmap_create(m.ctx(), C.byref(dm)) == 0
+    finally:
+        os.environ.pop("LA3DM_SCAN_RESIDENT", None)
+        os.environ.pop("LA3DM_RADIX_RESIDENT", None)
     yield H, dm
     H.la3dm_devmap_destroy(dm)
 

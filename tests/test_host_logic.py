@@ -68,6 +68,45 @@ def test_host_hash_lut_against_reference_kat(built, depth):
     assert (m.lut() == kat[f"d{depth}_lut"]).all()
 
 
+@pytest.mark.parametrize("cls", ["BGKOctoMap", "GPOctoMap", "BGKLOctoMap", "BGKLVOctoMap"])
+def test_set_resolution_and_set_block_depth(built, cls):
+    """BGKOctoMap::set_resolution / set_block_depth (reference src/bgkoctomap/bgkoctomap.cpp:66-80; the same pair in
+    gpoctomap.cpp:55-69, bgkloctomap.cpp:67-81, bgklvoctomap.cpp:73-87): block size and voxel LUT after the call are the
+    reference's own for that depth (tests/golden/ref_kat.npz, captured from its compiled sources), hashing follows the
+    new block size; on a map that holds blocks the call is an error instead of the reference's silent corruption."""
+    import la3dm_amd
+    kat = np.load(os.path.join(GOLDEN, "ref_kat.npz"))
+    yaml = {"BGKOctoMap": la3dm_amd.BGK_YAML, "GPOctoMap": la3dm_amd.GP_YAML, "BGKLOctoMap": la3dm_amd.L_YAML,
+            "BGKLVOctoMap": la3dm_amd.LV_YAML}[cls]
+    m = getattr(la3dm_amd, cls)(**dict(yaml, resolution=0.1, block_depth=3), device=-1)
+    for depth in (4, 5, 3):
+        m.set_block_depth(depth)
+        assert m.get_block_depth() == depth and m.get_resolution() == np.float32(0.1)
+        assert np.float32(m.get_block_size()) == kat[f"d{depth}_block_size"]
+        assert (m.lut() == kat[f"d{depth}_lut"]).all()
+        for p, k, c in zip(kat[f"d{depth}_hash_pts"], kat[f"d{depth}_hash_keys"], kat[f"d{depth}_hash_centres"]):
+            assert m.block_to_hash_key(*map(float, p)) == k and (m.hash_key_to_block(int(k)) == c).all()
+    m.set_resolution(0.25)
+    assert m.get_resolution() == np.float32(0.25) and m.get_block_size() == np.float32(4 * 0.25)
+    fresh = getattr(la3dm_amd, cls)(**dict(yaml, resolution=0.25, block_depth=3), device=-1)
+    assert (m.lut() == fresh.lut()).all()
+    for bad in (0.0, -1.0, float("nan")):
+        with pytest.raises(RuntimeError):
+            m.set_resolution(bad)
+    for bad in (0, 7):
+        with pytest.raises(RuntimeError):
+            m.set_block_depth(bad)
+    if cls == "BGKOctoMap":      # a map with blocks refuses
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+        assert m.prepare(xyz, origin, 0.25, 0.5, 8.0)
+        m.commit()
+        assert m.block_count() > 0
+        with pytest.raises(RuntimeError):
+            m.set_resolution(0.1)
+        with pytest.raises(RuntimeError):
+            m.set_block_depth(4)
+
+
 def _emulate_device(pk, params):
     """what la3dm_bgk_scan_* computes, done with the oracle's predict + node update"""
     from oracle import oracle as O
