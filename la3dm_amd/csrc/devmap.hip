@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -285,7 +284,6 @@ static int read_counters(la3dm_devmap *dm) {
         }
         __builtin_ia32_pause();
     }
-    std::atomic_thread_fence(std::memory_order_acquire);   // the counter words are read (non-volatile) after the flag
     if (dm->h_cnt[kCntError] & (kScanErrStuck | kRsErrStuck)) {
         dm->poisoned = true;
         if (getenv("LA3DM_DEBUG_CNT")) {
@@ -342,22 +340,15 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     DM_RESERVE(out, 12ull * n);
     // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
     DM_RESERVE(dm->big, 4ull * (n / kBigCell + 1));
-    if (dm->ctx->opt_grid_sum == 1) {   // double sums in the fixed three-level order (devmap_kernels.h): no serial chain per cell
-        hipLaunchKernelGGL(dm_grid_centroids<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntGridSegs,
-                           (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
-        hipLaunchKernelGGL(dm_grid_centroids_big64, dim3(256, 3), dim3(1024), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
-                           (const uint32_t *)dm->big.ptr, (float *)out.ptr);
-    } else {
-        hipLaunchKernelGGL(dm_grid_centroids<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntGridSegs,
-                           (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
-        const uint32_t nchunk = n / kChunk;
-        DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
-        if (nchunk)
-            hipLaunchKernelGGL(dm_big_chunks, dim3(nchunk), dim3(64), 0, st, d_in, v1, flag, scan, dm->d_cnt, (int)kCntGridValid,
-                               (uint4 *)dm->chunk_desc.ptr);
-        hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
-                           (const uint32_t *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
-    }
+    hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntGridSegs,
+                       (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
+    const uint32_t nchunk = n / kChunk;
+    DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
+    if (nchunk)
+        hipLaunchKernelGGL(dm_big_chunks, dim3(nchunk), dim3(64), 0, st, d_in, v1, flag, scan, dm->d_cnt, (int)kCntGridValid,
+                           (uint4 *)dm->chunk_desc.ptr);
+    hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
+                       (const uint32_t *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
     rc = read_counters(dm);
     if (rc != LA3DM_OK) return rc;
     memcpy(dm->h_gp, dm->h_cnt + kCntGrid, sizeof(GridParams));
@@ -480,10 +471,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         dm->own_sort = !(os && os[0] == '0');
     }
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
-              // the mailbox: coherent (the in-kernel publish must be visible while the kernel still runs, whatever
-              // HIP_HOST_COHERENT says), mapped, and cleared — the first wait is for sequence number 1
-              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
-              (memset(dm->h_cnt, 0, sizeof(uint32_t) * (kCntWords + 2)), true) &&
+              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2)) == hipSuccess &&
               hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 16) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&

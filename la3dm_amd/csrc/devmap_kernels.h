@@ -310,14 +310,6 @@ __global__ __launch_bounds__(256) void dm_grid_cells(const float *__restrict__ p
 // next to the sensor collect one sample per beam — tens of thousands of points) go to dm_grid_centroids_big.
 constexpr uint32_t kBigCell = 64;
 
-// kSum64 (the library's default sum mode, la3dm_set_option "bgk_sum" 1): the centroid is formed from DOUBLE sums in a fixed
-// three-level order that does not serialise a big cell — groups of 64 consecutive points of the cell (in cloud order) are
-// summed sequentially, the group sums of 64 consecutive groups sequentially, the resulting partial sums sequentially —
-// and divided in double, rounded to fp32 once: (float)(S / (double)n).  pcl::VoxelGrid's own order inside a cell is
-// whatever its unstable std::sort leaves (unpinned); this order is within ~1e-16 relative of the
-// exact mean whatever it is, and the restatement's double-sum mode (oracle/la3dm_oracle.cpp voxel_grid) follows it
-// operation for operation.  A cell of at most 64 points is one group: a plain sequential double sum.
-template <bool kSum64>
 __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict__ p, const uint32_t *__restrict__ vals,
                                                         const uint32_t *__restrict__ seg_start, uint32_t *counters,
                                                         int seg_slot, int big_slot, uint32_t *big, float *out) {
@@ -331,7 +323,6 @@ __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict
     // eight points per trip: the index loads, then the coordinate loads, are issued together (a cell is a chain of
     // dependent gathers otherwise); the sums still run in cloud order
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    double dx = 0.0, dy = 0.0, dz = 0.0;
     for (uint32_t j = s0; j < s1; j += 8) {
         uint32_t v[8];
         float x[8], y[8], z[8];
@@ -346,84 +337,15 @@ __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (j + u < s1) {
-                if (kSum64) {
-                    dx += (double)x[u];
-                    dy += (double)y[u];
-                    dz += (double)z[u];
-                } else {
-                    sx += x[u];
-                    sy += y[u];
-                    sz += z[u];
-                }
+                sx += x[u];
+                sy += y[u];
+                sz += z[u];
             }
     }
-    if (kSum64) {
-        const double cnt = (double)(s1 - s0);
-        out[3 * (size_t)seg] = (float)(dx / cnt);
-        out[3 * (size_t)seg + 1] = (float)(dy / cnt);
-        out[3 * (size_t)seg + 2] = (float)(dz / cnt);
-    } else {
-        const float cnt = (float)(s1 - s0);
-        out[3 * (size_t)seg] = sx / cnt;
-        out[3 * (size_t)seg + 1] = sy / cnt;
-        out[3 * (size_t)seg + 2] = sz / cnt;
-    }
-}
-
-// Cells with more than 64 points in the double-sum mode: one workgroup of 16 waves per (cell, coordinate).  Wave w takes
-// the 4096-point super-groups w, w + 16, ...; its lane j sums group j of the super-group (64 sequential double adds over
-// the cell's points 4096 m + 64 j ...), lane 0 then adds the 64 lane sums in lane order (the level-1 order) and leaves
-// the super-group's partial sum in LDS; thread 0 adds the partial sums in order (level 2).  The sensor-origin cell of a
-// 200 k-ray scan (one sample per beam) is 49 super-groups: a few microseconds instead of a 2 x 10^5-step serial chain.
-constexpr uint32_t kBig64Waves = 16, kBig64MaxSuper = 2048;   // 2048 super-groups = 8.4 M points per round
-__global__ __launch_bounds__(1024) void dm_grid_centroids_big64(const float *__restrict__ p, const uint32_t *__restrict__ vals,
-                                                               const uint32_t *__restrict__ seg_start,
-                                                               const uint32_t *__restrict__ counters, int big_slot,
-                                                               const uint32_t *__restrict__ big, float *out) {
-    __shared__ double s_part[kBig64MaxSuper];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t c = blockIdx.y;
-    const uint32_t nbig = counters[big_slot];
-    for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
-        const uint32_t seg = big[i];
-        const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
-        const uint32_t n_super = (s1 - s0 + 4095u) >> 12;
-        double S = 0.0;
-        for (uint32_t m0 = 0; m0 < n_super; m0 += kBig64MaxSuper) {   // (one round unless the cell holds > 8.4 M points)
-            const uint32_t m1 = min(n_super, m0 + kBig64MaxSuper);
-            for (uint32_t m = m0 + wave; m < m1; m += kBig64Waves) {
-                const uint32_t g0 = s0 + (m << 12) + (lane << 6);   // first point of my group
-                double g = 0.0;
-                if (g0 < s1) {
-                    const uint32_t ge = min(s1, g0 + 64u);
-                    for (uint32_t j = g0; j < ge; j += 8) {
-                        uint32_t v[8];
-                        float x[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = vals[min(j + u, ge - 1u)];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) x[u] = p[3 * (size_t)v[u] + c];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (j + u < ge) g += (double)x[u];
-                    }
-                }
-                // level 1: the 64 group sums in lane order (groups past the cell's end hold +0)
-                double h = 0.0;
-                for (int j = 0; j < 64; ++j) {
-                    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)__double_as_longlong(g), j);
-                    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(__double_as_longlong(g) >> 32), j);
-                    h += __longlong_as_double(((long long)hi << 32) | lo);
-                }
-                if (lane == 0) s_part[m - m0] = h;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0)
-                for (uint32_t m = m0; m < m1; ++m) S += s_part[m - m0];   // level 2
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[3 * (size_t)seg + c] = (float)(S / (double)(s1 - s0));
-    }
+    const float cnt = (float)(s1 - s0);
+    out[3 * (size_t)seg] = sx / cnt;
+    out[3 * (size_t)seg + 1] = sy / cnt;
+    out[3 * (size_t)seg + 2] = sz / cnt;
 }
 
 // s after m sequential fp32 additions of the same x:  for (k < m) s = s + x;  — bit-exact, in O(binades

@@ -23,9 +23,56 @@ namespace {
 double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline uint32_t layer_base(unsigned depth) { return 0x249249u & ((1u << (3u * depth)) - 1u); }
 
-// voxel-grid centroid filter: the BGK front end's (host/bgkoctomap.cpp), both sum modes
-void lv_voxel_grid(const std::vector<float> &in, float leaf, std::vector<float> &out, bool sum64) {
-    voxel_grid_filter(in.data(), in.size() / 3, leaf, out, sum64);
+// voxel-grid centroid filter (same semantics as the BGK front end; PCL is not a dependency)
+void lv_voxel_grid(const std::vector<float> &in, float leaf, std::vector<float> &out) {
+    out.clear();
+    const size_t n = in.size() / 3;
+    if (n == 0) return;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = &in[3 * i];
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], p[a]);
+            mx[a] = std::max(mx[a], p[a]);
+        }
+    }
+    const int64_t ex = (int64_t)((mx[0] - mn[0]) * inv) + 1, ey = (int64_t)((mx[1] - mn[1]) * inv) + 1,
+                  ez = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (ex * ey * ez > (int64_t)INT32_MAX) {
+        out = in;
+        return;
+    }
+    int lo[3], span[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = (int)std::floor(mn[a] * inv);
+        span[a] = (int)std::floor(mx[a] * inv) - lo[a] + 1;
+    }
+    std::vector<uint64_t> order;
+    order.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = &in[3 * i];
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        const int c0 = (int)(std::floor(p[0] * inv) - (float)lo[0]), c1 = (int)(std::floor(p[1] * inv) - (float)lo[1]),
+                  c2 = (int)(std::floor(p[2] * inv) - (float)lo[2]);
+        order.push_back(((uint64_t)(uint32_t)(c0 + c1 * span[0] + c2 * span[0] * span[1]) << 32) | (uint32_t)i);
+    }
+    std::sort(order.begin(), order.end());
+    for (size_t i = 0; i < order.size();) {
+        const uint32_t cell = (uint32_t)(order[i] >> 32);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        size_t j = i;
+        for (; j < order.size() && (uint32_t)(order[j] >> 32) == cell; ++j) {
+            const float *p = &in[3 * (uint32_t)order[j]];
+            sx += p[0];
+            sy += p[1];
+            sz += p[2];
+        }
+        const float c = (float)(j - i);
+        out.insert(out.end(), {sx / c, sy / c, sz / c});
+        i = j;
+    }
 }
 
 inline int lv_code(State s) { return s == State::PRUNED ? 4 : (s == State::UNCERTAIN ? 3 : (int)s); }
@@ -59,7 +106,7 @@ void BGKLVOctoMap::training_data_lv(const float *xyz, size_t n, size_t stride, c
         packed[3 * i + 1] = xyz[stride * i + 1];
         packed[3 * i + 2] = xyz[stride * i + 2];
     }
-    if (ds_resolution < 0) hits.swap(packed); else lv_voxel_grid(packed, ds_resolution, hits, sum64_mode());
+    if (ds_resolution < 0) hits.swap(packed); else lv_voxel_grid(packed, ds_resolution, hits);
     samples.clear();
     rays8.clear();
     rays6.clear();

@@ -491,13 +491,6 @@ void BGKOctoMap::create_context() {
     }
 }
 
-bool BGKOctoMap::sum64_mode() const {
-    int v = 0;
-    if (ctx != nullptr && la3dm_get_option(ctx, "grid_sum", &v) == LA3DM_OK) return v == 1;
-    const char *ev = getenv("LA3DM_GRID_SUM");
-    return ev && ev[0] == '1';
-}
-
 void BGKOctoMap::set_resolution(float r) { reconfigure(r, block_depth); }
 void BGKOctoMap::set_block_depth(unsigned short d) { reconfigure(resolution, d); }
 
@@ -847,29 +840,7 @@ namespace {
 // Voxel-grid centroid filter with the semantics of pcl::VoxelGrid<PointXYZ> (PCL is not a
 // dependency of this build): cell = floor(p * (1/leaf)) - floor(min * (1/leaf)), output cells in
 // ascending linear index, centroid = fp32 sum in cloud order / (float)count.
-// sum64: the double-sum mode of the device path (devmap_kernels.h dm_grid_centroids<true>): groups of 64 consecutive
-// points of a cell, 64 groups per super-group, super-groups in order — every level a sequential double sum from +0 —,
-// centroid = (float)(S / (double)n).  Streamed here: O(1) state per cell.
-namespace {
-struct GroupedSum {
-    double g = 0.0, h = 0.0, S = 0.0;
-    size_t n = 0;
-    void add(float x) {
-        g += (double)x;
-        if (++n % 64 == 0) { h += g; g = 0.0; }
-        if (n % 4096 == 0) { S += h; h = 0.0; }
-    }
-    double total() const {
-        double hh = h, SS = S;
-        if (n % 64) hh += g;
-        if (n % 4096) SS += hh;
-        return SS;
-    }
-};
-}  // namespace
-}  // namespace
-
-void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float> &out, bool sum64) {
+void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float> &out) {
     out.clear();
     if (n == 0) return;
     const float inv = 1.0f / leaf;
@@ -896,7 +867,7 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
     }
     const int m1 = span[0], m2 = span[0] * span[1];
     const size_t ncell = (size_t)span[0] * span[1] * span[2];
-    if (!sum64 && ncell <= ((size_t)1 << 24)) {
+    if (ncell <= ((size_t)1 << 24)) {
         // dense accumulation: one pass in cloud order (the same per-cell summation order as sorting by
         // (cell, index)), then the occupied cells in ascending index
         struct Acc {
@@ -982,23 +953,8 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
     size_t i = 0;
     while (i < order.size()) {
         const uint32_t cell = (uint32_t)(order[i] >> 32);
-        size_t j = i;
-        if (sum64) {
-            GroupedSum ax, ay, az;
-            for (; j < order.size() && (uint32_t)(order[j] >> 32) == cell; ++j) {
-                const float *p = in + 3 * (uint32_t)order[j];
-                ax.add(p[0]);
-                ay.add(p[1]);
-                az.add(p[2]);
-            }
-            const double cnt = (double)(j - i);
-            out.push_back((float)(ax.total() / cnt));
-            out.push_back((float)(ay.total() / cnt));
-            out.push_back((float)(az.total() / cnt));
-            i = j;
-            continue;
-        }
         float sx = 0.f, sy = 0.f, sz = 0.f;
+        size_t j = i;
         for (; j < order.size() && (uint32_t)(order[j] >> 32) == cell; ++j) {
             const float *p = in + 3 * (uint32_t)order[j];
             sx += p[0];
@@ -1013,6 +969,8 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
     }
 }
 
+}  // namespace
+
 void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,
                                    float free_resolution, float max_range) {
     std::vector<float> packed(3 * n);
@@ -1023,7 +981,7 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
     }
     std::vector<float> hits;
     const double tt0 = wall();
-    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits, sum64_mode());
+    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
     const double tt1 = wall();
 
     xy.clear();
@@ -1074,7 +1032,7 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
     }
     std::vector<float> sampled;
     const double tt2 = wall();
-    if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled, sum64_mode());
+    if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled);
     if (getenv("LA3DM_TIMING"))
         fprintf(stderr, "[la3dm] front end: grid(hits) %.4f beam %.4f grid(frees, %zu pts) %.4f\n", tt1 - tt0, tt2 - tt1,
                 frees.size() / 3, wall() - tt2);
@@ -1098,7 +1056,7 @@ void BGKOctoMap::get_training_data_l(const float *xyz, size_t n, size_t stride, 
         packed[3 * i + 2] = xyz[stride * i + 2];
     }
     std::vector<float> hits;
-    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits, sum64_mode());
+    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
     const float x0 = origin.x(), y0 = origin.y(), z0 = origin.z();
     const size_t nh = hits.size() / 3;
     // pass 1: range gate and sample count per hit (the float-stepped while loop, kept verbatim); pass 2: fill

@@ -186,10 +186,6 @@ BlockHashKey block_to_hash_key(float x, float y, float z);
 point3f hash_key_to_block(BlockHashKey key);
 ExtendedBlock get_extended_block(BlockHashKey key);
 
-/// pcl::VoxelGrid centroid filter restated (reference call site src/bgkoctomap/bgkoctomap.cpp:419-431); sum64 = the
-/// optional double-sum mode (option "grid_sum" 1: a fixed three-level order, see host/bgkoctomap.cpp), false = fp32 sums in cloud order
-void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float> &out, bool sum64);
-
 /// Voxel LUT, flat and depth-major: entry (d, i) at (8^d - 1)/7 + i
 /// (replaces the reference's unordered_map Block::key_loc_map; same values).
 std::vector<point3f> init_key_loc_map(float resolution, unsigned short max_depth);
@@ -466,8 +462,6 @@ protected:
     la3dm_ctx *ctx;
     la3dm_devmap *dmap = nullptr;
     mutable bool mirror_dirty = false;
-    /// the context's voxel-grid sum mode (la3dm_set_option "grid_sum"; maps without a context: env LA3DM_GRID_SUM, default 0)
-    bool sum64_mode() const;
     la3dm_params create_params;   // what the context was created with (lut_xyz is re-pointed on use)
     void create_context();        // la3dm_create + the device-resident pool from create_params and the current statics
     void reconfigure(float resolution, unsigned short depth);

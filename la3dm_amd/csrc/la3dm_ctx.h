@@ -35,8 +35,6 @@ struct la3dm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
-    int opt_grid_sum = 0;  // voxel-grid centroids: 0 = fp32 sums in cloud order (the restatement of pcl::VoxelGrid every parity test uses),
-                           // 1 = double sums in a fixed three-level order (no serial chain per cell; moves a centroid by <= 1 ulp)
     Arena pts_scaled, nbr_range, blk_desc, label_seq;
     uint32_t scan_seq = 0;  // la3dm_bgk_scan_device calls so far (BgkArgs::seq)
     Arena gp_loff, gp_totals, gp_order, gp_L, gp_alpha, gp_v;

@@ -219,9 +219,6 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
     if (const char *ev = getenv("LA3DM_BGK_SUM")) {  // default accumulate mode of new contexts (la3dm_set_option "bgk_sum" overrides)
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_sum = ev[0] - '0';
     }
-    if (const char *ev = getenv("LA3DM_GRID_SUM")) {
-        if (ev[0] == '0' || ev[0] == '1') ctx->opt_grid_sum = ev[0] - '0';
-    }
     auto fail = [&](const char *what, hipError_t e) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(e);
         delete ctx;
@@ -276,11 +273,6 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_bgk_sum = value;
         return LA3DM_OK;
     }
-    if (!strcmp(name, "grid_sum")) {  // voxel-grid centroids: 0 = fp32 sums in cloud order, 1 = double sums, fixed three-level order
-        if (value < 0 || value > 1) return bad_value("0 or 1");
-        ctx->opt_grid_sum = value;
-        return LA3DM_OK;
-    }
     if (!strcmp(name, "fast_trig")) {
         if (value < 0 || value > 2) return bad_value("0, 1 or 2");
         ctx->opt_fast_trig = value;
@@ -317,17 +309,6 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
     }
     ctx->err = std::string("la3dm_set_option: unknown option ") + name;
     return LA3DM_ERR_ARG;
-}
-
-int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value) {
-    if (!ctx || !name || !value) return LA3DM_ERR_ARG;
-    if (!strcmp(name, "bgk_sum")) *value = ctx->opt_bgk_sum;
-    else if (!strcmp(name, "grid_sum")) *value = ctx->opt_grid_sum;
-    else if (!strcmp(name, "fast_trig")) *value = ctx->opt_fast_trig;
-    else if (!strcmp(name, "waves_per_wg")) *value = ctx->opt_waves;
-    else if (!strcmp(name, "remap")) *value = ctx->opt_remap;
-    else return LA3DM_ERR_ARG;
-    return LA3DM_OK;
 }
 
 static int check_scan(la3dm_ctx *ctx, const la3dm_bgk_scan *s) {

@@ -301,10 +301,6 @@ extern "C" void orc_set_modes(int trig, int grid_sort) {
 //      (up to 2^-53 relative), so this is the value the reference's fp32 chains approximate.
 int g_orc_sum_mode = 0;
 extern "C" void orc_set_sum_mode(int mode) { g_orc_sum_mode = mode; }
-// Voxel-filter switch, the counterpart of the device option "grid_sum": 0 = fp32 sums in cloud order (default), 1 = double
-// sums in the fixed three-level order of GroupedSum below.
-int g_orc_grid_sum_mode = 0;
-extern "C" void orc_set_grid_sum_mode(int mode) { g_orc_grid_sum_mode = mode; }
 
 namespace orc_eigen337 {
 static inline float from_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
@@ -509,24 +505,6 @@ void gp_predict(const Params &p, const GPModel &g, const float *xs, int M, float
 // downsample_all_data_=true, min_points_per_voxel_=0, no field filter.
 // Call site: src/bgkoctomap/bgkoctomap.cpp:419-431.
 // ---------------------------------------------------------------------------
-// double-sum mode of the voxel filter (orc_set_grid_sum_mode 1): the three-level fixed order of the device's default mode
-// (la3dm_amd/csrc/devmap_kernels.h dm_grid_centroids<true> / dm_grid_centroids_big64), streamed: groups of 64 consecutive
-// points of the cell, 64 groups per super-group, super-groups in order; every level a sequential double sum from +0.
-struct GroupedSum {
-    double g = 0.0, h = 0.0, S = 0.0;
-    size_t n = 0;
-    void add(float x) {
-        g += (double)x;
-        if (++n % 64 == 0) { h += g; g = 0.0; }
-        if (n % 4096 == 0) { S += h; h = 0.0; }
-    }
-    double total() const {
-        double hh = h, SS = S;
-        if (n % 64) hh += g;
-        if (n % 4096) SS += hh;
-        return SS;
-    }
-};
 void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
     out.clear();
     if (in.empty()) return;
@@ -579,17 +557,6 @@ void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
     while (i < iv.size()) {
         size_t j = i + 1;
         while (j < iv.size() && iv[j].first == iv[i].first) ++j;
-        if (g_orc_grid_sum_mode == 1) {
-            GroupedSum ax, ay, az;
-            for (size_t k = i; k < j; ++k) {
-                const V3 &p = in[iv[k].second];
-                ax.add(p.x); ay.add(p.y); az.add(p.z);
-            }
-            const double n = (double)(j - i);
-            out.push_back(V3{(float)(ax.total() / n), (float)(ay.total() / n), (float)(az.total() / n)});
-            i = j;
-            continue;
-        }
         // CentroidPoint / AccumulatorXYZ: float sums, divide by (float)n
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         for (size_t k = i; k < j; ++k) {

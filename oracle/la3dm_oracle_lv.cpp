@@ -30,7 +30,6 @@
 #include <vector>
 
 extern int g_orc_trig_mode, g_orc_grid_sort_mode;   // la3dm_oracle.cpp: the sensitivity switches (orc_set_modes)
-extern int g_orc_grid_sum_mode;                      // la3dm_oracle.cpp: orc_set_grid_sum_mode
 namespace orc_eigen337 {
 float psin(float x);
 float pcos(float x);
@@ -177,24 +176,6 @@ std::vector<std::vector<V3>> build_lut(float resolution, int depth) {  // bgklvb
 }
 
 // voxel grid as in la3dm_oracle.cpp (PCL restated) — duplicated to keep this unit self-contained
-// double-sum mode of the voxel filter (orc_set_grid_sum_mode 1): the three-level fixed order of the device's default mode
-// (la3dm_amd/csrc/devmap_kernels.h dm_grid_centroids<true> / dm_grid_centroids_big64), streamed: groups of 64 consecutive
-// points of the cell, 64 groups per super-group, super-groups in order; every level a sequential double sum from +0.
-struct GroupedSum {
-    double g = 0.0, h = 0.0, S = 0.0;
-    size_t n = 0;
-    void add(float x) {
-        g += (double)x;
-        if (++n % 64 == 0) { h += g; g = 0.0; }
-        if (n % 4096 == 0) { S += h; h = 0.0; }
-    }
-    double total() const {
-        double hh = h, SS = S;
-        if (n % 64) hh += g;
-        if (n % 4096) SS += hh;
-        return SS;
-    }
-};
 void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
     out.clear();
     if (in.empty()) return;
@@ -226,14 +207,6 @@ void voxel_grid(const std::vector<V3> &in, float leaf, std::vector<V3> &out) {
     }
     for (size_t i = 0; i < iv.size();) {
         size_t j = i;
-        if (g_orc_grid_sum_mode == 1) {
-            GroupedSum ax, ay, az;
-            for (; j < iv.size() && iv[j].first == iv[i].first; ++j) { ax.add(in[iv[j].second].x); ay.add(in[iv[j].second].y); az.add(in[iv[j].second].z); }
-            const double n = (double)(j - i);
-            out.push_back(V3{(float)(ax.total() / n), (float)(ay.total() / n), (float)(az.total() / n)});
-            i = j;
-            continue;
-        }
         float sx = 0, sy = 0, sz = 0;
         for (; j < iv.size() && iv[j].first == iv[i].first; ++j) { sx += in[iv[j].second].x; sy += in[iv[j].second].y; sz += in[iv[j].second].z; }
         float n = (float)(j - i);

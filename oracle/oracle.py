@@ -115,7 +115,6 @@ def _load(name):
     lib.orc_num_threads.restype = C.c_int
     lib.orc_set_modes.argtypes = [C.c_int, C.c_int]
     lib.orc_set_sum_mode.argtypes = [C.c_int]
-    lib.orc_set_grid_sum_mode.argtypes = [C.c_int]
     lib.orc_block_count.restype = C.c_int64
     lib.orc_block_count.argtypes = [C.c_void_p]
     lib.orc_leaf_count.restype = C.c_int64
@@ -463,12 +462,6 @@ def set_sum_mode(mode=0, omp=False):
     """0 = the reference's fp32 summation order (default), 1 = double accumulators over all 7 neighbours, rounded once: the
     counterpart of the device option bgk_sum = 1 (oracle/la3dm_oracle.cpp orc_set_sum_mode).  Process-global."""
     lib(omp).orc_set_sum_mode(int(mode))
-
-
-def set_grid_sum_mode(mode=0, omp=False):
-    """voxel-filter centroids: 0 = fp32 sums in cloud order (default), 1 = double sums in the fixed three-level order of the
-    device option grid_sum = 1 (oracle/la3dm_oracle.cpp GroupedSum).  Process-global."""
-    lib(omp).orc_set_grid_sum_mode(int(mode))
 
 
 def set_modes(trig=0, grid_sort=0, omp=False):

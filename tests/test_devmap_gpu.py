@@ -568,41 +568,3 @@ def test_insert_after_set_resolution_and_set_block_depth(built, cls):
             a.set_block_depth(3)
         with pytest.raises(RuntimeError):
             a.set_resolution(0.3)
-
-
-@pytest.mark.parametrize("resident", [True, False])
-def test_grid_sum_option_double_sums_in_the_fixed_order(built, resident):
-    """option "grid_sum" 1: voxel-grid centroids from double sums in a fixed three-level order (64-point groups, 64-group
-    super-groups; devmap_kernels.h dm_grid_centroids<true> / dm_grid_centroids_big64, host/bgkoctomap.cpp GroupedSum) instead
-    of the fp32 cloud-order chain — the restatement's orc_set_grid_sum_mode(1) follows the same order operation for operation,
-    so the training set (cells of 1 .. 50 000 points: the sensor-origin cell holds one sample per beam) and, with the ordered
-    BGK sums, every leaf are bit-identical to it; against the default centroids a coordinate moves by at most one ulp."""
-    import la3dm_amd
-    from oracle import oracle as O
-    try:
-        for xyz_o, ds_res, fr, mr in ((la3dm_amd.load_pcd(pcd_path("sim_structured", 1)), 0.1, 0.5, 8.0),
-                                      (la3dm_amd.synthetic_scan(50000), 0.1, 0.5, -1.0)):
-            xyz, origin = xyz_o
-            m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0).set_device_resident(resident)
-            m.set_option("bgk_sum", 0)
-            m.set_option("grid_sum", 1)
-            assert m.get_option("grid_sum") == 1
-            m.insert_pointcloud(xyz, origin, ds_res, fr, mr)
-            O.set_grid_sum_mode(0)
-            ref0 = O.get_training_data(xyz, origin, ds_res, fr, mr)
-            O.set_grid_sum_mode(1)
-            ref1 = O.get_training_data(xyz, origin, ds_res, fr, mr)
-            t = m.training_data()
-            assert t.shape == ref1.shape == ref0.shape
-            assert (t.view(np.uint32) == ref1.view(np.uint32)).all(), int((t != ref1).any(axis=1).sum())
-            u = np.abs(ref1[:, :3].view(np.int32).astype(np.int64) - ref0[:, :3].view(np.int32))
-            assert 0 < u.max() <= 1 or (np.abs(ref1[:, :3] - ref0[:, :3]).max() <= 1e-6), int(u.max())
-            o = O.OracleMap(**O.BGK_YAML)
-            o.insert_pointcloud(xyz, origin, ds_res, fr, mr)
-            a, b = m.leaves(), o.leaves()
-            for k in ("block_key", "node_key", "state", "classified"):
-                assert (a[k] == b[k]).all(), k
-            for k in ("A", "B"):
-                assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), k
-    finally:
-        O.set_grid_sum_mode(0)
