@@ -125,15 +125,21 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out);
 void la3dm_destroy(la3dm_ctx *ctx);
 const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last create error */
 
-/* Options: "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial,
- * 2 = OCML; "bgk_variant" is accepted and ignored (one implementation is built; the measurement history of the
- * other variants is in DESIGN.md); "waves_per_wg" 1/2/4,
+/* Options: "bgk_sum" — the sum mode of the BGK predict + fuse kernel:
+ *   1 (default; env LA3DM_BGK_SUM sets the default of new contexts) = order-free: every leaf's sum(k), sum(k y) in double
+ *     accumulators over all 7 neighbours, alpha / beta rounded once (bgk_predict_fuse_r).  Within ~4e-7 of the reference's
+ *     fp32 chains on p; what bench.py is quoted on.
+ *   0 = the reference's fp32 summation order (bgk_predict_fuse_v5): bit-identical to the CPU restatement, the regression
+ *     mode of the parity suites.
+ * "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial, 2 = OCML; "waves_per_wg" 1/2/4 (bgk_sum 0),
  * "remap" 0-2, "ablate" 0-7 (profiling); values outside these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
  * rows than this take the split path (default 2048, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
  * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
  * 0 = the replay expands them itself (results do not depend on it). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
+/* current value of an option that has one ("bgk_sum", "fast_trig", "waves_per_wg", "remap") */
+int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */
 int la3dm_bgk_scan_host(la3dm_ctx *ctx, const la3dm_bgk_scan *scan, la3dm_bgk_counters *out);

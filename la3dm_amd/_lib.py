@@ -68,7 +68,7 @@ class DevmapStats(C.Structure):
 
 
 HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_destroy", "la3dm_last_error",
-               "la3dm_set_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_gp_scan_host",
+               "la3dm_set_option", "la3dm_get_option", "la3dm_bgk_scan_host", "la3dm_bgk_scan_device", "la3dm_gp_scan_host",
                "la3dm_gp_scan_device", "la3dm_bgklv_scan_host", "la3dm_bgklv_scan_device", "la3dm_kernel_times", "la3dm_diag_eval", "la3dm_diag_sweep",
                "la3dm_devmap_create", "la3dm_devmap_destroy", "la3dm_devmap_insert_pointcloud_host",
                "la3dm_devmap_insert_pointcloud_device", "la3dm_devmap_block_count", "la3dm_devmap_download",
@@ -111,6 +111,8 @@ def hip():
         L.la3dm_last_error.argtypes = [C.c_void_p]
         L.la3dm_set_option.restype = C.c_int
         L.la3dm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.la3dm_get_option.restype = C.c_int
+        L.la3dm_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
         L.la3dm_bgk_scan_host.restype = C.c_int
         L.la3dm_bgk_scan_host.argtypes = [C.c_void_p, C.POINTER(BgkScan), C.POINTER(BgkCounters)]
         L.la3dm_bgk_scan_device.restype = C.c_int

@@ -231,6 +231,12 @@ class BGKOctoMap:
         if rc != 0:
             raise RuntimeError(_lib.hip().la3dm_last_error(self.ctx()).decode())
 
+    def get_option(self, name):
+        v = C.c_int()
+        if _lib.hip().la3dm_get_option(self.ctx(), name.encode(), C.byref(v)) != 0:
+            raise RuntimeError(f"la3dm_get_option: unknown option {name}")
+        return v.value
+
     def scan_host(self, packed: PackedScan):
         cnt = _lib.BgkCounters()
         fn = _lib.hip().la3dm_gp_scan_host if self._gp else _lib.hip().la3dm_bgk_scan_host

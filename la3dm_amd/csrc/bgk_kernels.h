@@ -345,7 +345,9 @@ constexpr int kRing5 = 432;  // with the 64 scratch slots and the zero entry the
 // and k <= 0 for every r >= 1 —, so a pair with d2 >= T adds +0 to both sums and can be dropped at the distance
 // test (4.8 % of the pairs inside the unit ball).  The sign of (a + b) does not depend on sf2 > 0.  Checked against the
 // oracle's kernel over all 1.68 M fp32 values of [0.9, 1) (tests/test_oracle.py) and against the device arithmetic by
-// la3dm_diag_sweep(what = 8) (tests/test_bgk_gpu.py).
+// la3dm_diag_sweep(what = 8) (tests/test_bgk_gpu.py).  Exact for the correctly rounded trig (fast_trig = 0, the parity
+// configuration) only: with fast_trig 1 / 2 (f32 polynomial / OCML, <= 1.5 ulp, outside the parity contract) a pair with d2
+// just below 1 may have a kernel value of a few 1e-8 that this threshold drops.
 constexpr uint32_t kHitTBits = 0x3f77c08du;
 
 struct __attribute__((aligned(16))) WaveLds5 {

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -284,6 +285,7 @@ static int read_counters(la3dm_devmap *dm) {
         }
         __builtin_ia32_pause();
     }
+    std::atomic_thread_fence(std::memory_order_acquire);   // the counter words are read (non-volatile) after the flag
     if (dm->h_cnt[kCntError] & (kScanErrStuck | kRsErrStuck)) {
         dm->poisoned = true;
         if (getenv("LA3DM_DEBUG_CNT")) {
@@ -471,7 +473,10 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         dm->own_sort = !(os && os[0] == '0');
     }
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
-              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2)) == hipSuccess &&
+              // the mailbox: coherent (the in-kernel publish must be visible while the kernel still runs, whatever
+              // HIP_HOST_COHERENT says), mapped, and cleared — the first wait is for sequence number 1
+              hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
+              (memset(dm->h_cnt, 0, sizeof(uint32_t) * (kCntWords + 2)), true) &&
               hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 16) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&

@@ -755,6 +755,8 @@ constexpr int kGpLdsRows = 64;  // rows of v the LDS path can hold (one wave of 
 #define LA3DM_GP_MFMA_MIN_N 65
 #endif
 constexpr int kGpMfmaMinN = LA3DM_GP_MFMA_MIN_N;  // blocks with at least this many points are solved on the matrix cores
+static_assert(kGpMfmaMinN <= kGpLdsRows + 1, "the small path keeps v in s_v[64][64] (lane = column of L): every block with "
+                                             "more than kGpLdsRows points must take the matrix-core path");
 
 // Two launches share this body: the tiles whose seven neighbours all hold fewer than kGpMfmaMinN points (kMixed = false: no
 // matrix-core code in the kernel, so no 256-VGPR budget and no spills in the four-row loop — with both paths in one kernel

@@ -311,6 +311,16 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
     return LA3DM_ERR_ARG;
 }
 
+int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value) {
+    if (!ctx || !name || !value) return LA3DM_ERR_ARG;
+    if (!strcmp(name, "bgk_sum")) *value = ctx->opt_bgk_sum;
+    else if (!strcmp(name, "fast_trig")) *value = ctx->opt_fast_trig;
+    else if (!strcmp(name, "waves_per_wg")) *value = ctx->opt_waves;
+    else if (!strcmp(name, "remap")) *value = ctx->opt_remap;
+    else return LA3DM_ERR_ARG;
+    return LA3DM_OK;
+}
+
 static int check_scan(la3dm_ctx *ctx, const la3dm_bgk_scan *s) {
     if (!ctx) return LA3DM_ERR_ARG;
     if (!s) {
