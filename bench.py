@@ -32,6 +32,10 @@ import numpy as np
 
 # multi-process GPU work on this pool needs dmabuf IPC (the image exports this already; keep it if the launcher drops it)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the CPU legs run the restatement on every host core through OpenMP: its idle workers must sleep, not spin, or the host
+# thread that drives the GPU in the legs that follow competes with 128 spinning threads (measured: the BGK-L insert 3.7 -> 11.5 ms)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -299,20 +303,25 @@ def main():
             out["end_to_end"] = end_to_end(la3dm_amd, params, args)
         if world == 1 and not args.no_big and args.rays == 200000:
             out["roofline"]["out_of_cache"] = out_of_cache_leg(la3dm_amd, _lib, torch, dev)
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(params, xyz, origin, args, U)
-            if args.cpu_omp:
-                out["cpu_baseline_omp"] = cpu_baseline(params, xyz, origin, args, U, omp=True)
         if world == 1 and not args.no_side:
-            # the other BASELINE configs on this GPU, each with its own roofline and CPU leg (same protocol as --workload X)
+            # the other BASELINE configs on this GPU, each with its own roofline and CPU leg (same protocol as --workload X);
+            # every GPU measurement of the run comes before the first all-core CPU leg
             del m
             torch.cuda.synchronize()
             side = argparse.Namespace(**vars(args))
             side.steps, side.warmup = 10, 2
-            out["gp"] = {"depth3": gp_leg(side, torch, la3dm_amd, _lib, depth=3, cpu=not args.no_cpu),
+            out["gp"] = {"depth3": gp_leg(side, torch, la3dm_amd, _lib, depth=3, cpu=False),
                          "depth4": gp_leg(side, torch, la3dm_amd, _lib, depth=4, cpu=False)}
-            out["lv"] = lv_leg(side, torch, la3dm_amd, _lib, cpu=not args.no_cpu)
-            out["bgkl"] = l_leg(side, torch, la3dm_amd, cpu=not args.no_cpu)
+            out["lv"] = lv_leg(side, torch, la3dm_amd, _lib, cpu=False)
+            out["bgkl"] = l_leg(side, torch, la3dm_amd, cpu=False)
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(params, xyz, origin, args, U)
+            if args.cpu_omp:
+                out["cpu_baseline_omp"] = cpu_baseline(params, xyz, origin, args, U, omp=True)
+            if not args.no_side:
+                out["gp"]["depth3"]["cpu_baseline"] = gp_cpu(la3dm_amd)
+                out["lv"]["cpu_baseline"] = lv_cpu(la3dm_amd, out["lv"])
+                out["bgkl"]["cpu_baseline"] = l_cpu(la3dm_amd)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -501,19 +510,25 @@ def gp_leg(args, torch, la3dm_amd, _lib, depth, cpu):
                                          "frac": cnt["valu_insts_per_launch"] / (k_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
                                          "all_insts_per_s": rate, "source": cnt.get("source")}
     if cpu:
-        from oracle import oracle as O
-        o = O.OracleGPMap(**params, omp=True)
-        t0 = time.perf_counter()
-        o.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
-        tc = time.perf_counter() - t0
-        so = o.stats()
-        out["cpu_baseline"] = {"value": so["voxel_updates"] / so["t_predict"], "unit": "voxel-updates/s",
-                               "cores": O.lib(True).orc_num_threads(), "kind": "port",
-                               "sample": "the full scan, 1 insert_pointcloud into a fresh map of this repo's restatement (OpenMP "
-                                         "build); value = leaves of test blocks / train+predict+fuse stage time",
-                               "stage_s": {"predict_fuse": so["t_predict"], "insert_pointcloud": tc}}
+        out["cpu_baseline"] = gp_cpu(la3dm_amd)
     del m
     return out
+
+
+def gp_cpu(la3dm_amd):
+    from oracle import oracle as O
+    params = dict(la3dm_amd.GP_YAML, block_depth=3, resolution=0.1)
+    xyz, origin = la3dm_amd.synthetic_scan(50000)
+    o = O.OracleGPMap(**params, omp=True)
+    t0 = time.perf_counter()
+    o.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
+    tc = time.perf_counter() - t0
+    so = o.stats()
+    return {"value": so["voxel_updates"] / so["t_predict"], "unit": "voxel-updates/s",
+            "cores": O.lib(True).orc_num_threads(), "kind": "port",
+            "sample": "the full scan at block_depth 3, 1 insert_pointcloud into a fresh map of this repo's restatement (OpenMP "
+                      "build); value = leaves of test blocks / train+predict+fuse stage time",
+            "stage_s": {"predict_fuse": so["t_predict"], "insert_pointcloud": tc}}
 
 
 def lv_leg(args, torch, la3dm_amd, _lib, cpu):
@@ -568,17 +583,23 @@ def lv_leg(args, torch, la3dm_amd, _lib, cpu):
                                          "algorithmic_bytes_per_launch": b_alg, "achieved": b_alg / (k_ms * 1e-3) / 1e9,
                                          "peak": 8000.0, "unit": "GB/s", "frac": b_alg / (k_ms * 1e-3) / 1e9 / 8000.0}}
     if cpu:
-        from oracle import oracle as O
-        o = O.OracleLVMap(**params)
-        t0 = time.perf_counter()
-        for xyz, origin in scans[:3]:
-            o.insert_pointcloud(xyz, origin, 0.05, 0.1, 8.0)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 3 / tc, "unit": "scans/s", "cores": 1, "kind": "port",
-                               "sample": "the first 3 of the 12 scans into a fresh map of this repo's restatement (1 thread)",
-                               "s_per_scan": tc / 3, "gpu_scans_per_s": 12 / dt}
+        out["cpu_baseline"] = lv_cpu(la3dm_amd, out)
     del m
     return out
+
+
+def lv_cpu(la3dm_amd, leg):
+    from oracle import oracle as O
+    params = dict(la3dm_amd.LV_YAML, resolution=0.05, block_depth=5)
+    o = O.OracleLVMap(**params)
+    t0 = time.perf_counter()
+    for i in range(1, 4):
+        xyz, origin = la3dm_amd.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "sim_unstructured", f"sim_unstructured_{i}.pcd"))
+        o.insert_pointcloud(xyz, origin, 0.05, 0.1, 8.0)
+    tc = time.perf_counter() - t0
+    return {"value": 3 / tc, "unit": "scans/s", "cores": 1, "kind": "port",
+            "sample": "the first 3 of the 12 scans into a fresh map of this repo's restatement (1 thread, incl. reading the files)",
+            "s_per_scan": tc / 3, "gpu_scans_per_s": 12 / (leg["sequence_ms"] * 1e-3)}
 
 
 def side_bench(args, torch, la3dm_amd, _lib):
@@ -632,18 +653,24 @@ def l_leg(args, torch, la3dm_amd, cpu):
                         "frac": b_alg / dt / 1e9 / 8000.0, "traffic": None, "kernel": "insert_pointcloud (all kernels)",
                         "kernel_ms": dt * 1e3, "algorithmic_bytes_per_launch": b_alg}}
     if cpu:
-        from oracle import oracle as O
-        o = O.OracleLMap(**params, omp=True)
-        o.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)
-        t0 = time.perf_counter()
-        o.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": float(o.stats()["voxel_updates"]) / tc, "unit": "voxel-updates/s",
-                               "cores": O.lib(True).orc_num_threads(), "kind": "port",
-                               "sample": "the same scan re-inserted once into the OpenMP build of this repo's restatement",
-                               "insert_pointcloud_s": tc}
+        out["cpu_baseline"] = l_cpu(la3dm_amd)
     del m
     return out
+
+
+def l_cpu(la3dm_amd):
+    from oracle import oracle as O
+    params = dict(la3dm_amd.L_YAML, resolution=0.1, block_depth=3)
+    xyz, origin = la3dm_amd.synthetic_scan(200000)
+    o = O.OracleLMap(**params, omp=True)
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    t0 = time.perf_counter()
+    o.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    tc = time.perf_counter() - t0
+    return {"value": float(o.stats()["voxel_updates"]) / tc, "unit": "voxel-updates/s",
+            "cores": O.lib(True).orc_num_threads(), "kind": "port",
+            "sample": "the same scan re-inserted once into the OpenMP build of this repo's restatement",
+            "insert_pointcloud_s": tc}
 
 
 SEQ_POSES = [None, (1.5, 0.5, 1.0), (-1.5, 1.0, 1.2), (0.5, -2.0, 0.9), (2.5, 2.0, 1.1)]   # sensor poses of the e2e sequence

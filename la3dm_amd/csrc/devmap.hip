@@ -1129,7 +1129,7 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     uint32_t *nsamp = (uint32_t *)dm->lv_nsamp.ptr, *nray = (uint32_t *)dm->lv_nray.ptr;
     uint32_t *samp_off = (uint32_t *)dm->lv_samp_off.ptr, *ray_off = (uint32_t *)dm->lv_ray_off.ptr;
     hipLaunchKernelGGL(dm_lv_ranges, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (double *)dm->lv_rng.ptr);
-    if (nh <= 32768u) {  // membership of the "nearby" gather for all (beam, hit) pairs at once, then the ordered walk over the set bits
+    if (nh <= 98304u) {  // (the bit matrix is nh^2 / 8 bytes: 1.2 GB at this bound) membership of the "nearby" gather for all (beam, hit) pairs at once, then the ordered walk over the set bits
         const uint32_t nw = cdiv(nh, 64);
         DM_RESERVE(dm->lv_beam, sizeof(LvBeam) * (size_t)nh);
         DM_RESERVE(dm->lv_mask, 8ull * nh * nw);

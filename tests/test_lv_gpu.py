@@ -123,3 +123,28 @@ def test_lv_wide_kernel_several_bucket_groups(built, ell, depth, both_modes):
         m.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
         ea, eb = _compare(m, o, params, f"ell {ell} resident {resident}")
         assert ea == 1.0 and eb == 1.0
+
+
+def test_lv_synthetic_scan_that_fills_the_gpu(built):
+    """BGKLVOctoMap beyond the 3 500-point sim_unstructured scans — a synthetic 8 000-ray scan at
+    configs[3]'s parameters (0.05 m, block_depth 5, max_range 8): ~7 k filtered hits (the ray shortening's hit x hit bit
+    matrix, src/bgklvoctomap/bgklvoctomap.cpp:303-423), ~0.3 M samples, a few thousand packed blocks, split cubes next to the
+    sensor.  (The restatement's ray shortening is O(hits^2) on one core: 20 000 rays take 46 s per insert, which bounds the
+    size here; bench.py's lv leg runs 50 000 rays on the device.)  Training set (samples, segments) and every leaf."""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.LV_YAML, resolution=0.05, block_depth=5)
+    xyz, origin = la3dm_amd.synthetic_scan(8000)
+    m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+    assert m.is_device_resident()
+    o = O.OracleLVMap(**params)
+    m.insert_pointcloud(xyz, origin, 0.05, 0.1, 8.0)
+    o.insert_pointcloud(xyz, origin, 0.05, 0.1, 8.0)
+    st = m.lv_stats()
+    assert st["n_samples"] > 150_000 and st["n_hits"] > 4_000
+    xy_ref, rays_ref = o.training_data(xyz, origin, 0.05, 0.1, 8.0)
+    xy, rays = m.lv_training()
+    assert xy.shape == xy_ref.shape and (xy.view(np.uint32) == xy_ref.view(np.uint32)).all()
+    assert rays.shape == rays_ref.shape and (rays.view(np.uint32) == rays_ref.view(np.uint32)).all()
+    eqA, eqB = _compare(m, o, params, "synthetic 8 k rays")
+    assert eqA == 1.0 and eqB == 1.0
