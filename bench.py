@@ -379,6 +379,24 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, dt1 = float(tt[0].item()), float(tt[1].item())
     st = m.stats()
+    # per-stage wall times of rank 0 (a third replica created with LA3DM_TIMING=1: a host synchronisation after every stage,
+    # so the sum is larger than an untimed step — it says where the time goes, not how long a step takes)
+    os.environ["LA3DM_TIMING"] = "1"
+    try:
+        mt = la3dm_amd.BGKOctoMap(**params, device=local_rank)
+    finally:
+        os.environ.pop("LA3DM_TIMING", None)
+    mt.set_shard(rank, world, sharding.torch_allgather(dist, rank, dev, stage_through_host=selftest))
+    stages = {}
+    for i in range(3):
+        mt.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
+        sx = mt.stats()
+        stages = {"front_end": sx["t_frontend"] * 1e3, "partition": sx["t_partition"] * 1e3, "test_list_blocks_leaves": sx["t_pack"] * 1e3,
+                  "predict_fuse_own_range": sx["t_device"] * 1e3, "allgather_v": sx["t_gather"] * 1e3,
+                  "commit_prune": sx["t_commit"] * 1e3}
+    torch.cuda.synchronize()
+    dist.barrier()
+    del mt
     if rank == 0:
         print(json.dumps({
             "metric": "voxel-updates/sec per scan (200k pts, 0.1 m res); HBM GB/s vs roofline",
@@ -390,10 +408,13 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
                                    "(re-inserted every step), cloud resident in HBM",
                        "rays": rays, "resolution": res, "block_depth": args.depth,
                        "parallelism": f"block-sharded over {world} GPUs: replicated map, contiguous equal-weight ranges of the "
-                                      "test blocks per rank, one RCCL all-gather of leaf (alpha,beta,state) per insert, "
+                                      "test blocks per rank, one in-place all-gather-v of the leaves' (alpha, beta, state) per insert "
+                                      "queued on the map's stream (9 B per leaf, no padding, no host synchronisation), "
                                       "front end + partition + commit + prune redundant on every rank",
                        "voxel_updates_last_step": int(st["voxel_updates"]), "test_blocks": int(st["n_test_blocks"]),
-                       "allgather_payload_bytes_per_rank_approx": 9 * int(st["voxel_updates"]) // world},
+                       "allgather_v_bytes_total": 9 * int(st["voxel_updates"]),
+                       "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}},
+            "stages_ms_rank0": stages,
             "roofline": {"bound": "hbm", "achieved": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9,
                          "peak": 8000.0, "unit": "GB/s",
                          "frac": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9 / 8000.0,

@@ -259,6 +259,7 @@ typedef struct la3dm_devmap_stats {
     uint64_t n_blocks;                 /* blocks in the pool after the scan */
     uint32_t n_passes;                 /* 1 + repeats of a key in the candidate list */
     double t_frontend, t_partition, t_pack, t_kernel, t_commit, t_total; /* seconds, host clock at sync points */
+    double t_gather;                   /* sharded insert with LA3DM_TIMING=1: the all-gather-v (else inside t_kernel) */
 } la3dm_devmap_stats;
 
 /* The devmap keeps a pointer to `ctx`: destroy the devmap BEFORE the context (la3dm_destroy refuses — keeps the context
@@ -307,18 +308,29 @@ int la3dm_devmap_lv_set_original_size(la3dm_devmap *dm, int original_size);
 int la3dm_devmap_lv_training(la3dm_devmap *dm, float *samples4, uint32_t cap_samples, float *rays6, uint32_t cap_rays,
                              uint32_t *n_samples, uint32_t *n_rays);
 
-/* Block-sharded insert across the GPUs of a node (BASELINE.json configs[4]; the loop that is sharded is the test-block
- * loop of src/bgkoctomap/bgkoctomap.cpp:293-336).  Every rank holds a full replica of the map and is handed the SAME
- * cloud; front end and partition run redundantly (cheaper than a broadcast), the test-block list is cut into `world`
- * contiguous ranges of equal weight in candidate order, rank r predicts + fuses range r only, then ONE all-gather of the
- * leaf payload (alpha | beta | state, 9 B per leaf, padded to the largest range) reassembles the updated leaves on
- * every rank, and commit + prune run everywhere: after the call all replicas are identical to a single-GPU map, bit for
- * bit.  The library has no communication dependency: `fn` is called once per pass with the DEVICE pointer of the payload
- * ([world][bytes_per_rank]; slice `rank` is filled and the stream has been synchronised) and must return 0 after the
- * all-gather has completed (ncclAllGather / torch.distributed.all_gather_into_tensor on it, then a stream sync).
+/* Block-sharded insert_pointcloud (BASELINE configs[4]): `world` replicas of the map, one per GPU / process,
+ * every one is handed the same cloud; front end and partition run redundantly, the test-block list is cut into `world`
+ * contiguous ranges of equal weight in candidate order, rank r predicts + fuses range r only, then ONE all-gather-v
+ * reassembles the updated leaves on every rank, and commit + prune run everywhere: after the call all replicas are
+ * identical to a single-GPU map, bit for bit.
+ * The exchange is IN PLACE on the scan's leaf arrays (alpha, beta: 4 B per leaf, state: 1 B per leaf; a rank's leaves are
+ * a contiguous index range of each): no pack / unpack copies, no padding — the payload is exactly 9 B per leaf of the scan.
+ * The library has no communication dependency: `fn` is called once per pass with nseg = 3 segments; for segment s, rank q
+ * owns bytes [offset[q], offset[q] + bytes[q]) of the DEVICE buffer `base` (filled for q = rank by work already queued
+ * on `stream`), and fn must queue on `stream` — or order against it — an all-gather-v that fills every other rank's
+ * bytes, e.g. between ncclGroupStart / ncclGroupEnd one ncclBroadcast(base + offset[q], base + offset[q], bytes[q],
+ * ncclUint8, q, comm, stream) per rank and segment.  Nothing synchronises the host: the library queues commit and prune
+ * behind the call on the same stream.  fn returns 0 on success.  A rank whose own kernel launch failed still calls fn (its
+ * bytes are then not meaningful) so that no peer waits in the collective for ever, and reports the error afterwards.
  * world = 1 switches sharding off.  Variants 0 (BGK) and 1 (GP). */
-typedef int (*la3dm_allgather_fn)(void *user, void *payload, uint64_t bytes_per_rank, uint32_t world);
-int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user);
+typedef struct la3dm_gather_seg {
+    void *base;              /* device pointer */
+    const uint64_t *offset;  /* [world] byte offset of rank q's range */
+    const uint64_t *bytes;   /* [world] byte count of rank q's range */
+} la3dm_gather_seg;
+typedef int (*la3dm_allgatherv_fn)(void *user, const la3dm_gather_seg *segs, uint32_t nseg, uint32_t world, uint32_t rank,
+                                   void *stream);
+int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user);
 int la3dm_devmap_block_count(la3dm_devmap *dm, uint32_t *n_blocks, uint32_t *nodes_per_block);
 /* keys[n_blocks]; A, B, S [n_blocks * nodes_per_block], node order = depth-major (8^d - 1)/7 + index;
  * S: bits 0-2 State (FREE 0, OCCUPIED 1, UNKNOWN 2, PRUNED 3), bit 7 = classified */

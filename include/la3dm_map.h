@@ -20,6 +20,7 @@ typedef struct la3dm_scan_stats {
     uint64_t n_hits, n_frees, n_bbox_blocks, n_train_blocks, n_test_blocks;
     uint64_t voxel_updates, train_reads, pair_evals, n_tiles;
     double t_frontend, t_partition, t_pack, t_device, t_commit, t_prune, t_total;
+    double t_gather; /* sharded device-resident insert with LA3DM_TIMING=1: the all-gather-v (otherwise part of t_device) */
 } la3dm_scan_stats;
 
 /* BGKOctoMap(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh, prior_A, prior_B) */
@@ -84,7 +85,7 @@ la3dm_ctx *la3dm_map_ctx(la3dm_map *m);
 int la3dm_map_set_device_resident(la3dm_map *m, int on);
 /* block-sharded insert_pointcloud over `world` replicas of the map, one per GPU (la3dm_devmap_set_shard, la3dm_hip.h);
  * the map must be device resident; world = 1 switches it off */
-int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user);
+int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user);
 int la3dm_map_is_device_resident(const la3dm_map *m);
 
 int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out);

@@ -15,8 +15,13 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 HIP_SO = os.path.join(_CSRC, "libla3dm_hip.so")
 MAP_SO = os.path.join(_CSRC, "libla3dm_map.so")
 
-# la3dm_allgather_fn (include/la3dm_hip.h): int fn(void *user, void *payload, uint64_t bytes_per_rank, uint32_t world)
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32)
+class GatherSeg(C.Structure):
+    """la3dm_gather_seg (include/la3dm_hip.h)"""
+    _fields_ = [("base", C.c_void_p), ("offset", C.POINTER(C.c_uint64)), ("bytes", C.POINTER(C.c_uint64))]
+
+
+# la3dm_allgatherv_fn: int fn(void *user, const la3dm_gather_seg *segs, uint32_t nseg, uint32_t world, uint32_t rank, void *stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(GatherSeg), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 
 LEAF_UPDATED = 0x80
 SCAN_UPDATE_UNGATED = 0x1
@@ -53,7 +58,7 @@ class ScanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_hits", "n_frees", "n_bbox_blocks", "n_train_blocks", "n_test_blocks",
                                            "voxel_updates", "train_reads", "pair_evals", "n_tiles")] + \
                [(n, C.c_double) for n in ("t_frontend", "t_partition", "t_pack", "t_device", "t_commit", "t_prune",
-                                          "t_total")]
+                                          "t_total", "t_gather")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -64,7 +69,7 @@ class DevmapStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("n_hits", "n_frees", "n_train_blocks", "n_test_blocks", "n_bbox_blocks",
                                           "voxel_updates", "train_reads", "pair_evals", "n_blocks")] + \
                [("n_passes", C.c_uint32)] + \
-               [(k, C.c_double) for k in ("t_frontend", "t_partition", "t_pack", "t_kernel", "t_commit", "t_total")]
+               [(k, C.c_double) for k in ("t_frontend", "t_partition", "t_pack", "t_kernel", "t_commit", "t_total", "t_gather")]
 
 
 HIP_SYMBOLS = ["la3dm_device_count", "la3dm_version", "la3dm_create", "la3dm_destroy", "la3dm_last_error",

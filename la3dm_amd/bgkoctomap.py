@@ -64,15 +64,21 @@ class BGKOctoMap:
     def is_device_resident(self):
         return bool(self._M.la3dm_map_is_device_resident(self._h))
 
-    def set_shard(self, rank, world, allgather):
+    def set_shard(self, rank, world, allgatherv):
         """Block-sharded insert_pointcloud over `world` replicas of this map, one process per GPU (every process
-        inserts the same clouds): rank r predicts + fuses its contiguous range of the test blocks and
-        `allgather(payload_ptr, bytes_per_rank, world)` — called once per pass with the device pointer of the
-        [world][bytes_per_rank] leaf payload, slice `rank` filled — must complete an in-place all-gather before it
-        returns (la3dm_amd.sharding.torch_allgather builds one on torch.distributed).  world = 1 switches it off."""
-        def _cb(user, payload, bytes_per_rank, nranks):
+        inserts the same clouds): rank r predicts + fuses its contiguous range of the test blocks, then
+        `allgatherv(segments, world, rank, stream)` is called once per pass — segments = [(base_ptr, offsets, nbytes), ...]
+        (three: the scan's alpha, beta and state arrays; rank q owns bytes [offsets[q], offsets[q] + nbytes[q]) of each)
+        — and must queue, on the HIP stream `stream` (an integer handle) or ordered against it, an in-place
+        all-gather-v of every segment; nothing synchronises the host (la3dm_devmap_set_shard in include/la3dm_hip.h;
+        la3dm_amd.sharding.torch_allgather builds one on torch.distributed).  world = 1 switches it off."""
+        self._shard_error = None
+
+        def _cb(user, segs, nseg, nranks, r, stream):
             try:
-                allgather(int(payload), int(bytes_per_rank), int(nranks))
+                seg_list = [(int(segs[i].base), [int(segs[i].offset[q]) for q in range(nranks)],
+                             [int(segs[i].bytes[q]) for q in range(nranks)]) for i in range(nseg)]
+                allgatherv(seg_list, int(nranks), int(r), int(stream or 0))
                 return 0
             except Exception as e:           # never let an exception cross the C boundary
                 self._shard_error = e
@@ -88,6 +94,9 @@ class BGKOctoMap:
 
     def _chk(self, rc):
         if rc < 0:
+            err, self._shard_error = getattr(self, "_shard_error", None), None
+            if err is not None:          # the all-gather callback raised: that is the cause
+                raise RuntimeError(self._M.la3dm_map_last_error().decode()) from err
             raise RuntimeError(self._M.la3dm_map_last_error().decode())
         return rc
 

@@ -77,10 +77,11 @@ struct la3dm_devmap {
     la3dm_devmap_lv_stats lv_stats;
     // block-sharded insert (la3dm_devmap_set_shard)
     uint32_t shard_rank = 0, shard_world = 1;
-    la3dm_allgather_fn shard_fn = nullptr;
+    la3dm_allgatherv_fn shard_fn = nullptr;
     void *shard_user = nullptr;
-    Arena shard_w, shard_cumw, shard_bounds, shard_payload;
+    Arena shard_w, shard_cumw, shard_bounds;
     uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
+    std::vector<uint64_t> shard_off[3], shard_bytes[3];   // the all-gather-v's segments (alpha, beta, state), per rank
     uint32_t n_xy = 0;
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
     uint32_t mailbox_seq = 0;
@@ -523,7 +524,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node,
                     &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan,
-                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds, &dm->shard_payload,
+                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds,
                     &dm->lv_rng, &dm->lv_flags, &dm->lv_seg, &dm->lv_nsamp, &dm->lv_nray, &dm->lv_samp_off, &dm->lv_ray_off, &dm->lv_samples,
                     &dm->lv_rays, &dm->lv_sorted, &dm->lv_cell_off, &dm->lv_axis, &dm->lv_keys, &dm->lv_mult, &dm->lv_flag, &dm->lv_pos,
                     &dm->lv_slot, &dm->lv_center, &dm->lv_cell0, &dm->lv_pslot, &dm->lv_pmult, &dm->lv_info, &dm->lv_prune, &dm->lv_beam, &dm->lv_mask};
@@ -867,8 +868,10 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         DM_RESERVE(dm->shard_w, 4ull * n_test);
         DM_RESERVE(dm->shard_cumw, 4ull * n_test);
         DM_RESERVE(dm->shard_bounds, 8ull * (world + 1));
+        // (a block's weight is capped so that the 32-bit running sum cannot wrap: n_test * cap < 2^31 — ADVICE r02)
+        const uint32_t w_cap = std::max<uint32_t>(32u, (uint32_t)((1ull << 31) / n_test));
         hipLaunchKernelGGL(dm_shard_weight, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr, n_test,
-                           (uint32_t *)dm->shard_w.ptr);
+                           w_cap, (uint32_t *)dm->shard_w.ptr);
         if ((rc = exclusive_scan(dm, (const uint32_t *)dm->shard_w.ptr, (uint32_t *)dm->shard_cumw.ptr, n_test)) != LA3DM_OK) return rc;
         hipLaunchKernelGGL(dm_shard_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_cumw.ptr,
                            (const uint32_t *)dm->shard_w.ptr, n_test, world, (uint32_t *)dm->shard_bounds.ptr);
@@ -942,7 +945,6 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.beta = (float *)dm->leaf_beta.ptr;
     s.state = (uint8_t *)dm->leaf_state.ptr;
     s.flags = P.flags;
-    uint32_t chunk = 0;
     if (sharded) {
         // this rank's contiguous range of test blocks; leaf_off holds absolute leaf indices, so offsetting the per-block
         // arrays is all the kernel needs
@@ -950,10 +952,11 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         hipLaunchKernelGGL(dm_shard_leaf_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_bounds.ptr,
                            (const uint32_t *)leaf_off, world, lb);
         DM_TRY(hipMemcpyAsync(dm->h_shard, dm->shard_bounds.ptr, 8ull * (world + 1), hipMemcpyDeviceToHost, st));
-        DM_TRY(hipStreamSynchronize(st));
+        DM_TRY(hipStreamSynchronize(st));   // (the one host wait of the sharded path: launch sizes depend on the cut)
         const uint32_t *hb = dm->h_shard, *hl = dm->h_shard + (world + 1);
-        for (uint32_t q = 0; q < world; ++q) chunk = std::max(chunk, hl[q + 1] - hl[q]);
-        chunk = (chunk + 63u) & ~63u;
+        for (uint32_t q = 0; q < world; ++q)
+            if (hb[q] > hb[q + 1] || hb[q + 1] > n_test || hl[q] > hl[q + 1])
+                return dm_fail(dm, LA3DM_ERR_HIP, "devmap: internal error: the range cut of the sharded insert is not monotone");
         const uint32_t t0s = hb[dm->shard_rank], t1s = hb[dm->shard_rank + 1];
         s.nbr += 7ull * t0s;
         s.blk_center += 3ull * t0s;
@@ -965,30 +968,46 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         rc = ctx->p.variant == 1   ? la3dm_gp_scan_device(ctx, &s, st, nullptr)
              : ctx->p.variant == 3 ? la3dm_bgkl_scan_device(ctx, &s, st, nullptr)
                                    : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
-    if (rc != LA3DM_OK) return rc;
-    if (sharded && chunk) {
-        // one all-gather of the leaf payload (alpha, beta, state: 9 B per leaf) reassembles the updated leaves on every
-        // rank; commit and prune then run everywhere on identical data
+    if (rc != LA3DM_OK && !sharded) return rc;
+    double tg0 = tp1;
+    if (sharded) {
+        // ONE all-gather-v, in place on the leaf arrays (a rank's leaves are a contiguous index range of alpha, beta and
+        // state: 9 B per leaf, no pack / unpack, no padding), queued on this stream by the callback; commit and prune
+        // follow on the same stream on identical data everywhere.  A rank whose launch failed still enters the
+        // collective (its peers would wait for ever otherwise) and reports afterwards.
+        const int rc_kernel = rc;
         const uint32_t *hl = dm->h_shard + (world + 1);
-        const uint32_t first = hl[dm->shard_rank], n_own = hl[dm->shard_rank + 1] - first;
-        DM_RESERVE(dm->shard_payload, 9ull * chunk * world);
-        uint8_t *payload = (uint8_t *)dm->shard_payload.ptr;
-        if (n_own)
-            hipLaunchKernelGGL(dm_shard_pack, dim3(cdiv(n_own, 256)), dim3(256), 0, st, (const float *)dm->leaf_alpha.ptr,
-                               (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr, first, n_own, chunk,
-                               payload + 9ull * chunk * dm->shard_rank);
-        DM_TRY(hipStreamSynchronize(st));  // the callback runs on the caller's streams: hand over a finished slice
-        const int xrc = dm->shard_fn(dm->shard_user, payload, 9ull * chunk, world);
+        for (int g = 0; g < 3; ++g) {
+            dm->shard_off[g].resize(world);
+            dm->shard_bytes[g].resize(world);
+        }
+        for (uint32_t q = 0; q < world; ++q) {
+            const uint64_t f = hl[q], n_q = hl[q + 1] - hl[q];
+            dm->shard_off[0][q] = dm->shard_off[1][q] = 4 * f;
+            dm->shard_bytes[0][q] = dm->shard_bytes[1][q] = 4 * n_q;
+            dm->shard_off[2][q] = f;
+            dm->shard_bytes[2][q] = n_q;
+        }
+        la3dm_gather_seg segs[3] = {{dm->leaf_alpha.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()},
+                                    {dm->leaf_beta.ptr, dm->shard_off[1].data(), dm->shard_bytes[1].data()},
+                                    {dm->leaf_state.ptr, dm->shard_off[2].data(), dm->shard_bytes[2].data()}};
+        if (dm->stage_timing) {
+            DM_TRY(hipStreamSynchronize(st));
+            tg0 = wall();
+        }
+        const int xrc = hl[world] ? dm->shard_fn(dm->shard_user, segs, 3, world, dm->shard_rank, (void *)st) : 0;
+        if (rc_kernel != LA3DM_OK) return rc_kernel;
         if (xrc != 0) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed");
-        hipLaunchKernelGGL(dm_shard_unpack, dim3(std::min(cdiv(chunk, 256), 512u), world), dim3(256), 0, st, (const uint8_t *)payload,
-                           (const uint32_t *)dm->shard_bounds.ptr + (world + 1), world, dm->shard_rank, chunk,
-                           (float *)dm->leaf_alpha.ptr, (float *)dm->leaf_beta.ptr, (uint8_t *)dm->leaf_state.ptr);
+        if (dm->stage_timing) {
+            DM_TRY(hipStreamSynchronize(st));
+            S.t_gather += wall() - tg0;
+        }
     }
     double tp2 = tp1;
     if (dm->stage_timing) {
         DM_TRY(hipStreamSynchronize(st));
         tp2 = wall();
-        S.t_kernel += tp2 - tp1;
+        S.t_kernel += (sharded ? tg0 : tp2) - tp1;
     }
     // f3: write-back + prune
     hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
@@ -1424,7 +1443,7 @@ int la3dm_devmap_wait_event(la3dm_devmap *dm, void *event) {
     return LA3DM_OK;
 }
 
-int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
+int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user) {
     if (!dm) return LA3DM_ERR_ARG;
     if (world == 0 || world > 1023 || rank >= world || (world > 1 && !fn))
         return dm_fail(dm, LA3DM_ERR_ARG, "la3dm_devmap_set_shard: need rank < world <= 1023 and a callback when world > 1");

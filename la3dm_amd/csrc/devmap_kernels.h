@@ -947,9 +947,9 @@ __global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ 
 
 // ---- block-sharded insert: every rank builds the same test list, predicts a contiguous range of it ----
 // weight of a test block for the balance = its neighbourhood size (what the kernel streams) + a constant per tile
-__global__ void dm_shard_weight(const uint32_t *__restrict__ t_key, uint32_t n_test, uint32_t *__restrict__ w) {
+__global__ void dm_shard_weight(const uint32_t *__restrict__ t_key, uint32_t n_test, uint32_t cap, uint32_t *__restrict__ w) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_test) w[t] = test_key_weight(t_key[t]) + 16u;
+    if (t < n_test) w[t] = min(test_key_weight(t_key[t]) + 16u, cap);
 }
 // bounds[q] = first test block of rank q (q = 0..world): the list is cut where the running weight crosses q/world of
 // the total — contiguous ranges of the candidate order (x-major block index order: spatially coherent), equal work
@@ -972,30 +972,6 @@ __global__ void dm_shard_leaf_bounds(const uint32_t *__restrict__ bounds, const 
     const uint32_t q = threadIdx.x;
     if (q <= world) leaf_bounds[q] = leaf_off[bounds[q]];
 }
-// payload slice of rank r: alpha[chunk] | beta[chunk] | state[chunk] (bytes 9 * chunk); pack copies this rank's leaves
-// in, unpack copies every other rank's leaves out after the all-gather
-__global__ void dm_shard_pack(const float *__restrict__ alpha, const float *__restrict__ beta, const uint8_t *__restrict__ state,
-                              uint32_t first, uint32_t n, uint32_t chunk, uint8_t *__restrict__ slice) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    ((float *)slice)[i] = alpha[first + i];
-    ((float *)(slice + 4ull * chunk))[i] = beta[first + i];
-    slice[8ull * chunk + i] = state[first + i];
-}
-__global__ void dm_shard_unpack(const uint8_t *__restrict__ payload, const uint32_t *__restrict__ leaf_bounds, uint32_t world,
-                                uint32_t self, uint32_t chunk, float *__restrict__ alpha, float *__restrict__ beta,
-                                uint8_t *__restrict__ state) {
-    const uint32_t q = blockIdx.y;
-    if (q == self) return;
-    const uint32_t first = leaf_bounds[q], n = leaf_bounds[q + 1] - first;
-    const uint8_t *slice = payload + 9ull * chunk * q;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        alpha[first + i] = ((const float *)slice)[i];
-        beta[first + i] = ((const float *)(slice + 4ull * chunk))[i];
-        state[first + i] = slice[8ull * chunk + i];
-    }
-}
-
 // work counters of one pass: sum over test blocks of their neighbourhood size (train_reads) and of
 // neighbourhood size x leaf count (pair_evals), accumulated as 64-bit words inside the counter block
 __global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf,

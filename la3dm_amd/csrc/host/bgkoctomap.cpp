@@ -1550,7 +1550,7 @@ void BGKOctoMap::commit() {
     stats.t_prune = wall() - t1;
 }
 
-void BGKOctoMap::set_shard(uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
+void BGKOctoMap::set_shard(uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user) {
     if (dmap == nullptr) throw std::runtime_error("set_shard: the map is not in device-resident mode");
     if (la3dm_devmap_set_shard(dmap, rank, world, fn, user) != LA3DM_OK) throw std::runtime_error(la3dm_last_error(ctx));
 }
@@ -1597,6 +1597,7 @@ void BGKOctoMap::take_device_stats(const la3dm_devmap_stats &ds) {
     stats.t_pack = ds.t_pack;
     stats.t_device = ds.t_kernel;
     stats.t_commit = ds.t_commit;
+    stats.t_gather = ds.t_gather;
 }
 
 void BGKOctoMap::insert_pointcloud(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,

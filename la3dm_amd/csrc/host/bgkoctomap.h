@@ -238,6 +238,7 @@ struct ScanStats {
     uint64_t pair_evals = 0;     // P
     uint64_t n_tiles = 0;
     double t_frontend = 0, t_partition = 0, t_pack = 0, t_device = 0, t_commit = 0, t_prune = 0, t_total = 0;
+    double t_gather = 0;   // sharded device-resident insert with LA3DM_TIMING=1: the all-gather-v of the leaves
 };
 
 class BGKOctoMap {
@@ -340,7 +341,7 @@ public:
     bool is_device_resident() const { return dmap != nullptr; }
     /// Block-sharded insert_pointcloud across `world` GPUs (one process per GPU, every process holds a replica of the map
     /// and inserts the same clouds): see la3dm_devmap_set_shard in include/la3dm_hip.h.  Needs the device-resident mode.
-    void set_shard(uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user);
+    void set_shard(uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user);
     void sync_mirror() const;
     void take_device_stats(const la3dm_devmap_stats &ds);
     /// training set (x, y, z, label) the device front end produced for the last scan

@@ -185,6 +185,7 @@ int la3dm_map_stats(const la3dm_map *m, la3dm_scan_stats *out) {
     out->n_tiles = s.n_tiles;
     out->t_frontend = s.t_frontend; out->t_partition = s.t_partition; out->t_pack = s.t_pack;
     out->t_device = s.t_device; out->t_commit = s.t_commit; out->t_prune = s.t_prune; out->t_total = s.t_total;
+    out->t_gather = s.t_gather;
     return 0;
 }
 
@@ -207,7 +208,7 @@ int la3dm_map_training_data(const la3dm_map *m, float *xyzy, uint64_t cap) {
 
 int la3dm_map_set_device_resident(la3dm_map *m, int on) { GUARD(m->map->set_device_resident(on != 0); return 0;) }
 int la3dm_map_is_device_resident(const la3dm_map *m) { return m->map->is_device_resident() ? 1 : 0; }
-int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allgather_fn fn, void *user) {
+int la3dm_map_set_shard(la3dm_map *m, uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user) {
     GUARD(m->map->set_shard(rank, world, fn, user); return 0;)
 }
 

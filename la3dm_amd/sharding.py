@@ -81,26 +81,70 @@ class _DeviceBytes:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
 
 
+def gather_v(dist, buf, offsets, nbytes, r, world, async_op=False):
+    """in-place all-gather-v of one byte buffer (a uint8 tensor, host or device): rank q's range [offsets[q], offsets[q] +
+    nbytes[q]) is filled on rank q and broadcast to the others; equal contiguous ranges take one all_gather_into_tensor.
+    -> the list of pending works (async_op) or []"""
+    works = []
+    even = len(set(nbytes)) == 1 and all(offsets[q] == q * nbytes[0] for q in range(world))
+    if even and nbytes[0]:
+        # (the input is slice `rank` of the output; a private copy of it keeps the call clear of any in-place /
+        # aliasing rule of the backend)
+        w = dist.all_gather_into_tensor(buf[:world * nbytes[0]], buf[r * nbytes[0]:(r + 1) * nbytes[0]].clone(), async_op=async_op)
+        works.append(w)
+    elif not even:
+        for q in range(world):
+            if nbytes[q]:
+                works.append(dist.broadcast(buf[offsets[q]:offsets[q] + nbytes[q]], src=q, async_op=async_op))
+    return [w for w in works if w is not None] if async_op else []
+
+
+def leaf_segments(leaf_bounds):
+    """host mirror of what la3dm_devmap_insert_* hands the callback: (offsets, nbytes) per rank for the alpha, beta (4 B per
+    leaf) and state (1 B per leaf) arrays, from the leaf index bounds [world + 1] of the ranks' ranges"""
+    lb = [int(x) for x in leaf_bounds]
+    n = [lb[q + 1] - lb[q] for q in range(len(lb) - 1)]
+    four = ([4 * x for x in lb[:-1]], [4 * x for x in n])
+    return [four, four, (lb[:-1], n)]
+
+
 def torch_allgather(dist, rank, device, stage_through_host=False):
-    """-> allgather(payload_ptr, bytes_per_rank, world) for BGKOctoMap.set_shard: ONE in-place all-gather of the leaf
-    payload (RCCL over xGMI when the process group's backend is "nccl").  stage_through_host: the gloo self-test on a
-    single GPU (all ranks on cuda:0) — the payload goes through host memory; never a measurement."""
+    """-> allgatherv(segments, world, rank, stream) for BGKOctoMap.set_shard: the in-place all-gather-v of the scan's leaf
+    arrays on torch.distributed (RCCL over xGMI when the process group's backend is "nccl"), queued on the map's own HIP
+    stream (wrapped as a torch ExternalStream: the collective waits for what the library queued before it, what the
+    library queues after it waits for the collective; no host synchronisation).  Rank q owns a different number of leaves
+    in general, so every segment is `world` broadcasts (src = q) of rank q's byte range, issued asynchronously and
+    completed together — an all-gather-v; when all ranges happen to be equal it is one all_gather_into_tensor.
+    stage_through_host: the gloo self-test on a single GPU (all ranks on cuda:0) — the payload goes through host memory,
+    with the synchronisations that needs; never a measurement."""
     import torch
 
-    def allgather(ptr, bytes_per_rank, world):
-        buf = torch.as_tensor(_DeviceBytes(ptr, bytes_per_rank * world), device=device)
-        mine = buf[rank * bytes_per_rank:(rank + 1) * bytes_per_rank]
-        if stage_through_host:
-            out = torch.empty(bytes_per_rank * world, dtype=torch.uint8)
-            dist.all_gather_into_tensor(out, mine.cpu())
-            buf.copy_(out)
-        else:
-            # (the input is slice `rank` of the output; a private copy of it — a few MB — keeps the call clear of any
-            # in-place / aliasing rule of the backend)
-            dist.all_gather_into_tensor(buf, mine.clone())
-        torch.cuda.synchronize(device)
+    def allgatherv(segments, world, r, stream):
+        ext = torch.cuda.ExternalStream(stream, device=device) if stream else torch.cuda.current_stream(device)
+        with torch.cuda.stream(ext):
+            works = []
+            for base, offsets, nbytes in segments:
+                end = max(o + n for o, n in zip(offsets, nbytes))
+                if end == 0:
+                    continue
+                buf = torch.as_tensor(_DeviceBytes(base, end), device=device)
+                if stage_through_host:
+                    ext.synchronize()
+                    for q in range(world):
+                        if nbytes[q] == 0:
+                            continue
+                        part = buf[offsets[q]:offsets[q] + nbytes[q]]
+                        h = part.cpu() if q == r else torch.empty(nbytes[q], dtype=torch.uint8)
+                        dist.broadcast(h, src=q)
+                        if q != r:
+                            part.copy_(h)
+                    ext.synchronize()
+                    continue
+                works += gather_v(dist, buf, offsets, nbytes, r, world, async_op=True)
+            for w in works:
+                w.wait()          # (NCCL: makes `ext` wait for the collective on the device; does not block the host)
 
-    return allgather
+    return allgatherv
 
 
 def balanced_ranges(weights, world):
@@ -108,7 +152,9 @@ def balanced_ranges(weights, world):
     into `world` contiguous ranges where the running weight (neighbourhood size + 16 per block) crosses q / world of the
     total.  -> bounds [world + 1]"""
     w = np.asarray(weights, np.uint64) + 16
+    if len(w):
+        w = np.minimum(w, np.uint64(max(32, (1 << 31) // len(w))))
     cum = np.concatenate([[0], np.cumsum(w)[:-1]]).astype(np.uint64)          # exclusive
-    total = int(cum[-1] + w[-1]) if len(w) else 0
+    total = int(cum[-1] + w[-1]) if len(w) else 0   # (the device caps a block's weight at 2^31 / n so that its 32-bit sum cannot wrap)
     b = [int(np.searchsorted(cum, np.uint64(total * q // world), side="left")) for q in range(world)]
     return np.array(b + [len(w)], np.int64)

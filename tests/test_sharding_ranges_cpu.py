@@ -1,6 +1,6 @@
 """CPU coverage of the device-resident sharded insert's host-visible logic (la3dm_amd/sharding.py): the range cut that
-mirrors dm_shard_bounds, and the payload exchange protocol (pack -> ONE in-place all-gather -> unpack) driven over a
-2-rank gloo group with the device step emulated in numpy."""
+mirrors dm_shard_bounds, and the exchange protocol (ONE in-place all-gather-v over the alpha / beta / state arrays: a rank's
+leaves are a contiguous range of each) driven over 2- and 3-rank gloo groups with the device step emulated in numpy."""
 import os
 import sys
 
@@ -36,37 +36,28 @@ def _rank(rank, world, port, ret):
     leaf_off = np.concatenate([[0], np.cumsum(nleaf)])
     bounds = sharding.balanced_ranges(rng.integers(0, 300, n_test), world)
     lb = leaf_off[bounds]
-    chunk = int(((np.diff(lb).max() + 63) // 64) * 64)
     truth_a = rng.random(leaf_off[-1]).astype(np.float32)
     truth_b = rng.random(leaf_off[-1]).astype(np.float32)
     truth_s = rng.integers(0, 256, leaf_off[-1]).astype(np.uint8)
     a, b, s = np.zeros_like(truth_a), np.zeros_like(truth_b), np.zeros_like(truth_s)
     lo, hi = lb[rank], lb[rank + 1]                      # "predict + fuse" of this rank's range only
     a[lo:hi], b[lo:hi], s[lo:hi] = truth_a[lo:hi], truth_b[lo:hi], truth_s[lo:hi]
-    payload = np.zeros(9 * chunk * world, np.uint8)      # dm_shard_pack
-    sl = payload[9 * chunk * rank:9 * chunk * (rank + 1)]
-    sl[:4 * (hi - lo)] = a[lo:hi].view(np.uint8)
-    sl[4 * chunk:4 * chunk + 4 * (hi - lo)] = b[lo:hi].view(np.uint8)
-    sl[8 * chunk:8 * chunk + (hi - lo)] = s[lo:hi]
-    t = torch.from_numpy(payload)
-    dist.all_gather_into_tensor(t, t[9 * chunk * rank:9 * chunk * (rank + 1)].clone())   # the ONE collective
-    for q in range(world):                               # dm_shard_unpack
-        if q == rank:
-            continue
-        n = lb[q + 1] - lb[q]
-        sq = payload[9 * chunk * q:9 * chunk * (q + 1)]
-        a[lb[q]:lb[q + 1]] = sq[:4 * n].view(np.float32)
-        b[lb[q]:lb[q + 1]] = sq[4 * chunk:4 * chunk + 4 * n].view(np.float32)
-        s[lb[q]:lb[q + 1]] = sq[8 * chunk:8 * chunk + n]
+    # the exchange: ONE in-place all-gather-v over the three leaf arrays (no pack / unpack, no padding), exactly the
+    # segments la3dm_devmap_insert_* hands the callback
+    for arr, (offsets, nbytes) in zip((a, b, s), sharding.leaf_segments(lb)):
+        sharding.gather_v(dist, torch.from_numpy(arr.view(np.uint8)), offsets, nbytes, rank, world)
     ret[rank] = bool((a == truth_a).all() and (b == truth_b).all() and (s == truth_s).all())
     dist.destroy_process_group()
 
 
-def test_payload_protocol_two_ranks_gloo():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_payload_protocol_gloo(world):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29800 + os.getpid() % 100
+    port = 29800 + (os.getpid() + 7 * world) % 100
     procs = [mp.get_context("spawn").Process(target=_rank, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
