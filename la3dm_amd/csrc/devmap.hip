@@ -1153,7 +1153,7 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         DM_RESERVE(dm->lv_beam, sizeof(LvBeam) * (size_t)nh);
         DM_RESERVE(dm->lv_mask, 8ull * nh * nw);
         hipLaunchKernelGGL(dm_lv_beam_init, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (LvBeam *)dm->lv_beam.ptr);
-        hipLaunchKernelGGL(dm_lv_nearby, dim3(nw, nh), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+        hipLaunchKernelGGL(dm_lv_nearby, dim3(nw, cdiv(nh, kLvNearTile)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
                            (const LvBeam *)dm->lv_beam.ptr, (unsigned long long *)dm->lv_mask.ptr);
         const int lds_hits = 12ull * nh <= 60000 ? 1 : 0;   // the hit list in LDS (2 workgroups per CU still fit)
         hipLaunchKernelGGL(dm_lv_beams_walk, dim3(cdiv(nh, 64)), dim3(64), lds_hits ? 12 * nh : 0, st, d_hits, nh, ba,

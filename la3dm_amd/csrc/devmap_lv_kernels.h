@@ -157,18 +157,25 @@ __global__ __launch_bounds__(256) void dm_lv_beam_init(const float *__restrict__
     b.pz = pz;
     beams[h] = b;
 }
-// grid (ceil(nh / 64), nh), 64 threads: mask[h * nw + w] bit j <=> hit 64 w + j is "nearby" for beam h AND within `influence`
-// of the beam's line
+// grid (ceil(nh / 64), ceil(nh / kLvNearTile)), 64 threads: mask[h * nw + w] bit j <=> hit 64 w + j is "nearby" for beam h AND
+// within `influence` of the beam's line.  A wave keeps its 64 hits in registers and walks a tile of kLvNearTile beams (their
+// records are wave-uniform scalar loads): one wave per (beam, 64 hits) re-read the hit list once per beam — 24 GB through
+// the L2 at 45 k hits, 6.2 ms.
+constexpr uint32_t kLvNearTile = 256;
 __global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
                                                   const LvBeam *__restrict__ beams, unsigned long long *__restrict__ mask) {
-    const uint32_t h = blockIdx.y, q = blockIdx.x * 64u + threadIdx.x;
-    const LvBeam b = beams[h];
-    bool near = false;
-    if (q < nh) {
-        const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
-        const double dist2 = rng[q];
+    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+    const bool have = q < nh;
+    const float qx = have ? hits[3 * (size_t)q] : 0.f, qy = have ? hits[3 * (size_t)q + 1] : 0.f, qz = have ? hits[3 * (size_t)q + 2] : 0.f;
+    const double dist2 = have ? rng[q] : 0.0;
+    const bool in_range = have && !(a.max_range > 0 && dist2 > a.max_range);
+    const bool low = (double)qz < (double)a.oz + a.influence;
+    const uint32_t h0 = blockIdx.y * kLvNearTile, h1 = min(nh, h0 + kLvNearTile);
+    for (uint32_t h = h0; h < h1; ++h) {
+        const LvBeam b = beams[h];
+        bool near = false;
         const bool high = (double)b.pz > (a.offset + (double)a.oz);
-        if (!(a.max_range > 0 && dist2 > a.max_range) && !(high && (double)qz < (double)a.oz + a.influence)) {
+        if (in_range && !(high && low)) {
             const double dist1 = lv_norm(b.ex - qx, b.ey - qy, b.ez - qz);
             near = dist1 < a.influence || (dist1 < b.l0 && dist2 < b.l0);
             if (near) {
@@ -184,9 +191,9 @@ __global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hit
                 near = lv_norm(qx - mx, qy - my, qz - mz) < a.influence;
             }
         }
+        const unsigned long long m = __ballot(near);
+        if (threadIdx.x == 0) mask[(size_t)h * gridDim.x + blockIdx.x] = m;
     }
-    const unsigned long long m = __ballot(near);
-    if (threadIdx.x == 0) mask[(size_t)h * gridDim.x + blockIdx.x] = m;
 }
 __global__ __launch_bounds__(64) void dm_lv_beams_walk(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
                                                       const LvBeam *__restrict__ beams, const unsigned long long *__restrict__ mask,
