@@ -350,9 +350,61 @@ constexpr int kRing5 = 432;  // with the 64 scratch slots and the zero entry the
 // just below 1 may have a kernel value of a few 1e-8 that this threshold drops.
 constexpr uint32_t kHitTBits = 0x3f77c08du;
 
+// B, four candidates per trip, PACKED fp32: a VALU instruction occupies the SIMD for ~4 cycles whatever it is
+// (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0 in this kernel), so v_pk_add / v_pk_mul_f32 — two candidates per
+// instruction — halve the cost of the distance: 8 packed instructions per PAIR of candidates
+//   (dx, dy, dz)(A,B) = (X, Y, Z)(A,B) - (xs, ys, zs);  d2 = dx*dx + (dy*dy + dz*dz)   (bgkinference.h:88-93, same association)
+// against 8 per candidate.  The leaf's coordinates are broadcast to both halves by op_sel; the two pairs of a trip
+// alternate so that no packed instruction reads the result of the one before it (one wait state).  Registers are fixed
+// (v40-v63): the halves of a packed result feed v_cmp and ds_write separately.
+//   v[52:55] X of the four candidates, v[56:59] Y, v[60:63] Z;  pair 0 -> d2 in v40, v41;  pair 1 -> v46, v47
+// Push of one candidate (5 VALU + 4 SALU + 1 LDS): hit mask in vcc; the scalar popcount and the next entry word sit
+// between the v_cmp and the first VALU reader of vcc (gfx940: two wait states); hit lanes write {d2, entry word} at
+// ring[tail + rank] under exec = hit mask.
+#define LA3DM_RP_LOAD                                                                     \
+    "ds_read_b128 v[52:55], %[ca]\n"                                                     \
+    "ds_read_b128 v[56:59], %[ca] offset:272\n"                                          \
+    "ds_read_b128 v[60:63], %[ca] offset:544\n"                                          \
+    "s_waitcnt lgkmcnt(0)\n"
+#define LA3DM_RP_SUB(DX, DY, DZ, X, Y, Z)                                                 \
+    "v_pk_add_f32 " DX ", " X ", %[xy] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"      \
+    "v_pk_add_f32 " DY ", " Y ", %[xy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n" \
+    "v_pk_add_f32 " DZ ", " Z ", %[zz] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define LA3DM_RP_SQ(DX, DY, DZ)                                                           \
+    "v_pk_mul_f32 " DX ", " DX ", " DX "\n"                                              \
+    "v_pk_mul_f32 " DY ", " DY ", " DY "\n"                                              \
+    "v_pk_mul_f32 " DZ ", " DZ ", " DZ "\n"
+#define LA3DM_RP_PUSH(D, I, IN)                             \
+    "v_cmp_gt_f32 vcc, %[T], " D "\n"                       \
+    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
+    "v_add_u32 " IN ", 4, " I "\n"                          \
+    "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
+    "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
+    "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
+    "s_mov_b64 exec, vcc\n"                                 \
+    "ds_write2_b32 %[tr], " D ", " I " offset1:1\n"         \
+    "s_mov_b64 exec, -1\n"                                  \
+    "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
+
+// the ordered kernel's push: the same, + the lane's hit bit shifted into its history word (h = 2 h + hit: v_addc with the
+// mask as carry, after the write — it overwrites vcc) and a plain candidate index as the entry word
+#define LA3DM_RP_PUSH_H(D, I, IN)                           \
+    "v_cmp_gt_f32 vcc, %[T], " D "\n"                       \
+    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
+    "v_add_u32 " IN ", 1, " I "\n"                          \
+    "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
+    "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
+    "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
+    "s_mov_b64 exec, vcc\n"                                 \
+    "ds_write2_b32 %[tr], " D ", " I " offset1:1\n"         \
+    "s_mov_b64 exec, -1\n"                                  \
+    "v_addc_co_u32 %[h], vcc, %[h], %[h], vcc\n"            \
+    "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
+typedef float la3dm_v2f __attribute__((ext_vector_type(2)));
+
 struct __attribute__((aligned(16))) WaveLds5 {
-    float4 cand[kCand5 + 4];       // x/ell, y/ell, z/ell, label (+ padding slots)
-    uint2 ring[kRing5 + kWave + 1];  // {d2, candidate} -> {k, k*y}; then 64 per-lane scratch slots and one {0, 0} entry
+    float cx[kCand5 + 4], cy[kCand5 + 4], cz[kCand5 + 4], cw[kCand5 + 4];   // x/ell, y/ell, z/ell, label: one array per component
+    uint2 ring[kRing5 + kWave + 1];  // {d2, candidate} -> {k, k*y}; (64 spare slots) and one {0, 0} entry
 };
 
 // The two loops that run once per staged candidate are written in gfx950 assembly: the compiler's versions carried
@@ -472,6 +524,9 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
         hix = wave_max_dpp(xs0), hiy = wave_max_dpp(ys0), hiz = wave_max_dpp(zs0);
     }
     const float xs = active ? xs0 : __builtin_nanf(""), ys = ys0, zs = zs0;  // NaN never matches
+    la3dm_v2f xy, zz;   // the leaf's coordinates as packed operands: (xs, ys) and (zs, -)
+    xy.x = xs, xy.y = ys, zz.x = zs, zz.y = 0.0f;
+    (void)xs; (void)ys; (void)zs;
 
     const bool ungated = (a.flags & 1u) != 0;
     bool updated = false;
@@ -506,7 +561,12 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
             last_nb = b;
         }
         const uint32_t slot = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-        if (keep) L.cand[slot] = p;
+        if (keep) {
+            L.cx[slot] = p.x;
+            L.cy[slot] = p.y;
+            L.cz[slot] = p.z;
+            L.cw[slot] = p.w;
+        }
         ncand += (uint32_t)__popcll(m);
     };
 
@@ -535,13 +595,16 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
     const float hit_t = __uint_as_float(kHitTBits);
     // LDS byte addresses (the low 32 bits of a generic pointer into LDS are the LDS offset)
     const uint32_t ring_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&L.ring[0]);
-    const uint32_t scratch_addr = ring_base + 8u * (uint32_t)(kRing5 + lane);
     const uint32_t zero_addr = ring_base + 8u * (uint32_t)(kRing5 + kWave);
     if (lane == 0) L.ring[kRing5 + kWave] = make_uint2(0u, 0u);
     bool more = true;
     while (more) {
         // pad the list to a multiple of four with points no leaf can reach
-        if (lane < 4) L.cand[ncand + lane] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+        if (lane < 4) {
+            L.cx[ncand + lane] = 3.0e18f;
+            L.cy[ncand + lane] = 3.0e18f;
+            L.cz[ncand + lane] = 3.0e18f;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t ngroup = (a.flags & 0x200u) ? 0u : (ncand + 3u) >> 2;  // 0x200: profiling ablation
@@ -552,37 +615,39 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
             uint32_t tailb = ring_base;          // LDS byte address of ring[tail]
             uint32_t hA = 0, hB = 0;             // hit history: candidates 0-31 of this round in hA, 32-63 in hB
             uint32_t idx = 4 * g;                // candidate index, uniform, in a VGPR for the ring entry
+            const uint32_t cand_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&L.cx[0]);
             auto b_trip = [&](uint32_t &hw) {
-                float4 t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = L.cand[4 * g + u];
 #if LA3DM_ASM_B
-                // software-pipelined by hand: the first two instructions of the next candidate sit between a v_cmp and the
-                // first reader of its mask (the gfx940 two-wait-state rule); the last candidate pays an s_nop
-                float a0, a1, tb2, tc, tr;
-                uint32_t st;
-                asm volatile(LA3DM_B_HEAD("%[a0]", "%[x0]", "%[y0]") LA3DM_B_TAIL("%[a0]", "%[z0]")
-                             LA3DM_B_HEAD("%[a1]", "%[x1]", "%[y1]") LA3DM_B_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z1]")
-                             LA3DM_B_HEAD("%[a0]", "%[x2]", "%[y2]") LA3DM_B_PUSH("%[a1]") LA3DM_B_TAIL("%[a0]", "%[z2]")
-                             LA3DM_B_HEAD("%[a1]", "%[x3]", "%[y3]") LA3DM_B_PUSH("%[a0]") LA3DM_B_TAIL("%[a1]", "%[z3]")
-                             "s_nop 1\n" LA3DM_B_PUSH("%[a1]")
-                             : [h] "+v"(hw), [idx] "+v"(idx), [tail] "+s"(tailb), [a0] "=&v"(a0), [a1] "=&v"(a1), [tb] "=&v"(tb2),
-                               [tc] "=&v"(tc), [tr] "=&v"(tr), [st] "=&s"(st)
-                             : [xs] "v"(xs), [ys] "v"(ys), [zs] "v"(zs), [T] "s"(hit_t), [scr] "v"(scratch_addr), [x0] "v"(t[0].x),
-                               [y0] "v"(t[0].y), [z0] "v"(t[0].z), [x1] "v"(t[1].x), [y1] "v"(t[1].y), [z1] "v"(t[1].z),
-                               [x2] "v"(t[2].x), [y2] "v"(t[2].y), [z2] "v"(t[2].z), [x3] "v"(t[3].x), [y3] "v"(t[3].y),
-                               [z3] "v"(t[3].z)
-                             : "vcc", "scc", "memory");  // s_bcnt1 / s_lshl3_add write SCC
+                // packed fp32, two candidates per instruction (LA3DM_RP_* above): 4 + 6 VALU per candidate instead of 8 + 7
+                uint32_t i1, st;
+                float tr;
+                const uint32_t ca = cand_base + 16u * g;
+                asm volatile(LA3DM_RP_LOAD
+                             LA3DM_RP_SUB("v[40:41]", "v[42:43]", "v[44:45]", "v[52:53]", "v[56:57]", "v[60:61]")
+                             LA3DM_RP_SUB("v[46:47]", "v[48:49]", "v[50:51]", "v[54:55]", "v[58:59]", "v[62:63]")
+                             LA3DM_RP_SQ("v[40:41]", "v[42:43]", "v[44:45]")
+                             LA3DM_RP_SQ("v[46:47]", "v[48:49]", "v[50:51]")
+                             "v_pk_add_f32 v[42:43], v[42:43], v[44:45]\n"
+                             "v_pk_add_f32 v[48:49], v[48:49], v[50:51]\n"
+                             "s_nop 0\n"
+                             "v_pk_add_f32 v[40:41], v[40:41], v[42:43]\n"
+                             "v_pk_add_f32 v[46:47], v[46:47], v[48:49]\n"
+                             "s_nop 0\n"
+                             LA3DM_RP_PUSH_H("v40", "%[i0]", "%[i1]") LA3DM_RP_PUSH_H("v41", "%[i1]", "%[i0]")
+                             LA3DM_RP_PUSH_H("v46", "%[i0]", "%[i1]") LA3DM_RP_PUSH_H("v47", "%[i1]", "%[i0]")
+                             : [h] "+v"(hw), [i0] "+v"(idx), [i1] "=&v"(i1), [tail] "+s"(tailb), [tr] "=&v"(tr), [st] "=&s"(st)
+                             : [xy] "v"(xy), [zz] "v"(zz), [T] "s"(hit_t), [ca] "v"(ca)
+                             : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+                               "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 #else
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float dx = t[u].x - xs, dy = t[u].y - ys, dz = t[u].z - zs;
+                    const float dx = L.cx[4 * g + u] - xs, dy = L.cy[4 * g + u] - ys, dz = L.cz[4 * g + u] - zs;
                     const float d2 = dx * dx + (dy * dy + dz * dz);
                     const bool hit = d2 < hit_t;
                     const unsigned long long m = __ballot(hit);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                    const uint32_t slot = hit ? ((tailb - ring_base) >> 3) + rank : (uint32_t)(kRing5 + lane);
-                    L.ring[slot] = make_uint2(__float_as_uint(d2), idx);
+                    if (hit) L.ring[((tailb - ring_base) >> 3) + rank] = make_uint2(__float_as_uint(d2), idx);
                     tailb += 8u * (uint32_t)__popcll(m);
                     idx += 1;
                     hw = (hw << 1) | (hit ? 1u : 0u);
@@ -611,7 +676,7 @@ __global__ __launch_bounds__(kWaves *kWave) __attribute__((amdgpu_waves_per_eu(k
                 const uint32_t i = p + lane;
                 if (i < tail) {
                     const uint2 e = L.ring[i];
-                    const float y = L.cand[e.y].w;
+                    const float y = L.cw[e.y];
                     const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(e.x)), a.sf2);
                     L.ring[i] = make_uint2(__float_as_uint(kv), __float_as_uint(kv * y));
                 }
@@ -760,43 +825,6 @@ struct __attribute__((aligned(16))) WaveLdsR {
     double acc1[kWave];  // binary labels: sum(k) over the label-1 pairs;  any labels: sum(k * y)
     uint2 ring[kRingR];  // {d2, (lane << 13) | (candidate << 2)}
 };
-// B, four candidates per trip, PACKED fp32: a VALU instruction occupies the SIMD for ~4 cycles whatever it is
-// (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0 in this kernel), so v_pk_add / v_pk_mul_f32 — two candidates per
-// instruction — halve the cost of the distance: 8 packed instructions per PAIR of candidates
-//   (dx, dy, dz)(A,B) = (X, Y, Z)(A,B) - (xs, ys, zs);  d2 = dx*dx + (dy*dy + dz*dz)   (bgkinference.h:88-93, same association)
-// against 8 per candidate.  The leaf's coordinates are broadcast to both halves by op_sel; the two pairs of a trip
-// alternate so that no packed instruction reads the result of the one before it (one wait state).  Registers are fixed
-// (v40-v63): the halves of a packed result feed v_cmp and ds_write separately.
-//   v[52:55] X of the four candidates, v[56:59] Y, v[60:63] Z;  pair 0 -> d2 in v40, v41;  pair 1 -> v46, v47
-// Push of one candidate (5 VALU + 4 SALU + 1 LDS): hit mask in vcc; the scalar popcount and the next entry word sit
-// between the v_cmp and the first VALU reader of vcc (gfx940: two wait states); hit lanes write {d2, entry word} at
-// ring[tail + rank] under exec = hit mask.
-#define LA3DM_RP_LOAD                                                                     \
-    "ds_read_b128 v[52:55], %[ca]\n"                                                     \
-    "ds_read_b128 v[56:59], %[ca] offset:272\n"                                          \
-    "ds_read_b128 v[60:63], %[ca] offset:544\n"                                          \
-    "s_waitcnt lgkmcnt(0)\n"
-#define LA3DM_RP_SUB(DX, DY, DZ, X, Y, Z)                                                 \
-    "v_pk_add_f32 " DX ", " X ", %[xy] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"      \
-    "v_pk_add_f32 " DY ", " Y ", %[xy] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n" \
-    "v_pk_add_f32 " DZ ", " Z ", %[zz] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
-#define LA3DM_RP_SQ(DX, DY, DZ)                                                           \
-    "v_pk_mul_f32 " DX ", " DX ", " DX "\n"                                              \
-    "v_pk_mul_f32 " DY ", " DY ", " DY "\n"                                              \
-    "v_pk_mul_f32 " DZ ", " DZ ", " DZ "\n"
-#define LA3DM_RP_PUSH(D, I, IN)                             \
-    "v_cmp_gt_f32 vcc, %[T], " D "\n"                       \
-    "s_bcnt1_i32_b64 %[st], vcc\n"                          \
-    "v_add_u32 " IN ", 4, " I "\n"                          \
-    "v_mbcnt_lo_u32_b32 %[tr], vcc_lo, 0\n"                 \
-    "v_mbcnt_hi_u32_b32 %[tr], vcc_hi, %[tr]\n"             \
-    "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
-    "s_mov_b64 exec, vcc\n"                                 \
-    "ds_write2_b32 %[tr], " D ", " I " offset1:1\n"         \
-    "s_mov_b64 exec, -1\n"                                  \
-    "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
-
-typedef float la3dm_v2f __attribute__((ext_vector_type(2)));
 
 template <int kTrig>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_r(BgkArgs a) {

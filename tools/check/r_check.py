@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import la3dm_amd
 from la3dm_amd import _lib
 
@@ -47,7 +47,7 @@ def compare(name, xyz, origin, res, depth, reps=5, fr=0.5, mr=-1.0):
 
 
 if __name__ == "__main__":
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     xyz, origin = la3dm_amd.load_pcd(os.path.join(root, "tests/golden/data/sim_structured/sim_structured_1.pcd"))
     compare("sim_structured_1 d3", xyz, origin, 0.1, 3, fr=0.5, mr=8.0)
     compare("sim_structured_1 d4", xyz, origin, 0.1, 4, fr=0.5, mr=8.0)
