@@ -62,7 +62,9 @@ static inline int arena_reserve(la3dm_ctx *ctx, Arena &a, size_t bytes) {
         a.ptr = nullptr;
         a.cap = 0;
     }
-    size_t want = bytes + bytes / 2 + 256;   // 50 % head room: a regrow is a device-wide free + malloc (hundreds of us)
+    // 50 % head room: a regrow is a device-wide free + malloc (hundreds of us); above 1 GB an eighth (the BGK-L split
+    // scratch is 64 KB per item: tens of GB on a large scan — ADVICE r02)
+    size_t want = bytes + (bytes > (1ull << 30) ? bytes / 8 : bytes / 2) + 256;
     hipError_t e = hipMalloc(&a.ptr, want);
     if (e != hipSuccess) {
         ctx->err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);

@@ -784,14 +784,21 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         sp.bdesc = (uint4 *)ctx->l_bdesc.ptr;
         sp.nb_first = (uint32_t *)ctx->l_nb_first.ptr;
         sp.part = (float2 *)ctx->l_part.ptr;
-        // every item owns kLItemVals value slots (64 KB): no read-back of the hit total, no second distance pass
-        if ((rc = arena_reserve(ctx, ctx->l_vals, sizeof(float) * (size_t)n_items * kLItemVals)) != LA3DM_OK) return rc;
+        // every item owns kLItemVals value slots (64 KB): no read-back of the hit total, no second distance pass.  The
+        // scratch is sized from a device counter: bound it (a low bgkl_split_rows on a large scan asks for 10^5 items).
+        const size_t vals_bytes = sizeof(float) * (size_t)n_items * kLItemVals;
+        if (vals_bytes > (64ull << 30)) {
+            ctx->err = "la3dm_bgkl_scan: the split path would need " + std::to_string(vals_bytes >> 30) +
+                       " GB of scratch (" + std::to_string(n_items) + " items of 256 rows); raise bgkl_split_rows";
+            return LA3DM_ERR_OOM;
+        }
+        if ((rc = arena_reserve(ctx, ctx->l_vals, vals_bytes)) != LA3DM_OK) return rc;
         sp.vals = (float *)ctx->l_vals.ptr;
         hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_eval, dim3(n_items), dim3(kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
         hipLaunchKernelGGL(bgkl_split_kernelize, dim3(n_items), dim3(256), 0, stream, a, sp);
-        if (ctx->opt_l_dense_add) {
+        if (ctx->opt_l_dense_add && vals_bytes <= (16ull << 30)) {   // (above 16 GB: the replay expands itself, no second 64 KB per item)
             // the replay's expansion done for all items at once, the ordered part left to two waves per chain
             if ((rc = arena_reserve(ctx, ctx->l_dense, sizeof(float) * (size_t)n_items * kLItemVals)) != LA3DM_OK) return rc;
             if ((rc = arena_reserve(ctx, ctx->l_labmask, sizeof(unsigned long long) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;

@@ -6,10 +6,25 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, la3dm_amd
 from oracle import oracle as O
 
-def same(m, o, tag):
+# The library's default BGK sum mode (double accumulators) is compared with the restatement's double-sum mode within one
+# ulp of alpha / beta (states may differ where p sits within 1e-6 of a threshold); LA3DM_BGK_SUM=0 in the environment runs
+# the ordered mode, bit for bit.  The other variants are bit-identical in both.
+SUM1 = os.environ.get("LA3DM_BGK_SUM", "1") != "0"
+O.set_sum_mode(1 if SUM1 else 0)
+
+def same(m, o, tag, ulp=False):
     a, b = m.leaves(), o.leaves()
-    ok = a["A"].size == b["A"].size and all((a[k] == b[k]).all() for k in ("block_key", "node_key", "state", "classified")) \
-        and (a["A"].view(np.uint32) == b["A"].view(np.uint32)).all() and (a["B"].view(np.uint32) == b["B"].view(np.uint32)).all()
+    ok = a["A"].size == b["A"].size and all((a[k] == b[k]).all() for k in ("block_key", "node_key", "classified"))
+    if ok and not ulp:
+        ok = (a["state"] == b["state"]).all() and (a["A"].view(np.uint32) == b["A"].view(np.uint32)).all() and \
+            (a["B"].view(np.uint32) == b["B"].view(np.uint32)).all()
+    elif ok:
+        for k in ("A", "B"):
+            ok = ok and np.abs(a[k].view(np.int32).astype(np.int64) - b[k].view(np.int32)).max(initial=0) <= 1
+        d = a["state"] != b["state"]
+        if ok and d.any():
+            p = b["A"][d].astype(np.float64) / (b["A"][d].astype(np.float64) + b["B"][d])
+            ok = bool((np.minimum(np.abs(p - 0.3), np.abs(p - 0.7)) < 1e-6).all())
     if not ok:
         print("MISMATCH", tag, a["A"].size, b["A"].size, flush=True)
     return ok
@@ -74,7 +89,7 @@ for seed in range(first, first + count):
             ds, mr = res, float(rng.choice([2.5, 6.0, 8.0]))
         m.insert_pointcloud(pts, origin, ds, fr, mr)
         o.insert_pointcloud(pts, origin, ds, fr, mr)
-        if not same(m, o, f"seed {seed} kind {kind} scan {scan} {params} ds={ds} fr={fr} mr={mr} offset={offset.tolist()}"):
+        if not same(m, o, f"seed {seed} kind {kind} scan {scan} {params} ds={ds} fr={fr} mr={mr} offset={offset.tolist()}", ulp=SUM1 and kind == 0):
             bad += 1
             break
     else:
