@@ -82,6 +82,8 @@ struct la3dm_devmap {
     Arena shard_w, shard_cumw, shard_bounds;
     uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
     std::vector<uint64_t> shard_off[3], shard_bytes[3];   // the all-gather-v's segments (alpha, beta, state), per rank
+    Arena shard_hist, shard_nown, shard_own_off, shard_cnt, shard_frees;   // sharded sample filter (front_end)
+    std::vector<uint32_t> shard_hist_host, shard_cnt_host;
     uint32_t n_xy = 0;
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
     uint32_t mailbox_seq = 0;
@@ -524,7 +526,7 @@ void la3dm_devmap_destroy(la3dm_devmap *dm) {
                     &dm->t_key1, &dm->t_ent0, &dm->t_ent1, &dm->t_blockkey, &dm->t_center, &dm->t_nbr, &dm->t_slot, &dm->t_slot0, &dm->nleaf,
                     &dm->leaf_off, &dm->leaf_key, &dm->leaf_alpha, &dm->leaf_beta, &dm->leaf_state, &dm->leaf_node,
                     &dm->l_ray_idx, &dm->l_rays, &dm->l_rows, &dm->l_rows_off, &dm->l_rflag, &dm->l_rscan,
-                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds,
+                    &dm->shard_w, &dm->shard_cumw, &dm->shard_bounds, &dm->shard_hist, &dm->shard_nown, &dm->shard_own_off, &dm->shard_cnt, &dm->shard_frees,
                     &dm->lv_rng, &dm->lv_flags, &dm->lv_seg, &dm->lv_nsamp, &dm->lv_nray, &dm->lv_samp_off, &dm->lv_ray_off, &dm->lv_samples,
                     &dm->lv_rays, &dm->lv_sorted, &dm->lv_cell_off, &dm->lv_axis, &dm->lv_keys, &dm->lv_mult, &dm->lv_flag, &dm->lv_pos,
                     &dm->lv_slot, &dm->lv_center, &dm->lv_cell0, &dm->lv_pslot, &dm->lv_pmult, &dm->lv_info, &dm->lv_prune, &dm->lv_beam, &dm->lv_mask};
@@ -557,6 +559,23 @@ static int training_bbox(la3dm_devmap *dm, bool reduced = false) {
     if (rc != LA3DM_OK) return rc;
     memcpy(dm->h_bbox, dm->h_cnt + kCntBbox, sizeof(float) * 6);
     return LA3DM_OK;
+}
+
+// Sharded sample filter: cut[q] = first layer of rank q (q = 0..world), contiguous ranges whose sample counts cross
+// q / world of the total (mirrored by la3dm_amd/sharding.py layer_cuts for the CPU test).
+static void shard_layer_cuts(const uint32_t *hist, uint32_t nlayer, uint32_t world, std::vector<uint32_t> &cut) {
+    uint64_t total = 0;
+    for (uint32_t j = 0; j < nlayer; ++j) total += hist[j];
+    cut.assign(world + 1, nlayer);
+    cut[0] = 0;
+    uint64_t run = 0;
+    uint32_t q = 1;
+    for (uint32_t j = 0; j < nlayer && q < world; ++j) {
+        // layer j starts at running count `run`: it opens rank q's range when the count has reached q / world of the total
+        while (q < world && run * world >= total * q) cut[q++] = j;
+        run += hist[j];
+    }
+    while (q < world) cut[q++] = nlayer;
 }
 
 // f1 (bgkoctomap.cpp:383-458): voxel grid over the hits, range gate + beam samples, voxel grid over the free samples;
@@ -624,21 +643,124 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     const uint32_t n_kept = dm->h_cnt[kCntKept], n_free_raw = dm->h_cnt[kCntFreeRaw];
     if (n_kept == 0) return LA3DM_OK;
     DM_RESERVE(dm->xy, 16ull * ((size_t)n_kept + n_free_raw));
-    DM_RESERVE(dm->frees_raw, 12ull * n_free_raw);
     float4 *xy = (float4 *)dm->xy.ptr;
     // the beam kernel also reduces the box of the free samples (-> GridParams of the second voxel filter, finished by its
     // last workgroup) and the box of the kept hits (d_mm[8..13]); dm_append_frees then completes the training set's box
     uint32_t *mm_hits = dm->d_mm + 8;
-    {
-        MinmaxFin fin = {1, ds_resolution < 0 ? 1.0f : 1.0f / ds_resolution, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
-        hipLaunchKernelGGL(dm_beam_write, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep, keep_off,
-                           free_off, xy, (float *)dm->frees_raw.ptr, dm->d_mm, fin, mm_hits);
+    const float *d_frees = nullptr;
+    uint32_t n_f = 0;
+    // Block-sharded insert: the samples' voxel filter is divided over the ranks by z-layer of its grid (devmap_kernels.h,
+    // "sharded sample filter"); every rank ends up with the same filtered list, in the single-GPU order.
+    const GridParams &g1 = *dm->h_gp;   // (grid of the cloud's own filter: the box of the raw hits)
+    bool sharded_filter = dm->shard_world > 1 && !(ds_resolution < 0) && !g1.passthrough && !g1.empty;
+    int zbase = 0;
+    uint32_t nlayer = 0;
+    if (sharded_filter) {
+        // every sample lies between the origin and a filtered hit (a centroid of raw hits): its layer is inside
+        // [min(origin, box) - 1, max(origin, box) + 1]
+        const float inv = 1.0f / ds_resolution;
+        const double oz = floor((double)origin[2] * (double)inv);
+        const double lo = std::min((double)g1.lo[2], oz) - 1.0, hi = std::max((double)g1.lo[2] + g1.span[2] - 1.0, oz) + 1.0;
+        if (hi - lo + 1.0 > (double)kShardLayers || fabs(lo) > 1e9 || fabs(hi) > 1e9) sharded_filter = false;   // (a very tall scan: unsharded filter)
+        else {
+            zbase = (int)lo;
+            nlayer = (uint32_t)(hi - lo + 1.0);
+        }
     }
-    const float *d_frees = (const float *)dm->frees_raw.ptr;
-    uint32_t n_f = n_free_raw;
-    if (!(ds_resolution < 0)) {
-        if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f, free_key_bits, true)) != LA3DM_OK) return rc;
-        d_frees = (const float *)dm->frees_ds.ptr;
+    if (!sharded_filter) {
+        DM_RESERVE(dm->frees_raw, 12ull * n_free_raw);
+        {
+            MinmaxFin fin = {1, ds_resolution < 0 ? 1.0f : 1.0f / ds_resolution, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
+            hipLaunchKernelGGL(dm_beam_write<false>, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep,
+                               keep_off, free_off, xy, (float *)dm->frees_raw.ptr, dm->d_mm, fin, mm_hits, 0.0f, 0, 0);
+        }
+        d_frees = (const float *)dm->frees_raw.ptr;
+        n_f = n_free_raw;
+        if (!(ds_resolution < 0)) {
+            if ((rc = voxel_grid(dm, d_frees, n_free_raw, ds_resolution, dm->frees_ds, &n_f, free_key_bits, true)) != LA3DM_OK) return rc;
+            d_frees = (const float *)dm->frees_ds.ptr;
+        }
+    } else {
+        const float inv = 1.0f / ds_resolution;
+        const uint32_t world = dm->shard_world, rank = dm->shard_rank;
+        // 1. samples per layer -> contiguous layer ranges of equal sample count
+        DM_RESERVE(dm->shard_hist, 4ull * kShardLayers);
+        DM_TRY(hipMemsetAsync(dm->shard_hist.ptr, 0, 4ull * nlayer, st));
+        hipLaunchKernelGGL(dm_beam_hist, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep, inv, zbase,
+                           nlayer, (uint32_t *)dm->shard_hist.ptr, dm->d_cnt);
+        dm->shard_hist_host.resize(nlayer);
+        DM_TRY(hipMemcpyAsync(dm->shard_hist_host.data(), dm->shard_hist.ptr, 4ull * nlayer, hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));
+        std::vector<uint32_t> cut;
+        shard_layer_cuts(dm->shard_hist_host.data(), nlayer, world, cut);   // [world + 1] layer indices relative to zbase
+        const int lo = zbase + (int)cut[rank], hi = zbase + (int)cut[rank + 1];
+        if (getenv("LA3DM_DEBUG_SHARD"))
+            fprintf(stderr, "la3dm sharded sample filter: rank %u of %u takes layers [%d, %d) of [%d, %d), %u raw samples in all\n", rank, world,
+                    lo, hi, zbase, zbase + (int)nlayer, n_free_raw);
+        // 2. own samples per beam -> offsets, total
+        DM_RESERVE(dm->shard_nown, 4ull * n_h);
+        DM_RESERVE(dm->shard_own_off, 4ull * n_h);
+        uint32_t *nown = (uint32_t *)dm->shard_nown.ptr, *own_off = (uint32_t *)dm->shard_own_off.ptr;
+        hipLaunchKernelGGL(dm_beam_count_own, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, inv, lo, hi, nown);
+        if ((rc = exclusive_scan(dm, nown, own_off, n_h, (int)kCntFreeRaw, true)) != LA3DM_OK) return rc;
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        const uint32_t n_own = dm->h_cnt[kCntFreeRaw];
+        // 3. kept hits -> xy, own samples -> frees_raw, the box of ALL samples -> the filter grid's (global) parameters
+        DM_RESERVE(dm->frees_raw, 12ull * (n_own ? n_own : 1));
+        {
+            MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
+            hipLaunchKernelGGL(dm_beam_write<true>, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep,
+                               keep_off, own_off, xy, (float *)dm->frees_raw.ptr, dm->d_mm, fin, mm_hits, inv, lo, hi);
+        }
+        // 4. this rank's cells.  (The grid's parameters come back with the filter's counters; a rank without samples fetches
+        //    them on its own: whether the grid overflows int32 — PCL then returns its input unfiltered, which the layer
+        //    split cannot reproduce — must be decided identically everywhere BEFORE the first collective.)
+        uint32_t n_f_own = 0;
+        if (n_own) {
+            if ((rc = voxel_grid(dm, (const float *)dm->frees_raw.ptr, n_own, ds_resolution, dm->frees_ds, &n_f_own, free_key_bits, true)) != LA3DM_OK)
+                return rc;
+        } else {
+            if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+            memcpy(dm->h_gp, dm->h_cnt + kCntGrid, sizeof(GridParams));
+        }
+        if (dm->h_gp->passthrough)
+            return dm_fail(dm, LA3DM_ERR_ARG, "devmap: sharded insert: the samples' filter grid overflows int32 (PCL passes the cloud through); use one GPU");
+        // 5. all-gather-v of the filtered points behind a 4-byte-per-rank count exchange: every rank gets the whole list,
+        //    rank order = ascending cell index = the single-GPU order
+        DM_RESERVE(dm->shard_cnt, 4ull * world);
+        DM_TRY(hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &n_f_own, 4, hipMemcpyHostToDevice, st));
+        dm->shard_off[0].resize(world);
+        dm->shard_bytes[0].resize(world);
+        for (uint32_t q = 0; q < world; ++q) {
+            dm->shard_off[0][q] = 4ull * q;
+            dm->shard_bytes[0][q] = 4;
+        }
+        la3dm_gather_seg seg = {dm->shard_cnt.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()};
+        if (dm->shard_fn(dm->shard_user, &seg, 1, world, rank, (void *)st) != 0)
+            return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed (sample counts)");
+        dm->shard_cnt_host.resize(world);
+        DM_TRY(hipMemcpyAsync(dm->shard_cnt_host.data(), dm->shard_cnt.ptr, 4ull * world, hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));
+        uint64_t total = 0, mine_at = 0;
+        for (uint32_t q = 0; q < world; ++q) {
+            if (q == rank) mine_at = total;
+            dm->shard_off[0][q] = 12ull * total;
+            dm->shard_bytes[0][q] = 12ull * dm->shard_cnt_host[q];
+            total += dm->shard_cnt_host[q];
+        }
+        if (dm->shard_cnt_host[rank] != n_f_own || total > 0xFFFFFFFFull)
+            return dm_fail(dm, LA3DM_ERR_HIP, "devmap: sharded sample filter: inconsistent counts after the exchange");
+        n_f = (uint32_t)total;
+        if (n_f) {
+            DM_RESERVE(dm->shard_frees, 12ull * n_f);
+            if (n_f_own)
+                hipLaunchKernelGGL(dm_copy_f3, dim3(cdiv(3 * n_f_own, 256)), dim3(256), 0, st, (const float *)dm->frees_ds.ptr, 3 * n_f_own,
+                                   (float *)dm->shard_frees.ptr + 3 * mine_at);
+            la3dm_gather_seg seg2 = {dm->shard_frees.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()};
+            if (dm->shard_fn(dm->shard_user, &seg2, 1, world, rank, (void *)st) != 0)
+                return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed (filtered samples)");
+        }
+        d_frees = (const float *)dm->shard_frees.ptr;
     }
     const float free_label = ctx->p.variant == 1 ? -1.0f : 0.0f;  // bgkoctomap.cpp:415 / gpoctomap.cpp:399
     bool box_reduced = false;

@@ -626,11 +626,20 @@ __global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ h
 // hits that pass the gate -> xy (label 1) in order; their beam samples -> frees (xyz) in order
 // Also reduces, on the way, the box of the free samples it writes (the second voxel filter's grid: its min/max launch
 // and one-thread parameter launch are gone) and the box of the kept hits (half of the training set's box).
+// kOwn (sharded sample filter, below): free_off = offsets of the OWN samples, only samples whose filter layer
+// (int)floorf(z * inv) lies in [lo, hi) are written; the box is still the box of all samples.
+template <bool kOwn>
 __global__ __launch_bounds__(256) void dm_beam_write(const float *__restrict__ hits, uint32_t n, BeamArgs a,
                                                     const uint32_t *__restrict__ keep,
                                                     const uint32_t *__restrict__ keep_off,
                                                     const uint32_t *__restrict__ free_off, float4 *xy, float *frees,
-                                                    uint32_t *mm_frees, MinmaxFin fin_frees, uint32_t *mm_hits) {
+                                                    uint32_t *mm_frees, MinmaxFin fin_frees, uint32_t *mm_hits, float inv, int lo,
+                                                    int hi) {
+    auto own = [&](float sz) {
+        if (!kOwn) return true;
+        const int L = (int)floorf(sz * inv);
+        return L >= lo && L < hi;
+    };
     __shared__ float red[4][6];
     __shared__ uint32_t s_last;
     float fmn[3] = {INFINITY, INFINITY, INFINITY}, fmx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -644,19 +653,25 @@ __global__ __launch_bounds__(256) void dm_beam_write(const float *__restrict__ h
         const float l = f32_sqrt_cr(dx * dx + dy * dy + dz * dz);
         const float nx = dx / l, ny = dy / l, nz = dz / l;
         float *f = frees + 3 * (size_t)free_off[i];
-        f[0] = a.ox; f[1] = a.oy; f[2] = a.oz;
+        if (own(a.oz)) {
+            f[0] = a.ox; f[1] = a.oy; f[2] = a.oz;
+            f += 3;
+        }
         box_add(fmn, fmx, a.ox, a.oy, a.oz);
-        f += 3;
         for (float d = a.free_res; d < l; d += a.free_res) {
             const float sx = a.ox + nx * d, sy = a.oy + ny * d, sz = a.oz + nz * d;
-            f[0] = sx; f[1] = sy; f[2] = sz;
+            if (own(sz)) {
+                f[0] = sx; f[1] = sy; f[2] = sz;
+                f += 3;
+            }
             box_add(fmn, fmx, sx, sy, sz);
-            f += 3;
         }
         if (l > a.free_res) {
             const float d = l - a.free_res;
             const float sx = a.ox + nx * d, sy = a.oy + ny * d, sz = a.oz + nz * d;
-            f[0] = sx; f[1] = sy; f[2] = sz;
+            if (own(sz)) {
+                f[0] = sx; f[1] = sy; f[2] = sz;
+            }
             box_add(fmn, fmx, sx, sy, sz);
         }
     }
@@ -665,6 +680,65 @@ __global__ __launch_bounds__(256) void dm_beam_write(const float *__restrict__ h
     none.mode = 0;
     minmax_wg(hmn, hmx, mm_hits, none, red, &s_last);
     minmax_wg(fmn, fmx, mm_frees, fin_frees, red, &s_last);
+}
+
+// ---- sharded sample filter (block-sharded insert, la3dm_devmap_set_shard): the second voxel filter — the largest stage of
+// the front end — is divided over the ranks by ABSOLUTE z-LAYER of its grid: layer(s) = (int)floorf(s.z * inv), the same
+// expression dm_grid_cells uses, so a cell's samples all carry one layer.  The filter's linear cell index has z slowest
+// (bgkoctomap.cpp:419-431 -> pcl::VoxelGrid: idx = i0 + i1 d0 + i2 d0 d1), so a contiguous range of layers is a
+// contiguous range of cell indices: every cell lives on exactly one rank with ALL its samples in cloud order (the fp32
+// centroid chain is unchanged), and the ranks' filtered outputs, concatenated in rank order, ARE the single-GPU output.
+// Three walks over the beams (each is the float-stepped loop of beam_sample, bgkoctomap.cpp:433-458, positions included):
+//   dm_beam_hist        samples per layer (<= kShardLayers bins, LDS-private per workgroup) -> the host cuts the layers
+//   dm_beam_count_own   samples of beam i inside this rank's layer range
+//   dm_beam_write<true> kept hits -> xy as usual; only the own samples are written; the box of ALL samples is reduced
+//                       (the filter grid's parameters must be the global ones)
+constexpr uint32_t kShardLayers = 1024;
+template <class F>
+__device__ __forceinline__ void beam_walk_z(float x, float y, float z, const BeamArgs &a, F &&f) {   // f(sz) per sample, in order
+    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+    const float l = f32_sqrt_cr(dx * dx + dy * dy + dz * dz);
+    const float nz = dz / l;
+    f(a.oz);
+    uint32_t c = 1;
+    for (float d = a.free_res; d < l && c < kBeamCap; d += a.free_res, ++c) f(a.oz + nz * d);
+    if (l > a.free_res) f(a.oz + nz * (l - a.free_res));
+}
+__global__ __launch_bounds__(256) void dm_beam_hist(const float *__restrict__ hits, uint32_t n, BeamArgs a,
+                                                   const uint32_t *__restrict__ keep, float inv, int zbase, uint32_t nlayer,
+                                                   uint32_t *__restrict__ hist, uint32_t *counters) {
+    __shared__ uint32_t s_h[kShardLayers];
+    for (uint32_t j = threadIdx.x; j < nlayer; j += blockDim.x) s_h[j] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!keep[i]) continue;
+        beam_walk_z(hits[3 * (size_t)i], hits[3 * (size_t)i + 1], hits[3 * (size_t)i + 2], a, [&](float sz) {
+            const int L = (int)floorf(sz * inv) - zbase;
+            if ((unsigned)L < nlayer) atomicAdd(&s_h[L], 1u);
+            else atomicOr(&counters[kCntError], 1u);   // outside the bound the host derived from the cloud's box: cannot happen
+        });
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nlayer; j += blockDim.x)
+        if (s_h[j]) atomicAdd(&hist[j], s_h[j]);
+}
+__global__ __launch_bounds__(256) void dm_beam_count_own(const float *__restrict__ hits, uint32_t n, BeamArgs a,
+                                                        const uint32_t *__restrict__ keep, float inv, int lo, int hi,
+                                                        uint32_t *__restrict__ nown) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = 0;
+    if (keep[i])
+        beam_walk_z(hits[3 * (size_t)i], hits[3 * (size_t)i + 1], hits[3 * (size_t)i + 2], a, [&](float sz) {
+            const int L = (int)floorf(sz * inv);
+            c += (L >= lo && L < hi) ? 1u : 0u;
+        });
+    nown[i] = c;
+}
+// (rank q's filtered points into their place of the common list: a plain copy, after the count exchange)
+__global__ void dm_copy_f3(const float *__restrict__ src, uint32_t n3, float *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) dst[i] = src[i];
 }
 
 // ---- BGKLOctoMap front end (src/bgkloctomap/bgkloctomap.cpp:300-343, beam_sample :359-381): a hit is re-projected

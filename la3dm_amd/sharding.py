@@ -147,6 +147,24 @@ def torch_allgather(dist, rank, device, stage_through_host=False):
     return allgatherv
 
 
+def layer_cuts(hist, world):
+    """host mirror of shard_layer_cuts (la3dm_amd/csrc/devmap.hip): the sharded sample filter cuts the z-layers of the filter
+    grid into `world` contiguous ranges — layer j opens rank q's range when the running sample count has reached q / world
+    of the total.  -> cut [world + 1] (layer indices)"""
+    hist = [int(x) for x in hist]
+    total, n = sum(hist), len(hist)
+    cut = [0] + [n] * world
+    run, q = 0, 1
+    for j in range(n):
+        if q >= world:
+            break
+        while q < world and run * world >= total * q:
+            cut[q] = j
+            q += 1
+        run += hist[j]
+    return np.array(cut, np.int64)
+
+
 def balanced_ranges(weights, world):
     """host mirror of dm_shard_weight / dm_shard_bounds (devmap_kernels.h): cut the test-block list (candidate order)
     into `world` contiguous ranges where the running weight (neighbourhood size + 16 per block) crosses q / world of the

@@ -31,7 +31,7 @@ def main():
         m.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)
     lv = m.leaves()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: lv[k] for k in ("block_key", "node_key", "A", "B", "state", "classified")},
-             voxel_updates=np.int64(m.stats()["voxel_updates"]))
+             voxel_updates=np.int64(m.stats()["voxel_updates"]), training=m.training_data())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
 """Block-sharded, device-resident insert_pointcloud: `world` replicas of the map,
 every rank predicts + fuses a contiguous range of the test blocks (src/bgkoctomap/bgkoctomap.cpp:293-336 is the loop
-that is cut), one all-gather of the leaf payload, commit + prune everywhere.  Bar: every replica ends up BIT-IDENTICAL to
+that is cut), one in-place all-gather-v of the leaves, commit + prune everywhere; the samples' voxel filter of the front end is
+divided over the ranks by z-layer of its grid and its output all-gathered.  Bar: every replica ends up BIT-IDENTICAL to
 the map a single process builds from the same clouds — two fused scans, so the second one runs on a pruned pool.
 The ranks share the one GPU of the test box and exchange over gloo; with RCCL only the transport changes."""
 import os
@@ -23,21 +24,27 @@ def _single(variant, rays):
     for pose in (None, (1.5, 0.5, 1.0)):
         xyz, origin = la3dm_amd.synthetic_scan(rays, origin=pose)
         m.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)
-    return m.leaves(), int(m.stats()["voxel_updates"])
+    return m.leaves(), int(m.stats()["voxel_updates"]), m.training_data()
 
 
 @pytest.mark.parametrize("variant,rays,world", [("d3", 30000, 2), ("d4", 20000, 3), ("gp", 8000, 2)])
 def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant, rays, world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_DEBUG_SHARD="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + (os.getpid() % 500)), os.path.join(ROOT, "tests", "helpers", "shard_worker.py"),
            str(tmp_path), variant, str(rays)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    ref, U = _single(variant, rays)
+    for rank in range(world):        # the sharded form of the samples' filter really ran, on every rank
+        assert f"sharded sample filter: rank {rank} of {world}" in r.stderr, r.stderr[-2000:]
+    ref, U, train = _single(variant, rays)
     for rank in range(world):
         got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         assert int(got["voxel_updates"]) == U
+        # the samples' voxel filter is divided over the ranks by z-layer and all-gathered (devmap_kernels.h "sharded sample
+        # filter"): every rank must hold the single-process training set of the last scan, point for point, in its order
+        assert got["training"].shape == train.shape, (rank, got["training"].shape, train.shape)
+        assert (got["training"].view(np.uint32) == train.view(np.uint32)).all(), rank
         assert got["block_key"].size == ref["block_key"].size, rank
         for k in ("block_key", "node_key", "state", "classified"):
             assert (got[k] == ref[k]).all(), (rank, k)

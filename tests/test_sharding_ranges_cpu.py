@@ -25,6 +25,23 @@ def test_balanced_ranges_cover_the_list_once_and_balance_the_weight():
     assert (sharding.balanced_ranges(np.zeros(0), 4) == 0).all()
 
 
+def test_layer_cuts_of_the_sharded_sample_filter():
+    """the z-layer cut of the samples' voxel filter (mirror of shard_layer_cuts): contiguous, monotone, covers every layer once,
+    balanced to within the heaviest layer"""
+    from la3dm_amd import sharding
+    rng = np.random.default_rng(5)
+    for n, world in ((1, 2), (3, 8), (80, 2), (80, 8), (700, 8), (64, 3)):
+        hist = rng.integers(0, 5000, n)
+        hist[n // 3] += 200000                     # the sensor's layer holds a sample of every beam
+        cut = sharding.layer_cuts(hist, world)
+        assert cut[0] == 0 and cut[-1] == n and (np.diff(cut) >= 0).all()
+        per = np.array([hist[cut[q]:cut[q + 1]].sum() for q in range(world)], np.float64)
+        assert per.sum() == hist.sum()
+        if n >= 8 * world:
+            assert per.max() <= hist.sum() / world + hist.max()
+    assert (sharding.layer_cuts(np.zeros(10, np.int64), 4)[1:-1] == 0).all()
+
+
 def _rank(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
