@@ -146,12 +146,24 @@ __device__ __forceinline__ float rl(float v, int lane_idx) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx));
 }
 
+// Round 3.  The launch of configs[2] at depth 4 (3 364 large blocks, 1 255 of them with N > 352, N <= 528) took 4.7 ms.
+// Timestamps inside the kernel (wall_clock64 per phase) for the N = 518 block: 2.1 ms in the alpha solve (lane = row reading
+// its own row of the row-major factor: 32 cache lines per load, and a dependent global load of the pivot per step) -> now
+// 32 x 32 tiles through LDS, the solved part read with v_readlane (0.5 ms); results of the substitutions stored one row per
+// lane -> now 16-byte stores along the rows after a pass through LDS.  3.3 ms.  What remains is memory: every block re-reads
+// its factor ~9 times from HBM (the row panels of each 32 x 32 block, ~4.6 MB per N = 518 block; 2 048 blocks in flight
+// are 1.4 GB, nothing stays in the 4 MB L2s), VALU issue is at 30 %, the matrix cores at 12 % (profiles/r03/gp_train_pmc.txt).
+// Tried and dropped (all bit-identical, all slower): four waves per block with row panel J in LDS and the pairs of a column
+// dealt to the waves (one 1.1 ms block instead of 2.2 ms, but 4.3 wave-ms per block instead of 2.2: the diagonal block is
+// redundant per wave, the alpha solve serial, 129 KB of LDS leave one block per CU -> 1 024 blocks in 3.45 ms); the same
+// for the N > 352 blocks only (3.45 + 1.55 ms, the launches serialise).
+constexpr int kTileF = 32 * 36;   // floats of one operand tile in LDS
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void gp_train_kernel(GpArgs a) {
     // MFMA operand tiles of L (rows x 32 columns of an earlier block column), fetched as four coalesced 16-byte loads per
     // lane and passed through LDS: read straight from the row-major factor, lane c = row c touches 32 cache lines per load
     // and the wave waits a memory round trip per k-pair (this kernel was latency bound: 9.6 ms for 4 726 blocks).
     // The accumulator -> [row][col] transposes (s_tile) happen after the operand loop and share the space.
-    __shared__ __attribute__((aligned(16))) float s_lds[3 * 32 * 36];
+    __shared__ __attribute__((aligned(16))) float s_lds[3 * kTileF];
     float (*s_op)[32][36] = reinterpret_cast<float (*)[32][36]>(s_lds);
     float (*s_tile)[32][kTrT] = reinterpret_cast<float (*)[32][kTrT]>(s_lds);
     if (blockIdx.x >= (uint32_t)a.totals[2]) return;   // (the launch has one workgroup per training block; the large ones are listed)
@@ -208,19 +220,46 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             g[i] = q;
         }
     };
-    auto store_tile = [&](int t, const float4 (&g)[4]) {
+    // the diagonal tile of the last block may reach beyond column N - 1: element-wise there
+    auto load_tile_edge = [&](float4 (&g)[4], int R, int T) {
+        if (32 * T + 32 <= N) {
+            load_tile(g, R, T, true);
+            return;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&s_op[t][8 * i + trow][tcol]) = g[i];
+        for (int i = 0; i < 4; ++i) {
+            const int row = R + 8 * i + trow;
+            float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (row < N && 32 * T + tcol + e < N) q[e] = L[(size_t)row * N + 32 * T + tcol + e];
+            g[i] = make_float4(q[0], q[1], q[2], q[3]);
+        }
     };
-    auto read_ops = [&](int t, float (&o)[16]) {   // operand layout: lane (c, h) holds tile[c][2 m2 + h]
+    auto store_to = [&](float (*tile)[36], const float4 (&g)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&tile[8 * i + trow][tcol]) = g[i];
+    };
+    auto store_tile = [&](int t, const float4 (&g)[4]) { store_to(s_op[t], g); };
+    auto read_from = [&](const float (*tile)[36], float (&o)[16]) {   // operand layout: lane (c, h) holds tile[c][2 m2 + h]
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float4 q = *reinterpret_cast<const float4 *>(&s_op[t][c][4 * i]);
+            const float4 q = *reinterpret_cast<const float4 *>(&tile[c][4 * i]);
             o[2 * i] = h ? q.y : q.x;
             o[2 * i + 1] = h ? q.w : q.z;
         }
     };
-
+    auto read_ops = [&](int t, float (&o)[16]) { read_from(s_op[t], o); };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto group_sync = [&]() {   // the wave's own global accesses are ordered (lanes read what other lanes wrote)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     for (int J = 0; J < nblk; ++J) {
         const int RJ = 32 * J;
         // ---------------- diagonal block ----------------
@@ -235,8 +274,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 for (int T = 0; T < J; ++T) {
                     float lv[16];
                     store_tile(0, g);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync();
                     read_ops(0, lv);
                     if (T + 1 < J) load_tile(g, RJ, T + 1, true);
                     __builtin_amdgcn_wave_barrier();
@@ -245,8 +283,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
             to_tile(C, 0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
 #pragma unroll
             for (int w = 0; w < 32; ++w) dg[w] = s_tile[0][c][w];
             __builtin_amdgcn_wave_barrier();
@@ -276,40 +313,36 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
                 for (int r = 0; r < 16; ++r) C1[r] = 0.0f;
             }
-            {
-                float4 g0[4], g1[4], gb[4];
-                if (J > 0) {
-                    load_tile(g0, RI0, 0, true);
-                    load_tile(g1, RI1, 0, two);
-                    load_tile(gb, RJ, 0, true);
+            float4 g0[4], g1[4], gb[4];
+            if (J > 0) {
+                load_tile(g0, RI0, 0, true);
+                load_tile(g1, RI1, 0, two);
+                load_tile(gb, RJ, 0, true);
+            }
+            for (int T = 0; T < J; ++T) {
+                float a0[16], a1[16], bv[16];
+                store_tile(0, g0);
+                store_tile(1, g1);
+                store_tile(2, gb);
+                wave_sync();
+                read_ops(0, a0);
+                read_ops(1, a1);
+                read_ops(2, bv);
+                if (T + 1 < J) {   // the next tiles are in flight while this block's 32 MFMAs run
+                    load_tile(g0, RI0, T + 1, true);
+                    load_tile(g1, RI1, T + 1, two);
+                    load_tile(gb, RJ, T + 1, true);
                 }
-                for (int T = 0; T < J; ++T) {
-                    float a0[16], a1[16], bv[16];
-                    store_tile(0, g0);
-                    store_tile(1, g1);
-                    store_tile(2, gb);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    read_ops(0, a0);
-                    read_ops(1, a1);
-                    read_ops(2, bv);
-                    if (T + 1 < J) {   // the next tiles are in flight while this block's 32 MFMAs run
-                        load_tile(g0, RI0, T + 1, true);
-                        load_tile(g1, RI1, T + 1, two);
-                        load_tile(gb, RJ, T + 1, true);
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int m2 = 0; m2 < 16; ++m2) {
-                        C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0[m2], bv[m2], C0, 0, 0, 0);
-                        C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1[m2], bv[m2], C1, 0, 0, 0);
-                    }
+                for (int m2 = 0; m2 < 16; ++m2) {
+                    C0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0[m2], bv[m2], C0, 0, 0, 0);
+                    C1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1[m2], bv[m2], C1, 0, 0, 0);
                 }
             }
             to_tile(C0, 0);
             to_tile(C1, 1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
             float rw[32];  // lane = row: half 0 -> block I, half 1 -> block I + 1
 #pragma unroll
             for (int w = 0; w < 32; ++w) rw[w] = s_tile[h][c][w];
@@ -321,64 +354,132 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 for (int w = 0; w < j; ++w) acc = __builtin_fmaf(-rw[w], rl(dg[w], j), acc);
                 rw[j] = acc / rl(dg[j], j);
             }
-            const int orow = (h ? RI1 : RI0) + c;
-            if (orow < N && (h == 0 || two)) {
-                float *dst = L + (size_t)orow * N + RJ;
+            // back through LDS: 16-byte stores along the rows instead of one row per lane
 #pragma unroll
-                for (int w = 0; w < 32; ++w)
-                    if (RJ + w < N) dst[w] = rw[w];
+            for (int w = 0; w < 32; ++w) s_tile[h][c][w] = rw[w];
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int orow = (t ? RI1 : RI0) + 8 * i + trow;
+                    const float4 q = make_float4(s_tile[t][8 * i + trow][tcol], s_tile[t][8 * i + trow][tcol + 1],
+                                                 s_tile[t][8 * i + trow][tcol + 2], s_tile[t][8 * i + trow][tcol + 3]);
+                    if (orow < N) __builtin_memcpy(L + (size_t)orow * N + RJ + tcol, &q, 16);   // (columns RJ .. RJ + 31 < RI0 <= N)
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        // the block column is read back (as MFMA operands) by other lanes of this wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the block column is read back (as MFMA operands)
+        group_sync();
     }
 
     // ---------------- alpha = llt.solve(y) (gpregressor.h:48) ----------------
-    // forward: z_j = (y_j - sum_{k<j} L_jk z_k) / L_jj, k ascending.  lane = row inside a 32-row block.
+    // forward: z_j = (y_j - sum_{k<j} L_jk z_k) / L_jj, k ascending.  lane = row inside a 32-row block (both half-waves
+    // alike).  Round 3: the factor comes in 32 x 32 tiles through LDS (coalesced 16-byte loads) and the solved part as one
+    // register per tile read with v_readlane: with lane = row reading its own row from the row-major factor every load
+    // touched 32 cache lines, and the 32 steps inside a block each waited for a global load of the pivot (2.1 of the kernel's
+    // 4.7 ms for N = 528).  Same chains, same order.
     float *al = a.alpha_k + p0;
+    auto fwd_tile = [&](const float (*tile)[36], float zc, float &acc) {
+        float lt[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 q = *reinterpret_cast<const float4 *>(&tile[c][4 * i]);
+            lt[4 * i] = q.x, lt[4 * i + 1] = q.y, lt[4 * i + 2] = q.z, lt[4 * i + 3] = q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(-lt[k], rl(zc, k), acc);
+    };
+    auto fwd_diag = [&](const float (*tile)[36], int K, float &acc) {
+        float lt[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 q = *reinterpret_cast<const float4 *>(&tile[c][4 * i]);
+            lt[4 * i] = q.x, lt[4 * i + 1] = q.y, lt[4 * i + 2] = q.z, lt[4 * i + 3] = q.w;
+        }
+#pragma unroll
+        for (int w = 0; w < 32; ++w) {
+            const float dd = 32 * K + w < N ? rl(lt[w], w) : 1.0f;
+            const float z = rl(acc, w) / dd;
+            if (c == w) acc = z;
+            else if (c > w) acc = __builtin_fmaf(-lt[w], z, acc);   // (rows beyond N hold zeros)
+        }
+    };
+    auto bwd_tile = [&](const float (*tile)[36], int T, float zc, float &acc) {
+        float lt[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) lt[k] = tile[k][c];
+#pragma unroll
+        for (int k = 31; k >= 0; --k)
+            if (32 * T + k < N) acc = __builtin_fmaf(-lt[k], rl(zc, k), acc);   // wave-uniform
+    };
+    auto bwd_diag = [&](const float (*tile)[36], int K, float &acc) {
+        float lt[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) lt[k] = tile[k][c];
+#pragma unroll
+        for (int w = 31; w >= 0; --w) {
+            if (32 * K + w >= N) continue;  // wave-uniform: padded rows take no part
+            const float dd = rl(lt[w], w);
+            const float v = rl(acc, w) / dd;
+            if (c == w) acc = v;
+            else if (c < w) acc = __builtin_fmaf(-lt[w], v, acc);
+        }
+    };
     for (int K = 0; K < nblk; ++K) {
         const int row = 32 * K + c;
         const bool valid = row < N;
-        const float *Lr = L + (size_t)(valid ? row : 0) * N;
         float acc = valid ? x[row].w : 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < 32 * K; ++k) acc = __builtin_fmaf(-(valid ? Lr[k] : 0.0f), al[k], acc);
-#pragma unroll 4
-        for (int w = 0; w < 32; ++w) {
-            const int rw_ = 32 * K + w;
-            const float dd = rw_ < N ? L[(size_t)rw_ * N + rw_] : 1.0f;
-            const float z = rl(acc, w) / dd;
-            if (c == w) acc = z;
-            else if (c > w) acc = __builtin_fmaf(-(valid ? Lr[32 * K + w] : 0.0f), z, acc);
+        float4 g[4];
+        float zn = 0.0f;
+        if (K > 0) {
+            load_tile(g, 32 * K, 0, true);
+            zn = al[c];
+        } else load_tile_edge(g, 0, 0);
+        for (int T = 0; T <= K; ++T) {
+            store_tile(0, g);
+            wave_sync();
+            const float zc = zn;
+            if (T + 1 < K) {   // the next tile is in flight while this one is used
+                load_tile(g, 32 * K, T + 1, true);
+                zn = al[32 * (T + 1) + c];
+            } else if (T + 1 == K) load_tile_edge(g, 32 * K, K);
+            if (T < K) fwd_tile(s_op[0], zc, acc);
+            else fwd_diag(s_op[0], K, acc);
+            __builtin_amdgcn_wave_barrier();   // (the tile is in registers by now: the next one may be stored over it)
         }
         if (h == 0 && valid) al[row] = acc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        group_sync();
     }
-    // backward: alpha_j = (z_j - sum_{k>j} L_kj alpha_k) / L_jj, k descending
+    // backward: alpha_j = (z_j - sum_{k>j} L_kj alpha_k) / L_jj, k descending: tile (T, K) holds rows k of block T and this
+    // block's columns; lane = column reads it by rows (conflict-free)
     for (int K = nblk - 1; K >= 0; --K) {
         const int row = 32 * K + c;
         const bool valid = row < N;
         float acc = valid ? al[row] : 0.0f;
-#pragma unroll 8
-        for (int k = N - 1; k >= 32 * K + 32; --k) acc = __builtin_fmaf(-(valid ? L[(size_t)k * N + row] : 0.0f), al[k], acc);
-#pragma unroll 4
-        for (int w = 31; w >= 0; --w) {
-            const int rw_ = 32 * K + w;
-            if (rw_ >= N) continue;  // wave-uniform: padded rows take no part
-            const float dd = L[(size_t)rw_ * N + rw_];
-            const float v = rl(acc, w) / dd;
-            if (c == w) acc = v;
-            else if (c < w) acc = __builtin_fmaf(-(valid ? L[(size_t)rw_ * N + row] : 0.0f), v, acc);
+        float4 g[4];
+        float zn = 0.0f;
+        if (K < nblk - 1) {
+            load_tile(g, 32 * (nblk - 1), K, true);
+            zn = 32 * (nblk - 1) + c < N ? al[32 * (nblk - 1) + c] : 0.0f;
+        } else load_tile_edge(g, 32 * K, K);
+        for (int T = nblk - 1; T >= K; --T) {
+            store_tile(0, g);
+            wave_sync();
+            const float zc = zn;
+            if (T - 1 > K) {
+                load_tile(g, 32 * (T - 1), K, true);
+                zn = al[32 * (T - 1) + c];
+            } else if (T - 1 == K) load_tile_edge(g, 32 * K, K);
+            if (T > K) bwd_tile(s_op[0], T, zc, acc);
+            else bwd_diag(s_op[0], K, acc);
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
         if (h == 0 && valid) al[row] = acc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        group_sync();
     }
 }
 
