@@ -46,6 +46,23 @@ def compare(name, xyz, origin, res, depth, reps=5, fr=0.5, mr=-1.0):
     return m, pk
 
 
+def refused(name, m, pk, n=15):
+    """the same packed scan fused n times on top of its own result, in both modes: how far the modes drift apart"""
+    a0, b0 = pk.alpha.copy(), pk.beta.copy()
+    res = []
+    for mode in (0, 1):
+        m.set_option("bgk_sum", mode)
+        pk.alpha[:] = a0
+        pk.beta[:] = b0
+        for _ in range(n):
+            m.scan_host(pk)
+        res.append((pk.alpha.copy(), pk.beta.copy()))
+    pk.alpha[:] = a0
+    pk.beta[:] = b0
+    (x0, y0), (x1, y1) = res
+    print(f"{name}: {n} fused re-insertions: max|dp| between the modes {np.abs(x0 / (x0 + y0) - x1 / (x1 + y1)).max():.3e}")
+
+
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     xyz, origin = la3dm_amd.load_pcd(os.path.join(root, "tests/golden/data/sim_structured/sim_structured_1.pcd"))
@@ -53,6 +70,7 @@ if __name__ == "__main__":
     compare("sim_structured_1 d4", xyz, origin, 0.1, 4, fr=0.5, mr=8.0)
     xyz, origin = la3dm_amd.synthetic_scan(200000, seed=1234)
     m, pk = compare("synthetic 200k d3", xyz, origin, 0.1, 3, reps=10)
+    refused("synthetic 200k d3", m, pk)
     for ab in (1, 2, 8, 16):
         _, t = run(m, pk, 1, 5, opts=(("ablate", ab),))
         print(f"  f64-sum ablate {ab}: {np.median(t):.4f} ms")
