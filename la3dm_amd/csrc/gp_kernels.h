@@ -551,18 +551,21 @@ __global__ __launch_bounds__(kWave) void gp_train_wave_kernel(GpArgs a) {
     }
 }
 
-// GP node update, src/gpoctomap/gpoctree_node.cpp:36-49 (double expression for ivar, double exp)
-__device__ __forceinline__ void gp_node_update_dev(const GpArgs &a, float &m_ivar, float &ivar, uint8_t &state, float new_m,
-                                                   float new_var) {
+// GP node update, src/gpoctomap/gpoctree_node.cpp:36-49 (double expression for ivar, double exp), in two parts: the
+// reference classifies after every update, and each classification overwrites the one before — only the last one of a
+// leaf's (up to seven) updates is ever seen.  So the updates carry (m_ivar, ivar) and whether the LAST one left the node
+// unknown, and the logistic with its f64 exp (~100 instructions) runs once per leaf instead of once per neighbour.
+__device__ __forceinline__ void gp_node_accumulate_dev(const GpArgs &a, float &m_ivar, float &ivar, bool &unknown, float new_m,
+                                                       float new_var) {
     ivar = (float)((double)ivar + (1.0 / (double)new_var - (double)a.sf2));
     m_ivar += new_m / new_var;
-    if (ivar < a.min_known_ivar) {
-        state = 2;
-    } else {
-        ivar = ivar > a.max_ivar ? a.max_ivar : ivar;
-        const float p = 1.0f / (1.0f + (float)exp((double)(-a.l * m_ivar / a.max_ivar)));
-        state = p > a.occupied_thresh ? 1 : (p < a.free_thresh ? 0 : 2);
-    }
+    unknown = ivar < a.min_known_ivar;
+    if (!unknown) ivar = ivar > a.max_ivar ? a.max_ivar : ivar;
+}
+__device__ __forceinline__ uint8_t gp_node_state_dev(const GpArgs &a, float m_ivar, bool unknown) {
+    if (unknown) return 2;
+    const float p = 1.0f / (1.0f + (float)exp((double)(-a.l * m_ivar / a.max_ivar)));
+    return p > a.occupied_thresh ? 1 : (p < a.free_thresh ? 0 : 2);
 }
 
 // exp(x) for x in [-60, 0], correctly rounded to f32 in all but ~1e-7 of the cases (the same contract
@@ -591,9 +594,13 @@ __device__ __forceinline__ float exp_cr_dev(float xf) {
     return (float)__longlong_as_double(bits);
 }
 
+// The distance's square root is sqrt_cr (bgk_kernels.h: hardware estimate + one residual fix-up, 6 instructions, equal to
+// sqrtf on {0} U [2^-100, 2^100] — swept) instead of the compiler's IEEE sequence with its denormal pre-scaling (~12, and a
+// branch around it measured +8 % on the depth-3 kernel).  Outside that range it may be off: d^2 > 2^100 does not occur, and a
+// non-zero d^2 < 2^-100 means d < 1e-15, where (1 + d) exp(-d) is 1.0f whatever small value comes back.
 __device__ __forceinline__ float matern3_fast(float ax, float ay, float az, float bx, float by, float bz, float sf2) {
     const float dx = bx - ax, dy = by - ay, dz = bz - az;
-    const float d = sqrtf(dx * dx + (dy * dy + dz * dz));
+    const float d = sqrt_cr(dx * dx + (dy * dy + dz * dz));
     return ((1 + d) * exp_cr_dev(-d)) * sf2;
 }
 
@@ -889,8 +896,7 @@ __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_v
     const float ty = a.scale * (off4.y + a.blk_center[3 * blk + 1]);
     const float tz = a.scale * (off4.z + a.blk_center[3 * blk + 2]);
     float m_ivar = a.m_ivar[li], ivar = a.ivar[li];
-    uint8_t state = 2;
-    bool updated = false;
+    bool updated = false, unknown = true;
     float *vg = a.vscratch ? a.vscratch + (size_t)task * a.vmax * kWave : nullptr;
 
     for (int nb = 0; nb < 7; ++nb) {
@@ -939,14 +945,14 @@ __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_v
             gp_solve_mfma(a, L, x, al, N, tx, ty, tz, vg, s_vraw, lane, mj, ss);   // (its tile staging reuses the LDS of the small path)
         }
         const float var = a.sf2 - ss;
-        gp_node_update_dev(a, m_ivar, ivar, state, mj, var);
+        gp_node_accumulate_dev(a, m_ivar, ivar, unknown, mj, var);
         updated = true;
     }
     if (active) {
         if (updated) {
             a.m_ivar[li] = m_ivar;
             a.ivar[li] = ivar;
-            a.state[li] = (uint8_t)(state | 0x80u);
+            a.state[li] = (uint8_t)(gp_node_state_dev(a, m_ivar, unknown) | 0x80u);
         } else {
             a.state[li] = 0;
         }
