@@ -486,69 +486,113 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // Same arithmetic as gp_train_kernel for blocks with N <= 128: one wave64 per training block, the lower
 // triangle packed in LDS (row i at i(i+1)/2), lane = row (two rows per lane above 64), no workgroup barriers.
 // The factor is written to its global slot once, for the predict kernel.
-__global__ __launch_bounds__(kWave) void gp_train_wave_kernel(GpArgs a) {
-    extern __shared__ float s_l[];  // [N(N+1)/2 + N]
+// The launch takes the blocks with n_lo < N <= n_hi (its LDS is sized for n_hi): the waves are latency bound, what the
+// launch delivers is how many of them a CU holds, and sized for the largest small block (14 KB at N = 79) that was 11.
+constexpr int kGpTrainTinyN = 32;   // blocks up to this size get a launch of their own (2.8 KB of LDS each)
+__global__ __launch_bounds__(kWave) void gp_train_wave_kernel(GpArgs a, int n_lo, int n_hi) {
+    extern __shared__ __attribute__((aligned(16))) float s_l[];  // [N(N+1)/2 + N] + the block's points [N] float4 (gp_train_wave_lds)
     const uint32_t b = blockIdx.x;
     const uint32_t p0 = a.train_off[b];
     const int N = (int)(a.train_off[b + 1] - p0);
-    if (N == 0 || N > kGpTrainLdsMaxN) return;  // large blocks: gp_train_kernel
+    if (N <= n_lo || N > n_hi) return;  // (n_hi <= kGpTrainLdsMaxN; larger blocks: gp_train_kernel)
     const int lane = threadIdx.x;
     const float4 *x = a.pts + p0;
     float *Lg = a.Lmat + a.l_off[b];
-    float *zs = s_l + (N * (N + 1)) / 2;  // right-hand side / solution
+    const int T = (N * (N + 1)) / 2;
+    float *zs = s_l + T;  // right-hand side / solution
+    float4 *s_x = reinterpret_cast<float4 *>(s_l + ((T + N + 3) & ~3));
     auto tri = [](int i, int j) { return (i * (i + 1)) / 2 + j; };
-    // K(i, j), i >= j, + noise on the diagonal
+    // Round 3 (configs[2] at the YAML's depth 3 is 31 k blocks of 9 points on average, and this kernel took 0.86 ms): the
+    // points go to LDS first (one coalesced load; before, every kernel value waited for its own global load of x_j) and
+    // the N(N+1)/2 kernel values are dealt to the lanes by their packed index e = i(i+1)/2 + j (before, lane i computed
+    // row i: N values in sequence where N(N+1)/128 do).
     for (int i = lane; i < N; i += kWave) {
         const float4 xi = x[i];
-        for (int j = 0; j <= i; ++j) {
-            const float4 xj = x[j];
-            float kv = matern3_fast(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);
-            if (i == j) kv = kv + a.noise;
-            s_l[tri(i, j)] = kv;
-        }
+        s_x[i] = xi;
         zs[i] = xi.w;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // K(i, j), i >= j, + noise on the diagonal
+    for (int e = lane; e < T; e += kWave) {
+        int i = (int)((__builtin_sqrtf((float)(8 * e + 1)) - 1.0f) * 0.5f);   // row of packed index e, then exact
+        if ((i * (i + 1)) / 2 > e) --i;
+        if (((i + 1) * (i + 2)) / 2 <= e) ++i;
+        const int j = e - (i * (i + 1)) / 2;
+        const float4 xi = s_x[i], xj = s_x[j];
+        float kv = matern3_fast(xi.x, xi.y, xi.z, xj.x, xj.y, xj.z, a.sf2);
+        if (i == j) kv = kv + a.noise;
+        s_l[e] = kv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < N; ++j) {
-        // diagonal (every lane computes the same chain; wave-uniform result)
-        float dacc = s_l[tri(j, j)];
-        for (int k = 0; k < j; ++k) {
-            const float ljk = s_l[tri(j, k)];
-            dacc = __builtin_fmaf(-ljk, ljk, dacc);
-        }
-        const float d = sqrtf(dacc);
-        for (int i = j + 1 + lane; i < N; i += kWave) {
-            float acc = s_l[tri(i, j)];
-            for (int k = 0; k < j; ++k) acc = __builtin_fmaf(-s_l[tri(i, k)], s_l[tri(j, k)], acc);
-            s_l[tri(i, j)] = acc / d;
+        // rows j, j + 1, ... of column j, lane by lane; lane 0's row is the diagonal entry: its chain
+        // K_jj - sum_k L_jk L_jk is the same FMA sequence as the other rows' with i = j (before, every lane ran it as a
+        // separate loop ahead of its own row: twice the LDS reads and FMAs per column)
+        float d = 0.0f;
+        for (int i0 = j; i0 < N; i0 += kWave) {
+            const int i = i0 + lane;
+            float acc = 0.0f;
+            if (i < N) {
+                // eight steps of the chain at a time, their 16 LDS reads issued together (one round trip per step before:
+                // 120 cycles per step measured, 100 us of the N = 64 block's 140)
+                const float *ri = s_l + tri(i, 0), *rj = s_l + tri(j, 0);
+                acc = ri[j];
+                int k = 0;
+                for (; k + 8 <= j; k += 8) {
+                    float li[8], lj[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        li[u] = ri[k + u];
+                        lj[u] = rj[k + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(-li[u], lj[u], acc);
+                }
+                for (; k < j; ++k) acc = __builtin_fmaf(-ri[k], rj[k], acc);
+            }
+            if (i0 == j) d = sqrtf(rl(acc, 0));
+            if (i < N && i > j) s_l[tri(i, j)] = acc / d;
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) s_l[tri(j, j)] = d;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    // forward then backward substitution, right-looking (chains over k ascending / descending)
+    // forward then backward substitution, right-looking (chains over k ascending / descending), lane = row: rows lane and
+    // lane + 64 of the right-hand side live in two registers, the solved entry is broadcast with v_readlane, the only LDS
+    // access per step and row is the factor's entry (before: right-hand side in LDS, two barriers and ~450 cycles per step)
+    const int r0 = lane, r1 = lane + kWave;
+    float acc0 = r0 < N ? zs[r0] : 0.0f, acc1 = r1 < N ? zs[r1] : 0.0f;
+    const float *row0 = s_l + tri(r0, 0), *row1 = s_l + tri(r1, 0);
     for (int j = 0; j < N; ++j) {
-        const float z = zs[j] / s_l[tri(j, j)];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) zs[j] = z;
-        for (int i = j + 1 + lane; i < N; i += kWave) zs[i] = __builtin_fmaf(-s_l[tri(i, j)], z, zs[i]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const float z = (j < kWave ? rl(acc0, j) : rl(acc1, j - kWave)) / s_l[tri(j, j)];
+        if (r0 == j) acc0 = z;
+        else if (r0 > j && r0 < N) acc0 = __builtin_fmaf(-row0[j], z, acc0);
+        if (r1 == j) acc1 = z;
+        else if (r1 > j && r1 < N) acc1 = __builtin_fmaf(-row1[j], z, acc1);
     }
     for (int j = N - 1; j >= 0; --j) {
-        const float v = zs[j] / s_l[tri(j, j)];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) zs[j] = v;
-        for (int i = lane; i < j; i += kWave) zs[i] = __builtin_fmaf(-s_l[tri(j, i)], v, zs[i]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const float v = (j < kWave ? rl(acc0, j) : rl(acc1, j - kWave)) / s_l[tri(j, j)];
+        const float *rowj = s_l + tri(j, 0);
+        if (r0 == j) acc0 = v;
+        else if (r0 < j) acc0 = __builtin_fmaf(-rowj[r0], v, acc0);
+        if (r1 == j) acc1 = v;
+        else if (r1 < j) acc1 = __builtin_fmaf(-rowj[r1], v, acc1);
     }
-    for (int i = lane; i < N; i += kWave) {
-        a.alpha_k[p0 + i] = zs[i];
-        for (int j = 0; j <= i; ++j) Lg[(size_t)i * N + j] = s_l[tri(i, j)];
+    if (r0 < N) a.alpha_k[p0 + r0] = acc0;
+    if (r1 < N) a.alpha_k[p0 + r1] = acc1;
+    for (int e = lane; e < T; e += kWave) {   // the factor to its global slot (row-major N x N, lower triangle)
+        int i = (int)((__builtin_sqrtf((float)(8 * e + 1)) - 1.0f) * 0.5f);
+        if ((i * (i + 1)) / 2 > e) --i;
+        if (((i + 1) * (i + 2)) / 2 <= e) ++i;
+        Lg[(size_t)i * N + (e - (i * (i + 1)) / 2)] = s_l[e];
     }
+}
+// dynamic LDS of gp_train_wave_kernel for blocks of up to nn points
+__host__ __device__ constexpr size_t gp_train_wave_lds(uint32_t nn) {
+    return sizeof(float) * (((size_t)nn * (nn + 1) / 2 + nn + 3) / 4 * 4 + 4 * (size_t)nn);
 }
 
 // GP node update, src/gpoctomap/gpoctree_node.cpp:36-49 (double expression for ivar, double exp), in two parts: the

@@ -584,8 +584,10 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     }
     if (s->n_train_blk) {
         const uint32_t nn = max_n < (uint32_t)kGpTrainLdsMaxN ? (max_n ? max_n : 1u) : (uint32_t)kGpTrainLdsMaxN;
-        hipLaunchKernelGGL(gp_train_wave_kernel, dim3(s->n_train_blk), dim3(kWave), sizeof(float) * (nn * (nn + 1) / 2 + nn),
-                           stream, a);
+        const uint32_t n_tiny = nn < (uint32_t)kGpTrainTinyN ? nn : (uint32_t)kGpTrainTinyN;
+        hipLaunchKernelGGL(gp_train_wave_kernel, dim3(s->n_train_blk), dim3(kWave), gp_train_wave_lds(n_tiny), stream, a, 0, (int)n_tiny);
+        if (nn > n_tiny)
+            hipLaunchKernelGGL(gp_train_wave_kernel, dim3(s->n_train_blk), dim3(kWave), gp_train_wave_lds(nn), stream, a, (int)n_tiny, (int)nn);
         if (max_n > (uint32_t)kGpTrainLdsMaxN)
             hipLaunchKernelGGL(gp_train_kernel, dim3(s->n_train_blk), dim3(kWave), 0, stream, a);
     }
