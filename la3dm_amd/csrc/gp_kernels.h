@@ -914,17 +914,22 @@ static_assert(kGpMfmaMinN <= kGpLdsRows + 1, "the small path keeps v in s_v[64][
 // matrix-core code in the kernel, so no 256-VGPR budget and no spills in the four-row loop — with both paths in one kernel
 // the small path of configs[2] ran 7 % slower after the large path had grown) and the tiles with at least one large
 // neighbour (kMixed = true).  Every tile is taken by exactly one of them.
+// The small launch comes in classes by the tile's largest neighbour block (n_lo < max N <= n_hi, LDS sized for n_hi rows of
+// v): the kernel is VALU bound on Ks but a wave issues only a third of its life, and with v sized for 64 rows (16 KB) a SIMD
+// held 2.1 waves — 66 % VALU busy (profiles/r03/gp_d3_pmc.txt).
 template <bool kMixed>
-__device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_vraw) {
+__device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_vraw, int n_lo = -1, int n_hi = 0x7fffffff) {
     float (*s_v)[kWave] = reinterpret_cast<float (*)[kWave]>(s_vraw);
     const int lane = threadIdx.x;
     const uint32_t task = blockIdx.x;
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.tpb_shift;
     {
-        bool large = false;
-        for (int nb = 0; nb < 7; ++nb) large = large || (int)a.nbr_range[7 * blk + nb].y >= kGpMfmaMinN;
+        int mx = 0;
+        for (int nb = 0; nb < 7; ++nb) mx = max(mx, (int)a.nbr_range[7 * blk + nb].y);
+        const bool large = mx >= kGpMfmaMinN;
         if (large != kMixed) return;   // (uniform)
+        if (!kMixed && (mx <= n_lo || mx > n_hi)) return;
     }
     const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
     const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
@@ -1007,9 +1012,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64] or the tile staging: sized per launch
     gp_predict_fuse_body<true>(a, s_vraw);
 }
-__global__ __launch_bounds__(kWave) void gp_predict_fuse_small_kernel(GpArgs a) {
-    extern __shared__ float s_vraw[];  // [min(max N, kGpLdsRows)][64]: LDS is the occupancy limiter
-    gp_predict_fuse_body<false>(a, s_vraw);
+__global__ __launch_bounds__(kWave) void gp_predict_fuse_small_kernel(GpArgs a, int n_lo, int n_hi) {
+    extern __shared__ float s_vraw[];  // [n_hi][64]
+    gp_predict_fuse_body<false>(a, s_vraw, n_lo, n_hi);
 }
 
 // Test hook for the property gp_solve_mfma / gp_train_kernel rely on: D = A B through v_mfma_f32_32x32x2_f32

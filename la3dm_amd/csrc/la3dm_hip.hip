@@ -606,7 +606,14 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
         const uint32_t rows = max_n < (uint32_t)kGpLdsRows ? (max_n ? max_n : 1u) : (uint32_t)kGpLdsRows;
         const size_t lds = rows * kWave * sizeof(float);
         // tiles without a large neighbour; then (if there is any large block) the tiles with one — every tile once
-        hipLaunchKernelGGL(gp_predict_fuse_small_kernel, dim3(a.n_tasks), dim3(kWave), lds, stream, a);
+        // (the small launch in classes by the tile's largest neighbour block: LDS, and with it the waves per CU, per class)
+        int lo = -1;
+        for (uint32_t hi : {16u, 32u, (uint32_t)kGpLdsRows}) {
+            const uint32_t h = hi < rows ? hi : rows;
+            hipLaunchKernelGGL(gp_predict_fuse_small_kernel, dim3(a.n_tasks), dim3(kWave), h * kWave * sizeof(float), stream, a, lo, (int)h);
+            lo = (int)h;
+            if (h == rows) break;
+        }
         if (max_n >= (uint32_t)kGpMfmaMinN)
             hipLaunchKernelGGL(gp_predict_fuse_kernel, dim3(a.n_tasks), dim3(kWave),
                                std::max<size_t>(lds, 3 * 32 * 36 * sizeof(float)) /* gp_solve_mfma's three tile buffers */, stream, a);
