@@ -920,6 +920,7 @@ static_assert(kGpMfmaMinN <= kGpLdsRows + 1, "the small path keeps v in s_v[64][
 template <bool kMixed>
 __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_vraw, int n_lo = -1, int n_hi = 0x7fffffff) {
     float (*s_v)[kWave] = reinterpret_cast<float (*)[kWave]>(s_vraw);
+    __shared__ float4 s_pan[kWave];   // the small path's 4-row panel of L
     const int lane = threadIdx.x;
     const uint32_t task = blockIdx.x;
     if (task >= a.n_tasks) return;
@@ -969,11 +970,21 @@ __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_v
                     ks[u] = matern3_fast(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);  // Ks(k, j) = k(x_k, xs_j)
                     acc[u] = ks[u];
                 }
-                for (int i = 0; i < k0; ++i) {  // four independent chains over the solved rows
+                // the four rows' entries of a column, side by side in LDS (lane = column wrote them): one broadcast
+                // 16-byte read per solved row instead of four v_readlane — the substitution is half of this kernel's VALU
+                // at N = 50, and a v_readlane costs an issue slot like the FMA it feeds
+                lds_order();
+                s_pan[lane] = make_float4(Lr[0], Lr[1], Lr[2], Lr[3]);
+                lds_order();
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+                for (int i = 0; i < k0; ++i) {  // four independent chains over the solved rows (k0 is a multiple of 4)
                     const float vi = s_v[i][lane];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        acc[u] = __builtin_fmaf(-__int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lr[u]), i)), vi, acc[u]);
+                    const float4 l4 = s_pan[i];
+                    acc[0] = __builtin_fmaf(-l4.x, vi, acc[0]);
+                    acc[1] = __builtin_fmaf(-l4.y, vi, acc[1]);
+                    acc[2] = __builtin_fmaf(-l4.z, vi, acc[2]);
+                    acc[3] = __builtin_fmaf(-l4.w, vi, acc[3]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {  // the 4x4 triangle
