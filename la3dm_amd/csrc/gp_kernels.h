@@ -922,7 +922,17 @@ __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_v
     float (*s_v)[kWave] = reinterpret_cast<float (*)[kWave]>(s_vraw);
     __shared__ float4 s_pan[kWave];   // the small path's 4-row panel of L
     const int lane = threadIdx.x;
-    const uint32_t task = blockIdx.x;
+    // Workgroup w runs on XCD w % 8.  All tiles of a test block go to one XCD (they read the same seven factors: through one
+    // L2 instead of eight), the blocks are dealt to the XCDs round-robin (they are sorted heaviest first: contiguous ranges
+    // per XCD measured 3x slower).  One tile per block (depth 3): the identity.
+    uint32_t task = blockIdx.x;
+    {
+        const uint32_t nb8 = a.n_test_blk & ~7u;
+        if (task < (nb8 << a.tpb_shift)) {
+            const uint32_t xcd = task & 7u, slot = task >> 3;
+            task = ((((slot >> a.tpb_shift) << 3) | xcd) << a.tpb_shift) | (slot & ((1u << a.tpb_shift) - 1u));
+        }
+    }
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.tpb_shift;
     {
