@@ -37,7 +37,7 @@ struct GpArgs {
     const float4 *lut;
     float *vscratch;            // [n_tasks][vmax][64] when a block exceeds the LDS capacity, else null
     const uint32_t *order;      // large training blocks, largest first (gp_factor_offsets)
-    const unsigned long long *totals;   // [0] sum N^2, [1] max N, [2] large blocks
+    const unsigned long long *totals;   // [0] sum N^2, [1] max N, [2] large blocks, [3] small non-empty blocks (listed behind the large ones)
     uint32_t n_test_blk, tpb_shift, n_tasks, n_train_blk;
     uint32_t vmax;              // rows of v per task in vscratch
     float scale;                // (float)(1.73205 / ell)
@@ -79,14 +79,17 @@ __global__ void gp_prepare(const float4 *__restrict__ in, float4 *__restrict__ o
 
 // exclusive scan of N_b^2 (one workgroup; n_train_blk is a few 10^4) + max N_b
 // + the large blocks (gp_train_kernel's: one wave each, run time ~ N^3) listed largest first: the launch takes them in this
-// order, so the longest factorisations start at once instead of wherever their index puts them (totals[2] = their number)
+// order, so the longest factorisations start at once instead of wherever their index puts them (totals[2] = their number);
+// the small non-empty blocks (gp_train_wave_kernel's) follow in the same list, largest first too (totals[3])
 __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32_t n_blk,
                                   unsigned long long *__restrict__ l_off, unsigned long long *__restrict__ totals,
                                   uint32_t *__restrict__ order) {
     __shared__ unsigned long long s_sum[256];
     __shared__ uint32_t s_max[256];
     __shared__ uint32_t s_cls[64];   // large blocks per size class (32-row blocks, capped)
+    __shared__ uint32_t s_cls2[33];  // small non-empty blocks per size class (4 points)
     if (threadIdx.x < 64) s_cls[threadIdx.x] = 0;
+    if (threadIdx.x < 33) s_cls2[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_blk + 255u) / 256u;
@@ -98,6 +101,7 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
         sum += n * n;
         mx = max(mx, (uint32_t)n);
         if (n > (unsigned long long)kGpTrainLdsMaxN) atomicAdd(&s_cls[min(63u, (uint32_t)((n + 31) >> 5))], 1u);
+        else if (n) atomicAdd(&s_cls2[(uint32_t)((n + 3) >> 2)], 1u);
     }
     s_sum[tid] = sum;
     s_max[tid] = mx;
@@ -120,6 +124,12 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
             first += k;
         }
         totals[2] = first;
+        for (int c = 32; c >= 0; --c) {   // the small blocks behind them, largest first as well
+            const uint32_t k = s_cls2[c];
+            s_cls2[c] = first;
+            first += k;
+        }
+        totals[3] = first - (uint32_t)totals[2];
     }
     __syncthreads();
     unsigned long long run = s_sum[tid];
@@ -128,6 +138,7 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
         l_off[b] = run;
         run += n * n;
         if (n > (unsigned long long)kGpTrainLdsMaxN) order[atomicAdd(&s_cls[min(63u, (uint32_t)((n + 31) >> 5))], 1u)] = b;
+        else if (n) order[atomicAdd(&s_cls2[(uint32_t)((n + 3) >> 2)], 1u)] = b;
     }
 }
 
@@ -491,7 +502,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 constexpr int kGpTrainTinyN = 32;   // blocks up to this size get a launch of their own (2.8 KB of LDS each)
 __global__ __launch_bounds__(kWave) void gp_train_wave_kernel(GpArgs a, int n_lo, int n_hi) {
     extern __shared__ __attribute__((aligned(16))) float s_l[];  // [N(N+1)/2 + N] + the block's points [N] float4 (gp_train_wave_lds)
-    const uint32_t b = blockIdx.x;
+    if (blockIdx.x >= (uint32_t)a.totals[3]) return;   // (one workgroup per training block; the small non-empty ones are listed)
+    const uint32_t b = a.order[(uint32_t)a.totals[2] + blockIdx.x];   // largest first: the launch ends with the short ones
     const uint32_t p0 = a.train_off[b];
     const int N = (int)(a.train_off[b + 1] - p0);
     if (N <= n_lo || N > n_hi) return;  // (n_hi <= kGpTrainLdsMaxN; larger blocks: gp_train_kernel)

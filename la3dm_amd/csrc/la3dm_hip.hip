@@ -518,7 +518,7 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     if ((rc = arena_reserve(ctx, ctx->pts_scaled, sizeof(float4) * npts)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->nbr_range, sizeof(uint2) * 7 * (size_t)s->n_test_blk)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_loff, sizeof(unsigned long long) * nblk)) != LA3DM_OK) return rc;
-    if ((rc = arena_reserve(ctx, ctx->gp_totals, 24)) != LA3DM_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->gp_totals, 32)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_order, sizeof(uint32_t) * nblk)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_alpha, sizeof(float) * npts)) != LA3DM_OK) return rc;
     hipLaunchKernelGGL(gp_factor_offsets, dim3(1), dim3(256), 0, stream, s->train_off, s->n_train_blk,
