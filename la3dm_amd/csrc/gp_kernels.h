@@ -1008,6 +1008,8 @@ __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_v
                     acc[2] = __builtin_fmaf(-l4.z, vi, acc[2]);
                     acc[3] = __builtin_fmaf(-l4.w, vi, acc[3]);
                 }
+                float vloc[4];   // the group's own solved rows stay in registers (read back from LDS they were a write -> read round
+                                 // trip on the serial path of every row)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {  // the 4x4 triangle
                     const int k = k0 + u;
@@ -1015,8 +1017,9 @@ __device__ __forceinline__ void gp_predict_fuse_body(const GpArgs &a, float *s_v
 #pragma unroll
                         for (int w = 0; w < u; ++w)
                             acc[u] = __builtin_fmaf(-__int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lr[u]), k0 + w)),
-                                                    s_v[k0 + w][lane], acc[u]);
+                                                    vloc[w], acc[u]);
                         const float vk = acc[u] / __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Lr[u]), k));
+                        vloc[u] = vk;
                         s_v[k][lane] = vk;
                         mj = __builtin_fmaf(ks[u], al[k], mj);
                         ss = __builtin_fmaf(vk, vk, ss);
