@@ -940,17 +940,23 @@ __device__ __forceinline__ float axis_center(long long i, float bs) {  // bgkblo
 }
 
 struct AxisCandD {
-    int idx[3];
+    int first;   // the first of the n consecutive biased indices (a closed box can only be shared with an adjacent block)
     int n;
 };
-// biased block indices whose CLOSED fp32 box [c - h, c + h] holds v (what an R-tree box query sees)
+// biased block indices whose CLOSED fp32 box [c - h, c + h] holds v (what an R-tree box query sees).  No index array: filled
+// at a run-time position it lived in scratch memory (every store and load a memory round trip: dm_members_count took 32 us)
 __device__ __forceinline__ AxisCandD axis_candidates_dev(float v, float bs, float h) {
     AxisCandD r;
+    r.first = 0;
     r.n = 0;
     const long long i0 = axis_index(v, bs);
-    for (long long i = i0 - 1; i <= i0 + 1; ++i) {
-        const float c = axis_center(i, bs);
-        if (c - h <= v && v <= c + h) r.idx[r.n++] = (int)i;
+#pragma unroll
+    for (int o = -1; o <= 1; ++o) {
+        const float c = axis_center(i0 + o, bs);
+        if (c - h <= v && v <= c + h) {
+            if (r.n == 0) r.first = (int)(i0 + o);
+            ++r.n;
+        }
     }
     return r;
 }
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(256) void dm_members_count(const float4 *__restrict
                     az = axis_candidates_dev(p.z, a.bs, a.half);
     cnt[i] = (uint32_t)(ax.n * ay.n * az.n);
     // the candidates of one axis are consecutive indices (a closed box can only be shared with an adjacent block)
-    code[i] = make_int4(ax.n ? ax.idx[0] : 0, ay.n ? ay.idx[0] : 0, az.n ? az.idx[0] : 0, ax.n | (ay.n << 2) | (az.n << 4));
+    code[i] = make_int4(ax.first, ay.first, az.first, ax.n | (ay.n << 2) | (az.n << 4));
 }
 
 __global__ __launch_bounds__(256) void dm_members_write(const int4 *__restrict__ code, uint32_t n, PartArgs a,
