@@ -174,9 +174,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // lane and passed through LDS: read straight from the row-major factor, lane c = row c touches 32 cache lines per load
     // and the wave waits a memory round trip per k-pair (this kernel was latency bound: 9.6 ms for 4 726 blocks).
     // The accumulator -> [row][col] transposes (s_tile) happen after the operand loop and share the space.
-    __shared__ __attribute__((aligned(16))) float s_lds[3 * kTileF];
+    __shared__ __attribute__((aligned(16))) float s_lds[4 * kTileF];   // three operand / transpose tiles + the diagonal block (s_dg)
     float (*s_op)[32][36] = reinterpret_cast<float (*)[32][36]>(s_lds);
     float (*s_tile)[32][kTrT] = reinterpret_cast<float (*)[32][kTrT]>(s_lds);
+    float (*s_dg)[36] = reinterpret_cast<float (*)[36]>(s_lds + 3 * kTileF);   // L[J][J], row-major, for the substitutions
     if (blockIdx.x >= (uint32_t)a.totals[2]) return;   // (the launch has one workgroup per training block; the large ones are listed)
     const uint32_t b = a.order[blockIdx.x];            // largest first
     const uint32_t p0 = a.train_off[b];
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int J = 0; J < nblk; ++J) {
         const int RJ = 32 * J;
         // ---------------- diagonal block ----------------
-        float dg[32];  // lane = row (both half-waves hold the same rows): row (lane % 32) of L[J][J]
         {
+            float dg[32];  // lane = row (both half-waves hold the same rows): row (lane % 32) of L[J][J]
             f32x16 C;
             kblock(RJ, RJ, C);
             const int arow = RJ + c;
@@ -312,6 +313,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 for (int w = 0; w < 32; ++w)
                     if (w <= c && RJ + w < N) dst[w] = dg[w];
             }
+            // the block also goes to LDS: the substitutions below read L[J][J] rows as broadcast 16-byte reads (four entries
+            // per LDS instruction instead of a v_readlane per entry), and the 32 registers are free during the operand loop
+            // (where the kernel spilled: 35 scratch accesses per step)
+            if (h == 0) {
+#pragma unroll
+                for (int w4 = 0; w4 < 8; ++w4)
+                    *reinterpret_cast<float4 *>(&s_dg[c][4 * w4]) = make_float4(dg[4 * w4], dg[4 * w4 + 1], dg[4 * w4 + 2], dg[4 * w4 + 3]);
+            }
+            wave_sync();
         }
         // ---------------- blocks below the diagonal, two per pass ----------------
         for (int I = J + 1; I < nblk; I += 2) {
@@ -360,10 +370,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
+                float lj[32];   // row j of L[J][J] up to the diagonal (uniform addresses: broadcast reads)
+#pragma unroll
+                for (int w4 = 0; w4 <= j / 4; ++w4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(&s_dg[j][4 * w4]);
+                    lj[4 * w4] = q.x, lj[4 * w4 + 1] = q.y, lj[4 * w4 + 2] = q.z, lj[4 * w4 + 3] = q.w;
+                }
                 float acc = rw[j];
 #pragma unroll
-                for (int w = 0; w < j; ++w) acc = __builtin_fmaf(-rw[w], rl(dg[w], j), acc);
-                rw[j] = acc / rl(dg[j], j);
+                for (int w = 0; w < j; ++w) acc = __builtin_fmaf(-rw[w], lj[w], acc);
+                rw[j] = acc / lj[j];
             }
             // back through LDS: 16-byte stores along the rows instead of one row per lane
 #pragma unroll
