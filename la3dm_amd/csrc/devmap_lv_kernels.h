@@ -163,16 +163,22 @@ __global__ __launch_bounds__(256) void dm_lv_beam_init(const float *__restrict__
 // the L2 at 45 k hits, 6.2 ms.
 constexpr uint32_t kLvNearTile = 256;
 __global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
-                                                  const LvBeam *__restrict__ beams, unsigned long long *__restrict__ mask) {
+                                                  const LvBeam *__restrict__ beams, unsigned long long *__restrict__ mask, uint32_t tile) {
     const uint32_t q = blockIdx.x * 64u + threadIdx.x;
     const bool have = q < nh;
     const float qx = have ? hits[3 * (size_t)q] : 0.f, qy = have ? hits[3 * (size_t)q + 1] : 0.f, qz = have ? hits[3 * (size_t)q + 2] : 0.f;
     const double dist2 = have ? rng[q] : 0.0;
     const bool in_range = have && !(a.max_range > 0 && dist2 > a.max_range);
     const bool low = (double)qz < (double)a.oz + a.influence;
-    const uint32_t h0 = blockIdx.y * kLvNearTile, h1 = min(nh, h0 + kLvNearTile);
+    // the tile's beams go to LDS first: read one by one from memory (a wave-uniform load per beam, each waited for) the walk of
+    // a tile was a chain of memory round trips — 120 us for the 3 500-beam scans of configs[3], where a SIMD holds one wave
+    __shared__ LvBeam s_beam[kLvNearTile];
+    const uint32_t h0 = blockIdx.y * tile, h1 = min(nh, h0 + tile);
+    for (uint32_t h = h0 + threadIdx.x; h < h1; h += 64u) s_beam[h - h0] = beams[h];
+    __syncthreads();
+#pragma unroll 4
     for (uint32_t h = h0; h < h1; ++h) {
-        const LvBeam b = beams[h];
+        const LvBeam b = s_beam[h - h0];
         bool near = false;
         const bool high = (double)b.pz > (a.offset + (double)a.oz);
         if (in_range && !(high && low)) {
@@ -195,16 +201,21 @@ __global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hit
         if (threadIdx.x == 0) mask[(size_t)h * gridDim.x + blockIdx.x] = m;
     }
 }
-__global__ __launch_bounds__(64) void dm_lv_beams_walk(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
+__global__ __launch_bounds__(256) void dm_lv_beams_walk(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
                                                       const LvBeam *__restrict__ beams, const unsigned long long *__restrict__ mask,
                                                       uint32_t nw, uint8_t *__restrict__ flags, float *__restrict__ seg,
                                                       uint32_t *__restrict__ nsamp, uint32_t *__restrict__ nray, uint32_t *counters,
                                                       int lds_hits) {
     // the walk reads one hit per set bit, each read depending on the previous bit: with the hit list staged in LDS
     // (lds_hits != 0: it fits) that is an LDS latency per step instead of a trip to L2
-    extern __shared__ float lv_walk_hits[];
-    if (lds_hits) {
-        for (uint32_t i = threadIdx.x; i < 3u * nh; i += blockDim.x) lv_walk_hits[i] = hits[i];
+    extern __shared__ __attribute__((aligned(16))) float lv_walk_hits[];
+    if (lds_hits) {   // 16-byte loads, all in flight (one 4-byte load per trip, each waited for, was most of this kernel at 3 500 beams)
+        const uint32_t n4 = (3u * nh) / 4u;
+        const float4 *h4 = reinterpret_cast<const float4 *>(hits);
+        float4 *l4 = reinterpret_cast<float4 *>(lv_walk_hits);
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) l4[i] = h4[i];
+        for (uint32_t i = 4u * n4 + threadIdx.x; i < 3u * nh; i += blockDim.x) lv_walk_hits[i] = hits[i];
         __syncthreads();
     }
     const float *hp = lds_hits ? lv_walk_hits : hits;
