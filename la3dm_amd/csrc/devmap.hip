@@ -1276,9 +1276,14 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         DM_RESERVE(dm->lv_mask, 8ull * nh * nw);
         hipLaunchKernelGGL(dm_lv_beam_init, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (LvBeam *)dm->lv_beam.ptr);
         // (beams per workgroup: small scans need the parallelism — a tile is walked in sequence —, large ones the reuse of the wave's 64 hits)
-        const uint32_t near_tile = nh >= 16384u ? kLvNearTile : 32u;
-        hipLaunchKernelGGL(dm_lv_nearby, dim3(nw, cdiv(nh, near_tile)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
-                           (const LvBeam *)dm->lv_beam.ptr, (unsigned long long *)dm->lv_mask.ptr, near_tile);
+        const bool small_scan = nh < 16384u;
+        const uint32_t near_tile = small_scan ? 32u : kLvNearTile;
+        if (small_scan)
+            hipLaunchKernelGGL(dm_lv_nearby<true>, dim3(nw, cdiv(nh, near_tile)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+                               (const LvBeam *)dm->lv_beam.ptr, (unsigned long long *)dm->lv_mask.ptr, near_tile);
+        else
+            hipLaunchKernelGGL(dm_lv_nearby<false>, dim3(nw, cdiv(nh, near_tile)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+                               (const LvBeam *)dm->lv_beam.ptr, (unsigned long long *)dm->lv_mask.ptr, near_tile);
         const int lds_hits = 12ull * nh <= 60000 ? 1 : 0;   // the hit list in LDS (2 workgroups per CU still fit)
         const uint32_t walk_threads = lds_hits ? 256u : 64u;   // (the staged hit list is shared by the workgroup's four waves)
         hipLaunchKernelGGL(dm_lv_beams_walk, dim3(cdiv(nh, walk_threads)), dim3(walk_threads), lds_hits ? 12 * nh : 0, st, d_hits, nh, ba,

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void dm_lv_beam_init(const float *__restrict__
 // records are wave-uniform scalar loads): one wave per (beam, 64 hits) re-read the hit list once per beam — 24 GB through
 // the L2 at 45 k hits, 6.2 ms.
 constexpr uint32_t kLvNearTile = 256;
+template <bool kStage>
 __global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
                                                   const LvBeam *__restrict__ beams, unsigned long long *__restrict__ mask, uint32_t tile) {
     const uint32_t q = blockIdx.x * 64u + threadIdx.x;
@@ -170,15 +171,19 @@ __global__ __launch_bounds__(64) void dm_lv_nearby(const float *__restrict__ hit
     const double dist2 = have ? rng[q] : 0.0;
     const bool in_range = have && !(a.max_range > 0 && dist2 > a.max_range);
     const bool low = (double)qz < (double)a.oz + a.influence;
-    // the tile's beams go to LDS first: read one by one from memory (a wave-uniform load per beam, each waited for) the walk of
-    // a tile was a chain of memory round trips — 120 us for the 3 500-beam scans of configs[3], where a SIMD holds one wave
-    __shared__ LvBeam s_beam[kLvNearTile];
+    // kStage (small scans): the tile's beams go to LDS first.  Read one by one from memory (a wave-uniform load per beam, each
+    // waited for) the walk of a tile was a chain of memory round trips — 120 us for the 3 500-beam scans of configs[3], where a
+    // SIMD holds one wave.  Large scans keep the direct loads: thousands of waves hide them, and there the staged form
+    // measured slower (2.9 against 2.5 ms at 29 000 beams).
+    __shared__ LvBeam s_beam[kStage ? kLvNearTile : 1];
     const uint32_t h0 = blockIdx.y * tile, h1 = min(nh, h0 + tile);
-    for (uint32_t h = h0 + threadIdx.x; h < h1; h += 64u) s_beam[h - h0] = beams[h];
-    __syncthreads();
+    if (kStage) {
+        for (uint32_t h = h0 + threadIdx.x; h < h1; h += 64u) s_beam[h - h0] = beams[h];
+        __syncthreads();
+    }
 #pragma unroll 4
     for (uint32_t h = h0; h < h1; ++h) {
-        const LvBeam b = s_beam[h - h0];
+        const LvBeam b = kStage ? s_beam[h - h0] : beams[h];
         bool near = false;
         const bool high = (double)b.pz > (a.offset + (double)a.oz);
         if (in_range && !(high && low)) {
