@@ -508,13 +508,20 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
             const uint32_t q = base + (uint32_t)wave * kWave + lane;
             bool keep = false;
             LvCand c;
+            c.p = c.prev = c.r0 = c.r1 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < s1) {
                 uint32_t j = 0;   // first bucket whose inclusive count exceeds q
 #pragma unroll
                 for (uint32_t step = kLvGroup / 2; step > 0; step >>= 1)
                     if (L.g_incl[j + step - 1] <= q) j += step;
                 const uint32_t si = L.g_c0[j] + q;
-                c = a.cand[si];   // one 64-byte record (was: sorted -> samples -> rays -> previous sample, four dependent loads)
+                // one 64-byte record (was: sorted -> samples -> rays -> previous sample, four dependent loads), as four 16-byte
+                // loads (copied as a struct, part of it went through scratch memory: a store, a wait, a load and a wait per sample)
+                const float4 *cp = reinterpret_cast<const float4 *>(a.cand + si);
+                c.p = cp[0];
+                c.prev = cp[1];
+                c.r0 = cp[2];
+                c.r1 = cp[3];
                 keep = !(tlx > c.p.x || c.p.x > thx || tly > c.p.y || c.p.y > thy || tlz > c.p.z || c.p.z > thz);
                 if (keep && ((int)c.p.w & 3) == 2) {
                     const bool prev_core = !(clx > c.prev.x || c.prev.x > chx || cly > c.prev.y || c.prev.y > chy || clz > c.prev.z || c.prev.z > chz);
@@ -533,7 +540,13 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
                 before += v < wave ? cv : 0u;
                 total += cv;
             }
-            if (keep) L.cand[before + slot] = c;
+            if (keep) {
+                float4 *lp = reinterpret_cast<float4 *>(&L.cand[before + slot]);
+                lp[0] = c.p;
+                lp[1] = c.prev;
+                lp[2] = c.r0;
+                lp[3] = c.r1;
+            }
             __syncthreads();
             // Rounds of 64 staged candidates.  (T) every wave tests eight candidates against the 64 voxels (lane = voxel):
             // which voxels count it — as a hit in the box, or as its ray's lowest-index sample in the box.  (E) the counting
