@@ -52,6 +52,11 @@ def test_single_gpu_line(built):
     assert d["lv"]["sequence_ms"] > 0 and d["lv"]["voxel_kernel_ms_sum"] > 0 and d["lv"]["cpu_baseline"]["value"] > 0
     assert d["lv"]["synthetic_50k"]["roofline"]["kernel_ms"] > 0
     assert d["bgkl"]["ms_per_step"] > 0 and d["bgkl"]["cpu_baseline"]["value"] > 0
+    # the side legs time every insert on its own and quote the median (one stalled insert must not move the number)
+    assert d["bgkl"]["ms_per_step"] <= d["bgkl"]["ms_per_step_mean"] * 1.5 and d["bgkl"]["ms_per_step_max"] >= d["bgkl"]["ms_per_step"]
+    # the GP legs quote stamped instruction counts when profiles/gp_counters.json belongs to this build's gp_kernels.h
+    vi = d["gp"]["depth3"]["roofline"].get("valu_issue")
+    assert vi is None or (0 < vi["frac"] < 1 and vi["source"])
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["kernel_ms"] > 0 and rf["algorithmic_bytes_per_launch"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
