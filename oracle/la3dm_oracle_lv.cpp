@@ -12,9 +12,11 @@
 //   Occupancy (min_W, UNCERTAIN)        src/bgklvoctomap/bgklvoctree_node.cpp:17-77
 //   OcTree (key = (depth << 28) + index) src/bgklvoctomap/bgklvoctree.cpp:9-15, 72-148
 //
-// PARITY PINNING: node/octree/block layers are the same code as the BGK variant apart from the
-// wider index and the extra UNCERTAIN state (diff'ed); the LV node arithmetic and
-// the Eigen/PCL parts are restated here => **parity unpinned** for those.
+// PARITY PINNING: the LV node (get_prob / get_var / update / the (A, B) constructor), the 28-bit node key, the
+// LUT, leaf order, prune and block hashing are pinned against the reference's own compiled LV sources
+// (oracle/_ref/libla3dm_ref_lv.so = ref_harness.cpp -DLA3DM_REF_LV; golden tests/golden/ref_kat_lv.npz;
+// tests/test_oracle.py::test_lv_*_against_reference_kat).  The Eigen/PCL parts (kernel arithmetic, voxel grid) and
+// the R-tree gather order are restated here => **parity unpinned** for those.
 //
 // Row order.  The reference sums a voxel's kernel row in R-tree search order (then Eigen's GEMV
 // order) — both unpinned.  Restated order: the training points are bucketed on a grid of edge
@@ -495,6 +497,60 @@ void orc_lv_node_update(void *h, float *A, float *B, uint8_t *state, float ybar,
 }
 float orc_lv_node_prob(void *h, float A, float B) { return lv_prob(((Map *)h)->p, Node{0, A, B, 0}); }
 float orc_lv_node_var(void *h, float A, float B) { return lv_var(((Map *)h)->p, Node{0, A, B, 0}); }
+
+// (A, B) constructor of the node, bgklvoctree_node.cpp:17-27: prior + (A, B), classified = false, state from var / prob
+void orc_lv_node_ctor(void *h, float A, float B, float *mA, float *mB, uint8_t *state) {
+    const Params &p = ((Map *)h)->p;
+    Node n{0, p.prior_A + A, p.prior_B + B, LV_UNKNOWN};
+    float var = lv_var(p, n);
+    if (var > p.var_thresh)
+        n.state = LV_UNCERTAIN;
+    else {
+        float pr = lv_prob(p, n);
+        n.state = pr > p.occupied_thresh ? LV_OCCUPIED : (pr < p.free_thresh ? LV_FREE : LV_UNKNOWN);
+    }
+    *mA = n.A; *mB = n.B; *state = n.state;
+}
+// single-block entry points for the reference pin (tests/test_oracle.py)
+int64_t orc_lv_block_to_hash_key(void *h, float x, float y, float z) { return block_key(((Map *)h)->p, x, y, z); }
+void orc_lv_hash_key_to_block(void *h, int64_t key, float *out3) {
+    V3 c = key_center(((Map *)h)->p, key);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+int orc_lv_lut(void *h, int depth, uint32_t index, float *out3) {
+    Map *m = (Map *)h;
+    if (depth < 0 || depth >= (int)m->lut.size() || index >= m->lut[depth].size()) return 0;
+    const V3 &o = m->lut[depth][index];
+    out3[0] = o.x; out3[1] = o.y; out3[2] = o.z;
+    return 1;
+}
+void *orc_lv_block_new(void *h, float cx, float cy, float cz) { return block_new(((Map *)h)->p, V3{cx, cy, cz}); }
+void orc_lv_block_free(void *b) { delete (Block *)b; }
+int orc_lv_block_leaves(void *h, void *b, int32_t *keys, float *loc_xyz, float *sizes, int cap) {
+    Map *m = (Map *)h;
+    Block *blk = (Block *)b;
+    std::vector<uint32_t> ks;
+    enumerate_leaves(m->p, *blk, ks);
+    for (int i = 0; i < (int)ks.size() && i < cap; ++i) {
+        const V3 &o = m->lut[ks[i] >> 28][ks[i] & 0xFFFFFFFu];
+        keys[i] = (int32_t)ks[i];
+        loc_xyz[3 * i] = o.x + blk->center.x; loc_xyz[3 * i + 1] = o.y + blk->center.y; loc_xyz[3 * i + 2] = o.z + blk->center.z;
+        sizes[i] = float(m->p.block_size / pow(2, ks[i] >> 28));
+    }
+    return (int)ks.size();
+}
+void orc_lv_block_update(void *h, void *b, int32_t key, float ybar, float kbar) {
+    lv_update(((Map *)h)->p, ((Block *)b)->layer[(uint32_t)key >> 28][(uint32_t)key & 0xFFFFFFFu], ybar, kbar);
+}
+int orc_lv_block_prune(void *h, void *b) { return block_prune(((Map *)h)->p, *(Block *)b) ? 1 : 0; }
+int orc_lv_block_node(void *b, int32_t key, float *A, float *B, uint8_t *state, uint8_t *classified) {
+    Block *blk = (Block *)b;
+    uint32_t d = (uint32_t)key >> 28, i = (uint32_t)key & 0xFFFFFFFu;
+    if (d >= blk->layer.size() || !blk->alive[d]) return 0;
+    const Node &n = blk->layer[d][i];
+    *A = n.A; *B = n.B; *state = n.state; *classified = n.classified;
+    return 1;
+}
 
 int64_t orc_lv_block_count(void *h) { return (int64_t)((Map *)h)->blocks.size(); }
 // leaves of blocks that hold any classified node or any non-default state (all blocks if all != 0)

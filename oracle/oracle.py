@@ -30,8 +30,8 @@ def build(force=False):
     if need or max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("la3dm_oracle.cpp", "la3dm_oracle_lv.cpp")) > \
             os.path.getmtime(os.path.join(_HERE, "liboracle.so")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so", "liboracle_omp.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(
-            os.path.join(_HERE, "_ref", "libla3dm_ref.so"))):
+    if os.path.isdir("/root/reference/src") and (force or not all(os.path.exists(
+            os.path.join(_HERE, "_ref", f)) for f in ("libla3dm_ref.so", "libla3dm_ref_lv.so"))):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -54,6 +54,24 @@ def _load(name):
     lib.orc_lv_training_data.restype = C.c_int64
     lib.orc_lv_training_data.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.orc_lv_node_ctor.argtypes = [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.c_uint8)]
+    lib.orc_lv_block_to_hash_key.restype = C.c_int64
+    lib.orc_lv_block_to_hash_key.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    lib.orc_lv_hash_key_to_block.argtypes = [C.c_void_p, C.c_int64, f32p]
+    lib.orc_lv_lut.restype = C.c_int
+    lib.orc_lv_lut.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p]
+    lib.orc_lv_block_new.restype = C.c_void_p
+    lib.orc_lv_block_new.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    lib.orc_lv_block_free.argtypes = [C.c_void_p]
+    lib.orc_lv_block_leaves.restype = C.c_int
+    lib.orc_lv_block_leaves.argtypes = [C.c_void_p, C.c_void_p, i32p, f32p, f32p, C.c_int]
+    lib.orc_lv_block_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float]
+    lib.orc_lv_block_prune.restype = C.c_int
+    lib.orc_lv_block_prune.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_lv_block_node.restype = C.c_int
+    lib.orc_lv_block_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
     lib.orc_lv_seg_dist.restype = C.c_float
     lib.orc_lv_seg_dist.argtypes = [f32p, f32p, f32p]
     lib.orc_lv_kernel.restype = C.c_float
@@ -411,6 +429,54 @@ def bgk_predict(sf2, ell, xs, x, y):
 # compiled reference layer (oracle/_ref)
 # ---------------------------------------------------------------------------
 _ref = None
+_ref_lv = None
+
+
+def _bind_ref(R):
+    """prototypes of the entry points both builds of oracle/ref_harness.cpp export"""
+    R.ref_configure.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7
+    R.ref_block_size.restype = C.c_float
+    R.ref_lut.restype = C.c_int
+    R.ref_lut.argtypes = [C.c_int, C.c_int, f32p]
+    R.ref_block_to_hash_key.restype = C.c_int64
+    R.ref_block_to_hash_key.argtypes = [C.c_float] * 3
+    R.ref_hash_key_to_block.argtypes = [C.c_int64, f32p]
+    R.ref_get_extended_block.argtypes = [C.c_int64, i64p]
+    R.ref_block_new.restype = C.c_void_p
+    R.ref_block_new.argtypes = [C.c_float] * 3
+    R.ref_block_free.argtypes = [C.c_void_p]
+    R.ref_block_extended.argtypes = [C.c_void_p, i64p]
+    R.ref_block_grid.argtypes = [C.c_void_p, f32p, i32p, C.POINTER(C.c_int32), f32p]
+    R.ref_block_leaves.restype = C.c_int
+    R.ref_block_leaves.argtypes = [C.c_void_p, i32p, f32p, f32p, C.c_int]
+    R.ref_block_update.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+    R.ref_block_prune.restype = C.c_int
+    R.ref_block_prune.argtypes = [C.c_void_p]
+    R.ref_block_node.restype = C.c_int
+    R.ref_block_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    R.ref_node_sequence.argtypes = [f32p, f32p, C.c_int, f32p, f32p, u8p, f32p, f32p]
+    return R
+
+
+def ref_lv():
+    """ctypes handle of the reference's std-only BGK-LV layer (node, 28-bit key tree, block, point6f), or None."""
+    global _ref_lv
+    if _ref_lv is None:
+        build()
+        path = os.path.join(_HERE, "_ref", "libla3dm_ref_lv.so")
+        if not os.path.exists(path):
+            return None
+        R = _bind_ref(C.CDLL(path))
+        R.ref_configure_lv.argtypes = [C.c_int, C.c_float]
+        R.ref_node_to_hash_key.restype = C.c_int32
+        R.ref_node_to_hash_key.argtypes = [C.c_int, C.c_uint32]
+        R.ref_hash_key_to_node.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+        R.ref_node_ctor.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        R.ref_point6f.argtypes = [f32p] * 6
+        _ref_lv = R
+    return _ref_lv
 
 
 def ref_available():
@@ -424,29 +490,7 @@ def ref():
     if _ref is None:
         if not ref_available():
             return None
-        R = C.CDLL(os.path.join(_HERE, "_ref", "libla3dm_ref.so"))
-        R.ref_configure.argtypes = [C.c_float, C.c_int] + [C.c_float] * 7
-        R.ref_block_size.restype = C.c_float
-        R.ref_lut.restype = C.c_int
-        R.ref_lut.argtypes = [C.c_int, C.c_int, f32p]
-        R.ref_block_to_hash_key.restype = C.c_int64
-        R.ref_block_to_hash_key.argtypes = [C.c_float] * 3
-        R.ref_hash_key_to_block.argtypes = [C.c_int64, f32p]
-        R.ref_get_extended_block.argtypes = [C.c_int64, i64p]
-        R.ref_block_new.restype = C.c_void_p
-        R.ref_block_new.argtypes = [C.c_float] * 3
-        R.ref_block_free.argtypes = [C.c_void_p]
-        R.ref_block_extended.argtypes = [C.c_void_p, i64p]
-        R.ref_block_grid.argtypes = [C.c_void_p, f32p, i32p, C.POINTER(C.c_int32), f32p]
-        R.ref_block_leaves.restype = C.c_int
-        R.ref_block_leaves.argtypes = [C.c_void_p, i32p, f32p, f32p, C.c_int]
-        R.ref_block_update.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
-        R.ref_block_prune.restype = C.c_int
-        R.ref_block_prune.argtypes = [C.c_void_p]
-        R.ref_block_node.restype = C.c_int
-        R.ref_block_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                     C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        R.ref_node_sequence.argtypes = [f32p, f32p, C.c_int, f32p, f32p, u8p, f32p, f32p]
+        R = _bind_ref(C.CDLL(os.path.join(_HERE, "_ref", "libla3dm_ref.so")))
         R.ref_rtree_new.restype = C.c_void_p
         R.ref_rtree_new.argtypes = [f32p, C.c_int]
         R.ref_rtree_free.argtypes = [C.c_void_p]

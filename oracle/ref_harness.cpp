@@ -7,23 +7,45 @@
 // pins the oracle's restatement of block hashing, the voxel LUT, leaf order,
 // Occupancy::update, OcTree::prune and the R-tree closed-box rule.
 //
+// Built a second time with -DLA3DM_REF_LV over the reference's BGK-LV family (bgklvoctree_node.cpp, bgklvoctree.cpp,
+// bgklvblock.cpp, point6f.cpp — the same class names in the same namespace, hence a separate library,
+// oracle/_ref/libla3dm_ref_lv.so): the LV node (min_W floor, f64 pow variance, UNCERTAIN state), the 28-bit node key,
+// the LV block / tree and point6f's constructors.
+//
 // The reference's Eigen/PCL/ROS-dependent files (bgkinference.h, bgkoctomap.cpp, the
 // nodes) are NOT buildable here (no Eigen/PCL/ROS in the image) and are not used.
 //
 // Access to the reference's private statics goes through the friendship the
 // reference itself grants to `la3dm::BGKOctoMap` (bgkblock.h:56, bgkoctree.h:30,
-// bgkoctree_node.h:28): this harness defines a class of that name.
+// bgkoctree_node.h:28; the LV headers name `la3dm::BGKLVOctoMap`, bgklvoctree_node.h:29): this harness defines a class
+// of that name.
 
 #include <cmath>
 #include <cstdint>
 #include <vector>
 
+#ifdef LA3DM_REF_LV
+#include "bgklvblock.h"
+#include "point6f.h"
+#define REF_MAP_CLASS BGKLVOctoMap   // the friend the LV headers name (bgklvblock.h:56, bgklvoctree.h:30, bgklvoctree_node.h:29)
+typedef unsigned long ref_index_t;   // bgklvoctree.h:15-18
+#else
 #include "bgkblock.h"
+#define REF_MAP_CLASS BGKOctoMap
+typedef unsigned short ref_index_t;
+#endif
 #include "rtree.h"
 
 namespace la3dm {
-class BGKOctoMap {
+class REF_MAP_CLASS {
 public:
+#ifdef LA3DM_REF_LV
+    // the two extra statics of BGKLVOctoMap::BGKLVOctoMap, src/bgklvoctomap/bgklvoctomap.cpp:61-62
+    static void configure_lv(bool original_size, float min_W) {
+        OcTreeNode::original_size = original_size;
+        OcTreeNode::min_W = min_W;
+    }
+#endif
     // what BGKOctoMap::BGKOctoMap does, src/bgkoctomap/bgkoctomap.cpp:31-56
     static void configure(float resolution, unsigned short block_depth, float sf2, float ell, float free_thresh,
                           float occupied_thresh, float var_thresh, float prior_A, float prior_B) {
@@ -55,19 +77,20 @@ public:
 }  // namespace la3dm
 
 using namespace la3dm;
+typedef REF_MAP_CLASS BGKOctoMapShim;
 
 extern "C" {
 
 void ref_configure(float resolution, int block_depth, float sf2, float ell, float free_thresh, float occupied_thresh,
                    float var_thresh, float prior_A, float prior_B) {
-    BGKOctoMap::configure(resolution, (unsigned short) block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
+    BGKOctoMapShim::configure(resolution, (unsigned short) block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
                           prior_A, prior_B);
 }
-float ref_block_size() { return BGKOctoMap::block_size(); }
+float ref_block_size() { return BGKOctoMapShim::block_size(); }
 int ref_sizeof_node() { return (int) sizeof(OcTreeNode); }
 int ref_sizeof_block() { return (int) sizeof(Block); }
-int ref_lut_size() { return BGKOctoMap::lut_size(); }
-int ref_lut(int depth, int index, float *out3) { return BGKOctoMap::lut(node_to_hash_key(depth, index), out3); }
+int ref_lut_size() { return BGKOctoMapShim::lut_size(); }
+int ref_lut(int depth, int index, float *out3) { return BGKOctoMapShim::lut(node_to_hash_key(depth, index), out3); }
 
 int64_t ref_block_to_hash_key(float x, float y, float z) { return block_to_hash_key(x, y, z); }
 void ref_hash_key_to_block(int64_t key, float *out3) {
@@ -112,11 +135,12 @@ void ref_block_update(void *b, int32_t key, float ybar, float kbar) { (*(Block *
 int ref_block_prune(void *b) { return ((Block *) b)->prune() ? 1 : 0; }
 int ref_block_node(void *b, int32_t key, float *A, float *B, uint8_t *state, float *prob, float *var) {
     Block *blk = (Block *) b;
-    unsigned short depth, index;
+    unsigned short depth;
+    ref_index_t index;
     hash_key_to_node(key, depth, index);
-    if (!BGKOctoMap::layer_alive(*blk, depth)) return 0;
+    if (!BGKOctoMapShim::layer_alive(*blk, depth)) return 0;
     OcTreeNode &n = (*blk)[key];
-    *A = BGKOctoMap::A(n); *B = BGKOctoMap::B(n); *state = (uint8_t) n.get_state();
+    *A = BGKOctoMapShim::A(n); *B = BGKOctoMapShim::B(n); *state = (uint8_t) n.get_state();
     *prob = n.get_prob(); *var = n.get_var();
     return 1;
 }
@@ -127,10 +151,37 @@ void ref_node_sequence(const float *ybar, const float *kbar, int n, float *A, fl
     OcTreeNode node;
     for (int i = 0; i < n; ++i) {
         node.update(ybar[i], kbar[i]);
-        A[i] = BGKOctoMap::A(node); B[i] = BGKOctoMap::B(node); state[i] = (uint8_t) node.get_state();
+        A[i] = BGKOctoMapShim::A(node); B[i] = BGKOctoMapShim::B(node); state[i] = (uint8_t) node.get_state();
         prob[i] = node.get_prob(); var[i] = node.get_var();
     }
 }
+
+#ifdef LA3DM_REF_LV
+void ref_configure_lv(int original_size, float min_W) { BGKOctoMapShim::configure_lv(original_size != 0, min_W); }
+// node_to_hash_key / hash_key_to_node with the 28-bit index, src/bgklvoctomap/bgklvoctree.cpp:9-16
+int32_t ref_node_to_hash_key(int depth, uint32_t index) { return node_to_hash_key((unsigned short) depth, (unsigned long) index); }
+void ref_hash_key_to_node(int32_t key, int32_t *depth, uint32_t *index) {
+    unsigned short d;
+    unsigned long i;
+    hash_key_to_node(key, d, i);
+    *depth = d; *index = (uint32_t) i;
+}
+// Occupancy(A, B): prior + (A, B), classified by the constructor (bgklvoctree_node.cpp:17-27); get_prob / get_var of it
+void ref_node_ctor(float A, float B, float *mA, float *mB, uint8_t *state, float *prob, float *var) {
+    OcTreeNode n(A, B);
+    *mA = BGKOctoMapShim::A(n); *mB = BGKOctoMapShim::B(n); *state = (uint8_t) n.get_state();
+    *prob = n.get_prob(); *var = n.get_var();
+}
+// point6f's constructors (include/common/point6f.h:43-92) as the LV front end uses them, and start() / end()
+void ref_point6f(const float *a3, const float *b3, float *from_point, float *from_pair, float *from_xyz, float *start_end) {
+    point3f a(a3[0], a3[1], a3[2]), b(b3[0], b3[1], b3[2]);
+    point6f p(a), q(a, b), r(a3[0], a3[1], a3[2]);
+    for (int i = 0; i < 6; ++i) { from_point[i] = p(i); from_pair[i] = q(i); from_xyz[i] = r(i); }
+    point3f s = q.start(), e = q.end();
+    start_end[0] = s.x(); start_end[1] = s.y(); start_end[2] = s.z();
+    start_end[3] = e.x(); start_end[4] = e.y(); start_end[5] = e.z();
+}
+#endif
 
 // R-tree with the reference's instantiation shape (bgkoctomap.h:32 uses GPPointType*; ids suffice)
 typedef RTree<int, float, 3, float> RefRTree;
@@ -150,7 +201,7 @@ void ref_rtree_free(void *t) { delete (RefRTree *) t; }
 // box query as BGKOctoMap::get_gp_points_in_bbox(key, out) does it
 // (src/bgkoctomap/bgkoctomap.cpp:497-517): centre -/+ half_size in point3f arithmetic.
 int ref_rtree_block_query(void *t, int64_t key, int32_t *ids, int cap) {
-    float bs = BGKOctoMap::block_size();
+    float bs = BGKOctoMapShim::block_size();
     point3f half_size(bs / 2.0f, bs / 2.0f, bs / 2.0);
     point3f lim_min = hash_key_to_block(key) - half_size;
     point3f lim_max = hash_key_to_block(key) + half_size;

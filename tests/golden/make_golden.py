@@ -5,6 +5,10 @@ for the first file; the GPU box only reads the committed outputs).
   ref_kat.npz      known answers captured from the REFERENCE's own std-only sources compiled in
                    place (oracle/_ref, see oracle/ref_harness.cpp): block hashing, voxel LUT,
                    leaf order, Occupancy::update sequences, OcTree::prune, R-tree box queries.
+  ref_kat_lv.npz   the same for the reference's BGK-LV family (bgklvoctree_node.cpp, bgklvoctree.cpp, bgklvblock.cpp,
+                   point6f.cpp; oracle/_ref/libla3dm_ref_lv.so): node update sequences incl. the min_W floor and the
+                   UNCERTAIN state, the (A, B) constructor, get_prob / get_var, the 28-bit node key, LUT up to depth 5,
+                   leaf order / update / prune rounds of whole blocks, block hashing, point6f's constructors.
   oracle_kat.npz   known answers of the CPU restatement for the parts the reference cannot pin
                    (Eigen/PCL absent): kernel table k(r), per-block predict cases, voxel-grid
                    filter case.  Regression pins + inputs for the GPU parity tests.
@@ -169,6 +173,126 @@ def ref_kat():
     print("ref_kat.npz:", len(out), "arrays")
 
 
+LV_YAML = (0.1, 5, 0.1, 0.2, 0.3, 0.7, 0.2, 0.001, 0.001)     # config/methods/bgklvoctomap.yaml (+ original_size, min_W)
+
+
+def ref_kat_lv():
+    R = O.ref_lv()
+    assert R is not None, "oracle/_ref/libla3dm_ref_lv.so not built (needs /root/reference)"
+    rng = np.random.default_rng(20260929)
+    out = {}
+    R.ref_configure_lv(1, 0.001)
+    # 28-bit node keys
+    dk = np.array([(d, i) for d in range(6) for i in (0, 1, 7, 8 ** d - 1 if d else 0, (8 ** d) // 3)], np.int64)
+    keys = np.array([R.ref_node_to_hash_key(int(d), int(i)) for d, i in dk], np.int32)
+    back = np.zeros((len(keys), 2), np.int64)
+    d_, i_ = C.c_int32(), C.c_uint32()
+    for j, k in enumerate(keys):
+        R.ref_hash_key_to_node(int(k), C.byref(d_), C.byref(i_))
+        back[j] = (d_.value, i_.value)
+    out.update(key_depth_index=dk, key_value=keys, key_back=back)
+    t = np.zeros(3, np.float32)
+    e = np.zeros(7, np.int64)
+    for res, depth in ((0.1, 3), (0.1, 4), (0.05, 5)):
+        R.ref_configure(res, depth, *LV_YAML[2:])
+        bs = R.ref_block_size()
+        tag = f"d{depth}"
+        out[f"{tag}_resolution"], out[f"{tag}_block_size"] = np.float32(res), np.float32(bs)
+        pts = np.concatenate([rng.uniform(-40, 40, (300, 3)), (rng.integers(-50, 50, (150, 3)) + 0.5) * bs,
+                              rng.integers(-50, 50, (80, 3)) * bs, [[0, 0, 0], [0.39, -0.41, 7.45], [-3.75, 12.95, 4.25]]]).astype(np.float32)
+        hk = np.array([R.ref_block_to_hash_key(*p) for p in pts], np.int64)
+        centres = np.zeros((len(pts), 3), np.float32)
+        ebs = np.zeros((len(pts), 7), np.int64)
+        for i, k in enumerate(hk):
+            R.ref_hash_key_to_block(int(k), t)
+            centres[i] = t
+            R.ref_get_extended_block(int(k), e)
+            ebs[i] = e
+        out[f"{tag}_hash_pts"], out[f"{tag}_hash_keys"], out[f"{tag}_hash_centres"], out[f"{tag}_eblocks"] = pts, hk, centres, ebs
+        lut = []
+        for d in range(depth):
+            for i in range(8 ** d):
+                assert R.ref_lut(d, i, t)
+                lut.append(t.copy())
+        out[f"{tag}_lut"] = np.asarray(lut, np.float32)
+        # whole blocks: leaf order, update rounds that drive sibling groups to one state (incl. UNCERTAIN), prune
+        cap = 8 ** (depth - 1)
+        for case in range(2):
+            c = (np.array([[0.8, 0.8, 0.0], [-3.6, 12.8, 4.4]][case]) / 0.4 * bs).astype(np.float32)
+            b = R.ref_block_new(float(c[0]), float(c[1]), float(c[2]))
+            keys_l = np.zeros(cap, np.int32)
+            loc = np.zeros((cap, 3), np.float32)
+            sz = np.zeros(cap, np.float32)
+            n = R.ref_block_leaves(b, keys_l, loc, sz, cap)
+            bt = f"{tag}_blk{case}"
+            out[f"{bt}_center"] = c
+            out[f"{bt}_fresh_keys"], out[f"{bt}_fresh_loc"], out[f"{bt}_fresh_size"] = keys_l[:n].copy(), loc[:n].copy(), sz[:n].copy()
+            ops = []
+            for rnd in range(4):
+                n = R.ref_block_leaves(b, keys_l, loc, sz, cap)
+                for k in keys_l[:n].copy():
+                    kd, ki = (int(k) >> 28) & 0xF, int(k) & 0xFFFFFFF
+                    g = np.random.default_rng((ki // 8) + kd * 10 ** 7 + 17 * rnd + 1000 * case).integers(0, 5)
+                    if g == 0:
+                        yb, kb = 0.0, float(rng.uniform(0.5, 3))                  # free
+                    elif g == 1:
+                        kb = float(rng.uniform(0.5, 3)); yb = kb                  # occupied
+                    elif g == 2:
+                        kb = float(rng.uniform(0.0, 2)); yb = kb * float(rng.uniform(0, 1))
+                    elif g == 3:
+                        kb = float(rng.uniform(0.002, 0.05)); yb = kb * 0.5       # p = 0.5 with little mass: UNCERTAIN (var 0.25 > 0.2)
+                    else:
+                        continue
+                    R.ref_block_update(b, int(k), yb, kb)
+                    ops.append((rnd, int(k), yb, kb))
+                pr = R.ref_block_prune(b)
+                n = R.ref_block_leaves(b, keys_l, loc, sz, cap)
+                A = C.c_float(); B = C.c_float(); S = C.c_uint8(); P = C.c_float(); V = C.c_float()
+                rows = []
+                for k in keys_l[:n]:
+                    assert R.ref_block_node(b, int(k), C.byref(A), C.byref(B), C.byref(S), C.byref(P), C.byref(V))
+                    rows.append((int(k), A.value, B.value, S.value, P.value, V.value))
+                out[f"{bt}_r{rnd}_pruned"] = np.int32(pr)
+                out[f"{bt}_r{rnd}_leaves"] = np.asarray(rows, np.float64)
+                out[f"{bt}_r{rnd}_loc"], out[f"{bt}_r{rnd}_size"] = loc[:n].copy(), sz[:n].copy()
+            out[f"{bt}_ops"] = np.asarray(ops, np.float64)
+            R.ref_block_free(b)
+    # node sequences: the YAML's statics and the constructor defaults of bgklvoctomap.cpp:21-32 (min_W 0.1: the floor is active)
+    for name, cfg, min_w in (("yaml", LV_YAML, 0.001), ("ctor", (0.1, 4, 1.0, 1.0, 0.3, 0.7, 1.0, 1.0, 1.0), 0.1),
+                             ("floor", (0.1, 4, 1.0, 1.0, 0.3, 0.7, 0.2, 0.001, 0.001), 0.1)):
+        R.ref_configure(*cfg)
+        R.ref_configure_lv(1, min_w)
+        for seq in range(4):
+            n = 160
+            scale = [1.0, 0.01, 0.2, 3.0][seq]
+            kb = (rng.uniform(0, 1, n) * scale).astype(np.float32)
+            # seq 0 mostly free evidence, seq 2 mostly occupied, seq 1 tiny masses around min_W, seq 3 mixed
+            frac = [rng.choice([0.0, 0.0, 0.0, 0.05], n), rng.choice([0.0, 1.0, 0.5, 0.3], n), rng.choice([1.0, 1.0, 1.0, 0.9], n),
+                    rng.choice([0.0, 1.0, 0.5, 0.3], n)][seq]
+            yb = (kb * frac).astype(np.float32)
+            if seq == 1:
+                kb[:8], yb[:8] = [1e-9, 0.0015, 0.004, 0.0, 0.02, 0.001, 0.05, 0.09], [0, 0.00075, 0.002, 0, 0.01, 0.001, 0.025, 0]
+            A = np.zeros(n, np.float32); B = A.copy(); S = np.zeros(n, np.uint8); P = A.copy(); V = A.copy()
+            R.ref_node_sequence(yb, kb, n, A, B, S, P, V)
+            t_ = f"node_{name}{seq}"
+            out.update({f"{t_}_ybar": yb, f"{t_}_kbar": kb, f"{t_}_A": A, f"{t_}_B": B, f"{t_}_state": S, f"{t_}_prob": P, f"{t_}_var": V})
+        ab = np.concatenate([rng.uniform(0, 2, (200, 2)), rng.uniform(0, 0.05, (200, 2)), [[0, 0], [5, 0], [0, 5], [0.05, 0.04], [0.0004, 0.0005]]]).astype(np.float32)
+        res_ = np.zeros((len(ab), 5), np.float64)
+        mA, mB, S1, P1, V1 = C.c_float(), C.c_float(), C.c_uint8(), C.c_float(), C.c_float()
+        for i, (a_, b_) in enumerate(ab):
+            R.ref_node_ctor(float(a_), float(b_), C.byref(mA), C.byref(mB), C.byref(S1), C.byref(P1), C.byref(V1))
+            res_[i] = (mA.value, mB.value, S1.value, P1.value, V1.value)
+        out[f"ctor_{name}_ab"], out[f"ctor_{name}_out"] = ab, res_
+        out[f"cfg_{name}"] = np.asarray(list(cfg) + [min_w], np.float64)
+    # point6f
+    a3, b3 = rng.uniform(-5, 5, 3).astype(np.float32), rng.uniform(-5, 5, 3).astype(np.float32)
+    o = [np.zeros(6, np.float32) for _ in range(4)]
+    R.ref_point6f(a3, b3, *o)
+    out.update(p6_a=a3, p6_b=b3, p6_from_point=o[0], p6_from_pair=o[1], p6_from_xyz=o[2], p6_start_end=o[3])
+    np.savez_compressed(os.path.join(HERE, "ref_kat_lv.npz"), **out)
+    print("ref_kat_lv.npz:", len(out), "arrays")
+
+
 def oracle_kat():
     rng = np.random.default_rng(7)
     out = {}
@@ -235,6 +359,8 @@ if __name__ == "__main__":
         ref_grid_kat()
     elif len(sys.argv) > 1 and sys.argv[1] == "scan":
         scan_kat()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lv":     # round 4: the reference's compiled BGK-LV node / tree / block
+        ref_kat_lv()
     else:
         ref_kat()
         oracle_kat()

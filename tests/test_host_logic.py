@@ -68,6 +68,22 @@ def test_host_hash_lut_against_reference_kat(built, depth):
     assert (m.lut() == kat[f"d{depth}_lut"]).all()
 
 
+@pytest.mark.parametrize("depth", [3, 4, 5])
+def test_host_lv_hash_lut_against_reference_lv_kat(built, depth):
+    """the host-side BGKLVOctoMap's block hashing / ExtendedBlock / voxel LUT against the reference's compiled BGK-LV
+    sources (tests/golden/ref_kat_lv.npz: bgklvblock.cpp, depth 5 at 0.05 m is configs[3])"""
+    import la3dm_amd
+    kat = np.load(os.path.join(GOLDEN, "ref_kat_lv.npz"))
+    tag = f"d{depth}"
+    m = la3dm_amd.BGKLVOctoMap(**dict(la3dm_amd.LV_YAML, resolution=float(kat[f"{tag}_resolution"]), block_depth=depth), device=-1)
+    assert np.float32(m.get_block_size()) == kat[f"{tag}_block_size"]
+    for p, k, c, e in zip(kat[f"{tag}_hash_pts"], kat[f"{tag}_hash_keys"], kat[f"{tag}_hash_centres"], kat[f"{tag}_eblocks"]):
+        assert m.block_to_hash_key(*map(float, p)) == k
+        assert (m.hash_key_to_block(int(k)) == c).all()
+        assert (m.get_extended_block(int(k)) == e).all()
+    assert (m.lut() == kat[f"{tag}_lut"]).all()
+
+
 @pytest.mark.parametrize("cls", ["BGKOctoMap", "GPOctoMap", "BGKLOctoMap", "BGKLVOctoMap"])
 def test_set_resolution_and_set_block_depth(built, cls):
     """BGKOctoMap::set_resolution / set_block_depth (reference src/bgkoctomap/bgkoctomap.cpp:66-80; the same pair in

@@ -124,6 +124,136 @@ def test_live_reference_layer_if_present(O):
             assert (m.get_extended_block(k) == e1).all()
 
 
+# ---------------------------------------------------------------------------
+# BGK-LV node / tree / block against the reference's own compiled LV sources (tests/golden/ref_kat_lv.npz,
+# written by tests/golden/make_golden.py lv from oracle/_ref/libla3dm_ref_lv.so)
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def kat_lv():
+    return np.load(os.path.join(GOLDEN, "ref_kat_lv.npz"))
+
+
+def _lv_map(O, cfg):
+    keys = ("resolution", "block_depth", "sf2", "ell", "free_thresh", "occupied_thresh", "var_thresh", "prior_A", "prior_B")
+    d = dict(zip(keys, [float(v) for v in cfg[:9]]))
+    d["block_depth"] = int(d["block_depth"])
+    return O.OracleLVMap(**d, original_size=True, min_W=float(cfg[9]))
+
+
+@pytest.mark.parametrize("name", ["yaml", "ctor", "floor"])
+def test_lv_node_against_reference_kat(O, kat_lv, name):
+    """Occupancy::update / get_prob / get_var (f64 pow, min_W floor) / UNCERTAIN and the (A, B) constructor,
+    src/bgklvoctomap/bgklvoctree_node.cpp:17-77, bit for bit"""
+    cfg = kat_lv[f"cfg_{name}"]
+    m = _lv_map(O, cfg)
+    L = O.lib()
+    for seq in range(4):
+        t = f"node_{name}{seq}"
+        a, b, s = C.c_float(np.float32(cfg[7])), C.c_float(np.float32(cfg[8])), C.c_uint8(2)
+        seen = set()
+        for i in range(kat_lv[f"{t}_ybar"].size):
+            L.orc_lv_node_update(m.h, C.byref(a), C.byref(b), C.byref(s), float(kat_lv[f"{t}_ybar"][i]), float(kat_lv[f"{t}_kbar"][i]))
+            assert np.float32(a.value) == kat_lv[f"{t}_A"][i] and np.float32(b.value) == kat_lv[f"{t}_B"][i], (t, i)
+            assert s.value == kat_lv[f"{t}_state"][i], (t, i)
+            assert np.float32(L.orc_lv_node_prob(m.h, a.value, b.value)) == kat_lv[f"{t}_prob"][i], (t, i)
+            assert np.float32(L.orc_lv_node_var(m.h, a.value, b.value)) == kat_lv[f"{t}_var"][i], (t, i)
+            seen.add(s.value)
+    ab, want = kat_lv[f"ctor_{name}_ab"], kat_lv[f"ctor_{name}_out"]
+    mA, mB, st = C.c_float(), C.c_float(), C.c_uint8()
+    for (x, y), w in zip(ab, want):
+        L.orc_lv_node_ctor(m.h, float(x), float(y), C.byref(mA), C.byref(mB), C.byref(st))
+        assert np.float32(mA.value) == np.float32(w[0]) and np.float32(mB.value) == np.float32(w[1]) and st.value == int(w[2])
+        assert np.float32(L.orc_lv_node_prob(m.h, mA.value, mB.value)) == np.float32(w[3])
+        assert np.float32(L.orc_lv_node_var(m.h, mA.value, mB.value)) == np.float32(w[4])
+    if name == "floor":
+        assert {2, 3} <= set(kat_lv["ctor_floor_out"][:, 2].astype(int))      # the fixture does reach UNKNOWN and UNCERTAIN
+
+
+def test_lv_node_key_and_point6f_against_reference_kat(O, kat_lv):
+    """(depth << 28) + index, src/bgklvoctomap/bgklvoctree.cpp:9-16, as the restatement's leaf keys use it; point6f's
+    constructors (include/common/point6f.h:43-92) as the front end uses them: a hit is the degenerate segment (p, p)"""
+    for (d, i), k, back in zip(kat_lv["key_depth_index"], kat_lv["key_value"], kat_lv["key_back"]):
+        assert ((int(d) << 28) + int(i)) & 0xFFFFFFFF == int(k) & 0xFFFFFFFF
+        assert (int(k) & 0xFFFFFFFF) >> 28 == back[0] and int(k) & 0xFFFFFFF == back[1]
+    a, b = kat_lv["p6_a"], kat_lv["p6_b"]
+    assert (kat_lv["p6_from_point"] == np.concatenate([a, a])).all() and (kat_lv["p6_from_xyz"] == np.concatenate([a, a])).all()
+    assert (kat_lv["p6_from_pair"] == np.concatenate([a, b])).all() and (kat_lv["p6_start_end"] == np.concatenate([a, b])).all()
+
+
+@pytest.mark.parametrize("depth", [3, 4, 5])
+def test_lv_block_hash_lut_leaves_prune_against_reference_kat(O, kat_lv, depth):
+    """block hashing, LUT, LeafIterator order with the 28-bit key, update rounds and OcTree::prune (which collapses
+    groups of eight UNCERTAIN nodes too: it compares get_state(), not operator==) of the reference's compiled
+    bgklvblock.cpp / bgklvoctree.cpp, incl. depth 5 at 0.05 m (configs[3])"""
+    tag = f"d{depth}"
+    cfg = [float(kat_lv[f"{tag}_resolution"]), depth, 0.1, 0.2, 0.3, 0.7, 0.2, 0.001, 0.001, 0.001]
+    m = _lv_map(O, cfg)
+    L = O.lib()
+    assert np.float32((2.0 ** (depth - 1)) * np.float32(cfg[0])) == kat_lv[f"{tag}_block_size"]
+    t = np.zeros(3, np.float32)
+    for p, k, c in zip(kat_lv[f"{tag}_hash_pts"], kat_lv[f"{tag}_hash_keys"], kat_lv[f"{tag}_hash_centres"]):
+        assert L.orc_lv_block_to_hash_key(m.h, *map(float, p)) == k
+        L.orc_lv_hash_key_to_block(m.h, int(k), t)
+        assert (t == c).all()
+    lut, j = kat_lv[f"{tag}_lut"], 0
+    for d in range(depth):
+        for i in range(8 ** d):
+            assert L.orc_lv_lut(m.h, d, i, t) and (t == lut[j]).all()
+            j += 1
+    cap = 8 ** (depth - 1)
+    keys, loc, sz = np.zeros(cap, np.int32), np.zeros((cap, 3), np.float32), np.zeros(cap, np.float32)
+    for case in range(2):
+        bt = f"{tag}_blk{case}"
+        c = kat_lv[f"{bt}_center"]
+        b = L.orc_lv_block_new(m.h, float(c[0]), float(c[1]), float(c[2]))
+        n = L.orc_lv_block_leaves(m.h, b, keys, loc, sz, cap)
+        assert n == kat_lv[f"{bt}_fresh_keys"].size and (keys[:n] == kat_lv[f"{bt}_fresh_keys"]).all()
+        assert (loc[:n] == kat_lv[f"{bt}_fresh_loc"]).all() and (sz[:n] == kat_lv[f"{bt}_fresh_size"]).all()
+        ops = kat_lv[f"{bt}_ops"]
+        A, B, S, Cl = C.c_float(), C.c_float(), C.c_uint8(), C.c_uint8()
+        for rnd in range(4):
+            for _, k, yb, kb in ops[ops[:, 0] == rnd]:
+                L.orc_lv_block_update(m.h, b, int(k), float(yb), float(kb))
+            assert L.orc_lv_block_prune(m.h, b) == int(kat_lv[f"{bt}_r{rnd}_pruned"])
+            n = L.orc_lv_block_leaves(m.h, b, keys, loc, sz, cap)
+            rows = kat_lv[f"{bt}_r{rnd}_leaves"]
+            assert n == rows.shape[0] and (keys[:n] == rows[:, 0].astype(np.int64).astype(np.int32)).all()
+            assert (loc[:n] == kat_lv[f"{bt}_r{rnd}_loc"]).all() and (sz[:n] == kat_lv[f"{bt}_r{rnd}_size"]).all()
+            for k, row in zip(keys[:n], rows):
+                assert L.orc_lv_block_node(b, int(k), C.byref(A), C.byref(B), C.byref(S), C.byref(Cl))
+                assert np.float32(A.value) == np.float32(row[1]) and np.float32(B.value) == np.float32(row[2]) and S.value == int(row[3])
+                assert np.float32(L.orc_lv_node_prob(m.h, A.value, B.value)) == np.float32(row[4])
+                assert np.float32(L.orc_lv_node_var(m.h, A.value, B.value)) == np.float32(row[5])
+        L.orc_lv_block_free(b)
+
+
+def test_live_lv_reference_layer_if_present(O):
+    """12 000 fresh random update steps through the reference's compiled LV node and the restatement (skipped where
+    oracle/_ref was not built)"""
+    R = O.ref_lv()
+    if R is None:
+        pytest.skip("oracle/_ref/libla3dm_ref_lv.so not built here")
+    rng = np.random.default_rng(11)
+    L = O.lib()
+    for cfg in ([0.05, 5, 0.1, 0.2, 0.3, 0.7, 0.2, 0.001, 0.001, 0.001], [0.1, 4, 1.0, 1.0, 0.3, 0.7, 1.0, 1.0, 1.0, 0.1],
+                [0.1, 4, 1.0, 0.2, 0.3, 0.7, 0.15, 0.001, 0.001, 0.05]):
+        R.ref_configure(*cfg[:9])
+        R.ref_configure_lv(1, cfg[9])
+        m = _lv_map(O, cfg)
+        n = 4000
+        kb = (rng.uniform(0, 1, n) * rng.choice([1.0, 0.01, 0.1], n)).astype(np.float32)
+        yb = (kb * rng.choice([0.0, 1.0, 0.5, 0.2], n)).astype(np.float32)
+        for lo in range(0, n, 50):          # sequences of 50 steps from a default node
+            A = np.zeros(50, np.float32); B = A.copy(); S = np.zeros(50, np.uint8); P = A.copy(); V = A.copy()
+            R.ref_node_sequence(np.ascontiguousarray(yb[lo:lo + 50]), np.ascontiguousarray(kb[lo:lo + 50]), 50, A, B, S, P, V)
+            a, b, s = C.c_float(np.float32(cfg[7])), C.c_float(np.float32(cfg[8])), C.c_uint8(2)
+            for i in range(50):
+                L.orc_lv_node_update(m.h, C.byref(a), C.byref(b), C.byref(s), float(yb[lo + i]), float(kb[lo + i]))
+                assert np.float32(a.value) == A[i] and np.float32(b.value) == B[i] and s.value == S[i]
+                assert np.float32(L.orc_lv_node_prob(m.h, a.value, b.value)) == P[i]
+                assert np.float32(L.orc_lv_node_var(m.h, a.value, b.value)) == V[i]
+
+
 def test_kernel_properties(O):
     L = O.lib()
     assert L.orc_kernel(0.0, 1.0) == 1.0 and L.orc_kernel(0.0, 0.1) == np.float32(0.1)
