@@ -24,6 +24,7 @@
 // lane evaluates its leaf against the staged points (LDS broadcast reads).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace la3dm_dev {
@@ -826,18 +827,21 @@ struct __attribute__((aligned(16))) WaveLdsR {
     uint2 ring[kRingR];  // {d2, (lane << 13) | (candidate << 2)}
 };
 
-template <int kTrig>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_r(BgkArgs a) {
-    __shared__ WaveLdsR L;
-    const uint32_t lane = threadIdx.x;
+// workgroup -> tile: chunks of 8 logical workgroups stay on one XCD (remap 2, the default), see xcd_remap for mode 0
+__device__ __forceinline__ uint32_t bgk_task_of_workgroup(const BgkArgs &a) {
     uint32_t wg = blockIdx.x;
     if (a.remap == 0) wg = xcd_remap(wg, gridDim.x);
     else if (a.remap == 2) {
         const uint32_t G8 = gridDim.x & ~63u;
         if (wg < G8) wg = (wg & ~63u) | ((wg & 7u) << 3) | ((wg >> 3) & 7u);
     }
-    const uint32_t task = __builtin_amdgcn_readfirstlane(wg);
-    if (task >= a.n_tasks) return;
+    return __builtin_amdgcn_readfirstlane(wg);
+}
+
+// one tile through the general path (any leaf layout, any labels); L: the wave's 5 120 B of LDS
+template <int kTrig>
+__device__ __forceinline__ void bgk_tile_r(const BgkArgs &a, WaveLdsR &L, const uint32_t task) {
+    const uint32_t lane = threadIdx.x;
     const uint32_t blk = task >> a.tpb_shift;
     const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
     const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
@@ -950,6 +954,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
     const uint32_t acc_base = (uint32_t)(uintptr_t)&L.acc0[0];
     const uint32_t cw_base = (uint32_t)(uintptr_t)&L.cw[0];
+    const uint32_t cx_base = (uint32_t)(uintptr_t)&L.cx[0];
     const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRingR - 4 * kWave);
     uint32_t tailb = ring_base;  // LDS byte address of the ring's first free entry
 
@@ -1002,7 +1007,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         while (g < ngroup) {
             // ---- B: test + push ----
             uint32_t i0 = (lane << 13) | (g << 4);  // entry word of candidate 4 g: candidate * 4 in bits 2-7
-            uint32_t ca = 16u * g;                  // LDS byte address of cx[4 g] (the struct sits at LDS address 0)
+            uint32_t ca = cx_base + 16u * g;        // LDS byte address of cx[4 g]
             for (uint32_t left = ngroup - g; left != 0u; --left) {
                 uint32_t i1, st;
                 float tr;
@@ -1072,6 +1077,290 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (updated) {
             A = (float)((double)A + Y);
             B = (float)((double)B + (K - Y));
+            a.alpha[lw] = A;
+            a.beta[lw] = B;
+            a.state[lw] = (uint8_t)(classify(A, B, a) | 0x80u);
+        } else {
+            a.state[lw] = 0;
+        }
+    }
+}
+
+template <int kTrig>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_r(BgkArgs a) {
+    __shared__ WaveLdsR L;
+    const uint32_t task = bgk_task_of_workgroup(a);
+    if (task >= a.n_tasks) return;
+    bgk_tile_r<kTrig>(a, L, task);
+}
+
+// ---------------------------------------------------------------------------
+// bgk_predict_fuse_t (round 4, the default of bgk_sum = 1) — per-axis distance TABLES for aligned 4x4x4 tiles.
+//
+// Same pairs, same fp32 kernel values and the same double accumulators as bgk_predict_fuse_r; what changes is how a
+// (candidate, leaf) distance is formed.  The 64 leaves of an un-pruned tile are the product grid {X0..X3} x {Y0..Y3} x
+// {Z0..Z3} (LUT offsets depend on an axis' own index bits only, bgkblock.cpp:7-32), so the reference's
+//     d2 = dx*dx + (dy*dy + dz*dz)                                             (bgkinference.h:88-93)
+// of candidate c and leaf (i, j, k) is  X2[i][c] + (Y2[j][c] + Z2[k][c])  with 12 squares per candidate instead of
+// 64 x 3: the staging lanes (lane = training point) compute them — (p.x - X_i)^2 etc., the same two roundings as the
+// per-leaf form — and write them TRANSPOSED into LDS (row = axis value, column = candidate slot); the test lanes
+// (lane = leaf) read their three rows for four candidates at a time (3 ds_read_b128) and need two packed adds per PAIR
+// of candidates: 1 VALU per candidate for the distance instead of 4.  Bit-identical d2 (same operations, same order).
+//   * the box cull is exact and free of slack: fp32 + and * are monotone, so min over the leaves of d2 is
+//     minX2 + (minY2 + minZ2); a point is staged iff that is below the hit threshold, i.e. iff SOME leaf hits;
+//   * the label travels in the SIGN of the table entries (label 1: all twelve squares negated; the sums of negated
+//     terms are the negated sums, bit for bit), the hit test compares |d2|, the ring entry is {+-d2, address of the
+//     leaf's accumulator 0}: no per-candidate entry word (one VALU per candidate less in B) and no label read in C;
+//   * ring entries no longer name a candidate slot, so the ring is only drained at the end of the tile: a tile has ONE
+//     partly filled batch whatever its candidate count, and the tables can be small (32 slots: 1 536 B).
+// Tiles that are not an aligned cube of finest-depth leaves (short tiles, pruned blocks) and scans with labels other
+// than 0 / 1 (insert_training_data) take bgk_tile_r in the same launch.
+// LDS per wave: 12 x 32 table (1 536 B) + 2 x 64 double accumulators (1 024 B) + 320-entry ring (2 560 B) = 5 120 B.
+// B per candidate: 1 (packed adds) + v_cmp + 2 v_mbcnt + v_lshl_add = 5 VALU (r: 9).
+// ---------------------------------------------------------------------------
+constexpr int kTabSlots = 32;
+constexpr int kRingT = 320;
+struct __attribute__((aligned(16))) WaveLdsT {
+    float tab[12][kTabSlots];  // rows 0-3 (p.x - X_i)^2, 4-7 y, 8-11 z; all twelve negated for a label-1 point
+    double acc0[kWave];        // sum(k) over the label-0 pairs
+    double acc1[kWave];        // sum(k) over the label-1 pairs
+    uint2 ring[kRingT];        // {+-d2, LDS address of acc0[leaf]}
+};
+static_assert(sizeof(WaveLdsT) == 5120 && sizeof(WaveLdsR) == 5120, "8 waves per SIMD need <= 5 120 B of LDS per wave");
+
+// B, four candidates (one table column group): the four compares first (four SGPR pairs), then the four pushes.  Push of
+// one candidate: 3 VALU + 4 SALU + 1 LDS, all under exec = hit mask (only the hit lanes need a rank); hit lanes write
+// {d2, w} at ring[tail + rank].
+#define LA3DM_TP_LOAD(OFF)                                                                \
+    "ds_read_b128 v[52:55], %[ax] offset:" OFF "\n"                                       \
+    "ds_read_b128 v[56:59], %[ay] offset:" OFF "\n"                                       \
+    "ds_read_b128 v[60:63], %[az] offset:" OFF "\n"                                       \
+    "s_waitcnt lgkmcnt(0)\n"                                                              \
+    "v_pk_add_f32 v[56:57], v[56:57], v[60:61]\n"                                         \
+    "v_pk_add_f32 v[58:59], v[58:59], v[62:63]\n"                                         \
+    "s_nop 0\n"                                                                           \
+    "v_pk_add_f32 v[52:53], v[52:53], v[56:57]\n"                                         \
+    "v_pk_add_f32 v[54:55], v[54:55], v[58:59]\n"                                         \
+    "s_nop 0\n"                                                                           \
+    "v_cmp_gt_f32_e64 %[m0], %[T], |v52|\n"                                               \
+    "v_cmp_gt_f32_e64 %[m1], %[T], |v53|\n"                                               \
+    "v_cmp_gt_f32_e64 %[m2], %[T], |v54|\n"                                               \
+    "v_cmp_gt_f32_e64 %[m3], %[T], |v55|\n"
+// the rank is only needed on the hit lanes: exec = mask first, the two v_mbcnt read exec as their mask operand
+#define LA3DM_TP_PUSH(D, M)                                 \
+    "s_mov_b64 exec, " M "\n"                               \
+    "s_bcnt1_i32_b64 %[st], " M "\n"                        \
+    "v_mbcnt_lo_u32_b32 %[tr], exec_lo, 0\n"                \
+    "v_mbcnt_hi_u32_b32 %[tr], exec_hi, %[tr]\n"            \
+    "v_lshl_add_u32 %[tr], %[tr], 3, %[tail]\n"             \
+    "ds_write2_b32 %[tr], " D ", %[w] offset1:1\n"          \
+    "s_lshl3_add_u32 %[tail], %[st], %[tail]\n"
+#define LA3DM_TP_TRIP(OFF)                                                                          \
+    asm volatile(LA3DM_TP_LOAD(OFF)                                                                 \
+                 LA3DM_TP_PUSH("v52", "%[m0]") LA3DM_TP_PUSH("v53", "%[m1]") LA3DM_TP_PUSH("v54", "%[m2]") LA3DM_TP_PUSH("v55", "%[m3]") \
+                 "s_mov_b64 exec, -1\n"                                                             \
+                 : [tail] "+s"(tailb), [tr] "=&v"(tr), [st] "=&s"(st), [m0] "=&s"(hm0), [m1] "=&s"(hm1), [m2] "=&s"(hm2), [m3] "=&s"(hm3) \
+                 : [ax] "v"(aX), [ay] "v"(aY), [az] "v"(aZ), [T] "s"(hit_t), [w] "v"(w0)            \
+                 : "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
+
+template <int kTrig>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_t(BgkArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[5120];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t task = bgk_task_of_workgroup(a);
+    if (task >= a.n_tasks) return;
+    const uint32_t blk = task >> a.tpb_shift;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
+    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
+    const uint32_t l1 = a.leaf_off[blk + 1];
+    if (l0 >= l1) return;
+    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
+    const uint32_t li = l0 + (lane < nl ? lane : 0u);
+    const uint32_t key = a.leaf_key[li];
+    // an aligned 4x4x4 cube of finest-depth leaves: the indices 64 c + 63 ... 64 c in LeafIterator (descending) order
+    const uint32_t key_first = __builtin_amdgcn_readlane(key, 0), key_last = __builtin_amdgcn_readlane(key, 63);
+    const bool cube = nl == (uint32_t)kWave && (key_last & 63u) == 0u && key_first == key_last + 63u &&
+                      __ballot((key >> 16) + 1u != a.depth) == 0ull;
+    if (!cube || a.label_seq[0] == a.seq || (a.flags & 0x1000u) != 0u) {  // 0x1000: diagnostics, every tile through the general path
+        bgk_tile_r<kTrig>(a, *reinterpret_cast<WaveLdsR *>(s_lds), task);
+        return;
+    }
+    WaveLdsT &L = *reinterpret_cast<WaveLdsT *>(s_lds);
+
+    // flat view of the 7 neighbour ranges (as in bgk_tile_r).  The descriptor is read where it is used: the first two
+    // chunks share one read in the prologue, a tile with more than 128 points reads it again per further chunk (rare) —
+    // its 13 words would otherwise sit in registers for the whole tile.
+    const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
+    const uint32_t M = dsc[14];
+    auto load_chunk = [&](const uint32_t *d, uint32_t cb) {
+        uint32_t adjv[7], pend[6];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            adjv[b] = d[b];
+            asm volatile("" : "+v"(adjv[b]));
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) pend[b] = d[8 + b];
+        const uint32_t f = cb + lane;
+        uint32_t ad;
+        unsigned long long m1, m2, m3, m4, m5, m6;
+        asm("v_cmp_le_u32 %[m1], %[e0], %[f]\n"
+            "v_cmp_le_u32 %[m2], %[e1], %[f]\n"
+            "v_cmp_le_u32 %[m3], %[e2], %[f]\n"
+            "v_cmp_le_u32 %[m4], %[e3], %[f]\n"
+            "v_cmp_le_u32 %[m5], %[e4], %[f]\n"
+            "v_cmp_le_u32 %[m6], %[e5], %[f]\n"
+            "v_cndmask_b32 %[ad], %[a0], %[a1], %[m1]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a2], %[m2]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a3], %[m3]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a4], %[m4]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a5], %[m5]\n"
+            "v_cndmask_b32 %[ad], %[ad], %[a6], %[m6]\n"
+            : [ad] "=&v"(ad), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [m4] "=&s"(m4), [m5] "=&s"(m5), [m6] "=&s"(m6)
+            : [f] "v"(f), [e0] "s"(pend[0]), [e1] "s"(pend[1]), [e2] "s"(pend[2]), [e3] "s"(pend[3]), [e4] "s"(pend[4]),
+              [e5] "s"(pend[5]), [a0] "v"(adjv[0]), [a1] "v"(adjv[1]), [a2] "v"(adjv[2]), [a3] "v"(adjv[3]), [a4] "v"(adjv[4]),
+              [a5] "v"(adjv[5]), [a6] "v"(adjv[6]));
+        // lanes past the end hold a point no leaf can reach
+        return f < M ? a.pts[f + ad] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+    };
+    float4 pc = load_chunk(dsc, 0);
+    float4 pn = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+    if (M > (uint32_t)kWave) pn = load_chunk(dsc, kWave);
+
+    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
+    const float xs0 = div_by_ell(off4.x + cx, a.ell, a.inv_ell), ys0 = div_by_ell(off4.y + cy, a.ell, a.inv_ell),
+                zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
+    L.acc0[lane] = 0.0;
+    L.acc1[lane] = 0.0;
+
+    // the four coordinates per axis.  Lane l holds leaf index c = 63 - l of the cube; c = (i1 j1 k1 i0 j0 k0) in binary:
+    // child number i*4 + j*2 + k at the parent level (bits 5-3) and at the leaf level (bits 2-0), bgkblock.cpp:14-27.
+    // Axis value r = 2 * (high bit) + (low bit); the lanes read below have the other two axes' bits clear.
+    auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    const la3dm_v2f X01 = {rl(xs0, 63), rl(xs0, 59)}, X23 = {rl(xs0, 31), rl(xs0, 27)};
+    const la3dm_v2f Y01 = {rl(ys0, 63), rl(ys0, 61)}, Y23 = {rl(ys0, 47), rl(ys0, 45)};
+    const la3dm_v2f Z01 = {rl(zs0, 63), rl(zs0, 62)}, Z23 = {rl(zs0, 55), rl(zs0, 54)};
+    const uint32_t c6 = lane ^ 63u;
+    const uint32_t ix = ((c6 >> 4) & 2u) | ((c6 >> 2) & 1u), iy = ((c6 >> 3) & 2u) | ((c6 >> 1) & 1u), iz = ((c6 >> 2) & 2u) | (c6 & 1u);
+    const uint32_t tab_base = (uint32_t)(uintptr_t)&L.tab[0][0];
+    constexpr uint32_t kRowB = 4u * kTabSlots;
+    const uint32_t ax0 = tab_base + ix * kRowB, ay0 = tab_base + (4u + iy) * kRowB, az0 = tab_base + (8u + iz) * kRowB;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
+    const uint32_t w0 = (uint32_t)(uintptr_t)&L.acc0[0] + 8u * lane;
+    static_assert(offsetof(WaveLdsT, acc1) - offsetof(WaveLdsT, acc0) == 512 && offsetof(WaveLdsT, acc0) % 1024 == 512,
+                  "c_eval ORs 512 into the address of acc0[leaf] for a label-1 pair");
+    const float hit_t = __uint_as_float(kHitTBits);
+    const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRingT - 4 * kWave);
+    uint32_t tailb = ring_base;  // LDS byte address of the ring's first free entry
+
+    // C: lane evaluates ring entry i and adds k to the leaf's accumulator 0 or 1 (the sign of d2 is the label)
+    auto c_eval = [&](uint32_t i) {
+        const uint2 e = L.ring[i];
+        const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__builtin_fabsf(__uint_as_float(e.x))), a.sf2);
+        const double kd = (double)kv;
+        const uint32_t ad = e.y | ((uint32_t)((int32_t)e.x >> 31) & 0x200u);
+        asm volatile("ds_add_f64 %0, %1\n" : : "v"(ad), "v"(kd) : "memory");
+    };
+    // C round: the full 64-entry batches; the remainder (< 64 entries) moves to the front of the ring
+    auto c_flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t tail = (tailb - ring_base) >> 3;
+        const uint32_t nfull = tail & ~63u, rem = tail & 63u;
+        if (!(a.flags & 0x100u))  // 0x100: profiling ablation
+            for (uint32_t p = 0; p < nfull; p += kWave) c_eval(p + lane);
+        uint2 e = make_uint2(0u, 0u);
+        if (lane < rem) e = L.ring[nfull + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) L.ring[lane] = e;
+        tailb = ring_base + 8u * rem;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // A + B for one chunk of 64 training points (lane = point)
+    auto chunk = [&](const float4 &p) {
+        const la3dm_v2f bx = {p.x, p.x}, by = {p.y, p.y}, bz = {p.z, p.z};
+        la3dm_v2f x01 = bx - X01, x23 = bx - X23, y01 = by - Y01, y23 = by - Y23, z01 = bz - Z01, z23 = bz - Z23;
+        x01 *= x01, x23 *= x23, y01 *= y01, y23 *= y23, z01 *= z01, z23 *= z23;
+        const float mx = fminf(fminf(x01.x, x01.y), fminf(x23.x, x23.y));
+        const float my = fminf(fminf(y01.x, y01.y), fminf(y23.x, y23.y));
+        const float mz = fminf(fminf(z01.x, z01.y), fminf(z23.x, z23.y));
+        // min over the 64 leaves of d2 (+ and * are monotone): staged iff some leaf hits; the filler points of lanes past
+        // the end fail it
+        const bool keep = mx + (my + mz) < hit_t;
+        const unsigned long long m = __ballot(keep);
+        if (m == 0ull) return;
+        const float sg = 1.0f - (p.w + p.w);  // label 0 -> +1, label 1 -> -1 (exact)
+        const la3dm_v2f s2 = {sg, sg};
+        x01 *= s2, x23 *= s2, y01 *= s2, y23 *= s2, z01 *= s2, z23 *= s2;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        const uint32_t n = (uint32_t)__popcll(m);
+        for (uint32_t base = 0; base < n; base += kTabSlots) {
+            const uint32_t nr = min(n - base, (uint32_t)kTabSlots), ngroup = (nr + 3u) >> 2;
+            // pad the last column group with entries no leaf can reach (an X row suffices: the sum stays huge or NaN)
+            if (lane < 4u && nr + lane < 4u * ngroup) {
+                float big;
+                asm volatile("v_mov_b32 %0, 0x5e268890" : "=v"(big));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L.tab[r][nr + lane] = big;
+            }
+            const uint32_t slot = rank - base;
+            if (keep && slot < (uint32_t)kTabSlots) {
+                L.tab[0][slot] = x01.x, L.tab[1][slot] = x01.y, L.tab[2][slot] = x23.x, L.tab[3][slot] = x23.y;
+                L.tab[4][slot] = y01.x, L.tab[5][slot] = y01.y, L.tab[6][slot] = y23.x, L.tab[7][slot] = y23.y;
+                L.tab[8][slot] = z01.x, L.tab[9][slot] = z01.y, L.tab[10][slot] = z23.x, L.tab[11][slot] = z23.y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (a.flags & 0x200u) continue;  // 0x200: profiling ablation
+            uint32_t aX = ax0, aY = ay0, aZ = az0;
+            for (uint32_t g = 0; g < ngroup; ++g) {
+                uint32_t st;
+                float tr;
+                unsigned long long hm0, hm1, hm2, hm3;
+                LA3DM_TP_TRIP("0");
+                aX += 16u, aY += 16u, aZ += 16u;
+                if (tailb > tail_cap) c_flush();
+            }
+            // (the next sub-round overwrites the table: LDS operations of a wave complete in order)
+        }
+    };
+
+    for (uint32_t cb = 0;;) {
+        chunk(pc);
+        cb += kWave;
+        if (cb >= M) break;
+        pc = pn;
+        if (cb + kWave < M) {
+            const uint32_t *d = dsc;
+            asm volatile("" : "+s"(d));  // a fresh read of the descriptor (see above)
+            pn = load_chunk(d, cb + kWave);
+        }
+    }
+
+    // the tile's last, partly filled batch(es)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t tail = (tailb - ring_base) >> 3;
+        if (!(a.flags & 0x100u))
+            for (uint32_t p = 0; p < tail; p += kWave)
+                if (p + lane < tail) c_eval(p + lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    {
+        const double s0 = L.acc0[lane], s1 = L.acc1[lane];
+        const double K = s0 + s1, Y = s1;
+        uint32_t lw = li;
+        asm volatile("" : "+v"(lw));
+        if (K > 0.0 || (a.flags & 1u) != 0u) {  // flag 1: insert_training_data, update() runs unconditionally
+            const float A = (float)((double)a.alpha[lw] + Y);
+            const float B = (float)((double)a.beta[lw] + (K - Y));
             a.alpha[lw] = A;
             a.beta[lw] = B;
             a.state[lw] = (uint8_t)(classify(A, B, a) | 0x80u);

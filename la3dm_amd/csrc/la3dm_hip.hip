@@ -288,6 +288,11 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_ablate = value;
         return LA3DM_OK;
     }
+    if (!strcmp(name, "lds_pad")) {
+        if (value < 0 || value > 32768) return bad_value("0..32768");
+        ctx->opt_lds_pad = value;
+        return LA3DM_OK;
+    }
     if (!strcmp(name, "remap")) {
         if (value < 0 || value > 2) return bad_value("0, 1 or 2");
         ctx->opt_remap = value;
@@ -417,9 +422,9 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     }
 #define LAUNCH_BGK(KERNEL, ...)                                                                 \
     switch (ctx->opt_fast_trig) {                                                              \
-    case 1: hipLaunchKernelGGL((KERNEL<1 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
-    case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, 0, stream, a); break;     \
-    default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, 0, stream, a); break;    \
+    case 1: hipLaunchKernelGGL((KERNEL<1 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;     \
+    case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;     \
+    default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;    \
     }
     if (sum_f64) {
         grid = dim3(a.n_tasks);
