@@ -49,6 +49,10 @@ enum { LA3DM_FREE = 0, LA3DM_OCCUPIED = 1, LA3DM_UNKNOWN = 2, LA3DM_PRUNED = 3 }
 /* la3dm_bgk_scan.flags */
 #define LA3DM_SCAN_UPDATE_UNGATED 0x1u /* insert_training_data semantics: update even when kbar == 0
                                           (src/bgkoctomap/bgkoctomap.cpp:179-185) */
+#define LA3DM_SCAN_LABELS_01 0x2u      /* the caller guarantees that every training label is exactly 0.0f or 1.0f (what
+                                          get_training_data produces, bgkoctomap.cpp:383-458): bgk_sum = 1 may then run the
+                                          table kernel on the un-pruned blocks.  Without it the general kernel runs (and
+                                          detects other labels itself). */
 
 /* Map-wide constants: the statics BGKOctoMap's constructor sets
  * (src/bgkoctomap/bgkoctomap.cpp:31-56) plus the voxel look-up table

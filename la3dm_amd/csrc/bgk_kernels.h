@@ -1091,6 +1091,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ WaveLdsR L;
     const uint32_t task = bgk_task_of_workgroup(a);
     if (task >= a.n_tasks) return;
+    if (a.flags & 0x2000u) {  // launched behind bgk_predict_fuse_t: that kernel has taken the tiles of the full blocks
+        const uint32_t blk = task >> a.tpb_shift;
+        if (a.leaf_off[blk + 1] - a.leaf_off[blk] == 1u << (3u * (a.depth - 1u))) return;
+    }
     bgk_tile_r<kTrig>(a, L, task);
 }
 
@@ -1113,8 +1117,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 //     leaf's accumulator 0}: no per-candidate entry word (one VALU per candidate less in B) and no label read in C;
 //   * ring entries no longer name a candidate slot, so the ring is only drained at the end of the tile: a tile has ONE
 //     partly filled batch whatever its candidate count, and the tables can be small (32 slots: 1 536 B).
-// Tiles that are not an aligned cube of finest-depth leaves (short tiles, pruned blocks) and scans with labels other
-// than 0 / 1 (insert_training_data) take bgk_tile_r in the same launch.
+// The kernel takes the tiles of FULL blocks only (8^(depth-1) leaves, i.e. nothing pruned: by the leaf count alone, no key
+// is read) and needs every label to be 0 or 1 (LA3DM_SCAN_LABELS_01); the host launches bgk_predict_fuse_r behind it for
+// the tiles of the other blocks when the scan has any (n_leaf < n_test_blk * 8^(depth-1)), and instead of it for scans
+// without the label guarantee.
 // LDS per wave: 12 x 32 table (1 536 B) + 2 x 64 double accumulators (1 024 B) + 320-entry ring (2 560 B) = 5 120 B.
 // B per candidate: 1 (packed adds) + v_cmp + 2 v_mbcnt + v_lshl_add = 5 VALU (r: 9).
 // ---------------------------------------------------------------------------
@@ -1165,43 +1171,34 @@ static_assert(sizeof(WaveLdsT) == 5120 && sizeof(WaveLdsR) == 5120, "8 waves per
 
 template <int kTrig>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_t(BgkArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_lds[5120];
+    __shared__ WaveLdsT L;
     const uint32_t lane = threadIdx.x;
     const uint32_t task = bgk_task_of_workgroup(a);
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.tpb_shift;
     const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    const uint32_t l0 = a.leaf_off[blk] + tile * kWave;
-    const uint32_t l1 = a.leaf_off[blk + 1];
-    if (l0 >= l1) return;
-    const uint32_t nl = min(l1 - l0, (uint32_t)kWave);
-    const uint32_t li = l0 + (lane < nl ? lane : 0u);
-    const uint32_t key = a.leaf_key[li];
-    // an aligned 4x4x4 cube of finest-depth leaves: the indices 64 c + 63 ... 64 c in LeafIterator (descending) order
-    const uint32_t key_first = __builtin_amdgcn_readlane(key, 0), key_last = __builtin_amdgcn_readlane(key, 63);
-    const bool cube = nl == (uint32_t)kWave && (key_last & 63u) == 0u && key_first == key_last + 63u &&
-                      __ballot((key >> 16) + 1u != a.depth) == 0ull;
-    if (!cube || a.label_seq[0] == a.seq || (a.flags & 0x1000u) != 0u) {  // 0x1000: diagnostics, every tile through the general path
-        bgk_tile_r<kTrig>(a, *reinterpret_cast<WaveLdsR *>(s_lds), task);
-        return;
-    }
-    WaveLdsT &L = *reinterpret_cast<WaveLdsT *>(s_lds);
+    // only the tiles of FULL blocks (8^(depth-1) leaves: no node above the finest level is a leaf, so every 64
+    // consecutive leaves in LeafIterator order are one aligned 4x4x4 cube); bgk_predict_fuse_r takes the others
+    const uint32_t lb0 = a.leaf_off[blk];
+    if (a.leaf_off[blk + 1] - lb0 != 1u << (3u * (a.depth - 1u))) return;
+    const uint32_t li = lb0 + tile * kWave + lane;
+    // LeafIterator order is descending (bgkoctree.h:101-135): the leaf at list position j of a full block has the
+    // finest-level index 8^(depth-1) - 1 - j, so the key needs no load
+    const uint32_t key = ((a.depth - 1u) << 16) + ((1u << (3u * (a.depth - 1u))) - 1u - (tile * kWave + lane));
 
-    // flat view of the 7 neighbour ranges (as in bgk_tile_r).  The descriptor is read where it is used: the first two
-    // chunks share one read in the prologue, a tile with more than 128 points reads it again per further chunk (rare) —
-    // its 13 words would otherwise sit in registers for the whole tile.
+    // flat view of the 7 neighbour ranges (bgk_prepare's blk_desc, as in bgk_tile_r).  The descriptor is read where it is
+    // used: the first two chunks share one read here, a tile with more than 128 points reads it again per further chunk
+    // (rare) — its 13 words would otherwise sit in registers for the whole tile.
     const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
-    const uint32_t M = dsc[14];
-    auto load_chunk = [&](const uint32_t *d, uint32_t cb) {
-        uint32_t adjv[7], pend[6];
+    // the points of flat indices cb + lane; a lane past the end reads the range's last point (the caller masks it)
+    auto gather = [&](const uint32_t (&adj)[7], const uint32_t (&pend)[6], uint32_t cb, uint32_t M) {
+        uint32_t adjv[7];
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-            adjv[b] = d[b];
+            adjv[b] = adj[b];
             asm volatile("" : "+v"(adjv[b]));
         }
-#pragma unroll
-        for (int b = 0; b < 6; ++b) pend[b] = d[8 + b];
-        const uint32_t f = cb + lane;
+        const uint32_t f = min(cb + lane, M - 1u);
         uint32_t ad;
         unsigned long long m1, m2, m3, m4, m5, m6;
         asm("v_cmp_le_u32 %[m1], %[e0], %[f]\n"
@@ -1220,12 +1217,39 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             : [f] "v"(f), [e0] "s"(pend[0]), [e1] "s"(pend[1]), [e2] "s"(pend[2]), [e3] "s"(pend[3]), [e4] "s"(pend[4]),
               [e5] "s"(pend[5]), [a0] "v"(adjv[0]), [a1] "v"(adjv[1]), [a2] "v"(adjv[2]), [a3] "v"(adjv[3]), [a4] "v"(adjv[4]),
               [a5] "v"(adjv[5]), [a6] "v"(adjv[6]));
-        // lanes past the end hold a point no leaf can reach
-        return f < M ? a.pts[f + ad] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
+        return a.pts[f + ad];
     };
-    float4 pc = load_chunk(dsc, 0);
-    float4 pn = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.0f);
-    if (M > (uint32_t)kWave) pn = load_chunk(dsc, kWave);
+    const uint32_t M = dsc[14];
+    if (M == 0u) {  // no training point in the 7 blocks: nothing reaches the tile
+        if (!(a.flags & 1u)) a.state[li] = 0;
+        else {  // insert_training_data: update() runs with (0, 0)
+            const float A = a.alpha[li], B = a.beta[li];
+            a.state[li] = (uint8_t)(classify(A, B, a) | 0x80u);
+        }
+        return;
+    }
+    float4 pc, pn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    {
+        uint32_t adj[7], pend[6];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) adj[b] = dsc[b];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) pend[b] = dsc[8 + b];
+        pc = gather(adj, pend, 0, M);
+        if (M > (uint32_t)kWave) pn = gather(adj, pend, kWave, M);
+    }
+    auto gather_cold = [&](uint32_t cb) {  // an explicit scalar read (behind the memory-clobbering asm blocks the compiler makes it vector loads)
+        typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+        u32x8 lo, hi;
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n"
+                     "s_load_dwordx8 %1, %2, 0x20\n"
+                     "s_waitcnt lgkmcnt(0)\n"
+                     : "=&s"(lo), "=&s"(hi)
+                     : "s"(dsc));
+        const uint32_t adj[7] = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6]};
+        const uint32_t pend[6] = {hi[0], hi[1], hi[2], hi[3], hi[4], hi[5]};
+        return gather(adj, pend, cb, M);
+    };
 
     const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
     const float cx = a.blk_center[3 * blk + 0], cy = a.blk_center[3 * blk + 1], cz = a.blk_center[3 * blk + 2];
@@ -1248,8 +1272,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t ax0 = tab_base + ix * kRowB, ay0 = tab_base + (4u + iy) * kRowB, az0 = tab_base + (8u + iz) * kRowB;
     const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
     const uint32_t w0 = (uint32_t)(uintptr_t)&L.acc0[0] + 8u * lane;
-    static_assert(offsetof(WaveLdsT, acc1) - offsetof(WaveLdsT, acc0) == 512 && offsetof(WaveLdsT, acc0) % 1024 == 512,
-                  "c_eval ORs 512 into the address of acc0[leaf] for a label-1 pair");
+    static_assert(offsetof(WaveLdsT, acc1) - offsetof(WaveLdsT, acc0) == 512, "c_eval adds 512 to the address of acc0[leaf] for a label-1 pair");
     const float hit_t = __uint_as_float(kHitTBits);
     const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRingT - 4 * kWave);
     uint32_t tailb = ring_base;  // LDS byte address of the ring's first free entry
@@ -1259,7 +1282,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const uint2 e = L.ring[i];
         const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__builtin_fabsf(__uint_as_float(e.x))), a.sf2);
         const double kd = (double)kv;
-        const uint32_t ad = e.y | ((uint32_t)((int32_t)e.x >> 31) & 0x200u);
+        const uint32_t ad = e.y + ((e.x >> 31) << 9);  // label 1 (negative d2): acc1[leaf], 512 bytes up
         asm volatile("ds_add_f64 %0, %1\n" : : "v"(ad), "v"(kd) : "memory");
     };
     // C round: the full 64-entry batches; the remainder (< 64 entries) moves to the front of the ring
@@ -1281,16 +1304,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     };
 
     // A + B for one chunk of 64 training points (lane = point)
-    auto chunk = [&](const float4 &p) {
+    auto chunk = [&](const float4 &p, const uint32_t cb) {
         const la3dm_v2f bx = {p.x, p.x}, by = {p.y, p.y}, bz = {p.z, p.z};
         la3dm_v2f x01 = bx - X01, x23 = bx - X23, y01 = by - Y01, y23 = by - Y23, z01 = bz - Z01, z23 = bz - Z23;
         x01 *= x01, x23 *= x23, y01 *= y01, y23 *= y23, z01 *= z01, z23 *= z23;
         const float mx = fminf(fminf(x01.x, x01.y), fminf(x23.x, x23.y));
         const float my = fminf(fminf(y01.x, y01.y), fminf(y23.x, y23.y));
         const float mz = fminf(fminf(z01.x, z01.y), fminf(z23.x, z23.y));
-        // min over the 64 leaves of d2 (+ and * are monotone): staged iff some leaf hits; the filler points of lanes past
-        // the end fail it
-        const bool keep = mx + (my + mz) < hit_t;
+        // min over the 64 leaves of d2 (+ and * are monotone): staged iff some leaf hits (lanes past the end hold a
+        // copy of the last point: masked)
+        const bool keep = mx + (my + mz) < hit_t && cb + lane < M;
         const unsigned long long m = __ballot(keep);
         if (m == 0ull) return;
         const float sg = 1.0f - (p.w + p.w);  // label 0 -> +1, label 1 -> -1 (exact)
@@ -1330,15 +1353,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     };
 
     for (uint32_t cb = 0;;) {
-        chunk(pc);
+        chunk(pc, cb);
         cb += kWave;
         if (cb >= M) break;
         pc = pn;
-        if (cb + kWave < M) {
-            const uint32_t *d = dsc;
-            asm volatile("" : "+s"(d));  // a fresh read of the descriptor (see above)
-            pn = load_chunk(d, cb + kWave);
-        }
+        if (cb + kWave < M) pn = gather_cold(cb + kWave);
     }
 
     // the tile's last, partly filled batch(es)

@@ -1617,7 +1617,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     }
 
     if ((rc = front_end(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range)) != LA3DM_OK) return rc;
-    return scan_training_set(dm, 0u, t0, stats_out);
+    return scan_training_set(dm, LA3DM_SCAN_LABELS_01, t0, stats_out);  // the front end labels hits 1.0f and free samples 0.0f
 }
 
 int la3dm_devmap_insert_pointcloud_host(la3dm_devmap *dm, const float *xyz, uint32_t n, uint32_t stride, const float origin[3],

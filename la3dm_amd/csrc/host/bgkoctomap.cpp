@@ -1570,7 +1570,9 @@ bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3
     }
     get_training_data(xyz, n, stride, origin, ds_resolution, free_res, max_range);
     stats.t_frontend = wall() - t0;
-    return partition_and_pack(false);
+    const bool work = partition_and_pack(false);
+    scan_flags |= LA3DM_SCAN_LABELS_01;  // hits are labelled 1.0f, free samples 0.0f
+    return work;
 }
 
 bool BGKOctoMap::prepare_training_data(const float *xyzy, size_t n, bool ungated) {

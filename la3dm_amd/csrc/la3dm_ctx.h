@@ -24,6 +24,8 @@ struct la3dm_ctx {
     int opt_bgk_sum = 1;   // BGK accumulate mode: 1 (default) = order-free double accumulators (bgk_predict_fuse_r: the correctly rounded
                            // sums, |dp| <= ~4e-7 from the reference's fp32 chains), 0 = the reference's fp32 summation order
                            // (bgk_predict_fuse_v5, bit-identical to the CPU restatement); env LA3DM_BGK_SUM sets the default
+    int opt_bgk_tables = 1;  // bgk_sum = 1 only: 1 (default) = bgk_predict_fuse_t (per-axis distance tables for aligned 4x4x4 tiles, the
+                             // other tiles through the general path in the same launch), 0 = bgk_predict_fuse_r for every tile
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
     int opt_time_kernel = 0;

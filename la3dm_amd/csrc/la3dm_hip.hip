@@ -219,6 +219,9 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
     if (const char *ev = getenv("LA3DM_BGK_SUM")) {  // default accumulate mode of new contexts (la3dm_set_option "bgk_sum" overrides)
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_sum = ev[0] - '0';
     }
+    if (const char *ev = getenv("LA3DM_BGK_TABLES")) {  // bgk_sum = 1: 0 = bgk_predict_fuse_r for every tile
+        if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_tables = ev[0] - '0';
+    }
     auto fail = [&](const char *what, hipError_t e) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(e);
         delete ctx;
@@ -273,6 +276,11 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_bgk_sum = value;
         return LA3DM_OK;
     }
+    if (!strcmp(name, "bgk_tables")) {  // bgk_sum = 1: 1 = distance tables for aligned tiles (bgk_predict_fuse_t), 0 = bgk_predict_fuse_r
+        if (value < 0 || value > 1) return bad_value("0 or 1");
+        ctx->opt_bgk_tables = value;
+        return LA3DM_OK;
+    }
     if (!strcmp(name, "fast_trig")) {
         if (value < 0 || value > 2) return bad_value("0, 1 or 2");
         ctx->opt_fast_trig = value;
@@ -319,6 +327,7 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
 int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value) {
     if (!ctx || !name || !value) return LA3DM_ERR_ARG;
     if (!strcmp(name, "bgk_sum")) *value = ctx->opt_bgk_sum;
+    else if (!strcmp(name, "bgk_tables")) *value = ctx->opt_bgk_tables;
     else if (!strcmp(name, "fast_trig")) *value = ctx->opt_fast_trig;
     else if (!strcmp(name, "waves_per_wg")) *value = ctx->opt_waves;
     else if (!strcmp(name, "remap")) *value = ctx->opt_remap;
@@ -429,7 +438,16 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     if (sum_f64) {
         grid = dim3(a.n_tasks);
         block = dim3(kWave);
-        LAUNCH_BGK(bgk_predict_fuse_r)
+        // the table kernel takes the tiles of the full (un-pruned) blocks, the general kernel the others
+        const bool tables = ctx->opt_bgk_tables && ctx->p.block_depth >= 3 && (s->flags & LA3DM_SCAN_LABELS_01) != 0u;
+        const bool all_full = (uint64_t)s->n_leaf == ((uint64_t)s->n_test_blk << (3 * (ctx->p.block_depth - 1)));
+        if (tables) {
+            LAUNCH_BGK(bgk_predict_fuse_t)
+            a.flags |= 0x2000u;
+        }
+        if (!tables || !all_full) {
+            LAUNCH_BGK(bgk_predict_fuse_r)
+        }
     } else {
         const int w = ctx->opt_waves;
         grid = dim3((a.n_tasks + w - 1) / w);
