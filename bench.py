@@ -161,7 +161,7 @@ def main():
         scan.alpha = alpha_t.data_ptr()
         scan.beta = beta_t.data_ptr()
         scan.state = state_t.data_ptr()
-        scan.flags = 0
+        scan.flags = pk.flags          # LA3DM_SCAN_LABELS_01 from the front end (hits 1.0f, free samples 0.0f)
         payloads.append(payload)
         scans.append(scan)
         keep.append((alpha_t, beta_t, state_t))
@@ -330,7 +330,7 @@ def main():
 
 ACC_NAMES = {0: "the reference's fp32 summation order (bit-identical to the CPU restatement)",
              1: "double accumulators per leaf, alpha / beta rounded once (library default; |dp| <= ~4e-7 from the reference order)"}
-KERNEL_NAMES = {0: "bgk_predict_fuse_v5", 1: "bgk_predict_fuse_r"}
+KERNEL_NAMES = {0: "bgk_predict_fuse_v5", 1: "bgk_predict_fuse_t"}
 
 
 def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest):
@@ -770,7 +770,7 @@ def out_of_cache_leg(la3dm_amd, _lib, torch, dev):
     (scan.train_xyzy, scan.train_off, scan.nbr, scan.blk_center, scan.leaf_off, scan.leaf_key, scan.alpha,
      scan.beta) = [t.data_ptr() for t in keep]
     scan.state = state.data_ptr()
-    scan.n_train_pts, scan.n_train_blk, scan.n_test_blk, scan.n_leaf, scan.flags = pk.n_train_pts, pk.n_train_blk, pk.n_test_blk, pk.n_leaf, 0
+    scan.n_train_pts, scan.n_train_blk, scan.n_test_blk, scan.n_leaf, scan.flags = pk.n_train_pts, pk.n_train_blk, pk.n_test_blk, pk.n_leaf, pk.flags
     H = _lib.hip()
     stream = torch.cuda.current_stream().cuda_stream
     steps = 10

@@ -53,6 +53,10 @@ enum { LA3DM_FREE = 0, LA3DM_OCCUPIED = 1, LA3DM_UNKNOWN = 2, LA3DM_PRUNED = 3 }
                                           get_training_data produces, bgkoctomap.cpp:383-458): bgk_sum = 1 may then run the
                                           table kernel on the un-pruned blocks.  Without it the general kernel runs (and
                                           detects other labels itself). */
+#define LA3DM_SCAN_FULL_BLOCKS 0x4u    /* the caller guarantees that every test block of the call holds all its
+                                          8^(block_depth-1) finest-level leaves (nothing pruned: e.g. every block was
+                                          created by this scan).  Only a hint for the kernel choice of bgk_sum = 1; a
+                                          block that breaks the promise is left untouched. */
 
 /* Map-wide constants: the statics BGKOctoMap's constructor sets
  * (src/bgkoctomap/bgkoctomap.cpp:31-56) plus the voxel look-up table
@@ -131,18 +135,22 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
 
 /* Options: "bgk_sum" — the sum mode of the BGK predict + fuse kernel:
  *   1 (default; env LA3DM_BGK_SUM sets the default of new contexts) = order-free: every leaf's sum(k), sum(k y) in double
- *     accumulators over all 7 neighbours, alpha / beta rounded once (bgk_predict_fuse_r).  Within ~4e-7 of the reference's
- *     fp32 chains on p; what bench.py is quoted on.
+ *     accumulators over all 7 neighbours, alpha / beta rounded once.  Within ~4e-7 of the reference's fp32 chains on p;
+ *     NOT the reference's summation order; what bench.py's headline is quoted on (and labelled so).  Two kernels share
+ *     the mode: bgk_predict_fuse_t ("bgk_tables" 1, the default; env LA3DM_BGK_TABLES) — per-axis distance tables for the
+ *     tiles of un-pruned blocks, the general path for the others in the same launch; needs LA3DM_SCAN_LABELS_01 — and
+ *     bgk_predict_fuse_r ("bgk_tables" 0, and every scan without that flag).  Same pairs, same kernel values, same sums.
  *   0 = the reference's fp32 summation order (bgk_predict_fuse_v5): bit-identical to the CPU restatement, the regression
  *     mode of the parity suites.
  * "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial, 2 = OCML; "waves_per_wg" 1/2/4 (bgk_sum 0),
- * "remap" 0-2, "ablate" 0-7 (profiling); values outside these sets are rejected with LA3DM_ERR_ARG;
+ * "remap" 0-2, "ablate" 0-31 and "lds_pad" (profiling: extra dynamic LDS bytes on the BGK predict launch); values outside
+ * these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
  * rows than this take the split path (default 2048, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
  * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
  * 0 = the replay expands them itself (results do not depend on it). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
-/* current value of an option that has one ("bgk_sum", "fast_trig", "waves_per_wg", "remap") */
+/* current value of an option that has one ("bgk_sum", "bgk_tables", "fast_trig", "waves_per_wg", "remap") */
 int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */

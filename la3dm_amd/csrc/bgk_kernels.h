@@ -1091,10 +1091,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ WaveLdsR L;
     const uint32_t task = bgk_task_of_workgroup(a);
     if (task >= a.n_tasks) return;
-    if (a.flags & 0x2000u) {  // launched behind bgk_predict_fuse_t: that kernel has taken the tiles of the full blocks
-        const uint32_t blk = task >> a.tpb_shift;
-        if (a.leaf_off[blk + 1] - a.leaf_off[blk] == 1u << (3u * (a.depth - 1u))) return;
-    }
     bgk_tile_r<kTrig>(a, L, task);
 }
 
@@ -1117,10 +1113,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 //     leaf's accumulator 0}: no per-candidate entry word (one VALU per candidate less in B) and no label read in C;
 //   * ring entries no longer name a candidate slot, so the ring is only drained at the end of the tile: a tile has ONE
 //     partly filled batch whatever its candidate count, and the tables can be small (32 slots: 1 536 B).
-// The kernel takes the tiles of FULL blocks only (8^(depth-1) leaves, i.e. nothing pruned: by the leaf count alone, no key
-// is read) and needs every label to be 0 or 1 (LA3DM_SCAN_LABELS_01); the host launches bgk_predict_fuse_r behind it for
-// the tiles of the other blocks when the scan has any (n_leaf < n_test_blk * 8^(depth-1)), and instead of it for scans
-// without the label guarantee.
+// The table path takes the tiles of FULL blocks (8^(depth-1) leaves, i.e. nothing pruned: decided by the leaf count alone,
+// no key is read); the tiles of the other blocks go through bgk_tile_r in the same launch.  The kernel needs every label
+// to be 0 or 1 (LA3DM_SCAN_LABELS_01); without that guarantee the host launches bgk_predict_fuse_r.  kGeneral = false is
+// the same kernel without the general path, for scans whose caller vouches that no test block is pruned
+// (LA3DM_SCAN_FULL_BLOCKS: the first scan into an empty map, a packed scan whose leaf count says so): the general
+// path's presence costs the table path ~2 % (register allocation of the shared prologue).
 // LDS per wave: 12 x 32 table (1 536 B) + 2 x 64 double accumulators (1 024 B) + 320-entry ring (2 560 B) = 5 120 B.
 // B per candidate: 1 (packed adds) + v_cmp + 2 v_mbcnt + v_lshl_add = 5 VALU (r: 9).
 // ---------------------------------------------------------------------------
@@ -1169,18 +1167,24 @@ static_assert(sizeof(WaveLdsT) == 5120 && sizeof(WaveLdsR) == 5120, "8 waves per
                  : [ax] "v"(aX), [ay] "v"(aY), [az] "v"(aZ), [T] "s"(hit_t), [w] "v"(w0)            \
                  : "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
 
-template <int kTrig>
+template <int kTrig, bool kGeneral = true>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgk_predict_fuse_t(BgkArgs a) {
-    __shared__ WaveLdsT L;
-    const uint32_t lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[5120];
     const uint32_t task = bgk_task_of_workgroup(a);
     if (task >= a.n_tasks) return;
     const uint32_t blk = task >> a.tpb_shift;
-    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
-    // only the tiles of FULL blocks (8^(depth-1) leaves: no node above the finest level is a leaf, so every 64
-    // consecutive leaves in LeafIterator order are one aligned 4x4x4 cube); bgk_predict_fuse_r takes the others
+    // the table path takes the tiles of FULL blocks (8^(depth-1) leaves: no node above the finest level is a leaf, so
+    // every 64 consecutive leaves in LeafIterator order are one aligned 4x4x4 cube); the tiles of the other blocks go
+    // through the general path — decided here, before anything else is live, so that each path keeps its own
+    // register allocation (behind a later branch the general path spilled to scratch memory)
     const uint32_t lb0 = a.leaf_off[blk];
-    if (a.leaf_off[blk + 1] - lb0 != 1u << (3u * (a.depth - 1u))) return;
+    if (a.leaf_off[blk + 1] - lb0 != 1u << (3u * (a.depth - 1u))) {
+        if (kGeneral) bgk_tile_r<kTrig>(a, *reinterpret_cast<WaveLdsR *>(s_lds), task);
+        return;  // (kGeneral false: the caller vouched for full blocks, LA3DM_SCAN_FULL_BLOCKS — a tile that is not is left untouched)
+    }
+    WaveLdsT &L = *reinterpret_cast<WaveLdsT *>(s_lds);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = task & ((1u << a.tpb_shift) - 1u);
     const uint32_t li = lb0 + tile * kWave + lane;
     // LeafIterator order is descending (bgkoctree.h:101-135): the leaf at list position j of a full block has the
     // finest-level index 8^(depth-1) - 1 - j, so the key needs no load
@@ -1191,13 +1195,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // (rare) — its 13 words would otherwise sit in registers for the whole tile.
     const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
     // the points of flat indices cb + lane; a lane past the end reads the range's last point (the caller masks it)
-    auto gather = [&](const uint32_t (&adj)[7], const uint32_t (&pend)[6], uint32_t cb, uint32_t M) {
-        uint32_t adjv[7];
-#pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            adjv[b] = adj[b];
-            asm volatile("" : "+v"(adjv[b]));
-        }
+    auto gather = [&](const uint32_t (&adjv)[7], const uint32_t (&pend)[6], uint32_t cb, uint32_t M) {
         const uint32_t f = min(cb + lane, M - 1u);
         uint32_t ad;
         unsigned long long m1, m2, m3, m4, m5, m6;
@@ -1235,8 +1233,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         for (int b = 0; b < 7; ++b) adj[b] = dsc[b];
 #pragma unroll
         for (int b = 0; b < 6; ++b) pend[b] = dsc[8 + b];
-        pc = gather(adj, pend, 0, M);
-        if (M > (uint32_t)kWave) pn = gather(adj, pend, kWave, M);
+        // the offsets in VGPRs (a v_cndmask reads one scalar operand, and its mask is one)
+        uint32_t adjv[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            adjv[b] = adj[b];
+            asm volatile("" : "+v"(adjv[b]));
+        }
+        pc = gather(adjv, pend, 0, M);
+        if (M > (uint32_t)kWave) pn = gather(adjv, pend, kWave, M);
     }
     auto gather_cold = [&](uint32_t cb) {  // an explicit scalar read (behind the memory-clobbering asm blocks the compiler makes it vector loads)
         typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
@@ -1246,9 +1251,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                      "s_waitcnt lgkmcnt(0)\n"
                      : "=&s"(lo), "=&s"(hi)
                      : "s"(dsc));
-        const uint32_t adj[7] = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6]};
+        uint32_t adjv[7] = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6]};
+#pragma unroll
+        for (int b = 0; b < 7; ++b) asm volatile("" : "+v"(adjv[b]));
         const uint32_t pend[6] = {hi[0], hi[1], hi[2], hi[3], hi[4], hi[5]};
-        return gather(adj, pend, cb, M);
+        return gather(adjv, pend, cb, M);
     };
 
     const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
@@ -1340,13 +1347,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             __builtin_amdgcn_wave_barrier();
             if (a.flags & 0x200u) continue;  // 0x200: profiling ablation
             uint32_t aX = ax0, aY = ay0, aZ = az0;
-            for (uint32_t g = 0; g < ngroup; ++g) {
+            for (uint32_t g = 0; g < ngroup; g += 2u) {  // two column groups per trip: the three row addresses move once
                 uint32_t st;
                 float tr;
                 unsigned long long hm0, hm1, hm2, hm3;
                 LA3DM_TP_TRIP("0");
-                aX += 16u, aY += 16u, aZ += 16u;
                 if (tailb > tail_cap) c_flush();
+                if (g + 1u < ngroup) {
+                    LA3DM_TP_TRIP("16");
+                    if (tailb > tail_cap) c_flush();
+                }
+                aX += 32u, aY += 32u, aZ += 32u;
             }
             // (the next sub-round overwrites the table: LDS operations of a wave complete in order)
         }

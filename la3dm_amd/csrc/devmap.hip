@@ -41,6 +41,7 @@ struct la3dm_devmap {
     // pool + table
     size_t cap_blocks = 0;
     uint32_t n_blocks = 0;
+    bool insert_into_empty = false;  // this insert started on a map without blocks: every test block of its first pass is new, i.e. un-pruned
     float *A = nullptr, *B = nullptr;
     uint8_t *S = nullptr;
     long long *blk_key = nullptr;
@@ -1067,6 +1068,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.beta = (float *)dm->leaf_beta.ptr;
     s.state = (uint8_t *)dm->leaf_state.ptr;
     s.flags = P.flags;
+    if (pass == 0 && dm->insert_into_empty) s.flags |= LA3DM_SCAN_FULL_BLOCKS;
     if (sharded) {
         // this rank's contiguous range of test blocks; leaf_off holds absolute leaf indices, so offsetting the per-block
         // arrays is all the kernel needs
@@ -1217,6 +1219,7 @@ int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, 
     la3dm_devmap_stats &S = dm->stats;
     memset(&S, 0, sizeof(S));
     S.n_blocks = dm->n_blocks;
+    dm->insert_into_empty = dm->n_blocks == 0;
     dm->n_xy = 0;
     const double t0 = wall();
     hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, st, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);
@@ -1605,6 +1608,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     la3dm_devmap_stats &S = dm->stats;
     memset(&S, 0, sizeof(S));
     S.n_blocks = dm->n_blocks;
+    dm->insert_into_empty = dm->n_blocks == 0;
     dm->n_xy = 0;
     const double t0 = wall();
     hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, st, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);

@@ -1488,6 +1488,7 @@ la3dm_bgk_scan BGKOctoMap::packed(size_t pass) {
     s.beta = ps.beta.data();
     s.state = ps.state.data();
     s.flags = scan_flags;
+    if ((uint64_t)s.n_leaf == ((uint64_t)s.n_test_blk << (3 * (block_depth - 1)))) s.flags |= LA3DM_SCAN_FULL_BLOCKS;  // no test block of this pass is pruned
     s.train_max_n = train_max_n;
     s.train_sum_n2 = train_sum_n2;
     if (variant == 3) {  // BGKLOctoMap: segment rows (8 floats) instead of points

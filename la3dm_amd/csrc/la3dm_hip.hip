@@ -438,14 +438,15 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     if (sum_f64) {
         grid = dim3(a.n_tasks);
         block = dim3(kWave);
-        // the table kernel takes the tiles of the full (un-pruned) blocks, the general kernel the others
-        const bool tables = ctx->opt_bgk_tables && ctx->p.block_depth >= 3 && (s->flags & LA3DM_SCAN_LABELS_01) != 0u;
-        const bool all_full = (uint64_t)s->n_leaf == ((uint64_t)s->n_test_blk << (3 * (ctx->p.block_depth - 1)));
-        if (tables) {
-            LAUNCH_BGK(bgk_predict_fuse_t)
-            a.flags |= 0x2000u;
-        }
-        if (!tables || !all_full) {
+        // the table kernel: tiles of full (un-pruned) blocks through the distance tables, the others through the general
+        // path of the same launch; it needs every label to be 0 or 1
+        if (ctx->opt_bgk_tables && ctx->p.block_depth >= 3 && (s->flags & LA3DM_SCAN_LABELS_01) != 0u) {
+            if (s->flags & LA3DM_SCAN_FULL_BLOCKS) {  // no pruned block in this scan: the kernel without the general path
+                LAUNCH_BGK(bgk_predict_fuse_t, , false)
+            } else {
+                LAUNCH_BGK(bgk_predict_fuse_t)
+            }
+        } else {
             LAUNCH_BGK(bgk_predict_fuse_r)
         }
     } else {

@@ -1,5 +1,7 @@
-"""The library's DEFAULT BGK accumulate mode (la3dm_set_option "bgk_sum" 1, bgk_kernels.h bgk_predict_fuse_r): every
-evaluated pair adds its fp32 kernel value k (and k * y) to double accumulators in LDS, alpha / beta are rounded once.
+"""The library's DEFAULT BGK accumulate mode (la3dm_set_option "bgk_sum" 1): every evaluated pair adds its fp32 kernel value
+k (and k * y) to double accumulators in LDS, alpha / beta are rounded once.  Two kernels share the mode (bgk_kernels.h):
+bgk_predict_fuse_t (round 4: per-axis distance tables, the tiles of un-pruned blocks of a scan whose labels are 0 / 1) and
+bgk_predict_fuse_r (every other tile; every tile with "bgk_tables" 0) — the same pairs, the same k, the same sums.
 Same pairs and the same k as the ordered kernel; only the reference's fp32 SUMMATION ORDER
 (include/bgkoctomap/bgkinference.h:76-78, src/bgkoctomap/bgkoctomap.cpp:314-335) is given up.
 
@@ -63,9 +65,10 @@ def oracles():
     O.set_sum_mode(0, omp=True)
 
 
-def _maps(la3dm_amd, O, params, omp=False):
+def _maps(la3dm_amd, O, params, omp=False, tables=1):
     m = la3dm_amd.BGKOctoMap(**params, device=0)
     m.set_option("bgk_sum", 1)
+    m.set_option("bgk_tables", tables)
     assert m.is_device_resident()
     return m, O.OracleMap(**params, omp=omp), O.OracleMap(**params, omp=omp)
 
@@ -77,32 +80,35 @@ def _insert_both(O, o64, o32, omp, *args):
     o32.insert_pointcloud(*args)
 
 
+@pytest.mark.parametrize("tables", [1, 0])
 @pytest.mark.parametrize("depth", [3, 4])
-def test_config0_sim_structured_scan1(built, oracles, depth):
+def test_config0_sim_structured_scan1(built, oracles, depth, tables):
     import la3dm_amd
     O = oracles
     params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
-    m, o64, o32 = _maps(la3dm_amd, O, params)
+    m, o64, o32 = _maps(la3dm_amd, O, params, tables=tables)
     xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
     m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
     _insert_both(O, o64, o32, False, xyz, origin, 0.1, 0.5, 8.0)
     _check(m, o64, o32, f"configs[0] depth {depth}", params)
 
 
-def test_twelve_scans_and_fifteen_reinsertions(built, oracles):
+@pytest.mark.parametrize("tables", [1, 0])
+def test_twelve_scans_and_fifteen_reinsertions(built, oracles, tables):
     """posterior accumulation, pruning and re-testing of collapsed parents in the default mode: the 12 sim_structured
     scans fused, then scan 1 re-inserted 15 times (sim_structured_long_term) — the differences do not accumulate past
-    the tolerance"""
+    the tolerance.  With the table kernel every scan after the first is a mix: un-pruned blocks through
+    bgk_predict_fuse_t, pruned ones through bgk_predict_fuse_r behind it."""
     import la3dm_amd
     O = oracles
     params = dict(la3dm_amd.BGK_YAML)
-    m, o64, o32 = _maps(la3dm_amd, O, params)
+    m, o64, o32 = _maps(la3dm_amd, O, params, tables=tables)
     for i in range(1, 13):
         xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
         m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
         _insert_both(O, o64, o32, False, xyz, origin, 0.1, 0.5, 8.0)
     _check(m, o64, o32, "12 scans", params)
-    m, o64, o32 = _maps(la3dm_amd, O, params)
+    m, o64, o32 = _maps(la3dm_amd, O, params, tables=tables)
     xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
     for _ in range(15):
         m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
@@ -176,3 +182,40 @@ def test_both_modes_agree_and_default_is_the_order_free_one(built, monkeypatch):
     assert (a["block_key"] == b["block_key"]).all() and (a["node_key"] == b["node_key"]).all()
     assert (a["A"] != b["A"]).any()          # the default really is the other kernel
     assert np.abs(_prob(a) - _prob(b)).max() <= 1e-5
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_table_kernel_and_general_kernel_agree_bit_for_bit(built, depth):
+    """bgk_predict_fuse_t against bgk_predict_fuse_r on the same packed scans through the C ABI (la3dm_bgk_scan_host): a
+    fresh map (every block un-pruned: the table kernel alone), the third scan of a sequence (pruned blocks: both kernels in
+    one call), and the same scan without LA3DM_SCAN_LABELS_01 (the general kernel alone, whatever "bgk_tables" says).
+    Both kernels form the same double sums of the same fp32 terms: alpha, beta and state are equal bit for bit up to the
+    order of the double additions (<= 1 ulp, >= 99.999 % equal; observed: all equal)."""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+    xyz, origin = la3dm_amd.synthetic_scan(30000)
+    for earlier in (0, 2):
+        m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
+        m.set_option("bgk_sum", 1)
+        for s in range(earlier):
+            assert m.prepare(xyz + np.float32(0.013 * (s + 1)), origin, 0.1, 0.5, -1.0)
+            m.scan_host(m.packed())
+            m.commit()
+        assert m.prepare(xyz, origin, 0.1, 0.5, -1.0)
+        pk = m.packed()
+        assert pk.flags & 2          # LA3DM_SCAN_LABELS_01 from the front end
+        full = int(pk.n_leaf) == int(pk.n_test_blk) * 8 ** (depth - 1)
+        assert full == (earlier == 0)
+        a0, b0 = pk.alpha.copy(), pk.beta.copy()
+        out = []
+        for tables, flags in ((0, pk.flags), (1, pk.flags), (1, pk.flags & ~2)):
+            m.set_option("bgk_tables", tables)
+            pk.alpha[:], pk.beta[:], pk.c.flags = a0, b0, flags
+            m.scan_host(pk)
+            out.append((pk.alpha.copy(), pk.beta.copy(), pk.state.copy()))
+        for other in out[1:]:
+            for x, y in zip(out[0][:2], other[:2]):
+                u = _ulps(x, y)
+                assert u.max() <= 1 and (u == 0).mean() >= 0.99999
+            assert (out[0][2] == other[2]).mean() >= 0.99999
+        assert (out[0][0] != a0).any()

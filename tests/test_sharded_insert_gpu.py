@@ -27,9 +27,14 @@ def _single(variant, rays):
     return m.leaves(), int(m.stats()["voxel_updates"]), m.training_data()
 
 
-@pytest.mark.parametrize("variant,rays,world", [("d3", 30000, 2), ("d4", 20000, 3), ("gp", 8000, 2)])
-def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant, rays, world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_DEBUG_SHARD="1")
+@pytest.mark.parametrize("variant,rays,world,sum_mode", [("d3", 30000, 2, "0"), ("d4", 20000, 3, "0"), ("gp", 8000, 2, "0"),
+                                                          ("d3", 30000, 2, "1"), ("d4", 20000, 3, "1")])
+def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant, rays, world, sum_mode, monkeypatch):
+    """sum_mode "1" is the library's default accumulate mode (double sums; table kernel on the un-pruned blocks, general
+    kernel on the pruned ones of the second scan): a leaf's sums are formed on exactly one rank by the same kernel as in
+    the single process, so the replicas are bit-identical there too"""
+    monkeypatch.setenv("LA3DM_BGK_SUM", sum_mode)          # the single-process reference below; the workers inherit env
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_DEBUG_SHARD="1", LA3DM_BGK_SUM=sum_mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + (os.getpid() % 500)), os.path.join(ROOT, "tests", "helpers", "shard_worker.py"),
            str(tmp_path), variant, str(rays)]
