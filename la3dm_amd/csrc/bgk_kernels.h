@@ -106,12 +106,10 @@ __device__ __forceinline__ void sincos_0_2pi(float t, float &s, float &c) {
 }
 
 // ---------------------------------------------------------------------------
-// Correctly rounded sinf/cosf for t in [0, 2*pi]: reduce by pi/2 and evaluate the
-// classic double-precision minimax kernels (error < 2^-57 on [-pi/4, pi/4]) in f64,
-// then round once to f32.  The f32 result differs from the exactly rounded one only
-// when the true value lies within ~1e-15 relative of a rounding tie (~1e-7 of inputs).
-// This is what the oracle's cr_sinf/cr_cosf compute (double libm rounded to float).
-// f64 FMA runs at half the f32 rate on gfx950 (78.6 TF); ~20 f64 ops per pair.
+// Correctly rounded sinf/cosf for t in [0, 2*pi]: table + short f64 polynomials (sincos_cr_core below), rounded once
+// to f32.  The f32 result differs from the exactly rounded one only when the true value lies within ~1e-15 relative
+// of a rounding tie; swept exhaustively against what the oracle's cr_sinf/cr_cosf compute (double libm rounded to
+// float).  An f64 FMA costs the same 4 cycles per wave as an f32 one on gfx950.
 // ---------------------------------------------------------------------------
 // v_fma_f64 with the addend (a constant) in an SGPR pair: the compiler's own choice for a Horner chain on constants is
 // v_fmac_f64 + a v_mov_b64 of the constant into the accumulator per step (10 extra 4-cycle instructions per sin/cos
@@ -126,40 +124,70 @@ __device__ __forceinline__ double fma64_sb(double a, double b_const, double c) {
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_const), "v"(c));
     return r;
 }
-__device__ __forceinline__ void sincos_cr(float t, float &s, float &c) {
-    // quadrant by the magic-number trick: the low mantissa bits of u hold q = rint(t * 2 / pi) (0 <= q <= 4)
-    const float u = __builtin_fmaf(t, 0.636619772f, 12582912.0f);
+// {sin(q h), cos(q h)} for q = 0 .. 64, h = RN_f32(pi / 32), correctly rounded doubles (tools/gen/sincos_table.py)
+static __device__ const unsigned long long kSinCosTab[128][2] = {
+#include "sincos_table.inc"
+};
+typedef double la3dm_v2d __attribute__((ext_vector_type(2)));
+
+// Round 4 form: t = q h + y with q = rint(t / h) in 0 .. 64 and |y| <= h / 2 (+ the drift of q h against q pi / 32,
+// < 2e-6); the fp32 FMA t - q h is EXACT (t and q h are multiples of 2^-28 once q >= 1, |y| < 2^-4), so the table angle
+// q h needs no low word; sin(t) = sa + (ca sin y + sa (cos y - 1)), cos(t) = ca + (ca (cos y - 1) - sa sin y) with
+// the table's {sa, ca} and two short f64 polynomials (|error| < 2e-19 / 1e-21 on the interval).  Against the round-3
+// form (reduction by pi / 2, two 5-term chains, swap / sign logic on the quadrant's bits): 20 instead of 33 VALU per
+// pair of results, all of the quadrant logic gone.  tools/check/sincos_sweep.c: 0 mismatches against
+// (float)sin((double)t), (float)cos((double)t) over every fp32 t in [0, 2 pi] on the CPU (IEEE fma), la3dm_diag_sweep(3)
+// the same on the device.  fetch(bits of u, sa, ca) delivers the table entry of q = bits & 127.
+template <class Fetch>
+__device__ __forceinline__ void sincos_cr_core(float t, float &s, float &c, Fetch fetch) {
+    const float u = __builtin_fmaf(t, 10.1859164f /* 32 / pi */, 12582912.0f);  // low mantissa bits: q
     const float kf = u - 12582912.0f;
-    const double k = (double)kf;
-    const double PIO2_HI = 1.57079632673412561417e+00;  // first 33 bits of pi/2
-    const double PIO2_LO = 6.07710050650619224932e-11;  // pi/2 - PIO2_HI
-    double y = fma64_sb(k, -PIO2_HI, (double)t);        // exact
-    y = fma64_sb(k, -PIO2_LO, y);
+    const float y32 = __builtin_fmaf(-kf, 0x1.921fb6p-4f, t);  // exact
+    double sa, ca;
+    fetch(__float_as_uint(u), sa, ca);
+    const double y = (double)y32;
     const double z = y * y;
-    // the two Horner chains alternate: a dependent f64 pair back to back costs a wait state
-    double ps = fma64_sc(z, __builtin_bit_cast(double, 0x3de5d93a5acfd57cull) /* 1.58969099521155010221e-10 */, -2.50507602534068634195e-08);
-    double pc = fma64_sc(z, __builtin_bit_cast(double, 0xbda8fae9be8838d4ull) /* -1.13596475577881948265e-11 */, 2.08757232129817482790e-09);
+    double ps = fma64_sc(z, __builtin_bit_cast(double, 0xbf2a014a5f1de813ull), __builtin_bit_cast(double, 0x3f81111110c194d4ull));
+    double pc = fma64_sc(z, __builtin_bit_cast(double, 0x3efa015b846c26deull), __builtin_bit_cast(double, 0xbf56c16c1681d56aull));
     const double zy = z * y;
-    const double zz = z * z;
-    ps = fma64_sc(z, ps, 2.75573137070700676789e-06);
-    pc = fma64_sc(z, pc, -2.75573143513906633035e-07);
-    ps = fma64_sc(z, ps, -1.98412698298579493134e-04);
-    pc = fma64_sc(z, pc, 2.48015872894767294178e-05);
-    ps = fma64_sc(z, ps, 8.33333333332248946124e-03);
-    pc = fma64_sc(z, pc, -1.38888888888741095749e-03);
-    const double hz = __builtin_fma(z, -0.5, 1.0);
-    ps = fma64_sc(z, ps, -1.66666666666666324348e-01);
-    pc = fma64_sc(z, pc, 4.16666666666666019037e-02);
-    const double sy = __builtin_fma(zy, ps, y);
-    const double cy = __builtin_fma(zz, pc, hz);
-    const float sf = (float)sy, cf = (float)cy;
-    // sin(y + q pi/2), cos(y + q pi/2): swap on bit 0 of q, sin negative for q in {2, 3}, cos negative for q in {1, 2}
-    const uint32_t q = __float_as_uint(u);
-    const uint32_t q31 = q << 31, q30 = q << 30;       // bit 0 / bit 1 of q at the sign position
-    const bool odd = (int32_t)q31 < 0;
-    const uint32_t ss = __float_as_uint(odd ? cf : sf), cc = __float_as_uint(odd ? sf : cf);
-    s = __uint_as_float(ss ^ (q30 & 0x80000000u));
-    c = __uint_as_float(cc ^ ((q30 ^ q31) & 0x80000000u));
+    ps = fma64_sc(z, ps, __builtin_bit_cast(double, 0xbfc555555555552aull));
+    pc = fma64_sc(z, pc, __builtin_bit_cast(double, 0x3fa5555555555544ull));
+    const double sy = __builtin_fma(zy, ps, y);      // sin y
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cm1 = z * pc;                       // cos y - 1
+    const double sd = __builtin_fma(ca, sy, __builtin_fma(sa, cm1, sa));
+    const double cd = __builtin_fma(-sa, sy, __builtin_fma(ca, cm1, ca));
+    s = (float)sd;
+    c = (float)cd;
+}
+// the table read from memory (a 16-byte gather that stays in the vector L1): any t in [0, 2 pi], NaN in -> NaN out
+__device__ __forceinline__ void sincos_cr(float t, float &s, float &c) {
+    sincos_cr_core(t, s, c, [](uint32_t ub, double &sa, double &ca) {
+        const la3dm_v2d e = *reinterpret_cast<const la3dm_v2d *>(reinterpret_cast<const char *>(kSinCosTab) + ((ub & 127u) << 4));
+        sa = e.x;
+        ca = e.y;
+    });
+}
+// the table in the wave's own registers (lane q holds entry q, tab = the lane's four words) and read across lanes
+// by ds_bpermute_b32 (the LDS crossbar; no LDS memory, no vector-memory latency): t in [0, 63.5 h) only — the BGK
+// kernels' t = 2 r pi with r^2 below the hit threshold stays under 6.19 — and EVERY lane of the wave must be active
+// (a disabled source lane reads as 0).
+struct SinCosLanes {
+    int w0, w1, w2, w3;
+};
+__device__ __forceinline__ SinCosLanes sincos_lanes_load(uint32_t lane) {
+    const uint32_t *e = reinterpret_cast<const uint32_t *>(&kSinCosTab[lane & 63u][0]);
+    SinCosLanes r = {(int)e[0], (int)e[1], (int)e[2], (int)e[3]};
+    return r;
+}
+__device__ __forceinline__ void sincos_cr_lanes(float t, float &s, float &c, const SinCosLanes &tab) {
+    sincos_cr_core(t, s, c, [&](uint32_t ub, double &sa, double &ca) {
+        const int ad = (int)(ub << 2);  // byte address = source lane * 4; the crossbar takes bits 7:2
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ad, tab.w0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ad, tab.w1);
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(ad, tab.w2), a3 = (uint32_t)__builtin_amdgcn_ds_bpermute(ad, tab.w3);
+        sa = __builtin_bit_cast(double, ((unsigned long long)a1 << 32) | a0);
+        ca = __builtin_bit_cast(double, ((unsigned long long)a3 << 32) | a2);
+    });
 }
 
 // correctly rounded x / d for a compile-time constant d (|x| far from the subnormal range):
@@ -311,12 +339,14 @@ __device__ __forceinline__ float sqrt_cr(float x) {
 
 // covSparse elementwise (bgkinference.h:115-125) with the two constant divisions done by
 // div_const; bit-identical to cov_sparse<true, kTrig> (tests sweep the divisions exhaustively).
-template <int kTrig, bool kClamp = true>
-__device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
+template <int kTrig, bool kClamp = true, bool kLanes = false>
+__device__ __forceinline__ float cov_sparse_fast(float r, float sf2, const SinCosLanes *tab = nullptr) {
     const float t = (r * 2.0f) * 3.1415926f;
     float s, c;
-    if (kTrig == 0) sincos_cr(t, s, c);
-    else if (kTrig == 1) sincos_0_2pi(t, s, c);
+    if (kTrig == 0) {
+        if (kLanes) sincos_cr_lanes(t, s, c, *tab);
+        else sincos_cr(t, s, c);
+    } else if (kTrig == 1) sincos_0_2pi(t, s, c);
     else { s = sinf(t); c = cosf(t); }
     const float a = div_const((2.0f + c) * (1.0f - r), 3.0f, 0.333333343f);
     const float b = div_const(s, 2.0f * 3.1415926f, 0.159154952f);
@@ -1285,12 +1315,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     uint32_t tailb = ring_base;  // LDS byte address of the ring's first free entry
 
     // C: lane evaluates ring entry i and adds k to the leaf's accumulator 0 or 1 (the sign of d2 is the label)
-    auto c_eval = [&](uint32_t i) {
-        const uint2 e = L.ring[i];
-        const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__builtin_fabsf(__uint_as_float(e.x))), a.sf2);
+    // (every lane evaluates — the sin / cos table is read across the wave's lanes, a disabled lane would read as 0 — and
+    // the lanes with an entry accumulate)
+    const SinCosLanes sct = sincos_lanes_load(lane);
+    auto c_eval = [&](uint32_t i, bool valid) {
+        uint2 e = make_uint2(0u, 0u);
+        if (valid) e = L.ring[i];
+        const float kv = cov_sparse_fast<kTrig, true, true>(sqrt_cr(__builtin_fabsf(__uint_as_float(e.x))), a.sf2, &sct);
         const double kd = (double)kv;
         const uint32_t ad = e.y + ((e.x >> 31) << 9);  // label 1 (negative d2): acc1[leaf], 512 bytes up
-        asm volatile("ds_add_f64 %0, %1\n" : : "v"(ad), "v"(kd) : "memory");
+        if (valid) asm volatile("ds_add_f64 %0, %1\n" : : "v"(ad), "v"(kd) : "memory");
     };
     // C round: the full 64-entry batches; the remainder (< 64 entries) moves to the front of the ring
     auto c_flush = [&]() {
@@ -1299,7 +1333,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const uint32_t tail = (tailb - ring_base) >> 3;
         const uint32_t nfull = tail & ~63u, rem = tail & 63u;
         if (!(a.flags & 0x100u))  // 0x100: profiling ablation
-            for (uint32_t p = 0; p < nfull; p += kWave) c_eval(p + lane);
+            for (uint32_t p = 0; p < nfull; p += kWave) c_eval(p + lane, true);
         uint2 e = make_uint2(0u, 0u);
         if (lane < rem) e = L.ring[nfull + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1377,8 +1411,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     {
         const uint32_t tail = (tailb - ring_base) >> 3;
         if (!(a.flags & 0x100u))
-            for (uint32_t p = 0; p < tail; p += kWave)
-                if (p + lane < tail) c_eval(p + lane);
+            for (uint32_t p = 0; p < tail; p += kWave) c_eval(p + lane, p + lane < tail);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
