@@ -52,7 +52,28 @@ __global__ __launch_bounds__(256) void k_lds(float *out, int mode, unsigned long
     uint32_t addr = base + lane_addr(mode, lane);
     float v0 = lane * 0.5f, v1 = 1.0f;
     float r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    if (kOp == 4) {  // exec-masked write2: only the lanes in execmask write
+    if (kOp == 16 || kOp == 17) {  // exec-masked ds_write_b64 / ds_write_b32
+        for (int it = 0; it < kIters; ++it) {
+            if (kOp == 16)
+                asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, %2\n" R16("ds_write_b64 %0, %1\n")
+                             "s_mov_b64 exec, s[20:21]\n s_waitcnt lgkmcnt(0)\n"
+                             :
+                             : "v"(addr), "v"(make_float2(v0, v1)), "s"(execmask)
+                             : "memory", "s20", "s21");
+            else
+                asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, %2\n" R16("ds_write_b32 %0, %1\n")
+                             "s_mov_b64 exec, s[20:21]\n s_waitcnt lgkmcnt(0)\n"
+                             :
+                             : "v"(addr), "v"(v0), "s"(execmask)
+                             : "memory", "s20", "s21");
+        }
+    } else if (kOp == 18) {  // ds_bpermute_b32 (lane * 4 in the address register)
+        uint32_t t, ad = ((lane * 7u) & 63u) << 2;
+        for (int it = 0; it < kIters; ++it) {
+            asm volatile(R16("ds_bpermute_b32 %0, %1, %2\n") "s_waitcnt lgkmcnt(0)\n" : "=&v"(t) : "v"(ad), "v"(lane) : "memory");
+            r0 += (float)t;
+        }
+    } else if (kOp == 4) {  // exec-masked write2: only the lanes in execmask write
         for (int it = 0; it < kIters; ++it)
             asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, %3\n" R16("ds_write2_b32 %0, %1, %2 offset1:1\n")
                          "s_mov_b64 exec, s[20:21]\n s_waitcnt lgkmcnt(0)\n"
@@ -123,6 +144,10 @@ int main() {
         {"ds_write_b32 64 lanes contiguous", k_lds<3>, 1, 0},
         {"ds_write_b32 10 hit + 54 on ONE address", k_lds<3>, 2, 0},
         {"ds_write_b64 64 lanes contiguous", k_lds<7>, 0, 0},
+        {"ds_write_b64 exec = 10 lanes", k_lds<16>, 0, nine},
+        {"ds_write_b64 exec = all lanes", k_lds<16>, 0, ~0ull},
+        {"ds_write_b32 exec = 10 lanes", k_lds<17>, 1, nine},
+        {"ds_bpermute_b32", k_lds<18>, 0, 0},
         {"ds_add_f32 64 distinct", k_lds<1>, 1, 0},
         {"ds_add_f32 9 addresses x 7 lanes", k_lds<1>, 3, 0},
         {"ds_add_f32 one address x 64 lanes", k_lds<1>, 4, 0},
