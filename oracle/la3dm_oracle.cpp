@@ -301,6 +301,10 @@ extern "C" void orc_set_modes(int trig, int grid_sort) {
 //      (up to 2^-53 relative), so this is the value the reference's fp32 chains approximate.
 int g_orc_sum_mode = 0;
 extern "C" void orc_set_sum_mode(int mode) { g_orc_sum_mode = mode; }
+// GP sensitivity switch (orc_set_gp_mode): 0 = the restatement every parity test uses (FMA chains in ascending k);
+// 1 = an emulation of what an x86-64 / SSE2 (ROS Noetic) build of Eigen 3.3.7 most plausibly does — see gp_train_eigen.
+int g_orc_gp_mode = 0;
+extern "C" void orc_set_gp_mode(int mode) { g_orc_gp_mode = mode; }
 
 namespace orc_eigen337 {
 static inline float from_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
@@ -354,6 +358,31 @@ float pcos(float x0) {
     x = x + y * -2.4187564849853515625e-4f;
     x = x + y * -3.77489497744594108e-8f;
     return from_bits(to_bits(poly(x, use_sin)) ^ sign);
+}
+// pexp<Packet4f> of Eigen 3.3.7 (arch/SSE/MathFunctions.h, the Cephes expf), one lane, SSE2 path (no _mm_floor_ps,
+// pmadd = rounded multiply then rounded add)
+float pexp(float x0) {
+    float x = std::min(x0, 88.3762626647950f);
+    x = std::max(x, -88.3762626647949f);
+    float fx = x * 1.44269504088896341f + 0.5f;
+    float tmp = (float)(int32_t)fx;          // _mm_cvttps_epi32 + _mm_cvtepi32_ps
+    if (tmp > fx) tmp = tmp - 1.0f;          // floor
+    fx = tmp;
+    tmp = fx * 0.693359375f;
+    float z = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - z;
+    z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x + 1.3981999507E-3f;
+    y = y * x + 8.3334519073E-3f;
+    y = y * x + 4.1665795894E-2f;
+    y = y * x + 1.6666665459E-1f;
+    y = y * x + 5.0000001201E-1f;
+    y = y * z + x;
+    y = y + 1.0f;
+    const int32_t e = ((int32_t)fx + 0x7f) << 23;
+    return std::max(y * from_bits((uint32_t)e), x0);
 }
 }  // namespace orc_eigen337
 
@@ -439,9 +468,20 @@ struct GPModel {
     std::vector<float> xn;     // scaled training points
     std::vector<float> alpha;  // K^-1 y
     std::vector<float> L;      // lower Cholesky factor, row-major N x N
+    std::vector<double> xn64, alpha64, L64;  // the same in double (GP mode 2 only)
 };
 
+void gp_train_eigen(const Params &p, const float *x, const float *y, int N, GPModel &g);
+void gp_train_f64(const Params &p, const float *x, const float *y, int N, GPModel &g);
 void gp_train(const Params &p, const float *x, const float *y, int N, GPModel &g) {
+    if (g_orc_gp_mode == 1) {
+        gp_train_eigen(p, x, y, N, g);
+        return;
+    }
+    if (g_orc_gp_mode == 2) {
+        gp_train_f64(p, x, y, N, g);
+        return;
+    }
     g.N = N;
     g.xn.resize((size_t)N * 3);
     const float s = (float)(1.73205 / p.ell);  // double quotient narrowed before the product (:115)
@@ -479,7 +519,246 @@ void gp_train(const Params &p, const float *x, const float *y, int N, GPModel &g
     }
 }
 
+// ---------------------------------------------------------------------------
+// GP mode 1: the order of operations of Eigen 3.3.7 on x86-64 without FMA (SSE2 packets of 4 floats), as far as it is
+// determined by the library's algorithms rather than by run-time pointer alignment.  A SENSITIVITY PROBE (how far do
+// alpha, m and var move when the arithmetic is Eigen's and not an FMA chain), not a pin — Eigen is absent here.
+//   * no FMA anywhere: a product is rounded, then added (pmadd without EIGEN_HAS_SINGLE_INSTRUCTION_MADD);
+//   * inner products (squaredNorm, GEMV rows, Ks^T alpha) in packet order: two 4-lane accumulators over the aligned
+//     part (Redux.h LinearVectorizedTraversal), p0 + p1, predux = (s0 + s2) + (s1 + s3), the tail added one by one;
+//   * LLT (Cholesky/LLT.h llt_inplace<Lower>): unblocked below 32 rows; otherwise panels of
+//     bs = clamp((n / 8 / 16) * 16, 8, 128) columns — unblocked factor of A11, A21 <- A21 A11^-T, A22 -= A21 A21^T
+//     with the rank update accumulated from ZERO over the panel's columns and subtracted once (GEBP: C += alpha * acc);
+//   * triangular solves (TriangularSolverMatrix.h, row-major L): panels of 8 rows; inside a panel
+//     x_i = (b_i - sum_{k in panel, k < i} l_ik x_k) * (1 / l_ii) with the sum from zero and the RECIPROCAL of the
+//     diagonal; the rows below a panel get b -= L21 x as one from-zero accumulation per panel;
+//   * exp() as the SSE packet pexp (orc_eigen337::pexp) for every element.
+// ---------------------------------------------------------------------------
+inline float dot_sse(const float *a, const float *b, int n) {
+    const int n4 = n & ~3, n8 = n & ~7;
+    float res = 0.0f;
+    if (n4) {
+        float p0[4], p1[4];
+        for (int l = 0; l < 4; ++l) p0[l] = a[l] * b[l];
+        if (n4 > 4) {
+            for (int l = 0; l < 4; ++l) p1[l] = a[4 + l] * b[4 + l];
+            for (int i = 8; i < n8; i += 8)
+                for (int l = 0; l < 4; ++l) {
+                    p0[l] = p0[l] + a[i + l] * b[i + l];
+                    p1[l] = p1[l] + a[i + 4 + l] * b[i + 4 + l];
+                }
+            for (int l = 0; l < 4; ++l) p0[l] = p0[l] + p1[l];
+            if (n4 > n8)
+                for (int l = 0; l < 4; ++l) p0[l] = p0[l] + a[n8 + l] * b[n8 + l];
+        }
+        res = (p0[0] + p0[2]) + (p0[1] + p0[3]);
+    }
+    for (int i = n4; i < n; ++i) res = res + a[i] * b[i];
+    return res;
+}
+// llt_inplace<float, Lower>::unblocked on the n x n block at (o, o) of the row-major N x N matrix A (lower triangle)
+void llt_unblocked_eigen(float *A, int N, int o, int n) {
+    std::vector<float> col;
+    for (int k = 0; k < n; ++k) {
+        float *rk = A + (size_t)(o + k) * N + o;
+        float x = rk[k];
+        if (k > 0) x = x - dot_sse(rk, rk, k);                       // A10.squaredNorm()
+        x = sqrtf(x);
+        rk[k] = x;
+        for (int i = k + 1; i < n; ++i) {                              // A21 -= A20 * A10^T ; A21 /= x
+            float *ri = A + (size_t)(o + i) * N + o;
+            float v = ri[k];
+            if (k > 0) v = v - dot_sse(ri, rk, k);
+            ri[k] = v / x;
+        }
+    }
+}
+// rows [r0, r1) of A21 (columns [o, o + bs)) <- A21 * A11^-T, A11 the factored bs x bs block at (o, o): per row a
+// forward substitution in panels of 8 columns (sum from zero inside the panel, reciprocal of the diagonal; the
+// columns right of a panel get their update as one from-zero accumulation)
+void trsm_right_eigen(float *A, int N, int o, int bs, int r0, int r1) {
+    for (int i = r0; i < r1; ++i) {
+        float *ri = A + (size_t)i * N + o;
+        for (int p0 = 0; p0 < bs; p0 += 8) {
+            const int pw = std::min(8, bs - p0);
+            for (int k = 0; k < pw; ++k) {
+                const float *lk = A + (size_t)(o + p0 + k) * N + o;
+                float b = 0.0f;
+                for (int q = 0; q < k; ++q) b = b + lk[p0 + q] * ri[p0 + q];
+                ri[p0 + k] = (ri[p0 + k] - b) * (1.0f / lk[p0 + k]);
+            }
+            for (int c = p0 + pw; c < bs; ++c) {
+                const float *lc = A + (size_t)(o + c) * N + o;
+                float acc = 0.0f;
+                for (int q = 0; q < pw; ++q) acc = acc + ri[p0 + q] * lc[p0 + q];
+                ri[c] = ri[c] - acc;
+            }
+        }
+    }
+}
+void llt_eigen(float *A, int N) {
+    if (N < 32) {
+        llt_unblocked_eigen(A, N, 0, N);
+        return;
+    }
+    int bs = N / 8;
+    bs = (bs / 16) * 16;
+    bs = std::min(std::max(bs, 8), 128);
+    for (int k = 0; k < N; k += bs) {
+        const int b = std::min(bs, N - k), rs = N - k - b;
+        llt_unblocked_eigen(A, N, k, b);
+        if (rs > 0) {
+            trsm_right_eigen(A, N, k, b, k + b, N);
+            for (int i = k + b; i < N; ++i)                             // A22 -= A21 * A21^T (lower part)
+                for (int j = k + b; j <= i; ++j) {
+                    const float *ai = A + (size_t)i * N + k, *aj = A + (size_t)j * N + k;
+                    float acc = 0.0f;
+                    for (int q = 0; q < b; ++q) acc = acc + ai[q] * aj[q];
+                    A[(size_t)i * N + j] = A[(size_t)i * N + j] - acc;
+                }
+        }
+    }
+}
+// x <- L^-1 x (forward) for one right-hand side, panels of 8 rows (see the header of this block)
+void trsv_lower_eigen(const float *L, int N, float *x) {
+    for (int p0 = 0; p0 < N; p0 += 8) {
+        const int pw = std::min(8, N - p0);
+        for (int k = 0; k < pw; ++k) {
+            const float *lk = L + (size_t)(p0 + k) * N;
+            float b = 0.0f;
+            for (int q = 0; q < k; ++q) b = b + lk[p0 + q] * x[p0 + q];
+            x[p0 + k] = (x[p0 + k] - b) * (1.0f / lk[p0 + k]);
+        }
+        for (int i = p0 + pw; i < N; ++i) {
+            const float *li = L + (size_t)i * N;
+            float acc = 0.0f;
+            for (int q = 0; q < pw; ++q) acc = acc + li[p0 + q] * x[p0 + q];
+            x[i] = x[i] - acc;
+        }
+    }
+}
+// x <- L^-T x (backward), the mirror image: panels of 8 from the bottom
+void trsv_upper_eigen(const float *L, int N, float *x) {
+    for (int p1 = N; p1 > 0; p1 -= 8) {
+        const int pw = std::min(8, p1), p0 = p1 - pw;
+        for (int k = pw - 1; k >= 0; --k) {
+            float b = 0.0f;
+            for (int q = pw - 1; q > k; --q) b = b + L[(size_t)(p0 + q) * N + p0 + k] * x[p0 + q];
+            x[p0 + k] = (x[p0 + k] - b) * (1.0f / L[(size_t)(p0 + k) * N + p0 + k]);
+        }
+        for (int i = 0; i < p0; ++i) {
+            float acc = 0.0f;
+            for (int q = 0; q < pw; ++q) acc = acc + L[(size_t)(p0 + q) * N + i] * x[p0 + q];
+            x[i] = x[i] - acc;
+        }
+    }
+}
+inline float matern3_eigen(const float *a, const float *b, float sf2) {
+    float dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+    float d = sqrtf(dx * dx + (dy * dy + dz * dz));
+    return ((1 + d) * orc_eigen337::pexp(-d)) * sf2;
+}
+void gp_train_eigen(const Params &p, const float *x, const float *y, int N, GPModel &g) {
+    g.N = N;
+    g.xn.resize((size_t)N * 3);
+    const float s = (float)(1.73205 / p.ell);
+    for (int i = 0; i < N * 3; ++i) g.xn[i] = s * x[i];
+    g.L.assign((size_t)N * N, 0.0f);
+    float *L = g.L.data();
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j) L[(size_t)i * N + j] = matern3_eigen(&g.xn[3 * i], &g.xn[3 * j], p.sf2);
+    for (int i = 0; i < N; ++i) L[(size_t)i * N + i] = L[(size_t)i * N + i] + p.noise;
+    llt_eigen(L, N);
+    g.alpha.assign(y, y + N);
+    trsv_lower_eigen(L, N, g.alpha.data());
+    trsv_upper_eigen(L, N, g.alpha.data());
+}
+void gp_predict_eigen(const Params &p, const GPModel &g, const float *xs, int M, float *m, float *var) {
+    const int N = g.N;
+    const float s = (float)(1.73205 / p.ell);
+    std::vector<float> v(N);
+    for (int j = 0; j < M; ++j) {
+        const float t[3] = {s * xs[3 * j], s * xs[3 * j + 1], s * xs[3 * j + 2]};
+        for (int k = 0; k < N; ++k) v[k] = matern3_eigen(&g.xn[3 * k], t, p.sf2);
+        m[j] = dot_sse(v.data(), g.alpha.data(), N);                    // (Ks^T alpha)(j)
+        trsv_lower_eigen(g.L.data(), N, v.data());
+        var[j] = p.sf2 - dot_sse(v.data(), v.data(), N);               // Kss - (v^T v).diagonal()
+    }
+}
+
+// GP mode 2: the same regressor evaluated in double precision throughout (inputs and outputs stay fp32) — the yardstick
+// that tells how much of a difference between two fp32 evaluations is rounding noise of the ill-conditioned solve
+// (noise 0.01 on a Matern kernel of nearby points) rather than a defect of either.
+inline double matern3_64(const double *a, const double *b, double sf2) {
+    const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+    const double d = sqrt(dx * dx + (dy * dy + dz * dz));
+    return ((1 + d) * exp(-d)) * sf2;
+}
+void gp_train_f64(const Params &p, const float *x, const float *y, int N, GPModel &g) {
+    g.N = N;
+    const double s = (double)(float)(1.73205 / p.ell);
+    struct { std::vector<double> &xn, &alpha, &L; } h{g.xn64, g.alpha64, g.L64};
+    h.xn.resize((size_t)N * 3);
+    for (int i = 0; i < N * 3; ++i) h.xn[i] = s * (double)x[i];
+    h.L.assign((size_t)N * N, 0.0);
+    double *L = h.L.data();
+    for (int j = 0; j < N; ++j) {
+        double acc = matern3_64(&h.xn[3 * j], &h.xn[3 * j], p.sf2) + (double)p.noise;
+        for (int k = 0; k < j; ++k) acc -= L[(size_t)j * N + k] * L[(size_t)j * N + k];
+        const double d = sqrt(acc);
+        L[(size_t)j * N + j] = d;
+        for (int i = j + 1; i < N; ++i) {
+            double a2 = matern3_64(&h.xn[3 * i], &h.xn[3 * j], p.sf2);
+            for (int k = 0; k < j; ++k) a2 -= L[(size_t)i * N + k] * L[(size_t)j * N + k];
+            L[(size_t)i * N + j] = a2 / d;
+        }
+    }
+    std::vector<double> z(N);
+    for (int j = 0; j < N; ++j) {
+        double acc = y[j];
+        for (int k = 0; k < j; ++k) acc -= L[(size_t)j * N + k] * z[k];
+        z[j] = acc / L[(size_t)j * N + j];
+    }
+    h.alpha.resize(N);
+    for (int j = N - 1; j >= 0; --j) {
+        double acc = z[j];
+        for (int k = N - 1; k > j; --k) acc -= L[(size_t)k * N + j] * h.alpha[k];
+        h.alpha[j] = acc / L[(size_t)j * N + j];
+    }
+    g.xn.assign(h.xn.begin(), h.xn.end());
+    g.alpha.assign(h.alpha.begin(), h.alpha.end());
+    g.L.assign(h.L.begin(), h.L.end());
+}
+void gp_predict_f64(const Params &p, const GPModel &g, const float *xs, int M, float *m, float *var) {
+    struct { const std::vector<double> &xn, &alpha, &L; } h{g.xn64, g.alpha64, g.L64};
+    const int N = g.N;
+    const double s = (double)(float)(1.73205 / p.ell);
+    std::vector<double> v(N);
+    for (int j = 0; j < M; ++j) {
+        const double t[3] = {s * xs[3 * j], s * xs[3 * j + 1], s * xs[3 * j + 2]};
+        double mj = 0.0, ss = 0.0;
+        for (int k = 0; k < N; ++k) {
+            const double ks = matern3_64(&h.xn[3 * k], t, p.sf2);
+            mj += ks * h.alpha[k];
+            double acc = ks;
+            for (int i = 0; i < k; ++i) acc -= h.L[(size_t)k * N + i] * v[i];
+            v[k] = acc / h.L[(size_t)k * N + k];
+            ss += v[k] * v[k];
+        }
+        m[j] = (float)mj;
+        var[j] = (float)((double)p.sf2 - ss);
+    }
+}
+
 void gp_predict(const Params &p, const GPModel &g, const float *xs, int M, float *m, float *var) {
+    if (g_orc_gp_mode == 1) {
+        gp_predict_eigen(p, g, xs, M, m, var);
+        return;
+    }
+    if (g_orc_gp_mode == 2) {
+        gp_predict_f64(p, g, xs, M, m, var);
+        return;
+    }
     const int N = g.N;
     const float s = (float)(1.73205 / p.ell);
     std::vector<float> v(N);

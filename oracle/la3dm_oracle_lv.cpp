@@ -246,63 +246,89 @@ void get_training_data(const Params &P, const std::vector<V3> &cloud, V3 origin,
     int idx = 0;
     double offset = P.ell * pow(2, 0.5);
     double influence = P.ell;
-    std::vector<V3> nearby, frees;
-    for (const V3 &p : hits) {
-        double l = norm3(p - origin);
-        float nx = (float)((p.x - origin.x) / l), ny = (float)((p.y - origin.y) / l), nz = (float)((p.z - origin.z) / l);
-        if (max_range > 0) {
-            if (l < max_range) {
-                l = (float)sqrt((p.x - origin.x) * (p.x - origin.x) + (p.y - origin.y) * (p.y - origin.y) + (p.z - origin.z) * (p.z - origin.z));
-                l = l - offset;
-                T.xy.push_back(p);
-                T.ray_idx.push_back(-1);
-            } else
-                l = max_range - offset;
-        }
-        V3 nearest_point = p;
-        V3 free_endpt{(float)(origin.x + nx * l), (float)(origin.y + ny * l), (float)(origin.z + nz * l)};
-        nearby.clear();
-        for (const V3 &p0 : hits) {
+    // One hit's work (the reference's loop body, :312-420) reads the whole hit list and nothing of the other hits'
+    // results: in the OpenMP build the hits are processed in parallel into per-hit records, and the training set is
+    // assembled from the records in hit order — the same values in the same order as the serial loop.
+    struct PerHit {
+        bool is_sample = false, has_ray = false;
+        V3 free_origin, free_endpt;
+        std::vector<V3> frees;
+    };
+    std::vector<PerHit> rec(hits.size());
+#pragma omp parallel
+    {
+        std::vector<V3> nearby;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t hi = 0; hi < (int64_t)hits.size(); ++hi) {
+            const V3 &p = hits[hi];
+            PerHit &R = rec[hi];
+            double l = norm3(p - origin);
+            float nx = (float)((p.x - origin.x) / l), ny = (float)((p.y - origin.y) / l), nz = (float)((p.z - origin.z) / l);
             if (max_range > 0) {
-                double range = norm3(p0 - origin);
-                if (range > max_range) continue;
+                if (l < max_range) {
+                    l = (float)sqrt((p.x - origin.x) * (p.x - origin.x) + (p.y - origin.y) * (p.y - origin.y) + (p.z - origin.z) * (p.z - origin.z));
+                    l = l - offset;
+                    R.is_sample = true;
+                } else
+                    l = max_range - offset;
             }
-            if (p.z > (offset + origin.z) && p0.z < origin.z + influence) continue;
-            double dist1 = norm3(free_endpt - p0), dist2 = norm3(origin - p0);
-            if (dist1 < influence) nearby.push_back(p0);
-            else if (dist1 < l && dist2 < l) nearby.push_back(p0);
-        }
-        V3 line_vec = free_endpt - origin;
-        for (const V3 &p1 : nearby) {
-            double dist;
-            V3 pnt_vec = p1 - origin;
-            double b = dot3(pnt_vec, line_vec);
-            if (b > pow(l, 2)) continue;
-            V3 nearest = origin + mulf(line_vec, (float)(b / pow(norm3(line_vec), 2)));
-            dist = norm3(p1 - nearest);
-            if (dist < influence) {
-                nearest_point = p1;
-                l = b / norm3(line_vec);
+            V3 nearest_point = p;
+            V3 free_endpt{(float)(origin.x + nx * l), (float)(origin.y + ny * l), (float)(origin.z + nz * l)};
+            nearby.clear();
+            for (const V3 &p0 : hits) {
+                if (max_range > 0) {
+                    double range = norm3(p0 - origin);
+                    if (range > max_range) continue;
+                }
+                if (p.z > (offset + origin.z) && p0.z < origin.z + influence) continue;
+                double dist1 = norm3(free_endpt - p0), dist2 = norm3(origin - p0);
+                if (dist1 < influence) nearby.push_back(p0);
+                else if (dist1 < l && dist2 < l) nearby.push_back(p0);
             }
+            V3 line_vec = free_endpt - origin;
+            for (const V3 &p1 : nearby) {
+                double dist;
+                V3 pnt_vec = p1 - origin;
+                double b = dot3(pnt_vec, line_vec);
+                if (b > pow(l, 2)) continue;
+                V3 nearest = origin + mulf(line_vec, (float)(b / pow(norm3(line_vec), 2)));
+                dist = norm3(p1 - nearest);
+                if (dist < influence) {
+                    nearest_point = p1;
+                    l = b / norm3(line_vec);
+                }
+            }
+            if (l < max_range / 5.0 && l / (offset - nearest_point.z) > 0) continue;
+            free_endpt = V3{(float)(origin.x + nx * l), (float)(origin.y + ny * l), (float)(origin.z + nz * l)};
+            V3 free_origin = origin;
+            double mu = 1.0;
+            if (l > influence * mu)
+                free_origin = V3{(float)(origin.x + nx * influence * mu), (float)(origin.y + ny * influence * mu), (float)(origin.z + nz * influence * mu)};
+            else
+                free_origin = free_endpt;
+            beam_sample_lv(free_endpt, free_origin, free_resolution, R.frees);
+            R.has_ray = true;
+            R.free_origin = free_origin;
+            R.free_endpt = free_endpt;
         }
-        if (l < max_range / 5.0 && l / (offset - nearest_point.z) > 0) continue;
-        free_endpt = V3{(float)(origin.x + nx * l), (float)(origin.y + ny * l), (float)(origin.z + nz * l)};
-        V3 free_origin = origin;
-        double mu = 1.0;
-        if (l > influence * mu)
-            free_origin = V3{(float)(origin.x + nx * influence * mu), (float)(origin.y + ny * influence * mu), (float)(origin.z + nz * influence * mu)};
-        else
-            free_origin = free_endpt;
-        beam_sample_lv(free_endpt, free_origin, free_resolution, frees);
+    }
+    for (size_t hi = 0; hi < hits.size(); ++hi) {
+        const PerHit &R = rec[hi];
+        if (R.is_sample) {
+            T.xy.push_back(hits[hi]);
+            T.ray_idx.push_back(-1);
+        }
+        if (!R.has_ray) continue;
         T.ray_base.push_back((int)T.xy.size());
-        T.xy.push_back(free_origin);
+        T.xy.push_back(R.free_origin);
         T.ray_idx.push_back(idx);
-        for (const V3 &f : frees) { T.xy.push_back(f); T.ray_idx.push_back(idx); }
-        T.ray0.push_back(free_origin);
-        T.ray1.push_back(free_endpt);
+        for (const V3 &f : R.frees) { T.xy.push_back(f); T.ray_idx.push_back(idx); }
+        T.ray0.push_back(R.free_origin);
+        T.ray1.push_back(R.free_endpt);
         ++idx;
     }
 }
+
 
 // include/bgklvoctomap/bgklvinference.h:100-134 (one point, one segment) then :143-156
 inline float seg_dist(V3 p, V3 p0, V3 p1) {
@@ -375,13 +401,39 @@ void insert_lv(Map &m, const std::vector<V3> &cloud, V3 origin, float ds_resolut
     for (size_t i = 0; i < T.xy.size(); ++i) bucket[ckey(cidx(T.xy[i].x), cidx(T.xy[i].y), cidx(T.xy[i].z))].push_back((int)i);
 
     std::vector<int64_t> test_blocks;
+    const V3 hs{p.ell, p.ell, p.ell};
+    // Blocks are independent (a voxel reads the training set and writes its own node): the OpenMP build runs one task
+    // per DISTINCT block key; a key the float-stepped bbox loop lists twice is visited twice by the same task, in
+    // order, as the reference's serial loop does.
+    std::vector<Block *> blk_of(blocks.size());
+    std::vector<size_t> uniq;                 // positions of first occurrences
+    std::vector<std::vector<size_t>> occ;     // per distinct key: its positions in `blocks`, ascending
+    {
+        std::unordered_map<int64_t, size_t> slot;
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            const int64_t key = blocks[bi];
+            auto it = m.blocks.find(key);
+            if (it == m.blocks.end()) it = m.blocks.emplace(key, block_new(p, key_center(p, key))).first;  // :145-146
+            blk_of[bi] = it->second;
+            auto sl = slot.find(key);
+            if (sl == slot.end()) {
+                slot.emplace(key, uniq.size());
+                uniq.push_back(bi);
+                occ.emplace_back(1, bi);
+            } else
+                occ[sl->second].push_back(bi);
+        }
+    }
+    std::vector<char> info(blocks.size(), 0);
+    double n_visited = 0, n_rows = 0, n_updates = 0;
+#pragma omp parallel reduction(+ : n_visited, n_rows, n_updates)
+    {
     std::vector<uint32_t> keys;
     std::vector<int> cand;
-    const V3 hs{p.ell, p.ell, p.ell};
-    for (int64_t key : blocks) {
-        auto it = m.blocks.find(key);
-        if (it == m.blocks.end()) it = m.blocks.emplace(key, block_new(p, key_center(p, key))).first;  // :145-146
-        Block *block = it->second;
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t ui = 0; ui < (int64_t)uniq.size(); ++ui)
+    for (size_t bi : occ[ui]) {
+        Block *block = blk_of[bi];
         bool has_info = false;
         enumerate_leaves(p, *block, keys);
         for (uint32_t k : keys) {
@@ -392,7 +444,7 @@ void insert_lv(Map &m, const std::vector<V3> &cloud, V3 origin, float ds_resolut
             const V3 &o = m.lut[d][idx];
             const V3 c{o.x + block->center.x, o.y + block->center.y, o.z + block->center.z};
             const V3 bl = c - hs, bh = c + hs;
-            m.st.voxels_visited += 1;
+            n_visited += 1;
             // candidates in box, in gather order
             cand.clear();
             const int64_t cx = cidx(c.x), cy = cidx(c.y), cz = cidx(c.z);
@@ -423,17 +475,23 @@ void insert_lv(Map &m, const std::vector<V3> &cloud, V3 origin, float ds_resolut
                 }
                 ybar += kv * y;
                 kbar += kv;
-                m.st.rows += 1;
+                n_rows += 1;
             }
             Node &node = block->layer[d][idx];
             if (kbar > 0.001f) {  // :236-238
                 lv_update(p, node, ybar, kbar);
-                m.st.voxel_updates += 1;
+                n_updates += 1;
             }
             has_info = true;
         }
-        if (has_info) test_blocks.push_back(key);
+        info[bi] = has_info;
     }
+    }
+    m.st.voxels_visited += n_visited;
+    m.st.rows += n_rows;
+    m.st.voxel_updates += n_updates;
+    for (size_t bi = 0; bi < blocks.size(); ++bi)
+        if (info[bi]) test_blocks.push_back(blocks[bi]);
     m.st.n_info_blocks = (double)test_blocks.size();
     for (int64_t key : test_blocks)
         if (p.original_size) block_prune(p, *m.blocks[key]);  // :262-273

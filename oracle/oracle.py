@@ -133,6 +133,7 @@ def _load(name):
     lib.orc_num_threads.restype = C.c_int
     lib.orc_set_modes.argtypes = [C.c_int, C.c_int]
     lib.orc_set_sum_mode.argtypes = [C.c_int]
+    lib.orc_set_gp_mode.argtypes = [C.c_int]
     lib.orc_block_count.restype = C.c_int64
     lib.orc_block_count.argtypes = [C.c_void_p]
     lib.orc_leaf_count.restype = C.c_int64
@@ -349,8 +350,8 @@ class OracleLVMap:
     """CPU BGKLVOctoMap restatement (constructor argument order of include/bgklvoctomap/bgklvoctomap.h)."""
 
     def __init__(self, resolution=0.1, block_depth=4, sf2=1.0, ell=1.0, free_thresh=0.3, occupied_thresh=0.7,
-                 var_thresh=1.0, prior_A=1.0, prior_B=1.0, original_size=True, min_W=0.1):
-        self.L = lib()
+                 var_thresh=1.0, prior_A=1.0, prior_B=1.0, original_size=True, min_W=0.1, omp=False):
+        self.L = lib(omp)  # omp: the OpenMP build (hits / blocks in parallel, the same values in the same order)
         self.h = self.L.orc_lv_map_create(resolution, block_depth, sf2, ell, free_thresh, occupied_thresh, var_thresh,
                                           prior_A, prior_B, int(original_size), min_W)
 
@@ -506,6 +507,13 @@ def set_sum_mode(mode=0, omp=False):
     """0 = the reference's fp32 summation order (default), 1 = double accumulators over all 7 neighbours, rounded once: the
     counterpart of the device option bgk_sum = 1 (oracle/la3dm_oracle.cpp orc_set_sum_mode).  Process-global."""
     lib(omp).orc_set_sum_mode(int(mode))
+
+
+def set_gp_mode(mode=0, omp=False):
+    """GP sensitivity switch of the restatement: 0 = FMA chains in ascending k (what every parity test uses), 1 = an
+    emulation of Eigen 3.3.7's order of operations on x86-64 without FMA (oracle/la3dm_oracle.cpp, gp_train_eigen).
+    Process-global per library build."""
+    lib(omp).orc_set_gp_mode(int(mode))
 
 
 def set_modes(trig=0, grid_sort=0, omp=False):

@@ -148,3 +148,34 @@ def test_lv_synthetic_scan_that_fills_the_gpu(built):
     assert rays.shape == rays_ref.shape and (rays.view(np.uint32) == rays_ref.view(np.uint32)).all()
     eqA, eqB = _compare(m, o, params, "synthetic 8 k rays")
     assert eqA == 1.0 and eqB == 1.0
+
+
+def test_against_the_likely_reference_build(built):
+    """VERDICT r03 item 2c — the BGK guard of tests/test_bgk_gpu.py for BGKLVOctoMap: the HIP path against the
+    restatement with oracle.set_modes(1, 1) (Eigen 3.3.7 SSE packet sin / cos, pcl::VoxelGrid's unstable sort), four
+    fused sim_unstructured scans at 0.1 m / depth 4.  The LV occupancy probability is 0 or 1 wherever alpha + beta exceeds
+    min_W (bgklvoctree_node.cpp:29-40), so it does not see the difference; alpha and beta do.  Measured
+    (tools/check/likely_ref.py): identical leaf structure, states and `classified`, relative
+    differences <= 4.1e-5 (alpha) / 6.0e-5 (beta) against max(|value|, 1e-3), ~96 % of alpha bit-equal."""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.LV_YAML, resolution=0.1, block_depth=4)
+    m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+    O.set_modes(1, 1, omp=True)
+    try:
+        o = O.OracleLVMap(**params, omp=True)
+        for i in range(1, 5):
+            xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+            m.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+            o.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+    finally:
+        O.set_modes(0, 0, omp=True)
+    a, b = m.leaves(), o.leaves()
+    assert a["A"].size == b["A"].size
+    for k in ("block_key", "node_key", "state", "classified"):
+        assert (a[k] == b[k]).all(), (k, int((a[k] != b[k]).sum()))
+    for k, bound in (("A", 1e-4), ("B", 2e-4)):
+        rel = np.abs(a[k].astype(np.float64) - b[k]) / np.maximum(np.abs(b[k].astype(np.float64)), 1e-3)
+        assert rel.max() <= bound, (k, float(rel.max()))
+    assert np.abs(_lv_prob(a["A"], a["B"], params["min_W"]) - _lv_prob(b["A"], b["B"], params["min_W"])).max() <= 1e-5
+    assert (a["A"] == b["A"]).mean() > 0.9

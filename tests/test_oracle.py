@@ -481,3 +481,25 @@ def test_double_sum_mode_of_the_restatement_stays_within_the_tolerance(built):
             assert (la["A"] != lb["A"]).any()
     finally:
         O.set_sum_mode(0)
+
+
+def test_lv_openmp_build_equals_the_serial_build(O):
+    """The OpenMP build of the BGK-LV restatement (hits of the ray shortening and distinct blocks in parallel, results
+    assembled in the serial order) against the single-thread build: training set, statistics and every leaf identical,
+    over two fused scans (the second meets pruned nodes)."""
+    import la3dm_amd
+    from conftest import pcd_path
+    params = dict(O.LV_YAML, resolution=0.1, block_depth=4)
+    a, b = O.OracleLVMap(**params), O.OracleLVMap(**params, omp=True)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+        ta, tb = a.training_data(xyz, origin, 0.1, 0.1, 8.0), b.training_data(xyz, origin, 0.1, 0.1, 8.0)
+        assert ta[0].shape == tb[0].shape and (ta[0] == tb[0]).all() and (ta[1] == tb[1]).all()
+        a.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        b.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        sa, sb = a.stats(), b.stats()
+        for k in ("n_hits", "n_rays", "n_samples", "n_bbox_blocks", "n_info_blocks", "voxels_visited", "voxel_updates", "rows"):
+            assert sa[k] == sb[k], (i, k)
+        la, lb = a.leaves(), b.leaves()
+        for k in la:
+            assert la[k].shape == lb[k].shape and (la[k] == lb[k]).all(), (i, k)

@@ -36,6 +36,41 @@ def test_gp_regressor_against_float64(built):
     assert st.value == 0 and abs(g.L.orc_gp_node_prob(g.h, mi.value) - 1 / (1 + np.exp(0.1 * 90.0))) < 1e-6
 
 
+def test_gp_eigen_order_mode_against_float64(built):
+    """oracle.set_gp_mode(1): the GP restated in Eigen 3.3.7's order of operations (no FMA, SSE packet sums, blocked
+    LLT, panelled triangular solves, packet exp) is a valid fp32 evaluation of the same regressor — as close to the
+    float64 evaluation as the FMA-chain mode, for block sizes on both sides of the blocking threshold (32) and of a
+    panel (8) — and it is a DIFFERENT rounding: the two modes do not agree bit for bit."""
+    from oracle import oracle as O
+    g = O.OracleGPMap(**O.GP_YAML)
+    rng = np.random.default_rng(5)
+    differs = 0
+    for n in (1, 7, 8, 9, 31, 32, 40, 79, 200):
+        x = rng.uniform(-0.4, 0.4, (n, 3)).astype(np.float32)
+        y = np.where(rng.uniform(size=n) < 0.4, 1, -1).astype(np.float32)
+        xs = rng.uniform(-0.45, 0.45, (64, 3)).astype(np.float32)
+        a0, L0, m0, v0 = g.train_predict(x, y, xs)
+        O.set_gp_mode(1)
+        try:
+            a1, L1, m1, v1 = g.train_predict(x, y, xs)
+        finally:
+            O.set_gp_mode(0)
+        s = float(np.float32(1.73205 / 1.0))
+        d = np.linalg.norm(x[:, None].astype(np.float64) - x[None], axis=2) * s
+        K = (1 + d) * np.exp(-d) + 0.01 * np.eye(n)
+        dk = np.linalg.norm(x[:, None].astype(np.float64) - xs[None], axis=2) * s
+        ks = (1 + dk) * np.exp(-dk)
+        np.testing.assert_allclose(L1 @ L1.T, K, atol=1e-5)
+        assert np.allclose(np.triu(L1, 1), 0)
+        m64 = ks.T @ np.linalg.solve(K, y.astype(np.float64))
+        v64 = 1 - np.einsum("ij,ij->j", ks, np.linalg.solve(K, ks))
+        tol_m = 4e-3 * max(1.0, np.abs(m64).max())
+        assert np.abs(m1 - m64).max() < tol_m and np.abs(m0 - m64).max() < tol_m, n
+        assert np.abs(v1 - v64).max() < 1e-4 and np.abs(v0 - v64).max() < 1e-4, n
+        differs += int((a0 != a1).any() or (m0 != m1).any())
+    assert differs >= 5
+
+
 def test_gp_host_front_end_and_hints(built):
     import la3dm_amd
     from oracle import oracle as O
