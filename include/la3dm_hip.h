@@ -36,7 +36,8 @@ enum {
     LA3DM_ERR_ARG = -1,      /* null / inconsistent argument */
     LA3DM_ERR_HIP = -2,      /* a HIP runtime call failed */
     LA3DM_ERR_NODEVICE = -3, /* no usable HIP device */
-    LA3DM_ERR_OOM = -4       /* device arena allocation failed */
+    LA3DM_ERR_OOM = -4,      /* device arena allocation failed */
+    LA3DM_ERR_PEER = -5      /* block-sharded insert: another rank failed in its rank-local work; every rank gives the insert up */
 };
 
 /* Occupancy state codes, include/bgkoctomap/bgkoctree_node.h:10-12 */

@@ -579,14 +579,30 @@ static void shard_layer_cuts(const uint32_t *hist, uint32_t nlayer, uint32_t wor
     while (q < world) cut[q++] = nlayer;
 }
 
+// What the rank-local part of the front end leaves for its tail (and, in a sharded map, for the exchange in between).
+struct FrontState {
+    enum { kDone, kFilteredLocally, kShardedFilter } path = kDone;  // kDone: finished (no training set, or BGK-L's own path)
+    uint32_t n_kept = 0, n_f = 0, n_f_own = 0;
+    const float *d_frees = nullptr;
+    float4 *xy = nullptr;
+    uint32_t *mm_hits = nullptr;
+};
+// status word of a rank in the sharded front end's count exchange (values above any sample count)
+constexpr uint32_t kShardStatusFailed = 0xFFFFFFFFu;    // a rank-local error: every rank gives the insert up
+constexpr uint32_t kShardStatusNoFilter = 0xFFFFFFFEu;  // this insert does not shard its sample filter (decided alike everywhere)
+
 // f1 (bgkoctomap.cpp:383-458): voxel grid over the hits, range gate + beam samples, voxel grid over the free samples;
 // leaves the labelled training set in dm->xy (hits first), its size in dm->n_xy, and the scan's bbox in dm->h_bbox.
-static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3], float ds_resolution,
-                     float free_resolution, float max_range) {
+// front_end_local: everything a rank does on its own, up to (sharded map) its share of the filtered samples.
+static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3], float ds_resolution,
+                           float free_resolution, float max_range, FrontState &F) {
     la3dm_ctx *ctx = dm->ctx;
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
     int rc;
+    if (const char *ev = getenv("LA3DM_INJECT_FRONT_END_FAILURE"))  // test hook (tests/test_sharded_insert_gpu.py): rank <value> of a sharded map fails here
+        if (dm->shard_world > 1 && atoi(ev) == (int)dm->shard_rank)
+            return dm_fail(dm, LA3DM_ERR_OOM, "devmap: injected rank-local front-end failure (LA3DM_INJECT_FRONT_END_FAILURE)");
     const float *d_hits = d_xyz;
     uint32_t n_h = n;
     int free_key_bits = 32;
@@ -708,6 +724,8 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         const uint32_t n_own = dm->h_cnt[kCntFreeRaw];
         // 3. kept hits -> xy, own samples -> frees_raw, the box of ALL samples -> the filter grid's (global) parameters
         DM_RESERVE(dm->frees_raw, 12ull * (n_own ? n_own : 1));
+        DM_RESERVE(dm->shard_frees, 12ull * (n_free_raw ? n_free_raw : 1));  // the gathered list (<= every raw sample): sized HERE, so that a
+                                                                             // rank that cannot hold it fails before the exchange, not inside it
         {
             MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
             hipLaunchKernelGGL(dm_beam_write<true>, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep,
@@ -726,22 +744,78 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         }
         if (dm->h_gp->passthrough)
             return dm_fail(dm, LA3DM_ERR_ARG, "devmap: sharded insert: the samples' filter grid overflows int32 (PCL passes the cloud through); use one GPU");
-        // 5. all-gather-v of the filtered points behind a 4-byte-per-rank count exchange: every rank gets the whole list,
-        //    rank order = ascending cell index = the single-GPU order
-        DM_RESERVE(dm->shard_cnt, 4ull * world);
-        DM_TRY(hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &n_f_own, 4, hipMemcpyHostToDevice, st));
+        F.path = FrontState::kShardedFilter;
+        F.n_kept = n_kept;
+        F.n_f_own = n_f_own;
+        F.xy = xy;
+        F.mm_hits = mm_hits;
+        return LA3DM_OK;
+    }
+    F.path = FrontState::kFilteredLocally;
+    F.n_kept = n_kept;
+    F.n_f = n_f;
+    F.d_frees = d_frees;
+    F.xy = xy;
+    F.mm_hits = mm_hits;
+    return LA3DM_OK;
+}
+
+static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const float origin[3], float ds_resolution,
+                     float free_resolution, float max_range) {
+    la3dm_ctx *ctx = dm->ctx;
+    hipStream_t st = ctx->stream;
+    la3dm_devmap_stats &S = dm->stats;
+    FrontState F;
+    const int lrc = front_end_local(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range, F);
+    if (dm->shard_world > 1 && dm->shard_fn) {
+        // Sharded map: ONE status / count exchange per insert, entered by every rank whatever happened to it — a rank
+        // that failed on its own (out of memory, a scan that tripped, ...) posts kShardStatusFailed and all ranks give
+        // the insert up together instead of its peers waiting in a collective it never enters; an insert
+        // that does not shard its filter (no voxel grid, a grid that overflows, a very tall scan, nothing to train on)
+        // posts kShardStatusNoFilter.  4 bytes per rank.
+        const uint32_t world = dm->shard_world, rank = dm->shard_rank;
+        uint32_t status = lrc != LA3DM_OK ? kShardStatusFailed : F.path == FrontState::kShardedFilter ? F.n_f_own : kShardStatusNoFilter;
+        const std::string local_err = ctx->err;
+        int xrc = arena_reserve(ctx, dm->shard_cnt, 4ull * world);
+        if (xrc == LA3DM_OK && hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &status, 4, hipMemcpyHostToDevice, st) != hipSuccess) xrc = LA3DM_ERR_HIP;
         dm->shard_off[0].resize(world);
         dm->shard_bytes[0].resize(world);
         for (uint32_t q = 0; q < world; ++q) {
             dm->shard_off[0][q] = 4ull * q;
             dm->shard_bytes[0][q] = 4;
         }
+        // (even a rank that could not stage its word enters the collective: the buffer then holds whatever it held, and
+        //  the rank fails below on its own account)
         la3dm_gather_seg seg = {dm->shard_cnt.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()};
-        if (dm->shard_fn(dm->shard_user, &seg, 1, world, rank, (void *)st) != 0)
+        if (dm->shard_cnt.ptr && dm->shard_fn(dm->shard_user, &seg, 1, world, rank, (void *)st) != 0)
             return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed (sample counts)");
+        if (lrc != LA3DM_OK) {
+            ctx->err = local_err;
+            return lrc;
+        }
+        if (xrc != LA3DM_OK) return dm_fail(dm, xrc, "devmap: sharded insert: could not stage the status word");
         dm->shard_cnt_host.resize(world);
         DM_TRY(hipMemcpyAsync(dm->shard_cnt_host.data(), dm->shard_cnt.ptr, 4ull * world, hipMemcpyDeviceToHost, st));
         DM_TRY(hipStreamSynchronize(st));
+        for (uint32_t q = 0; q < world; ++q)
+            if (dm->shard_cnt_host[q] == kShardStatusFailed)
+                return dm_fail(dm, LA3DM_ERR_PEER, "devmap: sharded insert: rank " + std::to_string(q) + " failed in its front end; the insert is given up on every rank");
+        for (uint32_t q = 0; q < world; ++q)
+            if ((dm->shard_cnt_host[q] == kShardStatusNoFilter) != (status == kShardStatusNoFilter))
+                return dm_fail(dm, LA3DM_ERR_HIP, "devmap: sharded insert: the ranks disagree on whether this insert shards its sample filter");
+    } else if (lrc != LA3DM_OK) {
+        return lrc;
+    }
+    if (F.path == FrontState::kDone) return LA3DM_OK;
+    const uint32_t n_kept = F.n_kept;
+    float4 *xy = F.xy;
+    uint32_t *mm_hits = F.mm_hits;
+    const float *d_frees = F.d_frees;
+    uint32_t n_f = F.n_f;
+    if (F.path == FrontState::kShardedFilter) {
+        // all-gather-v of the filtered points behind the count exchange above: every rank gets the whole list, rank
+        // order = ascending cell index = the single-GPU order
+        const uint32_t world = dm->shard_world, rank = dm->shard_rank, n_f_own = F.n_f_own;
         uint64_t total = 0, mine_at = 0;
         for (uint32_t q = 0; q < world; ++q) {
             if (q == rank) mine_at = total;
@@ -749,11 +823,12 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
             dm->shard_bytes[0][q] = 12ull * dm->shard_cnt_host[q];
             total += dm->shard_cnt_host[q];
         }
-        if (dm->shard_cnt_host[rank] != n_f_own || total > 0xFFFFFFFFull)
+        if (dm->shard_cnt_host[rank] != n_f_own || total > 0xFFFFFFF0ull)
             return dm_fail(dm, LA3DM_ERR_HIP, "devmap: sharded sample filter: inconsistent counts after the exchange");
         n_f = (uint32_t)total;
         if (n_f) {
-            DM_RESERVE(dm->shard_frees, 12ull * n_f);
+            // (dm->shard_frees was sized for every raw sample by the local part: a rank that cannot hold the list has
+            //  already said so in its status word)
             if (n_f_own)
                 hipLaunchKernelGGL(dm_copy_f3, dim3(cdiv(3 * n_f_own, 256)), dim3(256), 0, st, (const float *)dm->frees_ds.ptr, 3 * n_f_own,
                                    (float *)dm->shard_frees.ptr + 3 * mine_at);

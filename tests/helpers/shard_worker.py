@@ -26,6 +26,20 @@ def main():
         m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, block_depth=int(variant[1:])), device=0)
         fr = 0.5
     m.set_shard(rank, world, sharding.torch_allgather(dist, rank, dev, stage_through_host=True))
+    if os.environ.get("LA3DM_INJECT_FRONT_END_FAILURE") is not None:
+        # one rank fails on its own in the front end: EVERY rank's insert must come back with an error (none may wait in a
+        # collective the failed rank never enters); the message goes to the test
+        xyz, origin = la3dm_amd.synthetic_scan(rays)
+        try:
+            m.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)
+            msg = "NO ERROR"
+        except Exception as e:                                   # noqa: BLE001
+            msg = f"{type(e).__name__}: {e}"
+        with open(os.path.join(out_dir, f"rank{rank}.err"), "w") as f:
+            f.write(msg)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for pose in (None, (1.5, 0.5, 1.0)):
         xyz, origin = la3dm_amd.synthetic_scan(rays, origin=pose)
         m.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)

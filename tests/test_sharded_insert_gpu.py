@@ -55,3 +55,25 @@ def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant,
             assert (got[k] == ref[k]).all(), (rank, k)
         for k in ("A", "B"):
             assert (got[k].view(np.uint32) == ref[k].view(np.uint32)).all(), (rank, k)
+
+
+@pytest.mark.parametrize("world,failing", [(2, 1), (3, 0)])
+def test_a_rank_local_failure_ends_the_insert_on_every_rank(built, tmp_path, world, failing):
+    """a rank that fails on its own ahead of the front end's collectives (out of memory, a tripped
+    scan, ...) must not leave its peers waiting in them.  LA3DM_INJECT_FRONT_END_FAILURE makes rank `failing` fail before
+    it has done anything; the sharded front end's status exchange (entered by every rank whatever happened to it) makes
+    all ranks give the insert up: the failed rank reports its own error, every other rank LA3DM_ERR_PEER naming it —
+    and the job ends (no hang: the subprocess timeout would catch it)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_INJECT_FRONT_END_FAILURE=str(failing))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + (os.getpid() % 500)), os.path.join(ROOT, "tests", "helpers", "shard_worker.py"),
+           str(tmp_path), "d3", "8000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for rank in range(world):
+        msg = open(os.path.join(tmp_path, f"rank{rank}.err")).read()
+        assert msg != "NO ERROR", rank
+        if rank == failing:
+            assert "injected rank-local front-end failure" in msg, (rank, msg)
+        else:
+            assert f"rank {failing} failed in its front end" in msg, (rank, msg)
