@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void dm_lv_beams_walk(const float *__restrict_
     // (lds_hits != 0: it fits) that is an LDS latency per step instead of a trip to L2
     extern __shared__ __attribute__((aligned(16))) float lv_walk_hits[];
     if (lds_hits) {   // 16-byte loads, all in flight (one 4-byte load per trip, each waited for, was most of this kernel at 3 500 beams)
-        const uint32_t n4 = (3u * nh) / 4u;
+        // (hits is the caller's own cloud when ds_resolution < 0 — any 4-byte aligned device pointer: the 16-byte form
+        //  only for a 16-byte aligned one)
+        const uint32_t n4 = ((uintptr_t)hits & 15u) == 0u ? (3u * nh) / 4u : 0u;
         const float4 *h4 = reinterpret_cast<const float4 *>(hits);
         float4 *l4 = reinterpret_cast<float4 *>(lv_walk_hits);
 #pragma unroll 4

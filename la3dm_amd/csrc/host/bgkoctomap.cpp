@@ -527,6 +527,10 @@ void BGKOctoMap::reconfigure(float r, unsigned short d) {
         la3dm_devmap_destroy(dmap);
         dmap = nullptr;
     }
+    // the new device map starts unsharded: a block-sharded map stays one
+    if (dmap != nullptr && shard_cfg.world > 1 &&
+        la3dm_devmap_set_shard(dmap, shard_cfg.rank, shard_cfg.world, shard_cfg.fn, shard_cfg.user) != LA3DM_OK)
+        throw std::runtime_error(la3dm_last_error(ctx));
 }
 
 const BGKOctoMap *BGKOctoMap::bound = nullptr;
@@ -1554,6 +1558,7 @@ void BGKOctoMap::commit() {
 void BGKOctoMap::set_shard(uint32_t rank, uint32_t world, la3dm_allgatherv_fn fn, void *user) {
     if (dmap == nullptr) throw std::runtime_error("set_shard: the map is not in device-resident mode");
     if (la3dm_devmap_set_shard(dmap, rank, world, fn, user) != LA3DM_OK) throw std::runtime_error(la3dm_last_error(ctx));
+    shard_cfg = {rank, world, fn, user};   // (reconfigure() rebuilds the device map and applies it again)
 }
 
 bool BGKOctoMap::prepare(const float *xyz, size_t n, size_t stride, const point3f &origin, float ds_resolution,

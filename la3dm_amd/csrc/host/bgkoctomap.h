@@ -466,6 +466,11 @@ protected:
     la3dm_params create_params;   // what the context was created with (lut_xyz is re-pointed on use)
     void create_context();        // la3dm_create + the device-resident pool from create_params and the current statics
     void reconfigure(float resolution, unsigned short depth);
+    struct ShardCfg {
+        uint32_t rank = 0, world = 1;
+        la3dm_allgatherv_fn fn = nullptr;
+        void *user = nullptr;
+    } shard_cfg;   // what set_shard() installed (re-applied to the device map reconfigure() builds)
 
     // per-scan buffers (capacity reused across scans)
     std::vector<float> xy;               // training set: x,y,z,label

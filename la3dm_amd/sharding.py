@@ -81,7 +81,7 @@ class _DeviceBytes:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
 
 
-def gather_v(dist, buf, offsets, nbytes, r, world, async_op=False):
+def gather_v(dist, buf, offsets, nbytes, r, world, async_op=False, group=None):
     """in-place all-gather-v of one byte buffer (a uint8 tensor, host or device): rank q's range [offsets[q], offsets[q] +
     nbytes[q]) is filled on rank q and broadcast to the others; equal contiguous ranges take one all_gather_into_tensor.
     -> the list of pending works (async_op) or []"""
@@ -90,12 +90,14 @@ def gather_v(dist, buf, offsets, nbytes, r, world, async_op=False):
     if even and nbytes[0]:
         # (the input is slice `rank` of the output; a private copy of it keeps the call clear of any in-place /
         # aliasing rule of the backend)
-        w = dist.all_gather_into_tensor(buf[:world * nbytes[0]], buf[r * nbytes[0]:(r + 1) * nbytes[0]].clone(), async_op=async_op)
+        w = dist.all_gather_into_tensor(buf[:world * nbytes[0]], buf[r * nbytes[0]:(r + 1) * nbytes[0]].clone(), group=group, async_op=async_op)
         works.append(w)
     elif not even:
         for q in range(world):
             if nbytes[q]:
-                works.append(dist.broadcast(buf[offsets[q]:offsets[q] + nbytes[q]], src=q, async_op=async_op))
+                # (broadcast's src is a GLOBAL rank: shard rank q of a sub-group is not rank q of the default group)
+                src = dist.get_global_rank(group, q) if group is not None else q
+                works.append(dist.broadcast(buf[offsets[q]:offsets[q] + nbytes[q]], src=src, group=group, async_op=async_op))
     return [w for w in works if w is not None] if async_op else []
 
 
@@ -108,7 +110,7 @@ def leaf_segments(leaf_bounds):
     return [four, four, (lb[:-1], n)]
 
 
-def torch_allgather(dist, rank, device, stage_through_host=False):
+def torch_allgather(dist, rank, device, stage_through_host=False, group=None):
     """-> allgatherv(segments, world, rank, stream) for BGKOctoMap.set_shard: the in-place all-gather-v of the scan's leaf
     arrays on torch.distributed (RCCL over xGMI when the process group's backend is "nccl"), queued on the map's own HIP
     stream (wrapped as a torch ExternalStream: the collective waits for what the library queued before it, what the
@@ -116,7 +118,9 @@ def torch_allgather(dist, rank, device, stage_through_host=False):
     in general, so every segment is `world` broadcasts (src = q) of rank q's byte range, issued asynchronously and
     completed together — an all-gather-v; when all ranges happen to be equal it is one all_gather_into_tensor.
     stage_through_host: the gloo self-test on a single GPU (all ranks on cuda:0) — the payload goes through host memory,
-    with the synchronisations that needs; never a measurement."""
+    with the synchronisations that needs; never a measurement.
+    group: the process group the shard ranks 0 .. world - 1 are the members of (default: the default group); the shard
+    rank handed to set_shard must be the rank INSIDE that group."""
     import torch
 
     def allgatherv(segments, world, r, stream):
@@ -135,12 +139,12 @@ def torch_allgather(dist, rank, device, stage_through_host=False):
                             continue
                         part = buf[offsets[q]:offsets[q] + nbytes[q]]
                         h = part.cpu() if q == r else torch.empty(nbytes[q], dtype=torch.uint8)
-                        dist.broadcast(h, src=q)
+                        dist.broadcast(h, src=dist.get_global_rank(group, q) if group is not None else q, group=group)
                         if q != r:
                             part.copy_(h)
                     ext.synchronize()
                     continue
-                works += gather_v(dist, buf, offsets, nbytes, r, world, async_op=True)
+                works += gather_v(dist, buf, offsets, nbytes, r, world, async_op=True, group=group)
             for w in works:
                 w.wait()          # (NCCL: makes `ext` wait for the collective on the device; does not block the host)
 

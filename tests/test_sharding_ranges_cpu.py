@@ -82,3 +82,42 @@ def test_payload_protocol_gloo(world):
         p.join(120)
         assert p.exitcode == 0
     assert all(ret[r] for r in range(world))
+
+
+def _rank_subgroup(rank, port, ret):
+    """world of 3, the shard group is global ranks {1, 2}: shard rank q is NOT global rank q (broadcast's src
+    is a global rank)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=3)
+    sys.path.insert(0, ROOT)
+    from la3dm_amd import sharding
+    grp = dist.new_group([1, 2])                          # (every rank of the default group makes the call)
+    ok = True
+    if rank in (1, 2):
+        r, world = rank - 1, 2
+        truth = np.arange(1000, dtype=np.uint8)
+        buf = np.zeros_like(truth)
+        offsets, nbytes = [0, 300], [300, 700]            # uneven ranges: the broadcast form
+        buf[offsets[r]:offsets[r] + nbytes[r]] = truth[offsets[r]:offsets[r] + nbytes[r]]
+        sharding.gather_v(dist, torch.from_numpy(buf), offsets, nbytes, r, world, group=grp)
+        ok = bool((buf == truth).all())
+        buf2 = np.zeros(1000, np.uint8)                   # even ranges: the all_gather_into_tensor form
+        buf2[500 * r:500 * (r + 1)] = truth[500 * r:500 * (r + 1)]
+        sharding.gather_v(dist, torch.from_numpy(buf2), [0, 500], [500, 500], r, world, group=grp)
+        ok = ok and bool((buf2 == truth).all())
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_payload_protocol_on_a_subgroup_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29900 + os.getpid() % 90
+    procs = [mp.get_context("spawn").Process(target=_rank_subgroup, args=(r, port, ret)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(3))
