@@ -321,7 +321,11 @@ def main():
                 out["cpu_baseline_omp"] = cpu_baseline(params, xyz, origin, args, U, omp=True)
             if not args.no_side:
                 out["gp"]["depth3"]["cpu_baseline"] = gp_cpu(la3dm_amd)
+                if args.cpu_omp:   # (a bounded sample: one quadrant of the scan)
+                    out["gp"]["depth4"]["cpu_baseline"] = gp_cpu(la3dm_amd, depth=4)
                 out["lv"]["cpu_baseline"] = lv_cpu(la3dm_amd, out["lv"])
+                if args.cpu_omp:
+                    out["lv"]["cpu_baseline_omp"] = lv_cpu(la3dm_amd, out["lv"], omp=True)
                 out["bgkl"]["cpu_baseline"] = l_cpu(la3dm_amd)
         print(json.dumps(out))
     if world > 1:
@@ -532,15 +536,23 @@ def gp_leg(args, torch, la3dm_amd, _lib, depth, cpu):
                                          "frac": cnt["valu_insts_per_launch"] / (k_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
                                          "all_insts_per_s": rate, "source": cnt.get("source")}
     if cpu:
-        out["cpu_baseline"] = gp_cpu(la3dm_amd)
+        out["cpu_baseline"] = gp_cpu(la3dm_amd, depth=depth)
     del m
     return out
 
 
-def gp_cpu(la3dm_amd):
+def gp_cpu(la3dm_amd, depth=3):
+    """CPU leg of the GP legs: the OpenMP build of the restatement on the full scan (depth 3), or — depth 4, where one
+    insert is ~1.4 Tflop of scalar fp32 — on a BOUNDED sample of it: the rays of one quadrant around the sensor (same
+    point density, hence the same block sizes up to N ~ 500; a quarter of the blocks)"""
     from oracle import oracle as O
-    params = dict(la3dm_amd.GP_YAML, block_depth=3, resolution=0.1)
+    params = dict(la3dm_amd.GP_YAML, block_depth=depth, resolution=0.1)
     xyz, origin = la3dm_amd.synthetic_scan(50000)
+    sample = "the full scan"
+    if depth >= 4:
+        d = xyz - np.asarray(origin, np.float32)[None, :]
+        xyz = np.ascontiguousarray(xyz[(d[:, 0] >= 0) & (d[:, 1] >= 0)])
+        sample = f"the {xyz.shape[0]} rays of the scan's +x +y quadrant"
     o = O.OracleGPMap(**params, omp=True)
     t0 = time.perf_counter()
     o.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
@@ -548,9 +560,9 @@ def gp_cpu(la3dm_amd):
     so = o.stats()
     return {"value": so["voxel_updates"] / so["t_predict"], "unit": "voxel-updates/s",
             "cores": O.lib(True).orc_num_threads(), "kind": "port",
-            "sample": "the full scan at block_depth 3, 1 insert_pointcloud into a fresh map of this repo's restatement (OpenMP "
+            "sample": f"{sample} at block_depth {depth}, 1 insert_pointcloud into a fresh map of this repo's restatement (OpenMP "
                       "build); value = leaves of test blocks / train+predict+fuse stage time",
-            "stage_s": {"predict_fuse": so["t_predict"], "insert_pointcloud": tc}}
+            "voxel_updates": so["voxel_updates"], "stage_s": {"predict_fuse": so["t_predict"], "insert_pointcloud": tc}}
 
 
 def lv_leg(args, torch, la3dm_amd, _lib, cpu):
@@ -606,24 +618,40 @@ def lv_leg(args, torch, la3dm_amd, _lib, cpu):
                             "roofline": {"bound": "hbm", "kernel": "bgklv_voxel_kernel (+ split add)", "kernel_ms": k_ms,
                                          "algorithmic_bytes_per_launch": b_alg, "achieved": b_alg / (k_ms * 1e-3) / 1e9,
                                          "peak": 8000.0, "unit": "GB/s", "frac": b_alg / (k_ms * 1e-3) / 1e9 / 8000.0}}
+    cnt = profiled_counters("lv50k", path="side_counters.json", sources=("lv_kernels.h", "devmap_lv_kernels.h"))
+    if cnt:   # HBM bytes per insert of the kernels the roofline names (tools/prof/side_pmc.sh; gfx950: FETCH_SIZE x 2 + WRITE_SIZE)
+        ks = [e for k, e in cnt["kernels"].items() if "bgklv_voxel_kernel" in k or "bgklv_split_add" in k]
+        rf = out["synthetic_50k"]["roofline"]
+        rf["traffic"] = sum((2 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024 for e in ks)
+        rf["traffic_source"] = cnt.get("source")
+        rf["valu_insts"] = sum(e.get("SQ_INSTS_VALU", 0.0) for e in ks)
+        rf["insert_traffic_all_kernels"] = cnt["hbm_bytes"]
+    else:
+        out["synthetic_50k"]["roofline"]["traffic"] = None
     if cpu:
         out["cpu_baseline"] = lv_cpu(la3dm_amd, out)
     del m
     return out
 
 
-def lv_cpu(la3dm_amd, leg):
+def lv_cpu(la3dm_amd, leg, omp=False):
+    """CPU leg of the BGK-LV sequence: 1 thread on the first 3 scans (the bounded sample), or — omp — the OpenMP build of
+    the restatement (hits of the ray shortening and distinct blocks in parallel) on ALL 12 scans; the files are read
+    before the clock starts"""
     from oracle import oracle as O
     params = dict(la3dm_amd.LV_YAML, resolution=0.05, block_depth=5)
-    o = O.OracleLVMap(**params)
+    n = 12 if omp else 3
+    scans = [la3dm_amd.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "sim_unstructured", f"sim_unstructured_{i}.pcd"))
+             for i in range(1, n + 1)]
+    o = O.OracleLVMap(**params, omp=omp)
     t0 = time.perf_counter()
-    for i in range(1, 4):
-        xyz, origin = la3dm_amd.load_pcd(os.path.join(ROOT, "tests", "golden", "data", "sim_unstructured", f"sim_unstructured_{i}.pcd"))
+    for xyz, origin in scans:
         o.insert_pointcloud(xyz, origin, 0.05, 0.1, 8.0)
     tc = time.perf_counter() - t0
-    return {"value": 3 / tc, "unit": "scans/s", "cores": 1, "kind": "port",
-            "sample": "the first 3 of the 12 scans into a fresh map of this repo's restatement (1 thread, incl. reading the files)",
-            "s_per_scan": tc / 3, "gpu_scans_per_s": 12 / (leg["sequence_ms"] * 1e-3)}
+    return {"value": n / tc, "unit": "scans/s", "cores": O.lib(True).orc_num_threads() if omp else 1, "kind": "port",
+            "sample": (f"all {n} scans" if omp else f"the first {n} of the 12 scans") + " into a fresh map of this repo's restatement ("
+                      + ("OpenMP build" if omp else "1 thread") + "; clouds in memory before the clock starts)",
+            "s_per_scan": tc / n, "gpu_scans_per_s": 12 / (leg["sequence_ms"] * 1e-3)}
 
 
 def side_bench(args, torch, la3dm_amd, _lib):
@@ -683,6 +711,11 @@ def l_leg(args, torch, la3dm_amd, cpu):
            "roofline": {"bound": "hbm", "achieved": b_alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": b_alg / dt / 1e9 / 8000.0, "traffic": None, "kernel": "insert_pointcloud (all kernels)",
                         "kernel_ms": dt * 1e3, "algorithmic_bytes_per_launch": b_alg}}
+    cnt = profiled_counters("l", path="side_counters.json", sources=("bgkl_kernels.h",))
+    if cnt:   # HBM bytes of one insert, all kernels (tools/prof/side_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)
+        out["roofline"]["traffic"] = cnt["hbm_bytes"]
+        out["roofline"]["traffic_source"] = cnt.get("source")
+        out["roofline"]["valu_insts"] = cnt.get("valu_insts")
     if cpu:
         out["cpu_baseline"] = l_cpu(la3dm_amd)
     del m

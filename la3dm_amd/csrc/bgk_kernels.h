@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // the same kernel without the general path, for scans whose caller vouches that no test block is pruned
 // (LA3DM_SCAN_FULL_BLOCKS: the first scan into an empty map, a packed scan whose leaf count says so): the general
 // path's presence costs the table path ~2 % (register allocation of the shared prologue).
-// LDS per wave: 12 x 32 table (1 536 B) + 2 x 64 double accumulators (1 024 B) + 320-entry ring (2 560 B) = 5 120 B.
+// LDS per wave: 2 x 12 x 16 table (1 536 B) + 2 x 64 double accumulators (1 024 B) + 320-entry ring (2 560 B) = 5 120 B.
 // B per candidate: 1 (packed adds) + v_cmp + 2 v_mbcnt + v_lshl_add = 5 VALU (r: 9).
 // ---------------------------------------------------------------------------
 #ifndef LA3DM_T_EARLY_AB
@@ -1172,7 +1172,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 constexpr int kTabSlots = 32;
 constexpr int kRingT = 320;
 struct __attribute__((aligned(16))) WaveLdsT {
-    float tab[12][kTabSlots];  // rows 0-3 (p.x - X_i)^2, 4-7 y, 8-11 z; all twelve negated for a label-1 point
+    // rows 0-3 (p.x - X_i)^2, 4-7 y, 8-11 z; all twelve negated for a label-1 point.  Two halves of 16 slots: a row is 64
+    // bytes, so the four rows of an axis that the lanes of one ds_read_b128 group read (same column group, different
+    // rows) start 16 banks apart and cover the 64 banks exactly — with 32-slot rows (128 B) rows i and i + 2 met on
+    // the same banks: 136 LDS conflict cycles per tile, a fifth of the kernel's LDS-array time
+    float tab[kTabSlots / 16][12][16];
     double acc0[kWave];        // sum(k) over the label-0 pairs
     double acc1[kWave];        // sum(k) over the label-1 pairs
     uint2 ring[kRingT];        // {+-d2, LDS address of acc0[leaf]}
@@ -1339,8 +1343,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const la3dm_v2f Z01 = {rl(zs0, 63), rl(zs0, 62)}, Z23 = {rl(zs0, 55), rl(zs0, 54)};
     const uint32_t c6 = lane ^ 63u;
     const uint32_t ix = ((c6 >> 4) & 2u) | ((c6 >> 2) & 1u), iy = ((c6 >> 3) & 2u) | ((c6 >> 1) & 1u), iz = ((c6 >> 2) & 2u) | (c6 & 1u);
-    const uint32_t tab_base = (uint32_t)(uintptr_t)&L.tab[0][0];
-    constexpr uint32_t kRowB = 4u * kTabSlots;
+    const uint32_t tab_base = (uint32_t)(uintptr_t)&L.tab[0][0][0];
+    constexpr uint32_t kRowB = 4u * 16u, kHalfB = 12u * kRowB;
+    static_assert(kTabSlots == 32, "the B loop below walks two halves of 16 slots");
     const uint32_t ax0 = tab_base + ix * kRowB, ay0 = tab_base + (4u + iy) * kRowB, az0 = tab_base + (8u + iz) * kRowB;
     const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
     const uint32_t w0 = (uint32_t)(uintptr_t)&L.acc0[0] + 8u * lane;
@@ -1403,13 +1408,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 float big;
                 asm volatile("v_mov_b32 %0, 0x5e268890" : "=v"(big));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) L.tab[r][nr + lane] = big;
+                for (int r = 0; r < 4; ++r) L.tab[(nr + lane) >> 4][r][(nr + lane) & 15u] = big;
             }
             const uint32_t slot = rank - base;
             if (keep && slot < (uint32_t)kTabSlots) {
-                L.tab[0][slot] = x01.x, L.tab[1][slot] = x01.y, L.tab[2][slot] = x23.x, L.tab[3][slot] = x23.y;
-                L.tab[4][slot] = y01.x, L.tab[5][slot] = y01.y, L.tab[6][slot] = y23.x, L.tab[7][slot] = y23.y;
-                L.tab[8][slot] = z01.x, L.tab[9][slot] = z01.y, L.tab[10][slot] = z23.x, L.tab[11][slot] = z23.y;
+                float(&T)[12][16] = L.tab[slot >> 4];
+                const uint32_t c = slot & 15u;
+                T[0][c] = x01.x, T[1][c] = x01.y, T[2][c] = x23.x, T[3][c] = x23.y;
+                T[4][c] = y01.x, T[5][c] = y01.y, T[6][c] = y23.x, T[7][c] = y23.y;
+                T[8][c] = z01.x, T[9][c] = z01.y, T[10][c] = z23.x, T[11][c] = z23.y;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1425,7 +1432,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     LA3DM_TP_TRIP("16");
                     if (tailb > tail_cap) c_flush();
                 }
-                aX += 32u, aY += 32u, aZ += 32u;
+                const uint32_t step = g == 2u ? kHalfB - 32u : 32u;   // column groups 0-3 sit in the first half, 4-7 in the second
+                aX += step, aY += step, aZ += step;
             }
             // (the next sub-round overwrites the table: LDS operations of a wave complete in order)
         }
