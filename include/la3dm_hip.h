@@ -335,6 +335,9 @@ int la3dm_devmap_lv_training(la3dm_devmap *dm, float *samples4, uint32_t cap_sam
  * ncclUint8, q, comm, stream) per rank and segment.  Nothing synchronises the host: the library queues commit and prune
  * behind the call on the same stream.  fn returns 0 on success.  A rank whose own kernel launch failed still calls fn (its
  * bytes are then not meaningful) so that no peer waits in the collective for ever, and reports the error afterwards.
+ * Besides that per-pass call the front end calls fn once per insert with ONE segment of 4 bytes per rank (the rank's
+ * status / count word: a rank that failed on its own posts a failure word and every rank returns — LA3DM_ERR_PEER on
+ * the healthy ones) and, when the insert shards its sample filter, once more with one segment of 12 bytes per sample.
  * world = 1 switches sharding off.  Variants 0 (BGK) and 1 (GP). */
 typedef struct la3dm_gather_seg {
     void *base;              /* device pointer */
