@@ -173,10 +173,23 @@ __device__ __forceinline__ void sincos_cr_core(float t, float &s, float &c, Fetc
 __device__ __forceinline__ la3dm_v2d sincos_cr_entry(uint32_t ub) {  // the table entry of q = ub & 127 (a 16-byte gather)
     return *reinterpret_cast<const la3dm_v2d *>(reinterpret_cast<const char *>(kSinCosTab) + ((ub & 127u) << 4));
 }
+// the same for a FINITE t in [0, 2 pi] (ub = 0x4B400000 + q, q <= 64): ub << 4 is 0xB4000000 + 16 q in 32 bits, so the
+// entry is at (table - 0xB4000000) + (ub << 4) — one shift, no mask.  Only where t cannot be NaN (the BGK kernels' ring
+// entries: a pair is pushed only if its d2 compared below the hit threshold).
+__device__ __forceinline__ la3dm_v2d sincos_cr_entry_finite(uint32_t ub) {
+    return *reinterpret_cast<const la3dm_v2d *>(reinterpret_cast<const char *>(kSinCosTab) - 0xB4000000ll + (unsigned long long)(ub << 4));
+}
 // the table read from memory (a 16-byte gather that stays in the vector L1): any t in [0, 2 pi], NaN in -> NaN out
 __device__ __forceinline__ void sincos_cr(float t, float &s, float &c) {
     sincos_cr_core(t, s, c, [](uint32_t ub, double &sa, double &ca) {
         const la3dm_v2d e = sincos_cr_entry(ub);
+        sa = e.x;
+        ca = e.y;
+    });
+}
+__device__ __forceinline__ void sincos_cr_finite(float t, float &s, float &c) {
+    sincos_cr_core(t, s, c, [](uint32_t ub, double &sa, double &ca) {
+        const la3dm_v2d e = sincos_cr_entry_finite(ub);
         sa = e.x;
         ca = e.y;
     });
@@ -359,11 +372,12 @@ __device__ __forceinline__ float cov_sparse_formula(float r, float s, float c, f
     if (kClamp) k = fmaxf(k, 0.0f);  // k is never NaN here; (-0 -> +0 adds the same to every sum)
     return k;
 }
-template <int kTrig, bool kClamp = true>
+template <int kTrig, bool kClamp = true, bool kFinite = false>
 __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     const float t = (r * 2.0f) * 3.1415926f;
     float s, c;
-    if (kTrig == 0) sincos_cr(t, s, c);
+    if (kTrig == 0 && kFinite) sincos_cr_finite(t, s, c);
+    else if (kTrig == 0) sincos_cr(t, s, c);
     else if (kTrig == 1) sincos_0_2pi(t, s, c);
     else { s = sinf(t); c = cosf(t); }
     return cov_sparse_formula<kClamp>(r, s, c, sf2);
@@ -1007,7 +1021,7 @@ __device__ __forceinline__ void bgk_tile_r(const BgkArgs &a, WaveLdsR &L, const 
         const uint2 e = L.ring[i];
         float y;
         asm volatile("ds_read_b32 %0, %1\n" : "=v"(y) : "v"(cw_base + (e.y & 0xFCu)) : "memory");
-        const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__uint_as_float(e.x)), a.sf2);
+        const float kv = cov_sparse_fast<kTrig, true, true>(sqrt_cr(__uint_as_float(e.x)), a.sf2);
         const double kd = (double)kv;
         uint32_t ad = acc_base + (e.y >> 10);
         if (a.flags & 0x800u) ad = acc_base + 8u * lane;  // profiling ablation: conflict-free accumulate (results invalid)
@@ -1082,13 +1096,9 @@ __device__ __forceinline__ void bgk_tile_r(const BgkArgs &a, WaveLdsR &L, const 
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t tail = (tailb - ring_base) >> 3;
                 const uint32_t nfull = tail & ~63u, rem = tail & 63u;
+                // (the batches come from the ring's end, entries [rem, tail): the remainder stays at the front, nothing moves)
                 if (!(a.flags & 0x100u))  // 0x100: profiling ablation
-                    for (uint32_t p = 0; p < nfull; p += kWave) c_eval(p + lane);
-                uint2 e = make_uint2(0u, 0u);
-                if (lane < rem) e = L.ring[nfull + lane];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < rem) L.ring[lane] = e;
+                    for (uint32_t p = rem; p < tail; p += kWave) c_eval(p + lane);
                 tailb = ring_base + 8u * rem;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1176,11 +1186,12 @@ struct __attribute__((aligned(16))) WaveLdsT {
     // bytes, so the four rows of an axis that the lanes of one ds_read_b128 group read (same column group, different
     // rows) start 16 banks apart and cover the 64 banks exactly — with 32-slot rows (128 B) rows i and i + 2 met on
     // the same banks: 136 LDS conflict cycles per tile, a fifth of the kernel's LDS-array time
-    float tab[kTabSlots / 16][12][16];
-    double acc0[kWave];        // sum(k) over the label-0 pairs
-    double acc1[kWave];        // sum(k) over the label-1 pairs
     uint2 ring[kRingT];        // {+-d2, LDS address of acc0[leaf]}
+    float tab[kTabSlots / 16][12][16];
+    double acc0[kWave];        // sum(k) over the label-0 pairs: at byte 4 096 — bit 9 of its addresses is clear, and
+    double acc1[kWave];        // sum(k) over the label-1 pairs: 512 bytes up, so the label bit can be OR-ed into the address
 };
+static_assert(offsetof(WaveLdsT, acc0) == 4096 && offsetof(WaveLdsT, tab) % 64 == 0, "c_eval ORs the label into bit 9 of acc0's address; the table rows are 64-byte aligned");
 static_assert(sizeof(WaveLdsT) == 5120 && sizeof(WaveLdsR) == 5120, "8 waves per SIMD need <= 5 120 B of LDS per wave");
 
 // B, four candidates (one table column group): the four compares first (four SGPR pairs), then the four pushes.  Push of
@@ -1349,6 +1360,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t ax0 = tab_base + ix * kRowB, ay0 = tab_base + (4u + iy) * kRowB, az0 = tab_base + (8u + iz) * kRowB;
     const uint32_t ring_base = (uint32_t)(uintptr_t)&L.ring[0];
     const uint32_t w0 = (uint32_t)(uintptr_t)&L.acc0[0] + 8u * lane;
+    if (w0 & 0x200u) __builtin_trap();   // (s_lds is the kernel's only static LDS object: it starts at LDS address 0)
     static_assert(offsetof(WaveLdsT, acc1) - offsetof(WaveLdsT, acc0) == 512, "c_eval adds 512 to the address of acc0[leaf] for a label-1 pair");
     const float hit_t = __uint_as_float(kHitTBits);
     const uint32_t tail_cap = ring_base + 8u * (uint32_t)(kRingT - 4 * kWave);
@@ -1360,9 +1372,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // gather of batch b + 1 ahead of the polynomials of batch b): 72.9 against 72.1 us.)
     auto c_eval = [&](uint32_t i) {
         const uint2 e = L.ring[i];
-        const float kv = cov_sparse_fast<kTrig>(sqrt_cr(__builtin_fabsf(__uint_as_float(e.x))), a.sf2);
+        const float kv = cov_sparse_fast<kTrig, true, true>(sqrt_cr(__builtin_fabsf(__uint_as_float(e.x))), a.sf2);
         const double kd = (double)kv;
-        const uint32_t ad = e.y + ((e.x >> 31) << 9);  // label 1 (negative d2): acc1[leaf], 512 bytes up
+        const uint32_t ad = e.y | ((e.x >> 22) & 0x200u);  // label 1 (negative d2): acc1[leaf], 512 bytes up (v_lshrrev + v_and_or)
         asm volatile("ds_add_f64 %0, %1\n" : : "v"(ad), "v"(kd) : "memory");
     };
     // C round: the full 64-entry batches; the remainder (< 64 entries) moves to the front of the ring
@@ -1371,13 +1383,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         __builtin_amdgcn_wave_barrier();
         const uint32_t tail = (tailb - ring_base) >> 3;
         const uint32_t nfull = tail & ~63u, rem = tail & 63u;
+        // the full batches are taken from the ring's END — entries [rem, tail) — so that the remainder stays where it is,
+        // at the front (the sums are order-free; moving the remainder cost a read, a write and two barriers per round)
         if (!(a.flags & 0x100u))  // 0x100: profiling ablation
-            for (uint32_t p = 0; p < nfull; p += kWave) c_eval(p + lane);
-        uint2 e = make_uint2(0u, 0u);
-        if (lane < rem) e = L.ring[nfull + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rem) L.ring[lane] = e;
+            for (uint32_t p = rem; p < tail; p += kWave) c_eval(p + lane);
         tailb = ring_base + 8u * rem;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
