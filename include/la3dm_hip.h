@@ -217,7 +217,10 @@ int la3dm_kernel_times(la3dm_ctx *ctx, float *ms, uint32_t cap, uint32_t *n_out)
 
 /* Diagnostics used by the parity tests: evaluate one primitive of the device
  * arithmetic elementwise on host arrays.  op: 0 sqrt(x)  1 sin(x)  2 cos(x)
- * 3 sparse kernel k(r) with the ctx's sf2 (clamped)  4 x / ell  5 k(r) unclamped. */
+ * 3 sparse kernel k(r) with the ctx's sf2 (clamped)  4 x / ell  5 k(r) unclamped
+ * 9 / 10 the correctly rounded sin / cos of the kernels  12 / 13 node state of the pairs (alpha, beta) =
+ * (in[2 j], in[2 j + 1]) with the ctx's thresholds, by the kernels' approximate-quotient form / by the IEEE
+ * divisions of bgkoctree_node.cpp:36-43 (out[2 j] = state). */
 int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *out);
 
 

@@ -309,12 +309,13 @@ __device__ __forceinline__ uint8_t classify(float A, float B, const BgkArgs &a) 
 // cost 22 VALU instructions per leaf tile, the approximations 4.  NaN / inf operands behave alike on both paths
 // (every comparison false -> 2; a product over an infinite denominator is 0 on both).
 __device__ __forceinline__ uint8_t classify_fast(float A, float B, const BgkArgs &a) {
-    const float s = A + B;
-    const float v = (A * B) * __builtin_amdgcn_rcpf((s * s) * (s + 1.0f));
+    const float s = A + B, den = (s * s) * (s + 1.0f);
+    const float v = (A * B) * __builtin_amdgcn_rcpf(den);
     const float p = A * __builtin_amdgcn_rcpf(s);
-    const bool near = __builtin_fabsf(v - a.var_thresh) <= a.var_thresh * 0x1p-18f ||
-                      __builtin_fabsf(p - a.occupied_thresh) <= a.occupied_thresh * 0x1p-18f ||
-                      __builtin_fabsf(p - a.free_thresh) <= a.free_thresh * 0x1p-18f;
+    // (v_rcp_f32 treats a denormal operand as zero: denominators that small — priors below 1e-19 — take the divisions too)
+    const bool near = __builtin_fabsf(v - a.var_thresh) <= __builtin_fabsf(a.var_thresh) * 0x1p-18f ||
+                      __builtin_fabsf(p - a.occupied_thresh) <= __builtin_fabsf(a.occupied_thresh) * 0x1p-18f ||
+                      __builtin_fabsf(p - a.free_thresh) <= __builtin_fabsf(a.free_thresh) * 0x1p-18f || !(den > 0x1p-100f);
     if (__ballot(near) != 0ull) return classify(A, B, a);
     if (v > a.var_thresh) return 2;
     return p > a.occupied_thresh ? 1 : (p < a.free_thresh ? 0 : 2);
@@ -1531,8 +1532,24 @@ __global__ void sweep_check_kernel(int what, uint32_t lo_bits, uint32_t hi_bits,
 }
 
 // diagnostics for the parity tests
-__global__ void diag_eval_kernel(int op, const float *in, float *out, uint32_t n, float sf2, float ell) {
+__global__ void diag_eval_kernel(int op, const float *in, float *out, uint32_t n, float sf2, float ell, float free_thresh = 0.0f,
+                                 float occupied_thresh = 0.0f, float var_thresh = 0.0f) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (op == 12 || op == 13) {  // node state of (alpha, beta) = (in[2 j], in[2 j + 1]): 12 classify_fast, 13 classify; out[2 j] = state
+        // (whole waves stay active: classify_fast votes over the wave)
+        const uint32_t j = i < n / 2u ? i : 0u;
+        BgkArgs a;
+        a.free_thresh = free_thresh;
+        a.occupied_thresh = occupied_thresh;
+        a.var_thresh = var_thresh;
+        const float A = in[2 * j], B = in[2 * j + 1];
+        const uint8_t st = op == 12 ? classify_fast(A, B, a) : classify(A, B, a);
+        if (i < n / 2u) {
+            out[2 * i] = (float)st;
+            out[2 * i + 1] = 0.0f;
+        }
+        return;
+    }
     if (i >= n) return;
     float x = in[i], y;
     float s, c;

@@ -952,7 +952,7 @@ int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_diag_in.ptr, in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(diag_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, op, (const float *)ctx->h_diag_in.ptr,
-                       (float *)ctx->h_diag_out.ptr, n, ctx->p.sf2, ctx->p.ell);
+                       (float *)ctx->h_diag_out.ptr, n, ctx->p.sf2, ctx->p.ell, ctx->p.free_thresh, ctx->p.occupied_thresh, ctx->p.var_thresh);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->h_diag_out.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

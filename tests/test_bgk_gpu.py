@@ -304,3 +304,36 @@ def test_against_the_likely_reference_build(built, mode):
         assert d.max() <= bound, (tag, float(d.max()))
         assert (d <= 1e-5).mean() >= 0.998, (tag, float((d <= 1e-5).mean()))
         print(tag, "mode", mode, "max |dp|", float(d.max()), "within 1e-5:", float((d <= 1e-5).mean()))
+
+
+def test_state_from_approximate_quotients_equals_the_ieee_divisions(built):
+    """The kernels' epilogue derives the node state (bgkoctree_node.cpp:36-43: variance against var_thresh, probability
+    against occupied / free thresholds) from v_rcp_f32 quotients and takes the IEEE divisions only when a quotient lies
+    within 2^-18 of a threshold (classify_fast, bgk_kernels.h).  Both forms on 2 M random (alpha, beta) pairs — priors,
+    large evidence, and pairs constructed to land within a few ulp of each threshold — for three threshold sets: equal
+    states everywhere."""
+    import la3dm_amd
+    rng = np.random.default_rng(77)
+    for vt, ft, ot in ((100.0, 0.3, 0.7), (0.15, 0.3, 0.7), (0.05, 0.45, 0.55)):
+        m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, var_thresh=vt, free_thresh=ft, occupied_thresh=ot), device=0)
+        n = 1 << 20
+        A = np.exp(rng.uniform(np.log(1e-3), np.log(50.0), n)).astype(np.float32)
+        B = np.exp(rng.uniform(np.log(1e-3), np.log(50.0), n)).astype(np.float32)
+        # pairs at the thresholds: p = A / (A + B) = t exactly in real arithmetic, then nudged by a few ulp
+        for k, t in enumerate((ft, ot)):
+            sl = slice(k * (n // 8), (k + 1) * (n // 8))
+            s = A[sl] + B[sl]
+            A[sl] = (np.float32(t) * s).astype(np.float32)
+            B[sl] = (s - A[sl]).astype(np.float32)
+            A[sl] = np.nextafter(A[sl], np.where(rng.integers(0, 2, s.size) == 1, np.float32(np.inf), np.float32(0))).astype(np.float32)
+        # pairs at the variance threshold: A = B = a with var = 1 / (4 (2 a + 1)) = vt  <=>  a = (1 / (4 vt) - 1) / 2
+        a0 = (1.0 / (4.0 * vt) - 1.0) / 2.0
+        if a0 > 1e-3:
+            sl = slice(n // 2, n // 2 + n // 8)
+            A[sl] = B[sl] = np.float32(a0)
+            A[sl] *= (1.0 + rng.integers(-4, 5, n // 8) * 2.0 ** -23).astype(np.float32)
+        x = np.stack([A, B], axis=1).ravel()
+        fast = m.diag_eval(12, x)[0::2]
+        exact = m.diag_eval(13, x)[0::2]
+        assert (fast == exact).all(), (vt, ft, ot, int((fast != exact).sum()))
+        assert len(np.unique(exact)) >= 2
