@@ -626,6 +626,10 @@ def lv_leg(args, torch, la3dm_amd, _lib, cpu):
         rf["traffic_source"] = cnt.get("source")
         rf["valu_insts"] = sum(e.get("SQ_INSTS_VALU", 0.0) for e in ks)
         rf["insert_traffic_all_kernels"] = cnt["hbm_bytes"]
+        # what the kernel is actually limited by: vector-instruction issue (one wave instruction per 4 cycles per SIMD), not HBM
+        rf["valu_issue"] = {"achieved": rf["valu_insts"] / (k_ms * 1e-3), "peak": 1024 * 2.4e9 / 4.0,
+                            "unit": "VALU wave-instr/s (one per 4 cycles per SIMD)",
+                            "frac": rf["valu_insts"] / (k_ms * 1e-3) / (1024 * 2.4e9 / 4.0)}
     else:
         out["synthetic_50k"]["roofline"]["traffic"] = None
     if cpu:
@@ -716,6 +720,10 @@ def l_leg(args, torch, la3dm_amd, cpu):
         out["roofline"]["traffic"] = cnt["hbm_bytes"]
         out["roofline"]["traffic_source"] = cnt.get("source")
         out["roofline"]["valu_insts"] = cnt.get("valu_insts")
+        if cnt.get("valu_insts"):
+            out["roofline"]["valu_issue"] = {"achieved": cnt["valu_insts"] / dt, "peak": 1024 * 2.4e9 / 4.0,
+                                             "unit": "VALU wave-instr/s (one per 4 cycles per SIMD), all kernels of the insert",
+                                             "frac": cnt["valu_insts"] / dt / (1024 * 2.4e9 / 4.0)}
     if cpu:
         out["cpu_baseline"] = l_cpu(la3dm_amd)
     del m

@@ -1269,7 +1269,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t li = lb0 + tile * kWave + lane;
     // LeafIterator order is descending (bgkoctree.h:101-135): the leaf at list position j of a full block has the
     // finest-level index 8^(depth-1) - 1 - j, so the key needs no load
-    const uint32_t key = ((a.depth - 1u) << 16) + ((1u << (3u * (a.depth - 1u))) - 1u - (tile * kWave + lane));
+    // (LUT entry: the finest layer's base + that index — wave-uniform base, one subtraction per lane)
+    const uint32_t n_fine = 1u << (3u * (a.depth - 1u));
+    const uint32_t lut_idx = lut_layer_base(a.depth - 1u) + (n_fine - 1u - tile * kWave) - lane;
 
     // flat view of the 7 neighbour ranges (bgk_prepare's blk_desc, as in bgk_tile_r).  The first two chunks use the
     // descriptor read above; a tile with more than 128 points reads it again per further chunk (rare) — its 13 words
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         return gather(adjv, pend, cb, M);
     };
 
-    const float4 off4 = a.lut[lut_layer_base(key >> 16) + (key & 0xFFFFu)];
+    const float4 off4 = a.lut[lut_idx];
     const float xs0 = div_by_ell(off4.x + cx, a.ell, a.inv_ell), ys0 = div_by_ell(off4.y + cy, a.ell, a.inv_ell),
                 zs0 = div_by_ell(off4.z + cz, a.ell, a.inv_ell);
     L.acc0[lane] = 0.0;

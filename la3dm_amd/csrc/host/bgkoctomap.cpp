@@ -103,6 +103,20 @@ Occupancy::Occupancy(float A, float B) : classified(false) {
     classify();
 }
 
+std::ofstream &operator<<(std::ofstream &os, const Occupancy &oc) {
+    os.write((const char *)&oc.m_A, sizeof(oc.m_A));
+    os.write((const char *)&oc.m_B, sizeof(oc.m_B));
+    return os;
+}
+std::ifstream &operator>>(std::ifstream &is, Occupancy &oc) {
+    float A, B;
+    is.read((char *)&A, sizeof(A));
+    is.read((char *)&B, sizeof(B));
+    oc = OcTreeNode(A, B);
+    return is;
+}
+std::ostream &operator<<(std::ostream &os, const Occupancy &oc) { return os << '(' << oc.m_A << ' ' << oc.m_B << ' ' << oc.get_prob() << ')'; }
+
 void Occupancy::update(float ybar, float kbar) {
     classified = true;
     if (variant == 1) {  // BCM: update(new_m, new_var), gpoctree_node.cpp:36-39

@@ -22,6 +22,8 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <fstream>
+#include <ostream>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -104,6 +106,13 @@ public:
     bool operator==(const Occupancy &rhs) const {
         return state != State::UNKNOWN && state != State::UNCERTAIN && state == rhs.state;
     }
+
+    /// The reference node's stream operators (src/bgkoctomap/bgkoctree_node.cpp:46-62; unused by its own nodes): the binary
+    /// pair writes m_A, m_B as 8 raw bytes and reads them back THROUGH the (A, B) constructor — which adds the priors again,
+    /// as the reference does —; the text form is "(m_A m_B prob)".
+    friend std::ofstream &operator<<(std::ofstream &os, const Occupancy &oc);
+    friend std::ifstream &operator>>(std::ifstream &is, Occupancy &oc);
+    friend std::ostream &operator<<(std::ostream &os, const Occupancy &oc);
 
     bool classified;
 
