@@ -77,3 +77,14 @@ def test_a_rank_local_failure_ends_the_insert_on_every_rank(built, tmp_path, wor
             assert "injected rank-local front-end failure" in msg, (rank, msg)
         else:
             assert f"rank {failing} failed in its front end" in msg, (rank, msg)
+
+
+def test_allgather_callback_on_rccl_single_rank(built):
+    """The transport the driver's multi-GPU runs use is torch.distributed's nccl backend (RCCL); the box these tests run on
+    has one GPU, so the sharded tests above exchange over gloo.  This runs the production form of the callback
+    (la3dm_amd.sharding.torch_allgather, not staged through the host) on a ONE-rank nccl group: backend setup, device
+    pointer wrapping, ExternalStream ordering and both collective forms execute on RCCL and leave the buffer intact."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_single_rank.py")],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rccl single-rank ok: nccl" in r.stdout
