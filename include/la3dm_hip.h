@@ -230,7 +230,7 @@ int la3dm_diag_eval(la3dm_ctx *ctx, int op, const float *in, uint32_t n, float *
  * 3  sin/cos (f64 kernels rounded to f32) vs the f64 library functions rounded to f32,
  * 7  +-x / ell by the context's reciprocal + correction vs the IEEE division (always equal when the context fell back
  *    to the division), 8  k(sqrt(x)) > 0 with the context's sf2 (the FIFO kernel's hit threshold 0x3f77c08d claims: none
- *    in [0x3f77c08d, 0x3f7fffff]). */
+ *    in [0x3f77c08d, 0x3f7fffff]),  10  the GP kernels' exp(x) for x in [-87, -0] vs the f64 library exp rounded to f32. */
 int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 
 /* Test hook for the property the GP kernels' matrix-core paths rely on: D = A B (A 32 x K row-major, B K x 32

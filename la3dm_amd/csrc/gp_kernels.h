@@ -666,6 +666,18 @@ __device__ __forceinline__ float exp_cr_dev(float xf) {
     return (float)__longlong_as_double(bits);
 }
 
+// exhaustive check of exp_cr_dev against the double-precision library function rounded to float (what the restatement's
+// cr_expf computes), over the fp32 bit patterns [lo_bits, hi_bits] (la3dm_diag_sweep, what = 10)
+__global__ void gp_exp_sweep_kernel(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatch) {
+    const uint64_t n = (uint64_t)hi_bits - lo_bits + 1;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo_bits + (uint32_t)i);
+        bad += exp_cr_dev(x) == (float)exp((double)x) ? 0 : 1;
+    }
+    if (bad) atomicAdd(mismatch, bad);
+}
+
 // The distance's square root is sqrt_cr (bgk_kernels.h: hardware estimate + one residual fix-up, 6 instructions, equal to
 // sqrtf on {0} U [2^-100, 2^100] — swept) instead of the compiler's IEEE sequence with its denormal pre-scaling (~12, and a
 // branch around it measured +8 % on the depth-3 kernel).  Outside that range it may be off: d^2 > 2^100 does not occur, and a

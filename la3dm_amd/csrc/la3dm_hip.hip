@@ -931,8 +931,11 @@ int la3dm_diag_sweep(la3dm_ctx *ctx, int what, uint32_t lo_bits, uint32_t hi_bit
     if (rc != LA3DM_OK) return rc;
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->h_diag_out.ptr, 0, 8, st));
-    hipLaunchKernelGGL(sweep_check_kernel, dim3(4096), dim3(256), 0, st, what, lo_bits, hi_bits,
-                       (unsigned long long *)ctx->h_diag_out.ptr, ctx->p.ell, ctx->inv_ell, ctx->p.sf2);
+    if (what == 10)
+        hipLaunchKernelGGL(gp_exp_sweep_kernel, dim3(4096), dim3(256), 0, st, lo_bits, hi_bits, (unsigned long long *)ctx->h_diag_out.ptr);
+    else
+        hipLaunchKernelGGL(sweep_check_kernel, dim3(4096), dim3(256), 0, st, what, lo_bits, hi_bits,
+                           (unsigned long long *)ctx->h_diag_out.ptr, ctx->p.ell, ctx->inv_ell, ctx->p.sf2);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long v = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->h_diag_out.ptr, 8, hipMemcpyDeviceToHost, st));

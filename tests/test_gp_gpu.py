@@ -134,3 +134,12 @@ def test_against_the_eigen_order_restatement(built, depth, nscan, share, bound, 
     d = np.abs(pa - pb)
     assert d.max() <= bound, float(d.max())
     assert (d <= 1e-5).mean() >= share, float((d <= 1e-5).mean())
+
+
+def test_exp_of_the_gp_kernels_is_the_restatement_s_for_every_argument(built):
+    """The Matern kernel's exp(-d) on the device (gp_kernels.h exp_cr_dev: f64 reduction by ln 2, degree-13 polynomial, one
+    rounding to f32) against (float)exp((double)x) — what the restatement's cr_expf computes — for EVERY fp32 x in
+    [-87, -0]: 1.1e9 arguments, 0 differences."""
+    import la3dm_amd
+    m = la3dm_amd.GPOctoMap(**la3dm_amd.GP_YAML, device=0)
+    assert m.diag_sweep(10, -0.0, -87.0) == 0
