@@ -235,6 +235,16 @@ def main():
         dt_o, k_o = timed(min(args.steps, 20))
         other = {"bgk_sum": 1 - sum_mode, "ms_per_step": dt_o / min(args.steps, 20) * 1e3, "kernel_ms": k_o}
     m.set_option("bgk_sum", sum_mode)
+    # the same launch without LA3DM_SCAN_FULL_BLOCKS (what a scan into a map with pruned blocks runs: the instance that
+    # carries the general path beside the table path) — its own short run, quoted next to the headline
+    general = None
+    if world == 1 and sum_mode == 1 and not args.no_other_mode and (scans[0].flags & 4):
+        for sc in scans:
+            sc.flags &= ~4
+        _, k_g = timed(min(args.steps, 20))
+        for sc in scans:
+            sc.flags |= 4
+        general = {"kernel_ms": k_g, "what": "the same scan without LA3DM_SCAN_FULL_BLOCKS: the kernel instance with the general (pruned-block) path compiled in"}
     dt, k_ms = timed(args.steps)
 
     total_U = U
@@ -272,7 +282,7 @@ def main():
                        "accumulate": ACC_NAMES[sum_mode], "bgk_sum": sum_mode, "waves_per_wg": args.waves, "remap": args.remap},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": KERNEL_NAMES[sum_mode], "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
+                         "kernel": kernel_name(m, sum_mode, scans[0].flags, pk), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
                          "pair_evals_per_s": int(st["pair_evals"]) / (k_ms * 1e-3)},
             "host": {"prepare_s": t_prepare, "frontend_s": st["t_frontend"], "partition_s": st["t_partition"],
                      "pack_s": st["t_pack"]},
@@ -280,8 +290,11 @@ def main():
         if other:
             ach_o = b_alg / (other["kernel_ms"] * 1e-3) / 1e9
             out["roofline"]["ordered" if other["bgk_sum"] == 0 else "double_sum"] = dict(
-                other, accumulate=ACC_NAMES[other["bgk_sum"]], kernel=KERNEL_NAMES[other["bgk_sum"]], achieved=ach_o,
+                other, accumulate=ACC_NAMES[other["bgk_sum"]], kernel=kernel_name(m, other["bgk_sum"], scans[0].flags, pk), achieved=ach_o,
                 frac=ach_o / 8000.0, voxel_updates_per_s=U / (other["ms_per_step"] * 1e-3))
+        if general:
+            ach_g = b_alg / (general["kernel_ms"] * 1e-3) / 1e9
+            out["roofline"]["general_instance"] = dict(general, kernel=kernel_name(m, sum_mode, scans[0].flags & ~4, pk), achieved=ach_g, frac=ach_g / 8000.0)
         if counters:
             # Instruction-issue roofline (the kernel is issue bound, not HBM bound).  Peaks are MEASURED on this chip
             # (profiles/r02/valu_issue.txt, tools/ubench/valu_issue.hip): a SIMD issues one instruction of any kind per
@@ -334,7 +347,18 @@ def main():
 
 ACC_NAMES = {0: "the reference's fp32 summation order (bit-identical to the CPU restatement)",
              1: "double accumulators per leaf, alpha / beta rounded once (library default; |dp| <= ~4e-7 from the reference order)"}
-KERNEL_NAMES = {0: "bgk_predict_fuse_v5", 1: "bgk_predict_fuse_t"}
+
+
+def kernel_name(m, sum_mode, flags, pk):
+    """the predict + fuse kernel la3dm_bgk_scan_device launches for these options and scan flags (la3dm_hip.hip), with its
+    template arguments <fast_trig, general path compiled in>"""
+    if sum_mode == 0:
+        return "bgk_predict_fuse_v5"
+    trig = m.get_option("fast_trig")
+    if not (m.get_option("bgk_tables") and (flags & 2)):
+        return f"bgk_predict_fuse_r<{trig}>"
+    full = bool(flags & 4) and int(pk.n_leaf) == int(pk.n_test_blk) * 8 ** (int(m.block_depth) - 1)
+    return f"bgk_predict_fuse_{'p' if m.get_option('bgk_p') else 't'}<{trig}, {'false' if full else 'true'}>"
 
 
 def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest):
@@ -431,15 +455,50 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
     dist.destroy_process_group()
 
 
+def kernel_source_files(sources=("bgk_kernels.h",)):
+    """the files a kernel is built from: the named sources of la3dm_amd/csrc plus everything they #include "locally",
+    transitively (bgk_kernels.h -> sincos_table.inc; gp_kernels.h / lv_kernels.h -> bgk_kernels.h -> ...), in a fixed order"""
+    import re
+    base = os.path.join(ROOT, "la3dm_amd", "csrc")
+    seen, order, todo = set(), [], list(sources)
+    while todo:
+        f = todo.pop(0)
+        if f in seen:
+            continue
+        seen.add(f)
+        order.append(f)
+        with open(os.path.join(base, f), "r", errors="replace") as fh:
+            incs = re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M)
+        todo.extend(i for i in incs if os.path.exists(os.path.join(base, i)))
+    return order
+
+
 def kernel_source_hash(sources=("bgk_kernels.h",)):
-    """sha256 of the file(s) a kernel is built from (the launch side is covered by the waves-per-launch check in
-    profiled_counters): PMC numbers quoted from profiles/ are only valid for this kernel"""
+    """sha256 over kernel_source_files(sources) (the launch side is covered by the waves-per-launch check in
+    profiled_counters): PMC numbers quoted from profiles/ are only valid for this kernel.
+    tests/test_profiles_stamps_cpu.py fails while any entry of profiles/*.json carries another hash."""
     import hashlib
     h = hashlib.sha256()
-    for f in sources:
+    for f in kernel_source_files(sources):
         with open(os.path.join(ROOT, "la3dm_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0")
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+# which sources each stamped counter file's entries are recorded against (bench legs, tools/prof/*.sh and
+# tests/test_profiles_stamps_cpu.py all read this table)
+STAMPED = {
+    "bgk_traffic.json": {None: ("bgk_kernels.h",)},
+    "gp_counters.json": {None: ("gp_kernels.h",)},
+    "side_counters.json": {"lv50k": ("lv_kernels.h", "devmap_lv_kernels.h"), "lvseq": ("lv_kernels.h", "devmap_lv_kernels.h"),
+                           "l": ("bgkl_kernels.h",)},
+}
+
+
+def stamped_sources(path, key):
+    t = STAMPED[path]
+    return t.get(key, t.get(None))
 
 
 def profiled_counters(key, tiles=None, path="bgk_traffic.json", sources=("bgk_kernels.h",)):

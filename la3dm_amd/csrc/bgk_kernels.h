@@ -46,6 +46,7 @@ struct BgkArgs {
     const uint2 *nbr_range;     // [n_test_blk * 7] {first point, count} of each neighbour model (resolved by the prescale launch)
     const uint32_t *blk_desc;   // [n_test_blk * 16] flat view of the 7 neighbour ranges for bgk_predict_fuse_r (see bgk_prepare)
     const uint32_t *label_seq;  // == seq when this scan has a label other than 0 / 1 (written by bgk_prepare)
+    const uint32_t *tile_rec;   // [n_tasks * 32] per-tile record of bgk_predict_fuse_p (see bgk_prepare / TileRec)
     uint32_t seq;               // number of this scan
     uint32_t n_test_blk;
     uint32_t tpb_shift;         // log2(tiles per test block)
@@ -243,6 +244,69 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
     return k;
 }
 
+// ---------------------------------------------------------------------------
+// Per-tile record of bgk_predict_fuse_p (round 5): everything a leaf tile's prologue needs, in ONE 128-byte scalar read —
+//   words  0-6   adj[b]: first point of neighbour b minus the flat index where b starts (bgk_prepare's blk_desc words 0-6)
+//   word   7     M: points in the 7 neighbour blocks (blk_desc word 14)
+//   words  8-13  flat index where neighbour b = 0 .. 5 ends (blk_desc words 8-13)
+//   word   14    index of the tile's first leaf in the leaf arrays (leaf_off[blk] + 64 * tile)
+//   word   15    leaves of the tile's block (leaf_off[blk + 1] - leaf_off[blk]): 8^(depth-1) <=> nothing pruned
+//   words 16-27  the four leaf-centre coordinates per axis of an un-pruned block's aligned 4x4x4 tile, over ell:
+//                X[r], Y[r], Z[r], r = 2 * (parent-level bit) + (leaf-level bit) — (LUT[key] + centre) / ell exactly as the
+//                leaf lanes of bgk_predict_fuse_t compute it (Block::get_loc bgkblock.h:64-66, x / ell bgkinference.h:114);
+//                the kernel no longer reads the LUT or the block centre, and twelve v_readlane are gone
+//   words 28-31  block index, 0, 0, 0
+// One thread per tile.
+// ---------------------------------------------------------------------------
+struct BgkTileRecArgs {
+    uint32_t *rec = nullptr;          // [n_tasks * 32]
+    const float4 *lut = nullptr;
+    const float *blk_center = nullptr;
+    const uint32_t *leaf_off = nullptr;
+    uint32_t n_tasks = 0, tpb_shift = 0, depth = 0;
+    float ell = 1.0f, inv_ell = 0.0f;
+};
+__device__ __forceinline__ void bgk_write_tile_rec(const BgkTileRecArgs &tr, const int32_t *__restrict__ nbr,
+                                                   const uint32_t *__restrict__ train_off, uint32_t i) {
+    if (i >= tr.n_tasks) return;
+    const uint32_t blk = i >> tr.tpb_shift, tile = i & ((1u << tr.tpb_shift) - 1u);
+    uint32_t d[32];
+    uint32_t pre = 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        const int tb = nbr[7 * blk + b];
+        uint32_t first = 0, cnt = 0;
+        if (tb >= 0) {
+            first = train_off[tb];
+            cnt = train_off[tb + 1] - first;
+        }
+        d[b] = first - pre;
+        pre += cnt;
+        if (b < 6) d[8 + b] = pre;
+    }
+    d[7] = pre;
+    const uint32_t l0 = tr.leaf_off[blk];
+    d[14] = l0 + tile * (uint32_t)kWave;
+    d[15] = tr.leaf_off[blk + 1] - l0;
+    // finest-level index of the tile's leaf c (c = 0 .. 63 in the cube's own numbering): the tile covers list positions
+    // 64 tile .. 64 tile + 63 of the descending LeafIterator order, position j <-> index n_fine - 1 - j
+    const uint32_t n_fine = 1u << (3u * (tr.depth - 1u));
+    const uint32_t base = lut_layer_base(tr.depth - 1u) + (n_fine - (tile + 1u) * (uint32_t)kWave);
+    const float cx = tr.blk_center[3 * blk + 0], cy = tr.blk_center[3 * blk + 1], cz = tr.blk_center[3 * blk + 2];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+        const uint32_t hi = r >> 1, lo = r & 1u;
+        d[16 + r] = __float_as_uint(div_by_ell(tr.lut[base + ((hi << 5) | (lo << 2))].x + cx, tr.ell, tr.inv_ell));
+        d[20 + r] = __float_as_uint(div_by_ell(tr.lut[base + ((hi << 4) | (lo << 1))].y + cy, tr.ell, tr.inv_ell));
+        d[24 + r] = __float_as_uint(div_by_ell(tr.lut[base + ((hi << 3) | lo)].z + cz, tr.ell, tr.inv_ell));
+    }
+    d[28] = blk;
+    d[29] = d[30] = d[31] = 0;
+    uint4 *o = (uint4 *)(tr.rec + 32 * (size_t)i);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+}
+
 // Same launch shape, second job: resolve nbr[t][b] -> {train_off[nb], count} once per scan, so that
 // the predict kernel's prologue needs one dependent memory round trip less per tile.
 // Third job (blk_desc != nullptr): the same seven ranges of a test block as ONE flat index space [0, M) — the
@@ -253,8 +317,9 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
 __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell,
                             const int32_t *__restrict__ nbr, const uint32_t *__restrict__ train_off,
                             uint2 *__restrict__ nbr_range, uint32_t n_nbr, uint32_t *__restrict__ blk_desc,
-                            uint32_t *__restrict__ label_seq, uint32_t seq) {
+                            uint32_t *__restrict__ label_seq, uint32_t seq, BgkTileRecArgs tr = BgkTileRecArgs()) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tr.rec) bgk_write_tile_rec(tr, nbr, train_off, i);
     if (blk_desc && i < n_nbr / 7u) {
         uint32_t d[16];
         uint32_t pre = 0, trained = 0;
@@ -1492,6 +1557,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         }
     }
 }
+
+}  // namespace la3dm_dev
+#include "bgk_predict_p.h"
+namespace la3dm_dev {
 
 // exhaustive sweeps of the kernel's shortcuts against the IEEE operations:
 // counts fp32 inputs in [lo_bits, hi_bits] (as unsigned bit patterns) where they differ.

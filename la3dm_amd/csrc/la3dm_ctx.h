@@ -26,6 +26,8 @@ struct la3dm_ctx {
                            // (bgk_predict_fuse_v5, bit-identical to the CPU restatement); env LA3DM_BGK_SUM sets the default
     int opt_bgk_tables = 1;  // bgk_sum = 1 only: 1 (default) = bgk_predict_fuse_t (per-axis distance tables for aligned 4x4x4 tiles, the
                              // other tiles through the general path in the same launch), 0 = bgk_predict_fuse_r for every tile
+    int opt_bgk_p = 1;       // bgk_sum = 1 with tables: 1 (default) = bgk_predict_fuse_p (one-read prologue from bgk_prepare's tile records, sin / cos
+                             // table in LDS), 0 = bgk_predict_fuse_t (round 4); env LA3DM_BGK_P
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
     int opt_time_kernel = 0;
@@ -38,7 +40,7 @@ struct la3dm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
-    Arena pts_scaled, nbr_range, blk_desc, label_seq;
+    Arena pts_scaled, nbr_range, blk_desc, label_seq, tile_rec;
     uint32_t scan_seq = 0;  // la3dm_bgk_scan_device calls so far (BgkArgs::seq)
     Arena gp_loff, gp_totals, gp_order, gp_L, gp_alpha, gp_v;
     Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask;

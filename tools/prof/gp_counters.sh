@@ -1,9 +1,10 @@
 #!/bin/bash
 # Instruction counts of the GP predict + fuse launches per step, for the kernel source of THIS build, stamped:
 #   profiles/gp_counters.json  (what bench.py's gp legs quote as roofline.valu_issue)
-# usage (GPU box): bash tools/prof/gp_counters.sh  ->  gpurun_out/r03/gp_counters/gp_counters.json, copy into profiles/
+# usage (GPU box): bash tools/prof/gp_counters.sh  ->  gpurun_out/$ROUND/gp_counters/gp_counters.json, copy into profiles/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/gp_counters; rm -rf $OUT; mkdir -p $OUT
+ROUND=${ROUND:-r05}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$ROUND/gp_counters; rm -rf $OUT; mkdir -p $OUT
 for D in 3 4; do
   timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_MFMA -d $OUT/d$D -o p -- \
     python bench.py --workload gp --depth $D --steps 1 --warmup 1 --no-cpu > $OUT/log$D.txt 2>&1 < /dev/null
@@ -24,7 +25,7 @@ for D in (3, 4):
             disp[row["Kernel_Name"][:40]].add(row["Dispatch_Id"])
     steps = 2.0   # --steps 1 --warmup 1
     out["gp_rays50000_d%d" % D] = {
-        "kernel": "gp_predict_fuse_small_kernel (size classes) + gp_predict_fuse_kernel, summed per step", "round": 3,
+        "kernel": "gp_predict_fuse_small_kernel (size classes) + gp_predict_fuse_kernel, summed per step", "round": int("$ROUND"[1:]),
         "kernel_sha": bench.kernel_source_hash(("gp_kernels.h",)),
         "source": "profiles/gp_counters.json (tools/prof/gp_counters.sh: rocprofv3 --pmc, one pass)",
         "dispatches_per_step": {k: len(v) / steps for k, v in disp.items()},

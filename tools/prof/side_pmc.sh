@@ -1,11 +1,12 @@
 #!/bin/bash
 # PMC counters of the BGK-LV and BGK-L inserts per kernel (separate rocprofv3 --pmc passes, no trace domains beside them),
 # stamped with the hashes of the kernel sources:
-#   gpurun_out/r04/side/side_counters.json  -> copy to profiles/side_counters.json (bench.py's lv / bgkl legs quote its traffic)
-#   gpurun_out/r04/side/side_pmc_<leg>.txt  -> profiles/r04/
+#   gpurun_out/$ROUND/side/side_counters.json  -> copy to profiles/side_counters.json (bench.py's lv / bgkl legs quote its traffic)
+#   gpurun_out/$ROUND/side/side_pmc_<leg>.txt  -> profiles/$ROUND/
 # usage (GPU box): bash tools/prof/side_pmc.sh
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04/side; rm -rf $OUT; mkdir -p $OUT
+ROUND=${ROUND:-r05}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$ROUND/side; rm -rf $OUT; mkdir -p $OUT
 N=3
 for LEG in lv50k lvseq l; do
   i=0
@@ -44,9 +45,9 @@ for leg, srcs in (("lv50k", ("lv_kernels.h", "devmap_lv_kernels.h")), ("lvseq", 
         for c, v in e.items():
             tot[c] += v
     fetch, write = tot.get("FETCH_SIZE", 0.0), tot.get("WRITE_SIZE", 0.0)
-    out[leg] = {"round": 4, "kernel_sha": bench.kernel_source_hash(srcs), "sources": list(srcs),
+    out[leg] = {"round": int("$ROUND"[1:]), "kernel_sha": bench.kernel_source_hash(srcs), "sources": list(srcs),
                 "unit": "per insert_pointcloud" if leg != "lvseq" else "per 12-scan sequence",
-                "source": "profiles/r04/side_pmc_%s.txt (tools/prof/side_pmc.sh: separate rocprofv3 --pmc passes)" % leg,
+                "source": "profiles/$ROUND/side_pmc_%s.txt (tools/prof/side_pmc.sh: separate rocprofv3 --pmc passes)" % leg,
                 "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                 # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): x2
                 "hbm_bytes": (2 * fetch + write) * 1024, "raw_bytes": (fetch + write) * 1024,

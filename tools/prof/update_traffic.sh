@@ -1,12 +1,13 @@
 #!/bin/bash
 # Regenerates the profiled numbers bench.py quotes, for the kernel source of THIS build, in both accumulate modes:
-#   profiles/r04/bench_kernel_stats_sum{0,1}.csv  rocprofv3 --kernel-trace --stats of the bench's timed region
-#   profiles/r04/bench_pmc_summary.txt            counters per launch (separate --pmc passes, as the guide prescribes)
-#   profiles/r04/phase_table.txt                  VALU / SALU / LDS instructions per tile by phase (ablate option)
+#   profiles/$ROUND/bench_kernel_stats_sum{0,1}.csv  rocprofv3 --kernel-trace --stats of the bench's timed region
+#   profiles/$ROUND/bench_pmc_summary.txt            counters per launch (separate --pmc passes, as the guide prescribes)
+#   profiles/$ROUND/phase_table.txt                  VALU / SALU / LDS instructions per tile by phase (ablate option)
 #   profiles/bgk_traffic.json                     per-launch HBM traffic + instruction counts, stamped with the kernel source hash
-# usage (GPU box): bash tools/prof/update_traffic.sh      ->  results under gpurun_out/r04/prof/, copy into profiles/
+# usage (GPU box): bash tools/prof/update_traffic.sh      ->  results under gpurun_out/$ROUND/prof/, copy into profiles/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04/prof; rm -rf $OUT; mkdir -p $OUT
+ROUND=${ROUND:-r05}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$ROUND/prof; rm -rf $OUT; mkdir -p $OUT
 for SUM in 1 0; do
   BENCH="python bench.py --steps 20 --warmup 3 --no-cpu --no-e2e --no-big --no-side --no-other-mode --sum $SUM"
   rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace$SUM -o t -- $BENCH > $OUT/bench_trace$SUM.log 2>&1
@@ -52,8 +53,8 @@ with open(out + "/bench_pmc_summary.txt", "w") as fo, open(out + "/phase_table.t
             mean = lambda c: sum(fuse[c]) / len(fuse[c]) if fuse.get(c) else None
             fetch_kb, write_kb = mean("FETCH_SIZE"), mean("WRITE_SIZE")
             entries[f"rays200000_d3_r0.1_sum{S}"] = {
-                "kernel": name, "round": 4, "kernel_sha": bench.kernel_source_hash(),
-                "source": "profiles/r04/bench_pmc_summary.txt (tools/prof/update_traffic.sh)",
+                "kernel": name, "round": int("$ROUND"[1:]), "kernel_sha": bench.kernel_source_hash(),
+                "source": "profiles/$ROUND/bench_pmc_summary.txt (tools/prof/update_traffic.sh)",
                 "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                 "raw_bytes_per_launch": (fetch_kb + write_kb) * 1024 if fetch_kb and write_kb else None,
                 # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): x2
