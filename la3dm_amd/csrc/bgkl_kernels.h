@@ -81,6 +81,7 @@ struct BgklSplit {
     float2 *part;                 // [split tiles * 7 * 64] (ybar, kbar) of one neighbour
     float4 *dense;                // [items * kLItemRows / 4 * 64] k of rows 4g .. 4g + 3 for lane = leaf, +0 where out of reach (bgkl_split_expand)
     unsigned long long *labmask;  // [items * kLBatches] bit r: row r of the batch has label 1
+    double2 *part64;              // [items * 64] {sum k * label, sum k} of one item in double (order-free mode, bgkl_split_sum)
     uint32_t threshold;
 };
 
@@ -606,6 +607,228 @@ __global__ __launch_bounds__(kWave) void bgkl_split_apply(BgklArgs a, BgklSplit 
     for (uint32_t b = 0; b < 7; ++b) {
         if (a.nbr[7 * blk + b] < 0) continue;
         const float2 yk = s.part[((size_t)h * 7u + b) * kWave + lane];
+        if (yk.y > 0.001f) {  // bgkloctomap.cpp:226-227
+            A += yk.x;
+            B += yk.y - yk.x;
+            updated = true;
+        }
+    }
+    bgkl_store(a, li, active, updated, A, B);
+}
+
+// ---------------------------------------------------------------------------
+// Order-free accumulate mode (round 5; la3dm_set_option "bgk_sum" 1, the default — what round 3 did for BGKOctoMap).
+// The reference's ybar = Ks * y and kbar = Ks.rowwise().sum() (bgklinference.h:86-87) are fp32 chains in row order, and the
+// only reason for the split path's scratch replay above (bgkl_split_eval -> kernelize -> expand -> add: 11x the algorithmic
+// bytes, profiles/r04/side_pmc_l.txt) is to reproduce that order across the waves that share a tile's rows.  Here every
+// (row, leaf) pair adds the SAME fp32 k and k * label to DOUBLE sums; a neighbour's two sums are rounded to fp32 once — the
+// correctly rounded values of what the fp32 chains approximate, whatever the order (a double sum of 10^5 fp32 terms is
+// exact to ~2^-36 of an fp32 ulp) — and the per-neighbour gate kbar > 0.001f and the fp32 update in ExtendedBlock order
+// (bgkloctomap.cpp:226-231) stay exactly as they are.  Checked against the restatement's own double-sum mode
+// (oracle.set_sum_mode(1)): <= 1 ulp on alpha / beta, tests/test_bgkl_sum_gpu.py.
+//   bgkl_predict_fuse_f64<kW>  the row-serial kernel with double sums in registers (lane = leaf: no atomics); kW = 8: every
+//                              wave sums its own rows, the eight partial sums are added in wave order at the neighbour's end
+//   bgkl_split_sum             one wave per 256-row item of a split tile: its two double sums per leaf -> part64
+//   bgkl_split_apply64         one workgroup per split tile, wave = neighbour: the items' partial sums added in item order
+//                              (deterministic), rounded, then the gated update in ExtendedBlock order
+// The order-free split path needs 1 KB of scratch per item (the ordered one: 64 KB + 64 KB + 4 KB) and three launches.
+// ---------------------------------------------------------------------------
+// The throughput form (many tiles; the items of split tiles): one wave per tile or item, lane = leaf.  Rows are staged 64
+// at a time through LDS (one coalesced read per lane instead of three wave-uniform loads per row, each waited for), the
+// distance test runs on every lane, and — the sums being order-free — the hit (row, leaf) pairs are COMPACTED into a ring
+// {d2, label, leaf} and evaluated densely, lane = pair: sqrt, d / ell, sin / cos and the formula at full lane utilisation
+// instead of once per row that has any hit (68 % of the rows of a light tile, ~10 lanes each); k and k * label go to the
+// leaf's double accumulators by ds_add_f64 (bgk_kernels.h bgk_predict_fuse_r: a native LDS atomic, 32 cycles).  Neighbours
+// are taken one after the other — the gate is per neighbour —, the ring is drained at a neighbour's end.
+constexpr int kLRing = 192;
+struct __attribute__((aligned(16))) WaveLdsL {
+    float4 rows[3][kWave];      // staged rows, one array per float4 of the row
+    double acc_k[kWave];        // sum k of the current neighbour
+    double acc_y[kWave];        // sum k * label
+    uint32_t ring[kLRing][3];   // {d2, label, leaf}
+};
+
+// the rows [r0, r1) into the leaf's two double sums (left in L.acc_k / L.acc_y of lane = leaf; zeroed here)
+__device__ __forceinline__ void bgkl_rows_sum(const BgklArgs &a, WaveLdsL &L, const int lane, const bool active, const float px,
+                                              const float py, const float pz, const uint32_t r0, const uint32_t r1) {
+    L.acc_k[lane] = 0.0;
+    L.acc_y[lane] = 0.0;
+    uint32_t tail = 0;
+    auto c_eval = [&](uint32_t i) {
+        const float d2 = __uint_as_float(L.ring[i][0]), lab = __uint_as_float(L.ring[i][1]);
+        const uint32_t leaf = L.ring[i][2];
+        const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+        const float ky = kv * lab;
+        const uint32_t ak = (uint32_t)(uintptr_t)&L.acc_k[leaf], ay = (uint32_t)(uintptr_t)&L.acc_y[leaf];
+        asm volatile("ds_add_f64 %0, %1\n" : : "v"(ak), "v"((double)kv) : "memory");
+        if (ky != 0.0f) asm volatile("ds_add_f64 %0, %1\n" : : "v"(ay), "v"((double)ky) : "memory");   // (+-0 adds nothing; NaN != 0)
+    };
+    for (uint32_t q = r0; q < r1; q += kWave) {
+        const uint32_t nr = min(r1 - q, (uint32_t)kWave);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < nr) {
+            const size_t row = (size_t)q + lane;
+            L.rows[0][lane] = a.rowx[3 * row];
+            L.rows[1][lane] = a.rowx[3 * row + 1];
+            L.rows[2][lane] = a.rowx[3 * row + 2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = 0; j < nr; ++j) {
+            const float4 q0 = L.rows[0][j], q1 = L.rows[1][j], q2 = L.rows[2][j];
+            const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
+            const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            if (hit) {
+                const uint32_t slot = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                L.ring[slot][0] = __float_as_uint(d2);
+                L.ring[slot][1] = __float_as_uint(q1.z);
+                L.ring[slot][2] = (uint32_t)lane;
+            }
+            tail += (uint32_t)__popcll(m);
+            if (tail > (uint32_t)(kLRing - kWave)) {
+                // the full batches from the ring's end (the sums are order-free): the remainder stays at the front
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rem = tail & 63u;
+                for (uint32_t p = rem; p < tail; p += kWave) c_eval(p + lane);
+                tail = rem;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t p = 0; p < tail; p += kWave)
+        if (p + lane < tail) c_eval(p + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int kW>
+__global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_f64(BgklArgs a, const uint32_t *__restrict__ task_item) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t task = blockIdx.x;
+    if (task >= a.n_tasks) return;
+    if (task_item && task_item[2 * task] != 0xFFFFFFFFu) return;  // split tile
+    uint32_t blk, li;
+    bool active;
+    float px, py, pz;
+    if (!bgkl_leaf(a, task, lane, blk, li, active, px, py, pz)) return;
+    float A = a.alpha[li], B = a.beta[li];
+    bool updated = false;
+    constexpr size_t kPartB = sizeof(double) * (size_t)kW * 2 * kWave;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kW > 1 ? kPartB : sizeof(WaveLdsL)];
+    double(*s_part)[2][kWave] = reinterpret_cast<double(*)[2][kWave]>(s_raw);   // kW > 1
+    WaveLdsL &s_L = *reinterpret_cast<WaveLdsL *>(s_raw);                        // kW == 1
+
+    for (int b = 0; b < 7; ++b) {
+        const int32_t tb = a.nbr[7 * blk + b];
+        if (tb < 0) continue;
+        const uint32_t r0 = __builtin_amdgcn_readfirstlane(a.row_off[tb]), r1 = __builtin_amdgcn_readfirstlane(a.row_off[tb + 1]);
+        double ysum = 0.0, ksum = 0.0;
+        if constexpr (kW == 1) {
+            if (r0 == r1) continue;   // (an empty model adds nothing and fails the gate)
+            bgkl_rows_sum(a, s_L, lane, active, px, py, pz, r0, r1);
+            ysum = s_L.acc_y[lane];
+            ksum = s_L.acc_k[lane];
+        } else {
+            // the latency form (few tiles, the GPU mostly empty): wave w takes rows w, w + kW, ... straight into its own
+            // sums; the partial sums are added in wave order
+            for (uint32_t j = r0 + (uint32_t)wave; j < r1; j += (uint32_t)kW) {
+                const float4 q0 = a.rowx[3 * (size_t)j], q1 = a.rowx[3 * (size_t)j + 1], q2 = a.rowx[3 * (size_t)j + 2];
+                const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
+                const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
+                if (__ballot(hit) == 0ull) continue;
+                if (hit) {
+                    const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+                    ysum += (double)(kv * q1.z);
+                    ksum += (double)kv;
+                }
+            }
+            s_part[wave][0][lane] = ysum;
+            s_part[wave][1][lane] = ksum;
+            __syncthreads();
+            if (wave == 0) {
+                ysum = s_part[0][0][lane];
+                ksum = s_part[0][1][lane];
+#pragma unroll
+                for (int w = 1; w < kW; ++w) {
+                    ysum += s_part[w][0][lane];
+                    ksum += s_part[w][1][lane];
+                }
+            }
+            __syncthreads();
+        }
+        const float ybar = (float)ysum, kbar = (float)ksum;
+        if (kbar > 0.001f) {  // bgkloctomap.cpp:226-227 (only wave 0 holds the sums)
+            A += ybar;
+            B += kbar - ybar;
+            updated = true;
+        }
+    }
+    if (wave == 0) bgkl_store(a, li, active, updated, A, B);
+}
+
+// one wave per item of a split tile (tile x neighbour x <= kLItemRows rows), lane = leaf
+__global__ __launch_bounds__(kWave) void bgkl_split_sum(BgklArgs a, BgklSplit s) {
+    __shared__ WaveLdsL L;
+    const int lane = threadIdx.x;
+    const uint32_t it = blockIdx.x;
+    const uint4 dsc = s.item_desc[it];
+    uint32_t blk, li;
+    bool active;
+    float px, py, pz;
+    if (!bgkl_leaf(a, dsc.x, lane, blk, li, active, px, py, pz)) return;  // (split tiles always hold leaves)
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(dsc.z), r1 = __builtin_amdgcn_readfirstlane(dsc.w);
+    bgkl_rows_sum(a, L, lane, active, px, py, pz, r0, r1);
+    s.part64[(size_t)it * kWave + lane] = make_double2(L.acc_y[lane], L.acc_k[lane]);
+}
+
+__global__ __launch_bounds__(7 * kWave) void bgkl_split_apply64(BgklArgs a, BgklSplit s) {
+    __shared__ float2 s_yk[7][kWave];
+    const int lane = threadIdx.x & 63;
+    const uint32_t b = threadIdx.x >> 6;
+    const uint32_t h = blockIdx.x;
+    const uint32_t task = s.split_list[h];
+    {
+        const uint32_t it0 = s.nb_first[8 * h + b], it1 = s.nb_first[8 * h + b + 1];
+        double ysum = 0.0, ksum = 0.0;
+        const double2 *p = s.part64 + (size_t)it0 * kWave + lane;
+        uint32_t it = it0;
+        for (; it + 8u <= it1; it += 8u) {   // eight 512-byte rows in flight
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)u * kWave];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ysum += v[u].x;
+                ksum += v[u].y;
+            }
+            p += 8 * kWave;
+        }
+        for (; it < it1; ++it) {
+            const double2 v = *p;
+            ysum += v.x;
+            ksum += v.y;
+            p += kWave;
+        }
+        s_yk[b][lane] = make_float2((float)ysum, (float)ksum);
+    }
+    __syncthreads();
+    if (b != 0u) return;
+    uint32_t blk, li;
+    bool active;
+    float px, py, pz;
+    if (!bgkl_leaf(a, task, lane, blk, li, active, px, py, pz)) return;
+    float A = a.alpha[li], B = a.beta[li];
+    bool updated = false;
+    for (uint32_t q = 0; q < 7; ++q) {
+        if (a.nbr[7 * blk + q] < 0) continue;
+        const float2 yk = s_yk[q][lane];
         if (yk.y > 0.001f) {  // bgkloctomap.cpp:226-227
             A += yk.x;
             B += yk.y - yk.x;

@@ -43,7 +43,7 @@ struct la3dm_ctx {
     Arena pts_scaled, nbr_range, blk_desc, label_seq, tile_rec;
     uint32_t scan_seq = 0;  // la3dm_bgk_scan_device calls so far (BgkArgs::seq)
     Arena gp_loff, gp_totals, gp_order, gp_L, gp_alpha, gp_v;
-    Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask;
+    Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask, l_part64;
     Arena lv_samples, lv_sorted, lv_rays, lv_cell, lv_center, lv_cell0, lv_alpha, lv_beta, lv_state;
     Arena lvp_sub_task, lvp_task, lvp_totals, lvp_rows, lvp_sub_out, lvp_cand;  // BGK-LV work plan + row scratch of split cubes
     // staging (host-pointer path)

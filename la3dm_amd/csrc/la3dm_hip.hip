@@ -90,11 +90,13 @@ static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[4], h
     const uint32_t n_heavy = totals[0], n_rows = totals[1], n_split = totals[2], n_subs = totals[0] + totals[3];
     if (n_subs == 0) return LA3DM_OK;
     int rc;
-    if ((rc = arena_reserve(ctx, ctx->lvp_rows, 256ull * (n_rows ? n_rows : 1))) != LA3DM_OK) return rc;
+    // scratch of the split cubes: ordered mode = one 256-byte row per staged candidate; order-free mode = 1 KB per workgroup
+    const bool lv_f64 = ctx->opt_bgk_sum == 1;
+    if ((rc = arena_reserve(ctx, ctx->lvp_rows, lv_f64 ? sizeof(double2) * kWave * (size_t)(n_heavy ? n_heavy : 1) : 256ull * (n_rows ? n_rows : 1))) != LA3DM_OK) return rc;
     constexpr size_t kWords = kLvChunk / kWave;
-    (void)n_heavy;
     if ((rc = arena_reserve(ctx, ctx->lvp_sub_out, 8ull * (2 * kWords + 1) * n_subs)) != LA3DM_OK) return rc;
     a.rows = (float *)ctx->lvp_rows.ptr;
+    a.sub_part = (double2 *)ctx->lvp_rows.ptr;
     a.sub_info = (unsigned long long *)ctx->lvp_sub_out.ptr;
     a.sub_nz = a.sub_info + n_subs;
     a.sub_y = a.sub_nz + kWords * n_subs;
@@ -109,8 +111,14 @@ static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[4], h
         ev = &ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(ctx, hipEventRecord(ev->first, stream));
     }
-    hipLaunchKernelGGL(bgklv_voxel_kernel, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
-    if (n_split) hipLaunchKernelGGL(bgklv_split_add_kernel, dim3(n_split), dim3(kLvWaves * kWave), 0, stream, a);
+    if (ctx->opt_bgk_sum == 1) {
+        // order-free accumulate mode (the default): double sums per voxel, a split cube's workgroups leave 1 KB of partial sums
+        hipLaunchKernelGGL(bgklv_voxel_kernel<true>, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
+        if (n_split) hipLaunchKernelGGL(bgklv_split_apply64, dim3(n_split), dim3(kWave), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(bgklv_voxel_kernel<false>, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
+        if (n_split) hipLaunchKernelGGL(bgklv_split_add_kernel, dim3(n_split), dim3(kLvWaves * kWave), 0, stream, a);
+    }
     if (ev) HIP_TRY(ctx, hipEventRecord(ev->second, stream));
     HIP_TRY(ctx, hipGetLastError());
     return LA3DM_OK;
@@ -253,7 +261,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
-    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask,
+    Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask, &ctx->l_part64,
                     &ctx->pts_scaled, &ctx->nbr_range, &ctx->blk_desc, &ctx->label_seq, &ctx->tile_rec, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
@@ -827,7 +835,16 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     // few tiles (a scan of a few thousand points): latency counts, eight waves per tile; many tiles: the launch is
     // throughput-bound and one wave per tile is the cheaper form (measured: 764 tiles 2.5 -> 0.8 ms with eight
     // waves, 41 694 tiles 2.9 -> 5.6 ms)
-    if (a.n_tasks <= kLWideTiles)
+    // accumulate mode ("bgk_sum", as for BGKOctoMap): 1 (default) = double sums, each neighbour's two sums rounded once —
+    // no order to keep, so the split tiles need no scratch replay; 0 = the reference's fp32 running sums in row order
+    const bool sum_f64 = ctx->opt_bgk_sum == 1;
+    if (sum_f64) {
+        if (a.n_tasks <= kLWideTiles)
+            hipLaunchKernelGGL(bgkl_predict_fuse_f64<kLWaves>, dim3(a.n_tasks), dim3(kLWaves * kWave), 0, stream, a,
+                               (const uint32_t *)sp.task_item);
+        else
+            hipLaunchKernelGGL(bgkl_predict_fuse_f64<1>, dim3(a.n_tasks), dim3(kWave), 0, stream, a, (const uint32_t *)sp.task_item);
+    } else if (a.n_tasks <= kLWideTiles)
         hipLaunchKernelGGL(bgkl_predict_fuse_kernel<kLWaves>, dim3(a.n_tasks), dim3(kLWaves * kWave), 0, stream, a,
                            (const uint32_t *)sp.task_item);
     else
@@ -839,7 +856,22 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         HIP_TRY(ctx, hipStreamSynchronize(stream));
     }
     const uint32_t n_items = head[0], n_split = head[1];
-    if (n_items) {
+    size_t split_scratch = 0;
+    if (n_items && sum_f64) {
+        // order-free: per item two double sums per leaf (1 KB), added per (tile, neighbour) in item order
+        if ((rc = arena_reserve(ctx, ctx->l_item_desc, sizeof(uint4) * (size_t)n_items)) != LA3DM_OK) return rc;
+        if ((rc = arena_reserve(ctx, ctx->l_nb_first, sizeof(uint32_t) * 8 * (size_t)n_split)) != LA3DM_OK) return rc;
+        if ((rc = arena_reserve(ctx, ctx->l_part64, sizeof(double2) * kWave * (size_t)n_items)) != LA3DM_OK) return rc;
+        sp.item_desc = (uint4 *)ctx->l_item_desc.ptr;
+        sp.nb_first = (uint32_t *)ctx->l_nb_first.ptr;
+        sp.part64 = (double2 *)ctx->l_part64.ptr;
+        hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_sum, dim3(n_items), dim3(kWave), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_apply64, dim3(n_split), dim3(7 * kWave), 0, stream, a, sp);
+        HIP_TRY(ctx, hipGetLastError());
+        split_scratch = sizeof(double2) * kWave * (size_t)n_items;
+    } else if (n_items) {
+        split_scratch = sizeof(uint4) * (size_t)n_items * kLItemRows + sizeof(float) * (size_t)n_items * kLItemVals;
         if ((rc = arena_reserve(ctx, ctx->l_item_desc, sizeof(uint4) * (size_t)n_items)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_rowrec, sizeof(uint4) * (size_t)n_items * kLItemRows)) != LA3DM_OK) return rc;
         if ((rc = arena_reserve(ctx, ctx->l_batch_off, sizeof(uint32_t) * (size_t)n_items * kLBatches)) != LA3DM_OK) return rc;
@@ -884,8 +916,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     }
     if (out) {
         out->n_tiles = a.n_tasks;
-        out->scratch_bytes = sizeof(uint4) * (size_t)n_items * kLItemRows + sizeof(float) * (size_t)n_items * kLItemVals +
-                             sizeof(float4) * 3 * (size_t)s->n_train_pts;
+        out->scratch_bytes = split_scratch + sizeof(float4) * 3 * (size_t)s->n_train_pts;
     }
     return LA3DM_OK;
 }

@@ -64,6 +64,7 @@ struct LvArgs {
     unsigned long long *sub_nz; // per workgroup: kLvChunk bits, row slot written
     unsigned long long *sub_y;  // per workgroup: kLvChunk bits, the row's sample is a hit (y = 1)
     unsigned long long *sub_info;   // per workgroup: voxels that saw a sample in their box
+    double2 *sub_part;          // order-free mode: per workgroup of a split cube, {sum k y, sum k} of its part of the stream per voxel
 };
 
 // LV state code <-> the host enum stored in the pool (State::PRUNED = 3, State::UNCERTAIN = 4; la3dm_lv_scan uses the
@@ -176,19 +177,25 @@ constexpr int kLvWaves = 8;
 constexpr uint32_t kLvChunk = 512;
 constexpr uint32_t kLvGroup = 64;   // buckets whose ranges are resident in LDS at a time
 
-struct LvLds {
+// kF64 (order-free accumulate mode, round 5): no [candidate][voxel] tile, no row maps — the E phase adds straight into the
+// voxels' double accumulators
+template <bool kF64>
+struct LvLdsT {
     LvCand cand[kLvWaves * kWave];
-    float k[kWave][kWave];
+    float k[kF64 ? 1 : kWave][kWave];
     unsigned long long y_round[2];               // rows of the current round that are hits with a counted voxel (by round parity)
     unsigned long long cmask[kWave];             // per candidate of the round: the voxels that count it
-    unsigned long long nz_map[kLvChunk / kWave];  // split cube: the same per staged candidate of the sub-task
-    unsigned long long y_map[kLvChunk / kWave];
+    unsigned long long nz_map[kF64 ? 1 : kLvChunk / kWave];  // split cube: the same per staged candidate of the sub-task
+    unsigned long long y_map[kF64 ? 1 : kLvChunk / kWave];
     uint32_t cnt[kLvWaves];
     unsigned long long info[kLvWaves];
     float ybar[kWave];
     uint32_t g_c0[kLvGroup];
     uint32_t g_incl[kLvGroup];
+    double acc_k[kF64 ? kWave : 1];              // order-free mode: sum k per voxel ...
+    double acc_y[kF64 ? kWave : 1];              // ... and sum k y (the hit rows: y = 1)
 };
+typedef LvLdsT<false> LvLds;
 
 struct LvTask {
     uint32_t blk, cube, node;
@@ -440,8 +447,15 @@ __device__ __forceinline__ void lv_commit(const LvArgs &a, const LvTask &t, floa
     if ((threadIdx.x & 63) == 0 && um) atomicAdd(a.upd_counter, (uint32_t)__popcll(um));
 }
 
+// kF64 = the order-free accumulate mode ("bgk_sum" 1, the default since round 5): the reference's two fp32 running sums in
+// gather order (bgklvinference.h:80-83) become double sums of the same fp32 kv and kv * y, rounded to fp32 once per voxel
+// (the restatement's set_sum_mode(1)); the gate kbar > 0.001f and the LV node update are unchanged.  Nothing is ordered any
+// more, so the E phase's lanes add their k straight into the voxel's accumulators (ds_add_f64, a native LDS atomic), the
+// [candidate][voxel] tile, its zeroing and the A phase disappear, and a split cube's workgroups hand 1 KB of partial sums
+// to bgklv_split_apply64 instead of their rows to bgklv_split_add_kernel (3.2x the algorithmic bytes in round 4).
+template <bool kF64>
 __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void bgklv_voxel_kernel(LvArgs a) {
-    __shared__ LvLds L;
+    __shared__ LvLdsT<kF64> L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t task = blockIdx.x, sub = 0, nsub = 1;
     if (a.sub_task) {
@@ -473,7 +487,11 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
     const float clx = wave_max_dpp(active ? lox : -inf), cly = wave_max_dpp(active ? loy : -inf), clz = wave_max_dpp(active ? loz : -inf);
     const float chx = wave_min_dpp(active ? hix : inf), chy = wave_min_dpp(active ? hiy : inf), chz = wave_min_dpp(active ? hiz : inf);
     if (threadIdx.x < 2) L.y_round[threadIdx.x] = 0ull;
-    if (threadIdx.x < kLvChunk / kWave) L.nz_map[threadIdx.x] = L.y_map[threadIdx.x] = 0ull;
+    if constexpr (kF64) {
+        if (threadIdx.x < kWave) L.acc_k[threadIdx.x] = L.acc_y[threadIdx.x] = 0.0;
+    } else {
+        if (threadIdx.x < kLvChunk / kWave) L.nz_map[threadIdx.x] = L.y_map[threadIdx.x] = 0ull;
+    }
     __syncthreads();  // every wave has read the cube's states before wave 0 may rewrite them
     if (!(tlx <= thx)) {  // no base-resolution leaf in this cube (uniform over the workgroup)
         if (wave == 0 && t.in_range && !t.pool) a.state[t.ni] = 0;
@@ -576,10 +594,12 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
                         info |= inb;
                         cm = __ballot(count);
                     }
-                    if (j < nr16) L.k[j][lane] = 0.0f;
+                    if constexpr (!kF64) {
+                        if (j < nr16) L.k[j][lane] = 0.0f;
+                    }
                     if (lane == 0) {
                         L.cmask[j] = cm;
-                        if (cm != 0ull && type == 0 && !split) atomicOr(&L.y_round[rnd & 1u], 1ull << j);
+                        if (!kF64 && cm != 0ull && type == 0 && !split) atomicOr(&L.y_round[rnd & 1u], 1ull << j);
                     }
                 }
                 __syncthreads();
@@ -614,11 +634,20 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
                                 qx = q0.x; qy = q0.y; qz = q0.z;
                                 if (!(ty & 4)) lv_seg_point(vx, vy, vz, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lx, q0.w, q1.w, qx, qy, qz);
                             }
-                            L.k[jc][vox] = lv_kernel_at(vx, vy, vz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
+                            const float kv = lv_kernel_at(vx, vy, vz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
+                            if constexpr (kF64) {
+                                const uint32_t ak = (uint32_t)(uintptr_t)&L.acc_k[vox], ay = (uint32_t)(uintptr_t)&L.acc_y[vox];
+                                asm volatile("ds_add_f64 %0, %1\n" : : "v"(ak), "v"((double)kv) : "memory");
+                                // kv * y: y = 1 for a hit, 0 for a ray's row (adds +-0: nothing)
+                                if (ty == 0) asm volatile("ds_add_f64 %0, %1\n" : : "v"(ay), "v"((double)kv) : "memory");
+                            } else {
+                                L.k[jc][vox] = kv;
+                            }
                         }
                     }
                 }
                 __syncthreads();
+                if constexpr (kF64) continue;   // (the barrier above also separates this round's reads of cmask / cand from the next T)
                 // ---- A
                 if (!split) {
                     if (wave == 0) kbar = lv_add_dense(L.k, nr16, lane, kbar);
@@ -653,6 +682,16 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
     unsigned long long all = 0;
 #pragma unroll
     for (int v = 0; v < kLvWaves; ++v) all |= L.info[v];
+    if constexpr (kF64) {
+        const double ys = L.acc_y[lane], ks = L.acc_k[lane];
+        if (split) {
+            a.sub_part[(size_t)blockIdx.x * kWave + lane] = make_double2(ys, ks);
+            if (lane == 0) a.sub_info[blockIdx.x] = all;
+            return;
+        }
+        lv_commit(a, t, (float)ys, (float)ks, (all >> lane) & 1ull);
+        return;
+    }
     if (split) {
         constexpr uint32_t kWords = kLvChunk / kWave;
         if (lane < (int)kWords) {
@@ -663,6 +702,24 @@ __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu
         return;
     }
     lv_commit(a, t, L.ybar[lane], kbar, (all >> lane) & 1ull);
+}
+
+// order-free mode: the partial sums of a split cube's workgroups, added in sub-task order, rounded once, committed
+__global__ __launch_bounds__(kWave) void bgklv_split_apply64(LvArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t task = a.split_list[blockIdx.x];
+    const LvTask t = lv_task(a, task, lane);
+    if (t.pool && a.blk_mult[t.blk] <= a.pass) return;
+    const uint32_t first = a.task_first[task], nsub = a.task_nsub[task];
+    double ys = 0.0, ks = 0.0;
+    unsigned long long info = 0;
+    for (uint32_t s = 0; s < nsub; ++s) {
+        info |= a.sub_info[first + s];
+        const double2 v = a.sub_part[(size_t)(first + s) * kWave + lane];
+        ys += v.x;
+        ks += v.y;
+    }
+    lv_commit(a, t, (float)ys, (float)ks, (info >> lane) & 1ull);
 }
 
 // The rows of a split cube, added in stream order: sub-task after sub-task, row after row (rows of zeros were not

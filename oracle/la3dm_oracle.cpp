@@ -291,7 +291,8 @@ extern "C" void orc_set_modes(int trig, int grid_sort) {
     g_orc_trig_mode = trig;
     g_orc_grid_sort_mode = grid_sort;
 }
-// Summation switch of the BGK update loop (variant 0), the counterpart of the device's order-free accumulate mode
+// Summation switch of the BGK update loop (variant 0; since round 5 also BGKLOctoMap, see bgkl_predict, and BGKLVOctoMap,
+// la3dm_oracle_lv.cpp), the counterpart of the device's order-free accumulate mode
 // (la3dm_set_option "bgk_sum" 1, bgk_kernels.h bgk_predict_fuse_r):
 //   0  the reference: fp32 running sums per neighbour in training-point order (bgkinference.h:76-78), one
 //      Occupancy::update per neighbour with kbar > 0 (bgkoctomap.cpp:314-335) — default, what every parity test uses;
@@ -974,6 +975,23 @@ void bgkl_predict(float sf2, float ell, const float *xs, int M, const Seg *rows,
                   float *kbar) {
     for (int i = 0; i < M; ++i) {
         const V3 q{xs[3 * i], xs[3 * i + 1], xs[3 * i + 2]};
+        if (g_orc_sum_mode == 1) {
+            // sum mode 1 (orc_set_sum_mode; the device's "bgk_sum" 1 for BGKLOctoMap): the same fp32 k and k * y of every row,
+            // summed in DOUBLE, each of the neighbour's two sums rounded to fp32 once — the correctly rounded value of what the
+            // fp32 chains below approximate, whatever the order of the rows.  The per-neighbour gate kbar > 0.001f
+            // (bgkloctomap.cpp:226-227) and the fp32 update per neighbour stay as they are.
+            double dy = 0.0, dk = 0.0;
+            for (int j = 0; j < N; ++j) {
+                const float r = seg_dist_l(q, rows[j].a, rows[j].b) / ell;
+                const float k = cov_sparse_elem(r, sf2);
+                const float ky = k * y[j];
+                dy += (double)ky;
+                dk += (double)k;
+            }
+            ybar[i] = (float)dy;
+            kbar[i] = (float)dk;
+            continue;
+        }
         float sy = 0.0f, sk = 0.0f;
         for (int j = 0; j < N; ++j) {
             const float r = seg_dist_l(q, rows[j].a, rows[j].b) / ell;  // Kxz /= ell

@@ -31,7 +31,7 @@
 #include <unordered_map>
 #include <vector>
 
-extern int g_orc_trig_mode, g_orc_grid_sort_mode;   // la3dm_oracle.cpp: the sensitivity switches (orc_set_modes)
+extern int g_orc_trig_mode, g_orc_grid_sort_mode, g_orc_sum_mode;   // la3dm_oracle.cpp: the sensitivity switches (orc_set_modes)
 namespace orc_eigen337 {
 float psin(float x);
 float pcos(float x);
@@ -458,6 +458,10 @@ void insert_lv(Map &m, const std::vector<V3> &cloud, V3 origin, float ds_resolut
                     }
             if (cand.empty()) continue;  // :168-175
             // one row per hit, one row per ray at its lowest-index sample in the box (:176-205)
+            // sum mode 1 (orc_set_sum_mode, la3dm_oracle.cpp): the same fp32 kv and kv * y, summed in double and rounded to
+            // fp32 once per voxel — the value the fp32 chains approximate, whatever the order of the rows
+            const bool sum64 = g_orc_sum_mode == 1;
+            double dybar = 0.0, dkbar = 0.0;
             float ybar = 0.0f, kbar = 0.0f;
             for (int i : cand) {
                 const int ray = T.ray_idx[i];
@@ -473,9 +477,19 @@ void insert_lv(Map &m, const std::vector<V3> &cloud, V3 origin, float ds_resolut
                     kv = cov_sparse_line(seg_dist(c, T.ray0[ray], T.ray1[ray]), p.ell, p.sf2);
                     y = 0.0f;
                 }
-                ybar += kv * y;
-                kbar += kv;
+                if (sum64) {
+                    const float ky = kv * y;
+                    dybar += (double)ky;
+                    dkbar += (double)kv;
+                } else {
+                    ybar += kv * y;
+                    kbar += kv;
+                }
                 n_rows += 1;
+            }
+            if (sum64) {
+                ybar = (float)dybar;
+                kbar = (float)dkbar;
             }
             Node &node = block->layer[d][idx];
             if (kbar > 0.001f) {  // :236-238
