@@ -284,6 +284,38 @@ __global__ void bgkl_split_items(BgklArgs a, BgklSplit s) {
     s.nb_first[8 * h + 7] = it;
 }
 
+// the item descriptors of the split tiles, one workgroup of seven waves per split tile (wave = neighbour slot, lanes stride
+// over the neighbour's items): bgkl_split_items above walks every tile with one thread — the sensor block's thread writes
+// thousands of descriptors one after the other (82 us of a 200 k-ray insert)
+__global__ __launch_bounds__(7 * kWave) void bgkl_split_items_wide(BgklArgs a, BgklSplit s) {
+    const uint32_t h = blockIdx.x, b = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t task = s.split_list[h];
+    const uint32_t blk = task >> a.tpb_shift;
+    uint32_t it = s.task_item[2 * task];
+    uint32_t r0 = 0, r1 = 0;
+    for (uint32_t q = 0; q <= b; ++q) {   // items of the slots before mine
+        const int32_t tb = a.nbr[7 * blk + q];
+        const uint32_t c = tb < 0 ? 0u : a.row_off[tb + 1] - a.row_off[tb];
+        if (q == b) {
+            if (tb >= 0) {
+                r0 = a.row_off[tb];
+                r1 = a.row_off[tb + 1];
+            }
+        } else {
+            it += (c + kLItemRows - 1) / kLItemRows;
+        }
+    }
+    const uint32_t n = (r1 - r0 + kLItemRows - 1) / kLItemRows;
+    if (lane == 0) {
+        s.nb_first[8 * h + b] = it;
+        if (b == 6u) s.nb_first[8 * h + 7] = it + n;
+    }
+    for (uint32_t i = lane; i < n; i += kWave) {
+        const uint32_t r = r0 + i * kLItemRows;
+        s.item_desc[it + i] = make_uint4(task, b, r, min(r + (uint32_t)kLItemRows, r1));
+    }
+}
+
 // One wave per item (tile x neighbour x <= kLItemRows rows), lane = leaf: the distance test of every row, the hit masks
 // and labels as row records, and the hit lanes' squared distances in (row, lane) order in the item's own value slots.
 __global__ __launch_bounds__(kWave) void bgkl_split_eval(BgklArgs a, BgklSplit s) {

@@ -113,7 +113,8 @@ static int lv_run_planned(la3dm_ctx *ctx, LvArgs &a, const uint32_t totals[4], h
     }
     if (ctx->opt_bgk_sum == 1) {
         // order-free accumulate mode (the default): double sums per voxel, a split cube's workgroups leave 1 KB of partial sums
-        hipLaunchKernelGGL(bgklv_voxel_kernel<true>, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
+        // (without the 16 KB tile four workgroups fit a CU: the 8-waves-per-SIMD build, 0.755 -> 0.661 ms on the 50 k-ray scan)
+        hipLaunchKernelGGL(bgklv_voxel_kernel_w8, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
         if (n_split) hipLaunchKernelGGL(bgklv_split_apply64, dim3(n_split), dim3(kWave), 0, stream, a);
     } else {
         hipLaunchKernelGGL(bgklv_voxel_kernel<false>, dim3(n_subs), dim3(kLvWaves * kWave), 0, stream, a);
@@ -230,6 +231,7 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
     if (const char *ev = getenv("LA3DM_BGK_TABLES")) {  // bgk_sum = 1: 0 = bgk_predict_fuse_r for every tile
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_tables = ev[0] - '0';
     }
+    if (const char *ev = getenv("LA3DM_BGKL_SPLIT_ROWS")) ctx->opt_l_split_rows = atoi(ev);   // default of "bgkl_split_rows"
     if (const char *ev = getenv("LA3DM_BGK_P")) {  // bgk_sum = 1 with tables: 1 = bgk_predict_fuse_p, 0 = bgk_predict_fuse_t
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_p = ev[0] - '0';
     }
@@ -865,7 +867,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         sp.item_desc = (uint4 *)ctx->l_item_desc.ptr;
         sp.nb_first = (uint32_t *)ctx->l_nb_first.ptr;
         sp.part64 = (double2 *)ctx->l_part64.ptr;
-        hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_items_wide, dim3(n_split), dim3(7 * kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_sum, dim3(n_items), dim3(kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_apply64, dim3(n_split), dim3(7 * kWave), 0, stream, a, sp);
         HIP_TRY(ctx, hipGetLastError());
@@ -896,7 +898,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         }
         if ((rc = arena_reserve(ctx, ctx->l_vals, vals_bytes)) != LA3DM_OK) return rc;
         sp.vals = (float *)ctx->l_vals.ptr;
-        hipLaunchKernelGGL(bgkl_split_items, dim3((a.n_tasks + 255) / 256), dim3(256), 0, stream, a, sp);
+        hipLaunchKernelGGL(bgkl_split_items_wide, dim3(n_split), dim3(7 * kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_eval, dim3(n_items), dim3(kWave), 0, stream, a, sp);
         hipLaunchKernelGGL(bgkl_split_bdesc, dim3((n_items * kLBatches + 255) / 256), dim3(256), 0, stream, sp, n_items);
         hipLaunchKernelGGL(bgkl_split_kernelize, dim3(n_items), dim3(256), 0, stream, a, sp);

@@ -454,8 +454,19 @@ __device__ __forceinline__ void lv_commit(const LvArgs &a, const LvTask &t, floa
 // [candidate][voxel] tile, its zeroing and the A phase disappear, and a split cube's workgroups hand 1 KB of partial sums
 // to bgklv_split_apply64 instead of their rows to bgklv_split_add_kernel (3.2x the algorithmic bytes in round 4).
 template <bool kF64>
+__device__ __forceinline__ void bgklv_voxel_body(const LvArgs &a, LvLdsT<kF64> &L);
+template <bool kF64>
 __global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void bgklv_voxel_kernel(LvArgs a) {
     __shared__ LvLdsT<kF64> L;
+    bgklv_voxel_body<kF64>(a, L);
+}
+// the order-free form without the 16 KB tile: four workgroups fit a CU's LDS, at 8 waves per SIMD (64 VGPRs)
+__global__ __launch_bounds__(kLvWaves *kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgklv_voxel_kernel_w8(LvArgs a) {
+    __shared__ LvLdsT<true> L;
+    bgklv_voxel_body<true>(a, L);
+}
+template <bool kF64>
+__device__ __forceinline__ void bgklv_voxel_body(const LvArgs &a, LvLdsT<kF64> &L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t task = blockIdx.x, sub = 0, nsub = 1;
     if (a.sub_task) {
