@@ -198,6 +198,49 @@ __device__ __forceinline__ void sincos_cr_finite(float t, float &s, float &c) {
 // (the table across the wave's lanes by ds_bpermute_b32 was measured slower: 24.5 cycles per SIMD per crossbar
 // instruction, four per batch, against one L1 gather)
 
+// ---------------------------------------------------------------------------
+// fast_trig 3 — the LIKELY REFERENCE trig: Eigen 3.3.7's psin / pcos<Packet4f> (arch/SSE/MathFunctions.h,
+// the Cephes sinf / cosf: reduction by pi / 4 in three Cody-Waite steps, two degree-3 / degree-2-in-z polynomials), one
+// lane, with every multiply-add as a rounded multiply followed by a rounded add (an x86-64 baseline build has no FMA) —
+// what la3dm's `cos(...)` / `sin(...)` array expressions (bgkinference.h:115-116) most plausibly execute in a ROS Noetic
+// build.  The same operations in the same order as the restatement's orc_eigen337::psin / pcos (oracle/la3dm_oracle.cpp,
+// oracle.set_modes(1, 0)): bit-identical results (tests/test_bgk_gpu.py).  Outside the parity contract of the default
+// (fast_trig 0 = correctly rounded): it exists so that a user who holds the real reference can compare against it.  The
+// hit threshold kHitTBits stays valid: with this trig the kernel is exactly 0 for every d2 >= 0x3f779dec < kHitTBits (swept
+// over every fp32 d2 of [0.9, 1.5) with the restatement's arithmetic).  This translation unit is built with
+// -ffp-contract=off: `a * b + c` below is two instructions.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_eigen337(float t, float &s, float &c) {
+    const uint32_t sign_in = __float_as_uint(t) & 0x80000000u;
+    float x = __builtin_fabsf(t);
+    float y = x * 1.27323954473516f;          // cephes_FOPI = 4 / pi
+    int32_t j = (int32_t)y;                   // _mm_cvttps_epi32
+    j = (j + 1) & ~1;
+    y = (float)j;
+    x = x + y * -0.78515625f;
+    x = x + y * -2.4187564849853515625e-4f;
+    x = x + y * -3.77489497744594108e-8f;
+    const float z = x * x;
+    float pc = 2.443315711809948E-005f;        // the cosine polynomial
+    pc = pc * z + -1.388731625493765E-003f;
+    pc = pc * z + 4.166664568298827E-002f;
+    pc = pc * z;
+    pc = pc * z;
+    pc = pc - z * 0.5f;
+    pc = pc + 1.0f;
+    float ps = -1.9515295891E-4f;              // the sine polynomial
+    ps = ps * z + 8.3321608736E-3f;
+    ps = ps * z + -1.6666654611E-1f;
+    ps = ps * z;
+    ps = ps * x;
+    ps = ps + x;
+    const bool use_sin = (j & 2) == 0;         // psin: the sine polynomial; pcos (j - 2): the other one
+    const uint32_t sign_s = sign_in ^ (((uint32_t)(j & 4)) << 29);
+    const uint32_t sign_c = ((uint32_t)(~(j - 2) & 4)) << 29;
+    s = __uint_as_float(__float_as_uint(use_sin ? ps : pc) ^ sign_s);
+    c = __uint_as_float(__float_as_uint(use_sin ? pc : ps) ^ sign_c);
+}
+
 // correctly rounded x / d for a compile-time constant d (|x| far from the subnormal range):
 // q = RN(x * (1/d)); one Newton correction with the exact residual.
 __device__ __forceinline__ float div_const(float x, float d, float inv_d) {
@@ -223,7 +266,7 @@ __device__ __forceinline__ float div_by_ell(float x, float ell, float inv_ell) {
 }
 
 // trig flavours: 0 = correctly rounded (default, parity), 1 = f32 polynomial (<= 1.5 ulp),
-// 2 = OCML sinf/cosf
+// 2 = OCML sinf/cosf, 3 = Eigen 3.3.7's psin / pcos without FMA (the likely reference build, sincos_eigen337)
 // covSparse elementwise, bgkinference.h:115-125.  r = distance of ell-scaled coords.
 template <bool kClamp, int kTrig>
 __device__ __forceinline__ float cov_sparse(float r, float sf2) {
@@ -233,6 +276,8 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
         sincos_cr(t, s, c);
     } else if (kTrig == 1) {
         sincos_0_2pi(t, s, c);
+    } else if (kTrig == 3) {
+        sincos_eigen337(t, s, c);
     } else {
         s = sinf(t);
         c = cosf(t);
@@ -445,6 +490,7 @@ __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     if (kTrig == 0 && kFinite) sincos_cr_finite(t, s, c);
     else if (kTrig == 0) sincos_cr(t, s, c);
     else if (kTrig == 1) sincos_0_2pi(t, s, c);
+    else if (kTrig == 3) sincos_eigen337(t, s, c);
     else { s = sinf(t); c = cosf(t); }
     return cov_sparse_formula<kClamp>(r, s, c, sf2);
 }
@@ -1637,6 +1683,10 @@ __global__ void diag_eval_kernel(int op, const float *in, float *out, uint32_t n
     case 9: sincos_cr(x, s, c); y = s; break;
     case 10: sincos_cr(x, s, c); y = c; break;
     case 11: y = cov_sparse<true, 2>(x, sf2); break;
+    case 14: sincos_eigen337(x, s, c); y = s; break;
+    case 15: sincos_eigen337(x, s, c); y = c; break;
+    case 16: y = cov_sparse<true, 3>(x, sf2); break;
+    case 17: y = cov_sparse_fast<3, true>(x, sf2); break;
     default: y = 0.0f;
     }
     out[i] = y;

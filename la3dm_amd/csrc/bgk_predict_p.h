@@ -150,6 +150,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             sincos_cr_finite(t, s, c);
         } else if (kTrig == 1) {
             sincos_0_2pi(t, s, c);
+        } else if (kTrig == 3) {
+            sincos_eigen337(t, s, c);
         } else {
             s = sinf(t);
             c = cosf(t);

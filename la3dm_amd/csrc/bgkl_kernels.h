@@ -39,6 +39,7 @@ struct BgklArgs {
     float sf2, ell, free_thresh, occupied_thresh, var_thresh;
     float inv_ell;   // RN(1 / ell) or 0 (bgk_kernels.h div_by_ell)
     float hit_d2;    // the smallest fp32 t with sqrtf(t) >= ell: d >= ell <=> d^2 >= hit_d2 for d = sqrtf(d^2) (host, exact)
+    int trig;        // "fast_trig": 0 correctly rounded (default), 3 = Eigen 3.3.7 psin / pcos (bgk_kernels.h sincos_eigen337)
 };
 
 // Split path for the tiles around the sensor.  Every beam crosses the sensor's block, so a 200 k-ray scan hands a
@@ -90,8 +91,10 @@ struct BgklSplit {
 // dense formula yields NaN, the `< 0 -> 0` clean-up lets it through and it poisons ybar / kbar of every leaf that
 // meets the row (the kbar > 0.001 gate then rejects the update) — kept, with k = NaN.
 __device__ __forceinline__ bool bgkl_row_counts(float d2, float hit_d2) { return !(d2 >= hit_d2) || d2 == __builtin_inff(); }
-__device__ __forceinline__ float bgkl_row_kernel(float d, float ell, float inv_ell, float sf2) {
-    return (d - d == 0.0f) ? cov_sparse_fast<0, true>(div_by_ell(d, ell, inv_ell), sf2) : __builtin_nanf("");
+__device__ __forceinline__ float bgkl_row_kernel(float d, float ell, float inv_ell, float sf2, int trig = 0) {
+    if (!(d - d == 0.0f)) return __builtin_nanf("");
+    const float r = div_by_ell(d, ell, inv_ell);
+    return trig == 3 ? cov_sparse_fast<3, true>(r, sf2) : cov_sparse_fast<0, true>(r, sf2);   // (wave-uniform)
 }
 
 // What point_to_line_dist computes from the segment alone — its direction l = b - a, |l|^2 and the "shorter than 0.1 mm"
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
                 const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
                 if (__ballot(hit) == 0ull) continue;
                 if (hit) {
-                    const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+                    const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2, a.trig);
                     ybar += kv * q1.z;
                     kbar += kv;
                 }
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_kernel(BgklArgs a
                     const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
                     float kv = 0.0f, kyv = 0.0f;
                     if (active && bgkl_row_counts(d2, a.hit_d2)) {
-                        kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+                        kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2, a.trig);
                         kyv = kv * q1.z;
                     }
                     s_k[j][lane] = kv;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void bgkl_split_kernelize(BgklArgs a, BgklSpli
     const uint32_t it = blockIdx.x;
     const uint32_t n = s.item_hits[it];
     float *v = s.vals + (size_t)it * kLItemVals;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v[i] = bgkl_row_kernel(sqrtf(v[i]), a.ell, a.inv_ell, a.sf2);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) v[i] = bgkl_row_kernel(sqrtf(v[i]), a.ell, a.inv_ell, a.sf2, a.trig);
 }
 
 __global__ void bgkl_split_bdesc(BgklSplit s, uint32_t n_items) {
@@ -689,7 +692,7 @@ __device__ __forceinline__ void bgkl_rows_sum(const BgklArgs &a, WaveLdsL &L, co
     auto c_eval = [&](uint32_t i) {
         const float d2 = __uint_as_float(L.ring[i][0]), lab = __uint_as_float(L.ring[i][1]);
         const uint32_t leaf = L.ring[i][2];
-        const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+        const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2, a.trig);
         const float ky = kv * lab;
         const uint32_t ak = (uint32_t)(uintptr_t)&L.acc_k[leaf], ay = (uint32_t)(uintptr_t)&L.acc_y[leaf];
         asm volatile("ds_add_f64 %0, %1\n" : : "v"(ak), "v"((double)kv) : "memory");
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_f64(BgklArgs a, c
                 const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
                 if (__ballot(hit) == 0ull) continue;
                 if (hit) {
-                    const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2);
+                    const float kv = bgkl_row_kernel(sqrtf(d2), a.ell, a.inv_ell, a.sf2, a.trig);
                     ysum += (double)(kv * q1.z);
                     ksum += (double)kv;
                 }

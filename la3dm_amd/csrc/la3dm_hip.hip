@@ -46,6 +46,7 @@ static void lv_fill_args(la3dm_ctx *ctx, LvArgs &a, uint32_t n_blk) {
     a.occupied_thresh = ctx->p.occupied_thresh;
     a.var_thresh = ctx->p.var_thresh;
     a.min_W = ctx->p.min_W;
+    a.trig = ctx->opt_fast_trig == 3 ? 3 : 0;
 }
 
 // ---- BGK-LV work plan (lv_kernels.h bgklv_plan_kernel): which cube gets how many workgroups ----
@@ -299,8 +300,9 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_bgk_p = value;
         return LA3DM_OK;
     }
-    if (!strcmp(name, "fast_trig")) {
-        if (value < 0 || value > 2) return bad_value("0, 1 or 2");
+    if (!strcmp(name, "fast_trig")) {  // 0 correctly rounded (default, the parity configuration), 1 f32 polynomial, 2 OCML, 3 = Eigen 3.3.7's psin / pcos
+        // without FMA, the likely reference build (BGK, BGK-L and BGK-LV kernels; 1 and 2: the BGK kernels only)
+        if (value < 0 || value > 3) return bad_value("0, 1, 2 or 3");
         ctx->opt_fast_trig = value;
         return LA3DM_OK;
     }
@@ -476,6 +478,7 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     switch (ctx->opt_fast_trig) {                                                              \
     case 1: hipLaunchKernelGGL((KERNEL<1 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;     \
     case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;     \
+    case 3: hipLaunchKernelGGL((KERNEL<3 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;     \
     default: hipLaunchKernelGGL((KERNEL<0 __VA_ARGS__>), grid, block, (size_t)ctx->opt_lds_pad, stream, a); break;    \
     }
     if (sum_f64) {
@@ -802,6 +805,7 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
     a.sf2 = ctx->p.sf2;
     a.ell = ctx->p.ell;
     a.inv_ell = ctx->inv_ell;
+    a.trig = ctx->opt_fast_trig == 3 ? 3 : 0;
     a.free_thresh = ctx->p.free_thresh;
     a.occupied_thresh = ctx->p.occupied_thresh;
     a.var_thresh = ctx->p.var_thresh;

@@ -52,6 +52,7 @@ struct LvArgs {
     uint32_t *upd_counter;
     uint32_t npb, layer_off, pass;
     float inv_ell;              // RN(1 / ell) or 0 (bgk_kernels.h div_by_ell)
+    int trig;                   // "fast_trig": 0 correctly rounded (default), 3 = Eigen 3.3.7 psin / pcos (sincos_eigen337)
     struct LvCand *cand;        // [n_samples] in bucket order: everything the voxel kernel needs of a sample (bgklv_cand_kernel)
     uint32_t n_samples;
     // work plan (bgklv_plan_kernel): workgroup -> cube, and the row scratch of the cubes that are split over workgroups
@@ -130,12 +131,12 @@ __device__ __forceinline__ float seg_dist_f32(float px, float py, float pz, floa
 
 // covSparseLine at distance |p - q| (bgklvinference.h:143-156: r = min(d / ell, 1), no clamp of negative values)
 __device__ __forceinline__ float lv_kernel_at(float px, float py, float pz, float qx, float qy, float qz, float ell, float inv_ell,
-                                              float sf2) {
+                                              float sf2, int trig = 0) {
     const float dx = px - qx, dy = py - qy, dz = pz - qz;
     const float d = sqrtf(dx * dx + dy * dy + dz * dz);
     float r = div_by_ell(d, ell, inv_ell);
     if (r > 1.0f) r = 1.0f;
-    return cov_sparse_fast<0, false>(r, sf2);
+    return trig == 3 ? cov_sparse_fast<3, false>(r, sf2) : cov_sparse_fast<0, false>(r, sf2);   // (wave-uniform)
 }
 
 // src/bgklvoctomap/bgklvoctree_node.cpp:29-63
@@ -645,7 +646,7 @@ __device__ __forceinline__ void bgklv_voxel_body(const LvArgs &a, LvLdsT<kF64> &
                                 qx = q0.x; qy = q0.y; qz = q0.z;
                                 if (!(ty & 4)) lv_seg_point(vx, vy, vz, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lx, q0.w, q1.w, qx, qy, qz);
                             }
-                            const float kv = lv_kernel_at(vx, vy, vz, qx, qy, qz, a.ell, a.inv_ell, a.sf2);
+                            const float kv = lv_kernel_at(vx, vy, vz, qx, qy, qz, a.ell, a.inv_ell, a.sf2, a.trig);
                             if constexpr (kF64) {
                                 const uint32_t ak = (uint32_t)(uintptr_t)&L.acc_k[vox], ay = (uint32_t)(uintptr_t)&L.acc_y[vox];
                                 asm volatile("ds_add_f64 %0, %1\n" : : "v"(ak), "v"((double)kv) : "memory");

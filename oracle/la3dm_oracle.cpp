@@ -1354,6 +1354,10 @@ void orc_lut(void *h, int depth, int index, float *out3) {
     out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
 }
 
+// sin / cos of the active trig mode (orc_set_modes), array form: what = 0 sin, 1 cos
+void orc_trig_array(const float *t, int n, int what, float *out) {
+    for (int i = 0; i < n; ++i) out[i] = what ? cr_cosf(t[i]) : cr_sinf(t[i]);
+}
 float orc_kernel(float r, float sf2) { return cov_sparse_elem(r, sf2); }
 void orc_kernel_array(const float *r, int n, float sf2, float *out) {
     for (int i = 0; i < n; ++i) out[i] = cov_sparse_elem(r[i], sf2);

@@ -133,6 +133,7 @@ def _load(name):
     lib.orc_num_threads.restype = C.c_int
     lib.orc_set_modes.argtypes = [C.c_int, C.c_int]
     lib.orc_set_sum_mode.argtypes = [C.c_int]
+    lib.orc_trig_array.argtypes = [f32p, C.c_int, C.c_int, f32p]
     lib.orc_set_gp_mode.argtypes = [C.c_int]
     lib.orc_block_count.restype = C.c_int64
     lib.orc_block_count.argtypes = [C.c_void_p]

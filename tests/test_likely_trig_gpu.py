@@ -1,0 +1,126 @@
+"""fast_trig 3 — the likely-reference trig as a DEVICE option.  la3dm's kernel evaluates `cos(...)` /
+`sin(...)` Eigen array expressions (include/bgkoctomap/bgkinference.h:115-116; the same in bgklinference.h:190-191 and
+bgklvinference.h:153-154); in the build a ROS Noetic user most plausibly has (Eigen 3.3.7, SSE2, no FMA) those are the
+Cephes-style packet functions psin / pcos.  The restatement has them as oracle.set_modes(1, 0) (oracle/la3dm_oracle.cpp
+orc_eigen337); the device has the same operations in the same order as `la3dm_set_option("fast_trig", 3)` for the BGK, BGK-L
+and BGK-LV kernels (bgk_kernels.h sincos_eigen337).  Here: the primitives over a dense sweep of the argument range, the
+kernel function, and whole inserts of the three map classes — all BIT-identical to the restatement in that mode (ordered
+accumulate mode, as every bit-identity suite).  Whether the real reference matches this emulation cannot be checked here
+(Eigen / PCL absent: parity unpinned); the option exists so that somebody who holds the reference can."""
+import numpy as np
+import pytest
+
+from conftest import pcd_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eigen_trig():
+    from oracle import oracle as O
+    O.set_modes(1, 0)
+    O.set_modes(1, 0, omp=True)
+    yield O
+    O.set_modes(0, 0)
+    O.set_modes(0, 0, omp=True)
+
+
+def test_primitives_bit_identical(built, eigen_trig):
+    import la3dm_amd
+    O = eigen_trig
+    L = O.lib()
+    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+    # every fp32 t of [0, 2 pi] is 1.09e9 values: a dense sample (every 97th) plus the neighbourhoods of the octant boundaries
+    hi = np.float32(6.2831855).view(np.uint32)
+    bits = np.arange(0, int(hi), 97, dtype=np.uint32)
+    edges = np.concatenate([np.float32(k * np.pi / 4).view(np.uint32).astype(np.int64) + np.arange(-2000, 2000) for k in range(1, 9)])
+    t = np.unique(np.concatenate([bits, edges[(edges >= 0) & (edges <= int(hi))].astype(np.uint32)])).view(np.float32)
+    for what, op in ((0, 14), (1, 15)):
+        ref = np.zeros_like(t)
+        L.orc_trig_array(t, t.size, what, ref)
+        dev = m.diag_eval(op, t)
+        bad = dev.view(np.uint32) != ref.view(np.uint32)
+        assert not bad.any(), (what, int(bad.sum()), t[bad][:4], dev[bad][:4], ref[bad][:4])
+    # the kernel function k(r), clamp included, both device forms (IEEE divisions / reciprocal + correction)
+    r = np.unique(np.concatenate([np.linspace(0, 1.2, 2_000_001, dtype=np.float32),
+                                  np.sqrt(np.arange(np.float32(0.96).view(np.uint32), np.float32(1.0).view(np.uint32), 3, dtype=np.uint32).view(np.float32))]))
+    ref = np.zeros_like(r)
+    L.orc_kernel_array(r, r.size, np.float32(la3dm_amd.BGK_YAML["sf2"]), ref)
+    for op in (16, 17):
+        dev = m.diag_eval(op, r)
+        bad = dev.view(np.uint32) != ref.view(np.uint32)
+        assert not bad.any(), (op, int(bad.sum()), r[bad][:4], dev[bad][:4], ref[bad][:4])
+
+
+def _same(a, b, tag):
+    assert a["block_key"].size == b["block_key"].size, tag
+    for k in ("block_key", "node_key", "state", "classified"):
+        assert (a[k] == b[k]).all(), (tag, k, int((a[k] != b[k]).sum()))
+    for k in ("A", "B"):
+        d = a[k].view(np.uint32) != b[k].view(np.uint32)
+        assert not d.any(), (tag, k, int(d.sum()), float(np.abs(a[k] - b[k]).max()))
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_bgk_inserts_bit_identical(built, eigen_trig, depth):
+    """BGKOctoMap, three fused scans (pruned blocks from the second on): the ordered kernel (bgk_sum 0) bit for bit; the
+    default kernels (bgk_sum 1: bgk_predict_fuse_p / _r with the same trig) within one ulp of it"""
+    import la3dm_amd
+    O = eigen_trig
+    params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+    m = la3dm_amd.BGKOctoMap(**params, device=0)
+    m.set_option("bgk_sum", 0)
+    m.set_option("fast_trig", 3)
+    m1 = la3dm_amd.BGKOctoMap(**params, device=0)
+    m1.set_option("bgk_sum", 1)
+    m1.set_option("fast_trig", 3)
+    o = O.OracleMap(**params)
+    for i in (1, 2, 3):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        for x in (m, m1, o):
+            x.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        _same(m.leaves(), o.leaves(), f"bgk d{depth} scan{i}")
+        a, b = m1.leaves(), o.leaves()
+        assert (a["node_key"] == b["node_key"]).all()
+        pa, pb = a["A"] / (a["A"] + a["B"]), b["A"] / (b["A"] + b["B"])
+        assert np.abs(pa - pb).max() <= 1e-6, float(np.abs(pa - pb).max())   # (the two modes differ by the summation order only)
+    assert (m.leaves()["A"] != 0).any()
+
+
+def test_bgkl_insert_bit_identical(built, eigen_trig):
+    import la3dm_amd
+    O = eigen_trig
+    params = dict(la3dm_amd.L_YAML)
+    m = la3dm_amd.BGKLOctoMap(**params, device=0)
+    m.set_option("bgk_sum", 0)
+    m.set_option("fast_trig", 3)
+    m.set_option("bgkl_split_rows", 300)      # some tiles through the split path (bgkl_split_kernelize evaluates k there)
+    o = O.OracleLMap(**params)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        _same(m.leaves(), o.leaves(), f"bgkl scan{i}")
+
+
+def test_bgklv_insert_bit_identical(built, eigen_trig):
+    import la3dm_amd
+    O = eigen_trig
+    params = dict(la3dm_amd.LV_YAML, resolution=0.1, block_depth=4)
+    m = la3dm_amd.BGKLVOctoMap(**params, device=0)
+    m.set_option("bgk_sum", 0)
+    m.set_option("fast_trig", 3)
+    o = O.OracleLVMap(**params)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        _same(m.leaves(), o.leaves(), f"bgklv scan{i}")
+
+
+def test_default_trig_is_unchanged(built):
+    import la3dm_amd
+    m = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)
+    assert m.get_option("fast_trig") == 0
+    with pytest.raises(Exception):
+        m.set_option("fast_trig", 4)
