@@ -77,6 +77,7 @@ struct la3dm_devmap {
     bool lv_original_size = true;
     la3dm_devmap_lv_stats lv_stats;
     // block-sharded insert (la3dm_devmap_set_shard)
+    int dbg_fail_rank = -1;       // LA3DM_INJECT_FRONT_END_FAILURE at la3dm_devmap_create (a test hook), else -1
     uint32_t shard_rank = 0, shard_world = 1;
     la3dm_allgatherv_fn shard_fn = nullptr;
     void *shard_user = nullptr;
@@ -84,6 +85,7 @@ struct la3dm_devmap {
     uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
     std::vector<uint64_t> shard_off[3], shard_bytes[3];   // the all-gather-v's segments (alpha, beta, state), per rank
     Arena shard_hist, shard_nown, shard_own_off, shard_cnt, shard_frees;   // sharded sample filter (front_end)
+    uint32_t shard_status_failed = 0xFFFFFFFFu;   // (the source of the slot's "failed" preset: lives as long as the map)
     std::vector<uint32_t> shard_hist_host, shard_cnt_host;
     uint32_t n_xy = 0;
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
@@ -456,6 +458,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     la3dm_devmap *dm = new la3dm_devmap;
     dm->ctx = ctx;
+    if (const char *ev = getenv("LA3DM_INJECT_FRONT_END_FAILURE")) dm->dbg_fail_rank = atoi(ev);   // test hook, read once
     ctx->n_devmaps++;   // (la3dm_devmap_destroy, also the failure paths' clean-up, counts it down)
     dm->depth = (uint32_t)ctx->p.block_depth;
     dm->npb = npb_of(ctx->p.block_depth);
@@ -600,9 +603,10 @@ static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, con
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
     int rc;
-    if (const char *ev = getenv("LA3DM_INJECT_FRONT_END_FAILURE"))  // test hook (tests/test_sharded_insert_gpu.py): rank <value> of a sharded map fails here
-        if (dm->shard_world > 1 && atoi(ev) == (int)dm->shard_rank)
-            return dm_fail(dm, LA3DM_ERR_OOM, "devmap: injected rank-local front-end failure (LA3DM_INJECT_FRONT_END_FAILURE)");
+    // test hook (tests/test_sharded_insert_gpu.py): rank dbg_fail_rank of a sharded map fails here.  The environment variable is
+    // read ONCE, when the map is created (not on every insert of the production path)
+    if (dm->dbg_fail_rank >= 0 && dm->shard_world > 1 && dm->dbg_fail_rank == (int)dm->shard_rank)
+        return dm_fail(dm, LA3DM_ERR_OOM, "devmap: injected rank-local front-end failure (LA3DM_INJECT_FRONT_END_FAILURE)");
     const float *d_hits = d_xyz;
     uint32_t n_h = n;
     int free_key_bits = 32;
@@ -776,18 +780,22 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         const uint32_t world = dm->shard_world, rank = dm->shard_rank;
         uint32_t status = lrc != LA3DM_OK ? kShardStatusFailed : F.path == FrontState::kShardedFilter ? F.n_f_own : kShardStatusNoFilter;
         const std::string local_err = ctx->err;
-        int xrc = arena_reserve(ctx, dm->shard_cnt, 4ull * world);
-        if (xrc == LA3DM_OK && hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &status, 4, hipMemcpyHostToDevice, st) != hipSuccess) xrc = LA3DM_ERR_HIP;
+        // the exchange buffer exists since la3dm_devmap_set_shard, and this rank's slot reads "failed" until the copy below has
+        // replaced it: a rank that cannot even stage its word is seen as failed by its peers instead of handing them a stale
+        // count of the insert before
+        int xrc = LA3DM_OK;
+        if (hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &status, 4, hipMemcpyHostToDevice, st) != hipSuccess) xrc = LA3DM_ERR_HIP;
         dm->shard_off[0].resize(world);
         dm->shard_bytes[0].resize(world);
         for (uint32_t q = 0; q < world; ++q) {
             dm->shard_off[0][q] = 4ull * q;
             dm->shard_bytes[0][q] = 4;
         }
-        // (even a rank that could not stage its word enters the collective: the buffer then holds whatever it held, and
-        //  the rank fails below on its own account)
         la3dm_gather_seg seg = {dm->shard_cnt.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()};
-        if (dm->shard_cnt.ptr && dm->shard_fn(dm->shard_user, &seg, 1, world, rank, (void *)st) != 0)
+        const int cbrc = dm->shard_fn(dm->shard_user, &seg, 1, world, rank, (void *)st);
+        // re-arm the slot for the next insert (queued behind the exchange on the same stream)
+        (void)hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &dm->shard_status_failed, 4, hipMemcpyHostToDevice, st);
+        if (cbrc != 0 && lrc == LA3DM_OK)   // (a rank that had failed on its own keeps its own error)
             return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed (sample counts)");
         if (lrc != LA3DM_OK) {
             ctx->err = local_err;
@@ -1662,7 +1670,13 @@ int la3dm_devmap_set_shard(la3dm_devmap *dm, uint32_t rank, uint32_t world, la3d
         (void)hipHostFree(dm->h_shard);
         dm->h_shard = nullptr;
     }
-    if (world > 1) DM_TRY(hipHostMalloc((void **)&dm->h_shard, 8ull * (world + 1)));
+    if (world > 1) {
+        DM_TRY(hipHostMalloc((void **)&dm->h_shard, 8ull * (world + 1)));
+        // the status / count exchange buffer of every insert, every slot preset to "failed"
+        int rc = arena_reserve(dm->ctx, dm->shard_cnt, 4ull * world);
+        if (rc != LA3DM_OK) return dm_fail(dm, rc, "la3dm_devmap_set_shard: " + dm->ctx->err);
+        DM_TRY(hipMemset(dm->shard_cnt.ptr, 0xFF, 4ull * world));
+    }
     dm->shard_rank = rank;
     dm->shard_world = world;
     dm->shard_fn = world > 1 ? fn : nullptr;

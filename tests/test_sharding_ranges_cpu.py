@@ -61,8 +61,9 @@ def _rank(rank, world, port, ret):
     a[lo:hi], b[lo:hi], s[lo:hi] = truth_a[lo:hi], truth_b[lo:hi], truth_s[lo:hi]
     # the exchange: ONE in-place all-gather-v over the three leaf arrays (no pack / unpack, no padding), exactly the
     # segments la3dm_devmap_insert_* hands the callback
-    for arr, (offsets, nbytes) in zip((a, b, s), sharding.leaf_segments(lb)):
-        sharding.gather_v(dist, torch.from_numpy(arr.view(np.uint8)), offsets, nbytes, rank, world)
+    # all three arrays in ONE grouped batch of sends / receives (sharding.exchange_v: what torch_allgather issues per exchange)
+    segs = [(torch.from_numpy(arr.view(np.uint8)), offsets, nbytes) for arr, (offsets, nbytes) in zip((a, b, s), sharding.leaf_segments(lb))]
+    sharding.exchange_v(dist, segs, rank, world)
     ret[rank] = bool((a == truth_a).all() and (b == truth_b).all() and (s == truth_s).all())
     dist.destroy_process_group()
 
@@ -97,14 +98,17 @@ def _rank_subgroup(rank, port, ret):
         r, world = rank - 1, 2
         truth = np.arange(1000, dtype=np.uint8)
         buf = np.zeros_like(truth)
-        offsets, nbytes = [0, 300], [300, 700]            # uneven ranges: the broadcast form
+        offsets, nbytes = [0, 300], [300, 700]            # uneven ranges
         buf[offsets[r]:offsets[r] + nbytes[r]] = truth[offsets[r]:offsets[r] + nbytes[r]]
         sharding.gather_v(dist, torch.from_numpy(buf), offsets, nbytes, r, world, group=grp)
         ok = bool((buf == truth).all())
-        buf2 = np.zeros(1000, np.uint8)                   # even ranges: the all_gather_into_tensor form
+        buf2 = np.zeros(1000, np.uint8)                   # even ranges, and a rank that owns nothing in a second array
         buf2[500 * r:500 * (r + 1)] = truth[500 * r:500 * (r + 1)]
-        sharding.gather_v(dist, torch.from_numpy(buf2), [0, 500], [500, 500], r, world, group=grp)
-        ok = ok and bool((buf2 == truth).all())
+        buf3 = np.zeros(64, np.uint8)
+        if r == 1:
+            buf3[:] = 7
+        sharding.exchange_v(dist, [(torch.from_numpy(buf2), [0, 500], [500, 500]), (torch.from_numpy(buf3), [0, 0], [0, 64])], r, world, group=grp)
+        ok = ok and bool((buf2 == truth).all()) and bool((buf3 == 7).all())
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()
