@@ -78,6 +78,8 @@ struct la3dm_devmap {
     la3dm_devmap_lv_stats lv_stats;
     // block-sharded insert (la3dm_devmap_set_shard)
     int dbg_fail_rank = -1;       // LA3DM_INJECT_FRONT_END_FAILURE at la3dm_devmap_create (a test hook), else -1
+    int dbg_stuck_at = 0;         // LA3DM_INJECT_SCAN_STUCK = n at la3dm_devmap_create (a test hook): the n-th counter read-back of this
+                                  // map reports the look-back loops' "stuck" bit as if a scan launch had found its state dirty
     uint32_t shard_rank = 0, shard_world = 1;
     la3dm_allgatherv_fn shard_fn = nullptr;
     void *shard_user = nullptr;
@@ -292,6 +294,7 @@ static int read_counters(la3dm_devmap *dm) {
         __builtin_ia32_pause();
     }
     std::atomic_thread_fence(std::memory_order_acquire);   // the counter words are read (non-volatile) after the flag
+    if (dm->dbg_stuck_at > 0 && --dm->dbg_stuck_at == 0) dm->h_cnt[kCntError] |= kScanErrStuck;   // (test hook, tests/test_devmap_gpu.py)
     if (dm->h_cnt[kCntError] & (kScanErrStuck | kRsErrStuck)) {
         dm->poisoned = true;
         if (getenv("LA3DM_DEBUG_CNT")) {
@@ -458,7 +461,8 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     la3dm_devmap *dm = new la3dm_devmap;
     dm->ctx = ctx;
-    if (const char *ev = getenv("LA3DM_INJECT_FRONT_END_FAILURE")) dm->dbg_fail_rank = atoi(ev);   // test hook, read once
+    if (const char *ev = getenv("LA3DM_INJECT_FRONT_END_FAILURE")) dm->dbg_fail_rank = atoi(ev);   // test hooks, read once
+    if (const char *ev = getenv("LA3DM_INJECT_SCAN_STUCK")) dm->dbg_stuck_at = atoi(ev);
     ctx->n_devmaps++;   // (la3dm_devmap_destroy, also the failure paths' clean-up, counts it down)
     dm->depth = (uint32_t)ctx->p.block_depth;
     dm->npb = npb_of(ctx->p.block_depth);
@@ -770,6 +774,9 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
     FrontState F;
+    // sharded map: this rank's slot of the status exchange reads "failed" from here until the local part has succeeded
+    if (dm->shard_world > 1 && dm->shard_fn)
+        (void)hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + dm->shard_rank, &dm->shard_status_failed, 4, hipMemcpyHostToDevice, st);
     const int lrc = front_end_local(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range, F);
     if (dm->shard_world > 1 && dm->shard_fn) {
         // Sharded map: ONE status / count exchange per insert, entered by every rank whatever happened to it — a rank
@@ -780,8 +787,8 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         const uint32_t world = dm->shard_world, rank = dm->shard_rank;
         uint32_t status = lrc != LA3DM_OK ? kShardStatusFailed : F.path == FrontState::kShardedFilter ? F.n_f_own : kShardStatusNoFilter;
         const std::string local_err = ctx->err;
-        // the exchange buffer exists since la3dm_devmap_set_shard, and this rank's slot reads "failed" until the copy below has
-        // replaced it: a rank that cannot even stage its word is seen as failed by its peers instead of handing them a stale
+        // the exchange buffer exists since la3dm_devmap_set_shard, and this rank's slot reads "failed" (preset above, before the
+        // local part) until the copy below has replaced it: a rank that cannot even stage its word is seen as failed by its peers instead of handing them a stale
         // count of the insert before
         int xrc = LA3DM_OK;
         if (hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &status, 4, hipMemcpyHostToDevice, st) != hipSuccess) xrc = LA3DM_ERR_HIP;
@@ -793,8 +800,6 @@ static int front_end(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         }
         la3dm_gather_seg seg = {dm->shard_cnt.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()};
         const int cbrc = dm->shard_fn(dm->shard_user, &seg, 1, world, rank, (void *)st);
-        // re-arm the slot for the next insert (queued behind the exchange on the same stream)
-        (void)hipMemcpyAsync((uint32_t *)dm->shard_cnt.ptr + rank, &dm->shard_status_failed, 4, hipMemcpyHostToDevice, st);
         if (cbrc != 0 && lrc == LA3DM_OK)   // (a rank that had failed on its own keeps its own error)
             return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed (sample counts)");
         if (lrc != LA3DM_OK) {

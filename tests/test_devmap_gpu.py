@@ -568,3 +568,37 @@ def test_insert_after_set_resolution_and_set_block_depth(built, cls):
             a.set_block_depth(3)
         with pytest.raises(RuntimeError):
             a.set_resolution(0.3)
+
+
+def test_look_back_error_path_leaves_the_process_usable(built, monkeypatch):
+    """a prefix-sum / radix launch whose bounded look-back spin trips flags an error bit, the host poisons
+    the map at its next counter read-back and every later call on it fails loudly — a defensible decision that had no test.
+    LA3DM_INJECT_SCAN_STUCK = n (read once, at la3dm_devmap_create) makes the n-th counter read-back of a map report that
+    bit.  Here: the insert fails with an error that names the cause, the map stays failed (no silent half-inserted state is
+    served), destroying it works, and the NEXT map created in the same process — same context type, same stream machinery,
+    same arenas' allocator — inserts the same scan bit-identically to the oracle."""
+    import la3dm_amd
+    from oracle import oracle as O
+    xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", 1))
+    params = dict(la3dm_amd.BGK_YAML)
+    monkeypatch.setenv("LA3DM_INJECT_SCAN_STUCK", "2")
+    bad = la3dm_amd.BGKOctoMap(**params, device=0)
+    assert bad.is_device_resident()
+    with pytest.raises(RuntimeError) as e:
+        bad.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    assert "prefix-sum launch found its state in use" in str(e.value)
+    with pytest.raises(RuntimeError):                      # poisoned: a second insert is refused, not attempted
+        bad.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    del bad
+    monkeypatch.delenv("LA3DM_INJECT_SCAN_STUCK")
+    m = la3dm_amd.BGKOctoMap(**params, device=0)
+    m.set_option("bgk_sum", 0)
+    o = O.OracleMap(**params)
+    for i in (1, 2):
+        xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+    a, b = m.leaves(), o.leaves()
+    assert (a["block_key"] == b["block_key"]).all() and (a["node_key"] == b["node_key"]).all()
+    assert (a["A"].view(np.uint32) == b["A"].view(np.uint32)).all() and (a["B"].view(np.uint32) == b["B"].view(np.uint32)).all()
+    assert (a["state"] == b["state"]).all()

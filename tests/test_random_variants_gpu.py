@@ -87,17 +87,20 @@ def test_bgklv_random(built):
             _same(m.leaves(), o.leaves(), f"lv case{case} scan{scan} {params} fr={fr}")
 
 
-@pytest.mark.parametrize("sum_mode,first", [("0", 300), ("1", 340)])
-def test_differential_fuzz_sample(built, sum_mode, first):
-    """a slice of tests/manual/fuzz_pool.py (all four variants, both map modes, offsets, NaN points, hits at the sensor,
-    duplicates, bbox and leaf export on the pool) in BOTH BGK accumulate modes: the reference's summation order (every seed
-    must match the oracle bit for bit) and the library's default (double sums through the table kernel and the general
-    kernel: within one ulp of the restatement's double-sum mode; the other variants bit for bit)"""
+@pytest.mark.parametrize("sum_mode,first,count,flavour", [("0", 300, 25, "degenerate"), ("1", 340, 25, "degenerate"),
+                                                          ("1", 2000, 3, "big"), ("0", 2100, 2, "big"), ("0", 3000, 3, "gp")])
+def test_differential_fuzz_sample(built, sum_mode, first, count, flavour):
+    """slices of tests/manual/fuzz_pool.py (all four variants, both map modes, offsets, NaN points, hits at the sensor,
+    duplicates, bbox and leaf export on the pool) in BOTH accumulate modes of the BGK family: the reference's summation
+    order (every seed must match the oracle bit for bit) and the library's default (double sums: within one ulp of the
+    restatement's double-sum mode; GP bit for bit).  Flavours (until round 4 only the first was in the
+    driver-run suite): degenerate = zero-length beams and duplicate hits; big = clouds of 1 000 - 5 000 points, 4 - 8 fused
+    scans (BGK and BGK-L); gp = GP maps with hundreds of points per block (the matrix-core Cholesky / solve)."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "manual", "fuzz_pool.py"), str(first), "25", "degenerate"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "manual", "fuzz_pool.py"), str(first), str(count), flavour],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, LA3DM_BGK_SUM=sum_mode))
     assert r.returncode == 0, r.stderr[-2000:]
-    assert f"seeds {first}..{first + 24}: 0 mismatching" in r.stdout, r.stdout[-2000:]
+    assert f"seeds {first}..{first + count - 1}: 0 mismatching" in r.stdout, r.stdout[-2000:]
