@@ -394,7 +394,7 @@ __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ 
         out[i] = make_float4(p.x / ell, p.y / ell, p.z / ell, p.w);
         if (label_seq && !(p.w == 0.0f || p.w == 1.0f)) *label_seq = seq;  // (same value from every writer)
     }
-    if (i < n_nbr) {
+    if (nbr_range && i < n_nbr) {   // (the ordered kernel's view of the neighbour ranges: nullptr when another kernel runs)
         const int tb = nbr[i];
         uint2 r = make_uint2(0u, 0u);
         if (tb >= 0) {

@@ -1,4 +1,4 @@
-// bgk_predict_p.h — bgk_predict_fuse_p (round 5, the default of bgk_sum = 1): the table kernel of bgk_kernels.h
+// bgk_predict_p.h — bgk_predict_fuse_p (round 5; option "bgk_p" 1, NOT the default): the table kernel of bgk_kernels.h
 // (bgk_predict_fuse_t) with a one-read prologue and the sin / cos table in LDS.  Included at the end of bgk_kernels.h (same
 // namespace, same macros).
 //
@@ -14,7 +14,10 @@
 //     gather from the vector L1 per batch — an LDS address cannot fault, and the C phase no longer touches the
 //     vector-memory counter.  The 1 KB come out of the ring: 192 entries instead of 320, B pushes two candidates between
 //     overflow checks instead of four (63 + 128 < 192).  configs[4]'s 1 M-ray scan (C is 80 % of a tile there): 0.771 ->
-//     0.744 ms; configs[1]: unchanged (67.0 - 68.0 against 67.6 - 68.2 us).
+//     0.744 ms; configs[1]: unchanged (67.0 - 68.4 against 67.6 - 68.2 us).
+// The records cost bgk_prepare 2.5 us per step at configs[1] (a second nbr -> train_off chain per block, 5.3 MB written), more
+// than the kernel returns there: the step is 82.6 us against 80.0 us with bgk_predict_fuse_t, which therefore stays the default.
+// (The same kernel with bgk_predict_fuse_t's prologue instead of the record — LDS table only — measured 70.1 us: dropped.)
 // LDS per wave: ring 1 536 B + tables 1 536 B + sin / cos 1 024 B + 2 x 64 double accumulators 1 024 B = 5 120 B (8 waves / SIMD).
 //
 // Measured in round 5 and NOT kept (VERDICT r04 #1 asked for persistent waves with the next tile prefetched; DESIGN.md 3.2

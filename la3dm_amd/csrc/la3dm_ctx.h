@@ -26,8 +26,9 @@ struct la3dm_ctx {
                            // (bgk_predict_fuse_v5, bit-identical to the CPU restatement); env LA3DM_BGK_SUM sets the default
     int opt_bgk_tables = 1;  // bgk_sum = 1 only: 1 (default) = bgk_predict_fuse_t (per-axis distance tables for aligned 4x4x4 tiles, the
                              // other tiles through the general path in the same launch), 0 = bgk_predict_fuse_r for every tile
-    int opt_bgk_p = 1;       // bgk_sum = 1 with tables: 1 (default) = bgk_predict_fuse_p (one-read prologue from bgk_prepare's tile records, sin / cos
-                             // table in LDS), 0 = bgk_predict_fuse_t (round 4); env LA3DM_BGK_P
+    int opt_bgk_p = 0;       // bgk_sum = 1 with tables: 0 (default) = bgk_predict_fuse_t, 1 = bgk_predict_fuse_p (round 5: one-read prologue from
+                             // bgk_prepare's tile records, sin / cos table in LDS — measured equal in cache, -2 % out of cache, and
+                             // 2.5 us per step dearer in bgk_prepare: an option, not the default); env LA3DM_BGK_P
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
     int opt_time_kernel = 0;

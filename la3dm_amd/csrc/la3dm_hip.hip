@@ -295,7 +295,8 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_bgk_tables = value;
         return LA3DM_OK;
     }
-    if (!strcmp(name, "bgk_p")) {  // bgk_sum = 1 with tables: 1 = bgk_predict_fuse_p (tile records, sin / cos table in LDS), 0 = bgk_predict_fuse_t
+    if (!strcmp(name, "bgk_p")) {  // bgk_sum = 1 with tables: 0 (default) = bgk_predict_fuse_t, 1 = bgk_predict_fuse_p (one-read prologue from
+        // bgk_prepare's tile records, sin / cos table in LDS: the same kernel time in cache, -2 % out of cache, +2.5 us in bgk_prepare)
         if (value < 0 || value > 1) return bad_value("0 or 1");
         ctx->opt_bgk_p = value;
         return LA3DM_OK;
@@ -403,13 +404,14 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     // the table kernels: tiles of full (un-pruned) blocks through the distance tables, the others through the general
     // path of the same launch; they need every label to be 0 or 1
     const bool use_tables = sum_f64 && ctx->opt_bgk_tables && ctx->p.block_depth >= 3 && (s->flags & LA3DM_SCAN_LABELS_01) != 0u;
-    const bool use_p = use_tables && ctx->opt_bgk_p != 0;
+    const bool use_p = use_tables && ctx->opt_bgk_p != 0;   // bgk_predict_fuse_p: the prologue from bgk_prepare's tile records, sin / cos in LDS
+    const bool use_rec = use_p;
     // the instance without the general path only when the caller's LA3DM_SCAN_FULL_BLOCKS can be verified here: a block
     // holds at most 8^(depth-1) leaves, so the total says whether every block is full (a tile of a block that is
     // not would be skipped silently)
     const bool full_blocks = (s->flags & LA3DM_SCAN_FULL_BLOCKS) != 0u && (uint64_t)s->n_leaf == ((uint64_t)s->n_test_blk << (3 * (ctx->p.block_depth - 1)));
     BgkTileRecArgs tr;
-    if (use_p) {
+    if (use_rec) {
         rc = arena_reserve(ctx, ctx->tile_rec, sizeof(uint32_t) * 32 * ((size_t)s->n_test_blk << tpb_shift));
         if (rc != LA3DM_OK) return rc;
         tr.rec = (uint32_t *)ctx->tile_rec.ptr;
@@ -425,11 +427,16 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     {
         const uint32_t n_nbr = 7u * s->n_test_blk;
         uint32_t n_thr = s->n_train_pts > n_nbr ? s->n_train_pts : n_nbr;
-        if (use_p && n_thr < tr.n_tasks) n_thr = tr.n_tasks;
+        if (use_rec && n_thr < tr.n_tasks) n_thr = tr.n_tasks;
         dim3 g((n_thr + 255) / 256), b(256);
+        // what the launch writes beside the scaled points depends on the kernel that follows: the ordered kernel reads the
+        // per-neighbour ranges, the general path (bgk_predict_fuse_r, and the pruned tiles of the table kernels) the 64-byte
+        // block descriptors, bgk_predict_fuse_p the 128-byte tile records — each of them a dependent chain nbr -> train_off per
+        // block, so only the ones that will be read are produced (all three: 13.2 us at configs[1]; one: 6 - 7 us)
+        const bool want_desc = sum_f64 && !(use_rec && full_blocks);
         hipLaunchKernelGGL(bgk_prepare, g, b, 0, stream, (const float4 *)s->train_xyzy, (float4 *)ctx->pts_scaled.ptr,
-                           s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, (uint2 *)ctx->nbr_range.ptr, n_nbr,
-                           sum_f64 ? (uint32_t *)ctx->blk_desc.ptr : (uint32_t *)nullptr,
+                           s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, sum_f64 ? (uint2 *)nullptr : (uint2 *)ctx->nbr_range.ptr, n_nbr,
+                           want_desc ? (uint32_t *)ctx->blk_desc.ptr : (uint32_t *)nullptr,
                            sum_f64 ? (uint32_t *)ctx->label_seq.ptr : (uint32_t *)nullptr, ctx->scan_seq, tr);
     }
 

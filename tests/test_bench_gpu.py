@@ -42,8 +42,8 @@ def test_single_gpu_line(built):
     assert d["scaling"] == "none"
     rf = d["roofline"]
     # the line is quoted on the library's default accumulate mode and carries the other one next to it
-    assert d["config"]["bgk_sum"] == 1 and rf["kernel"] == "bgk_predict_fuse_p<0, false>"   # fresh map: no general path needed
-    assert rf["general_instance"]["kernel"] == "bgk_predict_fuse_p<0, true>" and rf["general_instance"]["kernel_ms"] > 0
+    assert d["config"]["bgk_sum"] == 1 and rf["kernel"] == "bgk_predict_fuse_t<0, false>"   # fresh map: no general path needed
+    assert rf["general_instance"]["kernel"] == "bgk_predict_fuse_t<0, true>" and rf["general_instance"]["kernel_ms"] > 0
     assert rf["ordered"]["kernel"] == "bgk_predict_fuse_v5" and rf["ordered"]["kernel_ms"] > rf["kernel_ms"] > 0
     # every other BASELINE config rides on the same line, each with a roofline and a CPU leg of its own
     for depth in ("depth3", "depth4"):

@@ -186,7 +186,7 @@ def test_both_modes_agree_and_default_is_the_order_free_one(built, monkeypatch):
 
 @pytest.mark.parametrize("depth", [3, 4])
 def test_table_kernel_and_general_kernel_agree_bit_for_bit(built, depth):
-    """bgk_predict_fuse_p (default) and bgk_predict_fuse_t against bgk_predict_fuse_r on the same packed scans through the C ABI (la3dm_bgk_scan_host): a
+    """bgk_predict_fuse_t (default) and bgk_predict_fuse_p (option) against bgk_predict_fuse_r on the same packed scans through the C ABI (la3dm_bgk_scan_host): a
     fresh map (every block un-pruned: the table kernel alone), the third scan of a sequence (pruned blocks: both kernels in
     one call), and the same scan without LA3DM_SCAN_LABELS_01 (the general kernel alone, whatever "bgk_tables" says).
     Both kernels form the same double sums of the same fp32 terms: alpha, beta and state are equal bit for bit up to the
@@ -208,10 +208,11 @@ def test_table_kernel_and_general_kernel_agree_bit_for_bit(built, depth):
         assert full == (earlier == 0)
         a0, b0 = pk.alpha.copy(), pk.beta.copy()
         out = []
-        # (tables, flags, bgk_p): the general kernel; the table kernels of round 5 (bgk_predict_fuse_p: tile records, sin / cos
-        # table in LDS) and round 4 (bgk_predict_fuse_t); p without the caller's LA3DM_SCAN_FULL_BLOCKS (the instance with the
+        # (tables, flags, bgk_p): the general kernel; the table kernels bgk_predict_fuse_t (default) and bgk_predict_fuse_p (option
+        # "bgk_p" 1: tile-record prologue, sin / cos table in LDS); p without the caller's LA3DM_SCAN_FULL_BLOCKS (the instance with the
         # general path compiled in); the same scan without LA3DM_SCAN_LABELS_01 (the general kernel whatever the options say)
-        for tables, flags, p in ((0, pk.flags, 1), (1, pk.flags, 1), (1, pk.flags, 0), (1, pk.flags & ~4, 1), (1, pk.flags & ~2, 1)):
+        for tables, flags, p in ((0, pk.flags, 0), (1, pk.flags, 0), (1, pk.flags, 1), (1, pk.flags & ~4, 0), (1, pk.flags & ~4, 1),
+                                 (1, pk.flags & ~2, 0)):
             m.set_option("bgk_tables", tables)
             m.set_option("bgk_p", p)
             pk.alpha[:], pk.beta[:], pk.c.flags = a0, b0, flags

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import la3dm_amd
 from r_check import run
 
-MODES = (0, 1)   # bgk_p: 0 = bgk_predict_fuse_t (round 4), 1 = bgk_predict_fuse_p
+MODES = (0, 1)   # bgk_p: 0 = bgk_predict_fuse_t (default), 1 = bgk_predict_fuse_p
 
 
 def one(name, xyz, origin, res, depth, reps, fr=0.5, mr=-1.0, ablate=False, strip_full=False):
@@ -33,7 +33,7 @@ def one(name, xyz, origin, res, depth, reps, fr=0.5, mr=-1.0, ablate=False, stri
             m.set_option("ablate", 0)
             line += f"  (no C {ab[0]:.4f}, no B/C {ab[1]:.4f})"
         print(line, flush=True)
-    m.set_option("bgk_p", 1)
+    m.set_option("bgk_p", 0)
 
 
 if __name__ == "__main__":
