@@ -345,6 +345,8 @@ def main():
         dist.destroy_process_group()
 
 
+ACC_SIDE = {0: "the reference's fp32 running sums in row / gather order (bit-identical to the CPU restatement)",
+            1: "double sums of the same fp32 terms, rounded once per neighbour (BGK-L) / voxel (BGK-LV) — library default since round 5"}
 ACC_NAMES = {0: "the reference's fp32 summation order (bit-identical to the CPU restatement)",
              1: "double accumulators per leaf, alpha / beta rounded once (library default; |dp| <= ~4e-7 from the reference order)"}
 
@@ -674,12 +676,14 @@ def lv_leg(args, torch, la3dm_amd, _lib, cpu):
     b_alg = 16 * int(st["n_samples"]) + 9 * int(st["voxels"])
     out["synthetic_50k"] = {"workload": "BGKLVOctoMap synthetic 50000-ray scan re-inserted, 0.05 m, block_depth 5, max_range 8",
                             "ms_per_insert": dt_b * 1e3, "samples": int(st["n_samples"]), "voxels": int(st["voxels"]),
-                            "roofline": {"bound": "hbm", "kernel": "bgklv_voxel_kernel (+ split add)", "kernel_ms": k_ms,
+                            "accumulate": ACC_SIDE[m.get_option("bgk_sum")],
+                            "roofline": {"bound": "hbm", "kernel": "bgklv_voxel_kernel_w8 (+ bgklv_split_apply64)" if m.get_option("bgk_sum") == 1
+                                         else "bgklv_voxel_kernel<false> (+ bgklv_split_add_kernel)", "kernel_ms": k_ms,
                                          "algorithmic_bytes_per_launch": b_alg, "achieved": b_alg / (k_ms * 1e-3) / 1e9,
                                          "peak": 8000.0, "unit": "GB/s", "frac": b_alg / (k_ms * 1e-3) / 1e9 / 8000.0}}
     cnt = profiled_counters("lv50k", path="side_counters.json", sources=("lv_kernels.h", "devmap_lv_kernels.h"))
     if cnt:   # HBM bytes per insert of the kernels the roofline names (tools/prof/side_pmc.sh; gfx950: FETCH_SIZE x 2 + WRITE_SIZE)
-        ks = [e for k, e in cnt["kernels"].items() if "bgklv_voxel_kernel" in k or "bgklv_split_add" in k]
+        ks = [e for k, e in cnt["kernels"].items() if "bgklv_voxel_kernel" in k or "bgklv_split_a" in k]
         rf = out["synthetic_50k"]["roofline"]
         rf["traffic"] = sum((2 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024 for e in ks)
         rf["traffic_source"] = cnt.get("source")
@@ -768,6 +772,7 @@ def l_leg(args, torch, la3dm_amd, cpu):
                        f"free_resolution {fr}; a step = one insert_pointcloud (host cloud -> updated pool in HBM)",
            "ms_per_step": dt * 1e3, "ms_per_step_mean": float(np.mean(each)) * 1e3, "ms_per_step_max": float(np.max(each)) * 1e3,
            "timing": "median of the steps, each bracketed by a device synchronisation",
+           "accumulate": ACC_SIDE[m.get_option("bgk_sum")],
            "voxel_updates_per_s": U / dt, "steps": steps,
            "voxel_updates_per_scan": U, "rows_read_per_scan": rows, "pair_evals_per_scan": int(st["pair_evals"]),
            "test_blocks": int(st["n_test_blocks"]),
@@ -778,6 +783,10 @@ def l_leg(args, torch, la3dm_amd, cpu):
     if cnt:   # HBM bytes of one insert, all kernels (tools/prof/side_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)
         out["roofline"]["traffic"] = cnt["hbm_bytes"]
         out["roofline"]["traffic_source"] = cnt.get("source")
+        # the part of it the algorithmic bytes describe: the inference kernels (rows x tiles -> sums -> update); the rest is
+        # the insert's front end, partition, leaf lists, commit and prune
+        out["roofline"]["traffic_inference_kernels"] = sum((2 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024
+                                                            for k, e in cnt["kernels"].items() if "bgkl_" in k and "rows_prepare" not in k)
         out["roofline"]["valu_insts"] = cnt.get("valu_insts")
         if cnt.get("valu_insts"):
             out["roofline"]["valu_issue"] = {"achieved": cnt["valu_insts"] / dt, "peak": 1024 * 2.4e9 / 4.0,

@@ -134,24 +134,32 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out);
 void la3dm_destroy(la3dm_ctx *ctx);
 const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last create error */
 
-/* Options: "bgk_sum" — the sum mode of the BGK predict + fuse kernel:
+/* Options: "bgk_sum" — the sum mode of the BGK family's kernels (BGKOctoMap; since round 5 also BGKLOctoMap and
+ * BGKLVOctoMap, where 1 = each neighbour's / voxel's two sums formed in double from the same fp32 terms and rounded to fp32
+ * once, the gates and node updates unchanged, and 0 = the reference's fp32 running sums in row / gather order).  For the BGK
+ * predict + fuse kernel:
  *   1 (default; env LA3DM_BGK_SUM sets the default of new contexts) = order-free: every leaf's sum(k), sum(k y) in double
  *     accumulators over all 7 neighbours, alpha / beta rounded once.  Within ~4e-7 of the reference's fp32 chains on p;
  *     NOT the reference's summation order; what bench.py's headline is quoted on (and labelled so).  Two kernels share
  *     the mode: bgk_predict_fuse_t ("bgk_tables" 1, the default; env LA3DM_BGK_TABLES) — per-axis distance tables for the
  *     tiles of un-pruned blocks, the general path for the others in the same launch; needs LA3DM_SCAN_LABELS_01 — and
  *     bgk_predict_fuse_r ("bgk_tables" 0, and every scan without that flag).  Same pairs, same kernel values, same sums.
+ *     "bgk_p" 1 (default 0; env LA3DM_BGK_P) = bgk_predict_fuse_p instead of _t: one-read prologue from per-tile records that
+ *     the prescale launch writes, sin / cos table in LDS — the same results, no faster in cache, ~2 % faster out of cache.
  *   0 = the reference's fp32 summation order (bgk_predict_fuse_v5): bit-identical to the CPU restatement, the regression
  *     mode of the parity suites.
- * "fast_trig" 0 = correctly rounded sin/cos (default), 1 = f32 polynomial, 2 = OCML; "waves_per_wg" 1/2/4 (bgk_sum 0),
+ * "fast_trig" 0 = correctly rounded sin/cos (default: the parity configuration), 1 = f32 polynomial, 2 = OCML (BGK kernels
+ * only), 3 = Eigen 3.3.7's psin / pcos without FMA — the arithmetic a ROS Noetic build of the reference most plausibly runs
+ * (include/bgkoctomap/bgkinference.h:115-116), for the BGK, BGK-L and BGK-LV kernels, bit-identical to the restatement's
+ * oracle.set_modes(1, 0); "waves_per_wg" 1/2/4 (bgk_sum 0),
  * "remap" 0-2, "ablate" 0-31 and "lds_pad" (profiling: extra dynamic LDS bytes on the BGK predict launch); values outside
  * these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
  * rows than this take the split path (default 2048, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
  * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
- * 0 = the replay expands them itself (results do not depend on it). */
+ * 0 = the replay expands them itself (results do not depend on it; bgk_sum 0 only — the order-free mode has no replay). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
-/* current value of an option that has one ("bgk_sum", "bgk_tables", "fast_trig", "waves_per_wg", "remap") */
+/* current value of an option that has one ("bgk_sum", "bgk_tables", "bgk_p", "fast_trig", "waves_per_wg", "remap") */
 int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */

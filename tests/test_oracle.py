@@ -503,3 +503,76 @@ def test_lv_openmp_build_equals_the_serial_build(O):
         la, lb = a.leaves(), b.leaves()
         for k in la:
             assert la[k].shape == lb[k].shape and (la[k] == lb[k]).all(), (i, k)
+
+
+def test_double_sum_mode_of_the_bgkl_and_bgklv_restatements(built):
+    """round 5: oracle.set_sum_mode(1) also covers BGKLOctoMap (per neighbour: double sums of k and k * label, each rounded to
+    fp32 once, then the reference's gate kbar > 0.001f and fp32 update — bgklinference.h:86-87, bgkloctomap.cpp:226-231) and
+    BGKLVOctoMap (per voxel — bgklvinference.h:80-83, bgklvoctomap.cpp:236-238).  Against the fp32 summation order on two
+    fused scans: same leaf structure and `classified` flags (no gate flips), |dp| <= 1e-5 on the occupancy probability;
+    alpha / beta differ (the mode really is another summation) by no more than the fp32 chains' own rounding error."""
+    from oracle import oracle as O
+    import la3dm_amd
+
+    def lv_prob(A, B, min_W):
+        A, B = A.astype(np.float64), B.astype(np.float64)
+        W = np.maximum(A + B, min_W)
+        return np.where(A > B, A / (W - B) + (W - A - B) * 0.5 / (W - B), 0.5 * (W - B - A) / (W - A))
+
+    try:
+        # BGK-L
+        a, b = O.OracleLMap(**O.L_YAML), O.OracleLMap(**O.L_YAML)
+        for i in (1, 2):
+            xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+            O.set_sum_mode(0)
+            a.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+            O.set_sum_mode(1)
+            b.insert_pointcloud(xyz, origin, 0.1, 0.3, 8.0)
+        la, lb = a.leaves(), b.leaves()
+        assert (la["block_key"] == lb["block_key"]).all() and (la["node_key"] == lb["node_key"]).all()
+        assert (la["classified"] == lb["classified"]).all()
+        pa = la["A"].astype(np.float64) / (la["A"].astype(np.float64) + la["B"])
+        pb = lb["A"].astype(np.float64) / (lb["A"].astype(np.float64) + lb["B"])
+        assert np.abs(pa - pb).max() <= 1e-5, float(np.abs(pa - pb).max())
+        assert (la["A"] != lb["A"]).any()
+        # BGK-LV
+        params = dict(O.LV_YAML, resolution=0.1, block_depth=4)
+        a, b = O.OracleLVMap(**params), O.OracleLVMap(**params)
+        for i in (1, 2):
+            xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", i))
+            O.set_sum_mode(0)
+            a.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+            O.set_sum_mode(1)
+            b.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        la, lb = a.leaves(), b.leaves()
+        assert (la["block_key"] == lb["block_key"]).all() and (la["node_key"] == lb["node_key"]).all()
+        assert (la["classified"] == lb["classified"]).all()
+        dp = np.abs(lv_prob(la["A"], la["B"], params["min_W"]) - lv_prob(lb["A"], lb["B"], params["min_W"]))
+        assert dp.max() <= 1e-5, float(dp.max())
+        for k in ("A", "B"):
+            rel = np.abs(la[k].astype(np.float64) - lb[k]) / np.maximum(np.abs(lb[k].astype(np.float64)), 1e-3)
+            assert rel.max() <= 1e-3, (k, float(rel.max()))
+        assert (la["A"] != lb["A"]).any() or (la["B"] != lb["B"]).any()
+    finally:
+        O.set_sum_mode(0)
+
+
+def test_likely_reference_trig_restatement_is_cephes(built):
+    """oracle.set_modes(1, 0): sin / cos of the restatement are Eigen 3.3.7's psin / pcos (Cephes, no FMA) — within 2 ulp of
+    the correctly rounded values over [0, 2 pi] and not identical to them (the switch really changes the arithmetic); the
+    device's fast_trig 3 is checked bit for bit against this in tests/test_likely_trig_gpu.py."""
+    from oracle import oracle as O
+    L = O.lib()
+    t = np.linspace(0, 2 * np.pi, 200001).astype(np.float32)
+    try:
+        O.set_modes(1, 0)
+        s1, c1 = np.zeros_like(t), np.zeros_like(t)
+        L.orc_trig_array(t, t.size, 0, s1)
+        L.orc_trig_array(t, t.size, 1, c1)
+    finally:
+        O.set_modes(0, 0)
+    s0, c0 = np.sin(t.astype(np.float64)).astype(np.float32), np.cos(t.astype(np.float64)).astype(np.float32)
+    for a, b in ((s1, s0), (c1, c0)):
+        err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        assert err.max() <= 2.5e-7, float(err.max())      # absolute: ~2 ulp of values near 1 (relative error grows near the zeros)
+        assert (a != b).any()
