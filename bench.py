@@ -444,7 +444,8 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
                                       "front end + partition + commit + prune redundant on every rank",
                        "voxel_updates_last_step": int(st["voxel_updates"]), "test_blocks": int(st["n_test_blocks"]),
                        "allgather_v_bytes_total": 9 * int(st["voxel_updates"]),
-                       "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}},
+                       "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                         "exchange": os.environ.get("LA3DM_SHARD_EXCHANGE", "p2p") + " (sharding.exchange_v: one grouped batch of sends / receives per exchange; LA3DM_SHARD_EXCHANGE=broadcast: one broadcast per rank and array)"}},
             "stages_ms_rank0": stages,
             "roofline": {"bound": "hbm", "achieved": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9,
                          "peak": 8000.0, "unit": "GB/s",

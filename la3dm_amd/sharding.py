@@ -10,6 +10,8 @@ back into the packed order, after which BGKOctoMap.commit() writes the nodes and
 Pure index bookkeeping (numpy); the collective itself is torch.distributed (RCCL on GPUs,
 gloo in the CPU tests).
 """
+import os
+
 import numpy as np
 
 
@@ -90,6 +92,18 @@ def exchange_v(dist, segments, r, world, group=None):
     every pair of GPUs talks over its own link, once.  Sends and receives between a pair are listed in the same (segment)
     order on both sides, which is what NCCL / gloo match them by.  Blocks the host until the local requests complete (for
     NCCL: until they are queued on the current stream)."""
+    if os.environ.get("LA3DM_SHARD_EXCHANGE", "p2p") == "broadcast":
+        # diagnosis switch: the round-3 / round-4 form — one broadcast per rank and array, issued one by one
+        works = []
+        for buf, offsets, nbytes in segments:
+            for q in range(world):
+                if nbytes[q]:
+                    src = dist.get_global_rank(group, q) if group is not None else q
+                    works.append(dist.broadcast(buf[offsets[q]:offsets[q] + nbytes[q]], src=src, group=group, async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
+        return
     ops = []
     for buf, offsets, nbytes in segments:
         mine = buf[offsets[r]:offsets[r] + nbytes[r]]
