@@ -59,6 +59,12 @@ enum { LA3DM_FREE = 0, LA3DM_OCCUPIED = 1, LA3DM_UNKNOWN = 2, LA3DM_PRUNED = 3 }
                                           created by this scan).  Only a hint for the kernel choice of bgk_sum = 1; a
                                           block that breaks the promise is left untouched. */
 
+#define LA3DM_SCAN_ROWS_PREPARED 0x8u  /* la3dm_bgkl_scan_device only: train_xyzy holds the rows in the kernels' own 12-float form
+                                          {x0 y0 z0 x1 | y1 z1 label [segment shorter than 0.1 mm ? 1 : 0] | lx ly lz |l|^2} (what
+                                          the library otherwise derives from the 8-float rows in a launch of its own, the same fp32
+                                          expressions as point_to_line_dist, bgklinference.h:104-118) — the device-resident map
+                                          writes its rows in that form directly */
+
 /* Map-wide constants: the statics BGKOctoMap's constructor sets
  * (src/bgkoctomap/bgkoctomap.cpp:31-56) plus the voxel look-up table
  * Block::key_loc_map (src/bgkoctomap/bgkblock.cpp:7-32) flattened depth-major:

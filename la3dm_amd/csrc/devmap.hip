@@ -993,7 +993,7 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     if (ctx->p.variant == 3) {  // training rows: hits as degenerate segments, every beam once per block
         DM_RESERVE(dm->l_rflag, 4ull * n_mem);
         DM_RESERVE(dm->l_rscan, 4ull * n_mem);
-        DM_RESERVE(dm->l_rows, 32ull * n_mem);
+        DM_RESERVE(dm->l_rows, 48ull * n_mem);   // 12 floats per row (LA3DM_SCAN_ROWS_PREPARED)
         DM_RESERVE(dm->l_rows_off, 4ull * ((size_t)n_mem + 2));
         uint32_t *rflag = (uint32_t *)dm->l_rflag.ptr, *rscan = (uint32_t *)dm->l_rscan.ptr;
         hipLaunchKernelGGL(dm_l_row_flags, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, v1, sflag, n_mem,
@@ -1141,7 +1141,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.train_xyzy = (const float *)dm->train.ptr;
     s.train_off = train_off;
     s.n_train_pts = n_mem;
-    if (ctx->p.variant == 3) {  // rows of 8 floats; n_mem bounds their number
+    if (ctx->p.variant == 3) {  // rows of 12 floats (prepared form); n_mem bounds their number
         s.train_xyzy = (const float *)dm->l_rows.ptr;
         s.train_off = P.rows_off;
     }
@@ -1156,6 +1156,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     s.beta = (float *)dm->leaf_beta.ptr;
     s.state = (uint8_t *)dm->leaf_state.ptr;
     s.flags = P.flags;
+    if (ctx->p.variant == 3) s.flags |= LA3DM_SCAN_ROWS_PREPARED;   // dm_l_rows_write wrote the 12-float form
     if (pass == 0 && dm->insert_into_empty) s.flags |= LA3DM_SCAN_FULL_BLOCKS;
     if (sharded) {
         // this rank's contiguous range of test blocks; leaf_off holds absolute leaf indices, so offsetting the per-block

@@ -833,20 +833,30 @@ __global__ __launch_bounds__(256) void dm_l_rows_write(const uint32_t *__restric
                                                       const uint32_t *__restrict__ rflag, const uint32_t *__restrict__ rscan,
                                                       const float4 *__restrict__ xy, const int32_t *__restrict__ ray_idx,
                                                       const float *__restrict__ rays, float4 *rows) {
+    // The rows go out in the inference kernels' own 12-float form (bgkl_kernels.h bgkl_rows_prepare: the segment's direction,
+    // squared length and "shorter than 0.1 mm" decision beside the end points — the same fp32 expressions, so the same bits;
+    // LA3DM_SCAN_ROWS_PREPARED): the 8-float rows and the launch that widened them were 57 us and 0.17 GB of a 200 k-ray insert.
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_mem || !rflag[k]) return;
     const uint32_t src = member_pt[k];
     const int32_t r = ray_idx[src];
-    float4 *o = rows + 2 * (size_t)rscan[k];
+    float4 *o = rows + 3 * (size_t)rscan[k];
+    float4 p0, p1;
     if (r < 0) {
         const float4 p = xy[src];
-        o[0] = make_float4(p.x, p.y, p.z, p.x);
-        o[1] = make_float4(p.y, p.z, 1.0f, 0.0f);
+        p0 = make_float4(p.x, p.y, p.z, p.x);
+        p1 = make_float4(p.y, p.z, 1.0f, 0.0f);
     } else {
         const float *q = rays + 6 * (size_t)r;
-        o[0] = make_float4(q[0], q[1], q[2], q[3]);
-        o[1] = make_float4(q[4], q[5], 0.0f, 0.0f);
+        p0 = make_float4(q[0], q[1], q[2], q[3]);
+        p1 = make_float4(q[4], q[5], 0.0f, 0.0f);
     }
+    const float lx = p0.w - p0.x, ly = p1.x - p0.y, lz = p1.y - p0.z;
+    const float c2 = lx * lx + ly * ly + lz * lz;
+    const bool degenerate = sqrtf(c2) < 0.0001f;
+    o[0] = p0;
+    o[1] = make_float4(p1.x, p1.y, p1.z, degenerate ? 1.0f : 0.0f);
+    o[2] = make_float4(lx, ly, lz, c2);
 }
 
 // CSR of the rows over the training blocks: rows_off[b] = rows before the block's first member

@@ -825,10 +825,14 @@ int la3dm_bgkl_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream
         a.hit_d2 = t;
     }
     // the rows' own terms of the line distance, once per row
-    if ((rc = arena_reserve(ctx, ctx->l_rowx, sizeof(float4) * 3 * (size_t)s->n_train_pts)) != LA3DM_OK) return rc;
-    a.rowx = (const float4 *)ctx->l_rowx.ptr;
-    if (s->n_train_pts)
-        hipLaunchKernelGGL(bgkl_rows_prepare, dim3((s->n_train_pts + 255) / 256), dim3(256), 0, stream, a.rows, s->n_train_pts, (float4 *)ctx->l_rowx.ptr);
+    if (s->flags & LA3DM_SCAN_ROWS_PREPARED) {   // the caller's rows already are in the 12-float form (the device-resident map's)
+        a.rowx = (const float4 *)s->train_xyzy;
+    } else {
+        if ((rc = arena_reserve(ctx, ctx->l_rowx, sizeof(float4) * 3 * (size_t)s->n_train_pts)) != LA3DM_OK) return rc;
+        a.rowx = (const float4 *)ctx->l_rowx.ptr;
+        if (s->n_train_pts)
+            hipLaunchKernelGGL(bgkl_rows_prepare, dim3((s->n_train_pts + 255) / 256), dim3(256), 0, stream, a.rows, s->n_train_pts, (float4 *)ctx->l_rowx.ptr);
+    }
     // tiles with more than `bgkl_split_rows` rows take the split path (bgkl_kernels.h); the others run while
     // the host waits for the item count
     BgklSplit sp;
