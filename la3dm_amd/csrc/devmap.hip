@@ -63,7 +63,9 @@ struct la3dm_devmap {
     size_t radix_tiles = 0;
     uint32_t radix_seq = 0;       // sorts so far: which of the two histograms is current
     std::vector<uint8_t> lv_axis_host;   // BGK-LV: staging of the per-axis candidate tables (kept until the next insert)
+    bool test_sort = true;        // LA3DM_TEST_SORT=0: the test blocks stay in candidate order (no heaviest-first sort)
     bool own_sort = true;         // LA3DM_OWN_SORT=0: rocPRIM's radix sort instead (A/B)
+    int spec_bits = 32;           // key digits (x 8 bits) the cloud's own voxel filter needed last time (voxel_grid)
     Arena train, grid, axis_tab, m_code, q_out;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
     Arena nleaf, leaf_off, leaf_key, leaf_alpha, leaf_beta, leaf_state, leaf_node;
@@ -131,13 +133,21 @@ static int sort_pairs_cfg(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_ou
 // Stable sort of (key, value) pairs on the low `end_bit` key bits: devmap_sort.h (one histogram launch + one launch per
 // 8 key bits; the input arrays are left as they are).  rocPRIM's sort (LA3DM_OWN_SORT=0) is kept for comparison: above
 // 2^18 items its Onesweep costs three launches per pass, below that its merge sort log2(n / 1024) launch pairs.
-static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
-                      uint32_t n, int end_bit, int begin_bit = 0) {
-    if (n == 0) return LA3DM_OK;
-    if (!dm->own_sort || end_bit > 32 || end_bit <= begin_bit || begin_bit < 0)
-        return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit, begin_bit);
+// (sort_fusable: the own sort takes this key range, so a caller may hand its key producer to the histogram launch — sort_pairs_src)
+static bool sort_fusable(la3dm_devmap *dm, int end_bit, int begin_bit = 0) {
+    return dm->own_sort && end_bit <= 32 && end_bit > begin_bit && begin_bit >= 0;
+}
+struct SortJob {   // a sort between its histogram launch and its passes
+    RadixState rs;
+    uint32_t n_pass = 0, n_bound = 0;
+    int begin_bit = 0;
+};
+// histogram launch of a sort of at most n_bound keys (the keys come from `src`: n_items items, devmap_sort.h)
+template <class Src>
+static int sort_begin_src(la3dm_devmap *dm, const Src &src, uint32_t n_items, uint32_t n_bound, int end_bit, int begin_bit, SortJob &job) {
+    if (!sort_fusable(dm, end_bit, begin_bit)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: fused histogram on a key range the own sort does not take");
     hipStream_t st = dm->ctx->stream;
-    const uint32_t n_pass = ((uint32_t)(end_bit - begin_bit) + 7u) / 8u, tiles = cdiv(n, kRsTile);
+    const uint32_t n_pass = ((uint32_t)(end_bit - begin_bit) + 7u) / 8u, tiles = cdiv(n_bound, kRsTile);
     if (tiles > dm->radix_tiles) {
         const size_t want = std::max<size_t>(2 * (size_t)tiles, 1024);
         DM_TRY(hipStreamSynchronize(st));
@@ -146,7 +156,7 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         DM_TRY(hipMemsetAsync(dm->radix_state.ptr, 0, bytes, st));   // on the sorts' own stream
         dm->radix_tiles = want;
     }
-    RadixState rs;   // layout: two histograms (this sort's, the next sort's), 16 spare words, two status arrays
+    RadixState &rs = job.rs;   // layout: two histograms (this sort's, the next sort's), 16 spare words, two status arrays
     uint32_t *base = (uint32_t *)dm->radix_state.ptr;
     rs.hist = base + 1024 * kRsHistCopies * (dm->radix_seq & 1u);
     rs.hist_next = base + 1024 * kRsHistCopies * ((dm->radix_seq + 1u) & 1u);
@@ -154,9 +164,24 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
     rs.ticket = base + 2048 * kRsHistCopies;   // (the 16 spare words)
     rs.status[0] = base + 2048 * kRsHistCopies + 16;
     rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
-    DM_RESERVE(dm->radix_tmp, 8ull * n);
-    uint32_t *tk = (uint32_t *)dm->radix_tmp.ptr, *tv = tk + n;
-    hipLaunchKernelGGL(dm_radix_hist, dim3(std::max<uint32_t>(std::min<uint32_t>(cdiv(n, 4 * kRsThreads), 512u), kRsHistCopies)), dim3(kRsThreads), 0, st, k_in, n, n_pass, (uint32_t)begin_bit, rs);
+    job.n_pass = n_pass;
+    job.n_bound = n_bound;
+    job.begin_bit = begin_bit;
+    hipLaunchKernelGGL((dm_radix_hist_src<Src>), dim3(std::max<uint32_t>(std::min<uint32_t>(cdiv(n_items, 4 * kRsThreads), 512u), kRsHistCopies)), dim3(kRsThreads), 0, st, src, n_bound, n_items, n_pass, (uint32_t)begin_bit, rs);
+    DM_TRY(hipGetLastError());
+    return LA3DM_OK;
+}
+// the passes; n_dev != nullptr: the key count is read there by the launches (n_bound only sizes them)
+static int sort_passes(la3dm_devmap *dm, const SortJob &job, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
+                       const uint32_t *n_dev = nullptr) {
+    hipStream_t st = dm->ctx->stream;
+    const uint32_t n = job.n_bound, n_pass = job.n_pass, tiles = cdiv(n, kRsTile);
+    uint32_t *tk = nullptr, *tv = nullptr;
+    if (n_pass > 1) {
+        DM_RESERVE(dm->radix_tmp, 8ull * n);
+        tk = (uint32_t *)dm->radix_tmp.ptr;
+        tv = tk + n;
+    }
     const uint32_t *sk = k_in, *sv = v_in;
     for (uint32_t p = 0; p < n_pass; ++p) {
         const bool to_out = ((n_pass - 1u - p) & 1u) == 0u;   // the last pass lands in the output arrays
@@ -166,18 +191,36 @@ static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, c
         a.k_out = to_out ? k_out : tk;
         a.v_out = to_out ? v_out : tv;
         a.n = n;
+        a.n_dev = n_dev;
         a.n_pass = n_pass;
         a.pass = p;
-        a.begin_bit = (uint32_t)begin_bit;
+        a.begin_bit = (uint32_t)job.begin_bit;
         a.counters = dm->d_cnt;
         a.err_slot = (int)kCntError;
         a.use_ticket = tiles > dm->radix_resident ? 1u : 0u;
-        hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(kRsThreads), 0, st, a, rs);
+        hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(kRsThreads), 0, st, a, job.rs);
         sk = a.k_out;
         sv = a.v_out;
     }
     DM_TRY(hipGetLastError());
     return LA3DM_OK;
+}
+template <class Src>
+static int sort_pairs_src(la3dm_devmap *dm, const Src &src, uint32_t n_items, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in,
+                          uint32_t *v_out, uint32_t n, int end_bit, int begin_bit = 0) {
+    if (n == 0) return LA3DM_OK;
+    SortJob job;
+    int rc = sort_begin_src(dm, src, n_items, n, end_bit, begin_bit, job);
+    if (rc != LA3DM_OK) return rc;
+    return sort_passes(dm, job, k_in, k_out, v_in, v_out);
+}
+
+static int sort_pairs(la3dm_devmap *dm, const uint32_t *k_in, uint32_t *k_out, const uint32_t *v_in, uint32_t *v_out,
+                      uint32_t n, int end_bit, int begin_bit = 0) {
+    if (n == 0) return LA3DM_OK;
+    if (!sort_fusable(dm, end_bit, begin_bit))
+        return sort_pairs_cfg<(1u << 18)>(dm, k_in, k_out, v_in, v_out, n, end_bit, begin_bit);
+    return sort_pairs_src(dm, RsPlainKeys{k_in}, n, k_in, k_out, v_in, v_out, n, end_bit, begin_bit);
 }
 
 // The kernel about to be launched publishes the counter block itself (dm_publish_lane) under a fresh sequence number.
@@ -321,11 +364,18 @@ static int check_beam_counters(la3dm_devmap *dm) {
 // written to `out` (reserved here) and its point count returned.  One read-back (cell count).
 // key_bits: number of low key bits that can differ between cells (32 = unknown); must satisfy
 // cell count <= 2^key_bits - 1 so that the all-ones key of a non-finite point still sorts behind every cell.
-static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out, int key_bits = 32,
+// Round 5: key_bits = 0 — the caller does not know (the cloud's own filter: its grid is reduced on the device by this call): the
+// sort runs on as many 8-bit digits as the LAST such call needed (dm->spec_bits; all four the first time), and the
+// GridParams that come back with the cell count say whether that was enough; if not (the scene grew past 2^16 / 2^24 cells)
+// the filter is simply run again on 32 bits — a constant top digit used to cost a copy pass (10 us) on every insert.
+static const uint32_t kBigCellWgs = getenv("LA3DM_BIG_WGS") ? (uint32_t)atoi(getenv("LA3DM_BIG_WGS")) : 2048u;   // waves (one per cell at a time) of dm_grid_centroids_big
+static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out, int key_bits = 0,
                       bool params_ready = false) {
     hipStream_t st = dm->ctx->stream;
     *n_out = 0;
     if (n == 0) return LA3DM_OK;
+    const bool speculate = key_bits == 0;
+    if (speculate) key_bits = dm->spec_bits;
     const float inv = 1.0f / leaf;
     DM_RESERVE(dm->k0, 4ull * n);
     DM_RESERVE(dm->k1, 4ull * n);
@@ -340,8 +390,14 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
         MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
         hipLaunchKernelGGL(dm_minmax<3>, dim3(std::min<uint32_t>(cdiv(n, 1024), kMinmaxWgs)), dim3(256), 0, st, d_in, n, dm->d_mm, fin);
     }
-    hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
-    int rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
+    int rc;
+    if (sort_fusable(dm, key_bits)) {   // the cell keys are written by the sort's histogram launch
+        const GridCellsSrc src = {d_in, inv, dm->d_gp, k0, v0};
+        rc = sort_pairs_src(dm, src, n, k0, k1, v0, v1, n, key_bits);
+    } else {
+        hipLaunchKernelGGL(dm_grid_cells, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, inv, dm->d_gp, k0, v0);
+        rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
+    }
     if (rc != LA3DM_OK) return rc;
     rc = scan_heads(dm, k1, n, flag, scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid, (int)kCntBig, true);
     if (rc != LA3DM_OK) return rc;
@@ -350,16 +406,14 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     // with them.  (A pass-through grid lets them write junk that the copy below replaces.)
     DM_RESERVE(out, 12ull * n);
     // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
-    DM_RESERVE(dm->big, 4ull * (n / kBigCell + 1));
-    hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntGridSegs,
-                       (int)kCntBig, (uint32_t *)dm->big.ptr, (float *)out.ptr);
+    DM_RESERVE(dm->big, 16ull * (n / kBigCell + 1));   // {cell, first, end, -} per entry
     const uint32_t nchunk = n / kChunk;
     DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
-    if (nchunk)
-        hipLaunchKernelGGL(dm_big_chunks, dim3(nchunk), dim3(64), 0, st, d_in, v1, flag, scan, dm->d_cnt, (int)kCntGridValid,
-                           (uint4 *)dm->chunk_desc.ptr);
-    hipLaunchKernelGGL(dm_grid_centroids_big, dim3(512, 3), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
-                       (const uint32_t *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
+    hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256) + cdiv(nchunk, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
+                       (int)kCntGridSegs, (int)kCntBig, (uint4 *)dm->big.ptr, (float *)out.ptr, cdiv(n, 256), (const uint32_t *)flag,
+                       (const uint32_t *)scan, (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr);
+    hipLaunchKernelGGL(dm_grid_centroids_big, dim3(kBigCellWgs), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
+                       (const uint4 *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
     rc = read_counters(dm);
     if (rc != LA3DM_OK) return rc;
     memcpy(dm->h_gp, dm->h_cnt + kCntGrid, sizeof(GridParams));
@@ -367,6 +421,16 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
         DM_TRY(hipMemcpyAsync(out.ptr, d_in, 12ull * n, hipMemcpyDeviceToDevice, st));
         *n_out = n;
         return LA3DM_OK;
+    }
+    if (speculate && !dm->h_gp->empty) {
+        // cells <= 2^bits - 1 keeps the all-ones key of a non-finite point behind every cell on `bits` key bits
+        const uint64_t cells = (uint64_t)dm->h_gp->m2 * (uint64_t)dm->h_gp->span[2];
+        int need = 1;
+        while (need < 32 && ((1ull << need) - 1ull) < cells) ++need;
+        const int need_digits = std::min(32, 8 * ((need + 7) / 8));
+        dm->spec_bits = need_digits;
+        if (need_digits > key_bits)   // too few digits were sorted: again, with the GridParams in place
+            return voxel_grid(dm, d_in, n, leaf, out, n_out, 32, true);
     }
     *n_out = dm->h_cnt[kCntGridSegs];
     return LA3DM_OK;
@@ -482,13 +546,15 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         dm->mailbox = !(mb && mb[0] == '0');
         const char *os = getenv("LA3DM_OWN_SORT");
         dm->own_sort = !(os && os[0] == '0');
+        const char *ts = getenv("LA3DM_TEST_SORT");
+        dm->test_sort = !(ts && ts[0] == '0');
     }
     bool ok = hipMalloc((void **)&dm->d_cnt, sizeof(uint32_t) * kCntWords) == hipSuccess &&
               // the mailbox: coherent (the in-kernel publish must be visible while the kernel still runs, whatever
               // HIP_HOST_COHERENT says), mapped, and cleared — the first wait is for sequence number 1
               hipHostMalloc((void **)&dm->h_cnt, sizeof(uint32_t) * (kCntWords + 2), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
               (memset(dm->h_cnt, 0, sizeof(uint32_t) * (kCntWords + 2)), true) &&
-              hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * 16) == hipSuccess &&
+              hipMalloc((void **)&dm->d_mm, sizeof(uint32_t) * kMmWords) == hipSuccess &&
               hipMalloc((void **)&dm->d_bbox, sizeof(float) * 8) == hipSuccess &&
               hipHostMalloc((void **)&dm->h_bbox, sizeof(float) * 8) == hipSuccess &&
               hipMalloc((void **)&dm->d_gp, sizeof(GridParams)) == hipSuccess &&
@@ -978,11 +1044,16 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->v1, 4ull * n_mem);
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
     DM_RESERVE(dm->grid, 4ull * ncid);
-    hipLaunchKernelGGL(dm_members_write, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const int4 *)dm->m_code.ptr, npts, pa, m_off,
-                       k0, v0, dm->d_cnt, (int32_t *)dm->grid.ptr, (uint32_t)ncid);
     int bits = 1;
     while ((1ull << bits) < ncid) ++bits;
-    if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;
+    if (n_mem && sort_fusable(dm, bits)) {   // the pairs are written by the sort's histogram launch
+        const MembersSrc src = {(const int4 *)dm->m_code.ptr, pa, m_off, k0, v0, dm->d_cnt, (int32_t *)dm->grid.ptr, (uint32_t)ncid};
+        if ((rc = sort_pairs_src(dm, src, npts, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(dm_members_write, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const int4 *)dm->m_code.ptr, npts, pa, m_off,
+                           k0, v0, dm->d_cnt, (int32_t *)dm->grid.ptr, (uint32_t)ncid);
+        if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;
+    }
     DM_RESERVE(dm->c_flag, 4ull * std::max(n_mem, n_entries));
     DM_RESERVE(dm->c_scan, 4ull * std::max(n_mem, n_entries));
     DM_RESERVE(dm->seg_start, 4ull * (n_mem + 1));
@@ -1006,9 +1077,10 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
         P.rows_off = (uint32_t *)dm->l_rows_off.ptr;
     } else {
         DM_RESERVE(dm->train, 16ull * n_mem);
-        hipLaunchKernelGGL(dm_gather_train, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, v1, n_mem, (float4 *)dm->train.ptr);
     }
-    hipLaunchKernelGGL(dm_geo_fill, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
+    hipLaunchKernelGGL(dm_gather_geo, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, (const uint32_t *)v1, n_mem,
+                       ctx->p.variant == 3 ? (float4 *)nullptr : (float4 *)dm->train.ptr, (const uint32_t *)seg_key, dm->d_cnt, pa,
+                       (int32_t *)dm->grid.ptr);
     // the segment count is only needed on the host by the GP launches; the BGK path reads it (and the error flag)
     // together with the test-block count of the first pass
     uint32_t n_geo = n_mem;
@@ -1046,8 +1118,25 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     DM_RESERVE(dm->t_ent0, 4ull * n_entries);
     // (the scan's total is the test-block count: it publishes the counters, the compaction runs while the host waits)
     if ((rc = exclusive_scan(dm, c_flag, c_scan, n_entries, (int)kCntTest, true)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
-                       (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
+    // Heaviest test blocks first (the blocks are independent: order only balances the launch).  The compaction is the histogram
+    // launch of that one-digit sort, and the pass behind it takes the list's length from the counter block: both are queued
+    // before the host has read the length (round 5; compaction, read-back, histogram, pass were four steps in a row).
+    const bool sharded = dm->shard_world > 1;
+    const uint32_t world = dm->shard_world;
+    const bool sorted_on_device = !sharded && dm->test_sort && sort_fusable(dm, 32, 24);
+    if (sorted_on_device) {
+        DM_RESERVE(dm->t_key1, 4ull * n_entries);
+        DM_RESERVE(dm->t_ent1, 4ull * n_entries);
+        const TestCompactSrc src = {c_flag, c_scan, c_weight, n_entries, (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt};
+        SortJob job;
+        if ((rc = sort_begin_src(dm, src, n_entries, n_entries, 32, 24, job)) != LA3DM_OK) return rc;   // the weight class
+        if ((rc = sort_passes(dm, job, (const uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_key1.ptr, (const uint32_t *)dm->t_ent0.ptr,
+                              (uint32_t *)dm->t_ent1.ptr, dm->d_cnt + kCntTest)) != LA3DM_OK)
+            return rc;
+    } else {
+        hipLaunchKernelGGL(dm_test_compact, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, c_flag, c_scan, c_weight, n_entries,
+                           (uint32_t *)dm->t_key0.ptr, (uint32_t *)dm->t_ent0.ptr, dm->d_cnt);
+    }
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if (dm->h_cnt[kCntError])
         return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
@@ -1057,12 +1146,15 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     if (n_test == 0) return LA3DM_OK;
     S.n_test_blocks += n_test;
     S.n_passes = pass + 1;
-    DM_RESERVE(dm->t_key1, 4ull * n_test);
-    DM_RESERVE(dm->t_ent1, 4ull * n_test);
-    const bool sharded = dm->shard_world > 1;
-    const uint32_t world = dm->shard_world;
-    if (!sharded) {
-        // heaviest test blocks first (the blocks are independent: order only balances the launch)
+    // the list the rest of the pass works on: sorted copies, or (sharded / LA3DM_TEST_SORT=0) the compacted list in candidate order
+    const uint32_t *t_key = (const uint32_t *)dm->t_key1.ptr, *t_ent = (const uint32_t *)dm->t_ent1.ptr;
+    if (sorted_on_device) {
+        // (queued above)
+    } else if (!sharded && dm->test_sort) {   // the library sort (LA3DM_OWN_SORT=0)
+        DM_RESERVE(dm->t_key1, 4ull * n_test);
+        DM_RESERVE(dm->t_ent1, 4ull * n_test);
+        t_key = (const uint32_t *)dm->t_key1.ptr;
+        t_ent = (const uint32_t *)dm->t_ent1.ptr;
         if (n_test <= kSortSmallMax) {
             uint32_t N = 2;
             while (N < n_test) N <<= 1;
@@ -1072,16 +1164,18 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
                                     (uint32_t *)dm->t_ent1.ptr, n_test, 32, 24)) != LA3DM_OK)   // the weight class
             return rc;
     } else {
+        t_key = (const uint32_t *)dm->t_key0.ptr;
+        t_ent = (const uint32_t *)dm->t_ent0.ptr;
+    }
+    if (sharded) {
         // block-sharded: the list stays in candidate order (block indices x-major: neighbouring test blocks, which share
         // training blocks, stay on one GPU's L2) and is cut into `world` contiguous ranges of equal weight
-        DM_TRY(hipMemcpyAsync(dm->t_key1.ptr, dm->t_key0.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
-        DM_TRY(hipMemcpyAsync(dm->t_ent1.ptr, dm->t_ent0.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
         DM_RESERVE(dm->shard_w, 4ull * n_test);
         DM_RESERVE(dm->shard_cumw, 4ull * n_test);
         DM_RESERVE(dm->shard_bounds, 8ull * (world + 1));
         // (a block's weight is capped so that the 32-bit running sum cannot wrap: n_test * cap < 2^31 — ADVICE r02)
         const uint32_t w_cap = std::max<uint32_t>(32u, (uint32_t)((1ull << 31) / n_test));
-        hipLaunchKernelGGL(dm_shard_weight, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr, n_test,
+        hipLaunchKernelGGL(dm_shard_weight, dim3(cdiv(n_test, 256)), dim3(256), 0, st, t_key, n_test,
                            w_cap, (uint32_t *)dm->shard_w.ptr);
         if ((rc = exclusive_scan(dm, (const uint32_t *)dm->shard_w.ptr, (uint32_t *)dm->shard_cumw.ptr, n_test)) != LA3DM_OK) return rc;
         hipLaunchKernelGGL(dm_shard_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_cumw.ptr,
@@ -1091,20 +1185,18 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     DM_RESERVE(dm->t_center, 12ull * n_test);
     DM_RESERVE(dm->t_nbr, 28ull * n_test);
     DM_RESERVE(dm->t_slot, 4ull * n_test);
-    hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
-                       (const uint32_t *)dm->t_ent1.ptr, dm->d_cnt, (long long *)dm->t_blockkey.ptr, (float *)dm->t_center.ptr,
-                       (int32_t *)dm->t_nbr.ptr);
-    // blocks: find or create (bgkoctomap.cpp:298-305)
+    // blocks: find or create (bgkoctomap.cpp:298-305), in the launch that builds the test blocks' keys and neighbour tables
     if ((rc = grow_pool(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
     if ((rc = grow_table(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
     // (d_cnt[kCntBlocks] holds the pool's block count since dm_begin; the passes keep it current)
-    hipLaunchKernelGGL(dm_table_insert, dim3(cdiv(n_test, 256)), dim3(256), 0, st, (const long long *)dm->t_blockkey.ptr,
-                       dm->d_cnt, dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key,
-                       (uint32_t *)dm->t_slot.ptr);
-    // default nodes for the blocks this launch created: slots [old count, new count); the new count stays on
-    // the device (read back with the pass's other counters), the launch covers the worst case of n_test new blocks
-    hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)n_test * dm->npb, 256)), dim3(256), 0, st, dm->A, dm->B, dm->S,
-                       dm->n_blocks, (const uint32_t *)(dm->d_cnt + kCntBlocks), dm->npb, dm->init_A, dm->init_B);
+    {
+        const TableArgs tb = {dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key};
+        hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+                           t_ent, dm->d_cnt, (long long *)dm->t_blockkey.ptr, (float *)dm->t_center.ptr,
+                           (int32_t *)dm->t_nbr.ptr, tb, (uint32_t *)dm->t_slot.ptr);
+    }
+    // default nodes for the blocks this launch created — slots [old count, new count); the new count stays on the device (read
+    // back with the pass's other counters) — are written by the leaf-count launch below (LeafExtra)
     // pack: leaves in LeafIterator order
     DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
     DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
@@ -1115,20 +1207,32 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     DM_RESERVE(dm->leaf_node, 4 * max_leaves);
     DM_RESERVE(dm->leaf_state, max_leaves);
     uint32_t *nleaf = (uint32_t *)dm->nleaf.ptr, *leaf_off = (uint32_t *)dm->leaf_off.ptr;
+    LeafExtra lx;
+    memset(&lx, 0, sizeof(lx));
+    lx.old_blocks = dm->n_blocks;
+    lx.a0 = dm->init_A;
+    lx.b0 = dm->init_B;
+    lx.A_w = dm->A;
+    lx.B_w = dm->B;
+    lx.S_w = dm->S;
     hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                        (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
-                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
     if (ctx->p.variant == 3)
         hipLaunchKernelGGL(dm_l_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
                            (const uint32_t *)P.rows_off, (const uint32_t *)nleaf, n_test, dm->d_cnt);
-    else
-        hipLaunchKernelGGL(dm_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const uint32_t *)dm->t_key1.ptr,
-                           (const uint32_t *)nleaf, n_test, dm->d_cnt);
     if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1, (int)kCntLeaves)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL((dm_leaves<true>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
-                       (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
-                       (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
-                       (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr);
+    {
+        // the emitting launch carries the pass's work counters (train_reads, pair_evals) in a few workgroups of its own
+        const uint32_t main_wgs = cdiv(n_test, 4), stat_wgs = ctx->p.variant == 3 ? 0u : std::min(cdiv(n_test, 256), 32u);
+        lx.t_key = stat_wgs ? t_key : nullptr;
+        lx.counters_w = dm->d_cnt;
+        lx.main_wgs = main_wgs;
+        hipLaunchKernelGGL((dm_leaves<true>), dim3(main_wgs + stat_wgs), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                           (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                           (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
+    }
     double tp1 = tp0;
     if (dm->stage_timing) {
         DM_TRY(hipStreamSynchronize(st));
@@ -1223,19 +1327,27 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         S.t_kernel += (sharded ? tg0 : tp2) - tp1;
     }
     // f3: write-back + prune
-    hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
-                       (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
-                       (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
     // The reference prunes after ALL test blocks have been predicted (bgkoctomap.cpp:344-353): with repeated keys
     // the later passes must still see the un-pruned leaves, so the prune of pass 0 (which holds every distinct
-    // test block) is deferred to the end of the pass loop.
+    // test block) is deferred to the end of the pass loop.  A single-pass scan (the usual case) commits and prunes in ONE
+    // launch, whose last workgroup also sends the counter block to the host (dm_commit_prune).
     if (max_occ == 1) {
-        hipLaunchKernelGGL(dm_prune, dim3(cdiv(n_test, 4)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
-                           (const uint32_t *)dm->t_slot.ptr, n_test, dm->A, dm->B, dm->S, dm->npb, dm->depth);
-    } else if (pass == 0) {
-        DM_RESERVE(dm->t_slot0, 4ull * n_test);
-        DM_TRY(hipMemcpyAsync(dm->t_slot0.ptr, dm->t_slot.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
-        *n_test0 = n_test;
+        volatile uint32_t *mailbox = nullptr;
+        uint32_t mseq = 0;
+        publish_with(dm, mailbox, mseq);
+        hipLaunchKernelGGL(dm_commit_prune, dim3(std::min(cdiv(n_test, 4), kCommitPruneWgs)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
+                           (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off, (const uint32_t *)dm->leaf_node.ptr,
+                           (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr,
+                           dm->A, dm->B, dm->S, dm->npb, dm->depth, (const uint32_t *)dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq);
+    } else {
+        hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
+                           (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
+                           (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S);
+        if (pass == 0) {
+            DM_RESERVE(dm->t_slot0, 4ull * n_test);
+            DM_TRY(hipMemcpyAsync(dm->t_slot0.ptr, dm->t_slot.ptr, 4ull * n_test, hipMemcpyDeviceToDevice, st));
+            *n_test0 = n_test;
+        }
     }
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     dm->n_blocks = dm->h_cnt[kCntBlocks];

@@ -286,6 +286,7 @@ __global__ void dm_begin(uint32_t *counters, uint32_t n_blocks, uint32_t *mm, ui
     if (i < 3) mm[i] = mm[8 + i] = 0xFFFFFFFFu;   // mm[8..13]: the second box (kept hits) of the fused front end
     else if (i < 6) mm[i] = mm[8 + i] = 0u;
     if (i == 6) *done = 0u;
+    for (uint32_t k = i; k < 1u + 64u; k += blockDim.x) mm[32u + 32u * k] = 0u;   // dm_commit_prune's arrival words (kArriveBase, kArriveStride)
 }
 
 // cell index of every point (kInvalidCell for non-finite points), value = cloud index
@@ -305,19 +306,41 @@ __global__ __launch_bounds__(256) void dm_grid_cells(const float *__restrict__ p
     vals[i] = i;
 }
 
+// dm_grid_cells as the key source of the sort's histogram launch (devmap_sort.h dm_radix_hist_src): one launch less per filter
+struct GridCellsSrc {
+    const float *p;
+    float inv;
+    const GridParams *gp;
+    uint32_t *keys, *vals;
+    __device__ __forceinline__ void begin(uint32_t, uint32_t) const {}
+    template <class Add>
+    __device__ __forceinline__ void operator()(uint32_t i, Add &add) const {
+        const float x = p[3 * (size_t)i], y = p[3 * (size_t)i + 1], z = p[3 * (size_t)i + 2];
+        uint32_t cell = kInvalidCell;
+        if (finite3(x, y, z)) {
+            const int c0 = (int)(floorf(x * inv) - (float)gp->lo[0]);
+            const int c1 = (int)(floorf(y * inv) - (float)gp->lo[1]);
+            const int c2 = (int)(floorf(z * inv) - (float)gp->lo[2]);
+            cell = (uint32_t)(c0 + c1 * gp->m1 + c2 * gp->m2);
+        }
+        keys[i] = cell;
+        vals[i] = i;
+        add(cell);
+    }
+};
+
 // Centroid of one voxel-grid cell: fp32 sums in cloud order (the sort is stable, values ascend inside a
 // segment).  One thread per cell for the ordinary cells; cells with more than kBigCell points (the voxels
 // next to the sensor collect one sample per beam — tens of thousands of points) go to dm_grid_centroids_big.
 constexpr uint32_t kBigCell = 64;
 
-__global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict__ p, const uint32_t *__restrict__ vals,
-                                                        const uint32_t *__restrict__ seg_start, uint32_t *counters,
-                                                        int seg_slot, int big_slot, uint32_t *big, float *out) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void grid_centroids_thread(const uint32_t seg, const float *__restrict__ p, const uint32_t *__restrict__ vals,
+                                                      const uint32_t *__restrict__ seg_start, uint32_t *counters,
+                                                      int seg_slot, int big_slot, uint4 *big, float *out) {
     if (seg >= counters[seg_slot]) return;
     const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
     if (s1 - s0 > kBigCell) {
-        big[atomicAdd(&counters[big_slot], 1u)] = seg;
+        big[atomicAdd(&counters[big_slot], 1u)] = make_uint4(seg, s0, s1, 0u);   // (the bounds ride along: one dependent load less there)
         return;
     }
     // eight points per trip: the index loads, then the coordinate loads, are issued together (a cell is a chain of
@@ -403,11 +426,9 @@ __host__ __device__ inline float add_repeat_f32(float s, float x, uint32_t m) {
 // identical samples (the sensor origin, once per beam) without touching their data.
 constexpr uint32_t kChunk = 512;
 
-__global__ __launch_bounds__(64) void dm_big_chunks(const float *__restrict__ p, const uint32_t *__restrict__ vals,
-                                                        const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan,
-                                                        const uint32_t *__restrict__ counters, int valid_slot, uint4 *desc) {
-    const uint32_t q = blockIdx.x;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void big_chunks_wave(const uint32_t q, const int lane, const float *__restrict__ p, const uint32_t *__restrict__ vals,
+                                                const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan,
+                                                const uint32_t *__restrict__ counters, int valid_slot, uint4 *desc) {
     const uint32_t i0 = q * kChunk;
     uint4 d = make_uint4(0u, 0u, 0u, 0u);
     if (i0 + kChunk <= counters[valid_slot]) {
@@ -434,119 +455,181 @@ __global__ __launch_bounds__(64) void dm_big_chunks(const float *__restrict__ p,
     if (lane == 0) desc[q] = d;
 }
 
-// Large cells: one wave per (cell, coordinate).  The sum must stay a serial fp32 chain, so the wave turns it
-// into one dependent VALU op per point: lane j holds point j of a 64-point batch and 64 steps of
-// `v = wave_shr1(v) + x` (DPP full-wave shift, lane 0 holds carry-in + x_0) leave the running prefix in
-// every lane — sum_{k} = sum_{k-1} + x_k exactly as the sequential loop.  Loads run two batches ahead.  Runs of
-// identical values are summed in closed form (add_repeat_f32); chunks that dm_big_chunks found uniform extend the
-// pending run without loading anything.
+// The ordinary cells' centroids and the chunk descriptors in ONE launch (round 5: both only need the segment scan; two launches
+// before): the last main_wgs workgroups take one cell per thread, the workgroups before them one chunk per wave.
+__global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict__ p, const uint32_t *__restrict__ vals,
+                                                        const uint32_t *__restrict__ seg_start, uint32_t *counters,
+                                                        int seg_slot, int big_slot, uint4 *big, float *out, uint32_t main_wgs,
+                                                        const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan,
+                                                        int valid_slot, uint32_t nchunk, uint4 *desc) {
+    // (the chunk waves first: their short gather chains then run beside the cell threads instead of forming the launch's tail)
+    const uint32_t chunk_wgs = gridDim.x - main_wgs;
+    if (blockIdx.x >= chunk_wgs) {
+        grid_centroids_thread((blockIdx.x - chunk_wgs) * blockDim.x + threadIdx.x, p, vals, seg_start, counters, seg_slot, big_slot, big, out);
+        return;
+    }
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (q < nchunk) big_chunks_wave(q, (int)(threadIdx.x & 63u), p, vals, flag, scan, counters, valid_slot, desc);
+}
+
+// Large cells: one wave per cell.  The sums must stay serial fp32 chains in cloud order, so the wave loads 512 points at a time
+// (coalesced index loads one trip ahead, then 24 gathers), parks their coordinates in LDS, and lanes 0..2 each walk one
+// coordinate's values, 64 at a time, with dependent adds — sum_k = sum_{k-1} + x_k exactly as the sequential loop, three chains
+// in the same instructions.  Runs of identical values are summed in closed form (add_repeat_f32, per coordinate); chunks that
+// dm_big_chunks found uniform in all three coordinates extend the pending runs without loading anything.
+// Round 5, what the earlier form (rounds 2-4) taught: it ran the chain across the lanes with a full-wave DPP shift, one wave per
+// (cell, coordinate), every 64-step chain and all 8 sub-batches of a trip unrolled — 3 000 VALU lines of straight-line code that a wave
+// executes once or twice.  The launch took 41 us at 1 300 large cells whatever the chain or the loads cost (LDS chain: 54 us;
+// unpredicated loads: the same): a wave that runs cold straight-line code is bound by instruction fetch, not by the instructions.
+// This form keeps the sub-batch and chain loops rolled (the whole kernel is a few KB).
+constexpr uint32_t kBigTrip = 512;
 __global__ __launch_bounds__(64) void dm_grid_centroids_big(const float *__restrict__ p, const uint32_t *__restrict__ vals,
                                                            const uint32_t *__restrict__ seg_start,
                                                            const uint32_t *__restrict__ counters, int big_slot,
-                                                           const uint32_t *__restrict__ big, const uint4 *__restrict__ desc,
+                                                           const uint4 *__restrict__ big, const uint4 *__restrict__ desc,
                                                            float *out) {
+    __shared__ __attribute__((aligned(16))) float buf[3][kBigTrip];
     const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.y;
+    const int c = lane < 3 ? lane : 0;   // the coordinate this lane sums (lanes >= 3 shadow lane 0, their results are dropped)
     const uint32_t nbig = counters[big_slot];
     for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
-        const uint32_t seg = big[i];
-        const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
+        const uint4 item = big[i];
+        const uint32_t seg = item.x, s0 = item.y, s1 = item.z;
         float s = 0.f;
-        uint32_t run_x = 0u, run_len = 0u;  // pending run of identical values (bits, count)
+        uint32_t run_x = 0u, run_len = 0u;  // pending run of identical values of coordinate c (bits, count)
 
-        // generic path over sorted positions [lo, hi): kSub sub-batches of 64 points per trip; indices are fetched two
-        // trips ahead, values one trip ahead, so one memory round trip overlaps kSub * 64 chain steps
+        // generic path over sorted positions [lo, hi), 512 per trip.  Positions behind the stretch are clamped to its last one
+        // instead of predicated (a predicated load is a branch, and branches between the loads serialise their round trips).
         auto process = [&](const uint32_t lo, const uint32_t hi) {
             if (lo >= hi) return;
-            constexpr int kSub = 8;
-            constexpr uint32_t kTrip = 64u * kSub;
-            uint32_t vi[kSub];
-            float xn[kSub];
+            const uint32_t last = hi - 1u;
+            uint32_t vi[8];
 #pragma unroll
-            for (int u = 0; u < kSub; ++u) {
-                const uint32_t j = lo + 64u * u + lane;
-                const uint32_t v0 = j < hi ? vals[j] : 0u;
-                xn[u] = j < hi ? p[3 * (size_t)v0 + c] : 0.f;
-            }
+            for (int u = 0; u < 8; ++u) vi[u] = vals[min(lo + 64u * u + lane, last)];
+            for (uint32_t b = lo; b < hi; b += kBigTrip) {
+                float xc[8], yc[8], zc[8];
 #pragma unroll
-            for (int u = 0; u < kSub; ++u) {
-                const uint32_t j = lo + kTrip + 64u * u + lane;
-                vi[u] = j < hi ? vals[j] : 0u;
-            }
-            for (uint32_t b = lo; b < hi; b += kTrip) {
-                float xc[kSub];
-#pragma unroll
-                for (int u = 0; u < kSub; ++u) xc[u] = xn[u];
-#pragma unroll
-                for (int u = 0; u < kSub; ++u) {
-                    const uint32_t j1 = b + kTrip + 64u * u + lane, j2 = j1 + kTrip;
-                    xn[u] = j1 < hi ? p[3 * (size_t)vi[u] + c] : 0.f;
-                    vi[u] = j2 < hi ? vals[j2] : 0u;
+                for (int u = 0; u < 8; ++u) {
+                    xc[u] = p[3 * (size_t)vi[u]];
+                    yc[u] = p[3 * (size_t)vi[u] + 1];
+                    zc[u] = p[3 * (size_t)vi[u] + 2];
                 }
 #pragma unroll
-                for (int u = 0; u < kSub; ++u) {
-                    const uint32_t bu = b + 64u * u;
-                    if (bu >= hi) break;
-                    const uint32_t nb = min(64u, hi - bu);
-                    // a sub-batch of identical values extends the pending run (summed in closed form when it ends)
-                    const uint32_t xfirst = __builtin_amdgcn_readfirstlane(__float_as_uint(xc[u]));
-                    const bool uniform = __ballot((uint32_t)lane >= nb || __float_as_uint(xc[u]) == xfirst) == ~0ull;
-                    if (uniform && (run_len == 0u || xfirst == run_x)) {
-                        run_x = xfirst;
-                        run_len += nb;
-                        continue;
-                    }
-                    if (run_len) {
-                        s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
-                        run_len = 0;
-                    }
-                    if (uniform) {
-                        run_x = xfirst;
-                        run_len = nb;
-                        continue;
-                    }
-                    // lane 0 takes the carry-in first: (s + x_0) + x_1 + ... is the sequential order
-                    const float x0 = lane == 0 ? s + xc[u] : xc[u];
-                    float v = x0;
+                for (int u = 0; u < 8; ++u) vi[u] = vals[min(b + kBigTrip + 64u * u + lane, last)];   // the next trip's indices
+                __syncthreads();   // (one wave per workgroup: the buffer's previous readers are done)
 #pragma unroll
-                    for (int t = 0; t < 64; ++t) {
-                        // wave_shr:1 with bound_ctrl — lane j receives lane j-1, lane 0 receives 0 (0 + x is exact);
-                        // folds into one v_add_f32_dpp per step
-                        const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
-                        v = sh + x0;
+                for (int u = 0; u < 8; ++u) {
+                    buf[0][64 * u + lane] = xc[u];
+                    buf[1][64 * u + lane] = yc[u];
+                    buf[2][64 * u + lane] = zc[u];
+                }
+                __syncthreads();
+                const uint32_t nsub = (min(kBigTrip, hi - b) + 63u) / 64u;
+#pragma unroll 1
+                for (uint32_t u = 0; u < nsub; ++u) {
+                    const uint32_t nb = min(64u, hi - (b + 64u * u));
+                    const bool in = (uint32_t)lane < nb;
+                    const uint32_t xb = __float_as_uint(buf[0][64u * u + lane]), yb = __float_as_uint(buf[1][64u * u + lane]),
+                                   zb = __float_as_uint(buf[2][64u * u + lane]);
+                    // per coordinate: a sub-batch of identical values extends the pending run (summed in closed form when it ends)
+                    const uint32_t fx = __builtin_amdgcn_readfirstlane(xb), fy = __builtin_amdgcn_readfirstlane(yb),
+                                   fz = __builtin_amdgcn_readfirstlane(zb);
+                    const bool ux = __ballot(!in || xb == fx) == ~0ull, uy = __ballot(!in || yb == fy) == ~0ull,
+                               uz = __ballot(!in || zb == fz) == ~0ull;
+                    const bool uniform = c == 0 ? ux : (c == 1 ? uy : uz);
+                    const uint32_t first = c == 0 ? fx : (c == 1 ? fy : fz);
+                    bool chain = false;
+                    if (uniform && (run_len == 0u || first == run_x)) {
+                        run_x = first;
+                        run_len += nb;
+                    } else {
+                        if (run_len) {
+                            s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
+                            run_len = 0;
+                        }
+                        if (uniform) {
+                            run_x = first;
+                            run_len = nb;
+                        } else {
+                            chain = true;
+                        }
                     }
-                    s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)nb - 1));
+                    if (chain) {   // (the values behind the stretch's end are the clamped last point's: only nb of the 64 are added)
+                        const float *row = &buf[c][64u * u];
+                        uint32_t j = 0;
+#pragma unroll 2
+                        for (; j + 4u <= nb; j += 4u) {
+                            const float4 q = *reinterpret_cast<const float4 *>(row + j);
+                            s = s + q.x;
+                            s = s + q.y;
+                            s = s + q.z;
+                            s = s + q.w;
+                        }
+#pragma unroll 1
+                        for (; j < nb; ++j) s = s + row[j];
+                    }
                 }
             }
         };
 
-        // head up to the first chunk boundary, whole chunks by descriptor, tail
+        // Head up to the first chunk boundary, whole chunks by descriptor, tail — but a stretch is only handed to process()
+        // when a uniform chunk interrupts it (every process() call starts with two dependent memory round trips — indices,
+        // then coordinates).  Descriptors: 64 per load, the next load in flight.
         const uint32_t a = min(s1, (s0 + kChunk - 1u) & ~(kChunk - 1u));
         const uint32_t z = max(a, s1 & ~(kChunk - 1u));
-        process(s0, a);
-        for (uint32_t q0 = a / kChunk; q0 < z / kChunk; q0 += 64u) {
-            const uint32_t nq = min(64u, z / kChunk - q0);
-            uint4 dl = make_uint4(0u, 0u, 0u, 0u);
-            if ((uint32_t)lane < nq) dl = desc[q0 + lane];  // 64 descriptors per load
-            const uint32_t dflag = (dl.x >> c) & 1u, dval = c == 0 ? dl.y : (c == 1 ? dl.z : dl.w);
+        uint32_t cur_lo = s0, cur_hi = a;   // pending stretch (sorted positions)
+        const uint32_t qa = a / kChunk, qz = z / kChunk;
+        uint4 dl_next = make_uint4(0u, 0u, 0u, 0u);
+        if (qa + (uint32_t)lane < qz) dl_next = desc[qa + lane];
+        for (uint32_t q0 = qa; q0 < qz; q0 += 64u) {
+            const uint32_t nq = min(64u, qz - q0);
+            const uint4 dl = dl_next;
+            dl_next = make_uint4(0u, 0u, 0u, 0u);
+            if (q0 + 64u + (uint32_t)lane < qz) dl_next = desc[q0 + 64u + lane];
+            // (scalar view of the 64 flags: a chunk counts when all three coordinates are uniform in it)
+            const unsigned long long fmask = __ballot((dl.x & 7u) == 7u);
+            // The sensor's own voxel: every chunk of the round uniform, and with the same values — the round extends the runs in
+            // one step.  (Chunk by chunk, the loop below is ~60 instructions of ONE wave per chunk: 0.25 us each, 46 us for the
+            // 185 chunks of a 200 000-ray scan — measured in round 5; it was the whole launch.)
+            {
+                const bool inq = (uint32_t)lane < nq;
+                const uint32_t ax = __builtin_amdgcn_readfirstlane(dl.y), ay = __builtin_amdgcn_readfirstlane(dl.z),
+                               az = __builtin_amdgcn_readfirstlane(dl.w);
+                const bool all_same = __ballot(!inq || ((dl.x & 7u) == 7u && dl.y == ax && dl.z == ay && dl.w == az)) == ~0ull;
+                if (all_same) {   // (uniform over the wave)
+                    process(cur_lo, cur_hi);   // (no-op when empty)
+                    const uint32_t xb = c == 0 ? ax : (c == 1 ? ay : az);
+                    if (run_len && xb != run_x) {
+                        s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
+                        run_len = 0;
+                    }
+                    run_x = xb;
+                    run_len += nq * kChunk;
+                    cur_lo = cur_hi = (q0 + nq) * kChunk;
+                    continue;
+                }
+            }
+#pragma unroll 1
             for (uint32_t k = 0; k < nq; ++k) {
-                const uint32_t f = __builtin_amdgcn_readlane(dflag, (int)k);
-                if (f) {
-                    const uint32_t xb = __builtin_amdgcn_readlane(dval, (int)k);
+                if ((fmask >> k) & 1ull) {
+                    process(cur_lo, cur_hi);   // (no-op when empty)
+                    const uint32_t xb = c == 0 ? __builtin_amdgcn_readlane(dl.y, (int)k)
+                                               : (c == 1 ? __builtin_amdgcn_readlane(dl.z, (int)k) : __builtin_amdgcn_readlane(dl.w, (int)k));
                     if (run_len && xb != run_x) {
                         s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
                         run_len = 0;
                     }
                     run_x = xb;
                     run_len += kChunk;
+                    cur_lo = cur_hi = (q0 + k + 1u) * kChunk;
                 } else {
-                    process((q0 + k) * kChunk, (q0 + k + 1u) * kChunk);
+                    cur_hi = (q0 + k + 1u) * kChunk;
                 }
             }
         }
-        process(z, s1);
+        process(cur_lo, s1);
         if (run_len) s = add_repeat_f32(s, __uint_as_float(run_x), run_len);
-        if (lane == 0) out[3 * (size_t)seg + c] = s / (float)(s1 - s0);
+        if (lane < 3) out[3 * (size_t)seg + lane] = s / (float)(s1 - s0);
     }
 }
 
@@ -996,7 +1079,7 @@ __global__ __launch_bounds__(256) void dm_members_write(const int4 *__restrict__
                                                        const uint32_t *__restrict__ off, uint32_t *keys, uint32_t *vals,
                                                        uint32_t *counters, int32_t *grid, uint32_t ncid) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    // (also: grid[cid] = -1 for dm_geo_fill, which runs two launches later — a memset launch less)
+    // (also: grid[cid] = -1 for dm_gather_geo, which runs two launches later — a memset launch less)
     for (uint32_t c = i; c < ncid; c += gridDim.x * blockDim.x) grid[c] = -1;
     if (i >= n) return;
     const int4 cd = code[i];
@@ -1016,23 +1099,57 @@ __global__ __launch_bounds__(256) void dm_members_write(const int4 *__restrict__
             }
 }
 
-__global__ __launch_bounds__(256) void dm_gather_train(const float4 *__restrict__ xy, const uint32_t *__restrict__ vals,
-                                                      uint32_t n, float4 *train) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) train[i] = xy[vals[i]];
-}
+// dm_members_write as the key source of the membership sort's histogram launch (one launch less)
+struct MembersSrc {
+    const int4 *code;
+    PartArgs a;
+    const uint32_t *off;
+    uint32_t *keys, *vals, *counters;
+    int32_t *grid;
+    uint32_t ncid;
+    __device__ __forceinline__ void begin(uint32_t gtid, uint32_t gsize) const {
+        for (uint32_t c = gtid; c < ncid; c += gsize) grid[c] = -1;   // (for dm_gather_geo, two launches later)
+    }
+    template <class Add>
+    __device__ __forceinline__ void operator()(uint32_t i, Add &add) const {
+        const int4 cd = code[i];
+        const int nx = cd.w & 3, ny = (cd.w >> 2) & 3, nz = (cd.w >> 4) & 3;
+        uint32_t o = off[i];
+        for (int u = 0; u < nx; ++u)
+            for (int v = 0; v < ny; ++v)
+                for (int w = 0; w < nz; ++w) {
+                    uint32_t cid = 0;
+                    if (!grid_cid(a, cd.x + u, cd.y + v, cd.z + w, cid)) {
+                        atomicOr(&counters[kCntError], 1u);  // a point outside the index grid: cannot happen
+                        cid = 0;
+                    }
+                    keys[o] = cid;
+                    vals[o] = i;
+                    add(cid);
+                    ++o;
+                }
+    }
+};
 
-// grid[cid] = segment (training block) index; -1 elsewhere (memset before)
-// also counts the trained blocks (= blocks with points that are in the candidate list) in counters[kCntTrained]
-__global__ __launch_bounds__(256) void dm_geo_fill(const uint32_t *__restrict__ seg_key, uint32_t *counters, PartArgs a,
-                                                  int32_t *grid) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= counters[kCntGeo]) return;
-    const uint32_t cid = seg_key[s];
-    grid[cid] = (int32_t)s;
-    const uint32_t z = cid % (uint32_t)a.gn[2], y = (cid / (uint32_t)a.gn[2]) % (uint32_t)a.gn[1],
-                   x = cid / ((uint32_t)a.gn[2] * (uint32_t)a.gn[1]);
-    if (a.mult[0][x] && a.mult[1][y] && a.mult[2][z]) atomicAdd(&counters[kCntTrained], 1u);
+// Two jobs of one index space in one launch (round 5; dm_gather_train + dm_geo_fill before):
+//   i < n:                  train[i] = xy[vals[i]]   (the training rows in CSR order; train == nullptr: BGK-L gathers rows elsewhere)
+//   i < counters[kCntGeo]:  grid[cid] = segment (training block) index — -1 elsewhere, written by dm_members_write — and
+//                           counters[kCntTrained] += blocks with points that are in the candidate list (one atomic per wave)
+__global__ __launch_bounds__(256) void dm_gather_geo(const float4 *__restrict__ xy, const uint32_t *__restrict__ vals, uint32_t n,
+                                                    float4 *train, const uint32_t *__restrict__ seg_key, uint32_t *counters,
+                                                    PartArgs a, int32_t *grid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (train && i < n) train[i] = xy[vals[i]];
+    bool trained = false;
+    if (i < counters[kCntGeo]) {
+        const uint32_t cid = seg_key[i];
+        grid[cid] = (int32_t)i;
+        const uint32_t z = cid % (uint32_t)a.gn[2], y = (cid / (uint32_t)a.gn[2]) % (uint32_t)a.gn[1],
+                       x = cid / ((uint32_t)a.gn[2] * (uint32_t)a.gn[1]);
+        trained = a.mult[0][x] && a.mult[1][y] && a.mult[2][z];
+    }
+    const unsigned long long m = __ballot(trained);
+    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(m));
 }
 
 // ---- block-sharded insert: every rank builds the same test list, predicts a contiguous range of it ----
@@ -1062,40 +1179,6 @@ __global__ void dm_shard_leaf_bounds(const uint32_t *__restrict__ bounds, const 
     const uint32_t q = threadIdx.x;
     if (q <= world) leaf_bounds[q] = leaf_off[bounds[q]];
 }
-// work counters of one pass: sum over test blocks of their neighbourhood size (train_reads) and of
-// neighbourhood size x leaf count (pair_evals), accumulated as 64-bit words inside the counter block
-__global__ __launch_bounds__(256) void dm_test_stats(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf,
-                                                    uint32_t n_test, uint32_t *counters) {
-    // grid-stride partial sums, one pair of 64-bit atomics per workgroup (a few dozen in all: the per-wave version
-    // serialised ~1300 atomics on two addresses)
-    __shared__ unsigned long long s_w[4], s_pw[4];
-    unsigned long long *acc_reads = reinterpret_cast<unsigned long long *>(counters + kCntTrainReads);
-    unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
-    unsigned long long w = 0, pw = 0;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_test; t += gridDim.x * blockDim.x) {
-        const unsigned long long wt = test_key_weight(t_key[t]);
-        w += wt;
-        pw += wt * nleaf[t];
-    }
-    for (int o = 32; o >= 1; o >>= 1) {
-        w += __shfl_xor(w, o);
-        pw += __shfl_xor(pw, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_w[threadIdx.x >> 6] = w;
-        s_pw[threadIdx.x >> 6] = pw;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        pw = s_pw[0] + s_pw[1] + s_pw[2] + s_pw[3];
-        if (w | pw) {
-            atomicAdd(acc_reads, w);
-            atomicAdd(acc_pairs, pw);
-        }
-    }
-}
-
 struct CandArgs {
     PartArgs part;
     const int *seq[3];    // float-stepped candidate sequence per axis (biased indices, repeats kept)
@@ -1162,10 +1245,79 @@ __global__ __launch_bounds__(256) void dm_test_compact(const uint32_t *__restric
     if (e + 1 == n_entries) counters[kCntTest] = scan[e] + flag[e];
 }
 
-// per test block (heaviest first): key, centre, neighbour table (training-block index or -1)
+// dm_test_compact as the key source of the test list's sort (its histogram launch; the pass behind it reads the list's length
+// from counters[kCntTest], so neither waits for the host to learn it)
+struct TestCompactSrc {
+    const uint32_t *flag, *scan, *weight;
+    uint32_t n_entries;
+    uint32_t *t_key, *t_entry, *counters;
+    __device__ __forceinline__ void begin(uint32_t, uint32_t) const {}
+    template <class Add>
+    __device__ __forceinline__ void operator()(uint32_t e, Add &add) const {
+        if (flag[e]) {
+            const uint32_t k = test_key(weight[e]);
+            t_key[scan[e]] = k;
+            t_entry[scan[e]] = e;
+            add(k);
+        }
+        if (e + 1 == n_entries) counters[kCntTest] = scan[e] + flag[e];
+    }
+};
+
+// ---- block table (open addressing, linear probing) and pool ------------------------------------------------
+constexpr long long kEmptyKey = -1;
+
+__device__ __forceinline__ uint32_t hash_key64(long long k, uint32_t mask) {
+    unsigned long long x = (unsigned long long)k;
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    return (uint32_t)x & mask;
+}
+
+// find-or-create; new blocks take consecutive pool slots [old count, new count)
+struct TableArgs {
+    long long *tab_key;
+    uint32_t *tab_val;
+    uint32_t mask;
+    uint32_t *n_blocks;
+    long long *blk_key;
+};
+__device__ __forceinline__ uint32_t table_find_or_create(const TableArgs &tb, long long k) {
+    uint32_t h = hash_key64(k, tb.mask);
+    for (;;) {
+        const long long cur = tb.tab_key[h];
+        // the creator may not have published the slot yet only if another thread of THIS launch holds the
+        // same key — keys of one pass are distinct, so the value is from an earlier launch
+        if (cur == k) return tb.tab_val[h];
+        if (cur == kEmptyKey) {
+            const long long prev = (long long)atomicCAS((unsigned long long *)&tb.tab_key[h], (unsigned long long)kEmptyKey, (unsigned long long)k);
+            if (prev == kEmptyKey) {
+                const uint32_t s = atomicAdd(tb.n_blocks, 1u);
+                tb.tab_val[h] = s;
+                tb.blk_key[s] = k;
+                return s;
+            }
+            if (prev == k) return tb.tab_val[h];
+        }
+        h = (h + 1) & tb.mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void dm_table_insert(const long long *__restrict__ keys, const uint32_t *__restrict__ counters,
+                                                      long long *tab_key, uint32_t *tab_val, uint32_t mask,
+                                                      uint32_t *n_blocks, long long *blk_key, uint32_t *slot) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= counters[kCntTest]) return;
+    const TableArgs tb = {tab_key, tab_val, mask, n_blocks, blk_key};
+    slot[t] = table_find_or_create(tb, keys[t]);
+}
+
+// per test block (heaviest first): key, centre, neighbour table (training-block index or -1), and the block's pool slot
+// (find or create, bgkoctomap.cpp:298-305: the same thread-per-block launch did it as a kernel of its own before round 5)
 __global__ __launch_bounds__(256) void dm_test_build(CandArgs a, const int32_t *__restrict__ grid,
                                                     const uint32_t *__restrict__ t_entry, const uint32_t *__restrict__ counters,
-                                                    long long *t_blockkey, float *center, int32_t *nbr) {
+                                                    long long *t_blockkey, float *center, int32_t *nbr, TableArgs tb, uint32_t *slot) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= counters[kCntTest]) return;
     const uint32_t e = t_entry[t];
@@ -1173,7 +1325,9 @@ __global__ __launch_bounds__(256) void dm_test_build(CandArgs a, const int32_t *
                    ka = e / ((uint32_t)a.nseq[2] * (uint32_t)a.nseq[1]);
     const int ix = a.seq[0][ka], iy = a.seq[1][kb], iz = a.seq[2][kc];
     const PartArgs &p = a.part;
-    t_blockkey[t] = ((long long)ix << 40) | ((long long)iy << 20) | (long long)iz;
+    const long long key = ((long long)ix << 40) | ((long long)iy << 20) | (long long)iz;
+    t_blockkey[t] = key;
+    slot[t] = table_find_or_create(tb, key);
     center[3 * (size_t)t] = axis_center(ix, p.bs);
     center[3 * (size_t)t + 1] = axis_center(iy, p.bs);
     center[3 * (size_t)t + 2] = axis_center(iz, p.bs);
@@ -1191,51 +1345,7 @@ __global__ __launch_bounds__(256) void dm_test_build(CandArgs a, const int32_t *
     }
 }
 
-// ---- block table (open addressing, linear probing) and pool ------------------------------------------------
-constexpr long long kEmptyKey = -1;
-
-__device__ __forceinline__ uint32_t hash_key64(long long k, uint32_t mask) {
-    unsigned long long x = (unsigned long long)k;
-    x ^= x >> 33;
-    x *= 0xff51afd7ed558ccdull;
-    x ^= x >> 33;
-    return (uint32_t)x & mask;
-}
-
-// find-or-create; new blocks take consecutive pool slots [old count, new count)
-__global__ __launch_bounds__(256) void dm_table_insert(const long long *__restrict__ keys, const uint32_t *__restrict__ counters,
-                                                      long long *tab_key, uint32_t *tab_val, uint32_t mask,
-                                                      uint32_t *n_blocks, long long *blk_key, uint32_t *slot) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= counters[kCntTest]) return;
-    const long long k = keys[t];
-    uint32_t h = hash_key64(k, mask);
-    for (;;) {
-        const long long cur = tab_key[h];
-        if (cur == k) {
-            // the creator may not have published the slot yet only if another thread of THIS launch holds the
-            // same key — keys of one pass are distinct, so the value is from an earlier launch
-            slot[t] = tab_val[h];
-            return;
-        }
-        if (cur == kEmptyKey) {
-            const long long prev = (long long)atomicCAS((unsigned long long *)&tab_key[h], (unsigned long long)kEmptyKey, (unsigned long long)k);
-            if (prev == kEmptyKey) {
-                const uint32_t s = atomicAdd(n_blocks, 1u);
-                tab_val[h] = s;
-                blk_key[s] = k;
-                slot[t] = s;
-                return;
-            }
-            if (prev == k) {
-                slot[t] = tab_val[h];
-                return;
-            }
-        }
-        h = (h + 1) & mask;
-    }
-}
-
+// ---- block table: rebuild, search, pool ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void dm_table_rebuild(const long long *__restrict__ blk_key, uint32_t n, long long *tab_key,
                                                        uint32_t *tab_val, uint32_t mask) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1319,12 +1429,63 @@ __device__ __forceinline__ void covering_leaf(const uint8_t *__restrict__ Sb, ui
 
 // Leaves of the test blocks in LeafIterator order (descending DFS = descending finest-cell interval).
 // One wave per block, 64 finest cells per trip from the top; kEmit = false counts, true writes.
+// Round 5 (launch chain): the counting launch also gives the blocks the pass created — slots >= old_blocks, each exactly
+// once in a pass's list — their default nodes (Occupancy() = {prior A, prior B, UNKNOWN, not classified}; dm_pool_init was a
+// launch of its own), and such a block's leaves are its finest cells; the emitting launch carries the pass's work counters
+// in `stat_wgs` extra workgroups behind the block waves (dm_test_stats was a launch of its own): sum over test blocks of
+// their neighbourhood size and of neighbourhood size x leaf count, 64-bit words inside the counter block.
+struct LeafExtra {
+    uint32_t old_blocks;    // count launch: blocks with slot >= old_blocks are new (0xFFFFFFFF: none are initialised here)
+    float a0, b0;
+    float *A_w, *B_w;       // (writable views of the pool for the count launch)
+    uint8_t *S_w;
+    const uint32_t *t_key;  // emit launch: keys of the test blocks (weights), or nullptr: no work counters
+    uint32_t *counters_w;
+    uint32_t main_wgs;      // emit launch: workgroups that hold block waves; the rest accumulate the counters
+};
+
+__device__ __forceinline__ void test_stats_wg(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf, uint32_t n_test,
+                                              uint32_t *counters, uint32_t wg, uint32_t n_wg) {
+    // grid-stride partial sums, one pair of 64-bit atomics per workgroup (a few dozen in all: the per-wave version
+    // serialised ~1300 atomics on two addresses)
+    __shared__ unsigned long long s_w[4], s_pw[4];
+    unsigned long long *acc_reads = reinterpret_cast<unsigned long long *>(counters + kCntTrainReads);
+    unsigned long long *acc_pairs = reinterpret_cast<unsigned long long *>(counters + kCntPairEvals);
+    unsigned long long w = 0, pw = 0;
+    for (uint32_t t = wg * blockDim.x + threadIdx.x; t < n_test; t += n_wg * blockDim.x) {
+        const unsigned long long wt = test_key_weight(t_key[t]);
+        w += wt;
+        pw += wt * nleaf[t];
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        w += __shfl_xor(w, o);
+        pw += __shfl_xor(pw, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = w;
+        s_pw[threadIdx.x >> 6] = pw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        pw = s_pw[0] + s_pw[1] + s_pw[2] + s_pw[3];
+        if (w | pw) {
+            atomicAdd(acc_reads, w);
+            atomicAdd(acc_pairs, pw);
+        }
+    }
+}
+
 template <bool kEmit>
 __global__ __launch_bounds__(256) void dm_leaves(const uint32_t *__restrict__ slot, const uint32_t *__restrict__ counters,
                                                 const uint8_t *__restrict__ S, const float *__restrict__ A,
                                                 const float *__restrict__ B, uint32_t npb, uint32_t block_depth,
                                                 uint32_t *nleaf, const uint32_t *__restrict__ leaf_off, uint32_t *leaf_key,
-                                                float *alpha, float *beta, uint32_t *leaf_node) {
+                                                float *alpha, float *beta, uint32_t *leaf_node, LeafExtra x) {
+    if (kEmit && x.t_key && blockIdx.x >= x.main_wgs) {   // (uniform over the workgroup)
+        test_stats_wg(x.t_key, nleaf, counters[kCntTest], x.counters_w, blockIdx.x - x.main_wgs, gridDim.x - x.main_wgs);
+        return;
+    }
     const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) nleaf[counters[kCntTest]] = 0;   // the scan runs over n_test + 1 counts
@@ -1332,6 +1493,15 @@ __global__ __launch_bounds__(256) void dm_leaves(const uint32_t *__restrict__ sl
     const size_t base = (size_t)slot[t] * npb;
     const uint8_t *Sb = S + base;
     const uint32_t dl = block_depth - 1, ncell = 1u << (3 * dl);
+    if (!kEmit && slot[t] >= x.old_blocks) {   // created by this pass: default nodes, every finest cell a leaf
+        for (uint32_t i = lane; i < npb; i += 64) {
+            x.A_w[base + i] = x.a0;
+            x.B_w[base + i] = x.b0;
+            x.S_w[base + i] = kStateUnknown;
+        }
+        if (lane == 0) nleaf[t] = ncell;
+        return;
+    }
     uint32_t out = kEmit ? leaf_off[t] : 0u;
     for (uint32_t top = ncell; top > 0; top -= min(top, 64u)) {
         const bool in = (uint32_t)lane < top;
@@ -1422,6 +1592,112 @@ __global__ __launch_bounds__(256) void dm_prune(const uint32_t *__restrict__ slo
             B[base + i] = B[base + sr];
         }
     }
+}
+
+// dm_commit_prune's arrival words: top level at d_mm[kArriveBase], bucket k at d_mm[kArriveBase + kArriveStride (k + 1)] — a 128-byte
+// line each (atomics on one line serialise like atomics on one word)
+constexpr uint32_t kArriveBuckets = 64, kArriveStride = 32, kArriveBase = 32, kMmWords = kArriveBase + kArriveStride * (1 + kArriveBuckets);
+constexpr uint32_t kCommitPruneWgs = 2048;   // workgroups of the launch at most (each one arrival): grid-stride over the test blocks
+
+// Write-back + prune of a pass in ONE launch (round 5; single-pass scans: a pass's test blocks are distinct, and a block's
+// leaves live in that block only, so the wave that owns block t commits the leaves [leaf_off[t], leaf_off[t + 1]) and prunes
+// the block behind them).  The committed states go to the pool AND to the wave's LDS copy of the block, the sibling test runs on
+// that copy; alpha / beta of a collapsed chain are read back from nodes this wave may just have written — after its stores have
+// retired (vmcnt) and past the vector L1 (device-scope loads).  Bit for bit what dm_commit + dm_prune leave.  `done` (1 + kArriveBuckets words, zero
+// between launches): the last workgroup to finish also publishes the counter block (mailbox != nullptr) instead of a
+// dm_publish_counters launch behind this one.
+__global__ __launch_bounds__(256) void dm_commit_prune(const uint32_t *__restrict__ slot, uint32_t n_test,
+                                                      const uint32_t *__restrict__ leaf_off, const uint32_t *__restrict__ leaf_node,
+                                                      const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                      const uint8_t *__restrict__ state, float *A, float *B, uint8_t *S, uint32_t npb,
+                                                      uint32_t block_depth, const uint32_t *counters, uint32_t *done,
+                                                      volatile uint32_t *mailbox, uint32_t mailbox_seq) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dm_prune_smem[];
+    __shared__ uint32_t s_last;
+    const uint32_t wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t t = blockIdx.x * (blockDim.x >> 6) + wv; t < n_test; t += gridDim.x * (blockDim.x >> 6)) {
+        uint8_t *sS = dm_prune_smem + wv * prune_lds_stride(npb);
+        uint16_t *src = (uint16_t *)(sS + ((npb + 1u) & ~1u));
+        const size_t base = (size_t)slot[t] * npb;
+        for (uint32_t i = lane; i < npb; i += 64) {
+            sS[i] = S[base + i];
+            src[i] = (uint16_t)i;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t l0 = leaf_off[t], l1 = leaf_off[t + 1];
+        for (uint32_t l = l0 + lane; l < l1; l += 64) {
+            const uint8_t st = state[l];
+            if (!(st & 0x80u)) continue;
+            const uint32_t node = leaf_node[l];
+            const uint8_t ns = (uint8_t)((st & 3u) | kClassifiedBit);
+            A[node] = alpha[l];
+            B[node] = beta[l];
+            S[node] = ns;
+            sS[node - (uint32_t)base] = ns;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool any = false;
+        for (int depth = (int)block_depth - 1; depth > 0; --depth) {
+            const uint32_t lb = dm_layer_base(depth), pb = dm_layer_base(depth - 1), ngroup = 1u << (3 * (depth - 1));
+            for (uint32_t g = lane; g < ngroup; g += 64) {
+                const uint32_t c0 = lb + 8u * g;
+                const uint8_t st0 = sS[c0] & 7u;
+                if (st0 == kStatePruned || st0 == kStateUnknown) continue;
+                bool same = true;
+#pragma unroll
+                for (int c = 1; c < 8; ++c) same &= (sS[c0 + c] & 7u) == st0;
+                if (!same) continue;
+                const uint32_t par = pb + g;
+                sS[par] = (uint8_t)((sS[par] & kClassifiedBit) | st0);
+                src[par] = src[c0];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sS[c0 + c] = (uint8_t)((sS[c0 + c] & ~7u) | kStatePruned);
+                any = true;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (__any(any)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's committed alpha / beta have left for the L2
+            for (uint32_t i = lane; i < npb; i += 64) {
+                S[base + i] = sS[i];
+                const uint32_t sr = src[i];
+                if (sr != i) {
+                    const uint32_t av = __hip_atomic_load((const uint32_t *)&A[base + sr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t bv = __hip_atomic_load((const uint32_t *)&B[base + sr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    A[base + i] = __uint_as_float(av);
+                    B[base + i] = __uint_as_float(bv);
+                }
+            }
+        }
+    }
+    if (!mailbox) return;   // (uniform)
+    // arrival in two levels — kArriveBuckets words, then one: ten thousand returning atomics on ONE address serialise at ~25 ns each
+    // (and so do atomics on one 128-byte line).  done[0] = top level, done[kArriveStride (1 + k)] = bucket k; all zero
+    // between launches (the last arrival of a level resets its word).
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (no release fence: on this multi-L2 part it writes the whole L2 back — 10 000 of them made this launch 270 us.  The mailbox only
+        // tells the host that every workgroup has got here; whatever reads the pool afterwards is stream-ordered behind the launch.)
+        const uint32_t k = blockIdx.x % kArriveBuckets;
+        const uint32_t expect_k = (gridDim.x - k + kArriveBuckets - 1u) / kArriveBuckets;
+        uint32_t last = 0u;
+        uint32_t *bucket = done + kArriveStride * (1u + k);
+        if (atomicAdd(bucket, 1u) + 1u == expect_k) {
+            *bucket = 0u;
+            const uint32_t expect_top = min(gridDim.x, kArriveBuckets);
+            if (atomicAdd(&done[0], 1u) + 1u == expect_top) {
+                done[0] = 0u;
+                last = 1u;
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last) dm_publish_wave(counters, mailbox, mailbox_seq);
 }
 
 

@@ -34,6 +34,8 @@ struct RadixArgs {
     const uint32_t *k_in, *v_in;
     uint32_t *k_out, *v_out;
     uint32_t n, n_pass, pass;
+    const uint32_t *n_dev;   // nullptr, or where the item count lives on the device (then n is only its bound: the launch was sized before
+                             // the host knew the count — the test-block list, devmap.hip run_pass)
     uint32_t begin_bit;   // pass p sorts on key bits [begin_bit + 8 p, + 8)
     uint32_t *counters;
     int err_slot;
@@ -66,9 +68,19 @@ __device__ __forceinline__ uint32_t rs_scan256(uint32_t v, uint32_t tid, uint32_
 }
 
 // digit counts of all passes in one sweep over the keys.  Also clears status array 0 for the first pass and the next
-// sort's histogram.
-__global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__restrict__ keys, uint32_t n, uint32_t n_pass, uint32_t begin_bit,
-                                                           RadixState st) {
+// sort's histogram.  Round 5 (launch chain): the keys come from a source functor — `src.begin(gtid, gsize)` once per thread,
+// then `src(item, add)` for every item of a grid-stride loop over n_items, calling add(key) for each key the item holds — so that
+// the kernel that PRODUCES the keys (voxel-grid cells, membership pairs) is this launch instead of one before it; n = keys in all.
+struct RsPlainKeys {
+    const uint32_t *keys;
+    __device__ __forceinline__ void begin(uint32_t, uint32_t) const {}
+    template <class Add>
+    __device__ __forceinline__ void operator()(uint32_t i, Add &add) const { add(keys[i]); }
+};
+
+template <class Src>
+__global__ __launch_bounds__(kRsThreads) void dm_radix_hist_src(Src src, uint32_t n, uint32_t n_items, uint32_t n_pass, uint32_t begin_bit,
+                                                               RadixState st) {
     __shared__ uint32_t h[4][256];
     const uint32_t tid = threadIdx.x;
     for (uint32_t p = 0; p < 4; ++p) h[p][tid] = 0;
@@ -77,9 +89,9 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
     if (blockIdx.x == 0 && tid < 4u) st.ticket[tid] = 0u;
     if (blockIdx.x < kRsHistCopies)
         for (uint32_t p = 0; p < 4; ++p) st.hist_next[(blockIdx.x * 4u + p) * 256u + tid] = 0u;
+    src.begin(blockIdx.x * kRsThreads + tid, gridDim.x * kRsThreads);
     __syncthreads();
-    for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n; i += gridDim.x * kRsThreads) {
-        const uint32_t k = keys[i];
+    auto add = [&](const uint32_t k) {
         const unsigned long long act = __ballot(true);
         for (uint32_t p = 0; p < n_pass; ++p) {
             // the high digits of grid-cell keys are the same for whole waves: one add instead of 64 colliding LDS atomics
@@ -90,7 +102,8 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist(const uint32_t *__re
                 atomicAdd(&h[p][d], 1u);
             }
         }
-    }
+    };
+    for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n_items; i += gridDim.x * kRsThreads) src(i, add);
     __syncthreads();
     for (uint32_t p = 0; p < n_pass; ++p) {
         const uint32_t c = h[p][tid];
@@ -103,6 +116,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
     __shared__ uint32_t s_wcnt[kRsWaves][256];
     __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64], s_tile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (a.n_dev) a.n = min(a.n, *a.n_dev);
     const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = a.begin_bit + 8u * a.pass;
     uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
     uint32_t total_d = 0;   // keys with digit tid in this pass (written by the histogram launch)
