@@ -65,6 +65,7 @@ struct la3dm_devmap {
     std::vector<uint8_t> lv_axis_host;   // BGK-LV: staging of the per-axis candidate tables (kept until the next insert)
     bool test_sort = true;        // LA3DM_TEST_SORT=0: the test blocks stay in candidate order (no heaviest-first sort)
     bool own_sort = true;         // LA3DM_OWN_SORT=0: rocPRIM's radix sort instead (A/B)
+    bool counters_clean = false;  // the last insert's final launch left the counter block as dm_begin would (dm_commit_prune)
     int spec_bits = 32;           // key digits (x 8 bits) the cloud's own voxel filter needed last time (voxel_grid)
     Arena train, grid, axis_tab, m_code, q_out;
     Arena c_flag, c_weight, c_scan, t_key0, t_key1, t_ent0, t_ent1, t_blockkey, t_center, t_nbr, t_slot, t_slot0;
@@ -368,6 +369,7 @@ static int check_beam_counters(la3dm_devmap *dm) {
 // sort runs on as many 8-bit digits as the LAST such call needed (dm->spec_bits; all four the first time), and the
 // GridParams that come back with the cell count say whether that was enough; if not (the scene grew past 2^16 / 2^24 cells)
 // the filter is simply run again on 32 bits — a constant top digit used to cost a copy pass (10 us) on every insert.
+static const uint32_t kBigCellEnv = getenv("LA3DM_BIG_CELL") ? (uint32_t)std::max(8, atoi(getenv("LA3DM_BIG_CELL"))) : 0u;   // (A/B) cells above this many points: one wave each
 static const uint32_t kBigCellWgs = getenv("LA3DM_BIG_WGS") ? (uint32_t)atoi(getenv("LA3DM_BIG_WGS")) : 2048u;   // waves (one per cell at a time) of dm_grid_centroids_big
 static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float leaf, Arena &out, uint32_t *n_out, int key_bits = 0,
                       bool params_ready = false) {
@@ -406,12 +408,14 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     // with them.  (A pass-through grid lets them write junk that the copy below replaces.)
     DM_RESERVE(out, 12ull * n);
     // cells with more than kBigCell points hold at least kBigCell + 1 of the n points each
-    DM_RESERVE(dm->big, 16ull * (n / kBigCell + 1));   // {cell, first, end, -} per entry
+    // (a filter of a few hundred thousand points is bound by its longest one-thread cells, a larger one by its gathers: measured)
+    const uint32_t kBigCellMin = kBigCellEnv ? kBigCellEnv : (n <= (1u << 19) ? kBigCell / 2u : kBigCell);
+    DM_RESERVE(dm->big, 16ull * (n / kBigCellMin + 1));   // {cell, first, end, -} per entry
     const uint32_t nchunk = n / kChunk;
     DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
     hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256) + cdiv(nchunk, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
                        (int)kCntGridSegs, (int)kCntBig, (uint4 *)dm->big.ptr, (float *)out.ptr, cdiv(n, 256), (const uint32_t *)flag,
-                       (const uint32_t *)scan, (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr);
+                       (const uint32_t *)scan, (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr, kBigCellMin);
     hipLaunchKernelGGL(dm_grid_centroids_big, dim3(kBigCellWgs), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
                        (const uint4 *)dm->big.ptr, (const uint4 *)dm->chunk_desc.ptr, (float *)out.ptr);
     rc = read_counters(dm);
@@ -1331,6 +1335,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     // the later passes must still see the un-pruned leaves, so the prune of pass 0 (which holds every distinct
     // test block) is deferred to the end of the pass loop.  A single-pass scan (the usual case) commits and prunes in ONE
     // launch, whose last workgroup also sends the counter block to the host (dm_commit_prune).
+    bool reset_queued = false;   // dm_commit_prune leaves the counter block ready for the next insert
     if (max_occ == 1) {
         volatile uint32_t *mailbox = nullptr;
         uint32_t mseq = 0;
@@ -1338,7 +1343,8 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         hipLaunchKernelGGL(dm_commit_prune, dim3(std::min(cdiv(n_test, 4), kCommitPruneWgs)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off, (const uint32_t *)dm->leaf_node.ptr,
                            (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr,
-                           dm->A, dm->B, dm->S, dm->npb, dm->depth, (const uint32_t *)dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq);
+                           dm->A, dm->B, dm->S, dm->npb, dm->depth, dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq);
+        reset_queued = mailbox != nullptr;
     } else {
         hipLaunchKernelGGL(dm_commit, dim3(cdiv(max_leaves, 256)), dim3(256), 0, st, dm->d_cnt, (const uint32_t *)dm->leaf_node.ptr,
                            (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr,
@@ -1350,6 +1356,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         }
     }
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    dm->counters_clean = reset_queued;
     dm->n_blocks = dm->h_cnt[kCntBlocks];
     S.voxel_updates += dm->h_cnt[kCntLeaves];
     S.train_reads = (uint64_t)dm->h_cnt[kCntTrainReads] | ((uint64_t)dm->h_cnt[kCntTrainReads + 1] << 32);
@@ -1408,6 +1415,16 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
     return LA3DM_OK;
 }
 
+// Start of an insert: the counter block at its initial values — by dm_begin, unless the insert before left it so (round 5).
+static void begin_insert(la3dm_devmap *dm) {
+    if (dm->counters_clean && dm->mailbox) {
+        dm->counters_clean = false;
+        return;
+    }
+    dm->counters_clean = false;
+    hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, dm->ctx->stream, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);
+}
+
 // BGKOctoMap::insert_training_data (bgkoctomap.cpp:82-212) on the pool: n labelled points {x, y, z, label} (host
 // pointer) instead of a scan; every leaf of every test block is updated for every neighbour model (no kbar gate).
 int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, uint32_t n, la3dm_devmap_stats *stats_out) {
@@ -1423,7 +1440,7 @@ int la3dm_devmap_insert_training_data_host(la3dm_devmap *dm, const float *xyzy, 
     dm->insert_into_empty = dm->n_blocks == 0;
     dm->n_xy = 0;
     const double t0 = wall();
-    hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, st, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);
+    begin_insert(dm);
     if (n == 0) {  // bgkoctomap.cpp:83-84
         if (stats_out) *stats_out = S;
         return LA3DM_OK;
@@ -1818,7 +1835,7 @@ int la3dm_devmap_insert_pointcloud_device(la3dm_devmap *dm, const float *d_xyz, 
     dm->insert_into_empty = dm->n_blocks == 0;
     dm->n_xy = 0;
     const double t0 = wall();
-    hipLaunchKernelGGL(dm_begin, dim3(1), dim3(64), 0, st, dm->d_cnt, dm->n_blocks, dm->d_mm, dm->d_mm + 6);
+    begin_insert(dm);
     if (ctx->p.variant == 2) {
         rc = lv_insert(dm, d_xyz, n, origin, ds_resolution, free_resolution, max_range, t0);
         if (rc != LA3DM_OK) lv_recover(dm);

@@ -275,14 +275,15 @@ __global__ __launch_bounds__(1024) void dm_sort_small(const uint32_t *__restrict
 }
 
 // start of an insert: the counter block is zero except the pool's block count, the min/max words are at their identities
+__device__ __forceinline__ uint32_t counter_begin_value(uint32_t i, uint32_t n_blocks) {
+    uint32_t v = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
+    if (i >= (uint32_t)kCntLvmm && i < (uint32_t)kCntLvmm + 3u) v = 0x7FFFFFFFu;        // INT32_MAX
+    else if (i >= (uint32_t)kCntLvmm + 3u && i < (uint32_t)kCntLvmm + 6u) v = 0x80000000u;   // INT32_MIN
+    return v;
+}
 __global__ void dm_begin(uint32_t *counters, uint32_t n_blocks, uint32_t *mm, uint32_t *done) {
     const uint32_t i = threadIdx.x;
-    if (i < (uint32_t)kCntWords) {
-        uint32_t v = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
-        if (i >= (uint32_t)kCntLvmm && i < (uint32_t)kCntLvmm + 3u) v = 0x7FFFFFFFu;        // INT32_MAX
-        else if (i >= (uint32_t)kCntLvmm + 3u && i < (uint32_t)kCntLvmm + 6u) v = 0x80000000u;   // INT32_MIN
-        counters[i] = v;
-    }
+    if (i < (uint32_t)kCntWords) counters[i] = counter_begin_value(i, n_blocks);
     if (i < 3) mm[i] = mm[8 + i] = 0xFFFFFFFFu;   // mm[8..13]: the second box (kept hits) of the fused front end
     else if (i < 6) mm[i] = mm[8 + i] = 0u;
     if (i == 6) *done = 0u;
@@ -336,10 +337,10 @@ constexpr uint32_t kBigCell = 64;
 
 __device__ __forceinline__ void grid_centroids_thread(const uint32_t seg, const float *__restrict__ p, const uint32_t *__restrict__ vals,
                                                       const uint32_t *__restrict__ seg_start, uint32_t *counters,
-                                                      int seg_slot, int big_slot, uint4 *big, float *out) {
+                                                      int seg_slot, int big_slot, uint4 *big, float *out, uint32_t big_cell) {
     if (seg >= counters[seg_slot]) return;
     const uint32_t s0 = seg_start[seg], s1 = seg_start[seg + 1];
-    if (s1 - s0 > kBigCell) {
+    if (s1 - s0 > big_cell) {
         big[atomicAdd(&counters[big_slot], 1u)] = make_uint4(seg, s0, s1, 0u);   // (the bounds ride along: one dependent load less there)
         return;
     }
@@ -461,11 +462,11 @@ __global__ __launch_bounds__(256) void dm_grid_centroids(const float *__restrict
                                                         const uint32_t *__restrict__ seg_start, uint32_t *counters,
                                                         int seg_slot, int big_slot, uint4 *big, float *out, uint32_t main_wgs,
                                                         const uint32_t *__restrict__ flag, const uint32_t *__restrict__ scan,
-                                                        int valid_slot, uint32_t nchunk, uint4 *desc) {
+                                                        int valid_slot, uint32_t nchunk, uint4 *desc, uint32_t big_cell) {
     // (the chunk waves first: their short gather chains then run beside the cell threads instead of forming the launch's tail)
     const uint32_t chunk_wgs = gridDim.x - main_wgs;
     if (blockIdx.x >= chunk_wgs) {
-        grid_centroids_thread((blockIdx.x - chunk_wgs) * blockDim.x + threadIdx.x, p, vals, seg_start, counters, seg_slot, big_slot, big, out);
+        grid_centroids_thread((blockIdx.x - chunk_wgs) * blockDim.x + threadIdx.x, p, vals, seg_start, counters, seg_slot, big_slot, big, out, big_cell);
         return;
     }
     const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -1610,7 +1611,7 @@ __global__ __launch_bounds__(256) void dm_commit_prune(const uint32_t *__restric
                                                       const uint32_t *__restrict__ leaf_off, const uint32_t *__restrict__ leaf_node,
                                                       const float *__restrict__ alpha, const float *__restrict__ beta,
                                                       const uint8_t *__restrict__ state, float *A, float *B, uint8_t *S, uint32_t npb,
-                                                      uint32_t block_depth, const uint32_t *counters, uint32_t *done,
+                                                      uint32_t block_depth, uint32_t *counters, uint32_t *done,
                                                       volatile uint32_t *mailbox, uint32_t mailbox_seq) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dm_prune_smem[];
     __shared__ uint32_t s_last;
@@ -1697,7 +1698,14 @@ __global__ __launch_bounds__(256) void dm_commit_prune(const uint32_t *__restric
         s_last = last;
     }
     __syncthreads();
-    if (s_last) dm_publish_wave(counters, mailbox, mailbox_seq);
+    if (s_last) {
+        // ... and leaves the counter block as dm_begin would (the pool's block count stays): the next insert of a map whose last
+        // insert ended here starts without that launch.  (The min / max words and the arrival words reset themselves.)
+        uint32_t v = 0;
+        if (threadIdx.x < (uint32_t)kCntWords) v = __hip_atomic_load(&counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dm_publish_wave(counters, mailbox, mailbox_seq);
+        if (threadIdx.x < (uint32_t)kCntWords) counters[threadIdx.x] = counter_begin_value(threadIdx.x, v);
+    }
 }
 
 
