@@ -88,7 +88,7 @@ struct la3dm_devmap {
     void *shard_user = nullptr;
     Arena shard_w, shard_cumw, shard_bounds;
     uint32_t *h_shard = nullptr;  // pinned: bounds[world + 1] | leaf_bounds[world + 1]
-    std::vector<uint64_t> shard_off[3], shard_bytes[3];   // the all-gather-v's segments (alpha, beta, state), per rank
+    std::vector<uint64_t> shard_off[4], shard_bytes[4];   // the all-gather-v's segments (alpha, beta, state, leaf key), per rank
     Arena shard_hist, shard_nown, shard_own_off, shard_cnt, shard_frees;   // sharded sample filter (front_end)
     uint32_t shard_status_failed = 0xFFFFFFFFu;   // (the source of the slot's "failed" preset: lives as long as the map)
     std::vector<uint32_t> shard_hist_host, shard_cnt_host;
@@ -1226,16 +1226,39 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         hipLaunchKernelGGL(dm_l_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
                            (const uint32_t *)P.rows_off, (const uint32_t *)nleaf, n_test, dm->d_cnt);
     if ((rc = exclusive_scan(dm, nleaf, leaf_off, n_test + 1, (int)kCntLeaves)) != LA3DM_OK) return rc;
+    // Block-sharded, single pass (round 5, VERDICT r04 #4b): a rank lists the leaves of its OWN range of test blocks only; the
+    // other ranks' leaves arrive through the all-gather-v with their keys (13 B per leaf instead of 9), and the write-back finds
+    // their nodes from this replica's slot of the block.  The range cut needs the leaf offsets, so the one host wait of the
+    // sharded path moves in front of the emitting launch.
+    const bool own_emit = sharded && max_occ == 1;
+    uint32_t t0s = 0, t1s = n_test;
+    if (sharded) {
+        uint32_t *lb = (uint32_t *)dm->shard_bounds.ptr + (world + 1);
+        hipLaunchKernelGGL(dm_shard_leaf_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_bounds.ptr,
+                           (const uint32_t *)leaf_off, world, lb);
+        DM_TRY(hipMemcpyAsync(dm->h_shard, dm->shard_bounds.ptr, 8ull * (world + 1), hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));   // (the one host wait of the sharded path: launch sizes depend on the cut)
+        const uint32_t *hb = dm->h_shard, *hl = dm->h_shard + (world + 1);
+        for (uint32_t q = 0; q < world; ++q)
+            if (hb[q] > hb[q + 1] || hb[q + 1] > n_test || hl[q] > hl[q + 1])
+                return dm_fail(dm, LA3DM_ERR_HIP, "devmap: internal error: the range cut of the sharded insert is not monotone");
+        t0s = hb[dm->shard_rank];
+        t1s = hb[dm->shard_rank + 1];
+    }
     {
         // the emitting launch carries the pass's work counters (train_reads, pair_evals) in a few workgroups of its own
-        const uint32_t main_wgs = cdiv(n_test, 4), stat_wgs = ctx->p.variant == 3 ? 0u : std::min(cdiv(n_test, 256), 32u);
+        const uint32_t e0 = own_emit ? t0s : 0u, e1 = own_emit ? t1s : n_test;
+        const uint32_t main_wgs = cdiv(e1 - e0, 4), stat_wgs = ctx->p.variant == 3 ? 0u : std::min(cdiv(n_test, 256), 32u);
         lx.t_key = stat_wgs ? t_key : nullptr;
         lx.counters_w = dm->d_cnt;
         lx.main_wgs = main_wgs;
-        hipLaunchKernelGGL((dm_leaves<true>), dim3(main_wgs + stat_wgs), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
-                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
-                           (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
-                           (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
+        lx.t_begin = e0;
+        lx.t_end = e1;
+        if (main_wgs + stat_wgs)
+            hipLaunchKernelGGL((dm_leaves<true>), dim3(main_wgs + stat_wgs), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                               (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                               (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                               (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
     }
     double tp1 = tp0;
     if (dm->stage_timing) {
@@ -1269,16 +1292,6 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     if (sharded) {
         // this rank's contiguous range of test blocks; leaf_off holds absolute leaf indices, so offsetting the per-block
         // arrays is all the kernel needs
-        uint32_t *lb = (uint32_t *)dm->shard_bounds.ptr + (world + 1);
-        hipLaunchKernelGGL(dm_shard_leaf_bounds, dim3(1), dim3(1024), 0, st, (const uint32_t *)dm->shard_bounds.ptr,
-                           (const uint32_t *)leaf_off, world, lb);
-        DM_TRY(hipMemcpyAsync(dm->h_shard, dm->shard_bounds.ptr, 8ull * (world + 1), hipMemcpyDeviceToHost, st));
-        DM_TRY(hipStreamSynchronize(st));   // (the one host wait of the sharded path: launch sizes depend on the cut)
-        const uint32_t *hb = dm->h_shard, *hl = dm->h_shard + (world + 1);
-        for (uint32_t q = 0; q < world; ++q)
-            if (hb[q] > hb[q + 1] || hb[q + 1] > n_test || hl[q] > hl[q + 1])
-                return dm_fail(dm, LA3DM_ERR_HIP, "devmap: internal error: the range cut of the sharded insert is not monotone");
-        const uint32_t t0s = hb[dm->shard_rank], t1s = hb[dm->shard_rank + 1];
         s.nbr += 7ull * t0s;
         s.blk_center += 3ull * t0s;
         s.leaf_off += t0s;
@@ -1298,25 +1311,27 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         // collective (its peers would wait for ever otherwise) and reports afterwards.
         const int rc_kernel = rc;
         const uint32_t *hl = dm->h_shard + (world + 1);
-        for (int g = 0; g < 3; ++g) {
+        for (int g = 0; g < 4; ++g) {
             dm->shard_off[g].resize(world);
             dm->shard_bytes[g].resize(world);
         }
         for (uint32_t q = 0; q < world; ++q) {
             const uint64_t f = hl[q], n_q = hl[q + 1] - hl[q];
-            dm->shard_off[0][q] = dm->shard_off[1][q] = 4 * f;
-            dm->shard_bytes[0][q] = dm->shard_bytes[1][q] = 4 * n_q;
+            dm->shard_off[0][q] = dm->shard_off[1][q] = dm->shard_off[3][q] = 4 * f;
+            dm->shard_bytes[0][q] = dm->shard_bytes[1][q] = dm->shard_bytes[3][q] = 4 * n_q;
             dm->shard_off[2][q] = f;
             dm->shard_bytes[2][q] = n_q;
         }
-        la3dm_gather_seg segs[3] = {{dm->leaf_alpha.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()},
+        la3dm_gather_seg segs[4] = {{dm->leaf_alpha.ptr, dm->shard_off[0].data(), dm->shard_bytes[0].data()},
                                     {dm->leaf_beta.ptr, dm->shard_off[1].data(), dm->shard_bytes[1].data()},
-                                    {dm->leaf_state.ptr, dm->shard_off[2].data(), dm->shard_bytes[2].data()}};
+                                    {dm->leaf_state.ptr, dm->shard_off[2].data(), dm->shard_bytes[2].data()},
+                                    {dm->leaf_key.ptr, dm->shard_off[3].data(), dm->shard_bytes[3].data()}};
+        const uint32_t n_segs = own_emit ? 4u : 3u;   // (the keys travel only when the ranks did not list each other's leaves)
         if (dm->stage_timing) {
             DM_TRY(hipStreamSynchronize(st));
             tg0 = wall();
         }
-        const int xrc = hl[world] ? dm->shard_fn(dm->shard_user, segs, 3, world, dm->shard_rank, (void *)st) : 0;
+        const int xrc = hl[world] ? dm->shard_fn(dm->shard_user, segs, n_segs, world, dm->shard_rank, (void *)st) : 0;
         if (rc_kernel != LA3DM_OK) return rc_kernel;
         if (xrc != 0) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed");
         if (dm->stage_timing) {
@@ -1342,7 +1357,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         publish_with(dm, mailbox, mseq);
         hipLaunchKernelGGL(dm_commit_prune, dim3(std::min(cdiv(n_test, 4), kCommitPruneWgs)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off, (const uint32_t *)dm->leaf_node.ptr,
-                           (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr,
+                           own_emit ? (const uint32_t *)dm->leaf_key.ptr : (const uint32_t *)nullptr, (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr,
                            dm->A, dm->B, dm->S, dm->npb, dm->depth, dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq);
         reset_queued = mailbox != nullptr;
     } else {

@@ -1443,6 +1443,8 @@ struct LeafExtra {
     const uint32_t *t_key;  // emit launch: keys of the test blocks (weights), or nullptr: no work counters
     uint32_t *counters_w;
     uint32_t main_wgs;      // emit launch: workgroups that hold block waves; the rest accumulate the counters
+    uint32_t t_begin, t_end;  // emit launch: the test blocks [t_begin, min(t_end, count)) only (block-sharded insert: the rank's own
+                              // range — the other ranks' leaves arrive with their keys); the count launch takes every block
 };
 
 __device__ __forceinline__ void test_stats_wg(const uint32_t *__restrict__ t_key, const uint32_t *__restrict__ nleaf, uint32_t n_test,
@@ -1487,10 +1489,10 @@ __global__ __launch_bounds__(256) void dm_leaves(const uint32_t *__restrict__ sl
         test_stats_wg(x.t_key, nleaf, counters[kCntTest], x.counters_w, blockIdx.x - x.main_wgs, gridDim.x - x.main_wgs);
         return;
     }
-    const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t t = (kEmit ? x.t_begin : 0u) + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) nleaf[counters[kCntTest]] = 0;   // the scan runs over n_test + 1 counts
-    if (t >= counters[kCntTest]) return;
+    if (t >= counters[kCntTest] || (kEmit && t >= x.t_end)) return;
     const size_t base = (size_t)slot[t] * npb;
     const uint8_t *Sb = S + base;
     const uint32_t dl = block_depth - 1, ncell = 1u << (3 * dl);
@@ -1609,7 +1611,7 @@ constexpr uint32_t kCommitPruneWgs = 2048;   // workgroups of the launch at most
 // dm_publish_counters launch behind this one.
 __global__ __launch_bounds__(256) void dm_commit_prune(const uint32_t *__restrict__ slot, uint32_t n_test,
                                                       const uint32_t *__restrict__ leaf_off, const uint32_t *__restrict__ leaf_node,
-                                                      const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                      const uint32_t *__restrict__ leaf_key, const float *__restrict__ alpha, const float *__restrict__ beta,
                                                       const uint8_t *__restrict__ state, float *A, float *B, uint8_t *S, uint32_t npb,
                                                       uint32_t block_depth, uint32_t *counters, uint32_t *done,
                                                       volatile uint32_t *mailbox, uint32_t mailbox_seq) {
@@ -1631,7 +1633,15 @@ __global__ __launch_bounds__(256) void dm_commit_prune(const uint32_t *__restric
         for (uint32_t l = l0 + lane; l < l1; l += 64) {
             const uint8_t st = state[l];
             if (!(st & 0x80u)) continue;
-            const uint32_t node = leaf_node[l];
+            // (leaf_key != nullptr — block-sharded insert: a foreign leaf arrives with its key {depth << 16 | index}, pool slots are
+            // numbered per replica — the node is found from this replica's slot of the block)
+            uint32_t node;
+            if (leaf_key) {
+                const uint32_t key = leaf_key[l];
+                node = (uint32_t)base + dm_layer_base(key >> 16) + (key & 0xFFFFu);
+            } else {
+                node = leaf_node[l];
+            }
             const uint8_t ns = (uint8_t)((st & 3u) | kClassifiedBit);
             A[node] = alpha[l];
             B[node] = beta[l];

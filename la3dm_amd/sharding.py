@@ -127,13 +127,15 @@ def gather_v(dist, buf, offsets, nbytes, r, world, async_op=False, group=None):
     return []
 
 
-def leaf_segments(leaf_bounds):
+def leaf_segments(leaf_bounds, keys=True):
     """host mirror of what la3dm_devmap_insert_* hands the callback: (offsets, nbytes) per rank for the alpha, beta (4 B per
-    leaf) and state (1 B per leaf) arrays, from the leaf index bounds [world + 1] of the ranks' ranges"""
+    leaf), state (1 B per leaf) and — single-pass scans since round 5: a rank lists only its own range's leaves, the others'
+    arrive with their keys — leaf-key (4 B per leaf) arrays, from the leaf index bounds [world + 1] of the ranks' ranges:
+    13 B per leaf of the scan"""
     lb = [int(x) for x in leaf_bounds]
     n = [lb[q + 1] - lb[q] for q in range(len(lb) - 1)]
     four = ([4 * x for x in lb[:-1]], [4 * x for x in n])
-    return [four, four, (lb[:-1], n)]
+    return [four, four, (lb[:-1], n)] + ([four] if keys else [])
 
 
 def torch_allgather(dist, rank, device, stage_through_host=False, group=None):

@@ -521,7 +521,33 @@ print("CHK", lv["A"].size, zlib.crc32(lv["A"].tobytes()), zlib.crc32(lv["B"].tob
 """
 
 
-@pytest.mark.parametrize("switch", ["LA3DM_MAILBOX", "LA3DM_PUBLISH_IN_KERNEL", "LA3DM_OWN_SORT"])
+def test_cloud_filter_sorts_on_the_digits_the_last_insert_needed(built):
+    """round 5: the cloud's own voxel filter sorts its cell keys on as many 8-bit digits as the previous insert of the map
+    needed and runs again on all four when the grid that comes back is larger (devmap.hip voxel_grid): a tiny scan (< 2^16
+    cells), the same scan at full extent (< 2^24), a finer grid over a stretched copy (> 2^24), then small again — the
+    training set of every insert equals the restatement's bit for bit, and so does the map at the end"""
+    import la3dm_amd
+    from oracle import oracle as O
+    xyz, origin = la3dm_amd.synthetic_scan(20000)
+    origin = np.asarray(origin, np.float32)
+    m, o = _maps(dict(la3dm_amd.BGK_YAML))
+    cases = [(0.05, 0.1), (1.0, 0.1), (3.0, 0.04), (0.05, 0.1), (1.0, 0.1)]
+    cells = []
+    for k, (scale, ds) in enumerate(cases):
+        pts = ((xyz - origin) * np.float32(scale) + origin).astype(np.float32)
+        ext = np.floor(pts.max(0) / ds) - np.floor(pts.min(0) / ds) + 1
+        cells.append(float(np.prod(ext)))
+        m.insert_pointcloud(pts, origin, ds, 0.5, -1.0)
+        o.insert_pointcloud(pts, origin, ds, 0.5, -1.0)
+        t = m.training_data()
+        ref = O.get_training_data(pts, origin, ds, 0.5, -1.0)
+        assert t.shape == ref.shape, (k, t.shape, ref.shape)
+        assert (t.view(np.uint32) == ref.view(np.uint32)).all(), (k, int((t != ref).any(axis=1).sum()))
+    assert cells[0] < 2 ** 16 < cells[1] < 2 ** 24 < cells[2], cells   # the sequence crosses both digit boundaries, both ways
+    _same(m, o, "digits")
+
+
+@pytest.mark.parametrize("switch", ["LA3DM_MAILBOX", "LA3DM_PUBLISH_IN_KERNEL", "LA3DM_OWN_SORT", "LA3DM_TEST_SORT"])
 def test_fallback_switches_give_the_same_map(built, switch):
     """the A/B switches of the front end (copy + sync read-backs, a publish launch per read-back instead of the producing
     kernel's own mailbox write, rocPRIM's sort instead of devmap_sort.h) read their environment once per process: a child

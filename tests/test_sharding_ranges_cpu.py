@@ -56,15 +56,16 @@ def _rank(rank, world, port, ret):
     truth_a = rng.random(leaf_off[-1]).astype(np.float32)
     truth_b = rng.random(leaf_off[-1]).astype(np.float32)
     truth_s = rng.integers(0, 256, leaf_off[-1]).astype(np.uint8)
-    a, b, s = np.zeros_like(truth_a), np.zeros_like(truth_b), np.zeros_like(truth_s)
+    truth_k = rng.integers(0, 1 << 18, leaf_off[-1]).astype(np.uint32)   # leaf keys: only the owner lists its range's leaves
+    a, b, s, k = np.zeros_like(truth_a), np.zeros_like(truth_b), np.zeros_like(truth_s), np.zeros_like(truth_k)
     lo, hi = lb[rank], lb[rank + 1]                      # "predict + fuse" of this rank's range only
-    a[lo:hi], b[lo:hi], s[lo:hi] = truth_a[lo:hi], truth_b[lo:hi], truth_s[lo:hi]
-    # the exchange: ONE in-place all-gather-v over the three leaf arrays (no pack / unpack, no padding), exactly the
+    a[lo:hi], b[lo:hi], s[lo:hi], k[lo:hi] = truth_a[lo:hi], truth_b[lo:hi], truth_s[lo:hi], truth_k[lo:hi]
+    # the exchange: ONE in-place all-gather-v over the four leaf arrays (no pack / unpack, no padding), exactly the
     # segments la3dm_devmap_insert_* hands the callback
-    # all three arrays in ONE grouped batch of sends / receives (sharding.exchange_v: what torch_allgather issues per exchange)
-    segs = [(torch.from_numpy(arr.view(np.uint8)), offsets, nbytes) for arr, (offsets, nbytes) in zip((a, b, s), sharding.leaf_segments(lb))]
+    # all four arrays in ONE grouped batch of sends / receives (sharding.exchange_v: what torch_allgather issues per exchange)
+    segs = [(torch.from_numpy(arr.view(np.uint8)), offsets, nbytes) for arr, (offsets, nbytes) in zip((a, b, s, k), sharding.leaf_segments(lb))]
     sharding.exchange_v(dist, segs, rank, world)
-    ret[rank] = bool((a == truth_a).all() and (b == truth_b).all() and (s == truth_s).all())
+    ret[rank] = bool((a == truth_a).all() and (b == truth_b).all() and (s == truth_s).all() and (k == truth_k).all())
     dist.destroy_process_group()
 
 
