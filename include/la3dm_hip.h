@@ -343,9 +343,11 @@ int la3dm_devmap_lv_training(la3dm_devmap *dm, float *samples4, uint32_t cap_sam
  * contiguous ranges of equal weight in candidate order, rank r predicts + fuses range r only, then ONE all-gather-v
  * reassembles the updated leaves on every rank, and commit + prune run everywhere: after the call all replicas are
  * identical to a single-GPU map, bit for bit.
- * The exchange is IN PLACE on the scan's leaf arrays (alpha, beta: 4 B per leaf, state: 1 B per leaf; a rank's leaves are
- * a contiguous index range of each): no pack / unpack copies, no padding — the payload is exactly 9 B per leaf of the scan.
- * The library has no communication dependency: `fn` is called once per pass with nseg = 3 segments; for segment s, rank q
+ * The exchange is IN PLACE on the scan's leaf arrays (alpha, beta: 4 B per leaf, state: 1 B per leaf, and — single-pass scans,
+ * where a rank lists the leaves of its own range only and the write-back finds a foreign leaf's node from its key and this
+ * replica's slot of the block — the leaf keys: 4 B per leaf; a rank's leaves are a contiguous index range of each): no pack /
+ * unpack copies, no padding — the payload is exactly 13 B per leaf of the scan (9 B in a multi-pass scan).
+ * The library has no communication dependency: `fn` is called once per pass with nseg = 4 (or 3) segments; for segment s, rank q
  * owns bytes [offset[q], offset[q] + bytes[q]) of the DEVICE buffer `base` (filled for q = rank by work already queued
  * on `stream`), and fn must queue on `stream` — or order against it — an all-gather-v that fills every other rank's
  * bytes, e.g. between ncclGroupStart / ncclGroupEnd one ncclBroadcast(base + offset[q], base + offset[q], bytes[q],

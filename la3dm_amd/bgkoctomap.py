@@ -68,7 +68,7 @@ class BGKOctoMap:
         """Block-sharded insert_pointcloud over `world` replicas of this map, one process per GPU (every process
         inserts the same clouds): rank r predicts + fuses its contiguous range of the test blocks, then
         `allgatherv(segments, world, rank, stream)` is called once per pass — segments = [(base_ptr, offsets, nbytes), ...]
-        (three: the scan's alpha, beta and state arrays; rank q owns bytes [offsets[q], offsets[q] + nbytes[q]) of each)
+        (four: the scan's alpha, beta, state and leaf-key arrays; rank q owns bytes [offsets[q], offsets[q] + nbytes[q]) of each)
         — and must queue, on the HIP stream `stream` (an integer handle) or ordered against it, an in-place
         all-gather-v of every segment; nothing synchronises the host (la3dm_devmap_set_shard in include/la3dm_hip.h;
         la3dm_amd.sharding.torch_allgather builds one on torch.distributed).  world = 1 switches it off."""
