@@ -675,6 +675,28 @@ __global__ __launch_bounds__(kWave) void bgkl_split_apply(BgklArgs a, BgklSplit 
 // instead of once per row that has any hit (68 % of the rows of a light tile, ~10 lanes each); k and k * label go to the
 // leaf's double accumulators by ds_add_f64 (bgk_kernels.h bgk_predict_fuse_r: a native LDS atomic, 32 cycles).  Neighbours
 // are taken one after the other — the gate is per neighbour —, the ring is drained at a neighbour's end.
+// Bounding sphere of a tile's active leaves (centre of their box, radius to the farthest one), for the row cull of bgkl_rows_sum.
+__device__ __forceinline__ void bgkl_tile_sphere(const bool active, const float px, const float py, const float pz, float &cx,
+                                                 float &cy, float &cz, float &rad) {
+    float mn[3] = {active ? px : __builtin_inff(), active ? py : __builtin_inff(), active ? pz : __builtin_inff()};
+    float mx[3] = {active ? px : -__builtin_inff(), active ? py : -__builtin_inff(), active ? pz : -__builtin_inff()};
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o));
+        }
+    cx = 0.5f * (mn[0] + mx[0]);
+    cy = 0.5f * (mn[1] + mx[1]);
+    cz = 0.5f * (mn[2] + mx[2]);
+    const float dx = px - cx, dy = py - cy, dz = pz - cz;
+    float r = active ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.0f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
+    rad = r;   // (NaN / inf positions give a NaN / inf radius: nothing is culled then)
+}
+
 constexpr int kLRing = 192;
 struct __attribute__((aligned(16))) WaveLdsL {
     float4 rows[3][kWave];      // staged rows, one array per float4 of the row
@@ -684,8 +706,15 @@ struct __attribute__((aligned(16))) WaveLdsL {
 };
 
 // the rows [r0, r1) into the leaf's two double sums (left in L.acc_k / L.acc_y of lane = leaf; zeroed here)
+// Round 5, row cull: a training row is a whole beam (or a hit point), registered in every block it has samples in; most beams of a
+// neighbouring block pass the tile at more than ell.  While the 64 rows of a trip are staged (lane = row) each gets ONE distance —
+// to the centre of the tile's bounding sphere, by the same routine — and a row whose distance exceeds radius + ell by more than a
+// slack that covers the fp32 error of both evaluations (1e-5 of the coordinates' magnitude, two orders above it) cannot reach
+// any leaf: d(p, row) >= d(c, row) - |p - c|.  Such a row would have added exactly nothing (its k is 0 at every leaf: the test
+// below is d2 >= hit_d2 there), so skipping it is exact; non-finite distances are never culled.
 __device__ __forceinline__ void bgkl_rows_sum(const BgklArgs &a, WaveLdsL &L, const int lane, const bool active, const float px,
-                                              const float py, const float pz, const uint32_t r0, const uint32_t r1) {
+                                              const float py, const float pz, const uint32_t r0, const uint32_t r1, const float cx,
+                                              const float cy, const float cz, const float reach) {
     L.acc_k[lane] = 0.0;
     L.acc_y[lane] = 0.0;
     uint32_t tail = 0;
@@ -702,15 +731,25 @@ __device__ __forceinline__ void bgkl_rows_sum(const BgklArgs &a, WaveLdsL &L, co
         const uint32_t nr = min(r1 - q, (uint32_t)kWave);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        bool keep = false;
         if ((uint32_t)lane < nr) {
             const size_t row = (size_t)q + lane;
-            L.rows[0][lane] = a.rowx[3 * row];
-            L.rows[1][lane] = a.rowx[3 * row + 1];
-            L.rows[2][lane] = a.rowx[3 * row + 2];
+            const float4 w0 = a.rowx[3 * row], w1 = a.rowx[3 * row + 1], w2 = a.rowx[3 * row + 2];
+            L.rows[0][lane] = w0;
+            L.rows[1][lane] = w1;
+            L.rows[2][lane] = w2;
+            const float dc2 = bgkl_seg_d2(cx, cy, cz, w0, w1, w2);
+            const float mag = fmaxf(fmaxf(fmaxf(fabsf(w0.x), fabsf(w0.y)), fmaxf(fabsf(w0.z), fabsf(w0.w))),
+                                    fmaxf(fmaxf(fabsf(w1.x), fabsf(w1.y)), fmaxf(fmaxf(fabsf(cx), fabsf(cy)), fabsf(cz))));
+            const float lim = reach + 1e-5f * mag + 1e-4f;
+            keep = !(dc2 > lim * lim && dc2 < 1e30f);   // (NaN anywhere: kept)
         }
+        unsigned long long todo = __ballot(keep);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t j = 0; j < nr; ++j) {
+        while (todo) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
             const float4 q0 = L.rows[0][j], q1 = L.rows[1][j], q2 = L.rows[2][j];
             const float d2 = bgkl_seg_d2(px, py, pz, q0, q1, q2);
             const bool hit = active && bgkl_row_counts(d2, a.hit_d2);
@@ -757,6 +796,9 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_f64(BgklArgs a, c
     bool updated = false;
     constexpr size_t kPartB = sizeof(double) * (size_t)kW * 2 * kWave;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kW > 1 ? kPartB : sizeof(WaveLdsL)];
+    float tcx = 0.f, tcy = 0.f, tcz = 0.f, trad = 0.f;
+    if constexpr (kW == 1) bgkl_tile_sphere(active, px, py, pz, tcx, tcy, tcz, trad);
+    const float reach = trad * 1.000001f + sqrtf(a.hit_d2);
     double(*s_part)[2][kWave] = reinterpret_cast<double(*)[2][kWave]>(s_raw);   // kW > 1
     WaveLdsL &s_L = *reinterpret_cast<WaveLdsL *>(s_raw);                        // kW == 1
 
@@ -767,7 +809,7 @@ __global__ __launch_bounds__(kW *kWave) void bgkl_predict_fuse_f64(BgklArgs a, c
         double ysum = 0.0, ksum = 0.0;
         if constexpr (kW == 1) {
             if (r0 == r1) continue;   // (an empty model adds nothing and fails the gate)
-            bgkl_rows_sum(a, s_L, lane, active, px, py, pz, r0, r1);
+            bgkl_rows_sum(a, s_L, lane, active, px, py, pz, r0, r1, tcx, tcy, tcz, reach);
             ysum = s_L.acc_y[lane];
             ksum = s_L.acc_k[lane];
         } else {
@@ -819,7 +861,9 @@ __global__ __launch_bounds__(kWave) void bgkl_split_sum(BgklArgs a, BgklSplit s)
     float px, py, pz;
     if (!bgkl_leaf(a, dsc.x, lane, blk, li, active, px, py, pz)) return;  // (split tiles always hold leaves)
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(dsc.z), r1 = __builtin_amdgcn_readfirstlane(dsc.w);
-    bgkl_rows_sum(a, L, lane, active, px, py, pz, r0, r1);
+    float tcx, tcy, tcz, trad;
+    bgkl_tile_sphere(active, px, py, pz, tcx, tcy, tcz, trad);
+    bgkl_rows_sum(a, L, lane, active, px, py, pz, r0, r1, tcx, tcy, tcz, trad * 1.000001f + sqrtf(a.hit_d2));
     s.part64[(size_t)it * kWave + lane] = make_double2(L.acc_y[lane], L.acc_k[lane]);
 }
 
