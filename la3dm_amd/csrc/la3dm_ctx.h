@@ -35,7 +35,7 @@ struct la3dm_ctx {
     int opt_waves = 1;  // waves per workgroup (variant 3)
     int opt_remap = 2;
     int opt_l_dense_add = 1;      // BGK-L split tiles: 1 = expansion for all items at once + two-wave ordered add, 0 = producer / consumer workgroup
-    int opt_l_split_rows = 2048;  // BGK-L: tiles with more rows than this are split over waves (< 0: never); measured on the 200 k-ray scan: 4096 4.15 ms, 2560 3.9, 2048 3.75, 1536 3.8, 1024 4.0, 512 4.3
+    int opt_l_split_rows = 1024;  // BGK-L: tiles with more rows than this are split over waves (< 0: never); measured on the 200 k-ray scan, round 5 (order-free sums, row cull): 8192 1.67 ms, 4096 1.63, 2048 1.30, 1024 1.27, 512 1.27 (round 2, ordered: 2048 was the optimum)
     int opt_lds_pad = 0;  // profiling only: extra dynamic LDS bytes on the BGK predict launch (lowers the waves a CU holds)
     int opt_ablate = 0;  // profiling only: 1 skip kernel evaluation, 2 skip the candidate tests
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
