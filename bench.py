@@ -439,11 +439,12 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
                                    "(re-inserted every step), cloud resident in HBM",
                        "rays": rays, "resolution": res, "block_depth": args.depth,
                        "parallelism": f"block-sharded over {world} GPUs: replicated map, contiguous equal-weight ranges of the "
-                                      "test blocks per rank, one in-place all-gather-v of the leaves' (alpha, beta, state) per insert "
-                                      "queued on the map's stream (9 B per leaf, no padding, no host synchronisation), "
-                                      "front end + partition + commit + prune redundant on every rank",
+                                      "test blocks per rank, a rank lists the leaves of its own range only, one in-place all-gather-v of the "
+                                      "leaves' (alpha, beta, state, key) per insert queued on the map's stream (13 B per leaf, no padding, no "
+                                      "host synchronisation), front end (but the sample filter) + partition + leaf count + commit + prune "
+                                      "redundant on every rank",
                        "voxel_updates_last_step": int(st["voxel_updates"]), "test_blocks": int(st["n_test_blocks"]),
-                       "allgather_v_bytes_total": 9 * int(st["voxel_updates"]),
+                       "allgather_v_bytes_total": 13 * int(st["voxel_updates"]),
                        "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                          "exchange": os.environ.get("LA3DM_SHARD_EXCHANGE", "p2p") + " (sharding.exchange_v: one grouped batch of sends / receives per exchange; LA3DM_SHARD_EXCHANGE=broadcast: one broadcast per rank and array)"}},
             "stages_ms_rank0": stages,
