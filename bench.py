@@ -57,8 +57,10 @@ def main():
     ap.add_argument("--workload", choices=["bgk", "gp", "lv", "l"], default="bgk",
                     help="bgk = BASELINE configs[1] (default, the contract line); gp = configs[2] (GPOctoMap, 50k rays); "
                          "lv = configs[3] (BGKLV, sim_unstructured scan, 0.05 m), l = BGKLOctoMap insert (row f4) — single-GPU side benches")
-    ap.add_argument("--mode", choices=["shard", "scans"], default="shard",
-                    help="N>1 only. shard (default, strong scaling, BASELINE configs[4]): ONE 1M-ray scan at 0.05 m, every rank "
+    ap.add_argument("--mode", choices=["hotpath", "shard", "scans"], default=None,
+                    help="default: hotpath at N = 1 (the contract line: configs[1] through the hot-path kernel; it carries a `scale_n1` leg = "
+                         "the shard workload on this one GPU), shard at N > 1.  `--gpus 1 --mode shard` runs the N > 1 workload at world = 1, "
+                         "so that value(N) is ONE workload over N = 1, 2, 4, 8.  shard (strong scaling, BASELINE configs[4]): ONE 1M-ray scan at 0.05 m, every rank "
                          "holds a replica of the device-resident map, predicts + fuses its contiguous range of the test blocks, "
                          "one RCCL all-gather of the leaf payload (la3dm_devmap_set_shard); scans (weak scaling): one 200k-ray "
                          "scan per GPU through the hot-path kernel + an all-gather of its leaves (replicas)")
@@ -71,6 +73,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end (device-resident insert_pointcloud) leg")
     ap.add_argument("--no-big", action="store_true",
                     help="skip the out-of-cache leg (configs[4]'s 1M-ray scan on this GPU: working set > the 256 MiB Infinity Cache)")
+    ap.add_argument("--variants", action="store_true",
+                    help="add roofline.kernel_function_variants: the headline launch with cheaper / no kernel-function evaluation (VERDICT r05 #2)")
     ap.add_argument("--no-cpu-omp", dest="cpu_omp", action="store_false",
                     help="skip the all-core OpenMP run of the oracle (cpu_baseline_omp)")
     args = ap.parse_args()
@@ -106,8 +110,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        if args.mode == "shard":
-            return sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest)
+    if args.mode is None:
+        args.mode = "hotpath" if world == 1 else "shard"
+    if args.mode == "hotpath" and world > 1:
+        args.mode = "scans"      # (the hot-path kernel on N GPUs is the weak-scaling replica mode)
+    if args.mode == "shard":     # (world = 1 too: the same workload on one unsharded map — the N = 1 point of the scaling series)
+        return sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest)
 
     # ---- build the workload (host side, untimed) -------------------------------------
     params = dict(la3dm_amd.BGK_YAML, resolution=args.resolution, block_depth=args.depth)
@@ -316,6 +324,12 @@ def main():
             out["end_to_end"] = end_to_end(la3dm_amd, params, args)
         if world == 1 and not args.no_big and args.rays == 200000:
             out["roofline"]["out_of_cache"] = out_of_cache_leg(la3dm_amd, _lib, torch, dev)
+            out["roofline"]["depth4"] = depth4_leg(la3dm_amd, _lib, torch, dev)
+            if args.variants:
+                out["roofline"]["kernel_function_variants"] = kernel_variants_leg(la3dm_amd, _lib, torch, dev)
+            # the N = 1 point of the multi-GPU series (`--gpus N` times configs[4]'s whole insert, not this line's kernel-only step):
+            # the same W + K inserts `--gpus N --mode shard` runs, on this GPU — equals that line's `single_gpu`
+            out["scale_n1"] = scale_n1_leg(la3dm_amd, torch, dev, args)
         if world == 1 and not args.no_side:
             # the other BASELINE configs on this GPU, each with its own roofline and CPU leg (same protocol as --workload X);
             # every GPU measurement of the run comes before the first all-core CPU leg
@@ -363,72 +377,107 @@ def kernel_name(m, sum_mode, flags, pk):
     return f"bgk_predict_fuse_{'p' if m.get_option('bgk_p') else 't'}<{trig}, {'false' if full else 'true'}>"
 
 
+def shard_workload(args):
+    """configs[4]: the 1M-ray scan at 0.05 m (or what --rays / --resolution ask for)"""
+    return (1000000, 0.05) if args.rays == 200000 else (args.rays, args.resolution)
+
+
+def insert_loop(m, torch, d_cloud, origin, res, steps, warm, barrier=None):
+    """W untimed + K timed device-resident insert_pointcloud calls of the cloud in HBM -> (seconds, voxel updates of the K steps)"""
+    def fence():
+        torch.cuda.synchronize()
+        if barrier is not None:
+            barrier()
+            torch.cuda.synchronize()
+    ups = 0
+    for _ in range(warm):
+        m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
+        ups += int(m.stats()["voxel_updates"])
+    fence()
+    return time.perf_counter() - t0, ups
+
+
+def scale_n1_leg(la3dm_amd, torch, dev, args):
+    rays, res = shard_workload(args)
+    params = dict(la3dm_amd.BGK_YAML, resolution=res, block_depth=args.depth)
+    xyz, origin = la3dm_amd.synthetic_scan(rays)
+    d_cloud = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).to(dev)
+    m = la3dm_amd.BGKOctoMap(**params, device=dev.index or 0)
+    steps = min(args.steps, 20)
+    dt, ups = insert_loop(m, torch, d_cloud, origin, res, steps, min(args.warmup, 3))
+    del m
+    return {"what": f"BGKOctoMap synthetic {rays}-ray scan, {res} m res (configs[4]); a step = one whole device-resident insert_pointcloud, cloud "
+                    "in HBM, re-inserted every step: the workload of `--gpus N` (N > 1) and of `--gpus 1 --mode shard`, on this one GPU",
+            "value": ups / dt, "unit": "voxel-updates/s", "ms_per_step": dt / steps * 1e3, "steps": steps}
+
+
 def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, dev, selftest):
-    """N > 1 default: BASELINE configs[4] — ONE synthetic 1M-ray scan at 0.05 m, block-sharded.  Every rank holds a
+    """`--mode shard` (N > 1 default): BASELINE configs[4] — ONE synthetic 1M-ray scan at 0.05 m, block-sharded.  Every rank holds a
     replica of the device-resident map and is handed the same cloud (resident in its HBM); a step is one whole
     BGKOctoMap::insert_pointcloud: front end + partition redundantly on every GPU, predict + fuse of the rank's contiguous
     range of test blocks, ONE all-gather of the leaf payload over RCCL, commit + prune everywhere.  Strong scaling: the
-    work per step is fixed, value = voxel updates of the timed steps / max-over-ranks time.  Rank 0 also times the same
+    work per step is fixed, value = voxel updates of the timed steps / max-over-ranks time.  world = 1 (`--gpus 1 --mode shard`)
+    is the same workload on one unsharded map, so value(N) is one workload for every N.  Every rank also times the same
     steps unsharded on its own GPU beforehand so the line carries its own single-GPU reference."""
     from la3dm_amd import sharding
-    rays, res = (1000000, 0.05) if args.rays == 200000 else (args.rays, args.resolution)
+    rays, res = shard_workload(args)
     params = dict(la3dm_amd.BGK_YAML, resolution=res, block_depth=args.depth)
     xyz, origin = la3dm_amd.synthetic_scan(rays)
     d_cloud = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).to(dev)
     cdev = torch.device("cpu") if selftest else dev
+    barrier = dist.barrier if dist is not None else None
 
-    def run(m, steps, warm):
-        ups = 0
-        for _ in range(warm):
-            m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
-            ups += int(m.stats()["voxel_updates"])
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, ups
+    def callback():
+        return sharding.torch_allgather(dist, rank, dev, stage_through_host=selftest)
 
     # single-GPU reference: the same W + K inserts on an unsharded replica (all ranks do it, so every GPU is equally warm)
     ref = la3dm_amd.BGKOctoMap(**params, device=local_rank)
-    dt1, ups1 = run(ref, args.steps, args.warmup)
+    dt1, ups1 = insert_loop(ref, torch, d_cloud, origin, res, args.steps, args.warmup, barrier)
     del ref
     m = la3dm_amd.BGKOctoMap(**params, device=local_rank)
-    m.set_shard(rank, world, sharding.torch_allgather(dist, rank, dev, stage_through_host=selftest))
+    if world > 1:
+        m.set_shard(rank, world, callback())
     m.set_option("time_kernel", 1)       # HIP events around the predict + fuse kernel of every insert (this rank's range)
-    dt, ups = run(m, args.steps, args.warmup)
+    dt, ups = insert_loop(m, torch, d_cloud, origin, res, args.steps, args.warmup, barrier)
     from la3dm_amd import _lib
     kt = np.zeros(args.steps + args.warmup + 8, np.float32)
     nk = C.c_uint32()
     _lib.hip().la3dm_kernel_times(m.ctx(), kt.ctypes.data, kt.size, C.byref(nk))
     k_ms = float(kt[max(0, nk.value - args.steps):nk.value].mean()) if nk.value else float("nan")
-    tt = torch.tensor([dt, dt1], dtype=torch.float64, device=cdev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt, dt1 = float(tt[0].item()), float(tt[1].item())
+    if world > 1:
+        tt = torch.tensor([dt, dt1], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, dt1 = float(tt[0].item()), float(tt[1].item())
     st = m.stats()
-    # per-stage wall times of rank 0 (a third replica created with LA3DM_TIMING=1: a host synchronisation after every stage,
-    # so the sum is larger than an untimed step — it says where the time goes, not how long a step takes)
+    # per-stage wall times of EVERY rank (a third replica created with LA3DM_TIMING=1: a host synchronisation after every stage,
+    # so the sum is larger than an untimed step — it says where the time goes and how even the ranks are, not how long a step takes)
     os.environ["LA3DM_TIMING"] = "1"
     try:
         mt = la3dm_amd.BGKOctoMap(**params, device=local_rank)
     finally:
         os.environ.pop("LA3DM_TIMING", None)
-    mt.set_shard(rank, world, sharding.torch_allgather(dist, rank, dev, stage_through_host=selftest))
+    if world > 1:
+        mt.set_shard(rank, world, callback())
     stages = {}
     for i in range(3):
         mt.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, res, 0.5, -1.0)
         sx = mt.stats()
         stages = {"front_end": sx["t_frontend"] * 1e3, "partition": sx["t_partition"] * 1e3, "test_list_blocks_leaves": sx["t_pack"] * 1e3,
                   "predict_fuse_own_range": sx["t_device"] * 1e3, "allgather_v": sx["t_gather"] * 1e3,
-                  "commit_prune": sx["t_commit"] * 1e3}
+                  "commit_prune": sx["t_commit"] * 1e3, "predict_fuse_kernel_events_ms": k_ms}
     torch.cuda.synchronize()
-    dist.barrier()
+    all_stages = [stages]
+    if world > 1:
+        dist.barrier()
+        all_stages = [None] * world
+        dist.all_gather_object(all_stages, stages)
     del mt
     if rank == 0:
+        b_alg = 16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])
         print(json.dumps({
             "metric": "voxel-updates/sec per scan (200k pts, 0.1 m res); HBM GB/s vs roofline",
             "value": ups / dt, "unit": "voxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -438,25 +487,29 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
                                    "kernel params (configs[4]); a step = one device-resident insert_pointcloud of the scan "
                                    "(re-inserted every step), cloud resident in HBM",
                        "rays": rays, "resolution": res, "block_depth": args.depth,
-                       "parallelism": f"block-sharded over {world} GPUs: replicated map, contiguous equal-weight ranges of the "
-                                      "test blocks per rank, a rank lists the leaves of its own range only, one in-place all-gather-v of the "
-                                      "leaves' (alpha, beta, state, key) per insert queued on the map's stream (13 B per leaf, no padding, no "
-                                      "host synchronisation), front end (but the sample filter) + partition + leaf count + commit + prune "
-                                      "redundant on every rank",
+                       "parallelism": ("one GPU, unsharded map (the N = 1 point of the `--mode shard` series)" if world == 1 else
+                                       f"block-sharded over {world} GPUs: replicated map, contiguous equal-weight ranges of the "
+                                       "test blocks per rank, a rank lists the leaves of its own range only, one in-place all-gather-v of the "
+                                       "leaves' (alpha, beta, state, key) per insert queued on the map's stream (13 B per leaf, no padding, no "
+                                       "host synchronisation), front end (but the sample filter) + partition + leaf count + commit + prune "
+                                       "redundant on every rank"),
                        "voxel_updates_last_step": int(st["voxel_updates"]), "test_blocks": int(st["n_test_blocks"]),
-                       "allgather_v_bytes_total": 13 * int(st["voxel_updates"]),
-                       "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "allgather_v_bytes_total": 13 * int(st["voxel_updates"]) if world > 1 else 0,
+                       "process_group": None if dist is None else
+                                        {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                          "exchange": os.environ.get("LA3DM_SHARD_EXCHANGE", "p2p") + " (sharding.exchange_v: one grouped batch of sends / receives per exchange; LA3DM_SHARD_EXCHANGE=broadcast: one broadcast per rank and array)"}},
             "stages_ms_rank0": stages,
-            "roofline": {"bound": "hbm", "achieved": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9,
+            "stages_ms_by_rank": all_stages,
+            "roofline": {"bound": "hbm", "achieved": b_alg / world / (k_ms * 1e-3) / 1e9,
                          "peak": 8000.0, "unit": "GB/s",
-                         "frac": (16 * int(st["train_reads"]) + 17 * int(st["voxel_updates"])) / world / (k_ms * 1e-3) / 1e9 / 8000.0,
+                         "frac": b_alg / world / (k_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": None, "kernel": "bgk_predict_fuse (rank 0's range of the last steps; algorithmic bytes of the "
                                                     "scan / world: the ranges are cut to equal weight)", "kernel_ms": k_ms},
             "single_gpu": {"what": "the same steps on one unsharded replica, measured in this run on every rank's own GPU (max)",
                            "value": ups1 / dt1, "ms_per_step": dt1 / args.steps * 1e3},
             "speedup_vs_single_gpu": (ups / dt) / (ups1 / dt1)}))
-    dist.destroy_process_group()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def kernel_source_files(sources=("bgk_kernels.h",)):
@@ -874,14 +927,13 @@ def end_to_end(la3dm_amd, params, args):
                                    "pack_kernel_commit_prune": st["t_pack"]}}
 
 
-def out_of_cache_leg(la3dm_amd, _lib, torch, dev):
-    """The same kernel on configs[4]'s scan (1M rays, 0.05 m, depth 3) on this one GPU: B_alg ~ 0.58 GB per launch and a
-    working set beyond the 256 MiB Infinity Cache, so achieved GB/s here is a genuine HBM-side figure (at configs[1] the
-    ~45 MB working set stays cache resident across the in-place steps)."""
-    params = dict(la3dm_amd.BGK_YAML, resolution=0.05, block_depth=3)
-    xyz, origin = la3dm_amd.synthetic_scan(1000000)
+def packed_kernel_leg(la3dm_amd, _lib, torch, dev, rays, res, depth, workload, steps=10, options=None):
+    """la3dm_bgk_scan_device on another packed scan resident in HBM (same protocol as the headline step): kernel time by HIP
+    events, algorithmic bytes, pair evaluations; `options` = la3dm_set_option pairs applied for this leg only"""
+    params = dict(la3dm_amd.BGK_YAML, resolution=res, block_depth=depth)
+    xyz, origin = la3dm_amd.synthetic_scan(rays)
     m = la3dm_amd.BGKOctoMap(**params, device=0)
-    assert m.prepare(xyz, origin, 0.05, 0.5, -1.0)
+    assert m.prepare(xyz, origin, res, 0.5, -1.0)
     st, pk = m.stats(), m.packed()
     U = int(st["voxel_updates"])
     b_alg = 16 * int(st["train_reads"]) + 17 * U
@@ -896,7 +948,8 @@ def out_of_cache_leg(la3dm_amd, _lib, torch, dev):
     scan.n_train_pts, scan.n_train_blk, scan.n_test_blk, scan.n_leaf, scan.flags = pk.n_train_pts, pk.n_train_blk, pk.n_test_blk, pk.n_leaf, pk.flags
     H = _lib.hip()
     stream = torch.cuda.current_stream().cuda_stream
-    steps = 10
+    for k, v in (options or {}).items():
+        m.set_option(k, v)
     for _ in range(2):
         assert H.la3dm_bgk_scan_device(m.ctx(), C.byref(scan), stream, None) == 0
     m.set_option("time_kernel", 1)
@@ -912,10 +965,55 @@ def out_of_cache_leg(la3dm_amd, _lib, torch, dev):
     m.set_option("time_kernel", 0)
     k_ms = float(kt[:nk.value].mean())
     ach = b_alg / (k_ms * 1e-3) / 1e9
-    return {"workload": "BGKOctoMap synthetic 1000000-ray scan, 0.05 m, block_depth 3 (configs[4] on one GPU)",
-            "voxel_updates_per_scan": U, "algorithmic_bytes_per_launch": b_alg, "kernel_ms": k_ms, "ms_per_step": dt * 1e3,
-            "voxel_updates_per_s": U / dt, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-            "pair_evals_per_s": int(st["pair_evals"]) / (k_ms * 1e-3), "steps": steps}
+    sum_mode = m.get_option("bgk_sum")
+    out = {"workload": workload, "kernel": kernel_name(m, sum_mode, scan.flags, pk),
+           "voxel_updates_per_scan": U, "test_blocks": int(pk.n_test_blk), "pair_evals_per_scan": int(st["pair_evals"]),
+           "algorithmic_bytes_per_launch": b_alg, "kernel_ms": k_ms, "ms_per_step": dt * 1e3,
+           "voxel_updates_per_s": U / dt, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+           "pair_evals_per_s": int(st["pair_evals"]) / (k_ms * 1e-3), "steps": steps}
+    counters = profiled_counters(f"rays{rays}_d{depth}_r{res}_sum{sum_mode}")
+    if counters and not options:
+        n_valu, n_salu, n_lds = (counters.get(k, 0) for k in ("valu_insts_per_launch", "salu_insts_per_launch", "lds_insts_per_launch"))
+        simds, clk = 1024, 2.4e9
+        out["traffic"] = counters.get("hbm_bytes_per_launch")
+        out["issue"] = {"valu_insts_per_launch": n_valu, "salu_insts_per_launch": n_salu, "lds_insts_per_launch": n_lds,
+                        "valu_per_tile": n_valu / max(1.0, counters.get("waves_per_launch") or 1.0),
+                        "frac": (n_valu + n_salu + n_lds) / (k_ms * 1e-3) / (simds * clk / 2.2),
+                        "valu_frac_4cycle": n_valu / (k_ms * 1e-3) / (simds * clk / 4.1), "source": counters.get("source")}
+    return out
+
+
+def out_of_cache_leg(la3dm_amd, _lib, torch, dev):
+    """The same kernel on configs[4]'s scan (1M rays, 0.05 m, depth 3) on this one GPU: B_alg ~ 0.58 GB per launch and a
+    working set beyond the 256 MiB Infinity Cache, so achieved GB/s here is a genuine HBM-side figure (at configs[1] the
+    ~45 MB working set stays cache resident across the in-place steps)."""
+    return packed_kernel_leg(la3dm_amd, _lib, torch, dev, 1000000, 0.05, 3,
+                             "BGKOctoMap synthetic 1000000-ray scan, 0.05 m, block_depth 3 (configs[4] on one GPU)")
+
+
+def depth4_leg(la3dm_amd, _lib, torch, dev):
+    """configs[1]'s scan at block_depth 4 — the reference constructor's default (src/bgkoctomap/bgkoctomap.cpp:20-29; SURVEY 8d
+    and BASELINE.md ask for both depths): 0.8 m blocks of 512 leaves = eight 64-leaf tiles per test block, each with the block's
+    7-neighbourhood as candidates; ~8x the pair evaluations of depth 3 for ~1.2x the algorithmic bytes, so the HBM fraction is
+    far lower by construction — the issue fraction says how busy the SIMDs are"""
+    return packed_kernel_leg(la3dm_amd, _lib, torch, dev, 200000, 0.1, 4,
+                             "BGKOctoMap synthetic 200000-ray scan, 0.1 m, block_depth 4 (configs[1] at the reference constructor's default depth)")
+
+
+def kernel_variants_leg(la3dm_amd, _lib, torch, dev):
+    """what a cheaper kernel FUNCTION would buy.  The same launch (configs[1]; configs[4] out of cache) with the
+    evaluation swapped: the default (correctly rounded sqrt / sin / cos: bit-identical k), fast_trig 3 (Eigen 3.3.7 psin / pcos,
+    fp32 only, no f64 chain: the likely reference build's values), fast_trig 1 (fp32 polynomial, <= 1.5 ulp), and `ablate` 1 —
+    NO evaluation at all (results invalid: the floor any evaluation, however cheap, sits on)."""
+    rows = {}
+    for name, opts in (("default", None), ("fast_trig_3", {"fast_trig": 3}), ("fast_trig_1", {"fast_trig": 1}),
+                       ("no_evaluation(ablate 1, invalid results)", {"ablate": 1}),
+                       ("no_tests_no_evaluation(ablate 2, invalid results)", {"ablate": 2})):
+        a = packed_kernel_leg(la3dm_amd, _lib, torch, dev, 200000, 0.1, 3, "configs[1]", steps=20, options=opts)
+        b = packed_kernel_leg(la3dm_amd, _lib, torch, dev, 1000000, 0.05, 3, "configs[4]", steps=6, options=opts)
+        rows[name] = {"configs1_kernel_us": a["kernel_ms"] * 1e3, "configs1_frac": a["frac"], "configs1_kernel": a["kernel"],
+                      "out_of_cache_kernel_us": b["kernel_ms"] * 1e3, "out_of_cache_frac": b["frac"]}
+    return rows
 
 
 def cpu_baseline(params, xyz, origin, args, U, omp=False):

@@ -161,7 +161,8 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
  * "remap" 0-2, "ablate" 0-31 and "lds_pad" (profiling: extra dynamic LDS bytes on the BGK predict launch); values outside
  * these sets are rejected with LA3DM_ERR_ARG;
  * "time_kernel" see la3dm_kernel_times; "bgkl_split_rows" (variant 3): tiles whose seven neighbours hold more
- * rows than this take the split path (default 2048, < 0 = never; results do not depend on it); "bgkl_dense_add" 1 (default) =
+ * rows than this take the split path (default 1024 — env LA3DM_BGKL_SPLIT_ROWS sets another default —, -1 = never, values outside
+ * -1 .. 2^24 are rejected; results do not depend on it); "bgkl_dense_add" 1 (default) =
  * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
  * 0 = the replay expands them itself (results do not depend on it; bgk_sum 0 only — the order-free mode has no replay). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);

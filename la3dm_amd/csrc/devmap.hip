@@ -1189,6 +1189,17 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     DM_RESERVE(dm->t_center, 12ull * n_test);
     DM_RESERVE(dm->t_nbr, 28ull * n_test);
     DM_RESERVE(dm->t_slot, 4ull * n_test);
+    // Every fallible reservation of the pack stage comes BEFORE the launch that creates blocks: dm_test_build
+    // publishes new keys and bumps the device block count, and the new blocks' default nodes are only written by the
+    // leaf-count launch behind it — nothing that can fail may sit between the two.
+    DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
+    DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
+    const size_t max_leaves = (size_t)n_test * ncell;
+    DM_RESERVE(dm->leaf_key, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_alpha, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_beta, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_node, 4 * max_leaves);
+    DM_RESERVE(dm->leaf_state, max_leaves);
     // blocks: find or create (bgkoctomap.cpp:298-305), in the launch that builds the test blocks' keys and neighbour tables
     if ((rc = grow_pool(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
     if ((rc = grow_table(dm, (size_t)dm->n_blocks + n_test)) != LA3DM_OK) return rc;
@@ -1202,14 +1213,6 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     // default nodes for the blocks this launch created — slots [old count, new count); the new count stays on the device (read
     // back with the pass's other counters) — are written by the leaf-count launch below (LeafExtra)
     // pack: leaves in LeafIterator order
-    DM_RESERVE(dm->nleaf, 4ull * (n_test + 1));
-    DM_RESERVE(dm->leaf_off, 4ull * (n_test + 1));
-    const size_t max_leaves = (size_t)n_test * ncell;
-    DM_RESERVE(dm->leaf_key, 4 * max_leaves);
-    DM_RESERVE(dm->leaf_alpha, 4 * max_leaves);
-    DM_RESERVE(dm->leaf_beta, 4 * max_leaves);
-    DM_RESERVE(dm->leaf_node, 4 * max_leaves);
-    DM_RESERVE(dm->leaf_state, max_leaves);
     uint32_t *nleaf = (uint32_t *)dm->nleaf.ptr, *leaf_off = (uint32_t *)dm->leaf_off.ptr;
     LeafExtra lx;
     memset(&lx, 0, sizeof(lx));
@@ -1405,13 +1408,22 @@ static int scan_training_set(la3dm_devmap *dm, uint32_t flags, double t0, la3dm_
         if ((rc = run_pass(dm, P, pass, &n_test0)) != LA3DM_OK) {
             // run_pass is not failure-atomic: dm_table_insert may already have published new keys and bumped the device
             // block counter when a later step (arena growth, a sort, the scan) fails.  Adopt the device counter so that the
-            // table, the pool (new blocks carry their default nodes) and the host agree again — the map stays usable, the
+            // table, the pool (the new blocks get their default nodes here if the pass had not written them) and the host agree again — the map stays usable, the
             // scan is lost, as if the reference had thrown after creating its blocks.  If even that fails: poison.
             const std::string why = dm->ctx->err;
             uint32_t dev_blocks = 0;
             if (hipStreamSynchronize(st) == hipSuccess &&
                 hipMemcpy(&dev_blocks, dm->d_cnt + kCntBlocks, 4, hipMemcpyDeviceToHost) == hipSuccess && dev_blocks <= dm->cap_blocks) {
-                if (dev_blocks > dm->n_blocks) dm->n_blocks = dev_blocks;
+                if (dev_blocks > dm->n_blocks) {
+                    // the slots [old, new) may not have been initialised yet (their default nodes are written by the leaf-count
+                    // launch, which the failed pass may never have reached): write them now, then adopt the count
+                    hipLaunchKernelGGL(dm_pool_init, dim3(cdiv((size_t)(dev_blocks - dm->n_blocks) * dm->npb, 256)), dim3(256), 0, st, dm->A,
+                                       dm->B, dm->S, dm->n_blocks, (const uint32_t *)(dm->d_cnt + kCntBlocks), dm->npb, dm->init_A, dm->init_B);
+                    if (hipStreamSynchronize(st) == hipSuccess)
+                        dm->n_blocks = dev_blocks;
+                    else
+                        dm->poisoned = true;
+                }
             } else {
                 dm->poisoned = true;
             }
@@ -1960,6 +1972,7 @@ int la3dm_devmap_key_bounds(la3dm_devmap *dm, int32_t lo[3], int32_t hi[3]) {
 int la3dm_devmap_export_cells(la3dm_devmap *dm, int state, int original_size, float min_z, float max_z, float *cells,
                               float *rgba, int32_t *level, uint64_t cap, uint64_t *count) {
     if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
+    if (dm) dm->counters_clean = false;   // (this entry point's scans / sorts write counter slots; only an insert's own last launch leaves the block clean)
     if (!dm || !count || (state != 0 && state != 1)) return LA3DM_ERR_ARG;
     *count = 0;
     if (dm->n_blocks == 0) return LA3DM_OK;
@@ -2049,6 +2062,7 @@ int la3dm_devmap_diag_add_repeat(la3dm_ctx *ctx, const float *s, const float *x,
 // scan of the head flags, aux = {segments, valid keys, seg_start[0..segments]} (aux holds n + 3 words).
 int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *aux) {
     if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
+    if (dm) dm->counters_clean = false;   // (this entry point's scans / sorts write counter slots; only an insert's own last launch leaves the block clean)
     if (!dm || !in || !out || !aux || n == 0 || (mode != 0 && mode != 1)) return LA3DM_ERR_ARG;
     DM_TRY(hipSetDevice(dm->ctx->device));
     hipStream_t st = dm->ctx->stream;
@@ -2080,6 +2094,7 @@ int la3dm_devmap_diag_scan(la3dm_devmap *dm, int mode, const uint32_t *in, uint3
 int la3dm_devmap_diag_sort(la3dm_devmap *dm, const uint32_t *keys, const uint32_t *vals, uint32_t n, int bits, uint32_t *keys_out,
                            uint32_t *vals_out) {
     if (dm) dm->mailbox_pending = 0;   // (left behind by a call that failed between a publishing launch and its read_counters)
+    if (dm) dm->counters_clean = false;   // (this entry point's scans / sorts write counter slots; only an insert's own last launch leaves the block clean)
     if (!dm || !keys || !vals || !keys_out || !vals_out || n == 0 || bits < 1 || bits > 32) return LA3DM_ERR_ARG;
     DM_TRY(hipSetDevice(dm->ctx->device));
     hipStream_t st = dm->ctx->stream;

@@ -30,7 +30,7 @@ struct la3dm_ctx {
                              // bgk_prepare's tile records, sin / cos table in LDS — measured equal in cache, -2 % out of cache, and
                              // 2.5 us per step dearer in bgk_prepare: an option, not the default); env LA3DM_BGK_P
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
-    int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML
+    int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML, 3 Eigen 3.3.7 psin / pcos without FMA (the likely reference build)
     int opt_time_kernel = 0;
     int opt_waves = 1;  // waves per workgroup (variant 3)
     int opt_remap = 2;

@@ -232,7 +232,11 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
     if (const char *ev = getenv("LA3DM_BGK_TABLES")) {  // bgk_sum = 1: 0 = bgk_predict_fuse_r for every tile
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_tables = ev[0] - '0';
     }
-    if (const char *ev = getenv("LA3DM_BGKL_SPLIT_ROWS")) ctx->opt_l_split_rows = atoi(ev);   // default of "bgkl_split_rows"
+    if (const char *ev = getenv("LA3DM_BGKL_SPLIT_ROWS")) {   // default of "bgkl_split_rows": an integer (< 0: never split); anything else is ignored
+        char *end = nullptr;
+        const long v = strtol(ev, &end, 10);
+        if (end != ev && *end == 0 && v >= -1 && v <= (1 << 24)) ctx->opt_l_split_rows = (int)v;
+    }
     if (const char *ev = getenv("LA3DM_BGK_P")) {  // bgk_sum = 1 with tables: 1 = bgk_predict_fuse_p, 0 = bgk_predict_fuse_t
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_p = ev[0] - '0';
     }
@@ -328,6 +332,7 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         return LA3DM_OK;
     }
     if (!strcmp(name, "bgkl_split_rows")) {
+        if (value < -1 || value > (1 << 24)) return bad_value("-1 (never split) .. 2^24");
         ctx->opt_l_split_rows = value;
         return LA3DM_OK;
     }
@@ -535,6 +540,10 @@ static int scan_host_common(la3dm_ctx *ctx, const la3dm_bgk_scan *s, la3dm_bgk_c
     int rc = check_scan(ctx, s);
     if (rc != LA3DM_OK) return rc;
     if (out) memset(out, 0, sizeof(*out));
+    if (s->flags & LA3DM_SCAN_ROWS_PREPARED) {   // (the host form uploads 8 floats per row; the prepared form is 12 and device-only)
+        ctx->err = "la3dm_*_scan_host: LA3DM_SCAN_ROWS_PREPARED is a flag of la3dm_bgkl_scan_device only (rows of 12 floats already in HBM)";
+        return LA3DM_ERR_ARG;
+    }
     if (s->n_test_blk == 0) return LA3DM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -121,10 +121,10 @@ def exchange_v(dist, segments, r, world, group=None):
         req.wait()
 
 
-def gather_v(dist, buf, offsets, nbytes, r, world, async_op=False, group=None):
-    """in-place all-gather-v of ONE byte buffer (kept for callers with a single array): exchange_v on one segment"""
+def gather_v(dist, buf, offsets, nbytes, r, world, group=None):
+    """in-place all-gather-v of ONE byte buffer (kept for callers with a single array): exchange_v on one segment.
+    Blocking like exchange_v (round 5 dropped the `async_op` form: there is no list of work handles any more)."""
     exchange_v(dist, [(buf, offsets, nbytes)], r, world, group=group)
-    return []
 
 
 def leaf_segments(leaf_bounds, keys=True):
@@ -145,8 +145,9 @@ def torch_allgather(dist, rank, device, stage_through_host=False, group=None):
     library queues after it waits for the collective; no host synchronisation).  Rank q owns a different number of leaves
     in general (an all-gather-v): all arrays of an exchange go out as ONE grouped batch of point-to-point sends / receives
     (exchange_v: a single ncclGroupStart / End on RCCL).
-    stage_through_host: the gloo self-test on a single GPU (all ranks on cuda:0) — the payload goes through host memory,
-    with the synchronisations that needs; never a measurement.
+    stage_through_host: the gloo self-test on a single GPU (all ranks on cuda:0) — the payload goes through pinned host
+    mirrors of the segments, exchanged by the same exchange_v (one grouped batch of sends / receives) as on RCCL, with the
+    synchronisations that needs; never a measurement.
     group: the process group the shard ranks 0 .. world - 1 are the members of (default: the default group); the shard
     rank handed to set_shard must be the rank INSIDE that group."""
     import torch
@@ -159,22 +160,28 @@ def torch_allgather(dist, rank, device, stage_through_host=False, group=None):
                 end = max(o + n for o, n in zip(offsets, nbytes))
                 if end == 0:
                     continue
-                buf = torch.as_tensor(_DeviceBytes(base, end), device=device)
-                if stage_through_host:
-                    ext.synchronize()
-                    for q in range(world):
-                        if nbytes[q] == 0:
-                            continue
-                        part = buf[offsets[q]:offsets[q] + nbytes[q]]
-                        h = part.cpu() if q == r else torch.empty(nbytes[q], dtype=torch.uint8)
-                        dist.broadcast(h, src=dist.get_global_rank(group, q) if group is not None else q, group=group)
-                        if q != r:
-                            part.copy_(h)
-                    ext.synchronize()
-                    continue
-                segs.append((buf, offsets, nbytes))
-            if segs:
+                segs.append((torch.as_tensor(_DeviceBytes(base, end), device=device), offsets, nbytes))
+            if not segs:
+                return
+            if not stage_through_host:
                 exchange_v(dist, segs, r, world, group=group)   # (NCCL: queued on `ext`; the host is not blocked by the transfer)
+                return
+            # single-GPU self-test (gloo cannot move device memory): the SAME grouped exchange on pinned host mirrors of the
+            # segments — own range down, exchange_v, the others' ranges up — with the synchronisations that needs
+            ext.synchronize()
+            host = []
+            for buf, offsets, nbytes in segs:
+                h = torch.empty(buf.numel(), dtype=torch.uint8).pin_memory()
+                if nbytes[r]:
+                    h[offsets[r]:offsets[r] + nbytes[r]].copy_(buf[offsets[r]:offsets[r] + nbytes[r]])
+                host.append((h, offsets, nbytes))
+            ext.synchronize()
+            exchange_v(dist, host, r, world, group=group)
+            for (buf, offsets, nbytes), (h, _, _) in zip(segs, host):
+                for q in range(world):
+                    if q != r and nbytes[q]:
+                        buf[offsets[q]:offsets[q] + nbytes[q]].copy_(h[offsets[q]:offsets[q] + nbytes[q]])
+            ext.synchronize()
 
     return allgatherv
 

@@ -39,6 +39,17 @@ def test_scan_entry_points_reject_bad_arguments(built):
         setattr(s2, f, dummy.ctypes.data)
     assert H.la3dm_gp_scan_host(ctx, C.byref(s2), None) == ERR_ARG and "variant = 1" in _err(H, ctx)
     assert H.la3dm_bgkl_scan_host(ctx, C.byref(s2), None) == ERR_ARG and "variant = 3" in _err(H, ctx)
+    # LA3DM_SCAN_ROWS_PREPARED (rows of 12 floats already in HBM) is a flag of la3dm_bgkl_scan_device only: the host forms upload
+    # 8 floats per row, so they refuse it instead of letting the kernels read past the upload
+    ml = la3dm_amd.BGKLOctoMap(**la3dm_amd.L_YAML, device=0)
+    s3 = _lib.BgkScan()
+    s3.n_test_blk = 1
+    for f in ("nbr", "blk_center", "leaf_off", "leaf_key", "alpha", "beta", "state", "train_off", "train_xyzy"):
+        setattr(s3, f, dummy.ctypes.data)
+    s3.flags = 0x8
+    assert H.la3dm_bgkl_scan_host(ml.ctx(), C.byref(s3), None) == ERR_ARG and "ROWS_PREPARED" in _err(H, ml.ctx())
+    assert H.la3dm_set_option(ml.ctx(), b"bgkl_split_rows", -7) == ERR_ARG
+    assert H.la3dm_set_option(ml.ctx(), b"bgkl_split_rows", -1) == OK and H.la3dm_set_option(ml.ctx(), b"bgkl_split_rows", 1024) == OK
     assert H.la3dm_set_option(ctx, b"no_such_option", 1) == ERR_ARG and "unknown option" in _err(H, ctx)
     assert H.la3dm_set_option(ctx, None, 1) == ERR_ARG
     # the map still works after the failed calls

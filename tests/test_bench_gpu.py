@@ -86,6 +86,22 @@ def test_two_ranks_self_test(built, mode, scaling):
         assert d["single_gpu"]["value"] > 0 and d["speedup_vs_single_gpu"] > 0
         assert "block-sharded over 2 GPUs" in d["config"]["parallelism"]
         assert d["roofline"]["kernel_ms"] > 0
+        # per-stage wall times of EVERY rank, not only rank 0 (VERDICT r05 #1a)
+        assert len(d["stages_ms_by_rank"]) == 2 and all(s["predict_fuse_own_range"] > 0 for s in d["stages_ms_by_rank"])
+
+
+def test_shard_workload_at_world_1(built):
+    """`--gpus 1 --mode shard`: the N > 1 workload (whole device-resident inserts) on ONE unsharded map, no process group — the
+    N = 1 point of the series `--gpus 2/4/8` continue, so that value(N) is one workload for every N (VERDICT r05 #1a)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "shard", "--steps", "3", "--warmup", "1",
+                        "--rays", "50000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["process_group"] is None
+    assert "one GPU, unsharded" in d["config"]["parallelism"] and len(d["stages_ms_by_rank"]) == 1
+    assert 0.7 < d["speedup_vs_single_gpu"] < 1.4            # the same map twice
 
 
 @pytest.mark.parametrize("workload,extra", [("gp", []), ("lv", []), ("l", [])])

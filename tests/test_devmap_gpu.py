@@ -628,3 +628,53 @@ def test_look_back_error_path_leaves_the_process_usable(built, monkeypatch):
     assert (a["block_key"] == b["block_key"]).all() and (a["node_key"] == b["node_key"]).all()
     assert (a["A"].view(np.uint32) == b["A"].view(np.uint32)).all() and (a["B"].view(np.uint32) == b["B"].view(np.uint32)).all()
     assert (a["state"] == b["state"]).all()
+
+
+def test_counter_block_survives_non_insert_entry_points(built):
+    """an insert leaves the counter block clean for the next one (no dm_begin launch) — any other entry point that
+    runs a scan or a sort writes counter slots in between and must hand the next insert a reset block.  insert, then
+    diag_scan / diag_sort / export_cells, then insert == the same two inserts back to back, bit for bit."""
+    import ctypes as C
+    import la3dm_amd
+    from la3dm_amd import _lib
+    H = _lib.hip()
+    owner = la3dm_amd.BGKOctoMap(**la3dm_amd.BGK_YAML, device=0)      # (its context; the raw pools below are this test's own)
+    clouds = [la3dm_amd.load_pcd(pcd_path("sim_structured", i)) for i in (1, 2)]
+
+    def run(disturb):
+        dm = C.c_void_p()
+        assert H.la3dm_devmap_create(owner.ctx(), C.byref(dm)) == 0
+        try:
+            for k, (xyz, origin) in enumerate(clouds):
+                xyz = np.ascontiguousarray(xyz, np.float32)
+                org = np.asarray(origin, np.float32)
+                assert H.la3dm_devmap_insert_pointcloud_host(dm, xyz.ctypes.data, xyz.shape[0], 3, org.ctypes.data, 0.1, 0.5, 8.0, None) == 0
+                if disturb and k == 0:
+                    x = np.arange(100000, dtype=np.uint32) % 7
+                    out, aux = np.zeros_like(x), np.zeros(4, np.uint32)
+                    assert H.la3dm_devmap_diag_scan(dm, 0, x.ctypes.data, x.size, out.ctypes.data, aux.ctypes.data) == 0
+                    keys = (x * 2654435761 % 4096).astype(np.uint32)
+                    ko, vo = np.zeros_like(keys), np.zeros_like(keys)
+                    assert H.la3dm_devmap_diag_sort(dm, keys.ctypes.data, x.ctypes.data, x.size, 12, ko.ctypes.data, vo.ctypes.data) == 0
+                    assert (np.diff(ko.astype(np.int64)) >= 0).all()
+            nb, npb = C.c_uint32(), C.c_uint32()
+            assert H.la3dm_devmap_block_count(dm, C.byref(nb), C.byref(npb)) == 0
+            n = nb.value * npb.value
+            keys, A, B, S = np.zeros(nb.value, np.int64), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8)
+            assert H.la3dm_devmap_download(dm, keys.ctypes.data, A.ctypes.data, B.ctypes.data, S.ctypes.data) == 0
+            return keys, A, B, S
+        finally:
+            H.la3dm_devmap_destroy(dm)
+
+    ref, got = run(False), run(True)
+    assert ref[0].size > 100
+    for a, b in zip(ref, got):
+        assert a.shape == b.shape and (a.view(np.uint8) == b.view(np.uint8)).all()
+    # the class's own export (an exclusive scan on the pool) between two inserts
+    m, o = _maps(dict(la3dm_amd.BGK_YAML))
+    for k, (xyz, origin) in enumerate(clouds):
+        m.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        o.insert_pointcloud(xyz, origin, 0.1, 0.5, 8.0)
+        if k == 0:
+            assert m.export_cells("occupied")["cells"].shape[0] > 0
+    _same(m, o, "insert / export / insert")

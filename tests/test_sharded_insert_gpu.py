@@ -3,7 +3,8 @@ every rank predicts + fuses a contiguous range of the test blocks (src/bgkoctoma
 that is cut), one in-place all-gather-v of the leaves, commit + prune everywhere; the samples' voxel filter of the front end is
 divided over the ranks by z-layer of its grid and its output all-gathered.  Bar: every replica ends up BIT-IDENTICAL to
 the map a single process builds from the same clouds — two fused scans, so the second one runs on a pruned pool.
-The ranks share the one GPU of the test box and exchange over gloo; with RCCL only the transport changes."""
+The ranks share the one GPU of the test box and exchange over gloo — through the production sharding.exchange_v (one grouped
+batch of sends / receives per exchange) on pinned host mirrors of the segments; with RCCL only the transport changes."""
 import os
 import subprocess
 import sys
@@ -81,10 +82,13 @@ def test_a_rank_local_failure_ends_the_insert_on_every_rank(built, tmp_path, wor
 
 def test_allgather_callback_on_rccl_single_rank(built):
     """The transport the driver's multi-GPU runs use is torch.distributed's nccl backend (RCCL); the box these tests run on
-    has one GPU, so the sharded tests above exchange over gloo.  This runs the production form of the callback
-    (la3dm_amd.sharding.torch_allgather, not staged through the host) on a ONE-rank nccl group: backend setup, device
-    pointer wrapping, ExternalStream ordering and both collective forms execute on RCCL and leave the buffer intact."""
+    has one GPU, so the sharded tests above exchange over gloo (the same sharding.exchange_v, on pinned host mirrors).  This
+    runs what one GPU can of the production transport (tests/helpers/rccl_single_rank.py): the production callback on a
+    ONE-rank nccl group (no peers: plumbing only, it issues no operation) and then REAL RCCL operations — all-gather,
+    broadcast, all-reduce and, where accepted, a grouped send / receive to self — on the map-stream-as-ExternalStream with
+    work queued before and after them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_single_rank.py")],
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rccl single-rank ok: nccl" in r.stdout
+    assert "all_gather_into_tensor, broadcast, all_reduce" in r.stdout, r.stdout[-500:]
