@@ -651,6 +651,15 @@ def gp_leg(args, torch, la3dm_amd, _lib, depth, cpu):
                                          "unit": "VALU wave-instr/s (one per 4 cycles per SIMD)",
                                          "frac": cnt["valu_insts_per_launch"] / (k_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
                                          "all_insts_per_s": rate, "source": cnt.get("source")}
+    if depth == 3:
+        # the same step in option "gp_mode" 1 (gp_eigen_kernels.h): the order of an SSE2 build of Eigen 3.3.7 — no FMA, packet sums, panelled
+        # solves, fp32 pexp — bit-identical to the restatement's set_gp_mode(1) (reported next to mode 0, which stays the default)
+        m.set_option("gp_mode", 1)
+        dt1, k1 = _time_calls(torch, H, m, lambda: H.la3dm_gp_scan_device(m.ctx(), C.byref(scan), stream, None), args.steps, args.warmup)
+        m.set_option("gp_mode", 0)
+        out["gp_mode_1"] = {"what": "Eigen 3.3.7 / SSE2 order of operations on the VALU (no FMA, 4-lane packet sums, llt_inplace blocking, panels of 8 "
+                                    "with reciprocal diagonals, packet exp); an option, the default is gp_mode 0",
+                            "ms_per_step": dt1 * 1e3, "kernel_ms": k1, "voxel_updates_per_s": U / dt1}
     if cpu:
         out["cpu_baseline"] = gp_cpu(la3dm_amd, depth=depth)
     del m

@@ -74,6 +74,7 @@ struct la3dm_devmap {
     // BGKLVOctoMap (variant 2): beams, samples, segments, gather grid, packed blocks
     Arena lv_rng, lv_flags, lv_seg, lv_nsamp, lv_nray, lv_samp_off, lv_ray_off, lv_samples, lv_rays, lv_sorted, lv_cell_off;
     Arena lv_beam, lv_mask;
+    Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist, lv_ncnt, lv_noff;   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
     Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
     int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
     uint32_t lv_n_samples = 0, lv_n_rays = 0;
@@ -401,6 +402,29 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
         rc = sort_pairs(dm, k0, k1, v0, v1, n, key_bits);
     }
     if (rc != LA3DM_OK) return rc;
+    if (dm->ctx->opt_grid_order == 1) {
+        // Verification mode (la3dm_set_option "grid_order" 1): the order of the points INSIDE a cell — the order of the fp32
+        // centroid sums — as pcl::VoxelGrid leaves it: std::sort over {cell index, cloud index} comparing the cell index alone
+        // (PCL 1.10 voxel_grid.hpp, call site src/bgkoctomap/bgkoctomap.cpp:419-431), i.e. whatever libstdc++'s introsort does with equal
+        // keys.  That is a sequential algorithm: the keys go to the host, the host's own std::sort runs on them exactly as PCL's
+        // does, the permutation comes back.  Slow by design (two synchronous copies and a host sort per filter call), never the
+        // default; with "fast_trig" 3 the BGK family is then bit-identical to the restatement's set_modes(1, 1) — the arithmetic a
+        // ROS Noetic build of the reference most plausibly runs (tests/test_likely_trig_gpu.py).
+        std::vector<uint32_t> hk(n);
+        DM_TRY(hipMemcpyAsync(hk.data(), k0, 4ull * n, hipMemcpyDeviceToHost, st));
+        DM_TRY(hipStreamSynchronize(st));
+        std::vector<std::pair<unsigned, unsigned>> iv;
+        iv.reserve(n);
+        for (uint32_t i = 0; i < n; ++i)
+            if (hk[i] != kInvalidCell) iv.emplace_back((unsigned)hk[i], (unsigned)i);
+        struct PclLess {
+            bool operator()(const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) const { return a.first < b.first; }
+        };
+        std::sort(iv.begin(), iv.end(), PclLess());
+        for (size_t j = 0; j < iv.size(); ++j) hk[j] = iv[j].second;
+        if (!iv.empty()) DM_TRY(hipMemcpyAsync(v1, hk.data(), 4ull * iv.size(), hipMemcpyHostToDevice, st));
+        DM_TRY(hipStreamSynchronize(st));   // (hk is a local)
+    }
     rc = scan_heads(dm, k1, n, flag, scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid, (int)kCntBig, true);
     if (rc != LA3DM_OK) return rc;
     // The centroid kernels take the cell count from the counter block and are sized for the worst case (every point its
@@ -747,6 +771,8 @@ static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, con
     // Block-sharded insert: the samples' voxel filter is divided over the ranks by z-layer of its grid (devmap_kernels.h,
     // "sharded sample filter"); every rank ends up with the same filtered list, in the single-GPU order.
     const GridParams &g1 = *dm->h_gp;   // (grid of the cloud's own filter: the box of the raw hits)
+    if (dm->shard_world > 1 && ctx->opt_grid_order == 1 && !(ds_resolution < 0))
+        return dm_fail(dm, LA3DM_ERR_ARG, "devmap: option grid_order 1 (pcl::VoxelGrid's own sort, a verification mode) runs on one GPU only");
     bool sharded_filter = dm->shard_world > 1 && !(ds_resolution < 0) && !g1.passthrough && !g1.empty;
     int zbase = 0;
     uint32_t nlayer = 0;
@@ -1518,11 +1544,19 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     uint32_t *nsamp = (uint32_t *)dm->lv_nsamp.ptr, *nray = (uint32_t *)dm->lv_nray.ptr;
     uint32_t *samp_off = (uint32_t *)dm->lv_samp_off.ptr, *ray_off = (uint32_t *)dm->lv_ray_off.ptr;
     hipLaunchKernelGGL(dm_lv_ranges, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (double *)dm->lv_rng.ptr);
-    if (nh <= 98304u) {  // (the bit matrix is nh^2 / 8 bytes: 1.2 GB at this bound) membership of the "nearby" gather for all (beam, hit) pairs at once, then the ordered walk over the set bits
+    // ray shortening (bgklvoctomap.cpp:313-423).  Small scans (configs[3]'s 3 500-point clouds): the dense form — membership of
+    // the "nearby" gather for all (beam, hit) pairs at once as an nh x nh bit matrix, then the ordered walk over the set bits,
+    // hit list in LDS.  Larger scans: the same sets from a uniform grid over the hits, O(N k) in time and memory (round 6).
+    // LA3DM_LV_NEAR=dense | grid forces one of them (the tests compare the two).
+    const char *near_env = getenv("LA3DM_LV_NEAR");
+    const bool force_dense = near_env && !strcmp(near_env, "dense"), force_grid = near_env && !strcmp(near_env, "grid");
+    if (force_dense && nh > 98304u)
+        return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): LA3DM_LV_NEAR=dense needs nh^2 / 8 bytes of mask: at most 98 304 hits");
+    DM_RESERVE(dm->lv_beam, sizeof(LvBeam) * (size_t)nh);
+    hipLaunchKernelGGL(dm_lv_beam_init, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (LvBeam *)dm->lv_beam.ptr);
+    if (force_dense || (!force_grid && nh < 8192u)) {
         const uint32_t nw = cdiv(nh, 64);
-        DM_RESERVE(dm->lv_beam, sizeof(LvBeam) * (size_t)nh);
         DM_RESERVE(dm->lv_mask, 8ull * nh * nw);
-        hipLaunchKernelGGL(dm_lv_beam_init, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (LvBeam *)dm->lv_beam.ptr);
         // (beams per workgroup: small scans need the parallelism — a tile is walked in sequence —, large ones the reuse of the wave's 64 hits)
         const bool small_scan = nh < 16384u;
         const uint32_t near_tile = small_scan ? 32u : kLvNearTile;
@@ -1538,8 +1572,78 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
                            (const LvBeam *)dm->lv_beam.ptr, (const unsigned long long *)dm->lv_mask.ptr, nw, (uint8_t *)dm->lv_flags.ptr,
                            (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt, lds_hits);
     } else {
-        hipLaunchKernelGGL(dm_lv_beams, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, (const double *)dm->lv_rng.ptr,
+        const double *rng = (const double *)dm->lv_rng.ptr;
+        const LvBeam *beams = (const LvBeam *)dm->lv_beam.ptr;
+        // 1. the grid: bounds of the in-range hits in cells of edge `influence` around the sensor -> dimensions
+        hipLaunchKernelGGL(dm_lv_hit_bounds, dim3(std::min<uint32_t>(cdiv(nh, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, nh, ba, rng, dm->d_cnt);
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        if (dm->h_cnt[kCntError] & kErrLvExtent) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): hit coordinates beyond the ray-shortening grid's index range");
+        int32_t hmm[7];
+        memcpy(hmm, dm->h_cnt + kCntLvHmm, 28);
+        if (hmm[6] == 0) hmm[0] = hmm[1] = hmm[2] = hmm[3] = hmm[4] = hmm[5] = 0;   // no hit in range: one empty cell
+        LvHitGrid G;
+        uint64_t ncell = 0;
+        for (int m = 1;; m *= 2) {   // coarser cells while the dense grid would need more than 2^24 of them
+            ncell = 1;
+            for (int a = 0; a < 3; ++a) {
+                G.dim[a] = (int32_t)(((int64_t)hmm[3 + a] - hmm[a]) / m + 1);
+                ncell *= (uint64_t)G.dim[a];
+            }
+            G.cell = ba.influence * m;
+            if (ncell <= (1ull << 24)) break;
+        }
+        G.g0[0] = (double)ba.ox + (double)hmm[0] * ba.influence;
+        G.g0[1] = (double)ba.oy + (double)hmm[1] * ba.influence;
+        G.g0[2] = (double)ba.oz + (double)hmm[2] * ba.influence;
+        DM_RESERVE(dm->lv_hcell, 4ull * nh);
+        DM_RESERVE(dm->lv_hlist, 4ull * nh);
+        DM_RESERVE(dm->lv_hcnt, 4ull * (ncell + 1));
+        DM_RESERVE(dm->lv_hoff, 4ull * (ncell + 1));
+        DM_RESERVE(dm->lv_ncnt, 4ull * ((size_t)nh + 1));
+        DM_RESERVE(dm->lv_noff, 4ull * ((size_t)nh + 1));
+        uint32_t *hcnt = (uint32_t *)dm->lv_hcnt.ptr, *hoff = (uint32_t *)dm->lv_hoff.ptr, *ncnt = (uint32_t *)dm->lv_ncnt.ptr, *noff = (uint32_t *)dm->lv_noff.ptr;
+        DM_TRY(hipMemsetAsync(hcnt, 0, 4ull * (ncell + 1), st));
+        hipLaunchKernelGGL(dm_lv_hgrid_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, rng, G, (uint32_t *)dm->lv_hcell.ptr, hcnt);
+        if ((rc = exclusive_scan(dm, hcnt, hoff, (uint32_t)ncell + 1)) != LA3DM_OK) return rc;
+        DM_TRY(hipMemsetAsync(hcnt, 0, 4ull * (ncell + 1), st));
+        hipLaunchKernelGGL(dm_lv_hgrid_fill, dim3(cdiv(nh, 256)), dim3(256), 0, st, (const uint32_t *)dm->lv_hcell.ptr, nh, (const uint32_t *)hoff, hcnt,
+                           (uint32_t *)dm->lv_hlist.ptr);
+        if (!(near_env && !strcmp(near_env, "grid2"))) {
+            // 2. every beam in one wave: capsule walk, nearby hits collected and sorted in LDS, the ordered shortening (dm_lv_beams_grid)
+            hipLaunchKernelGGL(dm_lv_beams_grid, dim3(cdiv(nh, kLvGridWaves)), dim3(64 * kLvGridWaves), 0, st, d_hits, nh, ba, rng, beams, G,
+                               (const uint32_t *)hoff, (const uint32_t *)dm->lv_hlist.ptr, (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray,
+                               dm->d_cnt);
+            hipLaunchKernelGGL(dm_lv_beam_totals, dim3(std::min<uint32_t>(cdiv(nh, 256), kMinmaxWgs)), dim3(256), 0, st, (const uint32_t *)nsamp,
+                               (const uint8_t *)dm->lv_flags.ptr, nh, dm->d_cnt);
+        } else {
+        // 2. the beams' nearby sets: count, offsets, fill
+        DM_TRY(hipMemsetAsync(ncnt + nh, 0, 4, st));
+        hipLaunchKernelGGL((dm_lv_near_grid<false>), dim3(cdiv(nh, 4)), dim3(256), 0, st, d_hits, nh, ba, rng, beams, G, (const uint32_t *)hoff,
+                           (const uint32_t *)dm->lv_hlist.ptr, ncnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        if ((rc = exclusive_scan(dm, ncnt, noff, nh + 1, (int)kCntMembers, true)) != LA3DM_OK) return rc;
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        const uint32_t n_pairs = dm->h_cnt[kCntMembers];
+        if (n_pairs > (1u << 28)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): more than 2^28 (beam, nearby hit) pairs in one scan");
+        const size_t pb = 4ull * std::max<uint32_t>(n_pairs, 4u);
+        DM_RESERVE(dm->k0, pb);
+        DM_RESERVE(dm->k1, pb);
+        DM_RESERVE(dm->v0, pb);
+        DM_RESERVE(dm->v1, pb);
+        uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
+        if (n_pairs) {
+            hipLaunchKernelGGL((dm_lv_near_grid<true>), dim3(cdiv(nh, 4)), dim3(256), 0, st, d_hits, nh, ba, rng, beams, G, (const uint32_t *)hoff,
+                               (const uint32_t *)dm->lv_hlist.ptr, (uint32_t *)nullptr, (const uint32_t *)noff, k0, v0);
+            // 3. hit order inside every beam: stable sorts by hit index, then by beam (a beam's range [noff[h], noff[h + 1]) stays its own)
+            int bits = 1;
+            while ((1ull << bits) < nh) ++bits;
+            if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_pairs, bits)) != LA3DM_OK) return rc;
+            if ((rc = sort_pairs(dm, v1, v0, k1, k0, n_pairs, bits)) != LA3DM_OK) return rc;
+        }
+        // 4. the ordered walk
+        hipLaunchKernelGGL(dm_lv_beams_walk_list, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, beams, (const uint32_t *)noff, (const uint32_t *)k0,
                            (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
+        if (getenv("LA3DM_DEBUG_LV")) fprintf(stderr, "la3dm BGK-LV ray shortening on the hit grid: %u hits, %d x %d x %d cells of %.3f m, %u (beam, nearby hit) pairs\n", nh, G.dim[0], G.dim[1], G.dim[2], G.cell, n_pairs);
+        }
     }
     if ((rc = exclusive_scan(dm, nsamp, samp_off, nh, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
     if ((rc = exclusive_scan(dm, nray, ray_off, nh, (int)kCntKept, true)) != LA3DM_OK) return rc;

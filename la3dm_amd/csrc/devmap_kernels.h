@@ -51,7 +51,8 @@ enum DevCounter {
     kCntGrid = 21,       // GridParams of the last voxel-filter call (10 words), for the host
     kCntBbox = 31,       // training-set box (6 floats as bits), for the host
     kCntLvmm = 37,       // BGK-LV: bucket bounds of the finite samples (3 min, 3 max as int32) + their count
-    kCntWords = 48
+    kCntLvHmm = 48,      // BGK-LV: cell bounds of the in-range hits on the ray-shortening grid (3 min, 3 max as int32) + their count
+    kCntWords = 56       // (< 64: one lane per word in dm_publish_wave, word kCntWords of the mailbox is the sequence number)
 };
 
 struct GridParams {  // pcl::VoxelGrid bookkeeping of one filter call
@@ -279,6 +280,8 @@ __device__ __forceinline__ uint32_t counter_begin_value(uint32_t i, uint32_t n_b
     uint32_t v = i == (uint32_t)kCntBlocks ? n_blocks : 0u;
     if (i >= (uint32_t)kCntLvmm && i < (uint32_t)kCntLvmm + 3u) v = 0x7FFFFFFFu;        // INT32_MAX
     else if (i >= (uint32_t)kCntLvmm + 3u && i < (uint32_t)kCntLvmm + 6u) v = 0x80000000u;   // INT32_MIN
+    else if (i >= (uint32_t)kCntLvHmm && i < (uint32_t)kCntLvHmm + 3u) v = 0x7FFFFFFFu;
+    else if (i >= (uint32_t)kCntLvHmm + 3u && i < (uint32_t)kCntLvHmm + 6u) v = 0x80000000u;
     return v;
 }
 __global__ void dm_begin(uint32_t *counters, uint32_t n_blocks, uint32_t *mm, uint32_t *done) {

@@ -36,91 +36,12 @@ __global__ __launch_bounds__(256) void dm_lv_ranges(const float *__restrict__ hi
 }
 
 constexpr uint32_t kLvBeamHit = 1u, kLvBeamSkip = 2u;
+constexpr uint32_t kErrLvExtent = 4u;   // counters[kCntError]: coordinates beyond a grid's index range
 
-// One lane per beam; the hit list is walked in order by every lane (the shortening is order dependent: each accepted
-// hit changes the length the next ones are tested against).  The reference gathers the "nearby" hits first and then
-// walks them — the gather only uses the beam's initial length and end point, so the two loops fuse.
-__global__ __launch_bounds__(64) void dm_lv_beams(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
-                                                 const double *__restrict__ rng, uint8_t *__restrict__ flags,
-                                                 float *__restrict__ seg, uint32_t *__restrict__ nsamp,
-                                                 uint32_t *__restrict__ nray, uint32_t *counters) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0;
-    bool is_hit = false;
-    if (h < nh) {
-        const float px = hits[3 * (size_t)h], py = hits[3 * (size_t)h + 1], pz = hits[3 * (size_t)h + 2];
-        const float ox = a.ox, oy = a.oy, oz = a.oz;
-        double l = lv_norm(px - ox, py - oy, pz - oz);
-        const float nx = (float)((px - ox) / l), ny = (float)((py - oy) / l), nz = (float)((pz - oz) / l);
-        uint32_t fl = 0;
-        if (a.max_range > 0) {
-            if (l < a.max_range) {
-                l = (float)sqrt((double)((px - ox) * (px - ox) + (py - oy) * (py - oy) + (pz - oz) * (pz - oz)));
-                l = l - a.offset;
-                fl |= kLvBeamHit;
-            } else {
-                l = a.max_range - a.offset;
-            }
-        }
-        float npz = pz;                      // nearest_point.z()
-        const float ex = (float)(ox + nx * l), ey = (float)(oy + ny * l), ez = (float)(oz + nz * l);   // free_endpt
-        const float lvx = ex - ox, lvy = ey - oy, lvz = ez - oz;                                      // line_vec
-        const double lvn = lv_norm(lvx, lvy, lvz);
-        const double l0 = l;
-        const bool high = (double)pz > (a.offset + (double)oz);
-        for (uint32_t q = 0; q < nh; ++q) {
-            const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
-            const double dist2 = rng[q];
-            if (a.max_range > 0 && dist2 > a.max_range) continue;
-            if (high && (double)qz < (double)oz + a.influence) continue;  // keeps free space above the floor
-            const double dist1 = lv_norm(ex - qx, ey - qy, ez - qz);
-            if (!(dist1 < a.influence || (dist1 < l0 && dist2 < l0))) continue;
-            // nearby: shorten the beam where it passes within `influence` of this hit
-            const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
-            const double b = (double)(vx * lvx + vy * lvy + vz * lvz);
-            if (b > l * l) continue;
-            const float t = (float)(b / (lvn * lvn));
-            const float mx = ox + lvx * t, my = oy + lvy * t, mz = oz + lvz * t;   // nearest point of the line
-            if (lv_norm(qx - mx, qy - my, qz - mz) < a.influence) {
-                npz = qz;
-                l = b / lvn;
-            }
-        }
-        if (l < a.max_range / 5.0 && l / (a.offset - (double)npz) > 0) {  // downward rays close to the sensor
-            fl |= kLvBeamSkip;
-        } else {
-            const float fex = (float)(ox + nx * l), fey = (float)(oy + ny * l), fez = (float)(oz + nz * l);
-            float fox = fex, foy = fey, foz = fez;
-            if (l > a.influence * 1.0) {
-                fox = (float)(ox + nx * a.influence * 1.0);
-                foy = (float)(oy + ny * a.influence * 1.0);
-                foz = (float)(oz + nz * a.influence * 1.0);
-            }
-            float *s = seg + 6 * (size_t)h;
-            s[0] = fox; s[1] = foy; s[2] = foz; s[3] = fex; s[4] = fey; s[5] = fez;
-            // samples: the segment start, then from its end back towards the start (beam_sample, :439-462)
-            const float len = (float)sqrt((double)((fex - fox) * (fex - fox) + (fey - foy) * (fey - foy) + (fez - foz) * (fez - foz)));
-            c = 1;
-            for (float d = len; d > 0.0 && c < kBeamCap; d -= a.free_res) ++c;
-            if (c >= kBeamCap) {  // see beam_count in devmap_kernels.h
-                atomicOr(&counters[kCntError], kErrBeam);
-                c = 1;
-            }
-        }
-        flags[h] = (uint8_t)fl;
-        nray[h] = (fl & kLvBeamSkip) ? 0u : 1u;
-        c += (fl & kLvBeamHit) ? 1u : 0u;
-        nsamp[h] = c;
-        is_hit = (fl & kLvBeamHit) != 0u;
-    }
-    beam_total_add(c, counters);
-    const unsigned long long hm = __ballot(is_hit);
-    if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(hm));  // hit samples of the scan
-}
-
-// ---- the same beam computation in two parallel-friendly steps (used while the nh x nh bit matrix fits: nh <= 32768) ----
-// dm_lv_beams walks all nh hits per beam in one lane: nh / 64 waves of nh iterations with three f64 square roots each —
-// 0.7 ms for a 3 000-hit scan on a chip that then sits 95 % idle.  The membership test of the "nearby" gather depends
+// ---- the beam computation in two parallel-friendly steps (the dense form: small scans, nh < 8192) ----
+// One lane per beam walking all nh hits (the reference's loop, bgklvoctomap.cpp:313-423: the shortening is order dependent — each
+// accepted hit changes the length the next ones are tested against) is nh / 64 waves of nh iterations with three f64 square roots
+// each — 0.7 ms for a 3 000-hit scan on a chip that then sits 95 % idle.  The membership test of the "nearby" gather depends
 // only on the beam's INITIAL length and end point, so it runs for all (beam, hit) pairs at once (one wave per beam and
 // 64 hits, the ballot is the row's mask word); the order-dependent shortening then only visits the set bits.
 struct LvBeam {
@@ -282,6 +203,507 @@ __global__ __launch_bounds__(256) void dm_lv_beams_walk(const float *__restrict_
     if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(hm));
 }
 
+// ---- ray shortening in O(N k) (round 6): the "nearby" sets from a uniform grid over the hits ------------------------
+// dm_lv_nearby above tests every (beam, hit) pair and keeps an nh x nh bit matrix: O(N^2) time AND memory, as the reference's
+// own loop (bgklvoctomap.cpp:313-423) is in time — 2.5 of the 3.85 ms of a 50 k-ray insert, 5 GB of mask at 200 k hits.
+// A hit can only be "nearby" AND shorten a beam if it lies within `influence` of the beam's line and (within `influence` of the
+// free end point, or nearer than the initial length l0 to both the sensor and that end point) — i.e. inside a capsule of radius
+// `influence` around the segment sensor -> end point.  So: the in-range hits go into a uniform grid (cell >= influence), every
+// beam (one lane) visits the cells its capsule can touch — slab by slab along the beam's dominant axis, a handful of cells per
+// slab — and applies EXACTLY dm_lv_nearby's tests to the hits it finds there (lv_near below: the same expressions).  The
+// candidates of a beam come out in grid order; the shortening is order dependent (every accepted hit changes the length the
+// next ones are gated on), so the (beam, hit) pairs are sorted by hit index inside every beam — two stable radix sorts: by hit,
+// then by beam — and dm_lv_beams_walk_list walks a beam's list exactly as dm_lv_beams_walk walks the set bits of its mask
+// row: the same hits in the same order, bit-identical segments (tests/test_lv_gpu.py compares the two paths).
+struct LvHitGrid {
+    double cell;      // edge: influence * 2^k (k > 0 only when the scan's extent needs more than 2^24 cells)
+    double g0[3];     // lower corner: cell (i, j, k) = floor((p - g0) / cell)
+    int32_t dim[3];
+};
+// the membership test of one (beam, hit) pair — the expressions of dm_lv_nearby, in its order
+__device__ __forceinline__ bool lv_near(const LvBeam &b, const LvBeamArgs &a, float qx, float qy, float qz, double dist2) {
+    if (a.max_range > 0 && dist2 > a.max_range) return false;
+    const bool low = (double)qz < (double)a.oz + a.influence;
+    const bool high = (double)b.pz > (a.offset + (double)a.oz);
+    if (high && low) return false;
+    const double dist1 = lv_norm(b.ex - qx, b.ey - qy, b.ez - qz);
+    if (!(dist1 < a.influence || (dist1 < b.l0 && dist2 < b.l0))) return false;
+    const float ox = a.ox, oy = a.oy, oz = a.oz;
+    const float lvx = b.ex - ox, lvy = b.ey - oy, lvz = b.ez - oz;
+    const double lvn = lv_norm(lvx, lvy, lvz);
+    const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
+    const double bb = (double)(vx * lvx + vy * lvy + vz * lvz);
+    const float t = (float)(bb / (lvn * lvn));
+    const float mx = ox + lvx * t, my = oy + lvy * t, mz = oz + lvz * t;
+    return lv_norm(qx - mx, qy - my, qz - mz) < a.influence;
+}
+// cell coordinates (on the finest grid: edge = influence, origin = the sensor) of the hits that can be nearby at all:
+// finite and inside max_range; their bounds by one set of atomics per workgroup
+__global__ __launch_bounds__(256) void dm_lv_hit_bounds(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
+                                                       uint32_t *counters) {
+    __shared__ int32_t s_lo[4][3], s_hi[4][3];
+    __shared__ uint32_t s_n[4];
+    int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    uint32_t n_ok = 0;
+    const double org[3] = {(double)a.ox, (double)a.oy, (double)a.oz};
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nh; q += gridDim.x * blockDim.x) {
+        const float p[3] = {hits[3 * (size_t)q], hits[3 * (size_t)q + 1], hits[3 * (size_t)q + 2]};
+        if (!finite3(p[0], p[1], p[2]) || (a.max_range > 0 && rng[q] > a.max_range)) continue;
+        bool ok = true;
+        int32_t c[3];
+        for (int k = 0; k < 3; ++k) {
+            const double v = floor(((double)p[k] - org[k]) / a.influence);
+            ok &= v >= -1073741824.0 && v <= 1073741824.0;
+            c[k] = (int32_t)v;
+        }
+        if (!ok) {
+            atomicOr(&counters[kCntError], kErrLvExtent);
+            continue;
+        }
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = min(lo[k], c[k]);
+            hi[k] = max(hi[k], c[k]);
+        }
+        ++n_ok;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], o));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], o));
+        }
+        n_ok += __shfl_xor(n_ok, o);
+    }
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; ++k) {
+            s_lo[wv][k] = lo[k];
+            s_hi[wv][k] = hi[k];
+        }
+        s_n[wv] = n_ok;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (int w = 0; w < 4; ++w) n += s_n[w];
+        if (n) {
+            int32_t *mm = (int32_t *)(counters + kCntLvHmm);
+            for (int k = 0; k < 3; ++k) {
+                int32_t l = s_lo[0][k], h = s_hi[0][k];
+                for (int w = 1; w < 4; ++w) {
+                    l = min(l, s_lo[w][k]);
+                    h = max(h, s_hi[w][k]);
+                }
+                atomicMin(&mm[k], l);
+                atomicMax(&mm[3 + k], h);
+            }
+            atomicAdd(&counters[kCntLvHmm + 6], n);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t lv_hit_cell(const LvHitGrid &G, const LvBeamArgs &a, float x, float y, float z, double dist2) {
+    if (!finite3(x, y, z) || (a.max_range > 0 && dist2 > a.max_range)) return 0xFFFFFFFFu;
+    const long long i = (long long)floor(((double)x - G.g0[0]) / G.cell), j = (long long)floor(((double)y - G.g0[1]) / G.cell),
+                    k = (long long)floor(((double)z - G.g0[2]) / G.cell);
+    if (i < 0 || j < 0 || k < 0 || i >= G.dim[0] || j >= G.dim[1] || k >= G.dim[2]) return 0xFFFFFFFFu;   // (cannot happen: the grid spans their bounds)
+    return (uint32_t)((k * G.dim[1] + j) * G.dim[0] + i);
+}
+// cell of every hit + the cells' populations (cnt is zero on entry)
+__global__ __launch_bounds__(256) void dm_lv_hgrid_count(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
+                                                        LvHitGrid G, uint32_t *__restrict__ hcell, uint32_t *cnt) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nh) return;
+    const uint32_t c = lv_hit_cell(G, a, hits[3 * (size_t)q], hits[3 * (size_t)q + 1], hits[3 * (size_t)q + 2], rng[q]);
+    hcell[q] = c;
+    if (c != 0xFFFFFFFFu) atomicAdd(&cnt[c], 1u);
+}
+// the cells' hit lists (any order inside a cell: the pairs are sorted afterwards); fill is zero on entry
+__global__ __launch_bounds__(256) void dm_lv_hgrid_fill(const uint32_t *__restrict__ hcell, uint32_t nh, const uint32_t *__restrict__ off,
+                                                       uint32_t *fill, uint32_t *__restrict__ list) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nh) return;
+    const uint32_t c = hcell[q];
+    if (c != 0xFFFFFFFFu) list[off[c] + atomicAdd(&fill[c], 1u)] = q;
+}
+// The cells a beam's capsule can touch, slab by slab along the dominant axis of the (extended) segment.
+struct LvTube {
+    double A[3], D[3], w[3], inv;   // extended segment A + t D, t in [0, 1]; extent of the cylinder's cross-section per axis; 1 / D[ax]
+    int ax, u, v, i0, i1;           // dominant axis, the other two, slab range (empty: i0 > i1)
+};
+__device__ __forceinline__ LvTube lv_tube_setup(const LvBeam &b, const LvBeamArgs &a, const LvHitGrid &G) {
+    LvTube T;
+    T.ax = 0; T.u = 1; T.v = 2; T.i0 = 0; T.i1 = -1; T.inv = 0.0;
+    const double R = a.influence * 1.001 + 1e-4;   // (margin: the tests' own roundings, the float end point)
+    const double P0[3] = {(double)a.ox, (double)a.oy, (double)a.oz}, P1[3] = {(double)b.ex, (double)b.ey, (double)b.ez};
+    double d[3], len2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        d[k] = P1[k] - P0[k];
+        len2 += d[k] * d[k];
+    }
+    for (int k = 0; k < 3; ++k) T.A[k] = T.D[k] = T.w[k] = 0.0;
+    if (!(len2 < 1e30)) return T;   // a NaN / infinite beam is near nothing (every comparison of lv_near fails)
+    const double len = sqrt(len2);
+    double n[3] = {1.0, 0.0, 0.0};
+    if (len > 1e-9)
+        for (int k = 0; k < 3; ++k) n[k] = d[k] / len;
+    // the capsule lies inside the cylinder of radius R around [A, A + D], the segment extended by R at both ends
+    for (int k = 0; k < 3; ++k) {
+        T.A[k] = P0[k] - n[k] * R;
+        T.D[k] = d[k] + 2.0 * n[k] * R;
+        T.w[k] = R * sqrt(fmax(0.0, 1.0 - n[k] * n[k]));
+    }
+    int ax = fabs(T.D[1]) > fabs(T.D[0]) ? 1 : 0;
+    if (fabs(T.D[2]) > fabs(T.D[ax])) ax = 2;
+    T.ax = ax;
+    T.u = ax == 0 ? 1 : 0;
+    T.v = ax == 2 ? 1 : 2;
+    const double lo_a = fmin(T.A[ax], T.A[ax] + T.D[ax]) - T.w[ax], hi_a = fmax(T.A[ax], T.A[ax] + T.D[ax]) + T.w[ax];
+    const double fi0 = floor((lo_a - G.g0[ax]) / G.cell), fi1 = floor((hi_a - G.g0[ax]) / G.cell);
+    if (fi1 < 0.0 || fi0 >= (double)G.dim[ax]) return T;
+    T.i0 = (int)fmax(fi0, 0.0);
+    T.i1 = (int)fmin(fi1, (double)(G.dim[ax] - 1));
+    T.inv = 1.0 / T.D[ax];
+    return T;
+}
+// the cells of slab i (index along the dominant axis): visit(cell) once per cell
+template <class F>
+__device__ __forceinline__ void lv_tube_slab(const LvTube &T, const LvHitGrid &G, int i, F &&visit) {
+    const int ax = T.ax, u = T.u, v = T.v;
+    const double slo = G.g0[ax] + (double)i * G.cell - T.w[ax], shi = G.g0[ax] + (double)(i + 1) * G.cell + T.w[ax];
+    double t0 = (slo - T.A[ax]) * T.inv, t1 = (shi - T.A[ax]) * T.inv;
+    if (t0 > t1) {
+        const double tt = t0;
+        t0 = t1;
+        t1 = tt;
+    }
+    t0 = fmax(t0, 0.0);
+    t1 = fmin(t1, 1.0);
+    if (t0 > t1) return;
+    const double ua = T.A[u] + t0 * T.D[u], ub = T.A[u] + t1 * T.D[u], va = T.A[v] + t0 * T.D[v], vb = T.A[v] + t1 * T.D[v];
+    const double fj0 = floor((fmin(ua, ub) - T.w[u] - G.g0[u]) / G.cell), fj1 = floor((fmax(ua, ub) + T.w[u] - G.g0[u]) / G.cell);
+    const double fk0 = floor((fmin(va, vb) - T.w[v] - G.g0[v]) / G.cell), fk1 = floor((fmax(va, vb) + T.w[v] - G.g0[v]) / G.cell);
+    if (fj1 < 0.0 || fj0 >= (double)G.dim[u] || fk1 < 0.0 || fk0 >= (double)G.dim[v]) return;
+    const int j0 = (int)fmax(fj0, 0.0), j1 = (int)fmin(fj1, (double)(G.dim[u] - 1));
+    const int k0 = (int)fmax(fk0, 0.0), k1 = (int)fmin(fk1, (double)(G.dim[v] - 1));
+    const int stride[3] = {1, G.dim[0], G.dim[0] * G.dim[1]};
+    for (int k = k0; k <= k1; ++k)
+        for (int j = j0; j <= j1; ++j) visit((uint32_t)(i * stride[ax] + j * stride[u] + k * stride[v]));
+}
+// One WAVE per beam.  Phase 1, lane = slab: the non-empty cells of the capsule go to a queue in LDS.  Phase 2, lane = hit of
+// a queued cell: a cheap fp32 pre-test (distance to the beam's line, with a margin — a hit farther than that fails lv_near's
+// last comparison anyway) in front of the exact tests.  (First form: one lane per beam, ~1 000 dependent cell look-ups in a
+// row — 1.05 ms per pass at 43 k beams, 672 waves waiting for memory.  Second: lane = slab for the tests too — 0.48 ms: the hits
+// sit in the few slabs at the beam's end, two to four lanes did all the f64 work.)  kFill = false: cnt[h] = nearby hits of
+// beam h; true: their indices at pair_q[off[h] ..) in any order (the pairs are sorted afterwards), pair_h = h beside them.
+constexpr uint32_t kLvCellQ = 192;   // queued cells per beam; the rare beam with more tests the overflow cells lane by lane
+template <bool kFill>
+__global__ __launch_bounds__(256) void dm_lv_near_grid(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
+                                                      const LvBeam *__restrict__ beams, LvHitGrid G, const uint32_t *__restrict__ cell_off,
+                                                      const uint32_t *__restrict__ cell_list, uint32_t *__restrict__ cnt,
+                                                      const uint32_t *__restrict__ off, uint32_t *__restrict__ pair_q, uint32_t *__restrict__ pair_h) {
+    __shared__ uint32_t s_n[4], s_nc[4];
+    __shared__ uint2 s_cells[4][kLvCellQ];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t h = blockIdx.x * 4u + wv;
+    if (lane == 0) s_n[wv] = s_nc[wv] = 0u;
+    __syncthreads();
+    const bool live = h < nh;
+    const LvBeam b = beams[live ? h : 0u];
+    const LvTube T = lv_tube_setup(b, a, G);
+    uint32_t n = 0;
+    const uint32_t base = (kFill && live) ? off[h] : 0u;
+    // the line's direction in fp32 for the pre-test (from the tube's own extended segment: defined for every finite beam)
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    {
+        const double dl = sqrt(T.D[0] * T.D[0] + T.D[1] * T.D[1] + T.D[2] * T.D[2]);
+        if (dl > 0.0) {
+            ux = (float)(T.D[0] / dl);
+            uy = (float)(T.D[1] / dl);
+            uz = (float)(T.D[2] / dl);
+        }
+    }
+    const float r_pre = (float)(a.influence * 1.01 + 1e-3);
+    const float r_pre2 = r_pre * r_pre;
+    // |v|^2 - along^2 cancels: its fp32 error is < ~8 ulp of |v|^2 = 5e-7 |v|^2; the pre-test is used while that stays below half the
+    // margin r_pre^2 - influence^2 (ell = 0.2: within 35 m of the sensor), farther hits (and NaN) go straight to the exact tests
+    const float vv_max = (r_pre2 - (float)(a.influence * a.influence)) * 1e6f;
+    auto test = [&](uint32_t q) {
+        const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
+        const float vx = qx - a.ox, vy = qy - a.oy, vz = qz - a.oz;
+        const float along = vx * ux + vy * uy + vz * uz, vv = vx * vx + vy * vy + vz * vz;
+        if (vv < vv_max && vv - along * along > r_pre2) return;
+        if (lv_near(b, a, qx, qy, qz, rng[q])) {
+            if (kFill) {
+                const uint32_t pos = base + atomicAdd(&s_n[wv], 1u);
+                pair_q[pos] = q;
+                pair_h[pos] = h;
+            }
+            ++n;
+        }
+    };
+    if (live)
+        for (int i = T.i0 + (int)lane; i <= T.i1; i += 64)
+            lv_tube_slab(T, G, i, [&](uint32_t c) {
+                const uint32_t p0 = cell_off[c], p1 = cell_off[c + 1];
+                if (p1 == p0) return;
+                const uint32_t slot = atomicAdd(&s_nc[wv], 1u);
+                if (slot < kLvCellQ) s_cells[wv][slot] = make_uint2(p0, p1);
+                else
+                    for (uint32_t p = p0; p < p1; ++p) test(cell_list[p]);
+            });
+    __syncthreads();
+    if (!live) return;
+    const uint32_t nc = min(s_nc[wv], kLvCellQ);
+    for (uint32_t ci = 0; ci < nc; ++ci) {
+        const uint2 r = s_cells[wv][ci];
+        for (uint32_t p = r.x + lane; p < r.y; p += 64u) test(cell_list[p]);
+    }
+    if (!kFill) {
+        for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+        if (lane == 0) cnt[h] = n;
+    }
+}
+// ---- the whole beam in ONE kernel (round 6, third form): capsule walk -> the beam's nearby hits collected in LDS -> sorted by
+// hit index in LDS -> the ordered shortening -> segment + sample count.  No pair arrays, no device-wide sorts, no host read-back of
+// a pair count.  One wave per beam (its LDS is its own: only wave-level barriers).  A beam whose nearby set does not fit the LDS
+// buffer is walked in windows of the hit index (the shortening only needs the hits in ascending order: window after window
+// is the same sequence); cells beyond the queue's capacity are tested by the lane that found them.
+constexpr uint32_t kLvMatchCap = 1024;   // nearby hits per beam and window held in LDS
+__device__ __forceinline__ void lv_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+constexpr uint32_t kLvGridWaves = 2;   // beams per workgroup: 2 x (cell queue 1.5 KB + match buffer 4 KB)
+__global__ __launch_bounds__(64 * kLvGridWaves) void dm_lv_beams_grid(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
+                                                                     const LvBeam *__restrict__ beams, LvHitGrid G, const uint32_t *__restrict__ cell_off,
+                                                                     const uint32_t *__restrict__ cell_list, uint8_t *__restrict__ flags, float *__restrict__ seg,
+                                                                     uint32_t *__restrict__ nsamp, uint32_t *__restrict__ nray, uint32_t *counters) {
+    __shared__ uint32_t s_n[kLvGridWaves], s_nc[kLvGridWaves];
+    __shared__ uint2 s_cells[kLvGridWaves][kLvCellQ];
+    __shared__ uint32_t s_m[kLvGridWaves][kLvMatchCap];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t h = blockIdx.x * kLvGridWaves + wv;
+    if (h >= nh) return;   // (no workgroup barrier below)
+    const LvBeam b = beams[h];
+    const LvTube T = lv_tube_setup(b, a, G);
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    {
+        const double dl = sqrt(T.D[0] * T.D[0] + T.D[1] * T.D[1] + T.D[2] * T.D[2]);
+        if (dl > 0.0) {
+            ux = (float)(T.D[0] / dl);
+            uy = (float)(T.D[1] / dl);
+            uz = (float)(T.D[2] / dl);
+        }
+    }
+    const float r_pre = (float)(a.influence * 1.01 + 1e-3);
+    const float r_pre2 = r_pre * r_pre;
+    const float vv_max = (r_pre2 - (float)(a.influence * a.influence)) * 1e6f;   // (see dm_lv_near_grid)
+    const float ox = a.ox, oy = a.oy, oz = a.oz;
+    const float lvx = b.ex - ox, lvy = b.ey - oy, lvz = b.ez - oz;
+    const double lvn = lv_norm(lvx, lvy, lvz);
+    double l = b.l0;
+    float npz = b.pz;
+    uint32_t qlo = 0, win = nh;
+    while (qlo < nh) {
+        const uint32_t qhi = (nh - qlo <= win) ? nh : qlo + win;
+        if (lane == 0) s_n[wv] = 0u;
+        lv_wave_sync();
+        auto test = [&](uint32_t q) {
+            if (q < qlo || q >= qhi) return;
+            const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
+            const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
+            const float along = vx * ux + vy * uy + vz * uz, vv = vx * vx + vy * vy + vz * vz;
+            if (vv < vv_max && vv - along * along > r_pre2) return;
+            if (lv_near(b, a, qx, qy, qz, rng[q])) {
+                const uint32_t pos = atomicAdd(&s_n[wv], 1u);
+                if (pos < kLvMatchCap) s_m[wv][pos] = q;
+            }
+        };
+        for (int r0 = T.i0; r0 <= T.i1; r0 += 64) {
+            if (lane == 0) s_nc[wv] = 0u;
+            lv_wave_sync();
+            const int i = r0 + (int)lane;
+            if (i <= T.i1)
+                lv_tube_slab(T, G, i, [&](uint32_t c) {
+                    const uint32_t p0 = cell_off[c], p1 = cell_off[c + 1];
+                    if (p1 == p0) return;
+                    const uint32_t slot = atomicAdd(&s_nc[wv], 1u);
+                    if (slot < kLvCellQ) s_cells[wv][slot] = make_uint2(p0, p1);
+                    else
+                        for (uint32_t p = p0; p < p1; ++p) test(cell_list[p]);
+                });
+            lv_wave_sync();
+            const uint32_t nc = min(s_nc[wv], kLvCellQ);
+            for (uint32_t ci = 0; ci < nc; ++ci) {
+                const uint2 r = s_cells[wv][ci];
+                for (uint32_t p = r.x + lane; p < r.y; p += 64u) test(cell_list[p]);
+            }
+            lv_wave_sync();
+        }
+        const uint32_t n = s_n[wv];
+        if (n > kLvMatchCap) {   // too many for the buffer: the same hits, a narrower window of the hit index
+            win = max(1u, (qhi - qlo) >> 1);
+            continue;
+        }
+        if (n > 1u) {   // bitonic sort of s_m[0, n) (ascending), padded to a power of two with the largest key
+            uint32_t M = 64u;
+            while (M < n) M <<= 1;
+            for (uint32_t idx = n + lane; idx < M; idx += 64u) s_m[wv][idx] = 0xFFFFFFFFu;
+            lv_wave_sync();
+            for (uint32_t k = 2u; k <= M; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                    for (uint32_t t = lane; t < (M >> 1); t += 64u) {
+                        const uint32_t i0 = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), i1 = i0 + j;
+                        const uint32_t x0 = s_m[wv][i0], x1 = s_m[wv][i1];
+                        const bool up = (i0 & k) == 0u;
+                        if ((x0 > x1) == up) {
+                            s_m[wv][i0] = x1;
+                            s_m[wv][i1] = x0;
+                        }
+                    }
+                    lv_wave_sync();
+                }
+        }
+        // the ordered walk: a hit's projection term does not depend on the running length, so 64 of them are formed at once
+        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            const uint32_t m = min(64u, n - c0);
+            double bq = 0.0;
+            float qzl = 0.f;
+            if (lane < m) {
+                const uint32_t q = s_m[wv][c0 + lane];
+                const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
+                const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
+                bq = (double)(vx * lvx + vy * lvy + vz * lvz);
+                qzl = qz;
+            }
+            for (uint32_t i = 0; i < m; ++i) {
+                const double bi = __shfl(bq, (int)i);
+                const float qzi = __shfl(qzl, (int)i);
+                if (bi > l * l) continue;   // (the distance-to-the-line test is already in the list)
+                npz = qzi;
+                l = bi / lvn;
+            }
+        }
+        lv_wave_sync();
+        qlo = qhi;
+    }
+    if (lane != 0) return;
+    uint32_t fl = b.fl, c = 0;
+    const float nx = b.nx, ny = b.ny, nz = b.nz;
+    if (l < a.max_range / 5.0 && l / (a.offset - (double)npz) > 0) {  // downward rays close to the sensor
+        fl |= kLvBeamSkip;
+    } else {
+        const float fex = (float)(ox + nx * l), fey = (float)(oy + ny * l), fez = (float)(oz + nz * l);
+        float fox = fex, foy = fey, foz = fez;
+        if (l > a.influence * 1.0) {
+            fox = (float)(ox + nx * a.influence * 1.0);
+            foy = (float)(oy + ny * a.influence * 1.0);
+            foz = (float)(oz + nz * a.influence * 1.0);
+        }
+        float *s = seg + 6 * (size_t)h;
+        s[0] = fox; s[1] = foy; s[2] = foz; s[3] = fex; s[4] = fey; s[5] = fez;
+        const float len = (float)sqrt((double)((fex - fox) * (fex - fox) + (fey - foy) * (fey - foy) + (fez - foz) * (fez - foz)));
+        c = 1;
+        for (float d = len; d > 0.0 && c < kBeamCap; d -= a.free_res) ++c;
+        if (c >= kBeamCap) {
+            atomicOr(&counters[kCntError], kErrBeam);
+            c = 1;
+        }
+    }
+    flags[h] = (uint8_t)fl;
+    nray[h] = (fl & kLvBeamSkip) ? 0u : 1u;
+    c += (fl & kLvBeamHit) ? 1u : 0u;
+    nsamp[h] = c;
+}
+// the counters the walk kernels keep (64-bit sample total, hit samples), for dm_lv_beams_grid — one set of atomics per workgroup
+__global__ __launch_bounds__(256) void dm_lv_beam_totals(const uint32_t *__restrict__ nsamp, const uint8_t *__restrict__ flags, uint32_t nh, uint32_t *counters) {
+    __shared__ unsigned long long s_t[4];
+    __shared__ uint32_t s_h[4];
+    unsigned long long t = 0;
+    uint32_t hc = 0;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x) {
+        t += nsamp[h];
+        hc += (flags[h] & kLvBeamHit) ? 1u : 0u;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        t += __shfl_xor(t, o);
+        hc += __shfl_xor(hc, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_t[threadIdx.x >> 6] = t;
+        s_h[threadIdx.x >> 6] = hc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        uint32_t hh = 0;
+        for (int w = 0; w < 4; ++w) {
+            all += s_t[w];
+            hh += s_h[w];
+        }
+        if (all) atomicAdd(reinterpret_cast<unsigned long long *>(counters + kCntBeamTotal), all);
+        if (hh) atomicAdd(&counters[kCntTrained], hh);
+    }
+}
+
+// dm_lv_beams_walk over a beam's sorted list of nearby hits instead of the set bits of its mask row (the same hits, the same order)
+__global__ __launch_bounds__(64) void dm_lv_beams_walk_list(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
+                                                           const LvBeam *__restrict__ beams, const uint32_t *__restrict__ off,
+                                                           const uint32_t *__restrict__ list, uint8_t *__restrict__ flags, float *__restrict__ seg,
+                                                           uint32_t *__restrict__ nsamp, uint32_t *__restrict__ nray, uint32_t *counters) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0;
+    bool is_hit = false;
+    if (h < nh) {
+        const LvBeam bm = beams[h];
+        const float ox = a.ox, oy = a.oy, oz = a.oz;
+        const float nx = bm.nx, ny = bm.ny, nz = bm.nz;
+        double l = bm.l0;
+        uint32_t fl = bm.fl;
+        float npz = bm.pz;
+        const float lvx = bm.ex - ox, lvy = bm.ey - oy, lvz = bm.ez - oz;
+        const double lvn = lv_norm(lvx, lvy, lvz);
+        const uint32_t p1 = off[h + 1];
+        for (uint32_t p = off[h]; p < p1; ++p) {
+            const uint32_t q = list[p];
+            const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
+            const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
+            const double b = (double)(vx * lvx + vy * lvy + vz * lvz);
+            if (b > l * l) continue;   // (the distance-to-the-line test is already in the list)
+            npz = qz;
+            l = b / lvn;
+        }
+        if (l < a.max_range / 5.0 && l / (a.offset - (double)npz) > 0) {  // downward rays close to the sensor
+            fl |= kLvBeamSkip;
+        } else {
+            const float fex = (float)(ox + nx * l), fey = (float)(oy + ny * l), fez = (float)(oz + nz * l);
+            float fox = fex, foy = fey, foz = fez;
+            if (l > a.influence * 1.0) {
+                fox = (float)(ox + nx * a.influence * 1.0);
+                foy = (float)(oy + ny * a.influence * 1.0);
+                foz = (float)(oz + nz * a.influence * 1.0);
+            }
+            float *s = seg + 6 * (size_t)h;
+            s[0] = fox; s[1] = foy; s[2] = foz; s[3] = fex; s[4] = fey; s[5] = fez;
+            const float len = (float)sqrt((double)((fex - fox) * (fex - fox) + (fey - foy) * (fey - foy) + (fez - foz) * (fez - foz)));
+            c = 1;
+            for (float d = len; d > 0.0 && c < kBeamCap; d -= a.free_res) ++c;
+            if (c >= kBeamCap) {
+                atomicOr(&counters[kCntError], kErrBeam);
+                c = 1;
+            }
+        }
+        flags[h] = (uint8_t)fl;
+        nray[h] = (fl & kLvBeamSkip) ? 0u : 1u;
+        c += (fl & kLvBeamHit) ? 1u : 0u;
+        nsamp[h] = c;
+        is_hit = (fl & kLvBeamHit) != 0u;
+    }
+    beam_total_add(c, counters);
+    const unsigned long long hm = __ballot(is_hit);
+    if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(hm));
+}
+
 // samples {x, y, z, ray as float (-1 = hit)} and segments {start, first sample index bits | end, 0} in beam order
 __global__ __launch_bounds__(256) void dm_lv_emit(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
                                                  const uint8_t *__restrict__ flags, const float *__restrict__ seg,
@@ -315,7 +737,6 @@ struct LvGridArgs {
 __device__ __forceinline__ long long lv_cidx(float v, double half, double g) { return (long long)floor(((double)v + half) / g); }
 
 // mm[0..2] = min, mm[3..5] = max bucket coordinate over the finite samples (int32 range; error bit 4 otherwise), mm[6] = their count
-constexpr uint32_t kErrLvExtent = 4u;
 __global__ __launch_bounds__(256) void dm_lv_cell_bounds(const float4 *__restrict__ samples, uint32_t ns, double half, double g,
                                                         int32_t *mm, uint32_t *counters) {
     __shared__ int32_t s_lo[4][3], s_hi[4][3];

@@ -31,6 +31,10 @@ struct la3dm_ctx {
                              // 2.5 us per step dearer in bgk_prepare: an option, not the default); env LA3DM_BGK_P
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML, 3 Eigen 3.3.7 psin / pcos without FMA (the likely reference build)
+    int opt_gp_mode = 0;    // GPOctoMap: 0 = FMA chains in ascending order (VALU and matrix cores alike: the parity configuration), 1 = the order of an
+                            // x86-64 / SSE2 build of Eigen 3.3.7 on the VALU (gp_eigen_kernels.h; blocks of up to 128 points); env LA3DM_GP_MODE
+    int opt_grid_order = 0;  // device-resident map's voxel-grid filters: 0 = ascending cloud index inside a cell (the parity configuration), 1 = the order
+                             // pcl::VoxelGrid's unstable std::sort leaves (host sort of the downloaded keys: verification mode, slow by design)
     int opt_time_kernel = 0;
     int opt_waves = 1;  // waves per workgroup (variant 3)
     int opt_remap = 2;

@@ -15,6 +15,7 @@
 
 #include "bgk_kernels.h"
 #include "gp_kernels.h"
+#include "gp_eigen_kernels.h"
 #include "lv_kernels.h"
 #include "bgkl_kernels.h"
 
@@ -237,6 +238,9 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
         const long v = strtol(ev, &end, 10);
         if (end != ev && *end == 0 && v >= -1 && v <= (1 << 24)) ctx->opt_l_split_rows = (int)v;
     }
+    if (const char *ev = getenv("LA3DM_GP_MODE")) {  // default of "gp_mode"
+        if (ev[0] == '0' || ev[0] == '1') ctx->opt_gp_mode = ev[0] - '0';
+    }
     if (const char *ev = getenv("LA3DM_BGK_P")) {  // bgk_sum = 1 with tables: 1 = bgk_predict_fuse_p, 0 = bgk_predict_fuse_t
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_p = ev[0] - '0';
     }
@@ -331,6 +335,16 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_remap = value;
         return LA3DM_OK;
     }
+    if (!strcmp(name, "grid_order")) {
+        if (value < 0 || value > 1) return bad_value("0 (ascending cloud index inside a voxel-grid cell) or 1 (what libstdc++'s std::sort on the cell index alone leaves, as pcl::VoxelGrid: verification mode)");
+        ctx->opt_grid_order = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "gp_mode")) {
+        if (value < 0 || value > 1) return bad_value("0 (FMA chains in ascending order: the parity configuration) or 1 (Eigen 3.3.7 / SSE2 order, no FMA, pexp)");
+        ctx->opt_gp_mode = value;
+        return LA3DM_OK;
+    }
     if (!strcmp(name, "bgkl_split_rows")) {
         if (value < -1 || value > (1 << 24)) return bad_value("-1 (never split) .. 2^24");
         ctx->opt_l_split_rows = value;
@@ -356,6 +370,8 @@ int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value) {
     else if (!strcmp(name, "bgk_tables")) *value = ctx->opt_bgk_tables;
     else if (!strcmp(name, "bgk_p")) *value = ctx->opt_bgk_p;
     else if (!strcmp(name, "fast_trig")) *value = ctx->opt_fast_trig;
+    else if (!strcmp(name, "gp_mode")) *value = ctx->opt_gp_mode;
+    else if (!strcmp(name, "grid_order")) *value = ctx->opt_grid_order;
     else if (!strcmp(name, "waves_per_wg")) *value = ctx->opt_waves;
     else if (!strcmp(name, "remap")) *value = ctx->opt_remap;
     else return LA3DM_ERR_ARG;
@@ -635,7 +651,7 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     a.n_train_blk = s->n_train_blk;
     a.vmax = 0;
     a.vscratch = nullptr;
-    if (max_n >= (uint32_t)kGpMfmaMinN) {
+    if (max_n >= (uint32_t)kGpMfmaMinN && ctx->opt_gp_mode != 1) {
         a.vmax = (max_n + 31u) & ~31u;   // whole 32-row blocks: the solve stores its padded rows too
         if ((rc = arena_reserve(ctx, ctx->gp_v, sizeof(float) * (size_t)a.n_tasks * a.vmax * kWave)) != LA3DM_OK) return rc;
         a.vscratch = (float *)ctx->gp_v.ptr;
@@ -672,7 +688,18 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
                            (float4 *)ctx->pts_scaled.ptr, s->n_train_pts, a.scale, s->nbr, s->train_off,
                            (uint2 *)ctx->nbr_range.ptr, n_nbr);
     }
-    if (s->n_train_blk) {
+    const bool eigen_order = ctx->opt_gp_mode == 1;
+    if (eigen_order && max_n > (uint32_t)kGpEigenMaxN) {
+        ctx->err = "la3dm_gp_scan: gp_mode 1 (Eigen order on the VALU) takes training blocks of up to " + std::to_string(kGpEigenMaxN) +
+                   " points; this scan holds one of " + std::to_string(max_n) + " (block_depth 4 and up belong to the matrix-core path: gp_mode 0)";
+        return LA3DM_ERR_ARG;
+    }
+    if (s->n_train_blk && eigen_order) {
+        const uint32_t nn = max_n ? max_n : 1u, n_tiny = nn < (uint32_t)kGpTrainTinyN ? nn : (uint32_t)kGpTrainTinyN;
+        hipLaunchKernelGGL(gp_train_eigen_kernel, dim3(s->n_train_blk), dim3(kWave), gp_train_wave_lds(n_tiny), stream, a, 0, (int)n_tiny);
+        if (nn > n_tiny)
+            hipLaunchKernelGGL(gp_train_eigen_kernel, dim3(s->n_train_blk), dim3(kWave), gp_train_wave_lds(nn), stream, a, (int)n_tiny, (int)nn);
+    } else if (s->n_train_blk) {
         const uint32_t nn = max_n < (uint32_t)kGpTrainLdsMaxN ? (max_n ? max_n : 1u) : (uint32_t)kGpTrainLdsMaxN;
         const uint32_t n_tiny = nn < (uint32_t)kGpTrainTinyN ? nn : (uint32_t)kGpTrainTinyN;
         hipLaunchKernelGGL(gp_train_wave_kernel, dim3(s->n_train_blk), dim3(kWave), gp_train_wave_lds(n_tiny), stream, a, 0, (int)n_tiny);
@@ -692,7 +719,9 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
         ev = &ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(ctx, hipEventRecord(ev->first, stream));
     }
-    {
+    if (eigen_order) {
+        hipLaunchKernelGGL(gp_predict_fuse_eigen_kernel, dim3(a.n_tasks), dim3(kWave), (size_t)(max_n ? max_n : 1u) * kWave * sizeof(float), stream, a);
+    } else {
         const uint32_t rows = max_n < (uint32_t)kGpLdsRows ? (max_n ? max_n : 1u) : (uint32_t)kGpLdsRows;
         const size_t lds = rows * kWave * sizeof(float);
         // tiles without a large neighbour; then (if there is any large block) the tiles with one — every tile once

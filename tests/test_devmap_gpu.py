@@ -662,7 +662,9 @@ def test_counter_block_survives_non_insert_entry_points(built):
             n = nb.value * npb.value
             keys, A, B, S = np.zeros(nb.value, np.int64), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8)
             assert H.la3dm_devmap_download(dm, keys.ctypes.data, A.ctypes.data, B.ctypes.data, S.ctypes.data) == 0
-            return keys, A, B, S
+            order = np.argsort(keys, kind="stable")       # (pool slots are handed out by an atomic: their order differs from run to run)
+            per = lambda a: a.reshape(nb.value, npb.value)[order]
+            return keys[order], per(A), per(B), per(S)
         finally:
             H.la3dm_devmap_destroy(dm)
 

@@ -136,6 +136,60 @@ def test_against_the_eigen_order_restatement(built, depth, nscan, share, bound, 
     assert (d <= 1e-5).mean() >= share, float((d <= 1e-5).mean())
 
 
+@pytest.mark.parametrize("case", ["sim_structured_2_scans", "configs2_50k_rays"])
+def test_gp_mode_1_is_the_eigen_order_restatement_bit_for_bit(built, case):
+    """VERDICT r05 #4 — option "gp_mode" 1 (gp_eigen_kernels.h): the regressor in the order of an x86-64 / SSE2 build of Eigen
+    3.3.7 on the VALU — no FMA, 4-lane packet inner products, llt_inplace's unblocked / blocked factorisation, triangular solves
+    in panels of 8 with reciprocal diagonals, the SSE packet exp — against the restatement's oracle.set_gp_mode(1)
+    (include/gpoctomap/gpregressor.h:42-51, 80-92, 114-117 as that build would evaluate it): BIT-IDENTICAL at the YAML's
+    block_depth 3 — two fused sim_structured scans and configs[2]'s synthetic 50 000-ray scan (N <= 79).  With this the user
+    of a real la3dm build has a device mode for GPOctoMap like fast_trig 3 is for the BGK family."""
+    import la3dm_amd
+    from oracle import oracle as O
+    params = dict(la3dm_amd.GP_YAML)
+    m = la3dm_amd.GPOctoMap(**params, device=0)
+    m.set_option("gp_mode", 1)
+    assert m.get_option("gp_mode") == 1
+    O.set_gp_mode(1, omp=True)
+    try:
+        o = O.OracleGPMap(**params, omp=True)
+        if case == "sim_structured_2_scans":
+            for i in (1, 2):
+                xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_structured", i))
+                m.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+                o.insert_pointcloud(xyz, origin, 0.1, 0.1, 8.0)
+        else:
+            xyz, origin = la3dm_amd.synthetic_scan(50000)
+            m.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
+            o.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
+    finally:
+        O.set_gp_mode(0, omp=True)
+    a, b = m.leaves(), o.leaves()
+    assert a["A"].size == b["A"].size and a["A"].size > 10000
+    for k in ("block_key", "node_key", "state", "classified"):
+        assert (a[k] == b[k]).all(), k
+    for k in ("A", "B"):
+        assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), (k, int((a[k] != b[k]).sum()), float(np.abs(a[k] - b[k]).max()))
+
+
+def test_gp_mode_1_refuses_blocks_beyond_its_capacity(built):
+    """gp_mode 1 runs on the VALU with the factor in LDS: training blocks of up to 128 points.  block_depth 4 (N up to 531 at
+    configs[2]) belongs to the matrix-core path, whose accumulation order is mode 0's — the call fails with the cause named and
+    the map stays usable in mode 0."""
+    import la3dm_amd
+    params = dict(la3dm_amd.GP_YAML, block_depth=4)
+    m = la3dm_amd.GPOctoMap(**params, device=0)
+    m.set_option("gp_mode", 1)
+    xyz, origin = la3dm_amd.synthetic_scan(20000)
+    with pytest.raises(RuntimeError, match="gp_mode 1"):
+        m.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
+    m.set_option("gp_mode", 0)
+    m.insert_pointcloud(xyz, origin, 0.1, 0.1, -1.0)
+    assert m.block_count() > 100
+    with pytest.raises(RuntimeError):
+        m.set_option("gp_mode", 2)
+
+
 def test_exp_of_the_gp_kernels_is_the_restatement_s_for_every_argument(built):
     """The Matern kernel's exp(-d) on the device (gp_kernels.h exp_cr_dev: f64 reduction by ln 2, degree-13 polynomial, one
     rounding to f32) against (float)exp((double)x) — what the restatement's cr_expf computes — for EVERY fp32 x in
