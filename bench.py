@@ -374,7 +374,7 @@ def kernel_name(m, sum_mode, flags, pk):
     if not (m.get_option("bgk_tables") and (flags & 2)):
         return f"bgk_predict_fuse_r<{trig}>"
     full = bool(flags & 4) and int(pk.n_leaf) == int(pk.n_test_blk) * 8 ** (int(m.block_depth) - 1)
-    return f"bgk_predict_fuse_{'p' if m.get_option('bgk_p') else 't'}<{trig}, {'false' if full else 'true'}>"
+    return f"bgk_predict_fuse_t<{trig}, {'false' if full else 'true'}>"
 
 
 def shard_workload(args):

@@ -150,10 +150,18 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
  *     the mode: bgk_predict_fuse_t ("bgk_tables" 1, the default; env LA3DM_BGK_TABLES) — per-axis distance tables for the
  *     tiles of un-pruned blocks, the general path for the others in the same launch; needs LA3DM_SCAN_LABELS_01 — and
  *     bgk_predict_fuse_r ("bgk_tables" 0, and every scan without that flag).  Same pairs, same kernel values, same sums.
- *     "bgk_p" 1 (default 0; env LA3DM_BGK_P) = bgk_predict_fuse_p instead of _t: one-read prologue from per-tile records that
- *     the prescale launch writes, sin / cos table in LDS — the same results, no faster in cache, ~2 % faster out of cache.
+ *     "bgk_tile_desc" 1 (default) = at block_depth >= 4 every 64-leaf tile of a full block gets its own neighbour descriptor
+ *     without the face neighbours its voxel cube cannot reach (only while ell <= 4 * resolution; 0 = block-wide descriptors; same results).
  *   0 = the reference's fp32 summation order (bgk_predict_fuse_v5): bit-identical to the CPU restatement, the regression
  *     mode of the parity suites.
+ * "gp_mode" (GPOctoMap; env LA3DM_GP_MODE) 0 = every inner product an fp32 FMA chain in ascending order, on the VALU and the matrix
+ * cores alike (default: the parity configuration), 1 = the order of operations of an x86-64 / SSE2 build of Eigen 3.3.7 on the VALU
+ * (no FMA, packet sums, llt_inplace blocking, panels of 8 with reciprocal diagonals, packet exp: la3dm_amd/csrc/gp_eigen_kernels.h),
+ * bit-identical to the restatement's oracle.set_gp_mode(1); training blocks of up to 128 points (block_depth 3), else LA3DM_ERR_ARG.
+ * "grid_order" (device-resident maps) 0 = ascending cloud index inside a voxel-grid cell (default), 1 = what pcl::VoxelGrid's own
+ * std::sort on the cell index alone leaves (src/bgkoctomap/bgkoctomap.cpp:419-431): the keys are sorted on the HOST by libstdc++ —
+ * a verification mode, slow by design, single GPU; with "fast_trig" 3 (and "gp_mode" 1) the device path is bit-identical to the
+ * restatement's oracle.set_modes(1, 1): the configuration a ROS Noetic build of the reference most plausibly runs.
  * "fast_trig" 0 = correctly rounded sin/cos (default: the parity configuration), 1 = f32 polynomial, 2 = OCML (BGK kernels
  * only), 3 = Eigen 3.3.7's psin / pcos without FMA — the arithmetic a ROS Noetic build of the reference most plausibly runs
  * (include/bgkoctomap/bgkinference.h:115-116), for the BGK, BGK-L and BGK-LV kernels, bit-identical to the restatement's
@@ -166,7 +174,7 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
  * the split tiles' rows are expanded for all items at once (64 KB more scratch per item) and added by a copy-only replay,
  * 0 = the replay expands them itself (results do not depend on it; bgk_sum 0 only — the order-free mode has no replay). */
 int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value);
-/* current value of an option that has one ("bgk_sum", "bgk_tables", "bgk_p", "fast_trig", "waves_per_wg", "remap") */
+/* current value of an option that has one ("bgk_sum", "bgk_tables", "bgk_tile_desc", "fast_trig", "gp_mode", "grid_order", "waves_per_wg", "remap") */
 int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value);
 
 /* All pointers in *scan are HOST pointers. Synchronous: H2D, kernels, D2H. */

@@ -44,12 +44,12 @@ struct BgkArgs {
     uint8_t *state;
     const float4 *lut;          // voxel LUT, depth-major, w unused
     const uint2 *nbr_range;     // [n_test_blk * 7] {first point, count} of each neighbour model (resolved by the prescale launch)
-    const uint32_t *blk_desc;   // [n_test_blk * 16] flat view of the 7 neighbour ranges for bgk_predict_fuse_r (see bgk_prepare)
+    const uint32_t *blk_desc;   // [(n_test_blk << desc_shift) * 16] flat view of the 7 neighbour ranges for bgk_predict_fuse_r / _t (see bgk_prepare)
     const uint32_t *label_seq;  // == seq when this scan has a label other than 0 / 1 (written by bgk_prepare)
-    const uint32_t *tile_rec;   // [n_tasks * 32] per-tile record of bgk_predict_fuse_p (see bgk_prepare / TileRec)
     uint32_t seq;               // number of this scan
     uint32_t n_test_blk;
     uint32_t tpb_shift;         // log2(tiles per test block)
+    uint32_t desc_shift;        // 0: one descriptor per test block in blk_desc; tpb_shift: one per TILE (block_depth >= 4, see bgk_prepare)
     uint32_t n_tasks;           // n_test_blk << tpb_shift
     uint32_t flags;
     uint32_t remap;             // 0 contiguous range per XCD, 1 identity, 2 chunks of 8
@@ -174,12 +174,6 @@ __device__ __forceinline__ void sincos_cr_core(float t, float &s, float &c, Fetc
 __device__ __forceinline__ la3dm_v2d sincos_cr_entry(uint32_t ub) {  // the table entry of q = ub & 127 (a 16-byte gather)
     return *reinterpret_cast<const la3dm_v2d *>(reinterpret_cast<const char *>(kSinCosTab) + ((ub & 127u) << 4));
 }
-// the same for a FINITE t in [0, 2 pi] (ub = 0x4B400000 + q, q <= 64): ub << 4 is 0xB4000000 + 16 q in 32 bits, so the
-// entry is at (table - 0xB4000000) + (ub << 4) — one shift, no mask.  Only where t cannot be NaN (the BGK kernels' ring
-// entries: a pair is pushed only if its d2 compared below the hit threshold).
-__device__ __forceinline__ la3dm_v2d sincos_cr_entry_finite(uint32_t ub) {
-    return *reinterpret_cast<const la3dm_v2d *>(reinterpret_cast<const char *>(kSinCosTab) - 0xB4000000ll + (unsigned long long)(ub << 4));
-}
 // the table read from memory (a 16-byte gather that stays in the vector L1): any t in [0, 2 pi], NaN in -> NaN out
 __device__ __forceinline__ void sincos_cr(float t, float &s, float &c) {
     sincos_cr_core(t, s, c, [](uint32_t ub, double &sa, double &ca) {
@@ -188,13 +182,9 @@ __device__ __forceinline__ void sincos_cr(float t, float &s, float &c) {
         ca = e.y;
     });
 }
-__device__ __forceinline__ void sincos_cr_finite(float t, float &s, float &c) {
-    sincos_cr_core(t, s, c, [](uint32_t ub, double &sa, double &ca) {
-        const la3dm_v2d e = sincos_cr_entry_finite(ub);
-        sa = e.x;
-        ca = e.y;
-    });
-}
+// (Rounds 4 and 5 read the entry of a ring entry's t without the mask — `(ub << 4)` against a table pointer biased by 0xB4000000,
+//  one instruction less per batch — which is only in bounds while t is finite: true by construction of the ring, but a wild read
+//  the day that invariant breaks.  Round 6: the masked form everywhere; the 128-entry table cannot be left.)
 // (the table across the wave's lanes by ds_bpermute_b32 was measured slower: 24.5 cycles per SIMD per crossbar
 // instruction, four per batch, against one L1 gather)
 
@@ -290,68 +280,11 @@ __device__ __forceinline__ float cov_sparse(float r, float sf2) {
 }
 
 // ---------------------------------------------------------------------------
-// Per-tile record of bgk_predict_fuse_p (round 5): everything a leaf tile's prologue needs, in ONE 128-byte scalar read —
-//   words  0-6   adj[b]: first point of neighbour b minus the flat index where b starts (bgk_prepare's blk_desc words 0-6)
-//   word   7     M: points in the 7 neighbour blocks (blk_desc word 14)
-//   words  8-13  flat index where neighbour b = 0 .. 5 ends (blk_desc words 8-13)
-//   word   14    index of the tile's first leaf in the leaf arrays (leaf_off[blk] + 64 * tile)
-//   word   15    leaves of the tile's block (leaf_off[blk + 1] - leaf_off[blk]): 8^(depth-1) <=> nothing pruned
-//   words 16-27  the four leaf-centre coordinates per axis of an un-pruned block's aligned 4x4x4 tile, over ell:
-//                X[r], Y[r], Z[r], r = 2 * (parent-level bit) + (leaf-level bit) — (LUT[key] + centre) / ell exactly as the
-//                leaf lanes of bgk_predict_fuse_t compute it (Block::get_loc bgkblock.h:64-66, x / ell bgkinference.h:114);
-//                the kernel no longer reads the LUT or the block centre, and twelve v_readlane are gone
-//   words 28-31  block index, 0, 0, 0
-// One thread per tile.
-// ---------------------------------------------------------------------------
-struct BgkTileRecArgs {
-    uint32_t *rec = nullptr;          // [n_tasks * 32]
-    const float4 *lut = nullptr;
-    const float *blk_center = nullptr;
+struct BgkDescArgs {   // per-tile descriptors (shift != 0): what bgk_prepare needs beside the block-wide inputs
+    uint32_t shift = 0;            // 0: one descriptor per block; log2(tiles per block): one per tile
+    uint32_t depth = 0;            // block_depth
     const uint32_t *leaf_off = nullptr;
-    uint32_t n_tasks = 0, tpb_shift = 0, depth = 0;
-    float ell = 1.0f, inv_ell = 0.0f;
 };
-__device__ __forceinline__ void bgk_write_tile_rec(const BgkTileRecArgs &tr, const int32_t *__restrict__ nbr,
-                                                   const uint32_t *__restrict__ train_off, uint32_t i) {
-    if (i >= tr.n_tasks) return;
-    const uint32_t blk = i >> tr.tpb_shift, tile = i & ((1u << tr.tpb_shift) - 1u);
-    uint32_t d[32];
-    uint32_t pre = 0;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        const int tb = nbr[7 * blk + b];
-        uint32_t first = 0, cnt = 0;
-        if (tb >= 0) {
-            first = train_off[tb];
-            cnt = train_off[tb + 1] - first;
-        }
-        d[b] = first - pre;
-        pre += cnt;
-        if (b < 6) d[8 + b] = pre;
-    }
-    d[7] = pre;
-    const uint32_t l0 = tr.leaf_off[blk];
-    d[14] = l0 + tile * (uint32_t)kWave;
-    d[15] = tr.leaf_off[blk + 1] - l0;
-    // finest-level index of the tile's leaf c (c = 0 .. 63 in the cube's own numbering): the tile covers list positions
-    // 64 tile .. 64 tile + 63 of the descending LeafIterator order, position j <-> index n_fine - 1 - j
-    const uint32_t n_fine = 1u << (3u * (tr.depth - 1u));
-    const uint32_t base = lut_layer_base(tr.depth - 1u) + (n_fine - (tile + 1u) * (uint32_t)kWave);
-    const float cx = tr.blk_center[3 * blk + 0], cy = tr.blk_center[3 * blk + 1], cz = tr.blk_center[3 * blk + 2];
-#pragma unroll
-    for (uint32_t r = 0; r < 4; ++r) {
-        const uint32_t hi = r >> 1, lo = r & 1u;
-        d[16 + r] = __float_as_uint(div_by_ell(tr.lut[base + ((hi << 5) | (lo << 2))].x + cx, tr.ell, tr.inv_ell));
-        d[20 + r] = __float_as_uint(div_by_ell(tr.lut[base + ((hi << 4) | (lo << 1))].y + cy, tr.ell, tr.inv_ell));
-        d[24 + r] = __float_as_uint(div_by_ell(tr.lut[base + ((hi << 3) | lo)].z + cz, tr.ell, tr.inv_ell));
-    }
-    d[28] = blk;
-    d[29] = d[30] = d[31] = 0;
-    uint4 *o = (uint4 *)(tr.rec + 32 * (size_t)i);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-}
-
 // Same launch shape, second job: resolve nbr[t][b] -> {train_off[nb], count} once per scan, so that
 // the predict kernel's prologue needs one dependent memory round trip less per tile.
 // Third job (blk_desc != nullptr): the same seven ranges of a test block as ONE flat index space [0, M) — the
@@ -362,24 +295,50 @@ __device__ __forceinline__ void bgk_write_tile_rec(const BgkTileRecArgs &tr, con
 __global__ void bgk_prepare(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n, float ell,
                             const int32_t *__restrict__ nbr, const uint32_t *__restrict__ train_off,
                             uint2 *__restrict__ nbr_range, uint32_t n_nbr, uint32_t *__restrict__ blk_desc,
-                            uint32_t *__restrict__ label_seq, uint32_t seq, BgkTileRecArgs tr = BgkTileRecArgs()) {
+                            uint32_t *__restrict__ label_seq, uint32_t seq, BgkDescArgs dsc = BgkDescArgs()) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tr.rec) bgk_write_tile_rec(tr, nbr, train_off, i);
-    if (blk_desc && i < n_nbr / 7u) {
+    if (blk_desc && i < ((n_nbr / 7u) << dsc.shift)) {
+        // dsc.shift != 0 (block_depth >= 4, round 6): one descriptor per TILE.  A tile of a FULL block is an aligned 4 x 4 x 4 cube of
+        // voxels at a known place in its block; a face neighbour the cube does not touch is at least four voxel edges away from
+        // the cube's box, 4.5 from its nearest leaf centre — beyond the kernel's support when ell <= 4 * resolution (the host checks
+        // that) — so its points are left out of the tile's flat range: at depth 4 every tile keeps its own block and three of the six
+        // face neighbours, where the block-wide descriptor made all eight tiles stage and cull all seven (the points a tile drops
+        // this way can reach none of its leaves: same pairs, same sums).  Tiles of pruned blocks keep all seven ranges.
+        const uint32_t blk = i >> dsc.shift, tile = i & ((1u << dsc.shift) - 1u);
+        uint32_t keep = 0x7Fu;
+        if (dsc.shift) {
+            const uint32_t n_fine = 1u << (3u * (dsc.depth - 1u));
+            if (dsc.leaf_off[blk + 1] - dsc.leaf_off[blk] == n_fine) {
+                const uint32_t q = (n_fine >> 6) - 1u - tile;   // the cube's index on the (depth - 3)-level octree of cubes: 3 bits per level, child = 4 x + 2 y + z
+                uint32_t px = 0, py = 0, pz = 0;
+                const uint32_t levels = dsc.depth - 3u;
+                for (uint32_t l = 0; l < levels; ++l) {
+                    const uint32_t c = (q >> (3u * l)) & 7u;
+                    px |= ((c >> 2) & 1u) << l;
+                    py |= ((c >> 1) & 1u) << l;
+                    pz |= (c & 1u) << l;
+                }
+                const uint32_t last = (1u << levels) - 1u;
+                // ExtendedBlock order: self, +x, -x, +y, -y, +z, -z
+                keep = 1u | (px == last ? 2u : 0u) | (px == 0u ? 4u : 0u) | (py == last ? 8u : 0u) | (py == 0u ? 16u : 0u) |
+                       (pz == last ? 32u : 0u) | (pz == 0u ? 64u : 0u);
+            }
+        }
         uint32_t d[16];
         uint32_t pre = 0, trained = 0;
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
-            const int tb = nbr[7 * i + b];
+            const int tb = nbr[7 * blk + b];
             uint32_t first = 0, cnt = 0;
             if (tb >= 0) {
                 first = train_off[tb];
                 cnt = train_off[tb + 1] - first;
             }
+            trained |= (cnt ? 1u : 0u) << b;
+            if (!((keep >> b) & 1u)) cnt = 0;
             d[b] = first - pre;
             pre += cnt;
             d[8 + b] = pre;
-            trained |= (cnt ? 1u : 0u) << b;
         }
         d[7] = trained;
         d[15] = 0;
@@ -487,8 +446,7 @@ template <int kTrig, bool kClamp = true, bool kFinite = false>
 __device__ __forceinline__ float cov_sparse_fast(float r, float sf2) {
     const float t = (r * 2.0f) * 3.1415926f;
     float s, c;
-    if (kTrig == 0 && kFinite) sincos_cr_finite(t, s, c);
-    else if (kTrig == 0) sincos_cr(t, s, c);
+    if (kTrig == 0) sincos_cr(t, s, c);   // (kFinite: kept in the signature; since round 6 every gather of the table is masked)
     else if (kTrig == 1) sincos_0_2pi(t, s, c);
     else if (kTrig == 3) sincos_eigen337(t, s, c);
     else { s = sinf(t); c = cosf(t); }
@@ -1025,7 +983,7 @@ __device__ __forceinline__ void bgk_tile_r(const BgkArgs &a, WaveLdsR &L, const 
     const bool binary = a.label_seq[0] != a.seq;
 
     // flat view of the 7 neighbour ranges
-    const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
+    const uint32_t *dsc = a.blk_desc + 16 * (size_t)(a.desc_shift ? task : blk);
     uint32_t adj[7], pend[7];
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
@@ -1356,7 +1314,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // as three vector loads)
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const uint32_t *dsc = a.blk_desc + 16 * (size_t)blk;
+    const uint32_t *dsc = a.blk_desc + 16 * (size_t)(a.desc_shift ? task : blk);
     u32x8 dlo, dhi;
     u32x2 lbr;
     float cx, cy, cz;
@@ -1605,7 +1563,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 }  // namespace la3dm_dev
-#include "bgk_predict_p.h"
 namespace la3dm_dev {
 
 // exhaustive sweeps of the kernel's shortcuts against the IEEE operations:

@@ -74,7 +74,7 @@ struct la3dm_devmap {
     // BGKLVOctoMap (variant 2): beams, samples, segments, gather grid, packed blocks
     Arena lv_rng, lv_flags, lv_seg, lv_nsamp, lv_nray, lv_samp_off, lv_ray_off, lv_samples, lv_rays, lv_sorted, lv_cell_off;
     Arena lv_beam, lv_mask;
-    Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist, lv_ncnt, lv_noff;   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
+    Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist;   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
     Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
     int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
     uint32_t lv_n_samples = 0, lv_n_rays = 0;
@@ -1599,51 +1599,20 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         DM_RESERVE(dm->lv_hlist, 4ull * nh);
         DM_RESERVE(dm->lv_hcnt, 4ull * (ncell + 1));
         DM_RESERVE(dm->lv_hoff, 4ull * (ncell + 1));
-        DM_RESERVE(dm->lv_ncnt, 4ull * ((size_t)nh + 1));
-        DM_RESERVE(dm->lv_noff, 4ull * ((size_t)nh + 1));
-        uint32_t *hcnt = (uint32_t *)dm->lv_hcnt.ptr, *hoff = (uint32_t *)dm->lv_hoff.ptr, *ncnt = (uint32_t *)dm->lv_ncnt.ptr, *noff = (uint32_t *)dm->lv_noff.ptr;
+        uint32_t *hcnt = (uint32_t *)dm->lv_hcnt.ptr, *hoff = (uint32_t *)dm->lv_hoff.ptr;
         DM_TRY(hipMemsetAsync(hcnt, 0, 4ull * (ncell + 1), st));
         hipLaunchKernelGGL(dm_lv_hgrid_count, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, rng, G, (uint32_t *)dm->lv_hcell.ptr, hcnt);
         if ((rc = exclusive_scan(dm, hcnt, hoff, (uint32_t)ncell + 1)) != LA3DM_OK) return rc;
         DM_TRY(hipMemsetAsync(hcnt, 0, 4ull * (ncell + 1), st));
         hipLaunchKernelGGL(dm_lv_hgrid_fill, dim3(cdiv(nh, 256)), dim3(256), 0, st, (const uint32_t *)dm->lv_hcell.ptr, nh, (const uint32_t *)hoff, hcnt,
                            (uint32_t *)dm->lv_hlist.ptr);
-        if (!(near_env && !strcmp(near_env, "grid2"))) {
-            // 2. every beam in one wave: capsule walk, nearby hits collected and sorted in LDS, the ordered shortening (dm_lv_beams_grid)
-            hipLaunchKernelGGL(dm_lv_beams_grid, dim3(cdiv(nh, kLvGridWaves)), dim3(64 * kLvGridWaves), 0, st, d_hits, nh, ba, rng, beams, G,
-                               (const uint32_t *)hoff, (const uint32_t *)dm->lv_hlist.ptr, (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray,
-                               dm->d_cnt);
-            hipLaunchKernelGGL(dm_lv_beam_totals, dim3(std::min<uint32_t>(cdiv(nh, 256), kMinmaxWgs)), dim3(256), 0, st, (const uint32_t *)nsamp,
-                               (const uint8_t *)dm->lv_flags.ptr, nh, dm->d_cnt);
-        } else {
-        // 2. the beams' nearby sets: count, offsets, fill
-        DM_TRY(hipMemsetAsync(ncnt + nh, 0, 4, st));
-        hipLaunchKernelGGL((dm_lv_near_grid<false>), dim3(cdiv(nh, 4)), dim3(256), 0, st, d_hits, nh, ba, rng, beams, G, (const uint32_t *)hoff,
-                           (const uint32_t *)dm->lv_hlist.ptr, ncnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-        if ((rc = exclusive_scan(dm, ncnt, noff, nh + 1, (int)kCntMembers, true)) != LA3DM_OK) return rc;
-        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
-        const uint32_t n_pairs = dm->h_cnt[kCntMembers];
-        if (n_pairs > (1u << 28)) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): more than 2^28 (beam, nearby hit) pairs in one scan");
-        const size_t pb = 4ull * std::max<uint32_t>(n_pairs, 4u);
-        DM_RESERVE(dm->k0, pb);
-        DM_RESERVE(dm->k1, pb);
-        DM_RESERVE(dm->v0, pb);
-        DM_RESERVE(dm->v1, pb);
-        uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
-        if (n_pairs) {
-            hipLaunchKernelGGL((dm_lv_near_grid<true>), dim3(cdiv(nh, 4)), dim3(256), 0, st, d_hits, nh, ba, rng, beams, G, (const uint32_t *)hoff,
-                               (const uint32_t *)dm->lv_hlist.ptr, (uint32_t *)nullptr, (const uint32_t *)noff, k0, v0);
-            // 3. hit order inside every beam: stable sorts by hit index, then by beam (a beam's range [noff[h], noff[h + 1]) stays its own)
-            int bits = 1;
-            while ((1ull << bits) < nh) ++bits;
-            if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_pairs, bits)) != LA3DM_OK) return rc;
-            if ((rc = sort_pairs(dm, v1, v0, k1, k0, n_pairs, bits)) != LA3DM_OK) return rc;
-        }
-        // 4. the ordered walk
-        hipLaunchKernelGGL(dm_lv_beams_walk_list, dim3(cdiv(nh, 64)), dim3(64), 0, st, d_hits, nh, ba, beams, (const uint32_t *)noff, (const uint32_t *)k0,
-                           (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray, dm->d_cnt);
-        if (getenv("LA3DM_DEBUG_LV")) fprintf(stderr, "la3dm BGK-LV ray shortening on the hit grid: %u hits, %d x %d x %d cells of %.3f m, %u (beam, nearby hit) pairs\n", nh, G.dim[0], G.dim[1], G.dim[2], G.cell, n_pairs);
-        }
+        // 2. every beam in one wave: capsule walk, nearby hits collected and sorted in LDS, the ordered shortening (dm_lv_beams_grid)
+        hipLaunchKernelGGL(dm_lv_beams_grid, dim3(cdiv(nh, kLvGridWaves)), dim3(64 * kLvGridWaves), 0, st, d_hits, nh, ba, rng, beams, G,
+                           (const uint32_t *)hoff, (const uint32_t *)dm->lv_hlist.ptr, (uint8_t *)dm->lv_flags.ptr, (float *)dm->lv_seg.ptr, nsamp, nray,
+                           dm->d_cnt);
+        hipLaunchKernelGGL(dm_lv_beam_totals, dim3(std::min<uint32_t>(cdiv(nh, 256), kMinmaxWgs)), dim3(256), 0, st, (const uint32_t *)nsamp,
+                           (const uint8_t *)dm->lv_flags.ptr, nh, dm->d_cnt);
+        if (getenv("LA3DM_DEBUG_LV")) fprintf(stderr, "la3dm BGK-LV ray shortening on the hit grid: %u hits, %d x %d x %d cells of %.3f m\n", nh, G.dim[0], G.dim[1], G.dim[2], G.cell);
     }
     if ((rc = exclusive_scan(dm, nsamp, samp_off, nh, (int)kCntFreeRaw)) != LA3DM_OK) return rc;
     if ((rc = exclusive_scan(dm, nray, ray_off, nh, (int)kCntKept, true)) != LA3DM_OK) return rc;

@@ -209,12 +209,16 @@ __global__ __launch_bounds__(256) void dm_lv_beams_walk(const float *__restrict_
 // A hit can only be "nearby" AND shorten a beam if it lies within `influence` of the beam's line and (within `influence` of the
 // free end point, or nearer than the initial length l0 to both the sensor and that end point) — i.e. inside a capsule of radius
 // `influence` around the segment sensor -> end point.  So: the in-range hits go into a uniform grid (cell >= influence), every
-// beam (one lane) visits the cells its capsule can touch — slab by slab along the beam's dominant axis, a handful of cells per
+// beam (one WAVE) visits the cells its capsule can touch — slab by slab along the beam's dominant axis, a handful of cells per
 // slab — and applies EXACTLY dm_lv_nearby's tests to the hits it finds there (lv_near below: the same expressions).  The
 // candidates of a beam come out in grid order; the shortening is order dependent (every accepted hit changes the length the
-// next ones are gated on), so the (beam, hit) pairs are sorted by hit index inside every beam — two stable radix sorts: by hit,
-// then by beam — and dm_lv_beams_walk_list walks a beam's list exactly as dm_lv_beams_walk walks the set bits of its mask
-// row: the same hits in the same order, bit-identical segments (tests/test_lv_gpu.py compares the two paths).
+// next ones are gated on), so the wave sorts them by hit index (in LDS) and walks them exactly as dm_lv_beams_walk walks the
+// set bits of its mask row: the same hits in the same order, bit-identical segments (tests/test_lv_gpu.py compares the two
+// paths and the restatement).  Measured on the way (50 k rays, 43 k hits, per pass): one lane per beam 1.05 ms (~1 000 dependent
+// cell look-ups in a row, 672 waves waiting for memory); one wave per beam with lane = slab for the tests too 0.48 ms (the hits
+// sit in the few slabs at the beam's end: two to four lanes did all the f64 work); cells queued in LDS and tested lane = hit
+// behind an fp32 pre-test 0.25 ms — those three as a count pass + a fill pass + two device-wide radix sorts of the (beam, hit)
+// pairs + a walk kernel; everything in one kernel (below) 0.31 ms in all.
 struct LvHitGrid {
     double cell;      // edge: influence * 2^k (k > 0 only when the scan's extent needs more than 2^24 cells)
     double g0[3];     // lower corner: cell (i, j, k) = floor((p - g0) / cell)
@@ -388,80 +392,7 @@ __device__ __forceinline__ void lv_tube_slab(const LvTube &T, const LvHitGrid &G
     for (int k = k0; k <= k1; ++k)
         for (int j = j0; j <= j1; ++j) visit((uint32_t)(i * stride[ax] + j * stride[u] + k * stride[v]));
 }
-// One WAVE per beam.  Phase 1, lane = slab: the non-empty cells of the capsule go to a queue in LDS.  Phase 2, lane = hit of
-// a queued cell: a cheap fp32 pre-test (distance to the beam's line, with a margin — a hit farther than that fails lv_near's
-// last comparison anyway) in front of the exact tests.  (First form: one lane per beam, ~1 000 dependent cell look-ups in a
-// row — 1.05 ms per pass at 43 k beams, 672 waves waiting for memory.  Second: lane = slab for the tests too — 0.48 ms: the hits
-// sit in the few slabs at the beam's end, two to four lanes did all the f64 work.)  kFill = false: cnt[h] = nearby hits of
-// beam h; true: their indices at pair_q[off[h] ..) in any order (the pairs are sorted afterwards), pair_h = h beside them.
-constexpr uint32_t kLvCellQ = 192;   // queued cells per beam; the rare beam with more tests the overflow cells lane by lane
-template <bool kFill>
-__global__ __launch_bounds__(256) void dm_lv_near_grid(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a, const double *__restrict__ rng,
-                                                      const LvBeam *__restrict__ beams, LvHitGrid G, const uint32_t *__restrict__ cell_off,
-                                                      const uint32_t *__restrict__ cell_list, uint32_t *__restrict__ cnt,
-                                                      const uint32_t *__restrict__ off, uint32_t *__restrict__ pair_q, uint32_t *__restrict__ pair_h) {
-    __shared__ uint32_t s_n[4], s_nc[4];
-    __shared__ uint2 s_cells[4][kLvCellQ];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t h = blockIdx.x * 4u + wv;
-    if (lane == 0) s_n[wv] = s_nc[wv] = 0u;
-    __syncthreads();
-    const bool live = h < nh;
-    const LvBeam b = beams[live ? h : 0u];
-    const LvTube T = lv_tube_setup(b, a, G);
-    uint32_t n = 0;
-    const uint32_t base = (kFill && live) ? off[h] : 0u;
-    // the line's direction in fp32 for the pre-test (from the tube's own extended segment: defined for every finite beam)
-    float ux = 0.f, uy = 0.f, uz = 0.f;
-    {
-        const double dl = sqrt(T.D[0] * T.D[0] + T.D[1] * T.D[1] + T.D[2] * T.D[2]);
-        if (dl > 0.0) {
-            ux = (float)(T.D[0] / dl);
-            uy = (float)(T.D[1] / dl);
-            uz = (float)(T.D[2] / dl);
-        }
-    }
-    const float r_pre = (float)(a.influence * 1.01 + 1e-3);
-    const float r_pre2 = r_pre * r_pre;
-    // |v|^2 - along^2 cancels: its fp32 error is < ~8 ulp of |v|^2 = 5e-7 |v|^2; the pre-test is used while that stays below half the
-    // margin r_pre^2 - influence^2 (ell = 0.2: within 35 m of the sensor), farther hits (and NaN) go straight to the exact tests
-    const float vv_max = (r_pre2 - (float)(a.influence * a.influence)) * 1e6f;
-    auto test = [&](uint32_t q) {
-        const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
-        const float vx = qx - a.ox, vy = qy - a.oy, vz = qz - a.oz;
-        const float along = vx * ux + vy * uy + vz * uz, vv = vx * vx + vy * vy + vz * vz;
-        if (vv < vv_max && vv - along * along > r_pre2) return;
-        if (lv_near(b, a, qx, qy, qz, rng[q])) {
-            if (kFill) {
-                const uint32_t pos = base + atomicAdd(&s_n[wv], 1u);
-                pair_q[pos] = q;
-                pair_h[pos] = h;
-            }
-            ++n;
-        }
-    };
-    if (live)
-        for (int i = T.i0 + (int)lane; i <= T.i1; i += 64)
-            lv_tube_slab(T, G, i, [&](uint32_t c) {
-                const uint32_t p0 = cell_off[c], p1 = cell_off[c + 1];
-                if (p1 == p0) return;
-                const uint32_t slot = atomicAdd(&s_nc[wv], 1u);
-                if (slot < kLvCellQ) s_cells[wv][slot] = make_uint2(p0, p1);
-                else
-                    for (uint32_t p = p0; p < p1; ++p) test(cell_list[p]);
-            });
-    __syncthreads();
-    if (!live) return;
-    const uint32_t nc = min(s_nc[wv], kLvCellQ);
-    for (uint32_t ci = 0; ci < nc; ++ci) {
-        const uint2 r = s_cells[wv][ci];
-        for (uint32_t p = r.x + lane; p < r.y; p += 64u) test(cell_list[p]);
-    }
-    if (!kFill) {
-        for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
-        if (lane == 0) cnt[h] = n;
-    }
-}
+constexpr uint32_t kLvCellQ = 192;   // queued cells per beam and round of 64 slabs; cells beyond that are tested by the lane that found them
 // ---- the whole beam in ONE kernel (round 6, third form): capsule walk -> the beam's nearby hits collected in LDS -> sorted by
 // hit index in LDS -> the ordered shortening -> segment + sample count.  No pair arrays, no device-wide sorts, no host read-back of
 // a pair count.  One wave per beam (its LDS is its own: only wave-level barriers).  A beam whose nearby set does not fit the LDS
@@ -644,64 +575,6 @@ __global__ __launch_bounds__(256) void dm_lv_beam_totals(const uint32_t *__restr
         if (all) atomicAdd(reinterpret_cast<unsigned long long *>(counters + kCntBeamTotal), all);
         if (hh) atomicAdd(&counters[kCntTrained], hh);
     }
-}
-
-// dm_lv_beams_walk over a beam's sorted list of nearby hits instead of the set bits of its mask row (the same hits, the same order)
-__global__ __launch_bounds__(64) void dm_lv_beams_walk_list(const float *__restrict__ hits, uint32_t nh, LvBeamArgs a,
-                                                           const LvBeam *__restrict__ beams, const uint32_t *__restrict__ off,
-                                                           const uint32_t *__restrict__ list, uint8_t *__restrict__ flags, float *__restrict__ seg,
-                                                           uint32_t *__restrict__ nsamp, uint32_t *__restrict__ nray, uint32_t *counters) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0;
-    bool is_hit = false;
-    if (h < nh) {
-        const LvBeam bm = beams[h];
-        const float ox = a.ox, oy = a.oy, oz = a.oz;
-        const float nx = bm.nx, ny = bm.ny, nz = bm.nz;
-        double l = bm.l0;
-        uint32_t fl = bm.fl;
-        float npz = bm.pz;
-        const float lvx = bm.ex - ox, lvy = bm.ey - oy, lvz = bm.ez - oz;
-        const double lvn = lv_norm(lvx, lvy, lvz);
-        const uint32_t p1 = off[h + 1];
-        for (uint32_t p = off[h]; p < p1; ++p) {
-            const uint32_t q = list[p];
-            const float qx = hits[3 * (size_t)q], qy = hits[3 * (size_t)q + 1], qz = hits[3 * (size_t)q + 2];
-            const float vx = qx - ox, vy = qy - oy, vz = qz - oz;
-            const double b = (double)(vx * lvx + vy * lvy + vz * lvz);
-            if (b > l * l) continue;   // (the distance-to-the-line test is already in the list)
-            npz = qz;
-            l = b / lvn;
-        }
-        if (l < a.max_range / 5.0 && l / (a.offset - (double)npz) > 0) {  // downward rays close to the sensor
-            fl |= kLvBeamSkip;
-        } else {
-            const float fex = (float)(ox + nx * l), fey = (float)(oy + ny * l), fez = (float)(oz + nz * l);
-            float fox = fex, foy = fey, foz = fez;
-            if (l > a.influence * 1.0) {
-                fox = (float)(ox + nx * a.influence * 1.0);
-                foy = (float)(oy + ny * a.influence * 1.0);
-                foz = (float)(oz + nz * a.influence * 1.0);
-            }
-            float *s = seg + 6 * (size_t)h;
-            s[0] = fox; s[1] = foy; s[2] = foz; s[3] = fex; s[4] = fey; s[5] = fez;
-            const float len = (float)sqrt((double)((fex - fox) * (fex - fox) + (fey - foy) * (fey - foy) + (fez - foz) * (fez - foz)));
-            c = 1;
-            for (float d = len; d > 0.0 && c < kBeamCap; d -= a.free_res) ++c;
-            if (c >= kBeamCap) {
-                atomicOr(&counters[kCntError], kErrBeam);
-                c = 1;
-            }
-        }
-        flags[h] = (uint8_t)fl;
-        nray[h] = (fl & kLvBeamSkip) ? 0u : 1u;
-        c += (fl & kLvBeamHit) ? 1u : 0u;
-        nsamp[h] = c;
-        is_hit = (fl & kLvBeamHit) != 0u;
-    }
-    beam_total_add(c, counters);
-    const unsigned long long hm = __ballot(is_hit);
-    if ((threadIdx.x & 63) == 0 && hm) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(hm));
 }
 
 // samples {x, y, z, ray as float (-1 = hit)} and segments {start, first sample index bits | end, 0} in beam order

@@ -26,13 +26,11 @@ struct la3dm_ctx {
                            // (bgk_predict_fuse_v5, bit-identical to the CPU restatement); env LA3DM_BGK_SUM sets the default
     int opt_bgk_tables = 1;  // bgk_sum = 1 only: 1 (default) = bgk_predict_fuse_t (per-axis distance tables for aligned 4x4x4 tiles, the
                              // other tiles through the general path in the same launch), 0 = bgk_predict_fuse_r for every tile
-    int opt_bgk_p = 0;       // bgk_sum = 1 with tables: 0 (default) = bgk_predict_fuse_t, 1 = bgk_predict_fuse_p (round 5: one-read prologue from
-                             // bgk_prepare's tile records, sin / cos table in LDS — measured equal in cache, -2 % out of cache, and
-                             // 2.5 us per step dearer in bgk_prepare: an option, not the default); env LA3DM_BGK_P
     float inv_ell = 0.0f;   // RN(1 / ell), or 0 when x / ell must stay an IEEE division (bgk_kernels.h div_by_ell)
     int opt_fast_trig = 0;  // 0 correctly rounded (f64 kernels), 1 f32 polynomial, 2 OCML, 3 Eigen 3.3.7 psin / pcos without FMA (the likely reference build)
     int opt_gp_mode = 0;    // GPOctoMap: 0 = FMA chains in ascending order (VALU and matrix cores alike: the parity configuration), 1 = the order of an
                             // x86-64 / SSE2 build of Eigen 3.3.7 on the VALU (gp_eigen_kernels.h; blocks of up to 128 points); env LA3DM_GP_MODE
+    int opt_bgk_tile_desc = 1;   // block_depth >= 4, bgk_sum 1: per-tile neighbour descriptors without the face neighbours out of the tile's reach (bgk_prepare); 0 = block-wide descriptors (A/B)
     int opt_grid_order = 0;  // device-resident map's voxel-grid filters: 0 = ascending cloud index inside a cell (the parity configuration), 1 = the order
                              // pcl::VoxelGrid's unstable std::sort leaves (host sort of the downloaded keys: verification mode, slow by design)
     int opt_time_kernel = 0;
@@ -45,7 +43,7 @@ struct la3dm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // events around the dominant kernel
     size_t ev_used = 0;
     // scratch (device-pointer path)
-    Arena pts_scaled, nbr_range, blk_desc, label_seq, tile_rec;
+    Arena pts_scaled, nbr_range, blk_desc, label_seq;
     uint32_t scan_seq = 0;  // la3dm_bgk_scan_device calls so far (BgkArgs::seq)
     Arena gp_loff, gp_totals, gp_order, gp_L, gp_alpha, gp_v;
     Arena l_task_item, l_split_list, l_nb_first, l_part, l_counters, l_item_desc, l_rowrec, l_batch_off, l_item_hits, l_bdesc, l_vals, l_rowx, l_dense, l_labmask, l_part64;

@@ -241,9 +241,6 @@ int la3dm_create(const la3dm_params *params, la3dm_ctx **out) {
     if (const char *ev = getenv("LA3DM_GP_MODE")) {  // default of "gp_mode"
         if (ev[0] == '0' || ev[0] == '1') ctx->opt_gp_mode = ev[0] - '0';
     }
-    if (const char *ev = getenv("LA3DM_BGK_P")) {  // bgk_sum = 1 with tables: 1 = bgk_predict_fuse_p, 0 = bgk_predict_fuse_t
-        if (ev[0] == '0' || ev[0] == '1') ctx->opt_bgk_p = ev[0] - '0';
-    }
     auto fail = [&](const char *what, hipError_t e) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(e);
         delete ctx;
@@ -273,7 +270,7 @@ void la3dm_destroy(la3dm_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     Arena *all[] = {&ctx->l_task_item, &ctx->l_split_list, &ctx->l_nb_first, &ctx->l_part, &ctx->l_counters, &ctx->l_item_desc, &ctx->l_rowrec, &ctx->l_batch_off, &ctx->l_item_hits, &ctx->l_bdesc, &ctx->l_vals, &ctx->l_rowx, &ctx->l_dense, &ctx->l_labmask, &ctx->l_part64,
-                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->blk_desc, &ctx->label_seq, &ctx->tile_rec, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
+                    &ctx->pts_scaled, &ctx->nbr_range, &ctx->blk_desc, &ctx->label_seq, &ctx->gp_loff, &ctx->gp_totals, &ctx->gp_order, &ctx->gp_L, &ctx->gp_alpha, &ctx->gp_v, &ctx->lv_samples, &ctx->lv_sorted, &ctx->lv_rays, &ctx->lv_cell, &ctx->lv_center,
                     &ctx->lv_cell0, &ctx->lv_alpha, &ctx->lv_beta, &ctx->lv_state, &ctx->lvp_sub_task, &ctx->lvp_task, &ctx->lvp_cand, &ctx->lvp_totals, &ctx->lvp_rows, &ctx->lvp_sub_out, &ctx->h_train, &ctx->h_train_off, &ctx->h_nbr, &ctx->h_center, &ctx->h_leaf_off,
                     &ctx->h_leaf_key, &ctx->h_alpha, &ctx->h_beta, &ctx->h_state, &ctx->h_diag_in, &ctx->h_diag_out};
     for (Arena *a : all)
@@ -303,12 +300,6 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
         ctx->opt_bgk_tables = value;
         return LA3DM_OK;
     }
-    if (!strcmp(name, "bgk_p")) {  // bgk_sum = 1 with tables: 0 (default) = bgk_predict_fuse_t, 1 = bgk_predict_fuse_p (one-read prologue from
-        // bgk_prepare's tile records, sin / cos table in LDS: the same kernel time in cache, -2 % out of cache, +2.5 us in bgk_prepare)
-        if (value < 0 || value > 1) return bad_value("0 or 1");
-        ctx->opt_bgk_p = value;
-        return LA3DM_OK;
-    }
     if (!strcmp(name, "fast_trig")) {  // 0 correctly rounded (default, the parity configuration), 1 f32 polynomial, 2 OCML, 3 = Eigen 3.3.7's psin / pcos
         // without FMA, the likely reference build (BGK, BGK-L and BGK-LV kernels; 1 and 2: the BGK kernels only)
         if (value < 0 || value > 3) return bad_value("0, 1, 2 or 3");
@@ -333,6 +324,11 @@ int la3dm_set_option(la3dm_ctx *ctx, const char *name, int value) {
     if (!strcmp(name, "remap")) {
         if (value < 0 || value > 2) return bad_value("0, 1 or 2");
         ctx->opt_remap = value;
+        return LA3DM_OK;
+    }
+    if (!strcmp(name, "bgk_tile_desc")) {
+        if (value < 0 || value > 1) return bad_value("0 or 1");
+        ctx->opt_bgk_tile_desc = value;
         return LA3DM_OK;
     }
     if (!strcmp(name, "grid_order")) {
@@ -368,10 +364,10 @@ int la3dm_get_option(const la3dm_ctx *ctx, const char *name, int *value) {
     if (!ctx || !name || !value) return LA3DM_ERR_ARG;
     if (!strcmp(name, "bgk_sum")) *value = ctx->opt_bgk_sum;
     else if (!strcmp(name, "bgk_tables")) *value = ctx->opt_bgk_tables;
-    else if (!strcmp(name, "bgk_p")) *value = ctx->opt_bgk_p;
     else if (!strcmp(name, "fast_trig")) *value = ctx->opt_fast_trig;
     else if (!strcmp(name, "gp_mode")) *value = ctx->opt_gp_mode;
     else if (!strcmp(name, "grid_order")) *value = ctx->opt_grid_order;
+    else if (!strcmp(name, "bgk_tile_desc")) *value = ctx->opt_bgk_tile_desc;
     else if (!strcmp(name, "waves_per_wg")) *value = ctx->opt_waves;
     else if (!strcmp(name, "remap")) *value = ctx->opt_remap;
     else return LA3DM_ERR_ARG;
@@ -407,8 +403,18 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     rc = arena_reserve(ctx, ctx->nbr_range, sizeof(uint2) * 7 * (size_t)s->n_test_blk);
     if (rc != LA3DM_OK) return rc;
     const bool sum_f64 = ctx->opt_bgk_sum == 1;
+    uint32_t max_leaves = 1u << (3 * (ctx->p.block_depth - 1));
+    uint32_t tpb = (max_leaves + kWave - 1) / kWave;  // power of two
+    uint32_t tpb_shift = 0;
+    while ((1u << tpb_shift) < tpb) ++tpb_shift;
+    // block_depth >= 4: one neighbour descriptor per TILE, without the face neighbours the tile's voxel cube cannot reach
+    // (bgk_prepare) — valid while the kernel's support, ell, is at most four voxel edges (the cube's edge), and for gated scans
+    // only (insert_training_data updates a leaf for every neighbour that has a model, reachable or not); option "bgk_tile_desc" 0 = off
+    const bool tile_desc = sum_f64 && tpb_shift >= 3 && ctx->opt_bgk_tile_desc && !(s->flags & LA3DM_SCAN_UPDATE_UNGATED) &&
+                           ctx->p.ell <= 4.0f * ctx->p.resolution;
+    const uint32_t desc_shift = tile_desc ? tpb_shift : 0u;
     if (sum_f64) {
-        rc = arena_reserve(ctx, ctx->blk_desc, sizeof(uint32_t) * 16 * (size_t)s->n_test_blk);
+        rc = arena_reserve(ctx, ctx->blk_desc, sizeof(uint32_t) * 16 * ((size_t)s->n_test_blk << desc_shift));
         if (rc != LA3DM_OK) return rc;
         if (!ctx->label_seq.ptr) {
             rc = arena_reserve(ctx, ctx->label_seq, sizeof(uint32_t));
@@ -418,47 +424,30 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
         }
         if (++ctx->scan_seq == 0u) ctx->scan_seq = 1u;  // 0 is the cleared state
     }
-    uint32_t max_leaves = 1u << (3 * (ctx->p.block_depth - 1));
-    uint32_t tpb = (max_leaves + kWave - 1) / kWave;  // power of two
-    uint32_t tpb_shift = 0;
-    while ((1u << tpb_shift) < tpb) ++tpb_shift;
     // the table kernels: tiles of full (un-pruned) blocks through the distance tables, the others through the general
     // path of the same launch; they need every label to be 0 or 1
     const bool use_tables = sum_f64 && ctx->opt_bgk_tables && ctx->p.block_depth >= 3 && (s->flags & LA3DM_SCAN_LABELS_01) != 0u;
-    const bool use_p = use_tables && ctx->opt_bgk_p != 0;   // bgk_predict_fuse_p: the prologue from bgk_prepare's tile records, sin / cos in LDS
-    const bool use_rec = use_p;
     // the instance without the general path only when the caller's LA3DM_SCAN_FULL_BLOCKS can be verified here: a block
     // holds at most 8^(depth-1) leaves, so the total says whether every block is full (a tile of a block that is
     // not would be skipped silently)
     const bool full_blocks = (s->flags & LA3DM_SCAN_FULL_BLOCKS) != 0u && (uint64_t)s->n_leaf == ((uint64_t)s->n_test_blk << (3 * (ctx->p.block_depth - 1)));
-    BgkTileRecArgs tr;
-    if (use_rec) {
-        rc = arena_reserve(ctx, ctx->tile_rec, sizeof(uint32_t) * 32 * ((size_t)s->n_test_blk << tpb_shift));
-        if (rc != LA3DM_OK) return rc;
-        tr.rec = (uint32_t *)ctx->tile_rec.ptr;
-        tr.lut = ctx->d_lut;
-        tr.blk_center = s->blk_center;
-        tr.leaf_off = s->leaf_off;
-        tr.n_tasks = s->n_test_blk << tpb_shift;
-        tr.tpb_shift = tpb_shift;
-        tr.depth = (uint32_t)ctx->p.block_depth;
-        tr.ell = ctx->p.ell;
-        tr.inv_ell = ctx->inv_ell;
-    }
     {
         const uint32_t n_nbr = 7u * s->n_test_blk;
         uint32_t n_thr = s->n_train_pts > n_nbr ? s->n_train_pts : n_nbr;
-        if (use_rec && n_thr < tr.n_tasks) n_thr = tr.n_tasks;
+        BgkDescArgs da;
+        da.shift = desc_shift;
+        da.depth = (uint32_t)ctx->p.block_depth;
+        da.leaf_off = s->leaf_off;
+        if (desc_shift && n_thr < (s->n_test_blk << desc_shift)) n_thr = s->n_test_blk << desc_shift;
         dim3 g((n_thr + 255) / 256), b(256);
         // what the launch writes beside the scaled points depends on the kernel that follows: the ordered kernel reads the
-        // per-neighbour ranges, the general path (bgk_predict_fuse_r, and the pruned tiles of the table kernels) the 64-byte
-        // block descriptors, bgk_predict_fuse_p the 128-byte tile records — each of them a dependent chain nbr -> train_off per
-        // block, so only the ones that will be read are produced (all three: 13.2 us at configs[1]; one: 6 - 7 us)
-        const bool want_desc = sum_f64 && !(use_rec && full_blocks);
+        // per-neighbour ranges, the others (bgk_predict_fuse_t / _r) the 64-byte descriptors — each of them a dependent chain
+        // nbr -> train_off per block, so only the one that will be read is produced
+        const bool want_desc = sum_f64;
         hipLaunchKernelGGL(bgk_prepare, g, b, 0, stream, (const float4 *)s->train_xyzy, (float4 *)ctx->pts_scaled.ptr,
                            s->n_train_pts, ctx->p.ell, s->nbr, s->train_off, sum_f64 ? (uint2 *)nullptr : (uint2 *)ctx->nbr_range.ptr, n_nbr,
                            want_desc ? (uint32_t *)ctx->blk_desc.ptr : (uint32_t *)nullptr,
-                           sum_f64 ? (uint32_t *)ctx->label_seq.ptr : (uint32_t *)nullptr, ctx->scan_seq, tr);
+                           sum_f64 ? (uint32_t *)ctx->label_seq.ptr : (uint32_t *)nullptr, ctx->scan_seq, da);
     }
 
     // 2. predict + fuse
@@ -476,10 +465,10 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     a.nbr_range = (const uint2 *)ctx->nbr_range.ptr;
     a.blk_desc = (const uint32_t *)ctx->blk_desc.ptr;
     a.label_seq = (const uint32_t *)ctx->label_seq.ptr;
-    a.tile_rec = (const uint32_t *)ctx->tile_rec.ptr;
     a.seq = ctx->scan_seq;
     a.n_test_blk = s->n_test_blk;
     a.tpb_shift = tpb_shift;
+    a.desc_shift = desc_shift;
     a.n_tasks = s->n_test_blk << tpb_shift;
     a.flags = s->flags | ((uint32_t)ctx->opt_ablate << 8);
     a.remap = (uint32_t)ctx->opt_remap;
@@ -512,13 +501,7 @@ int la3dm_bgk_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_
     if (sum_f64) {
         grid = dim3(a.n_tasks);
         block = dim3(kWave);
-        if (use_p) {
-            if (full_blocks) {  // no pruned block in this scan: the instance without the general path
-                LAUNCH_BGK(bgk_predict_fuse_p, , false)
-            } else {
-                LAUNCH_BGK(bgk_predict_fuse_p, , true)
-            }
-        } else if (use_tables) {
+        if (use_tables) {
             if (full_blocks) {  // no pruned block in this scan: the kernel without the general path
                 LAUNCH_BGK(bgk_predict_fuse_t, , false)
             } else {

@@ -186,7 +186,7 @@ def test_both_modes_agree_and_default_is_the_order_free_one(built, monkeypatch):
 
 @pytest.mark.parametrize("depth", [3, 4])
 def test_table_kernel_and_general_kernel_agree_bit_for_bit(built, depth):
-    """bgk_predict_fuse_t (default) and bgk_predict_fuse_p (option) against bgk_predict_fuse_r on the same packed scans through the C ABI (la3dm_bgk_scan_host): a
+    """bgk_predict_fuse_t (default) against bgk_predict_fuse_r on the same packed scans through the C ABI (la3dm_bgk_scan_host): a
     fresh map (every block un-pruned: the table kernel alone), the third scan of a sequence (pruned blocks: both kernels in
     one call), and the same scan without LA3DM_SCAN_LABELS_01 (the general kernel alone, whatever "bgk_tables" says).
     Both kernels form the same double sums of the same fp32 terms: alpha, beta and state are equal bit for bit up to the
@@ -208,13 +208,11 @@ def test_table_kernel_and_general_kernel_agree_bit_for_bit(built, depth):
         assert full == (earlier == 0)
         a0, b0 = pk.alpha.copy(), pk.beta.copy()
         out = []
-        # (tables, flags, bgk_p): the general kernel; the table kernels bgk_predict_fuse_t (default) and bgk_predict_fuse_p (option
-        # "bgk_p" 1: tile-record prologue, sin / cos table in LDS); p without the caller's LA3DM_SCAN_FULL_BLOCKS (the instance with the
-        # general path compiled in); the same scan without LA3DM_SCAN_LABELS_01 (the general kernel whatever the options say)
-        for tables, flags, p in ((0, pk.flags, 0), (1, pk.flags, 0), (1, pk.flags, 1), (1, pk.flags & ~4, 0), (1, pk.flags & ~4, 1),
-                                 (1, pk.flags & ~2, 0)):
+        # (tables, flags): the general kernel; the table kernel bgk_predict_fuse_t (default); the same without the caller's
+        # LA3DM_SCAN_FULL_BLOCKS (the instance with the general path compiled in); the same scan without LA3DM_SCAN_LABELS_01 (the
+        # general kernel whatever the options say)
+        for tables, flags in ((0, pk.flags), (1, pk.flags), (1, pk.flags & ~4), (1, pk.flags & ~2)):
             m.set_option("bgk_tables", tables)
-            m.set_option("bgk_p", p)
             pk.alpha[:], pk.beta[:], pk.c.flags = a0, b0, flags
             m.scan_host(pk)
             out.append((pk.alpha.copy(), pk.beta.copy(), pk.state.copy()))
@@ -224,3 +222,53 @@ def test_table_kernel_and_general_kernel_agree_bit_for_bit(built, depth):
                 assert u.max() <= 1 and (u == 0).mean() >= 0.99999
             assert (out[0][2] == other[2]).mean() >= 0.99999
         assert (out[0][0] != a0).any()
+
+
+@pytest.mark.parametrize("depth,rays", [(4, 30000), (5, 20000)])
+def test_per_tile_descriptors_change_nothing(built, depth, rays):
+    """block_depth >= 4 (round 6, bgk_prepare): every tile of a full block gets its own neighbour descriptor without the face
+    neighbours its 4 x 4 x 4 voxel cube cannot reach (at depth 4: its own block + three of the six; at depth 5 an inner cube keeps its
+    own block only).  The dropped points can reach none of the tile's leaves, so the table kernel, the general kernel (pruned blocks:
+    the third scan of a sequence; unlabelled scans) and both together must give the block-wide descriptors' alpha, beta and state
+    ("bgk_tile_desc" 0) — same pairs, same fp32 terms, the same double sums up to the order of the additions (<= 1 ulp; observed: equal)."""
+    import la3dm_amd
+    params = dict(la3dm_amd.BGK_YAML, block_depth=depth)
+    xyz, origin = la3dm_amd.synthetic_scan(rays)
+    for earlier in (0, 2):
+        m = la3dm_amd.BGKOctoMap(**params, device=0).set_device_resident(False)
+        m.set_option("bgk_sum", 1)
+        for s in range(earlier):
+            assert m.prepare(xyz + np.float32(0.013 * (s + 1)), origin, 0.1, 0.5, -1.0)
+            m.scan_host(m.packed())
+            m.commit()
+        assert m.prepare(xyz, origin, 0.1, 0.5, -1.0)
+        pk = m.packed()
+        a0, b0 = pk.alpha.copy(), pk.beta.copy()
+        out = []
+        for desc, tables, flags in ((0, 1, pk.flags), (1, 1, pk.flags), (1, 0, pk.flags), (1, 1, pk.flags & ~4), (1, 1, pk.flags & ~2)):
+            m.set_option("bgk_tile_desc", desc)
+            m.set_option("bgk_tables", tables)
+            pk.alpha[:], pk.beta[:], pk.c.flags = a0, b0, flags
+            m.scan_host(pk)
+            out.append((pk.alpha.copy(), pk.beta.copy(), pk.state.copy()))
+        for other in out[1:]:
+            for x, y in zip(out[0][:2], other[:2]):
+                u = _ulps(x, y)
+                assert u.max() <= 1 and (u == 0).mean() >= 0.99999
+            assert (out[0][2] == other[2]).mean() >= 0.99999
+        assert (out[0][0] != a0).any()
+    # a kernel wider than the cube's edge (ell > 4 voxel edges): the host keeps the block-wide descriptors, results as before
+    wide = dict(params, ell=0.45)
+    m = la3dm_amd.BGKOctoMap(**wide, device=0).set_device_resident(False)
+    m.set_option("bgk_sum", 1)
+    assert m.prepare(xyz[::3], origin, 0.1, 0.5, -1.0)
+    pk = m.packed()
+    a0, b0 = pk.alpha.copy(), pk.beta.copy()
+    res = []
+    for desc in (0, 1):
+        m.set_option("bgk_tile_desc", desc)
+        pk.alpha[:], pk.beta[:] = a0, b0
+        m.scan_host(pk)
+        res.append((pk.alpha.copy(), pk.beta.copy(), pk.state.copy()))
+    for x, y in zip(res[0], res[1]):
+        assert (x.view(np.uint8) == y.view(np.uint8)).all()

@@ -64,7 +64,7 @@ def _same(a, b, tag):
 @pytest.mark.parametrize("depth", [3, 4])
 def test_bgk_inserts_bit_identical(built, eigen_trig, depth):
     """BGKOctoMap, three fused scans (pruned blocks from the second on): the ordered kernel (bgk_sum 0) bit for bit; the
-    default kernels (bgk_sum 1: bgk_predict_fuse_p / _r with the same trig) within one ulp of it"""
+    default kernels (bgk_sum 1: bgk_predict_fuse_t / _r with the same trig) within one ulp of it"""
     import la3dm_amd
     O = eigen_trig
     params = dict(la3dm_amd.BGK_YAML, block_depth=depth)

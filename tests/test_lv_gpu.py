@@ -150,10 +150,11 @@ def test_lv_synthetic_scan_that_fills_the_gpu(built):
     assert eqA == 1.0 and eqB == 1.0
 
 
-@pytest.mark.parametrize("case", ["synthetic_8k_oracle", "dense_vs_grid_30k", "no_range_gate_unfiltered", "sim_unstructured_grid"])
+@pytest.mark.parametrize("case", ["synthetic_8k_oracle", "dense_vs_grid_30k", "no_range_gate_unfiltered", "sim_unstructured_grid",
+                                  "crowded_capsules"])
 def test_ray_shortening_on_the_hit_grid(built, case, monkeypatch):
     """VERDICT r05 #5 — the O(N k) ray shortening (devmap_lv_kernels.h "ray shortening in O(N k)": uniform grid over the hits,
-    per-beam capsule walk, pairs sorted by hit inside every beam) against the dense hits x hits form and the restatement
+    one wave per beam: capsule walk, nearby hits collected and sorted by hit index in LDS, ordered walk) against the dense hits x hits form and the restatement
     (src/bgklvoctomap/bgklvoctomap.cpp:313-423): the same "nearby" sets walked in the same order, so samples and segments are
     BIT-IDENTICAL.  LA3DM_LV_NEAR forces a path (default: dense below 8 192 hits, grid above)."""
     import la3dm_amd
@@ -201,6 +202,21 @@ def test_ray_shortening_on_the_hit_grid(built, case, monkeypatch):
             a, _ = train("dense", xyz, origin, -1.0, 0.2, mr)
             b, _ = train("grid", xyz, origin, -1.0, 0.2, mr)
             same(a, b)
+    elif case == "crowded_capsules":
+        # beams whose capsule holds more nearby hits than the kernel's LDS buffer (1 024: it then walks windows of the hit index) and
+        # more non-empty cells per round of slabs than its cell queue (192: the lane that found a cell tests it): 4 000 points strung
+        # along one ray, a sheet of 6 000 points that other rays graze, 6 000 scattered ones; unfiltered, in shuffled order
+        rng = np.random.default_rng(11)
+        t = rng.uniform(0.5, 7.8, 4000)
+        line = np.stack([t, 0.3 * t, 0.1 * t], 1) + rng.normal(0, 0.02, (4000, 3))
+        gx, gz = np.meshgrid(np.linspace(0.4, 7.6, 400), np.linspace(-0.25, 0.25, 15))
+        sheet = np.stack([gx.ravel(), np.full(gx.size, 0.05), 1.0 + gz.ravel()], 1)
+        cloud = np.concatenate([line + [0, 0, 1.0], sheet, rng.uniform(-6, 6, (6000, 3)) + [0, 0, 2.0]]).astype(np.float32)
+        cloud = cloud[rng.permutation(cloud.shape[0])]
+        origin = [0.0, 0.0, 1.0]
+        a, _ = train("dense", cloud, origin, -1.0, 0.2, 8.0)
+        b, _ = train("grid", cloud, origin, -1.0, 0.2, 8.0)
+        same(a, b)
     else:
         xyz, origin = la3dm_amd.load_pcd(pcd_path("sim_unstructured", 3))
         a, _ = train("dense", xyz, origin, 0.05, 0.1, 8.0)
