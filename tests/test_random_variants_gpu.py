@@ -72,7 +72,7 @@ def test_bgklv_random(built):
     import la3dm_amd
     from oracle import oracle as O
     rng = np.random.default_rng(303)
-    for case in range(6):
+    for case in range(4):   # (round 6: 6 -> 4 cases; the CPU restatement's per-voxel loop is what takes the time)
         res = float(rng.choice([0.05, 0.1]))
         params = dict(resolution=res, block_depth=int(rng.choice([3, 4, 5])), sf2=0.1, ell=float(rng.choice([0.2, 0.3])),
                       free_thresh=0.3, occupied_thresh=0.7, var_thresh=0.2, prior_A=0.001, prior_B=0.001,
@@ -87,8 +87,8 @@ def test_bgklv_random(built):
             _same(m.leaves(), o.leaves(), f"lv case{case} scan{scan} {params} fr={fr}")
 
 
-@pytest.mark.parametrize("sum_mode,first,count,flavour", [("0", 300, 25, "degenerate"), ("1", 340, 25, "degenerate"),
-                                                          ("1", 2000, 3, "big"), ("0", 2100, 2, "big"), ("0", 3000, 3, "gp")])
+@pytest.mark.parametrize("sum_mode,first,count,flavour", [("0", 300, 14, "degenerate"), ("1", 340, 12, "degenerate"),
+                                                          ("1", 2000, 2, "big"), ("0", 2100, 2, "big"), ("0", 3000, 3, "gp")])
 def test_differential_fuzz_sample(built, sum_mode, first, count, flavour):
     """slices of tests/manual/fuzz_pool.py (all four variants, both map modes, offsets, NaN points, hits at the sensor,
     duplicates, bbox and leaf export on the pool) in BOTH accumulate modes of the BGK family: the reference's summation

@@ -4,10 +4,10 @@
 # a kernel header (tests/test_profiles_stamps_cpu.py is red until then).
 #   gpurun --timeout 2400 -- 'bash tools/prof/restamp_all.sh'
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 S=$GRAFT_REPO_ROOT/gpurun_out/$ROUND/stamped; rm -rf $S; mkdir -p $S/$ROUND
 bash tools/prof/update_traffic.sh > $S/log_update_traffic.txt 2>&1
-cp gpurun_out/$ROUND/prof/bgk_traffic.json $S/ && cp gpurun_out/$ROUND/prof/{bench_pmc_summary.txt,phase_table.txt,bench_kernel_stats_sum0.csv,bench_kernel_stats_sum1.csv} $S/$ROUND/
+cp gpurun_out/$ROUND/prof/bgk_traffic.json $S/ && cp gpurun_out/$ROUND/prof/{bench_pmc_summary.txt,phase_table.txt,bench_kernel_stats_sum0.csv,bench_kernel_stats_sum1.csv,bench_kernel_stats_depth4.csv} $S/$ROUND/
 bash tools/prof/gp_counters.sh > $S/log_gp_counters.txt 2>&1
 cp gpurun_out/$ROUND/gp_counters/gp_counters.json $S/
 bash tools/prof/side_pmc.sh > $S/log_side_pmc.txt 2>&1
