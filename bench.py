@@ -815,12 +815,14 @@ def l_leg(args, torch, la3dm_amd, cpu):
     fr = 0.3
     m = la3dm_amd.BGKLOctoMap(**params, device=0)
     assert m.is_device_resident()
-    for _ in range(2):
+    # After a leg that released gigabytes of device memory ONE insert of the next map stalls for 10 - 80 ms somewhere in its first
+    # dozen — no allocation, same work (tools/check/leg_order.py: it follows the release, whichever leg comes next).  Steady-state
+    # loops show none: 1 500 inserts in a row, max 1.29 ms for this class, 0.82 ms for BGKOctoMap (tools/check/outliers.py,
+    # profiles/r06/outliers.txt).  So the warm-up here is longer than the stall's window, every insert is timed on its own (it ends
+    # with the host's read of the pass counters anyway) and the median is what is reported, with mean and max beside it.
+    for _ in range(14):
         m.insert_pointcloud(xyz, origin, 0.1, fr, -1.0)
     steps = 10
-    # every insert timed on its own (it ends with the host's read of the pass counters anyway), the median reported: after a
-    # leg that freed gigabytes (GP depth 4) ONE insert of the next map stalls for ~80 ms somewhere in its first dozen — no
-    # allocation, same work (tools/check/leg_order.py) — and the mean of ten then reads 11 ms instead of 3.7
     each = []
     for _ in range(steps):
         torch.cuda.synchronize()

@@ -1554,7 +1554,8 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
         return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): LA3DM_LV_NEAR=dense needs nh^2 / 8 bytes of mask: at most 98 304 hits");
     DM_RESERVE(dm->lv_beam, sizeof(LvBeam) * (size_t)nh);
     hipLaunchKernelGGL(dm_lv_beam_init, dim3(cdiv(nh, 256)), dim3(256), 0, st, d_hits, nh, ba, (LvBeam *)dm->lv_beam.ptr);
-    if (force_dense || (!force_grid && nh < 8192u)) {
+    static const uint32_t kGridMin = getenv("LA3DM_LV_GRID_MIN") ? (uint32_t)std::max(1, atoi(getenv("LA3DM_LV_GRID_MIN"))) : 8192u;   // (A/B: hits from which the grid form runs)
+    if (force_dense || (!force_grid && nh < kGridMin)) {
         const uint32_t nw = cdiv(nh, 64);
         DM_RESERVE(dm->lv_mask, 8ull * nh * nw);
         // (beams per workgroup: small scans need the parallelism — a tile is walked in sequence —, large ones the reuse of the wave's 64 hits)
@@ -1574,13 +1575,21 @@ static int lv_insert(la3dm_devmap *dm, const float *d_xyz, uint32_t n, const flo
     } else {
         const double *rng = (const double *)dm->lv_rng.ptr;
         const LvBeam *beams = (const LvBeam *)dm->lv_beam.ptr;
-        // 1. the grid: bounds of the in-range hits in cells of edge `influence` around the sensor -> dimensions
-        hipLaunchKernelGGL(dm_lv_hit_bounds, dim3(std::min<uint32_t>(cdiv(nh, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, nh, ba, rng, dm->d_cnt);
-        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
-        if (dm->h_cnt[kCntError] & kErrLvExtent) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): hit coordinates beyond the ray-shortening grid's index range");
-        int32_t hmm[7];
-        memcpy(hmm, dm->h_cnt + kCntLvHmm, 28);
-        if (hmm[6] == 0) hmm[0] = hmm[1] = hmm[2] = hmm[3] = hmm[4] = hmm[5] = 0;   // no hit in range: one empty cell
+        // 1. the grid: cells of edge `influence` around the sensor.  With a range gate every hit that can be nearby at all lies within
+        //    max_range of the sensor, so the grid's extent is known here; without one, the bounds of the hits come from a reduction and
+        //    one counter read-back
+        int32_t hmm[7] = {0, 0, 0, 0, 0, 0, 1};
+        const double reach = max_range > 0 ? ceil((double)max_range / ba.influence) + 1.0 : 0.0;
+        if (max_range > 0 && reach < 1.0e6) {
+            hmm[0] = hmm[1] = hmm[2] = -(int32_t)reach;
+            hmm[3] = hmm[4] = hmm[5] = (int32_t)reach;
+        } else {
+            hipLaunchKernelGGL(dm_lv_hit_bounds, dim3(std::min<uint32_t>(cdiv(nh, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, nh, ba, rng, dm->d_cnt);
+            if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+            if (dm->h_cnt[kCntError] & kErrLvExtent) return dm_fail(dm, LA3DM_ERR_ARG, "devmap (BGK-LV): hit coordinates beyond the ray-shortening grid's index range");
+            memcpy(hmm, dm->h_cnt + kCntLvHmm, 28);
+            if (hmm[6] == 0) hmm[0] = hmm[1] = hmm[2] = hmm[3] = hmm[4] = hmm[5] = 0;   // no hit in range: one empty cell
+        }
         LvHitGrid G;
         uint64_t ncell = 0;
         for (int m = 1;; m *= 2) {   // coarser cells while the dense grid would need more than 2^24 of them

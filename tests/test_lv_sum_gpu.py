@@ -60,11 +60,11 @@ def sum64():
     O.set_sum_mode(0, omp=True)
 
 
-def _insert(O, m, o64, o32, *args):
+def _insert(O, m, o64, o32, *args, omp=False):
     m.insert_pointcloud(*args)
-    O.set_sum_mode(1)
+    O.set_sum_mode(1, omp=omp)
     o64.insert_pointcloud(*args)
-    O.set_sum_mode(0)
+    O.set_sum_mode(0, omp=omp)
     o32.insert_pointcloud(*args)
 
 
@@ -91,8 +91,8 @@ def test_synthetic_scan_with_split_cubes(built, sum64):
     xyz, origin = la3dm_amd.synthetic_scan(8000)
     m = la3dm_amd.BGKLVOctoMap(**params, device=0)
     m.set_option("bgk_sum", 1)
-    o64, o32 = O.OracleLVMap(**params), O.OracleLVMap(**params)
-    _insert(O, m, o64, o32, xyz, origin, 0.05, 0.1, 8.0)
+    o64, o32 = O.OracleLVMap(**params, omp=True), O.OracleLVMap(**params, omp=True)   # (the OpenMP build of the restatement: equal to the serial one, tests/test_oracle.py)
+    _insert(O, m, o64, o32, xyz, origin, 0.05, 0.1, 8.0, omp=True)
     _check(m, o64, o32, params, "synthetic 8 k rays")
 
 

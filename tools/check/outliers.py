@@ -20,12 +20,14 @@ def report(tag, wall, lib):
         print(f"{tag:28s} {name:16s} median {med:.3f} ms  p99 {np.percentile(t, 99):.3f}  max {t.max():.3f}  > 3 x median: {int((t > 3 * med).sum())} of {t.size}   worst: {np.round(np.sort(t)[-4:], 2)}", flush=True)
 
 
-for tag in ("cloud in pageable memory", "cloud in pinned memory", "cloud in HBM"):
+for tag in ("cloud in pageable memory", "cloud in pinned memory", "cloud in HBM", "cloud in HBM, Python gc ON"):
+    if tag.endswith("gc ON"):
+        gc.enable()
     m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML), device=0)
     wall, lib = [], []
     for i in range(n):
         t0 = time.perf_counter()
-        if tag == "cloud in HBM":
+        if tag.startswith("cloud in HBM"):
             m.insert_pointcloud_device(d_cloud.data_ptr(), d_cloud.shape[0], origin, 0.1, 0.5, -1.0)
         elif tag == "cloud in pinned memory":
             m.insert_pointcloud(pinned.numpy(), origin, 0.1, 0.5, -1.0)
@@ -35,3 +37,16 @@ for tag in ("cloud in pageable memory", "cloud in pinned memory", "cloud in HBM"
         lib.append(m.stats()["t_total"])
     report(tag, wall, lib)
     del m
+
+# BGKLOctoMap (the class whose insert loops showed "1 in 400 at ~10 ms" in round 5), gc off, cloud in pageable memory
+gc.disable()
+m = la3dm_amd.BGKLOctoMap(**dict(la3dm_amd.L_YAML), device=0)
+wall, lib = [], []
+for i in range(n):
+    t0 = time.perf_counter()
+    m.insert_pointcloud(xyz, origin, 0.1, 0.3, -1.0)
+    wall.append(time.perf_counter() - t0)
+    lib.append(m.stats()["t_total"])
+report("BGK-L, pageable cloud", wall, lib)
+big = np.argsort(np.array(wall[5:]))[-4:] + 5
+print("BGK-L: positions of the four slowest inserts", sorted(big.tolist()))
