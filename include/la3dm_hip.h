@@ -158,7 +158,7 @@ const char *la3dm_last_error(const la3dm_ctx *ctx); /* ctx may be NULL: last cre
  * cores alike (default: the parity configuration), 1 = the order of operations of an x86-64 / SSE2 build of Eigen 3.3.7 on the VALU
  * (no FMA, packet sums, llt_inplace blocking, panels of 8 with reciprocal diagonals, packet exp: la3dm_amd/csrc/gp_eigen_kernels.h),
  * bit-identical to the restatement's oracle.set_gp_mode(1); training blocks of up to 128 points (block_depth 3), else LA3DM_ERR_ARG.
- * "grid_order" (device-resident maps) 0 = ascending cloud index inside a voxel-grid cell (default), 1 = what pcl::VoxelGrid's own
+ * "grid_order" (the maps' voxel-grid filters, device-resident and host-orchestrated) 0 = ascending cloud index inside a cell (default), 1 = what pcl::VoxelGrid's own
  * std::sort on the cell index alone leaves (src/bgkoctomap/bgkoctomap.cpp:419-431): the keys are sorted on the HOST by libstdc++ —
  * a verification mode, slow by design, single GPU; with "fast_trig" 3 (and "gp_mode" 1) the device path is bit-identical to the
  * restatement's oracle.set_modes(1, 1): the configuration a ROS Noetic build of the reference most plausibly runs.

@@ -289,7 +289,9 @@ __global__ __launch_bounds__(kWave) void gp_predict_fuse_eigen_kernel(GpArgs a) 
         const int tb = a.nbr[7 * blk + nb];
         const float *L = a.Lmat + a.l_off[tb];
         const float4 *x = a.pts + r.x;
-        const float *al = a.alpha_k + r.x;
+        const float *al = a.alpha_k + r.x;   // (L, x, alpha: the same address in every lane.  As SCALAR loads — the pointers made uniform with
+                                            //  v_readfirstlane — the kernel was slower, 5.0 against 4.4 ms: s_load and ds_read share lgkmcnt, and
+                                            //  every wait for an LDS column then also waits for the scalar loads in flight)
         for (int k = 0; k < N; ++k) {
             const float4 xk = x[k];
             s_v[k][lane] = matern3_eigen_dev(xk.x, xk.y, xk.z, tx, ty, tz, a.sf2);   // matern3_eigen(&xn[3 k], t)

@@ -24,7 +24,7 @@ double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::
 inline uint32_t layer_base(unsigned depth) { return 0x249249u & ((1u << (3u * depth)) - 1u); }
 
 // voxel-grid centroid filter (same semantics as the BGK front end; PCL is not a dependency)
-void lv_voxel_grid(const std::vector<float> &in, float leaf, std::vector<float> &out) {
+void lv_voxel_grid(const std::vector<float> &in, float leaf, std::vector<float> &out, bool pcl_order = false) {
     out.clear();
     const size_t n = in.size() / 3;
     if (n == 0) return;
@@ -58,7 +58,15 @@ void lv_voxel_grid(const std::vector<float> &in, float leaf, std::vector<float> 
                   c2 = (int)(std::floor(p[2] * inv) - (float)lo[2]);
         order.push_back(((uint64_t)(uint32_t)(c0 + c1 * span[0] + c2 * span[0] * span[1]) << 32) | (uint32_t)i);
     }
-    std::sort(order.begin(), order.end());
+    if (pcl_order) {   // option "grid_order" 1: pcl::VoxelGrid's own std::sort, on the cell index alone (see host/bgkoctomap.cpp voxel_grid_filter)
+        // (pairs {cell, index} as pcl::VoxelGrid's cloud_point_index_idx: same size, same comparator, hence the same introsort moves)
+        std::vector<std::pair<unsigned, unsigned>> iv(order.size());
+        for (size_t i = 0; i < order.size(); ++i) iv[i] = {(unsigned)(order[i] >> 32), (unsigned)order[i]};
+        std::sort(iv.begin(), iv.end(), [](const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) { return a.first < b.first; });
+        for (size_t i = 0; i < order.size(); ++i) order[i] = ((uint64_t)iv[i].first << 32) | iv[i].second;
+    } else {
+        std::sort(order.begin(), order.end());
+    }
     for (size_t i = 0; i < order.size();) {
         const uint32_t cell = (uint32_t)(order[i] >> 32);
         float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -106,7 +114,11 @@ void BGKLVOctoMap::training_data_lv(const float *xyz, size_t n, size_t stride, c
         packed[3 * i + 1] = xyz[stride * i + 1];
         packed[3 * i + 2] = xyz[stride * i + 2];
     }
-    if (ds_resolution < 0) hits.swap(packed); else lv_voxel_grid(packed, ds_resolution, hits);
+    {
+        int go = 0;
+        const bool pcl_order = device_ctx() && la3dm_get_option(device_ctx(), "grid_order", &go) == 0 && go == 1;
+        if (ds_resolution < 0) hits.swap(packed); else lv_voxel_grid(packed, ds_resolution, hits, pcl_order);
+    }
     samples.clear();
     rays8.clear();
     rays6.clear();

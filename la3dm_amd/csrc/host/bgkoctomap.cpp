@@ -858,7 +858,12 @@ namespace {
 // Voxel-grid centroid filter with the semantics of pcl::VoxelGrid<PointXYZ> (PCL is not a
 // dependency of this build): cell = floor(p * (1/leaf)) - floor(min * (1/leaf)), output cells in
 // ascending linear index, centroid = fp32 sum in cloud order / (float)count.
-void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float> &out) {
+bool grid_order_option(la3dm_ctx *ctx) {
+    int v = 0;
+    return ctx && la3dm_get_option(ctx, "grid_order", &v) == 0 && v == 1;
+}
+
+void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float> &out, bool pcl_order = false) {
     out.clear();
     if (n == 0) return;
     const float inv = 1.0f / leaf;
@@ -885,6 +890,40 @@ void voxel_grid_filter(const float *in, size_t n, float leaf, std::vector<float>
     }
     const int m1 = span[0], m2 = span[0] * span[1];
     const size_t ncell = (size_t)span[0] * span[1] * span[2];
+    if (pcl_order) {
+        // option "grid_order" 1 (verification mode, include/la3dm_hip.h): the order of the points inside a cell as pcl::VoxelGrid's own
+        // std::sort leaves it — {cell, cloud index} pairs compared on the cell alone (src/bgkoctomap/bgkoctomap.cpp:419-431)
+        std::vector<std::pair<unsigned, unsigned>> iv;
+        iv.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = in + 3 * i;
+            if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+            const int c0 = (int)(std::floor(p[0] * inv) - (float)lo[0]);
+            const int c1 = (int)(std::floor(p[1] * inv) - (float)lo[1]);
+            const int c2 = (int)(std::floor(p[2] * inv) - (float)lo[2]);
+            iv.emplace_back((unsigned)(c0 + c1 * m1 + c2 * m2), (unsigned)i);
+        }
+        struct PclLess {
+            bool operator()(const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) const { return a.first < b.first; }
+        };
+        std::sort(iv.begin(), iv.end(), PclLess());
+        for (size_t i = 0; i < iv.size();) {
+            size_t j = i;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (; j < iv.size() && iv[j].first == iv[i].first; ++j) {
+                const float *p = in + 3 * (size_t)iv[j].second;
+                sx += p[0];
+                sy += p[1];
+                sz += p[2];
+            }
+            const float cnt = (float)(j - i);
+            out.push_back(sx / cnt);
+            out.push_back(sy / cnt);
+            out.push_back(sz / cnt);
+            i = j;
+        }
+        return;
+    }
     if (ncell <= ((size_t)1 << 24)) {
         // dense accumulation: one pass in cloud order (the same per-cell summation order as sorting by
         // (cell, index)), then the occupied cells in ascending index
@@ -999,7 +1038,8 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
     }
     std::vector<float> hits;
     const double tt0 = wall();
-    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
+    const bool pcl_order = grid_order_option(ctx);
+    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits, pcl_order);
     const double tt1 = wall();
 
     xy.clear();
@@ -1050,7 +1090,7 @@ void BGKOctoMap::get_training_data(const float *xyz, size_t n, size_t stride, co
     }
     std::vector<float> sampled;
     const double tt2 = wall();
-    if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled);
+    if (ds_resolution < 0) sampled.swap(frees); else voxel_grid_filter(frees.data(), frees.size() / 3, ds_resolution, sampled, pcl_order);
     if (getenv("LA3DM_TIMING"))
         fprintf(stderr, "[la3dm] front end: grid(hits) %.4f beam %.4f grid(frees, %zu pts) %.4f\n", tt1 - tt0, tt2 - tt1,
                 frees.size() / 3, wall() - tt2);
@@ -1074,7 +1114,7 @@ void BGKOctoMap::get_training_data_l(const float *xyz, size_t n, size_t stride, 
         packed[3 * i + 2] = xyz[stride * i + 2];
     }
     std::vector<float> hits;
-    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits);
+    if (ds_resolution < 0) hits.swap(packed); else voxel_grid_filter(packed.data(), n, ds_resolution, hits, grid_order_option(ctx));
     const float x0 = origin.x(), y0 = origin.y(), z0 = origin.z();
     const size_t nh = hits.size() / 3;
     // pass 1: range gate and sample count per hit (the float-stepped while loop, kept verbatim); pass 2: fill

@@ -3,7 +3,7 @@
 #   profiles/gp_counters.json  (what bench.py's gp legs quote as roofline.valu_issue)
 # usage (GPU box): bash tools/prof/gp_counters.sh  ->  gpurun_out/$ROUND/gp_counters/gp_counters.json, copy into profiles/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-ROUND=${ROUND:-r05}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
+ROUND=${ROUND:-r06}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$ROUND/gp_counters; rm -rf $OUT; mkdir -p $OUT
 for D in 3 4; do
   timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_MFMA -d $OUT/d$D -o p -- \
@@ -19,8 +19,8 @@ for D in (3, 4):
     disp = collections.defaultdict(set)
     for f in glob.glob("$OUT/d%d/**/*counter_collection.csv" % D, recursive=True):
         for row in csv.DictReader(open(f)):
-            if "gp_predict_fuse" not in row["Kernel_Name"]:
-                continue
+            if "gp_predict_fuse" not in row["Kernel_Name"] or "eigen" in row["Kernel_Name"]:
+                continue     # (the depth-3 leg also times option gp_mode 1 — gp_predict_fuse_eigen_kernel: not part of the default step)
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
             disp[row["Kernel_Name"][:40]].add(row["Dispatch_Id"])
     steps = 2.0   # --steps 1 --warmup 1

@@ -5,7 +5,7 @@
 #   gpurun_out/$ROUND/side/side_pmc_<leg>.txt  -> profiles/$ROUND/
 # usage (GPU box): bash tools/prof/side_pmc.sh
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-ROUND=${ROUND:-r05}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
+ROUND=${ROUND:-r06}   # output directory under gpurun_out/ and profiles/; the entries' "round" field
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$ROUND/side; rm -rf $OUT; mkdir -p $OUT
 N=3
 for LEG in lv50k lvseq l; do
