@@ -74,7 +74,12 @@ struct la3dm_devmap {
     // BGKLVOctoMap (variant 2): beams, samples, segments, gather grid, packed blocks
     Arena lv_rng, lv_flags, lv_seg, lv_nsamp, lv_nray, lv_samp_off, lv_ray_off, lv_samples, lv_rays, lv_sorted, lv_cell_off;
     Arena lv_beam, lv_mask;
-    Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist;   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
+    Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist;
+    Arena cell_cnt, slab_range;   // x-slab partition of a sharded insert: per-cell point counts; {first, last} grid cell of the own slab
+    int shard_slab = getenv("LA3DM_SHARD_SLAB") ? atoi(getenv("LA3DM_SHARD_SLAB")) : -1;   // x-slab partition of a sharded insert: 1 on, 0 off (every rank builds the CSR of all
+                                                                                            // training blocks), -1 (default) = on for GPOctoMap — a rank then also TRAINS its slab's blocks only —, off for BGKOctoMap, where the
+                                                                                            // global per-cell histogram costs what the divided sort saves (measured)
+    bool force_slab = getenv("LA3DM_FORCE_SLAB") && atoi(getenv("LA3DM_FORCE_SLAB")) == 1;   // (test / profiling hook: the x-slab form on an UNSHARDED map, its slab = the whole test list)   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
     Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
     int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
     uint32_t lv_n_samples = 0, lv_n_rays = 0;
@@ -976,6 +981,8 @@ struct ScanPlan {
     uint32_t *train_off = nullptr;
     uint32_t *rows_off = nullptr;  // BGKLOctoMap: CSR of the training rows over the training blocks
     uint32_t flags = 0;      // la3dm_bgk_scan.flags of the passes (LA3DM_SCAN_UPDATE_UNGATED for insert_training_data)
+    bool slab = false;       // sharded, single pass: the CSR is built per rank, for its own x-slab, inside the pass (build_slab_csr)
+    int cell_bits = 0;       // key bits of a grid cell index
 };
 
 // f2 (bgkoctomap.cpp:234-284, 486-552): candidate sequences of get_blocks_in_bbox, closed-box membership of every
@@ -1065,6 +1072,31 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->m_code, 16ull * npts);
     hipLaunchKernelGGL(dm_members_count, dim3(cdiv(npts, 256)), dim3(256), 0, st, xy, npts, pa, m_cnt,
                        (int4 *)dm->m_code.ptr);
+    int bits = 1;
+    while ((1ull << bits) < ncid) ++bits;
+    P.cell_bits = bits;
+    const bool want_slab = dm->shard_slab < 0 ? ctx->p.variant == 1 : dm->shard_slab != 0;
+    if (((dm->shard_world > 1 && dm->shard_fn && want_slab) || dm->force_slab) && max_occ == 1 && ctx->p.variant != 3) {
+        // x-slab partition (devmap_kernels.h): only the per-cell point counts are formed for all blocks here; pairs, sort, CSR, rows
+        // and neighbour tables follow inside the pass, once the cut is known, for the cells of this rank's slab (build_slab_csr)
+        DM_RESERVE(dm->cell_cnt, 4ull * ncid);
+        DM_RESERVE(dm->grid, 4ull * ncid);
+        DM_TRY(hipMemsetAsync(dm->cell_cnt.ptr, 0, 4ull * ncid, st));
+        hipLaunchKernelGGL(dm_members_hist, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const int4 *)dm->m_code.ptr, npts, pa, (uint32_t *)dm->cell_cnt.ptr,
+                           dm->d_cnt);
+        hipLaunchKernelGGL(dm_cell_trained, dim3(std::min<uint32_t>(cdiv((uint32_t)ncid, 256), 64u)), dim3(256), 0, st, (const uint32_t *)dm->cell_cnt.ptr, (uint32_t)ncid, pa,
+                           dm->d_cnt);
+        DM_RESERVE(dm->c_flag, 4ull * n_entries);
+        DM_RESERVE(dm->c_scan, 4ull * n_entries);
+        P.slab = true;
+        P.ncid = ncid;
+        P.n_entries = n_entries;
+        P.max_occ = max_occ;
+        P.n_mem = 0;
+        P.n_geo = 0;
+        P.train_off = nullptr;
+        return LA3DM_OK;
+    }
     if ((rc = exclusive_scan(dm, m_cnt, m_off, npts, (int)kCntMembers, true)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     const uint32_t n_mem = dm->h_cnt[kCntMembers];
@@ -1074,8 +1106,6 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->v1, 4ull * n_mem);
     uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
     DM_RESERVE(dm->grid, 4ull * ncid);
-    int bits = 1;
-    while ((1ull << bits) < ncid) ++bits;
     if (n_mem && sort_fusable(dm, bits)) {   // the pairs are written by the sort's histogram launch
         const MembersSrc src = {(const int4 *)dm->m_code.ptr, pa, m_off, k0, v0, dm->d_cnt, (int32_t *)dm->grid.ptr, (uint32_t)ncid};
         if ((rc = sort_pairs_src(dm, src, npts, k0, k1, v0, v1, n_mem, bits)) != LA3DM_OK) return rc;
@@ -1111,6 +1141,7 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     hipLaunchKernelGGL(dm_gather_geo, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, (const uint32_t *)v1, n_mem,
                        ctx->p.variant == 3 ? (float4 *)nullptr : (float4 *)dm->train.ptr, (const uint32_t *)seg_key, dm->d_cnt, pa,
                        (int32_t *)dm->grid.ptr);
+    hipLaunchKernelGGL(dm_count_trained, dim3(std::min<uint32_t>(cdiv(n_mem, 256 * 4), 64u)), dim3(256), 0, st, (const uint32_t *)seg_key, pa, dm->d_cnt);
     // the segment count is only needed on the host by the GP launches; the BGK path reads it (and the error flag)
     // together with the test-block count of the first pass
     uint32_t n_geo = n_mem;
@@ -1127,6 +1158,69 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     return LA3DM_OK;
 }
 
+// x-slab partition, second half (sharded single-pass inserts; devmap_kernels.h): the (block, point) pairs, their sort, the CSR, the
+// training rows and the dense cell -> training-block index — for the grid cells of the own range [t0, t1) of the test list and its
+// halo (the cells of those test blocks' extended blocks) only.  Training-block indices are local to the rank.
+static int build_slab_csr(la3dm_devmap *dm, ScanPlan &P, const uint32_t *t_ent, uint32_t t0, uint32_t t1) {
+    la3dm_ctx *ctx = dm->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t npts = dm->n_xy;
+    const float4 *xy = (const float4 *)dm->xy.ptr;
+    const PartArgs &pa = P.pa;
+    const uint32_t ncid = (uint32_t)P.ncid;
+    int rc;
+    DM_RESERVE(dm->slab_range, 8);
+    uint32_t *range = (uint32_t *)dm->slab_range.ptr;
+    DM_TRY(hipMemsetAsync(range, 0xFF, 4, st));
+    DM_TRY(hipMemsetAsync(range + 1, 0, 4, st));
+    if (t1 > t0) hipLaunchKernelGGL(dm_slab_range, dim3(1), dim3(64), 0, st, P.ca, t_ent, t0, t1, range, dm->shard_world > 1 ? 0u : ncid);
+    uint32_t *m_cnt = (uint32_t *)dm->flag.ptr, *m_off = (uint32_t *)dm->scan.ptr;   // (reserved by partition: 4 npts each)
+    hipLaunchKernelGGL(dm_members_count_slab, dim3(cdiv(npts, 256)), dim3(256), 0, st, (const int4 *)dm->m_code.ptr, npts, pa, (const uint32_t *)range, m_cnt);
+    if ((rc = exclusive_scan(dm, m_cnt, m_off, npts, (int)kCntMembers, true)) != LA3DM_OK) return rc;
+    if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+    const uint32_t n_mem = dm->h_cnt[kCntMembers];
+    const size_t pb = 4ull * std::max<uint32_t>(n_mem, 4u);
+    DM_RESERVE(dm->k0, pb);
+    DM_RESERVE(dm->k1, pb);
+    DM_RESERVE(dm->v0, pb);
+    DM_RESERVE(dm->v1, pb);
+    uint32_t *k0 = (uint32_t *)dm->k0.ptr, *k1 = (uint32_t *)dm->k1.ptr, *v0 = (uint32_t *)dm->v0.ptr, *v1 = (uint32_t *)dm->v1.ptr;
+    DM_RESERVE(dm->c_flag, pb);
+    DM_RESERVE(dm->c_scan, pb);
+    DM_RESERVE(dm->seg_start, 4ull * ((size_t)n_mem + 1));
+    DM_RESERVE(dm->seg_key, 4ull * ((size_t)n_mem + 1));
+    DM_RESERVE(dm->train, 16ull * std::max<uint32_t>(n_mem, 1u));
+    uint32_t *train_off = (uint32_t *)dm->seg_start.ptr, *seg_key = (uint32_t *)dm->seg_key.ptr;
+    if (n_mem) {
+        const MembersSlabSrc src = {(const int4 *)dm->m_code.ptr, pa, m_off, range, k0, v0, (int32_t *)dm->grid.ptr, ncid};
+        if (sort_fusable(dm, P.cell_bits)) {   // the pairs are written by the sort's histogram launch
+            if ((rc = sort_pairs_src(dm, src, npts, k0, k1, v0, v1, n_mem, P.cell_bits)) != LA3DM_OK) return rc;
+        } else {
+            hipLaunchKernelGGL((dm_run_src<MembersSlabSrc>), dim3(cdiv(npts, 256)), dim3(256), 0, st, src, npts);
+            if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, P.cell_bits)) != LA3DM_OK) return rc;
+        }
+        if ((rc = scan_heads(dm, k1, n_mem, (uint32_t *)dm->c_flag.ptr, (uint32_t *)dm->c_scan.ptr, train_off, seg_key, (int)kCntGeo,
+                             (int)kCntGridValid)) != LA3DM_OK)
+            return rc;
+        hipLaunchKernelGGL(dm_gather_geo, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, (const uint32_t *)v1, n_mem, (float4 *)dm->train.ptr,
+                           (const uint32_t *)seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
+    } else {   // a rank whose slab holds no training point: no block has a model
+        DM_TRY(hipMemsetAsync(dm->grid.ptr, 0xFF, 4ull * ncid, st));
+        DM_TRY(hipMemsetAsync(train_off, 0, 8, st));
+    }
+    P.n_mem = n_mem;
+    P.n_geo = n_mem;
+    P.train_off = train_off;
+    if (ctx->p.variant == 1) {   // the GP launches are sized by the number of training blocks
+        if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
+        P.n_geo = n_mem ? dm->h_cnt[kCntGeo] : 0u;
+    }
+    if (getenv("LA3DM_DEBUG_SHARD"))
+        fprintf(stderr, "la3dm x-slab partition: rank %u of %u builds the CSR of %u (block, point) pairs for test blocks [%u, %u)\n", dm->shard_rank,
+                dm->shard_world, n_mem, t0, t1);
+    return LA3DM_OK;
+}
+
 // One pass over the candidate list (bgkoctomap.cpp:286-353): test-block decision, find-or-create, leaves in
 // LeafIterator order, predict + fuse, write-back, prune.  A pass holds every candidate key once; keys the float
 // stepping of get_blocks_in_bbox repeats come back in later passes, as in the serial reference.
@@ -1135,15 +1229,20 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     hipStream_t st = ctx->stream;
     la3dm_devmap_stats &S = dm->stats;
     CandArgs &ca = P.ca;
-    const uint32_t n_entries = P.n_entries, max_occ = P.max_occ, n_mem = P.n_mem, ncell = dm->ncell;
-    uint32_t *train_off = P.train_off;
+    const uint32_t n_entries = P.n_entries, max_occ = P.max_occ, ncell = dm->ncell;
+    uint32_t n_mem = P.n_mem;
+    uint32_t *train_off = P.train_off;   // (both set by build_slab_csr, further down, in the x-slab form of a sharded insert)
     uint32_t *c_flag = (uint32_t *)dm->c_flag.ptr, *c_weight = (uint32_t *)dm->c_weight.ptr, *c_scan = (uint32_t *)dm->c_scan.ptr;
     uint32_t &n_geo = P.n_geo;
     int rc;
     const double tp0 = wall();
     ca.pass = pass;
-    hipLaunchKernelGGL(dm_candidates, dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
-                       (const uint32_t *)train_off, n_entries, c_flag, c_weight);
+    if (P.slab)
+        hipLaunchKernelGGL((dm_candidates<true>), dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->cell_cnt.ptr,
+                           (const uint32_t *)nullptr, n_entries, c_flag, c_weight);
+    else
+        hipLaunchKernelGGL((dm_candidates<false>), dim3(cdiv(n_entries, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+                           (const uint32_t *)train_off, n_entries, c_flag, c_weight);
     DM_RESERVE(dm->t_key0, 4ull * n_entries);
     DM_RESERVE(dm->t_ent0, 4ull * n_entries);
     // (the scan's total is the test-block count: it publishes the counters, the compaction runs while the host waits)
@@ -1170,7 +1269,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
     if (dm->h_cnt[kCntError])
         return dm_fail(dm, LA3DM_ERR_ARG, "devmap: internal error: training point outside the block index grid");
-    if (ctx->p.variant != 1) n_geo = dm->h_cnt[kCntGeo];
+    if (ctx->p.variant != 1 && !P.slab) n_geo = dm->h_cnt[kCntGeo];
     S.n_train_blocks = dm->h_cnt[kCntTrained];
     const uint32_t n_test = dm->h_cnt[kCntTest];
     if (n_test == 0) return LA3DM_OK;
@@ -1232,7 +1331,7 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     // (d_cnt[kCntBlocks] holds the pool's block count since dm_begin; the passes keep it current)
     {
         const TableArgs tb = {dm->tab_key, dm->tab_val, dm->tab_cap - 1, dm->d_cnt + kCntBlocks, dm->blk_key};
-        hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr,
+        hipLaunchKernelGGL(dm_test_build, dim3(cdiv(n_test, 256)), dim3(256), 0, st, ca, P.slab ? (const int32_t *)nullptr : (const int32_t *)dm->grid.ptr,
                            t_ent, dm->d_cnt, (long long *)dm->t_blockkey.ptr, (float *)dm->t_center.ptr,
                            (int32_t *)dm->t_nbr.ptr, tb, (uint32_t *)dm->t_slot.ptr);
     }
@@ -1273,6 +1372,15 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
                 return dm_fail(dm, LA3DM_ERR_HIP, "devmap: internal error: the range cut of the sharded insert is not monotone");
         t0s = hb[dm->shard_rank];
         t1s = hb[dm->shard_rank + 1];
+    }
+    if (P.slab) {
+        // the cut is known: pairs, sort, CSR and rows of the own slab, then the own range's neighbour tables
+        if ((rc = build_slab_csr(dm, P, t_ent, t0s, t1s)) != LA3DM_OK) return rc;
+        n_mem = P.n_mem;
+        train_off = P.train_off;
+        if (t1s > t0s)
+            hipLaunchKernelGGL(dm_test_nbr, dim3(cdiv(t1s - t0s, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr, t_ent, t0s, t1s,
+                               (int32_t *)dm->t_nbr.ptr);
     }
     {
         // the emitting launch carries the pass's work counters (train_reads, pair_evals) in a few workgroups of its own

@@ -1137,23 +1137,94 @@ struct MembersSrc {
 
 // Two jobs of one index space in one launch (round 5; dm_gather_train + dm_geo_fill before):
 //   i < n:                  train[i] = xy[vals[i]]   (the training rows in CSR order; train == nullptr: BGK-L gathers rows elsewhere)
-//   i < counters[kCntGeo]:  grid[cid] = segment (training block) index — -1 elsewhere, written by dm_members_write — and
-//                           counters[kCntTrained] += blocks with points that are in the candidate list (one atomic per wave)
+//   i < counters[kCntGeo]:  grid[cid] = segment (training block) index — -1 elsewhere, written by dm_members_write
 __global__ __launch_bounds__(256) void dm_gather_geo(const float4 *__restrict__ xy, const uint32_t *__restrict__ vals, uint32_t n,
                                                     float4 *train, const uint32_t *__restrict__ seg_key, uint32_t *counters,
                                                     PartArgs a, int32_t *grid) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (train && i < n) train[i] = xy[vals[i]];
-    bool trained = false;
-    if (i < counters[kCntGeo]) {
+    if (i < counters[kCntGeo]) grid[seg_key[i]] = (int32_t)i;
+}
+// counters[kCntTrained] += training blocks (CSR segments) that are in the candidate list.  Its own launch of at most 64 workgroups,
+// one atomic each: inside dm_gather_geo it was one atomic per wave on ONE address — ~25 ns per caller, serialised: 65 of that
+// kernel's 94 us at configs[4]'s 200 k training blocks (found while measuring the x-slab form, round 6).
+__global__ __launch_bounds__(256) void dm_count_trained(const uint32_t *__restrict__ seg_key, PartArgs a, uint32_t *counters) {
+    __shared__ uint32_t s_n[4];
+    const uint32_t n_geo = counters[kCntGeo];
+    uint32_t c = 0;
+#pragma unroll 4
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_geo; i += gridDim.x * blockDim.x) {
         const uint32_t cid = seg_key[i];
-        grid[cid] = (int32_t)i;
         const uint32_t z = cid % (uint32_t)a.gn[2], y = (cid / (uint32_t)a.gn[2]) % (uint32_t)a.gn[1],
                        x = cid / ((uint32_t)a.gn[2] * (uint32_t)a.gn[1]);
-        trained = a.mult[0][x] && a.mult[1][y] && a.mult[2][z];
+        c += (a.mult[0][x] && a.mult[1][y] && a.mult[2][z]) ? 1u : 0u;
     }
-    const unsigned long long m = __ballot(trained);
-    if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&counters[kCntTrained], (uint32_t)__popcll(m));
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63u) == 0u) s_n[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        if (t) atomicAdd(&counters[kCntTrained], t);
+    }
+}
+
+// ---- x-slab partition of the block-sharded insert (round 6, VERDICT r05 #1d) ---------------------------------------------
+// Unsharded, every (block, point) membership pair is sorted into the CSR of ALL training blocks (the largest stage of the
+// partition).  A rank of a sharded insert only evaluates a contiguous range of the test list — candidate order is x-major, so
+// that is an x-slab of blocks — and needs the training blocks of that range's 7-neighbourhoods only.  What has to stay global is
+// small: the per-block point COUNTS (which candidates are test blocks, their weights for the cut, the scan's statistics) — a
+// histogram over the dense block grid.  So: counts for all cells (dm_members_hist), candidates / weights / the cut from the
+// counts (dm_candidates<true>), then pairs, sort, CSR, rows and neighbour tables for the cells of the own slab only.
+// cell_cnt[cid] += 1 for every (block cell, point) pair (zero on entry).  The training set is two voxel-filter outputs, i.e. sorted
+// by grid cell: the lanes of a wave mostly share a block, and the sensor's own blocks hold thousands of points — one atomic per
+// lane serialised on those addresses (104 us at configs[4]'s size; matching equal cells by a ballot loop: 55 us, a wave spans ~16
+// blocks along x); so the head of every RUN of equal cells in lane order adds the run's length — one ballot, no loop.
+__global__ __launch_bounds__(256) void dm_members_hist(const int4 *__restrict__ code, uint32_t n, PartArgs a, uint32_t *cell_cnt,
+                                                      uint32_t *counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int4 cd = make_int4(0, 0, 0, 0);
+    if (i < n) cd = code[i];
+    const int nx = cd.w & 3, ny = (cd.w >> 2) & 3, nz = (cd.w >> 4) & 3;
+    const int mine = i < n ? nx * ny * nz : 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int sl = 0; sl < 8; ++sl) {
+        uint32_t c = 0xFFFFFFFFu;
+        if (sl < mine) {
+            const int w = sl % nz, v = (sl / nz) % ny, u = sl / (nz * ny);
+            if (!grid_cid(a, cd.x + u, cd.y + v, cd.z + w, c)) {
+                atomicOr(&counters[kCntError], 1u);  // a point outside the index grid: cannot happen
+                c = 0xFFFFFFFFu;
+            }
+        }
+        // runs of equal cells in lane order: the head of a run adds its length (the same cell in two runs of a wave: two atomics)
+        const uint32_t prev = (uint32_t)__shfl_up((int)c, 1);
+        const unsigned long long heads = __ballot(lane == 0u || c != prev);
+        if (c != 0xFFFFFFFFu && ((heads >> lane) & 1ull)) {
+            const unsigned long long later = lane == 63u ? 0ull : heads >> (lane + 1u);
+            const uint32_t len = later ? (uint32_t)__builtin_ctzll(later) + 1u : 64u - lane;
+            atomicAdd(&cell_cnt[c], len);
+        }
+    }
+}
+// blocks with training points that are in the candidate list (what dm_gather_geo counts from the CSR's segments); at most 64
+// workgroups, one atomic each (an atomic on one address costs ~25 ns per caller, serialised)
+__global__ __launch_bounds__(256) void dm_cell_trained(const uint32_t *__restrict__ cell_cnt, uint32_t ncid, PartArgs a, uint32_t *counters) {
+    __shared__ uint32_t s_n[4];
+    uint32_t c = 0;
+#pragma unroll 8
+    for (uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x; cid < ncid; cid += gridDim.x * blockDim.x) {   // (unrolled: eight loads in flight per thread)
+        if (!cell_cnt[cid]) continue;
+        const uint32_t z = cid % (uint32_t)a.gn[2], y = (cid / (uint32_t)a.gn[2]) % (uint32_t)a.gn[1],
+                       x = cid / ((uint32_t)a.gn[2] * (uint32_t)a.gn[1]);
+        c += (a.mult[0][x] && a.mult[1][y] && a.mult[2][z]) ? 1u : 0u;
+    }
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63u) == 0u) s_n[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        if (t) atomicAdd(&counters[kCntTrained], t);
+    }
 }
 
 // ---- block-sharded insert: every rank builds the same test list, predicts a contiguous range of it ----
@@ -1207,6 +1278,8 @@ __device__ __forceinline__ void extended_indices(int ix, int iy, int iz, float b
 
 // one thread per entry of the candidate list (x-major, then y, then z — get_blocks_in_bbox order):
 // flag = "this entry is a test block of this pass", weight = training points in its 7-neighbourhood
+// kCounts (x-slab partition of a sharded insert): `grid` holds the cells' point counts instead of the CSR's segment indices
+template <bool kCounts>
 __global__ __launch_bounds__(256) void dm_candidates(CandArgs a, const int32_t *__restrict__ grid,
                                                     const uint32_t *__restrict__ train_off, uint32_t n_entries,
                                                     uint32_t *flag, uint32_t *weight) {
@@ -1227,10 +1300,10 @@ __global__ __launch_bounds__(256) void dm_candidates(CandArgs a, const int32_t *
         uint32_t cid;
         if (!grid_cid(p, eb[q][0], eb[q][1], eb[q][2], cid)) continue;
         const int32_t s = grid[cid];
-        if (s < 0) continue;
+        if (kCounts ? s == 0 : s < 0) continue;
         any = true;  // the block geometrically holds points (R-tree hit)
         const bool cand = p.mult[0][eb[q][0] - p.g0[0]] && p.mult[1][eb[q][1] - p.g0[1]] && p.mult[2][eb[q][2] - p.g0[2]];
-        if (cand) w += train_off[s + 1] - train_off[s];  // ... and was trained (it is in the candidate list)
+        if (cand) w += kCounts ? (uint32_t)s : train_off[s + 1] - train_off[s];  // ... and was trained (it is in the candidate list)
     }
     flag[e] = (any && occ == a.pass) ? 1u : 0u;
     weight[e] = w;
@@ -1335,6 +1408,111 @@ __global__ __launch_bounds__(256) void dm_test_build(CandArgs a, const int32_t *
     center[3 * (size_t)t] = axis_center(ix, p.bs);
     center[3 * (size_t)t + 1] = axis_center(iy, p.bs);
     center[3 * (size_t)t + 2] = axis_center(iz, p.bs);
+    if (!grid) return;   // (x-slab partition: the CSR does not exist yet — dm_test_nbr writes the own range's tables later)
+    int eb[7][3];
+    extended_indices(ix, iy, iz, p.bs, eb);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        int32_t s = -1;
+        uint32_t cid;
+        if (grid_cid(p, eb[q][0], eb[q][1], eb[q][2], cid)) {
+            const bool cand = p.mult[0][eb[q][0] - p.g0[0]] && p.mult[1][eb[q][1] - p.g0[1]] && p.mult[2][eb[q][2] - p.g0[2]];
+            if (cand) s = grid[cid];
+        }
+        nbr[7 * (size_t)t + q] = s;
+    }
+}
+
+// ---- x-slab partition, second half: the own range [t0, t1) of the test list -----------------------------------------------
+__device__ __forceinline__ void test_entry_indices(const CandArgs &a, uint32_t e, int &ix, int &iy, int &iz) {
+    const uint32_t kc = e % (uint32_t)a.nseq[2], kb = (e / (uint32_t)a.nseq[2]) % (uint32_t)a.nseq[1],
+                   ka = e / ((uint32_t)a.nseq[2] * (uint32_t)a.nseq[1]);
+    ix = a.seq[0][ka];
+    iy = a.seq[1][kb];
+    iz = a.seq[2][kc];
+}
+// range[0] = first, range[1] = last grid cell of the own slab: the test list is in candidate order, x-major with non-decreasing x
+// indices (the float-stepped sequence of get_blocks_in_bbox), and the grid's cell index is x-major too — so the own blocks
+// [t0, t1) and their face neighbours lie in the y-z planes x_first - 1 .. x_last + 1.  One thread.  (First form: min / max over the
+// extended blocks of every own test block — 23 us of f64 index arithmetic for a range that is two look-ups.)
+__global__ void dm_slab_range(CandArgs a, const uint32_t *__restrict__ t_entry, uint32_t t0, uint32_t t1, uint32_t *range, uint32_t whole_ncid) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || t1 <= t0) return;   // (empty range: {0xFFFFFFFF, 0} stays — no cell)
+    if (whole_ncid) {   // (LA3DM_FORCE_SLAB on an unsharded map: its test list is sorted heaviest first, and its slab is everything)
+        range[0] = 0u;
+        range[1] = whole_ncid - 1u;
+        return;
+    }
+    int ix0, ix1, iy, iz;
+    test_entry_indices(a, t_entry[t0], ix0, iy, iz);
+    test_entry_indices(a, t_entry[t1 - 1], ix1, iy, iz);
+    const PartArgs &p = a.part;
+    const int plane = p.gn[1] * p.gn[2];
+    const int xlo = max(min(ix0, ix1) - 1 - p.g0[0], 0), xhi = min(max(ix0, ix1) + 1 - p.g0[0], p.gn[0] - 1);
+    range[0] = (uint32_t)xlo * (uint32_t)plane;
+    range[1] = (uint32_t)(xhi + 1) * (uint32_t)plane - 1u;
+}
+// (block, point) pairs of a point whose cell lies in the slab
+__global__ __launch_bounds__(256) void dm_members_count_slab(const int4 *__restrict__ code, uint32_t n, PartArgs a,
+                                                            const uint32_t *__restrict__ range, uint32_t *cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t lo = range[0], hi = range[1];
+    const int4 cd = code[i];
+    const int nx = cd.w & 3, ny = (cd.w >> 2) & 3, nz = (cd.w >> 4) & 3;
+    uint32_t c = 0;
+    for (int u = 0; u < nx; ++u)
+        for (int v = 0; v < ny; ++v)
+            for (int w = 0; w < nz; ++w) {
+                uint32_t cid = 0;
+                if (grid_cid(a, cd.x + u, cd.y + v, cd.z + w, cid) && cid >= lo && cid <= hi) ++c;
+            }
+    cnt[i] = c;
+}
+// MembersSrc for the slab: the pairs of the cells in [range[0], range[1]] only
+struct MembersSlabSrc {
+    const int4 *code;
+    PartArgs a;
+    const uint32_t *off;
+    const uint32_t *range;
+    uint32_t *keys, *vals;
+    int32_t *grid;
+    uint32_t ncid;
+    __device__ __forceinline__ void begin(uint32_t gtid, uint32_t gsize) const {
+        for (uint32_t c = gtid; c < ncid; c += gsize) grid[c] = -1;   // (for dm_gather_geo, two launches later)
+    }
+    template <class Add>
+    __device__ __forceinline__ void operator()(uint32_t i, Add &add) const {
+        const uint32_t lo = range[0], hi = range[1];
+        const int4 cd = code[i];
+        const int nx = cd.w & 3, ny = (cd.w >> 2) & 3, nz = (cd.w >> 4) & 3;
+        uint32_t o = off[i];
+        for (int u = 0; u < nx; ++u)
+            for (int v = 0; v < ny; ++v)
+                for (int w = 0; w < nz; ++w) {
+                    uint32_t cid = 0;
+                    if (!grid_cid(a, cd.x + u, cd.y + v, cd.z + w, cid) || cid < lo || cid > hi) continue;
+                    keys[o] = cid;
+                    vals[o] = i;
+                    add(cid);
+                    ++o;
+                }
+    }
+};
+// a key source run for its writes alone (the library-sort fallback has no histogram launch to ride on)
+template <class Src>
+__global__ __launch_bounds__(256) void dm_run_src(Src src, uint32_t n_items) {
+    src.begin(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    auto add = [](uint32_t) {};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) src(i, add);
+}
+// neighbour tables (training-block index of the slab's CSR, or -1) of the test blocks [t0, t1)
+__global__ __launch_bounds__(256) void dm_test_nbr(CandArgs a, const int32_t *__restrict__ grid, const uint32_t *__restrict__ t_entry,
+                                                  uint32_t t0, uint32_t t1, int32_t *nbr) {
+    const uint32_t t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= t1) return;
+    int ix, iy, iz;
+    test_entry_indices(a, t_entry[t], ix, iy, iz);
+    const PartArgs &p = a.part;
     int eb[7][3];
     extended_indices(ix, iy, iz, p.bs, eb);
 #pragma unroll

@@ -28,14 +28,21 @@ def _single(variant, rays):
     return m.leaves(), int(m.stats()["voxel_updates"]), m.training_data()
 
 
-@pytest.mark.parametrize("variant,rays,world,sum_mode", [("d3", 30000, 2, "0"), ("d4", 20000, 3, "0"), ("gp", 8000, 2, "0"),
-                                                          ("d3", 30000, 2, "1"), ("d4", 20000, 3, "1")])
-def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant, rays, world, sum_mode, monkeypatch):
+@pytest.mark.parametrize("variant,rays,world,sum_mode,slab", [("d3", 30000, 2, "0", "1"), ("d4", 20000, 3, "0", "1"), ("gp", 8000, 2, "0", "1"),
+                                                               ("d3", 30000, 2, "1", "1"), ("d4", 20000, 3, "1", "1"), ("d3", 30000, 3, "0", "0"),
+                                                               ("gp", 8000, 3, "0", "1")])
+def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant, rays, world, sum_mode, slab, monkeypatch):
     """sum_mode "1" is the library's default accumulate mode (double sums; table kernel on the un-pruned blocks, general
     kernel on the pruned ones of the second scan): a leaf's sums are formed on exactly one rank by the same kernel as in
-    the single process, so the replicas are bit-identical there too"""
+    the single process, so the replicas are bit-identical there too.
+    slab "1" (round 6; the default for GPOctoMap, where a rank then also trains its slab's blocks only; an option for BGKOctoMap, where the
+    global per-cell histogram costs what the divided sort saves): the x-slab partition — every rank forms the per-block point counts of the whole scan but sorts
+    membership pairs and builds the CSR, the training rows and the neighbour tables for the blocks of its own range of the test list
+    (+ halo) only (devmap_kernels.h "x-slab partition"; src/bgkoctomap/bgkoctomap.cpp:234-284 is the loop that is divided);
+    "0" (LA3DM_SHARD_SLAB=0): the CSR of all training blocks on every rank, as before."""
     monkeypatch.setenv("LA3DM_BGK_SUM", sum_mode)          # the single-process reference below; the workers inherit env
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_DEBUG_SHARD="1", LA3DM_BGK_SUM=sum_mode)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_DEBUG_SHARD="1", LA3DM_BGK_SUM=sum_mode,
+               LA3DM_SHARD_SLAB=slab)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + (os.getpid() % 500)), os.path.join(ROOT, "tests", "helpers", "shard_worker.py"),
            str(tmp_path), variant, str(rays)]
@@ -43,6 +50,14 @@ def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant,
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for rank in range(world):        # the sharded form of the samples' filter really ran, on every rank
         assert f"sharded sample filter: rank {rank} of {world}" in r.stderr, r.stderr[-2000:]
+        assert (f"x-slab partition: rank {rank} of {world}" in r.stderr) == (slab == "1"), r.stderr[-2000:]
+    if slab == "1":                  # ... and a rank's CSR holds a fraction of the scan's membership pairs, not all of them
+        import re
+        pairs = {}
+        for mm in re.finditer(r"x-slab partition: rank (\d+) of \d+ builds the CSR of (\d+) \(block, point\) pairs", r.stderr):
+            pairs.setdefault(int(mm.group(1)), []).append(int(mm.group(2)))
+        last = [pairs[q][-1] for q in range(world)]
+        assert max(last) < 0.9 * sum(last), last
     ref, U, train = _single(variant, rays)
     for rank in range(world):
         got = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
