@@ -76,9 +76,7 @@ struct la3dm_devmap {
     Arena lv_beam, lv_mask;
     Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist;
     Arena cell_cnt, slab_range;   // x-slab partition of a sharded insert: per-cell point counts; {first, last} grid cell of the own slab
-    int shard_slab = getenv("LA3DM_SHARD_SLAB") ? atoi(getenv("LA3DM_SHARD_SLAB")) : -1;   // x-slab partition of a sharded insert: 1 on, 0 off (every rank builds the CSR of all
-                                                                                            // training blocks), -1 (default) = on for GPOctoMap — a rank then also TRAINS its slab's blocks only —, off for BGKOctoMap, where the
-                                                                                            // global per-cell histogram costs what the divided sort saves (measured)
+    int shard_slab = getenv("LA3DM_SHARD_SLAB") ? atoi(getenv("LA3DM_SHARD_SLAB")) : 1;   // x-slab partition of a sharded insert (default); 0 = every rank builds the CSR of all training blocks (A/B)
     bool force_slab = getenv("LA3DM_FORCE_SLAB") && atoi(getenv("LA3DM_FORCE_SLAB")) == 1;   // (test / profiling hook: the x-slab form on an UNSHARDED map, its slab = the whole test list)   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
     Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
     int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
@@ -742,7 +740,7 @@ static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, con
     uint32_t *keep = (uint32_t *)dm->keep.ptr, *nfree = (uint32_t *)dm->nfree.ptr, *keep_off = (uint32_t *)dm->keep_off.ptr,
              *free_off = (uint32_t *)dm->free_off.ptr;
     if (ctx->p.variant == 3) {  // BGKLOctoMap: samples keep their beam, no second voxel filter
-        hipLaunchKernelGGL(dm_l_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
+        hipLaunchKernelGGL(dm_l_beam_count, dim3(std::min<uint32_t>(cdiv(n_h, 256), kBeamCountWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
         if ((rc = exclusive_scan(dm, keep, keep_off, n_h, (int)kCntKept)) != LA3DM_OK) return rc;
         if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw, true)) != LA3DM_OK) return rc;
         if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
@@ -759,7 +757,7 @@ static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, con
         S.n_frees = n_samples - n_beams;
         return training_bbox(dm);
     }
-    hipLaunchKernelGGL(dm_beam_count, dim3(cdiv(n_h, 256)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
+    hipLaunchKernelGGL(dm_beam_count, dim3(std::min<uint32_t>(cdiv(n_h, 256), kBeamCountWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep, nfree, dm->d_cnt);
     if ((rc = exclusive_scan(dm, keep, keep_off, n_h, (int)kCntKept)) != LA3DM_OK) return rc;
     if ((rc = exclusive_scan(dm, nfree, free_off, n_h, (int)kCntFreeRaw, true)) != LA3DM_OK) return rc;
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;
@@ -1075,7 +1073,7 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     int bits = 1;
     while ((1ull << bits) < ncid) ++bits;
     P.cell_bits = bits;
-    const bool want_slab = dm->shard_slab < 0 ? ctx->p.variant == 1 : dm->shard_slab != 0;
+    const bool want_slab = dm->shard_slab != 0;
     if (((dm->shard_world > 1 && dm->shard_fn && want_slab) || dm->force_slab) && max_occ == 1 && ctx->p.variant != 3) {
         // x-slab partition (devmap_kernels.h): only the per-cell point counts are formed for all blocks here; pairs, sort, CSR, rows
         // and neighbour tables follow inside the pass, once the cut is known, for the cells of this rank's slab (build_slab_csr)

@@ -678,7 +678,7 @@ __device__ __forceinline__ uint32_t beam_count(float l, float fr, uint32_t *coun
 // wave-reduced 64-bit total of the per-beam sample counts (the 32-bit offsets wrap silently above 2^32 samples)
 // (one atomic per workgroup of up to 256 threads, all of which call this: every atomic on this one address costs ~25 ns,
 // serialised)
-__device__ __forceinline__ void beam_total_add(uint32_t c, uint32_t *counters) {
+__device__ __forceinline__ void beam_total_add(unsigned long long c, uint32_t *counters) {
     __shared__ unsigned long long s_t[4];
     unsigned long long t = c;
     for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
@@ -691,11 +691,13 @@ __device__ __forceinline__ void beam_total_add(uint32_t c, uint32_t *counters) {
     }
 }
 
+constexpr uint32_t kBeamCountWgs = 256;
 __global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
                                                     uint32_t *nfree, uint32_t *counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0;
-    if (i < n) {
+    // grid-stride over at most kBeamCountWgs workgroups: the 64-bit total is ONE atomic per workgroup on one address (~25 ns per
+    // caller, serialised) — with a workgroup per 256 beams that chain WAS this kernel at configs[4]'s size (1 630 atomics, 24 us)
+    unsigned long long total = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
         const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
         const float s = dx * dx + dy * dy + dz * dz;
@@ -704,10 +706,11 @@ __global__ __launch_bounds__(256) void dm_beam_count(const float *__restrict__ h
         // gap between a float s and R*R is far above half an ulp of the f64 root)
         if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);
         keep[i] = k ? 1u : 0u;
-        c = k ? beam_count(f32_sqrt_cr(s), a.free_res, counters) : 0u;
+        const uint32_t c = k ? beam_count(f32_sqrt_cr(s), a.free_res, counters) : 0u;
         nfree[i] = c;
+        total += c;
     }
-    beam_total_add(c, counters);
+    beam_total_add(total, counters);
 }
 
 // hits that pass the gate -> xy (label 1) in order; their beam samples -> frees (xyz) in order
@@ -859,14 +862,14 @@ __device__ __forceinline__ LBeam l_beam(float x, float y, float z, const BeamArg
 
 __global__ __launch_bounds__(256) void dm_l_beam_count(const float *__restrict__ hits, uint32_t n, BeamArgs a, uint32_t *keep,
                                                       uint32_t *nsamp, uint32_t *counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0;
-    if (i < n) {
+    unsigned long long total = 0;   // (grid-stride, at most kBeamCountWgs workgroups: see dm_beam_count)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float x = hits[3 * (size_t)i], y = hits[3 * (size_t)i + 1], z = hits[3 * (size_t)i + 2];
         const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
         const float s = dx * dx + dy * dy + dz * dz;
         bool k = true;
         if (a.max_range > 0.0f) k = !((double)s > (double)a.max_range * (double)a.max_range);  // see dm_beam_count
+        uint32_t c = 0;
         if (k) {
             const LBeam b = l_beam(x, y, z, a);
             c = 2;  // the re-projected hit and the origin sample
@@ -878,8 +881,9 @@ __global__ __launch_bounds__(256) void dm_l_beam_count(const float *__restrict__
         }
         keep[i] = k ? 1u : 0u;
         nsamp[i] = c;
+        total += c;
     }
-    beam_total_add(c, counters);
+    beam_total_add(total, counters);
 }
 
 __global__ __launch_bounds__(256) void dm_l_beam_write(const float *__restrict__ hits, uint32_t n, BeamArgs a,
@@ -1065,6 +1069,16 @@ __device__ __forceinline__ bool grid_cid(const PartArgs &a, int ix, int iy, int 
     return true;
 }
 
+// the same cell in the COUNT array of the x-slab partition: x fastest.  The training set is sorted by voxel-grid cell, x fastest, so
+// the lanes of a wave hold consecutive x blocks of one (y, z): in the x-major cell index those are ~12 KB apart (one L2 line per
+// lane and atomic), x fastest they share a line
+__device__ __forceinline__ bool grid_cnt_idx(const PartArgs &a, int ix, int iy, int iz, uint32_t &idx) {
+    const int x = ix - a.g0[0], y = iy - a.g0[1], z = iz - a.g0[2];
+    if ((unsigned)x >= (unsigned)a.gn[0] || (unsigned)y >= (unsigned)a.gn[1] || (unsigned)z >= (unsigned)a.gn[2]) return false;
+    idx = ((uint32_t)z * (uint32_t)a.gn[1] + (uint32_t)y) * (uint32_t)a.gn[0] + (uint32_t)x;
+    return true;
+}
+
 // per point: its closed-box candidates per axis, packed {first index x, y, z, nx | ny << 2 | nz << 4} (the f64 index
 // arithmetic runs once; the write pass replays the code), and the number of (block, point) pairs
 __global__ __launch_bounds__(256) void dm_members_count(const float4 *__restrict__ xy, uint32_t n, PartArgs a, uint32_t *cnt,
@@ -1177,8 +1191,10 @@ __global__ __launch_bounds__(256) void dm_count_trained(const uint32_t *__restri
 // counts (dm_candidates<true>), then pairs, sort, CSR, rows and neighbour tables for the cells of the own slab only.
 // cell_cnt[cid] += 1 for every (block cell, point) pair (zero on entry).  The training set is two voxel-filter outputs, i.e. sorted
 // by grid cell: the lanes of a wave mostly share a block, and the sensor's own blocks hold thousands of points — one atomic per
-// lane serialised on those addresses (104 us at configs[4]'s size; matching equal cells by a ballot loop: 55 us, a wave spans ~16
-// blocks along x); so the head of every RUN of equal cells in lane order adds the run's length — one ballot, no loop.
+// lane on the x-major cell index: 104 us at configs[4]'s size; matching equal cells by a ballot loop: 55 us (a wave spans ~16 blocks
+// along x); the head of every RUN of equal cells in lane order adds the run's length — one ballot, no loop: 62 us, i.e. not the
+// number of atomics but WHERE they go: a wave's cells are consecutive in x, ~12 KB apart in the x-major index.  With the count
+// array indexed x fastest (grid_cnt_idx) they share cache lines: 20 us.
 __global__ __launch_bounds__(256) void dm_members_hist(const int4 *__restrict__ code, uint32_t n, PartArgs a, uint32_t *cell_cnt,
                                                       uint32_t *counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1191,7 +1207,7 @@ __global__ __launch_bounds__(256) void dm_members_hist(const int4 *__restrict__ 
         uint32_t c = 0xFFFFFFFFu;
         if (sl < mine) {
             const int w = sl % nz, v = (sl / nz) % ny, u = sl / (nz * ny);
-            if (!grid_cid(a, cd.x + u, cd.y + v, cd.z + w, c)) {
+            if (!grid_cnt_idx(a, cd.x + u, cd.y + v, cd.z + w, c)) {
                 atomicOr(&counters[kCntError], 1u);  // a point outside the index grid: cannot happen
                 c = 0xFFFFFFFFu;
             }
@@ -1211,12 +1227,19 @@ __global__ __launch_bounds__(256) void dm_members_hist(const int4 *__restrict__ 
 __global__ __launch_bounds__(256) void dm_cell_trained(const uint32_t *__restrict__ cell_cnt, uint32_t ncid, PartArgs a, uint32_t *counters) {
     __shared__ uint32_t s_n[4];
     uint32_t c = 0;
-#pragma unroll 8
-    for (uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x; cid < ncid; cid += gridDim.x * blockDim.x) {   // (unrolled: eight loads in flight per thread)
-        if (!cell_cnt[cid]) continue;
-        const uint32_t z = cid % (uint32_t)a.gn[2], y = (cid / (uint32_t)a.gn[2]) % (uint32_t)a.gn[1],
-                       x = cid / ((uint32_t)a.gn[2] * (uint32_t)a.gn[1]);
-        c += (a.mult[0][x] && a.mult[1][y] && a.mult[2][z]) ? 1u : 0u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x; base < ncid; base += 8u * stride) {
+        uint32_t v[8];   // eight loads in flight per thread (most cells are empty; behind a `continue` the compiler issued them one by one: 20 us)
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) v[u] = base + u * stride < ncid ? cell_cnt[base + u * stride] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            if (!v[u]) continue;
+            const uint32_t cid = base + u * stride;   // (cell_cnt is indexed x fastest: grid_cnt_idx)
+            const uint32_t x = cid % (uint32_t)a.gn[0], y = (cid / (uint32_t)a.gn[0]) % (uint32_t)a.gn[1],
+                           z = cid / ((uint32_t)a.gn[0] * (uint32_t)a.gn[1]);
+            c += (a.mult[0][x] && a.mult[1][y] && a.mult[2][z]) ? 1u : 0u;
+        }
     }
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63u) == 0u) s_n[threadIdx.x >> 6] = c;
@@ -1298,7 +1321,7 @@ __global__ __launch_bounds__(256) void dm_candidates(CandArgs a, const int32_t *
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
         uint32_t cid;
-        if (!grid_cid(p, eb[q][0], eb[q][1], eb[q][2], cid)) continue;
+        if (kCounts ? !grid_cnt_idx(p, eb[q][0], eb[q][1], eb[q][2], cid) : !grid_cid(p, eb[q][0], eb[q][1], eb[q][2], cid)) continue;
         const int32_t s = grid[cid];
         if (kCounts ? s == 0 : s < 0) continue;
         any = true;  // the block geometrically holds points (R-tree hit)

@@ -35,8 +35,7 @@ def test_sharded_replicas_equal_the_single_process_map(built, tmp_path, variant,
     """sum_mode "1" is the library's default accumulate mode (double sums; table kernel on the un-pruned blocks, general
     kernel on the pruned ones of the second scan): a leaf's sums are formed on exactly one rank by the same kernel as in
     the single process, so the replicas are bit-identical there too.
-    slab "1" (round 6; the default for GPOctoMap, where a rank then also trains its slab's blocks only; an option for BGKOctoMap, where the
-    global per-cell histogram costs what the divided sort saves): the x-slab partition — every rank forms the per-block point counts of the whole scan but sorts
+    slab "1" (the default, round 6): the x-slab partition — every rank forms the per-block point counts of the whole scan but sorts
     membership pairs and builds the CSR, the training rows and the neighbour tables for the blocks of its own range of the test list
     (+ halo) only (devmap_kernels.h "x-slab partition"; src/bgkoctomap/bgkoctomap.cpp:234-284 is the loop that is divided);
     "0" (LA3DM_SHARD_SLAB=0): the CSR of all training blocks on every rank, as before."""
