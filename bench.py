@@ -491,8 +491,8 @@ def sharded_insert_bench(args, torch, dist, la3dm_amd, rank, world, local_rank, 
                                        f"block-sharded over {world} GPUs: replicated map, contiguous equal-weight ranges of the "
                                        "test blocks per rank, a rank lists the leaves of its own range only, one in-place all-gather-v of the "
                                        "leaves' (alpha, beta, state, key) per insert queued on the map's stream (13 B per leaf, no padding, no "
-                                       "host synchronisation), front end (but the sample filter) + partition + leaf count + commit + prune "
-                                       "redundant on every rank"),
+                                       "host synchronisation); x-slab partition (per-block counts global, membership pairs / sort / CSR / rows per rank for its own slab); "
+                                       "front end (but the sample filter), leaf count, commit + prune redundant on every rank"),
                        "voxel_updates_last_step": int(st["voxel_updates"]), "test_blocks": int(st["n_test_blocks"]),
                        "allgather_v_bytes_total": 13 * int(st["voxel_updates"]) if world > 1 else 0,
                        "process_group": None if dist is None else
