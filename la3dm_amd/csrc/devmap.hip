@@ -85,6 +85,7 @@ struct la3dm_devmap {
     la3dm_devmap_lv_stats lv_stats;
     // block-sharded insert (la3dm_devmap_set_shard)
     int dbg_fail_rank = -1;       // LA3DM_INJECT_FRONT_END_FAILURE at la3dm_devmap_create (a test hook), else -1
+    int dbg_fail_slab_rank = -1;  // LA3DM_INJECT_SLAB_FAILURE: that rank of a sharded map fails in build_slab_csr, i.e. AFTER the cut (test hook)
     int dbg_stuck_at = 0;         // LA3DM_INJECT_SCAN_STUCK = n at la3dm_devmap_create (a test hook): the n-th counter read-back of this
                                   // map reports the look-back loops' "stuck" bit as if a scan launch had found its state dirty
     uint32_t shard_rank = 0, shard_world = 1;
@@ -557,6 +558,7 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
     la3dm_devmap *dm = new la3dm_devmap;
     dm->ctx = ctx;
     if (const char *ev = getenv("LA3DM_INJECT_FRONT_END_FAILURE")) dm->dbg_fail_rank = atoi(ev);   // test hooks, read once
+    if (const char *ev = getenv("LA3DM_INJECT_SLAB_FAILURE")) dm->dbg_fail_slab_rank = atoi(ev);
     if (const char *ev = getenv("LA3DM_INJECT_SCAN_STUCK")) dm->dbg_stuck_at = atoi(ev);
     ctx->n_devmaps++;   // (la3dm_devmap_destroy, also the failure paths' clean-up, counts it down)
     dm->depth = (uint32_t)ctx->p.block_depth;
@@ -1167,6 +1169,8 @@ static int build_slab_csr(la3dm_devmap *dm, ScanPlan &P, const uint32_t *t_ent, 
     const PartArgs &pa = P.pa;
     const uint32_t ncid = (uint32_t)P.ncid;
     int rc;
+    if (dm->dbg_fail_slab_rank >= 0 && dm->shard_world > 1 && dm->dbg_fail_slab_rank == (int)dm->shard_rank)
+        return dm_fail(dm, LA3DM_ERR_OOM, "devmap: injected rank-local failure in the x-slab partition (LA3DM_INJECT_SLAB_FAILURE)");
     DM_RESERVE(dm->slab_range, 8);
     uint32_t *range = (uint32_t *)dm->slab_range.ptr;
     DM_TRY(hipMemsetAsync(range, 0xFF, 4, st));
@@ -1371,12 +1375,16 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         t0s = hb[dm->shard_rank];
         t1s = hb[dm->shard_rank + 1];
     }
+    int rc_slab = LA3DM_OK;
     if (P.slab) {
-        // the cut is known: pairs, sort, CSR and rows of the own slab, then the own range's neighbour tables
-        if ((rc = build_slab_csr(dm, P, t_ent, t0s, t1s)) != LA3DM_OK) return rc;
+        // the cut is known: pairs, sort, CSR and rows of the own slab, then the own range's neighbour tables.  A rank of a sharded
+        // insert that fails here (out of memory for its pairs, ...) must still enter the leaf exchange its peers are about to wait
+        // in: it skips its kernel, hands its range over as "no leaf updated" and reports afterwards (see the exchange below)
+        rc_slab = build_slab_csr(dm, P, t_ent, t0s, t1s);
+        if (rc_slab != LA3DM_OK && !sharded) return rc_slab;
         n_mem = P.n_mem;
         train_off = P.train_off;
-        if (t1s > t0s)
+        if (rc_slab == LA3DM_OK && t1s > t0s)
             hipLaunchKernelGGL(dm_test_nbr, dim3(cdiv(t1s - t0s, 256)), dim3(256), 0, st, ca, (const int32_t *)dm->grid.ptr, t_ent, t0s, t1s,
                                (int32_t *)dm->t_nbr.ptr);
     }
@@ -1432,8 +1440,9 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         s.leaf_off += t0s;
         s.n_test_blk = t1s - t0s;
     }
-    rc = LA3DM_OK;
-    if (s.n_test_blk)
+    rc = rc_slab;
+    const std::string slab_err = rc_slab != LA3DM_OK ? ctx->err : std::string();
+    if (s.n_test_blk && rc_slab == LA3DM_OK)
         rc = ctx->p.variant == 1   ? la3dm_gp_scan_device(ctx, &s, st, nullptr)
              : ctx->p.variant == 3 ? la3dm_bgkl_scan_device(ctx, &s, st, nullptr)
                                    : la3dm_bgk_scan_device(ctx, &s, st, nullptr);
@@ -1446,6 +1455,11 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         // collective (its peers would wait for ever otherwise) and reports afterwards.
         const int rc_kernel = rc;
         const uint32_t *hl = dm->h_shard + (world + 1);
+        if (rc_kernel != LA3DM_OK && hl[dm->shard_rank + 1] > hl[dm->shard_rank]) {
+            // this rank's range goes out as "update() ran on no leaf" (state 0: the write-back skips such leaves), so that every
+            // replica — this one included — stays what it was for these blocks instead of committing whatever the arrays hold
+            (void)hipMemsetAsync((uint8_t *)dm->leaf_state.ptr + hl[dm->shard_rank], 0, hl[dm->shard_rank + 1] - hl[dm->shard_rank], st);
+        }
         for (int g = 0; g < 4; ++g) {
             dm->shard_off[g].resize(world);
             dm->shard_bytes[g].resize(world);
@@ -1467,7 +1481,10 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
             tg0 = wall();
         }
         const int xrc = hl[world] ? dm->shard_fn(dm->shard_user, segs, n_segs, world, dm->shard_rank, (void *)st) : 0;
-        if (rc_kernel != LA3DM_OK) return rc_kernel;
+        if (rc_kernel != LA3DM_OK) {
+            if (!slab_err.empty()) ctx->err = slab_err;
+            return rc_kernel;
+        }
         if (xrc != 0) return dm_fail(dm, LA3DM_ERR_ARG, "devmap: the all-gather callback of the sharded insert failed");
         if (dm->stage_timing) {
             DM_TRY(hipStreamSynchronize(st));

@@ -26,7 +26,7 @@ def main():
         m = la3dm_amd.BGKOctoMap(**dict(la3dm_amd.BGK_YAML, block_depth=int(variant[1:])), device=0)
         fr = 0.5
     m.set_shard(rank, world, sharding.torch_allgather(dist, rank, dev, stage_through_host=True))
-    if os.environ.get("LA3DM_INJECT_FRONT_END_FAILURE") is not None:
+    if os.environ.get("LA3DM_INJECT_FRONT_END_FAILURE") is not None or os.environ.get("LA3DM_INJECT_SLAB_FAILURE") is not None:
         # one rank fails on its own in the front end: EVERY rank's insert must come back with an error (none may wait in a
         # collective the failed rank never enters); the message goes to the test
         xyz, origin = la3dm_amd.synthetic_scan(rays)

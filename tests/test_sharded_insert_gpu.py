@@ -94,6 +94,26 @@ def test_a_rank_local_failure_ends_the_insert_on_every_rank(built, tmp_path, wor
             assert f"rank {failing} failed in its front end" in msg, (rank, msg)
 
 
+@pytest.mark.parametrize("world,failing", [(2, 0), (3, 2)])
+def test_a_failure_after_the_cut_does_not_hang_the_peers(built, tmp_path, world, failing):
+    """A rank that fails AFTER the range cut (round 6: in the x-slab partition — out of memory for its membership pairs, say;
+    LA3DM_INJECT_SLAB_FAILURE) has peers that are about to wait in the leaf exchange: it must still enter it.  It skips its kernel,
+    hands its range over as "update() ran on no leaf" (the write-back skips such leaves on every replica) and reports its own error;
+    the other ranks finish the insert — and the job ends (no hang: the subprocess timeout would catch it)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", LA3DM_INJECT_SLAB_FAILURE=str(failing))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + (os.getpid() % 500)), os.path.join(ROOT, "tests", "helpers", "shard_worker.py"),
+           str(tmp_path), "d3", "8000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for rank in range(world):
+        msg = open(os.path.join(tmp_path, f"rank{rank}.err")).read()
+        if rank == failing:
+            assert "injected rank-local failure in the x-slab partition" in msg, (rank, msg)
+        else:
+            assert msg == "NO ERROR", (rank, msg)
+
+
 def test_allgather_callback_on_rccl_single_rank(built):
     """The transport the driver's multi-GPU runs use is torch.distributed's nccl backend (RCCL); the box these tests run on
     has one GPU, so the sharded tests above exchange over gloo (the same sharding.exchange_v, on pinned host mirrors).  This
