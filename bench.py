@@ -754,6 +754,8 @@ def lv_leg(args, torch, la3dm_amd, _lib, cpu):
         rf["valu_insts"] = sum(e.get("SQ_INSTS_VALU", 0.0) for e in ks)
         rf["insert_traffic_all_kernels"] = cnt["hbm_bytes"]
         # what the kernel is actually limited by: vector-instruction issue (one wave instruction per 4 cycles per SIMD), not HBM
+        rf["limited_by"] = ("VALU issue, not HBM: the point-to-segment distance in the reference's mixed f32 / f64 is ~1 000 vector instructions per wave "
+                            "and candidate batch — `valu_issue.frac` is the fraction that explains the time, `frac` (HBM) is reported because BASELINE's metric asks for it")
         rf["valu_issue"] = {"achieved": rf["valu_insts"] / (k_ms * 1e-3), "peak": 1024 * 2.4e9 / 4.0,
                             "unit": "VALU wave-instr/s (one per 4 cycles per SIMD)",
                             "frac": rf["valu_insts"] / (k_ms * 1e-3) / (1024 * 2.4e9 / 4.0)}
