@@ -100,7 +100,7 @@ struct la3dm_devmap {
     uint32_t n_xy = 0;
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
     uint32_t mailbox_seq = 0;
-    uint32_t scan_resident = kScanResident, radix_resident = kRsResident;   // workgroups the chip holds at once (create)
+    uint32_t scan_resident = kScanResident, radix_resident = kRsResident, radix_resident_wide = 256;   // workgroups the chip holds at once (create)
     uint32_t mailbox_pending = 0;   // sequence number a queued kernel will publish itself (0: none — read_counters launches the publisher)
     bool poisoned = false;  // a failed insert whose block table could not be reconciled with the host's block count
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
@@ -157,12 +157,12 @@ static int sort_begin_src(la3dm_devmap *dm, const Src &src, uint32_t n_items, ui
     if (tiles > dm->radix_tiles) {
         const size_t want = std::max<size_t>(2 * (size_t)tiles, 1024);
         DM_TRY(hipStreamSynchronize(st));
-        const size_t bytes = 2 * 4096 * kRsHistCopies + 64 + 2 * want * 1024;
+        const size_t bytes = 2 * 4096 * kRsHistCopies + 64 + 2 * want * 1024 + 2 * (want / kRsGroup + 1) * 1024;
         DM_RESERVE(dm->radix_state, bytes);
         DM_TRY(hipMemsetAsync(dm->radix_state.ptr, 0, bytes, st));   // on the sorts' own stream
         dm->radix_tiles = want;
     }
-    RadixState &rs = job.rs;   // layout: two histograms (this sort's, the next sort's), 16 spare words, two status arrays
+    RadixState &rs = job.rs;   // layout: two histograms (this sort's, the next sort's), 16 spare words, two status arrays, two group arrays
     uint32_t *base = (uint32_t *)dm->radix_state.ptr;
     rs.hist = base + 1024 * kRsHistCopies * (dm->radix_seq & 1u);
     rs.hist_next = base + 1024 * kRsHistCopies * ((dm->radix_seq + 1u) & 1u);
@@ -170,6 +170,8 @@ static int sort_begin_src(la3dm_devmap *dm, const Src &src, uint32_t n_items, ui
     rs.ticket = base + 2048 * kRsHistCopies;   // (the 16 spare words)
     rs.status[0] = base + 2048 * kRsHistCopies + 16;
     rs.status[1] = rs.status[0] + dm->radix_tiles * 256;
+    rs.agg[0] = rs.status[1] + dm->radix_tiles * 256;
+    rs.agg[1] = rs.agg[0] + (dm->radix_tiles / kRsGroup + 1) * 256;
     job.n_pass = n_pass;
     job.n_bound = n_bound;
     job.begin_bit = begin_bit;
@@ -203,8 +205,13 @@ static int sort_passes(la3dm_devmap *dm, const SortJob &job, const uint32_t *k_i
         a.begin_bit = (uint32_t)job.begin_bit;
         a.counters = dm->d_cnt;
         a.err_slot = (int)kCntError;
-        a.use_ticket = tiles > dm->radix_resident ? 1u : 0u;
-        hipLaunchKernelGGL(dm_radix_pass, dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(kRsThreads), 0, st, a, job.rs);
+        if (tiles <= dm->radix_resident_wide) {   // every tile on the chip at once, sixteen waves each (devmap_sort.h)
+            a.use_ticket = 0u;
+            hipLaunchKernelGGL((dm_radix_pass<1024, 4>), dim3(tiles), dim3(1024), 0, st, a, job.rs);
+        } else {
+            a.use_ticket = tiles > dm->radix_resident ? 1u : 0u;
+            hipLaunchKernelGGL((dm_radix_pass<256, 16>), dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(256), 0, st, a, job.rs);
+        }
         sk = a.k_out;
         sv = a.v_out;
     }
@@ -603,11 +610,12 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         // The single-launch scan and the radix passes hand tiles to at most as many workgroups as the chip holds at once
         // (a workgroup waits for tiles of workgroups that started before it): the bound comes from the occupancy of the
         // kernels as compiled, not from a constant that a change of their register count would silently falsify.
-        int cus = 0, b0 = 0, b1 = 0, b2 = 0;   // (hipGetDeviceProperties would cost tens of ms here)
+        int cus = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;   // (hipGetDeviceProperties would cost tens of ms here)
         ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0 &&
              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, dm_scan_lb<false>, (int)kScanThreads, 0) == hipSuccess &&
              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, dm_scan_lb<true>, (int)kScanThreads, 0) == hipSuccess &&
-             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, dm_radix_pass, (int)kRsThreads, 0) == hipSuccess && b0 > 0 && b1 > 0 && b2 > 0;
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, dm_radix_pass<256, 16>, 256, 0) == hipSuccess &&
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b3, dm_radix_pass<1024, 4>, 1024, 0) == hipSuccess && b0 > 0 && b1 > 0 && b2 > 0 && b3 > 0;
         if (!ok) {
             ctx->err = "la3dm_devmap_create: occupancy query failed";
             la3dm_devmap_destroy(dm);
@@ -615,9 +623,14 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         }
         dm->scan_resident = std::min<uint32_t>(kScanResident, (uint32_t)std::min(b0, b1) * (uint32_t)cus);
         dm->radix_resident = std::min<uint32_t>(kRsResident, (uint32_t)b2 * (uint32_t)cus);
+        dm->radix_resident_wide = (uint32_t)cus;   // (one sixteen-wave workgroup per CU, whatever the occupancy allows: the shape is for tile latency)
         // test hook: a handful of workgroups per launch forces the multi-round (ticket) form of the scan / sort on small inputs
         if (const char *ev = getenv("LA3DM_SCAN_RESIDENT")) dm->scan_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->scan_resident));
-        if (const char *ev = getenv("LA3DM_RADIX_RESIDENT")) dm->radix_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->radix_resident));
+        if (const char *ev = getenv("LA3DM_RADIX_RESIDENT")) {
+            dm->radix_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->radix_resident));
+            dm->radix_resident_wide = std::min(dm->radix_resident_wide, dm->radix_resident);
+        }
+        if (const char *ev = getenv("LA3DM_RADIX_WIDE")) dm->radix_resident_wide = (uint32_t)std::max(0, atoi(ev));   // (A/B: 0 = four-wave tiles only)
     }
     *out = dm;
     return LA3DM_OK;
@@ -2315,6 +2328,23 @@ int la3dm_devmap_diag_sort(la3dm_devmap *dm, const uint32_t *keys, const uint32_
     DM_TRY(hipMemcpyAsync(vals_out, dm->v1.ptr, 4ull * n, hipMemcpyDeviceToHost, st));
     if ((rc = read_counters(dm)) != LA3DM_OK) return rc;   // (carries the "stuck" error bit of the look-back loops)
     DM_TRY(hipStreamSynchronize(st));
+#ifdef LA3DM_RS_TRACE
+    {   // per pass: the phases of the first, a middle and the last tile, relative to the pass's earliest entry stamp (us)
+        std::vector<unsigned long long> tr(4 * 1024 * 8);
+        DM_TRY(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(la3dm_dev::g_rs_trace), 8ull * tr.size()));
+        const uint32_t tiles = std::min(1024u, (n + la3dm_dev::kRsTile - 1) / la3dm_dev::kRsTile), passes = (uint32_t)(bits + 7) / 8;
+        for (uint32_t p = 0; p < passes; ++p) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (uint32_t t = 0; t < tiles; ++t) t0 = std::min(t0, tr[(p * 1024 + t) * 8]), t1 = std::max(t1, tr[(p * 1024 + t) * 8 + 7]);
+            fprintf(stderr, "rs_trace pass %u: %u tiles, first entry -> last end %.2f us\n", p, tiles, (t1 - t0) * 0.01);
+            for (uint32_t t : {0u, tiles / 4, tiles / 2, 3 * tiles / 4, tiles - 1}) {
+                fprintf(stderr, "  tile %4u:", t);
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %6.2f", (double)(long long)(tr[(p * 1024 + t) * 8 + k] - t0) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     return LA3DM_OK;
 }
 

@@ -21,6 +21,7 @@ namespace la3dm_dev {
 
 constexpr uint32_t kScanThreads = 512, kScanItems = 8, kScanTile = kScanThreads * kScanItems;
 constexpr uint32_t kScanInvalid = 0xFFFFFFFFu;
+constexpr int kScanLook = 2;   // status words per lane and look-back round
 
 struct ScanState {
     unsigned long long *status;  // per tile: bits 63..62 = 0 empty / 1 tile aggregate / 2 inclusive prefix; low 32 bits = value
@@ -134,27 +135,41 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
             if (lane == 0) scan_st(&st.status[0], (2ull << 62) | agg);
         } else {
             if (lane == 0) scan_st(&st.status[tile], (1ull << 62) | agg);
+            // kScanLook x 64 predecessors per round: a round is one round trip to the status words (~1 us), and the tiles of a
+            // front-end scan all publish together, so tile t walks over all t of them (a 2 M-element scan has 489)
             int look = (int)tile - 1;
             for (;;) {
-                const int idx = look - (int)lane;
-                unsigned long long s = idx >= 0 ? scan_ld(&st.status[idx]) : (2ull << 62);
-                for (uint32_t spins = 0; __any((s >> 62) == 0ull); ++spins) {
-                    if ((s >> 62) == 0ull) s = scan_ld(&st.status[idx]);
-                    if (spins > (1u << 22)) {   // seconds: the state was not clean when the launch began — give up, flag it
-                        if ((s >> 62) == 0ull) {
-                            atomicOr(&a.counters[a.err_slot], kScanErrStuck);
-                            s = 2ull << 62;
+                unsigned long long s[kScanLook];
+#pragma unroll
+                for (int u = 0; u < kScanLook; ++u) {
+                    const int idx = look - 64 * u - (int)lane;
+                    s[u] = idx >= 0 ? scan_ld(&st.status[idx]) : (2ull << 62);
+                }
+                uint32_t part = 0;
+                bool fin = false;
+#pragma unroll
+                for (int u = 0; u < kScanLook; ++u) {
+                    if (fin) break;
+                    const int idx = look - 64 * u - (int)lane;
+                    for (uint32_t spins = 0; __any((s[u] >> 62) == 0ull); ++spins) {
+                        if ((s[u] >> 62) == 0ull) s[u] = scan_ld(&st.status[idx]);
+                        if (spins > (1u << 22)) {   // seconds: the state was not clean when the launch began — give up, flag it
+                            if ((s[u] >> 62) == 0ull) {
+                                atomicOr(&a.counters[a.err_slot], kScanErrStuck);
+                                s[u] = 2ull << 62;
+                            }
                         }
                     }
+                    const unsigned long long pm = __ballot((s[u] >> 62) == 2ull);
+                    const int first = pm ? __builtin_ctzll(pm) : 64;
+                    part += (int)lane <= first ? (uint32_t)s[u] : 0u;
+                    fin = pm != 0ull;
                 }
-                const unsigned long long pm = __ballot((s >> 62) == 2ull);
-                const int first = pm ? __builtin_ctzll(pm) : 64;
-                uint32_t part = (int)lane <= first ? (uint32_t)s : 0u;
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
                 excl += part;
-                if (pm) break;
-                look -= 64;
+                if (fin) break;
+                look -= 64 * kScanLook;
             }
             if (lane == 0) scan_st(&st.status[tile], (2ull << 62) | (unsigned long long)(excl + agg));
         }
@@ -163,14 +178,31 @@ __global__ __launch_bounds__(kScanThreads) void dm_scan_lb(ScanArgs a, ScanState
     __syncthreads();
     uint32_t run = s_excl + wave_off + (incl - sum);   // exclusive prefix of this thread's first item
     const uint32_t after = kHeads && i0 + kScanItems < a.n ? a.in[i0 + kScanItems] : kScanInvalid;   // key behind my last item
-    // ---- results
+    // ---- results.  A thread's eight prefixes (and head flags) leave as two 16-byte stores where the tile is full: eight
+    // 4-byte stores 32 bytes apart across the lanes touched 64 sectors per instruction (a 2 M-element scan: 19 us)
+    const bool vec = i0 + kScanItems <= a.n;
+    const bool vec_out = vec && a.out && ((uintptr_t)a.out & 15u) == 0, vec_flag = kHeads && vec && a.flag && ((uintptr_t)a.flag & 15u) == 0;
+    if (vec_out) {
+        uint32_t pre[kScanItems], r = run;
+#pragma unroll
+        for (uint32_t u = 0; u < kScanItems; ++u) {
+            pre[u] = r;
+            r += v[u];
+        }
+        *(uint4 *)(a.out + i0) = make_uint4(pre[0], pre[1], pre[2], pre[3]);
+        *(uint4 *)(a.out + i0 + 4) = make_uint4(pre[4], pre[5], pre[6], pre[7]);
+    }
+    if (vec_flag) {
+        *(uint4 *)(a.flag + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+        *(uint4 *)(a.flag + i0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+    }
 #pragma unroll
     for (uint32_t u = 0; u < kScanItems; ++u) {
         const uint32_t i = i0 + u;
         if (i < a.n) {
-            if (a.out) a.out[i] = run;
+            if (a.out && !vec_out) a.out[i] = run;
             if (kHeads) {
-                if (a.flag) a.flag[i] = v[u];
+                if (a.flag && !vec_flag) a.flag[i] = v[u];
                 if (v[u]) {
                     a.seg_start[run] = i;
                     if (a.seg_key) a.seg_key[run] = raw[u];

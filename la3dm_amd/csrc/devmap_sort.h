@@ -15,9 +15,11 @@
 
 namespace la3dm_dev {
 
-constexpr uint32_t kRsThreads = 256, kRsWaves = 4, kRsRows = 16, kRsTile = kRsThreads * kRsRows;   // 4096 items per tile
+constexpr uint32_t kRsThreads = 256;   // histogram launch (thread = digit)
+constexpr uint32_t kRsTile = 4096;     // items per tile (both shapes of the pass kernel)
 constexpr uint32_t kRsErrStuck = 16u;
 constexpr int kRsLook = 16;
+constexpr uint32_t kRsGroup = 16;   // tiles per group of the two-level prefix (<= kRsLook: one thread reads its group's predecessors in one go)
 constexpr uint32_t kRsHistCopies = 8;   // predecessor tiles whose status words are in flight at a time
 
 struct RadixState {
@@ -25,7 +27,9 @@ struct RadixState {
                           // workgroup b of the histogram launch adds into copy b % kRsHistCopies (an atomic on one
                           // address costs ~25 ns per workgroup, serialised), the passes add the copies up
     uint32_t *hist_next;  // the histogram of the NEXT sort: the histogram launch clears it
-    uint32_t *status[2];  // [tiles][256] per array: bits 31..30 = 0 empty / 1 tile count / 2 inclusive prefix, low 30 bits = value
+    uint32_t *status[2];  // [tiles][256] per array: bits 31..30 = 0 empty / 1 tile count, low 30 bits = value
+    uint32_t *agg[2];     // [tiles / kRsGroup][256] per array, one row per group of kRsGroup tiles, written by the group's last tile:
+                          // bits 31..30 = 0 empty / 1 the group's count / 2 inclusive prefix through the group
     uint32_t *ticket;     // [4] one tile ticket per pass (cleared by the histogram launch); used when a pass has more tiles
                           // than workgroups (devmap_scan.h explains why index-assigned tiles are only safe for one round)
 };
@@ -51,8 +55,8 @@ constexpr uint32_t kRsResident = 768;
 __device__ __forceinline__ uint32_t rs_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rs_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// exclusive prefix over the 256 threads' values (one per thread)
-__device__ __forceinline__ uint32_t rs_scan256(uint32_t v, uint32_t tid, uint32_t *s_part) {
+// exclusive prefix over the first 256 threads' values (one per thread; the other threads of the workgroup pass 0 and take part in the barriers)
+__device__ __forceinline__ uint32_t rs_scan_digits(uint32_t v, uint32_t tid, uint32_t *s_part) {
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -65,6 +69,15 @@ __device__ __forceinline__ uint32_t rs_scan256(uint32_t v, uint32_t tid, uint32_
     uint32_t off = 0;
     for (uint32_t w = 0; w < (tid >> 6); ++w) off += s_part[w];
     return off + incl - v;
+}
+
+// "does any digit's thread (tid < 256) say yes", told to the whole workgroup with one barrier (__syncthreads_or is three barriers
+// around an LDS atomic per thread).  A second call may only follow a barrier behind the first one's return.
+__device__ __forceinline__ bool rs_any_digit(bool pred, uint32_t tid, uint32_t *s_flag) {
+    const bool w = __ballot(pred) != 0ull;
+    if (tid < 256u && (tid & 63u) == 0u) s_flag[tid >> 6] = w ? 1u : 0u;
+    __syncthreads();
+    return (s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3]) != 0u;
 }
 
 // digit counts of all passes in one sweep over the keys.  Also clears status array 0 for the first pass and the next
@@ -86,6 +99,7 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist_src(Src src, uint32_
     for (uint32_t p = 0; p < 4; ++p) h[p][tid] = 0;
     const uint32_t n_tiles = (n + kRsTile - 1) / kRsTile;
     for (uint32_t i = blockIdx.x * kRsThreads + tid; i < n_tiles * 256u; i += gridDim.x * kRsThreads) st.status[0][i] = 0u;
+    for (uint32_t i = blockIdx.x * kRsThreads + tid; i < (n_tiles / kRsGroup) * 256u; i += gridDim.x * kRsThreads) st.agg[0][i] = 0u;
     if (blockIdx.x == 0 && tid < 4u) st.ticket[tid] = 0u;
     if (blockIdx.x < kRsHistCopies)
         for (uint32_t p = 0; p < 4; ++p) st.hist_next[(blockIdx.x * 4u + p) * 256u + tid] = 0u;
@@ -111,20 +125,44 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_hist_src(Src src, uint32_
     }
 }
 
-__global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixState st) {
+// -DLA3DM_RS_TRACE: wall_clock64 stamps (10 ns) of thread 0 at the phases of every tile's life, read back and printed by
+// la3dm_devmap_diag_sort (tools/check/sort_trace.py); not part of a product build
+#ifdef LA3DM_RS_TRACE
+__device__ unsigned long long g_rs_trace[4 * 1024 * 8];
+#define RS_STAMP(k)                                                                                       \
+    do {                                                                                                  \
+        if (tid == 0 && tile < 1024u) g_rs_trace[(a.pass * 1024u + tile) * 8u + (k)] = wall_clock64();   \
+    } while (0)
+#else
+#define RS_STAMP(k) do {} while (0)
+#endif
+
+// Two shapes of the same tile of 4096 items.  <1024, 4>: sixteen waves rank four rows each — the shortest tile life (ranking is VALU
+// work: 4 us of a 15 us pass with four waves), one workgroup per CU; for sorts whose tiles all fit on the chip that way (<= 1 M
+// items: the cloud's filter, the membership pairs, the test list).  <256, 16>: four waves, three workgroups per CU — tiles
+// overlap on a CU, for the sorts with more tiles than CUs (the free samples' filter), which are bound by throughput.
+template <uint32_t kThreads, uint32_t kRows>
+__global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_pass(RadixArgs a, RadixState st) {
+    constexpr uint32_t kWaves = kThreads / 64u, kLb = kThreads / 256u;   // kLb: thread groups of 256 (thread group 0 = the digits' own threads)
+    constexpr uint32_t kReaders = kLb > 1u ? kLb - 1u : 1u;             // thread groups that read group entries in a look-back round
+    static_assert(kThreads * kRows == kRsTile && kThreads % 256u == 0u, "tile shape");
     __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
-    __shared__ uint32_t s_wcnt[kRsWaves][256];
-    __shared__ uint32_t s_start[256], s_gbase[256], s_part[kRsThreads / 64], s_tile;
+    __shared__ uint32_t s_wcnt[kWaves][256];
+    __shared__ uint32_t s_start[256], s_gbase[256], s_part[kWaves], s_tile;
+    __shared__ uint32_t s_lb[kReaders][256];      // look-back: the reader groups' partial sums, bit 31 = the group met an inclusive prefix
+    __shared__ uint32_t s_in[256];                // look-back: sum over the tiles before mine in my group
+    __shared__ uint32_t s_done[256];              // look-back: digit finished (its own thread tells the groups)
+    __shared__ uint32_t s_flag[4];                // rs_any_digit
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t dg = tid & 255u, grp = tid >> 8;   // look-back: digit and group (which predecessors of a round) of this thread
+    const bool digit_thread = tid < 256u;             // thread = digit wherever a step is per digit
     if (a.n_dev) a.n = min(a.n, *a.n_dev);
     const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = a.begin_bit + 8u * a.pass;
     uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
-    uint32_t total_d = 0;   // keys with digit tid in this pass (written by the histogram launch)
-#pragma unroll
-    for (uint32_t cpy = 0; cpy < kRsHistCopies; ++cpy) total_d += st.hist[(cpy * 4u + a.pass) * 256u + tid];
-    // every key has the same digit in this pass (the top byte of grid-cell keys, mostly): the pass is a copy
-    const bool copy_pass = __syncthreads_or(total_d == a.n) != 0;
-    const uint32_t digit_base = rs_scan256(total_d, tid, s_part);   // first output position of digit tid
+    uint32_t *agg = st.agg[a.pass & 1u], *other_agg = st.agg[(a.pass + 1u) & 1u];
+#ifdef LA3DM_RS_TRACE
+    const unsigned long long t_entry = wall_clock64();
+#endif
     auto next_tile = [&](uint32_t prev) -> uint32_t {
         if (!a.use_ticket) return prev + gridDim.x;
         __syncthreads();
@@ -132,93 +170,176 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
         __syncthreads();
         return s_tile;
     };
-    for (uint32_t tile = a.use_ticket ? next_tile(0u) : blockIdx.x; tile < n_tiles; tile = next_tile(tile)) {
-    other[tile * 256u + tid] = 0u;   // my row of the array the next pass (or the next sort's second pass) uses
+    // ---- a tile's items: wave w holds items [tile * 4096 + w * kRows * 64, + kRows * 64), row r = 64 consecutive items
+    uint32_t key[kRows], val[kRows], rank[kRows];
+    auto load_tile = [&](uint32_t t) {
+        const uint32_t j0 = t * kRsTile + wave * (kRows * 64u) + lane;
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint32_t i = j0 + r * 64u;
+            key[r] = i < a.n ? a.k_in[i] : 0xFFFFFFFFu;
+            val[r] = i < a.n ? a.v_in[i] : 0u;
+        }
+    };
+    uint32_t tile = a.use_ticket ? next_tile(0u) : blockIdx.x;
+    bool loaded = tile < n_tiles;
+    if (loaded) load_tile(tile);   // the first tile's items are on their way while the histogram is read (a round trip each, ~1 us)
+    uint32_t total_d = 0;   // keys with digit tid in this pass (written by the histogram launch)
+    if (digit_thread) {
+#pragma unroll
+        for (uint32_t cpy = 0; cpy < kRsHistCopies; ++cpy) total_d += st.hist[(cpy * 4u + a.pass) * 256u + tid];
+    }
+    // every key has the same digit in this pass (the top byte of grid-cell keys, mostly): the pass is a copy
+    const bool copy_pass = rs_any_digit(digit_thread && total_d == a.n, tid, s_flag);
+    const uint32_t digit_base = rs_scan_digits(total_d, tid, s_part);   // first output position of digit tid
+    for (; tile < n_tiles; tile = next_tile(tile), loaded = false) {
+#ifdef LA3DM_RS_TRACE
+    if (tid == 0 && tile < 1024u) g_rs_trace[(a.pass * 1024u + tile) * 8u + 0] = t_entry;
+#endif
+    RS_STAMP(1);
+    if (digit_thread) {   // my rows of the arrays the next pass (or the next sort's second pass) uses
+        other[tile * 256u + tid] = 0u;
+        if (tile % kRsGroup == kRsGroup - 1u) other_agg[(tile / kRsGroup) * 256u + tid] = 0u;
+    }
     if (copy_pass) {
         const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
-        for (uint32_t j = tid; j < in_tile; j += kRsThreads) {
+        for (uint32_t j = tid; j < in_tile; j += kThreads) {
             a.k_out[tile * kRsTile + j] = a.k_in[tile * kRsTile + j];
             a.v_out[tile * kRsTile + j] = a.v_in[tile * kRsTile + j];
         }
         continue;
     }
+    if (digit_thread) {
 #pragma unroll
-    for (uint32_t w = 0; w < kRsWaves; ++w) s_wcnt[w][tid] = 0u;
-    __syncthreads();
-    // ---- load: wave w holds items [tile * 4096 + w * 1024, + 1024), row r = 64 consecutive items
-    const uint32_t i0 = tile * kRsTile + wave * (kRsRows * 64u) + lane;
-    uint32_t key[kRsRows], val[kRsRows], rank[kRsRows];
-#pragma unroll
-    for (uint32_t r = 0; r < kRsRows; ++r) {
-        const uint32_t i = i0 + r * 64u;
-        key[r] = i < a.n ? a.k_in[i] : 0xFFFFFFFFu;
-        val[r] = i < a.n ? a.v_in[i] : 0u;
+        for (uint32_t w = 0; w < kWaves; ++w) s_wcnt[w][tid] = 0u;
     }
+    __syncthreads();
+    const uint32_t i0 = tile * kRsTile + wave * (kRows * 64u) + lane;
+    if (!loaded) load_tile(tile);
+#ifdef LA3DM_RS_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    RS_STAMP(2);
     // ---- rank inside the wave, row after row: peers = lanes of the row with my digit
+    // (the wave's counters are read and written through wavefront-scope atomics: a `volatile` pointer made every access a flat,
+    // system-coherent load / store behind s_waitcnt vmcnt(0) — behind the tile's key loads —, most of the 4 us the ranking took)
     const unsigned long long lt = (1ull << lane) - 1ull;
-    volatile uint32_t *wc = s_wcnt[wave];
+    uint32_t *wc = s_wcnt[wave];
 #pragma unroll
-    for (uint32_t r = 0; r < kRsRows; ++r) {
+    for (uint32_t r = 0; r < kRows; ++r) {
         const bool valid = i0 + r * 64u < a.n;
         const uint32_t d = (key[r] >> shift) & 255u;
-        unsigned long long peers = __ballot(valid);
+        uint32_t mlo = 0, mhi = 0;   // lanes whose digit differs from mine in some bit
 #pragma unroll
         for (uint32_t b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+            const int32_t m = __builtin_amdgcn_sbfe((int32_t)key[r], shift + b, 1u);   // my bit b, as 0 / -1
+            const unsigned long long bal = __ballot(m != 0);
+            mlo |= (uint32_t)bal ^ (uint32_t)m;
+            mhi |= (uint32_t)(bal >> 32) ^ (uint32_t)m;
         }
-        const uint32_t prev = wc[d];
+        const unsigned long long peers = __ballot(valid) & ~(((unsigned long long)mhi << 32) | mlo);
+        const uint32_t prev = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         rank[r] = prev + (uint32_t)__popcll(peers & lt);
         __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lt) == 0ull) wc[d] = prev + (uint32_t)__popcll(peers);   // the lowest peer
+        if (valid && (peers & lt) == 0ull) __hip_atomic_store(&wc[d], prev + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // the lowest peer
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    RS_STAMP(3);
     // ---- per digit (thread = digit): count in the tile, wave offsets, tile-local start
     uint32_t cnt = 0;
+    if (digit_thread) {
 #pragma unroll
-    for (uint32_t w = 0; w < kRsWaves; ++w) {
-        const uint32_t c = s_wcnt[w][tid];
-        s_wcnt[w][tid] = cnt;   // exclusive over the waves
-        cnt += c;
+        for (uint32_t w = 0; w < kWaves; ++w) {
+            const uint32_t c = s_wcnt[w][tid];
+            s_wcnt[w][tid] = cnt;   // exclusive over the waves
+            cnt += c;
+        }
+        rs_st(&status[tile * 256u + tid], (1u << 30) | cnt);   // published: my count of digit tid
     }
-    // ---- chained prefix over the tiles, one digit per thread, kRsLook predecessors in flight (all tiles of a front-end
-    // sort are resident at once and publish their counts together: a tile walks back over most of its predecessors)
+    const uint32_t start = rs_scan_digits(cnt, tid, s_part);
+    if (digit_thread) s_start[tid] = start;
+    RS_STAMP(4);
+    // ---- exclusive prefix over the tiles before this one, two levels.  All tiles of a front-end sort are resident at once and
+    // publish their counts together, so a plain decoupled look-back walks over every predecessor: 131 tiles read 8.6 MB of
+    // status words through agent-scope loads, 6 us of a 15 us pass, however many were in flight per round
+    // (tools/check/sort_trace.py).  Now tiles come in groups of kRsGroup: a tile adds up the counts of the tiles before it in
+    // its own group (<= 15 words per digit, read by the digit's own thread) and the group entries before its group, which
+    // each group's last tile publishes: first the group's sum (state 1: needs nothing but its own group's counts, so no
+    // group waits for an earlier one), then, once it knows its own prefix, the inclusive prefix through its group (state 2: cuts the
+    // walk over the groups short in the long sorts, where tiles run in rounds).  The thread groups beside the digits' own read 16 group
+    // entries each per round (the four-wave shape: the digits' own threads, after their group's tiles).
+    const uint32_t q = tile % kRsGroup, grp_idx = tile / kRsGroup;
+    const bool leader = q == kRsGroup - 1u;
+    const bool reader = kLb > 1u ? grp >= 1u : true;
+    const uint32_t ri = kLb > 1u ? grp - 1u : 0u;
+    if (digit_thread) {   // the tiles before mine in my group
+        uint32_t s[kRsLook], part = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kRsLook; ++u) s[u] = u < q ? rs_ld(&status[(tile - 1u - u) * 256u + tid]) : (1u << 30);
+#pragma unroll
+        for (uint32_t u = 0; u < kRsLook; ++u) {
+            for (uint32_t spins = 0; (s[u] >> 30) == 0u; ++spins) {
+                s[u] = rs_ld(&status[(tile - 1u - u) * 256u + tid]);
+                if (spins > (1u << 22)) {   // seconds: the state was not clean when the sort began — give up, flag it
+                    atomicOr(&a.counters[a.err_slot], kRsErrStuck);
+                    s[u] = 1u << 30;
+                }
+            }
+            part += s[u] & 0x3FFFFFFFu;
+        }
+        if (leader) rs_st(&agg[grp_idx * 256u + tid], (1u << 30) | (part + cnt));
+        s_in[tid] = part;
+        s_done[tid] = 0u;
+    }
     uint32_t excl = 0;
-    if (tile == 0) {
-        rs_st(&status[tid], (2u << 30) | cnt);
-    } else {
-        rs_st(&status[tile * 256u + tid], (1u << 30) | cnt);
-    }
-    s_start[tid] = rs_scan256(cnt, tid, s_part);
-    if (tile != 0) {
-        bool done = false;
-        for (int idx = (int)tile - 1; !done; idx -= kRsLook) {
+    bool done = false;
+    for (uint32_t base = 0;; base += kReaders * kRsLook) {
+        uint32_t part = 0;
+        bool found = false;
+        if (reader && !(base != 0u && s_done[dg])) {
+            const int g0 = (int)grp_idx - 1 - (int)(base + ri * kRsLook);
             uint32_t s[kRsLook];
 #pragma unroll
-            for (int u = 0; u < kRsLook; ++u) s[u] = idx - u >= 0 ? rs_ld(&status[(uint32_t)(idx - u) * 256u + tid]) : (2u << 30);
+            for (int u = 0; u < kRsLook; ++u) s[u] = g0 - u >= 0 ? rs_ld(&agg[(uint32_t)(g0 - u) * 256u + dg]) : (2u << 30);
 #pragma unroll
             for (int u = 0; u < kRsLook; ++u) {
-                if (done) break;
+                if (found) break;
                 for (uint32_t spins = 0; (s[u] >> 30) == 0u; ++spins) {
-                    s[u] = rs_ld(&status[(uint32_t)(idx - u) * 256u + tid]);
-                    if (spins > (1u << 22)) {   // seconds: the state was not clean when the sort began — give up, flag it
+                    s[u] = rs_ld(&agg[(uint32_t)(g0 - u) * 256u + dg]);
+                    if (spins > (1u << 22)) {
                         atomicOr(&a.counters[a.err_slot], kRsErrStuck);
                         s[u] = 2u << 30;
                     }
                 }
-                excl += s[u] & 0x3FFFFFFFu;
-                done = (s[u] >> 30) == 2u;
+                part += s[u] & 0x3FFFFFFFu;
+                found = (s[u] >> 30) == 2u;
             }
         }
-        rs_st(&status[tile * 256u + tid], (2u << 30) | (excl + cnt));
+        if (reader) s_lb[ri][dg] = part | (found ? 0x80000000u : 0u);
+        __syncthreads();
+        if (digit_thread && !done) {
+            if (base == 0u) excl = s_in[tid];
+#pragma unroll
+            for (uint32_t g = 0; g < kReaders; ++g) {
+                if (done) break;
+                const uint32_t v = s_lb[g][tid];
+                excl += v & 0x7FFFFFFFu;
+                done = (v >> 31) != 0u;
+            }
+            s_done[tid] = done ? 1u : 0u;
+        }
+        if (!rs_any_digit(digit_thread && !done, tid, s_flag)) break;
     }
-    s_gbase[tid] = digit_base + excl;
+    if (digit_thread) {
+        if (leader) rs_st(&agg[grp_idx * 256u + tid], (2u << 30) | (excl + cnt));
+        s_gbase[tid] = digit_base + excl;
+    }
     __syncthreads();
+    RS_STAMP(5);
     // ---- reorder through LDS, then write runs of equal digits
 #pragma unroll
-    for (uint32_t r = 0; r < kRsRows; ++r) {
+    for (uint32_t r = 0; r < kRows; ++r) {
         if (i0 + r * 64u < a.n) {
             const uint32_t d = (key[r] >> shift) & 255u;
             const uint32_t pos = s_start[d] + s_wcnt[wave][d] + rank[r];
@@ -227,13 +348,15 @@ __global__ __launch_bounds__(kRsThreads) void dm_radix_pass(RadixArgs a, RadixSt
         }
     }
     __syncthreads();
+    RS_STAMP(6);
     const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
-    for (uint32_t j = tid; j < in_tile; j += kRsThreads) {
+    for (uint32_t j = tid; j < in_tile; j += kThreads) {
         const uint32_t k = s_key[j], d = (k >> shift) & 255u;
         const uint32_t g = s_gbase[d] + (j - s_start[d]);
         a.k_out[g] = k;
         a.v_out[g] = s_val[j];
     }
+    RS_STAMP(7);
     __syncthreads();   // the LDS arrays are reused by the next tile
     }
 }
