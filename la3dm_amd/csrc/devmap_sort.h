@@ -3,12 +3,25 @@
 //
 // Why not the library sort: rocPRIM's Onesweep costs three dependent launches per pass (two state resets + the pass)
 // and its merge-sort fallback 7-9 for the sizes that occur here; each dependent launch is ≈ 4.7 us on this GPU whatever it
-// does, and a scan runs three sorts.  Same algorithm family (Onesweep: chained per-digit prefix with decoupled
-// look-back), but the state cleans itself: the histogram launch clears status array 0 and the next sort's histogram,
-// every pass clears the rows of the status array the NEXT pass uses.  Everything is zero between sorts.
+// does, and a scan runs three sorts.  Same algorithm family (Onesweep: per-digit prefix over the tiles through status words in
+// memory), but the state cleans itself: the histogram launch clears status / group array 0 and the next sort's histogram,
+// every pass clears the rows of the arrays the NEXT pass uses.  Everything a sort reads was cleared by the launch before.
 //
-// Stability (the voxel filter's fp32 centroid sums depend on it): a tile is 4 waves x 16 rows x 64 lanes of consecutive
-// items, ranked row by row inside a wave (ballot matching), wave after wave, tile after tile.
+// Stability (the voxel filter's fp32 centroid sums depend on it): a tile is 4096 consecutive items, a wave holds kRows rows
+// of 64 consecutive items, ranked row by row inside the wave (ballot matching), wave after wave, tile after tile.
+//
+// Round 6: where a pass's time goes (wall_clock64 stamps per tile, -DLA3DM_RS_TRACE, tools/check/sort_trace.py; 534 k pairs =
+// 131 tiles, all resident): every dependent trip to memory is ~1 us on this GPU — histogram, keys, the neighbours' status
+// words — and the 15.5 us pass was  1.1 (histogram) + 1.3 (keys) + 4.0 (ranking) + 0.4 + 0.2 … 7 (tile prefix) + 1.0 + 1.5.
+//   * ranking: the wave's LDS counters went through a `volatile` pointer = flat, system-coherent accesses behind
+//     s_waitcnt vmcnt(0); now ds_read / ds_write (wavefront-scope atomics), 9 -> 5 VALU per key bit; sixteen waves rank
+//     four rows each where the whole sort fits on the chip that way (<= 256 tiles): 4.0 -> 1.5 us;
+//   * tile prefix: all tiles publish together, so decoupled look-back walked over EVERY predecessor (131 tiles: 8.6 MB of
+//     agent-scope loads, the same 6 us with 16 or 48 words in flight); now two levels — the tiles before mine in my group of
+//     16, and one entry per earlier group, published by the group's last tile: 7 -> 4.5 us for the last tile;
+//   * the first tile's keys are requested before the histogram is read; __syncthreads_or (three barriers around an LDS
+//     atomic per thread) replaced by one barrier.
+// 15.5 -> 9.7 us in the kernel; the insert of configs[1] 0.576 -> 0.514 ms (ten passes per insert).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,7 +29,7 @@
 namespace la3dm_dev {
 
 constexpr uint32_t kRsThreads = 256;   // histogram launch (thread = digit)
-constexpr uint32_t kRsTile = 4096;     // items per tile (both shapes of the pass kernel)
+constexpr uint32_t kRsTile = 4096;     // items per tile (the status arrays are sized for this; the long sorts' shape takes 8192)
 constexpr uint32_t kRsErrStuck = 16u;
 constexpr int kRsLook = 16;
 constexpr uint32_t kRsGroup = 16;   // tiles per group of the two-level prefix (<= kRsLook: one thread reads its group's predecessors in one go)
@@ -137,16 +150,18 @@ __device__ unsigned long long g_rs_trace[4 * 1024 * 8];
 #define RS_STAMP(k) do {} while (0)
 #endif
 
-// Two shapes of the same tile of 4096 items.  <1024, 4>: sixteen waves rank four rows each — the shortest tile life (ranking is VALU
-// work: 4 us of a 15 us pass with four waves), one workgroup per CU; for sorts whose tiles all fit on the chip that way (<= 1 M
-// items: the cloud's filter, the membership pairs, the test list).  <256, 16>: four waves, three workgroups per CU — tiles
-// overlap on a CU, for the sorts with more tiles than CUs (the free samples' filter), which are bound by throughput.
+// Three shapes of the tile.  <1024, 4>: 4096 items, sixteen waves rank four rows each — the shortest tile life (ranking is VALU
+// work), one workgroup per CU; for sorts whose tiles all fit on the chip that way (<= 1 M items: the cloud's filter, the
+// membership pairs, the test list).  <1024, 8>: 8192 items, for up to 2 M items (the free samples' filter) — still every tile
+// on the chip at once, half as many tiles to add up (17.6 us per pass against 19.6 with the next shape).  <256, 16>: 4096
+// items, four waves, two workgroups per CU — the long sorts, which run their tiles in rounds (through the ticket beyond 512).
 template <uint32_t kThreads, uint32_t kRows>
-__global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_pass(RadixArgs a, RadixState st) {
+__global__ __launch_bounds__(kThreads, kThreads == 1024u ? 4 : 2) void dm_radix_pass(RadixArgs a, RadixState st) {
     constexpr uint32_t kWaves = kThreads / 64u, kLb = kThreads / 256u;   // kLb: thread groups of 256 (thread group 0 = the digits' own threads)
     constexpr uint32_t kReaders = kLb > 1u ? kLb - 1u : 1u;             // thread groups that read group entries in a look-back round
-    static_assert(kThreads * kRows == kRsTile && kThreads % 256u == 0u, "tile shape");
-    __shared__ uint32_t s_key[kRsTile], s_val[kRsTile];
+    constexpr uint32_t kTile = kThreads * kRows;   // items per tile: 4096, or 8192 in the shape for the long sorts
+    static_assert(kTile % kRsTile == 0u && kThreads % 256u == 0u, "tile shape");
+    __shared__ uint32_t s_key[kTile], s_val[kTile];
     __shared__ uint32_t s_wcnt[kWaves][256];
     __shared__ uint32_t s_start[256], s_gbase[256], s_part[kWaves], s_tile;
     __shared__ uint32_t s_lb[kReaders][256];      // look-back: the reader groups' partial sums, bit 31 = the group met an inclusive prefix
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_p
     const uint32_t dg = tid & 255u, grp = tid >> 8;   // look-back: digit and group (which predecessors of a round) of this thread
     const bool digit_thread = tid < 256u;             // thread = digit wherever a step is per digit
     if (a.n_dev) a.n = min(a.n, *a.n_dev);
-    const uint32_t n_tiles = (a.n + kRsTile - 1) / kRsTile, shift = a.begin_bit + 8u * a.pass;
+    const uint32_t n_tiles = (a.n + kTile - 1) / kTile, shift = a.begin_bit + 8u * a.pass;
     uint32_t *status = st.status[a.pass & 1u], *other = st.status[(a.pass + 1u) & 1u];
     uint32_t *agg = st.agg[a.pass & 1u], *other_agg = st.agg[(a.pass + 1u) & 1u];
 #ifdef LA3DM_RS_TRACE
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_p
     // ---- a tile's items: wave w holds items [tile * 4096 + w * kRows * 64, + kRows * 64), row r = 64 consecutive items
     uint32_t key[kRows], val[kRows], rank[kRows];
     auto load_tile = [&](uint32_t t) {
-        const uint32_t j0 = t * kRsTile + wave * (kRows * 64u) + lane;
+        const uint32_t j0 = t * kTile + wave * (kRows * 64u) + lane;
 #pragma unroll
         for (uint32_t r = 0; r < kRows; ++r) {
             const uint32_t i = j0 + r * 64u;
@@ -202,10 +217,10 @@ __global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_p
         if (tile % kRsGroup == kRsGroup - 1u) other_agg[(tile / kRsGroup) * 256u + tid] = 0u;
     }
     if (copy_pass) {
-        const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
+        const uint32_t in_tile = min(kTile, a.n - tile * kTile);
         for (uint32_t j = tid; j < in_tile; j += kThreads) {
-            a.k_out[tile * kRsTile + j] = a.k_in[tile * kRsTile + j];
-            a.v_out[tile * kRsTile + j] = a.v_in[tile * kRsTile + j];
+            a.k_out[tile * kTile + j] = a.k_in[tile * kTile + j];
+            a.v_out[tile * kTile + j] = a.v_in[tile * kTile + j];
         }
         continue;
     }
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_p
         for (uint32_t w = 0; w < kWaves; ++w) s_wcnt[w][tid] = 0u;
     }
     __syncthreads();
-    const uint32_t i0 = tile * kRsTile + wave * (kRows * 64u) + lane;
+    const uint32_t i0 = tile * kTile + wave * (kRows * 64u) + lane;
     if (!loaded) load_tile(tile);
 #ifdef LA3DM_RS_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -273,63 +288,71 @@ __global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_p
     const bool leader = q == kRsGroup - 1u;
     const bool reader = kLb > 1u ? grp >= 1u : true;
     const uint32_t ri = kLb > 1u ? grp - 1u : 0u;
-    if (digit_thread) {   // the tiles before mine in my group
-        uint32_t s[kRsLook], part = 0;
+    constexpr int kAgg = kLb > 1u ? kRsLook : 2 * kRsLook;   // group entries per reader and round (the four-wave shape has one reader group)
+    uint32_t sa[kAgg];
+    auto agg_issue = [&](uint32_t base) {
+        const int g0 = (int)grp_idx - 1 - (int)(base + ri * (uint32_t)kAgg);
 #pragma unroll
-        for (uint32_t u = 0; u < kRsLook; ++u) s[u] = u < q ? rs_ld(&status[(tile - 1u - u) * 256u + tid]) : (1u << 30);
-#pragma unroll
-        for (uint32_t u = 0; u < kRsLook; ++u) {
-            for (uint32_t spins = 0; (s[u] >> 30) == 0u; ++spins) {
-                s[u] = rs_ld(&status[(tile - 1u - u) * 256u + tid]);
-                if (spins > (1u << 22)) {   // seconds: the state was not clean when the sort began — give up, flag it
-                    atomicOr(&a.counters[a.err_slot], kRsErrStuck);
-                    s[u] = 1u << 30;
-                }
-            }
-            part += s[u] & 0x3FFFFFFFu;
-        }
-        if (leader) rs_st(&agg[grp_idx * 256u + tid], (1u << 30) | (part + cnt));
-        s_in[tid] = part;
-        s_done[tid] = 0u;
-    }
+        for (int u = 0; u < kAgg; ++u) sa[u] = g0 - u >= 0 ? rs_ld(&agg[(uint32_t)(g0 - u) * 256u + dg]) : (2u << 30);
+    };
     uint32_t excl = 0;
     bool done = false;
-    for (uint32_t base = 0;; base += kReaders * kRsLook) {
-        uint32_t part = 0;
-        bool found = false;
-        if (reader && !(base != 0u && s_done[dg])) {
-            const int g0 = (int)grp_idx - 1 - (int)(base + ri * kRsLook);
-            uint32_t s[kRsLook];
+    if (tile != 0u) {   // (uniform; tile 0 has nothing before it — a one-tile sort, every pass of a small scan's filters, skips the whole exchange)
+        if (kLb == 1u) agg_issue(0u);   // (four-wave shape: the same threads read both levels — both sets of loads are on their way before either is waited for)
+        if (digit_thread) {   // the tiles before mine in my group
+            uint32_t s[kRsLook], part = 0;
 #pragma unroll
-            for (int u = 0; u < kRsLook; ++u) s[u] = g0 - u >= 0 ? rs_ld(&agg[(uint32_t)(g0 - u) * 256u + dg]) : (2u << 30);
+            for (uint32_t u = 0; u < kRsLook; ++u) s[u] = u < q ? rs_ld(&status[(tile - 1u - u) * 256u + tid]) : (1u << 30);
 #pragma unroll
-            for (int u = 0; u < kRsLook; ++u) {
-                if (found) break;
+            for (uint32_t u = 0; u < kRsLook; ++u) {
                 for (uint32_t spins = 0; (s[u] >> 30) == 0u; ++spins) {
-                    s[u] = rs_ld(&agg[(uint32_t)(g0 - u) * 256u + dg]);
-                    if (spins > (1u << 22)) {
+                    s[u] = rs_ld(&status[(tile - 1u - u) * 256u + tid]);
+                    if (spins > (1u << 22)) {   // seconds: the state was not clean when the sort began — give up, flag it
                         atomicOr(&a.counters[a.err_slot], kRsErrStuck);
-                        s[u] = 2u << 30;
+                        s[u] = 1u << 30;
                     }
                 }
                 part += s[u] & 0x3FFFFFFFu;
-                found = (s[u] >> 30) == 2u;
             }
+            if (leader) rs_st(&agg[grp_idx * 256u + tid], (1u << 30) | (part + cnt));
+            s_in[tid] = part;
+            s_done[tid] = 0u;
         }
-        if (reader) s_lb[ri][dg] = part | (found ? 0x80000000u : 0u);
-        __syncthreads();
-        if (digit_thread && !done) {
-            if (base == 0u) excl = s_in[tid];
+        for (uint32_t base = 0;; base += kReaders * (uint32_t)kAgg) {
+            uint32_t part = 0;
+            bool found = false;
+            if (reader && !(base != 0u && s_done[dg])) {
+                if (!(kLb == 1u && base == 0u)) agg_issue(base);
+                const int g0 = (int)grp_idx - 1 - (int)(base + ri * (uint32_t)kAgg);
 #pragma unroll
-            for (uint32_t g = 0; g < kReaders; ++g) {
-                if (done) break;
-                const uint32_t v = s_lb[g][tid];
-                excl += v & 0x7FFFFFFFu;
-                done = (v >> 31) != 0u;
+                for (int u = 0; u < kAgg; ++u) {
+                    if (found) break;
+                    for (uint32_t spins = 0; (sa[u] >> 30) == 0u; ++spins) {
+                        sa[u] = rs_ld(&agg[(uint32_t)(g0 - u) * 256u + dg]);
+                        if (spins > (1u << 22)) {
+                            atomicOr(&a.counters[a.err_slot], kRsErrStuck);
+                            sa[u] = 2u << 30;
+                        }
+                    }
+                    part += sa[u] & 0x3FFFFFFFu;
+                    found = (sa[u] >> 30) == 2u;
+                }
             }
-            s_done[tid] = done ? 1u : 0u;
+            if (reader) s_lb[ri][dg] = part | (found ? 0x80000000u : 0u);
+            __syncthreads();
+            if (digit_thread && !done) {
+                if (base == 0u) excl = s_in[tid];
+#pragma unroll
+                for (uint32_t g = 0; g < kReaders; ++g) {
+                    if (done) break;
+                    const uint32_t v = s_lb[g][tid];
+                    excl += v & 0x7FFFFFFFu;
+                    done = (v >> 31) != 0u;
+                }
+                s_done[tid] = done ? 1u : 0u;
+            }
+            if (!rs_any_digit(digit_thread && !done, tid, s_flag)) break;
         }
-        if (!rs_any_digit(digit_thread && !done, tid, s_flag)) break;
     }
     if (digit_thread) {
         if (leader) rs_st(&agg[grp_idx * 256u + tid], (2u << 30) | (excl + cnt));
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256u ? 3 : 4) void dm_radix_p
     }
     __syncthreads();
     RS_STAMP(6);
-    const uint32_t in_tile = min(kRsTile, a.n - tile * kRsTile);
+    const uint32_t in_tile = min(kTile, a.n - tile * kTile);
     for (uint32_t j = tid; j < in_tile; j += kThreads) {
         const uint32_t k = s_key[j], d = (k >> shift) & 255u;
         const uint32_t g = s_gbase[d] + (j - s_start[d]);

@@ -81,18 +81,20 @@ __global__ void gp_prepare(const float4 *__restrict__ in, float4 *__restrict__ o
 // + the large blocks (gp_train_kernel's: one wave each, run time ~ N^3) listed largest first: the launch takes them in this
 // order, so the longest factorisations start at once instead of wherever their index puts them (totals[2] = their number);
 // the small non-empty blocks (gp_train_wave_kernel's) follow in the same list, largest first too (totals[3])
-__global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32_t n_blk,
+constexpr uint32_t kGpOffThreads = 1024;   // one workgroup: its threads walk n_blk / 1024 blocks each (256 threads: 86 us at configs[2]'s 31 k
+                                            // blocks, a chain of dependent loads per thread)
+__global__ __launch_bounds__(kGpOffThreads) void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32_t n_blk,
                                   unsigned long long *__restrict__ l_off, unsigned long long *__restrict__ totals,
                                   uint32_t *__restrict__ order) {
-    __shared__ unsigned long long s_sum[256];
-    __shared__ uint32_t s_max[256];
+    __shared__ unsigned long long s_sum[kGpOffThreads];
+    __shared__ uint32_t s_max[kGpOffThreads];
     __shared__ uint32_t s_cls[64];   // large blocks per size class (32-row blocks, capped)
     __shared__ uint32_t s_cls2[33];  // small non-empty blocks per size class (4 points)
     if (threadIdx.x < 64) s_cls[threadIdx.x] = 0;
     if (threadIdx.x < 33) s_cls2[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_blk + 255u) / 256u;
+    const uint32_t per = (n_blk + kGpOffThreads - 1u) / kGpOffThreads;
     const uint32_t b0 = tid * per, b1 = min(n_blk, b0 + per);
     unsigned long long sum = 0;
     uint32_t mx = 0;
@@ -109,7 +111,7 @@ __global__ void gp_factor_offsets(const uint32_t *__restrict__ train_off, uint32
     if (tid == 0) {
         unsigned long long run = 0;
         uint32_t m = 0;
-        for (int i = 0; i < 256; ++i) {
+        for (int i = 0; i < (int)kGpOffThreads; ++i) {
             const unsigned long long t = s_sum[i];
             s_sum[i] = run;
             run += t;

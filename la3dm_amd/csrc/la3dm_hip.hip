@@ -610,7 +610,7 @@ int la3dm_gp_scan_device(la3dm_ctx *ctx, const la3dm_bgk_scan *s, void *stream_,
     if ((rc = arena_reserve(ctx, ctx->gp_totals, 32)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_order, sizeof(uint32_t) * nblk)) != LA3DM_OK) return rc;
     if ((rc = arena_reserve(ctx, ctx->gp_alpha, sizeof(float) * npts)) != LA3DM_OK) return rc;
-    hipLaunchKernelGGL(gp_factor_offsets, dim3(1), dim3(256), 0, stream, s->train_off, s->n_train_blk,
+    hipLaunchKernelGGL(gp_factor_offsets, dim3(1), dim3(kGpOffThreads), 0, stream, s->train_off, s->n_train_blk,
                        (unsigned long long *)ctx->gp_loff.ptr, (unsigned long long *)ctx->gp_totals.ptr, (uint32_t *)ctx->gp_order.ptr);
     unsigned long long sum_n2 = s->train_sum_n2;
     uint32_t max_n = s->train_max_n;

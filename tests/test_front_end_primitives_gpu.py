@@ -1,7 +1,7 @@
 """The device-resident front end's own primitives against numpy: the single-launch exclusive scan (plain and "head flags
 of a sorted key array" forms, la3dm_amd/csrc/devmap_scan.h) and the one-launch-per-pass stable radix sort
-(devmap_sort.h), through their C-ABI test hooks.  Sizes straddle the tile sizes (4096), the resident / ticket switch
-(more than 1024 tiles) and run back to back on one map, so that every launch starts on the state the previous one
+(devmap_sort.h), through their C-ABI test hooks.  Sizes straddle the tile sizes (4096), the sort's tile groups and shapes, the resident / ticket
+switch (more than 1024 / 512 tiles) and run back to back on one map, so that every launch starts on the state the previous one
 left behind (the status arrays and histograms clean themselves)."""
 import ctypes as C
 
@@ -34,7 +34,9 @@ def devmap(built, request):
     H.la3dm_devmap_destroy(dm)
 
 
-SIZES = [1, 2, 63, 64, 65, 4095, 4096, 4097, 12345, 262144, 1000003, 4096 * 512, 4096 * 512 + 1, 3_000_001, 4096 * 1024 + 17, 6_000_011, 7, 4096 * 1024, 5]
+SIZES = [1, 2, 63, 64, 65, 4095, 4096, 4097, 12345, 262144, 1000003, 4096 * 512, 4096 * 512 + 1, 3_000_001, 4096 * 1024 + 17, 6_000_011, 7, 4096 * 1024, 5,
+         # the sort's two-level tile prefix (groups of 16 tiles) and its two tile shapes (sixteen waves up to 256 tiles, four waves beyond)
+         4096 * 16, 4096 * 16 + 1, 4096 * 17 - 1, 4096 * 33, 4096 * 256, 4096 * 256 + 1]
 
 
 def test_exclusive_scan(devmap):
@@ -81,7 +83,7 @@ def test_stable_radix_sort(devmap, bits):
             kinds.append(rng.integers(0, 5, n, dtype=np.uint64) << (bits - 3))                  # few distinct keys, high digits only
             kinds.append(np.minimum(rng.geometric(0.01, n), 2 ** bits - 1).astype(np.uint64))    # skewed
             kinds.append(np.full(n, (2 ** bits - 1) // 3, np.uint64))                            # one key: every pass is a copy
-        if n > 6_000_000:
+        if n > 6_000_000 or n in (4096 * 256, 4096 * 256 + 1):
             kinds = kinds[:1]
         for keys64 in kinds:
             keys = keys64.astype(np.uint32)
