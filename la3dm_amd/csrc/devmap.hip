@@ -101,7 +101,7 @@ struct la3dm_devmap {
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
     uint32_t mailbox_seq = 0;
     uint32_t scan_resident = kScanResident, radix_resident = kRsResident, radix_resident_wide = 256, radix_resident_big = 256;   // workgroups the chip holds at once (create)
-    bool radix_big_tiles = !(getenv("LA3DM_RADIX_BIG") && atoi(getenv("LA3DM_RADIX_BIG")) == 0);   // (A/B: LA3DM_RADIX_BIG=0 sends every sort beyond 256 tiles to the four-wave shape)
+    bool radix_big_tiles = !(getenv("LA3DM_RADIX_BIG") && atoi(getenv("LA3DM_RADIX_BIG")) == 0);   // (A/B: LA3DM_RADIX_BIG=0 sends every sort beyond 256 tiles to the four-wave shape)   // (A/B: LA3DM_RADIX_BIG=0 sends every sort beyond 256 tiles to the four-wave shape)
     uint32_t mailbox_pending = 0;   // sequence number a queued kernel will publish itself (0: none — read_counters launches the publisher)
     bool poisoned = false;  // a failed insert whose block table could not be reconciled with the host's block count
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
@@ -209,9 +209,10 @@ static int sort_passes(la3dm_devmap *dm, const SortJob &job, const uint32_t *k_i
         if (tiles <= dm->radix_resident_wide) {   // every tile on the chip at once, sixteen waves each (devmap_sort.h)
             a.use_ticket = 0u;
             hipLaunchKernelGGL((dm_radix_pass<1024, 4>), dim3(tiles), dim3(1024), 0, st, a, job.rs);
-        } else if (dm->radix_big_tiles && cdiv(n, 2 * kRsTile) <= dm->radix_resident_big) {   // up to ~2 M items (the free samples' filter): 8192-item tiles, still one per CU
-            a.use_ticket = 0u;
-            hipLaunchKernelGGL((dm_radix_pass<1024, 8>), dim3(cdiv(n, 2 * kRsTile)), dim3(1024), 0, st, a, job.rs);
+        } else if (dm->radix_big_tiles) {   // 8192-item tiles, one workgroup per CU: every tile on the chip up to ~2 M items (the free samples' filter), through the ticket beyond
+            const uint32_t t2 = cdiv(n, 2 * kRsTile);
+            a.use_ticket = t2 > dm->radix_resident_big ? 1u : 0u;
+            hipLaunchKernelGGL((dm_radix_pass<1024, 8>), dim3(std::min(t2, dm->radix_resident_big)), dim3(1024), 0, st, a, job.rs);
         } else {
             a.use_ticket = tiles > dm->radix_resident ? 1u : 0u;
             hipLaunchKernelGGL((dm_radix_pass<256, 16>), dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(256), 0, st, a, job.rs);

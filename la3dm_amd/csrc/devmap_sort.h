@@ -152,9 +152,10 @@ __device__ unsigned long long g_rs_trace[4 * 1024 * 8];
 
 // Three shapes of the tile.  <1024, 4>: 4096 items, sixteen waves rank four rows each — the shortest tile life (ranking is VALU
 // work), one workgroup per CU; for sorts whose tiles all fit on the chip that way (<= 1 M items: the cloud's filter, the
-// membership pairs, the test list).  <1024, 8>: 8192 items, for up to 2 M items (the free samples' filter) — still every tile
-// on the chip at once, half as many tiles to add up (17.6 us per pass against 19.6 with the next shape).  <256, 16>: 4096
-// items, four waves, two workgroups per CU — the long sorts, which run their tiles in rounds (through the ticket beyond 512).
+// membership pairs, the test list).  <1024, 8>: 8192 items, everything longer — up to 2 M items (the free samples' filter at
+// configs[1]) every tile is still on the chip at once, half as many tiles to add up (17.6 us per pass against 19.6 with the
+// next shape); beyond that the tiles go out through the ticket (10 M items: 56 us per pass against 66).  <256, 16>: 4096
+// items, four waves, two workgroups per CU — round 5's shape with this round's prefix, kept behind LA3DM_RADIX_BIG=0 for comparison.
 template <uint32_t kThreads, uint32_t kRows>
 __global__ __launch_bounds__(kThreads, kThreads == 1024u ? 4 : 2) void dm_radix_pass(RadixArgs a, RadixState st) {
     constexpr uint32_t kWaves = kThreads / 64u, kLb = kThreads / 256u;   // kLb: thread groups of 256 (thread group 0 = the digits' own threads)
