@@ -201,11 +201,19 @@ __global__ __launch_bounds__(256) void dm_minmax(const float *__restrict__ p, ui
     __shared__ float red[4][6];
     __shared__ uint32_t s_last;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float x = p[(size_t)kStride * i], y = p[(size_t)kStride * i + 1], z = p[(size_t)kStride * i + 2];
-        if (!finite3(x, y, z)) continue;
-        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
-        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    // eight points per thread and trip, their loads in flight together: a trip per point is a round trip to memory per point
+    // (BGK-L's 2.9 M samples on 128 workgroups: 88 dependent trips, 37 us)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 8u * stride) {
+        float q[8][3];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t ij = i + j * stride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[j][c] = ij < n ? p[(size_t)kStride * ij + c] : NAN;   // (box_add skips a NaN point)
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) box_add(mn, mx, q[j][0], q[j][1], q[j][2]);
     }
     minmax_wg(mn, mx, mm, fin, red, &s_last);
 }
