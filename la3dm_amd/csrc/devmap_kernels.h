@@ -1023,10 +1023,21 @@ __global__ __launch_bounds__(256) void dm_append_frees(const float *__restrict__
     __shared__ float red[4][6];
     __shared__ uint32_t s_last;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
-        xy[base + i] = make_float4(x, y, z, label);
-        box_add(mn, mx, x, y, z);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4u * stride) {   // (four points per trip, loads in flight together: see dm_minmax)
+        float q[4][3];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t ij = i + j * stride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[j][c] = ij < n ? pts[3 * (size_t)ij + c] : NAN;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t ij = i + j * stride;
+            if (ij < n) xy[base + ij] = make_float4(q[j][0], q[j][1], q[j][2], label);
+            box_add(mn, mx, q[j][0], q[j][1], q[j][2]);
+        }
     }
     if (!mm) return;   // (uniform) the unfused form
     minmax_wg(mn, mx, mm, fin, red, &s_last);   // mode 2 with mm_extra = the kept hits' box: the training set's box
