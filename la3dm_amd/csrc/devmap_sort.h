@@ -7,7 +7,7 @@
 // memory), but the state cleans itself: the histogram launch clears status / group array 0 and the next sort's histogram,
 // every pass clears the rows of the arrays the NEXT pass uses.  Everything a sort reads was cleared by the launch before.
 //
-// Stability (the voxel filter's fp32 centroid sums depend on it): a tile is 4096 consecutive items, a wave holds kRows rows
+// Stability (the voxel filter's fp32 centroid sums depend on it): a tile is 4096 (or 8192) consecutive items, a wave holds kRows rows
 // of 64 consecutive items, ranked row by row inside the wave (ballot matching), wave after wave, tile after tile.
 //
 // Round 6: where a pass's time goes (wall_clock64 stamps per tile, -DLA3DM_RS_TRACE, tools/check/sort_trace.py; 534 k pairs =
@@ -21,7 +21,7 @@
 //     16, and one entry per earlier group, published by the group's last tile: 7 -> 4.5 us for the last tile;
 //   * the first tile's keys are requested before the histogram is read; __syncthreads_or (three barriers around an LDS
 //     atomic per thread) replaced by one barrier.
-// 15.5 -> 9.7 us in the kernel; the insert of configs[1] 0.576 -> 0.514 ms (ten passes per insert).
+// 15.5 -> 9.7 us in the kernel; the insert of configs[1] 0.576 -> 0.507 ms (ten passes per insert; with the scan's share).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,9 +31,9 @@ namespace la3dm_dev {
 constexpr uint32_t kRsThreads = 256;   // histogram launch (thread = digit)
 constexpr uint32_t kRsTile = 4096;     // items per tile (the status arrays are sized for this; the long sorts' shape takes 8192)
 constexpr uint32_t kRsErrStuck = 16u;
-constexpr int kRsLook = 16;
+constexpr int kRsLook = 16;          // status words per thread in flight in a round of the tile prefix
 constexpr uint32_t kRsGroup = 16;   // tiles per group of the two-level prefix (<= kRsLook: one thread reads its group's predecessors in one go)
-constexpr uint32_t kRsHistCopies = 8;   // predecessor tiles whose status words are in flight at a time
+constexpr uint32_t kRsHistCopies = 8;   // copies of the histogram the histogram launch's workgroups add into (see RadixState.hist)
 
 struct RadixState {
     uint32_t *hist;       // [kRsHistCopies][4][256] digit counts of the sort in flight (zero before its histogram launch):
