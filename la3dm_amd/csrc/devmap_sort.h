@@ -59,10 +59,12 @@ struct RadixArgs {
     uint32_t use_ticket;  // tiles > workgroups of the launch
 };
 
-// A pass has at most kRsResident workgroups (what the chip holds at once: 256 CUs x 3 workgroups at 159 VGPRs); workgroup
+// A pass has at most as many workgroups as the chip holds at once of its shape (devmap.hip asks the occupancy calculator when a
+// map is created: one per CU for the sixteen-wave shapes, two for the four-wave one; kRsResident bounds the latter); workgroup
 // b takes the tiles b, b + G, b + 2 G, ... in this order, and workgroups are handed out in order, so a tile only ever
-// waits for tiles of workgroups that started before its own.  No ticket and no arrival counter: every device-scope atomic with a returned value is
-// a ~2.5 us round trip, and on ONE address they serialise at ~25 ns per workgroup.
+// waits for tiles of workgroups that started before its own.  No ticket and no arrival counter while every tile has its own
+// workgroup: every device-scope atomic with a returned value is a ~2.5 us round trip, and on ONE address they serialise at
+// ~25 ns per workgroup.
 constexpr uint32_t kRsResident = 768;
 
 __device__ __forceinline__ uint32_t rs_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
