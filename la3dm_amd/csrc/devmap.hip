@@ -100,8 +100,7 @@ struct la3dm_devmap {
     uint32_t n_xy = 0;
     bool mailbox = true;      // read_counters through pinned host memory + a sequence number (LA3DM_MAILBOX=0: copy + sync)
     uint32_t mailbox_seq = 0;
-    uint32_t scan_resident = kScanResident, radix_resident = kRsResident, radix_resident_wide = 256, radix_resident_big = 256;   // workgroups the chip holds at once (create)
-    bool radix_big_tiles = !(getenv("LA3DM_RADIX_BIG") && atoi(getenv("LA3DM_RADIX_BIG")) == 0);   // (A/B: LA3DM_RADIX_BIG=0 sends every sort beyond 256 tiles to the four-wave shape)   // (A/B: LA3DM_RADIX_BIG=0 sends every sort beyond 256 tiles to the four-wave shape)
+    uint32_t scan_resident = kScanResident, radix_resident_wide = 256, radix_resident_big = 256;   // workgroups the chip holds at once (create)
     uint32_t mailbox_pending = 0;   // sequence number a queued kernel will publish itself (0: none — read_counters launches the publisher)
     bool poisoned = false;  // a failed insert whose block table could not be reconciled with the host's block count
     bool stage_timing = false;  // LA3DM_TIMING=1 at creation: extra synchronisations that split t_pack / t_kernel / t_commit
@@ -209,13 +208,10 @@ static int sort_passes(la3dm_devmap *dm, const SortJob &job, const uint32_t *k_i
         if (tiles <= dm->radix_resident_wide) {   // every tile on the chip at once, sixteen waves each (devmap_sort.h)
             a.use_ticket = 0u;
             hipLaunchKernelGGL((dm_radix_pass<1024, 4>), dim3(tiles), dim3(1024), 0, st, a, job.rs);
-        } else if (dm->radix_big_tiles) {   // 8192-item tiles, one workgroup per CU: every tile on the chip up to ~2 M items (the free samples' filter), through the ticket beyond
+        } else {   // 8192-item tiles, one workgroup per CU: every tile on the chip up to ~2 M items (the free samples' filter), through the ticket beyond
             const uint32_t t2 = cdiv(n, 2 * kRsTile);
             a.use_ticket = t2 > dm->radix_resident_big ? 1u : 0u;
             hipLaunchKernelGGL((dm_radix_pass<1024, 8>), dim3(std::min(t2, dm->radix_resident_big)), dim3(1024), 0, st, a, job.rs);
-        } else {
-            a.use_ticket = tiles > dm->radix_resident ? 1u : 0u;
-            hipLaunchKernelGGL((dm_radix_pass<256, 16>), dim3(std::min<uint32_t>(tiles, dm->radix_resident)), dim3(256), 0, st, a, job.rs);
         }
         sk = a.k_out;
         sv = a.v_out;
@@ -615,30 +611,28 @@ int la3dm_devmap_create(la3dm_ctx *ctx, la3dm_devmap **out) {
         // The single-launch scan and the radix passes hand tiles to at most as many workgroups as the chip holds at once
         // (a workgroup waits for tiles of workgroups that started before it): the bound comes from the occupancy of the
         // kernels as compiled, not from a constant that a change of their register count would silently falsify.
-        int cus = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;   // (hipGetDeviceProperties would cost tens of ms here)
+        int cus = 0, b0 = 0, b1 = 0, b3 = 0, b4 = 0;   // (hipGetDeviceProperties would cost tens of ms here)
         ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0 &&
              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, dm_scan_lb<false>, (int)kScanThreads, 0) == hipSuccess &&
              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, dm_scan_lb<true>, (int)kScanThreads, 0) == hipSuccess &&
-             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, dm_radix_pass<256, 16>, 256, 0) == hipSuccess &&
              hipOccupancyMaxActiveBlocksPerMultiprocessor(&b3, dm_radix_pass<1024, 4>, 1024, 0) == hipSuccess &&
-             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, dm_radix_pass<1024, 8>, 1024, 0) == hipSuccess && b0 > 0 && b1 > 0 && b2 > 0 && b3 > 0 && b4 > 0;
+             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, dm_radix_pass<1024, 8>, 1024, 0) == hipSuccess && b0 > 0 && b1 > 0 && b3 > 0 && b4 > 0;
         if (!ok) {
             ctx->err = "la3dm_devmap_create: occupancy query failed";
             la3dm_devmap_destroy(dm);
             return LA3DM_ERR_HIP;
         }
         dm->scan_resident = std::min<uint32_t>(kScanResident, (uint32_t)std::min(b0, b1) * (uint32_t)cus);
-        dm->radix_resident = std::min<uint32_t>(kRsResident, (uint32_t)b2 * (uint32_t)cus);
         dm->radix_resident_big = (uint32_t)cus;
         dm->radix_resident_wide = (uint32_t)cus;   // (one sixteen-wave workgroup per CU, whatever the occupancy allows: the shape is for tile latency)
         // test hook: a handful of workgroups per launch forces the multi-round (ticket) form of the scan / sort on small inputs
         if (const char *ev = getenv("LA3DM_SCAN_RESIDENT")) dm->scan_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->scan_resident));
         if (const char *ev = getenv("LA3DM_RADIX_RESIDENT")) {
-            dm->radix_resident = std::max(1, std::min<int>(atoi(ev), (int)dm->radix_resident));
-            dm->radix_resident_wide = std::min(dm->radix_resident_wide, dm->radix_resident);
-            dm->radix_resident_big = std::min(dm->radix_resident_big, dm->radix_resident);
+            const uint32_t cap = (uint32_t)std::max(1, atoi(ev));
+            dm->radix_resident_wide = std::min(dm->radix_resident_wide, cap);
+            dm->radix_resident_big = std::min(dm->radix_resident_big, cap);
         }
-        if (const char *ev = getenv("LA3DM_RADIX_WIDE")) dm->radix_resident_wide = (uint32_t)std::max(0, atoi(ev));   // (A/B: 0 = four-wave tiles only)
+        if (const char *ev = getenv("LA3DM_RADIX_WIDE")) dm->radix_resident_wide = (uint32_t)std::max(0, atoi(ev));   // (A/B: 0 = 8192-item tiles only)
     }
     *out = dm;
     return LA3DM_OK;

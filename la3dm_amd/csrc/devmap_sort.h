@@ -59,13 +59,11 @@ struct RadixArgs {
     uint32_t use_ticket;  // tiles > workgroups of the launch
 };
 
-// A pass has at most as many workgroups as the chip holds at once of its shape (devmap.hip asks the occupancy calculator when a
-// map is created: one per CU for the sixteen-wave shapes, two for the four-wave one; kRsResident bounds the latter); workgroup
-// b takes the tiles b, b + G, b + 2 G, ... in this order, and workgroups are handed out in order, so a tile only ever
-// waits for tiles of workgroups that started before its own.  No ticket and no arrival counter while every tile has its own
-// workgroup: every device-scope atomic with a returned value is a ~2.5 us round trip, and on ONE address they serialise at
-// ~25 ns per workgroup.
-constexpr uint32_t kRsResident = 768;
+// A pass has at most one workgroup per CU (devmap.hip checks with the occupancy calculator, when a map is created, that the chip
+// holds that many at once); workgroup b takes the tiles b, b + G, b + 2 G, ... in this order, and workgroups are handed out in
+// order, so a tile only ever waits for tiles of workgroups that started before its own.  No ticket and no arrival counter while
+// every tile has its own workgroup: every device-scope atomic with a returned value is a ~2.5 us round trip, and on ONE address
+// they serialise at ~25 ns per workgroup.
 
 __device__ __forceinline__ uint32_t rs_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rs_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -152,18 +150,17 @@ __device__ unsigned long long g_rs_trace[4 * 1024 * 8];
 #define RS_STAMP(k) do {} while (0)
 #endif
 
-// Three shapes of the tile.  <1024, 4>: 4096 items, sixteen waves rank four rows each — the shortest tile life (ranking is VALU
-// work), one workgroup per CU; for sorts whose tiles all fit on the chip that way (<= 1 M items: the cloud's filter, the
+// Two shapes of the tile, sixteen waves and one workgroup per CU both.  <1024, 4>: 4096 items, four rows per wave — the shortest
+// tile life (ranking is VALU work); for sorts whose tiles all fit on the chip that way (<= 1 M items: the cloud's filter, the
 // membership pairs, the test list).  <1024, 8>: 8192 items, everything longer — up to 2 M items (the free samples' filter at
-// configs[1]) every tile is still on the chip at once, half as many tiles to add up (17.6 us per pass against 19.6 with the
-// next shape); beyond that the tiles go out through the ticket (10 M items: 56 us per pass against 66).  <256, 16>: 4096
-// items, four waves, two workgroups per CU — round 5's shape with this round's prefix, kept behind LA3DM_RADIX_BIG=0 for comparison.
+// configs[1]) every tile is still on the chip at once, half as many tiles to add up (17.6 us per pass; round 5's four waves x 16
+// rows with this round's prefix: 19.6); beyond that the tiles go out through the ticket (10 M items: 56 us per pass against 66).
 template <uint32_t kThreads, uint32_t kRows>
-__global__ __launch_bounds__(kThreads, kThreads == 1024u ? 4 : 2) void dm_radix_pass(RadixArgs a, RadixState st) {
-    constexpr uint32_t kWaves = kThreads / 64u, kLb = kThreads / 256u;   // kLb: thread groups of 256 (thread group 0 = the digits' own threads)
-    constexpr uint32_t kReaders = kLb > 1u ? kLb - 1u : 1u;             // thread groups that read group entries in a look-back round
+__global__ __launch_bounds__(kThreads, 4) void dm_radix_pass(RadixArgs a, RadixState st) {
+    constexpr uint32_t kWaves = kThreads / 64u;
+    constexpr uint32_t kReaders = kThreads / 256u - 1u;   // thread groups of 256 beside the digits' own: they read the group entries of the tile prefix
     constexpr uint32_t kTile = kThreads * kRows;   // items per tile: 4096, or 8192 in the shape for the long sorts
-    static_assert(kTile % kRsTile == 0u && kThreads % 256u == 0u, "tile shape");
+    static_assert(kTile % kRsTile == 0u && kThreads % 256u == 0u && kThreads >= 512u, "tile shape");
     __shared__ uint32_t s_key[kTile], s_val[kTile];
     __shared__ uint32_t s_wcnt[kWaves][256];
     __shared__ uint32_t s_start[256], s_gbase[256], s_part[kWaves], s_tile;
@@ -286,12 +283,12 @@ __global__ __launch_bounds__(kThreads, kThreads == 1024u ? 4 : 2) void dm_radix_
     // each group's last tile publishes: first the group's sum (state 1: needs nothing but its own group's counts, so no
     // group waits for an earlier one), then, once it knows its own prefix, the inclusive prefix through its group (state 2: cuts the
     // walk over the groups short in the long sorts, where tiles run in rounds).  The thread groups beside the digits' own read 16 group
-    // entries each per round (the four-wave shape: the digits' own threads, after their group's tiles).
+    // entries each per round.
     const uint32_t q = tile % kRsGroup, grp_idx = tile / kRsGroup;
     const bool leader = q == kRsGroup - 1u;
-    const bool reader = kLb > 1u ? grp >= 1u : true;
-    const uint32_t ri = kLb > 1u ? grp - 1u : 0u;
-    constexpr int kAgg = kLb > 1u ? kRsLook : 2 * kRsLook;   // group entries per reader and round (the four-wave shape has one reader group)
+    const bool reader = grp >= 1u;
+    const uint32_t ri = grp - 1u;
+    constexpr int kAgg = kRsLook;   // group entries per reader and round
     uint32_t sa[kAgg];
     auto agg_issue = [&](uint32_t base) {
         const int g0 = (int)grp_idx - 1 - (int)(base + ri * (uint32_t)kAgg);
@@ -301,7 +298,6 @@ __global__ __launch_bounds__(kThreads, kThreads == 1024u ? 4 : 2) void dm_radix_
     uint32_t excl = 0;
     bool done = false;
     if (tile != 0u) {   // (uniform; tile 0 has nothing before it — a one-tile sort, every pass of a small scan's filters, skips the whole exchange)
-        if (kLb == 1u) agg_issue(0u);   // (four-wave shape: the same threads read both levels — both sets of loads are on their way before either is waited for)
         if (digit_thread) {   // the tiles before mine in my group
             uint32_t s[kRsLook], part = 0;
 #pragma unroll
@@ -325,7 +321,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 1024u ? 4 : 2) void dm_radix_
             uint32_t part = 0;
             bool found = false;
             if (reader && !(base != 0u && s_done[dg])) {
-                if (!(kLb == 1u && base == 0u)) agg_issue(base);
+                agg_issue(base);
                 const int g0 = (int)grp_idx - 1 - (int)(base + ri * (uint32_t)kAgg);
 #pragma unroll
                 for (int u = 0; u < kAgg; ++u) {
