@@ -1,6 +1,9 @@
 """Long differential fuzz of the device-resident pool against the oracle (not collected by pytest): seeded random
 scenes, map parameters and scan arguments for the BGK, GP and BGK-L variants, offsets far from the origin included.
-usage: python tests/manual/fuzz_pool.py [first_seed] [n_seeds]"""
+usage: python tests/manual/fuzz_pool.py [first_seed] [n_seeds] [degenerate|big|gp|likely]
+`likely` (round 6): the verification configuration for holders of a real la3dm build — device options bgk_sum 0, fast_trig 3,
+grid_order 1 (and gp_mode 1 for GPOctoMap) against the restatement's set_modes(1, 1) / set_gp_mode(1): Eigen 3.3.7 packet sin / cos,
+pcl::VoxelGrid's own sort order, the Eigen-order GP regressor — bit for bit, all four classes, both map modes."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, la3dm_amd
@@ -9,8 +12,12 @@ from oracle import oracle as O
 # The library's default accumulate mode of the BGK family (BGK, BGK-L, BGK-LV since round 5: double sums, rounded once) is
 # compared with the restatement's double-sum mode within one ulp of alpha / beta (states may differ where p sits within
 # 1e-6 of a threshold); LA3DM_BGK_SUM=0 in the environment runs the ordered mode, bit for bit.  GP is bit-identical in both.
-SUM1 = os.environ.get("LA3DM_BGK_SUM", "1") != "0"
+LIKELY = len(sys.argv) > 3 and sys.argv[3] == "likely"
+SUM1 = os.environ.get("LA3DM_BGK_SUM", "1") != "0" and not LIKELY
 O.set_sum_mode(1 if SUM1 else 0)
+if LIKELY:
+    O.set_modes(1, 1)
+    O.set_gp_mode(1)
 
 def same(m, o, tag, ulp=False):
     a, b = m.leaves(), o.leaves()
@@ -65,6 +72,12 @@ for seed in range(first, first + count):
         assert m.is_device_resident()
         if rng.random() < 0.25:
             m.set_device_resident(False)
+    if LIKELY:
+        m.set_option("bgk_sum", 0)
+        m.set_option("fast_trig", 3)
+        m.set_option("grid_order", 1)
+        if kind == 1:
+            m.set_option("gp_mode", 1)
     offset = rng.choice([0.0, 0.0, 37.3, -412.7, 5000.2]) * np.array([1, rng.choice([0, 1]), 0], np.float32)
     for scan in range(int(rng.integers(4, 9)) if big else int(rng.integers(1, 4))):
         n = int(rng.integers(1, 60 if kind == 1 else (120 if kind == 3 else 500)))
