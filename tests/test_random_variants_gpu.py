@@ -88,14 +88,17 @@ def test_bgklv_random(built):
 
 
 @pytest.mark.parametrize("sum_mode,first,count,flavour", [("0", 300, 14, "degenerate"), ("1", 340, 12, "degenerate"),
-                                                          ("1", 2000, 2, "big"), ("0", 2100, 2, "big"), ("0", 3000, 3, "gp")])
+                                                          ("1", 2000, 2, "big"), ("0", 2100, 2, "big"), ("0", 3000, 3, "gp"),
+                                                          ("0", 60200, 12, "likely")])
 def test_differential_fuzz_sample(built, sum_mode, first, count, flavour):
     """slices of tests/manual/fuzz_pool.py (all four variants, both map modes, offsets, NaN points, hits at the sensor,
     duplicates, bbox and leaf export on the pool) in BOTH accumulate modes of the BGK family: the reference's summation
     order (every seed must match the oracle bit for bit) and the library's default (double sums: within one ulp of the
     restatement's double-sum mode; GP bit for bit).  Flavours (until round 4 only the first was in the
     driver-run suite): degenerate = zero-length beams and duplicate hits; big = clouds of 1 000 - 5 000 points, 4 - 8 fused
-    scans (BGK and BGK-L); gp = GP maps with hundreds of points per block (the matrix-core Cholesky / solve)."""
+    scans (BGK and BGK-L); gp = GP maps with hundreds of points per block (the matrix-core Cholesky / solve); likely (round 6) = the verification
+    configuration for holders of a real la3dm build — fast_trig 3 + grid_order 1 (+ gp_mode 1) on the device against the restatement's
+    Eigen 3.3.7 packet trig, pcl::VoxelGrid sort order and Eigen-order GP, bit for bit, all four classes."""
     import os
     import subprocess
     import sys
