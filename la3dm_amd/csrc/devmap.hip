@@ -21,6 +21,7 @@
 #include "devmap_scan.h"
 #include "devmap_sort.h"
 #include "devmap_lv_kernels.h"
+#include "devmap_depth3.h"
 
 using namespace la3dm_dev;
 
@@ -77,6 +78,7 @@ struct la3dm_devmap {
     Arena lv_hcell, lv_hcnt, lv_hoff, lv_hlist;
     Arena cell_cnt, slab_range;   // x-slab partition of a sharded insert: per-cell point counts; {first, last} grid cell of the own slab
     int shard_slab = getenv("LA3DM_SHARD_SLAB") ? atoi(getenv("LA3DM_SHARD_SLAB")) : 1;   // x-slab partition of a sharded insert (default); 0 = every rank builds the CSR of all training blocks (A/B)
+    int depth3_batch = getenv("LA3DM_DEPTH3") ? atoi(getenv("LA3DM_DEPTH3")) : -1;   // block_depth 3: leaf lists and write-back + prune with 4 / 8 test blocks per wave (devmap_depth3.h); -1 = by the size of the test list, 0 = the general kernels (A/B)
     bool force_slab = getenv("LA3DM_FORCE_SLAB") && atoi(getenv("LA3DM_FORCE_SLAB")) == 1;   // (test / profiling hook: the x-slab form on an UNSHARDED map, its slab = the whole test list)   // ray shortening on the hit grid (devmap_lv_kernels.h, round 6)
     Arena lv_axis, lv_keys, lv_mult, lv_flag, lv_pos, lv_slot, lv_center, lv_cell0, lv_pslot, lv_pmult, lv_info, lv_prune;
     int32_t *d_lvmm = nullptr, *h_lvmm = nullptr;   // bucket bounds of the finite samples (+ their count)
@@ -481,7 +483,10 @@ static int grow_pool(la3dm_devmap *dm, size_t want_blocks) {
     hipStream_t st = dm->ctx->stream;
     // a regrow copies the pool and synchronises: the first allocation leaves room for a few scans' worth of new blocks
     // (9 bytes per node: 164 k blocks of 73 nodes are 108 MB), later ones double
-    size_t cap = std::max<size_t>((dm->cap_blocks ? 2 : 4) * want_blocks, 4096);
+    // (node indices travel as 32-bit words — leaf_node, the write-back's slot * nodes-per-block: a pool ends at 2^32 nodes)
+    const size_t cap_max = 0xFFFFFFFFull / dm->npb;
+    if (want_blocks > cap_max) return dm_fail(dm, LA3DM_ERR_OOM, "devmap: the block pool would exceed 2^32 nodes");
+    size_t cap = std::min(std::max<size_t>((dm->cap_blocks ? 2 : 4) * want_blocks, 4096), cap_max);
     float *A = nullptr, *B = nullptr;
     uint8_t *S = nullptr;
     long long *bk = nullptr;
@@ -1364,9 +1369,20 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     lx.A_w = dm->A;
     lx.B_w = dm->B;
     lx.S_w = dm->S;
-    hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
-                       (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
-                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
+    // test blocks per wave (devmap_depth3.h; measured at configs[4]'s 266 k test blocks: 8 beats 4 by 27 us, at configs[1]'s 42 k they are level)
+    const int d3_env = dm->depth3_batch < 0 ? (n_test >= 65536u ? 8 : 4) : dm->depth3_batch;
+    const uint32_t d3 = dm->depth == 3 && dm->npb == kD3Npb ? (d3_env >= 8 ? 8u : d3_env > 0 ? 4u : 0u) : 0u;
+#define LA3DM_D3_LEAVES(EMIT, KB, GRID, ...) hipLaunchKernelGGL((dm_leaves_d3<EMIT, KB>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__)
+    if (d3 == 8)
+        LA3DM_D3_LEAVES(false, 8, cdiv(n_test, 32), (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
+                        (const float *)dm->B, nleaf, (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
+    else if (d3)
+        LA3DM_D3_LEAVES(false, 4, cdiv(n_test, 16), (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
+                        (const float *)dm->B, nleaf, (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
+    else
+        hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
+                           (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
     if (ctx->p.variant == 3)
         hipLaunchKernelGGL(dm_l_test_stats, dim3(std::min(cdiv(n_test, 256), 32u)), dim3(256), 0, st, (const int32_t *)dm->t_nbr.ptr,
                            (const uint32_t *)P.rows_off, (const uint32_t *)nleaf, n_test, dm->d_cnt);
@@ -1406,13 +1422,22 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     {
         // the emitting launch carries the pass's work counters (train_reads, pair_evals) in a few workgroups of its own
         const uint32_t e0 = own_emit ? t0s : 0u, e1 = own_emit ? t1s : n_test;
-        const uint32_t main_wgs = cdiv(e1 - e0, 4), stat_wgs = ctx->p.variant == 3 ? 0u : std::min(cdiv(n_test, 256), 32u);
+        const uint32_t main_wgs = cdiv(e1 - e0, d3 ? 4 * d3 : 4), stat_wgs = ctx->p.variant == 3 ? 0u : std::min(cdiv(n_test, 256), 32u);
         lx.t_key = stat_wgs ? t_key : nullptr;
         lx.counters_w = dm->d_cnt;
         lx.main_wgs = main_wgs;
         lx.t_begin = e0;
         lx.t_end = e1;
-        if (main_wgs + stat_wgs)
+        if ((main_wgs + stat_wgs) && d3 == 8)
+            LA3DM_D3_LEAVES(true, 8, main_wgs + stat_wgs, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
+                            (const float *)dm->B, nleaf, (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                            (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
+        else if ((main_wgs + stat_wgs) && d3)
+            LA3DM_D3_LEAVES(true, 4, main_wgs + stat_wgs, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
+                            (const float *)dm->B, nleaf, (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                            (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
+#undef LA3DM_D3_LEAVES
+        else if (main_wgs + stat_wgs)
             hipLaunchKernelGGL((dm_leaves<true>), dim3(main_wgs + stat_wgs), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                                (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
                                (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
@@ -1522,6 +1547,18 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         volatile uint32_t *mailbox = nullptr;
         uint32_t mseq = 0;
         publish_with(dm, mailbox, mseq);
+#define LA3DM_D3_COMMIT(KB)                                                                                                                     \
+    hipLaunchKernelGGL((dm_commit_prune_d3<KB>), dim3(std::min(cdiv(cdiv(n_test, KB), 4), kCommitPruneWgs)), dim3(256),                         \
+                       4 * KB * prune_lds_stride(kD3Npb), st, (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off,              \
+                       (const uint32_t *)dm->leaf_node.ptr, own_emit ? (const uint32_t *)dm->leaf_key.ptr : (const uint32_t *)nullptr,           \
+                       (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B,   \
+                       dm->S, dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq)
+        if (d3 == 8)
+            LA3DM_D3_COMMIT(8);
+        else if (d3)
+            LA3DM_D3_COMMIT(4);
+#undef LA3DM_D3_COMMIT
+        else
         hipLaunchKernelGGL(dm_commit_prune, dim3(std::min(cdiv(n_test, 4), kCommitPruneWgs)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off, (const uint32_t *)dm->leaf_node.ptr,
                            own_emit ? (const uint32_t *)dm->leaf_key.ptr : (const uint32_t *)nullptr, (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr,

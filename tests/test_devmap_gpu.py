@@ -547,7 +547,7 @@ def test_cloud_filter_sorts_on_the_digits_the_last_insert_needed(built):
     _same(m, o, "digits")
 
 
-@pytest.mark.parametrize("switch", ["LA3DM_MAILBOX", "LA3DM_PUBLISH_IN_KERNEL", "LA3DM_OWN_SORT", "LA3DM_TEST_SORT", "LA3DM_FORCE_SLAB=1"])
+@pytest.mark.parametrize("switch", ["LA3DM_MAILBOX", "LA3DM_PUBLISH_IN_KERNEL", "LA3DM_OWN_SORT", "LA3DM_TEST_SORT", "LA3DM_FORCE_SLAB=1", "LA3DM_DEPTH3"])
 def test_fallback_switches_give_the_same_map(built, switch):
     """the A/B switches of the front end (copy + sync read-backs, a publish launch per read-back instead of the producing
     kernel's own mailbox write, rocPRIM's sort instead of devmap_sort.h) read their environment once per process: a child
@@ -562,7 +562,8 @@ def test_fallback_switches_give_the_same_map(built, switch):
         return [l for l in r.stdout.splitlines() if l.startswith("CHK")][-1]
 
     # (LA3DM_FORCE_SLAB=1, round 6: the x-slab partition of the sharded insert — per-cell counts first, pairs / sort / CSR / neighbour tables
-    #  inside the pass — on an unsharded map, its "slab" being the whole test list: the same map, leaf for leaf)
+    #  inside the pass — on an unsharded map, its "slab" being the whole test list: the same map, leaf for leaf;
+    #  LA3DM_DEPTH3=0: the general leaf-list / write-back + prune kernels instead of the block_depth-3 forms of devmap_depth3.h)
     name, _, value = switch.partition("=")
     assert run({name: value or "0"}) == run({})
 
