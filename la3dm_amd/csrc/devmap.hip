@@ -22,6 +22,7 @@
 #include "devmap_sort.h"
 #include "devmap_lv_kernels.h"
 #include "devmap_depth3.h"
+#include "devmap_grid_keys.h"
 
 using namespace la3dm_dev;
 
@@ -439,7 +440,11 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
         if (!iv.empty()) DM_TRY(hipMemcpyAsync(v1, hk.data(), 4ull * iv.size(), hipMemcpyHostToDevice, st));
         DM_TRY(hipStreamSynchronize(st));   // (hk is a local)
     }
-    rc = scan_heads(dm, k1, n, flag, scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid, (int)kCntBig, true);
+    // (no head-flag / prefix arrays: their one reader, the chunk descriptors, asks the sorted keys instead — devmap_grid_keys.h;
+    //  LA3DM_GRID_KEYS=0 keeps the round-5 form for A/B)
+    static const bool kGridKeys = !(getenv("LA3DM_GRID_KEYS") && atoi(getenv("LA3DM_GRID_KEYS")) == 0);
+    rc = scan_heads(dm, k1, n, kGridKeys ? nullptr : flag, kGridKeys ? nullptr : scan, seg_start, nullptr, (int)kCntGridSegs, (int)kCntGridValid,
+                    (int)kCntBig, true);
     if (rc != LA3DM_OK) return rc;
     // The centroid kernels take the cell count from the counter block and are sized for the worst case (every point its
     // own cell), so they are queued before the host waits for the counters: the wait and the next launches' latency overlap
@@ -451,6 +456,11 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
     DM_RESERVE(dm->big, 16ull * (n / kBigCellMin + 1));   // {cell, first, end, -} per entry
     const uint32_t nchunk = n / kChunk;
     DM_RESERVE(dm->chunk_desc, 16ull * (nchunk + 1));
+    if (kGridKeys)
+        hipLaunchKernelGGL(dm_grid_centroids_keys, dim3(cdiv(n, 256) + cdiv(nchunk, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
+                           (int)kCntGridSegs, (int)kCntBig, (uint4 *)dm->big.ptr, (float *)out.ptr, cdiv(n, 256), (const uint32_t *)k1,
+                           (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr, kBigCellMin);
+    else
     hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256) + cdiv(nchunk, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
                        (int)kCntGridSegs, (int)kCntBig, (uint4 *)dm->big.ptr, (float *)out.ptr, cdiv(n, 256), (const uint32_t *)flag,
                        (const uint32_t *)scan, (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr, kBigCellMin);
@@ -1138,9 +1148,10 @@ static int partition(la3dm_devmap *dm, ScanPlan &P) {
     DM_RESERVE(dm->c_scan, 4ull * std::max(n_mem, n_entries));
     DM_RESERVE(dm->seg_start, 4ull * (n_mem + 1));
     DM_RESERVE(dm->seg_key, 4ull * (n_mem + 1));
-    uint32_t *sflag = (uint32_t *)dm->c_flag.ptr, *sscan = (uint32_t *)dm->c_scan.ptr;
+    uint32_t *sflag = (uint32_t *)dm->c_flag.ptr;
     uint32_t *train_off = (uint32_t *)dm->seg_start.ptr, *seg_key = (uint32_t *)dm->seg_key.ptr;
-    if ((rc = scan_heads(dm, k1, n_mem, sflag, sscan, train_off, seg_key, (int)kCntGeo, (int)kCntGridValid)) != LA3DM_OK) return rc;
+    // (the head flags have one reader — BGK-L's row flags; the prefix array none: left unwritten)
+    if ((rc = scan_heads(dm, k1, n_mem, ctx->p.variant == 3 ? sflag : nullptr, nullptr, train_off, seg_key, (int)kCntGeo, (int)kCntGridValid)) != LA3DM_OK) return rc;
     if (ctx->p.variant == 3) {  // training rows: hits as degenerate segments, every beam once per block
         DM_RESERVE(dm->l_rflag, 4ull * n_mem);
         DM_RESERVE(dm->l_rscan, 4ull * n_mem);
@@ -1221,8 +1232,7 @@ static int build_slab_csr(la3dm_devmap *dm, ScanPlan &P, const uint32_t *t_ent, 
             hipLaunchKernelGGL((dm_run_src<MembersSlabSrc>), dim3(cdiv(npts, 256)), dim3(256), 0, st, src, npts);
             if ((rc = sort_pairs(dm, k0, k1, v0, v1, n_mem, P.cell_bits)) != LA3DM_OK) return rc;
         }
-        if ((rc = scan_heads(dm, k1, n_mem, (uint32_t *)dm->c_flag.ptr, (uint32_t *)dm->c_scan.ptr, train_off, seg_key, (int)kCntGeo,
-                             (int)kCntGridValid)) != LA3DM_OK)
+        if ((rc = scan_heads(dm, k1, n_mem, nullptr, nullptr, train_off, seg_key, (int)kCntGeo, (int)kCntGridValid)) != LA3DM_OK)
             return rc;
         hipLaunchKernelGGL(dm_gather_geo, dim3(cdiv(n_mem, 256)), dim3(256), 0, st, xy, (const uint32_t *)v1, n_mem, (float4 *)dm->train.ptr,
                            (const uint32_t *)seg_key, dm->d_cnt, pa, (int32_t *)dm->grid.ptr);
