@@ -125,6 +125,12 @@ static int dm_fail(la3dm_devmap *dm, int code, const std::string &msg) {
 // Workgroups of a launch that ends in atomics on a handful of addresses (min/max words, arrival counters): a device-scope
 // atomic on one address costs ~25 ns per workgroup, serialised — 512 workgroups spent 12 us on them, whatever the data.
 constexpr uint32_t kMinmaxWgs = 128;
+// dm_beam_write's workgroups: a thread walks n / (256 x workgroups) beams one after the other, each a chain of two dependent loads before its
+// samples can be written (kept? -> the hit and its offsets), and every workgroup ends in twelve atomics of the two box reductions (~25 ns each,
+// serialised per address).  Kernel trace (profiles/r06/wgs.txt), 128 / 256 / 512 / 1024 workgroups: configs[1]'s 92 k kept hits 25.9 / 30.2 / 35.0 /
+// 33.9 us, configs[4]'s 417 k 75.8 / 62.6 / 66.4 / 84.6 us — 256 from 2^18 kept hits up, 128 below (LA3DM_BEAM_WGS: A/B)
+static const uint32_t kBeamWgsEnv = getenv("LA3DM_BEAM_WGS") ? (uint32_t)std::max(1, atoi(getenv("LA3DM_BEAM_WGS"))) : 0u;
+static inline uint32_t beam_wgs(uint32_t n_h) { return kBeamWgsEnv ? kBeamWgsEnv : (n_h >= (1u << 18) ? 2u * kMinmaxWgs : kMinmaxWgs); }
 
 // ---- library plumbing: device-wide sort / scan (rocPRIM through hipCUB) ---------------------------------
 template <size_t kMergeLimit>
@@ -827,7 +833,7 @@ static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, con
         DM_RESERVE(dm->frees_raw, 12ull * n_free_raw);
         {
             MinmaxFin fin = {1, ds_resolution < 0 ? 1.0f : 1.0f / ds_resolution, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
-            hipLaunchKernelGGL(dm_beam_write<false>, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep,
+            hipLaunchKernelGGL(dm_beam_write<false>, dim3(std::min<uint32_t>(cdiv(n_h, 256), beam_wgs(n_h))), dim3(256), 0, st, d_hits, n_h, ba, keep,
                                keep_off, free_off, xy, (float *)dm->frees_raw.ptr, dm->d_mm, fin, mm_hits, 0.0f, 0, 0);
         }
         d_frees = (const float *)dm->frees_raw.ptr;
@@ -867,7 +873,7 @@ static int front_end_local(la3dm_devmap *dm, const float *d_xyz, uint32_t n, con
                                                                              // rank that cannot hold it fails before the exchange, not inside it
         {
             MinmaxFin fin = {1, inv, dm->d_gp, nullptr, dm->d_cnt, dm->d_mm + 6, nullptr};
-            hipLaunchKernelGGL(dm_beam_write<true>, dim3(std::min<uint32_t>(cdiv(n_h, 256), kMinmaxWgs)), dim3(256), 0, st, d_hits, n_h, ba, keep,
+            hipLaunchKernelGGL(dm_beam_write<true>, dim3(std::min<uint32_t>(cdiv(n_h, 256), beam_wgs(n_h))), dim3(256), 0, st, d_hits, n_h, ba, keep,
                                keep_off, own_off, xy, (float *)dm->frees_raw.ptr, dm->d_mm, fin, mm_hits, inv, lo, hi);
         }
         // 4. this rank's cells.  (The grid's parameters come back with the filter's counters; a rank without samples fetches
