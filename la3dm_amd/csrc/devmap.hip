@@ -467,7 +467,7 @@ static int voxel_grid(la3dm_devmap *dm, const float *d_in, uint32_t n, float lea
                            (int)kCntGridSegs, (int)kCntBig, (uint4 *)dm->big.ptr, (float *)out.ptr, cdiv(n, 256), (const uint32_t *)k1,
                            (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr, kBigCellMin);
     else
-    hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256) + cdiv(nchunk, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
+        hipLaunchKernelGGL(dm_grid_centroids, dim3(cdiv(n, 256) + cdiv(nchunk, 4)), dim3(256), 0, st, d_in, v1, seg_start, dm->d_cnt,
                        (int)kCntGridSegs, (int)kCntBig, (uint4 *)dm->big.ptr, (float *)out.ptr, cdiv(n, 256), (const uint32_t *)flag,
                        (const uint32_t *)scan, (int)kCntGridValid, nchunk, (uint4 *)dm->chunk_desc.ptr, kBigCellMin);
     hipLaunchKernelGGL(dm_grid_centroids_big, dim3(kBigCellWgs), dim3(64), 0, st, d_in, v1, seg_start, dm->d_cnt, (int)kCntBig,
@@ -1259,6 +1259,33 @@ static int build_slab_csr(la3dm_devmap *dm, ScanPlan &P, const uint32_t *t_ent, 
     return LA3DM_OK;
 }
 
+// block_depth 3: the leaf-list and write-back + prune launches with `batch` (4 or 8) test blocks per wave (devmap_depth3.h)
+static void launch_leaves_d3(bool emit, uint32_t batch, uint32_t grid, hipStream_t st, const uint32_t *slot, const uint32_t *counters,
+                             const uint8_t *S, const float *A, const float *B, uint32_t *nleaf, const uint32_t *leaf_off, uint32_t *leaf_key,
+                             float *alpha, float *beta, uint32_t *leaf_node, const LeafExtra &lx) {
+    if (emit && batch == 8)
+        hipLaunchKernelGGL((dm_leaves_d3<true, 8>), dim3(grid), dim3(256), 0, st, slot, counters, S, A, B, nleaf, leaf_off, leaf_key, alpha, beta, leaf_node, lx);
+    else if (emit)
+        hipLaunchKernelGGL((dm_leaves_d3<true, 4>), dim3(grid), dim3(256), 0, st, slot, counters, S, A, B, nleaf, leaf_off, leaf_key, alpha, beta, leaf_node, lx);
+    else if (batch == 8)
+        hipLaunchKernelGGL((dm_leaves_d3<false, 8>), dim3(grid), dim3(256), 0, st, slot, counters, S, A, B, nleaf, leaf_off, leaf_key, alpha, beta, leaf_node, lx);
+    else
+        hipLaunchKernelGGL((dm_leaves_d3<false, 4>), dim3(grid), dim3(256), 0, st, slot, counters, S, A, B, nleaf, leaf_off, leaf_key, alpha, beta, leaf_node, lx);
+}
+static void launch_commit_prune_d3(uint32_t batch, hipStream_t st, const uint32_t *slot, uint32_t n_test, const uint32_t *leaf_off,
+                                   const uint32_t *leaf_node, const uint32_t *leaf_key, const float *alpha, const float *beta,
+                                   const uint8_t *state, float *A, float *B, uint8_t *S, uint32_t *counters, uint32_t *done,
+                                   volatile uint32_t *mailbox, uint32_t mseq) {
+    const dim3 grid(std::min(cdiv(cdiv(n_test, batch), 4), kCommitPruneWgs));
+    const size_t lds = 4 * (size_t)batch * prune_lds_stride(kD3Npb);
+    if (batch == 8)
+        hipLaunchKernelGGL((dm_commit_prune_d3<8>), grid, dim3(256), lds, st, slot, n_test, leaf_off, leaf_node, leaf_key, alpha, beta, state, A, B, S,
+                           counters, done, mailbox, mseq);
+    else
+        hipLaunchKernelGGL((dm_commit_prune_d3<4>), grid, dim3(256), lds, st, slot, n_test, leaf_off, leaf_node, leaf_key, alpha, beta, state, A, B, S,
+                           counters, done, mailbox, mseq);
+}
+
 // One pass over the candidate list (bgkoctomap.cpp:286-353): test-block decision, find-or-create, leaves in
 // LeafIterator order, predict + fuse, write-back, prune.  A pass holds every candidate key once; keys the float
 // stepping of get_blocks_in_bbox repeats come back in later passes, as in the serial reference.
@@ -1388,13 +1415,9 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
     // test blocks per wave (devmap_depth3.h; measured at configs[4]'s 266 k test blocks: 8 beats 4 by 27 us, at configs[1]'s 42 k they are level)
     const int d3_env = dm->depth3_batch < 0 ? (n_test >= 65536u ? 8 : 4) : dm->depth3_batch;
     const uint32_t d3 = dm->depth == 3 && dm->npb == kD3Npb ? (d3_env >= 8 ? 8u : d3_env > 0 ? 4u : 0u) : 0u;
-#define LA3DM_D3_LEAVES(EMIT, KB, GRID, ...) hipLaunchKernelGGL((dm_leaves_d3<EMIT, KB>), dim3(GRID), dim3(256), 0, st, __VA_ARGS__)
-    if (d3 == 8)
-        LA3DM_D3_LEAVES(false, 8, cdiv(n_test, 32), (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
-                        (const float *)dm->B, nleaf, (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
-    else if (d3)
-        LA3DM_D3_LEAVES(false, 4, cdiv(n_test, 16), (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
-                        (const float *)dm->B, nleaf, (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (float *)nullptr, (uint32_t *)nullptr, lx);
+    if (d3)
+        launch_leaves_d3(false, d3, cdiv(n_test, 4 * d3), st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
+                         (const float *)dm->B, nleaf, nullptr, nullptr, nullptr, nullptr, nullptr, lx);
     else
         hipLaunchKernelGGL((dm_leaves<false>), dim3(cdiv(n_test, 4)), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                            (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
@@ -1444,15 +1467,10 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         lx.main_wgs = main_wgs;
         lx.t_begin = e0;
         lx.t_end = e1;
-        if ((main_wgs + stat_wgs) && d3 == 8)
-            LA3DM_D3_LEAVES(true, 8, main_wgs + stat_wgs, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
-                            (const float *)dm->B, nleaf, (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
-                            (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
-        else if ((main_wgs + stat_wgs) && d3)
-            LA3DM_D3_LEAVES(true, 4, main_wgs + stat_wgs, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
-                            (const float *)dm->B, nleaf, (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
-                            (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
-#undef LA3DM_D3_LEAVES
+        if ((main_wgs + stat_wgs) && d3)
+            launch_leaves_d3(true, d3, main_wgs + stat_wgs, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt, (const uint8_t *)dm->S, (const float *)dm->A,
+                             (const float *)dm->B, nleaf, (const uint32_t *)leaf_off, (uint32_t *)dm->leaf_key.ptr, (float *)dm->leaf_alpha.ptr,
+                             (float *)dm->leaf_beta.ptr, (uint32_t *)dm->leaf_node.ptr, lx);
         else if (main_wgs + stat_wgs)
             hipLaunchKernelGGL((dm_leaves<true>), dim3(main_wgs + stat_wgs), dim3(256), 0, st, (const uint32_t *)dm->t_slot.ptr, dm->d_cnt,
                                (const uint8_t *)dm->S, (const float *)dm->A, (const float *)dm->B, dm->npb, dm->depth, nleaf,
@@ -1563,19 +1581,13 @@ static int run_pass(la3dm_devmap *dm, ScanPlan &P, uint32_t pass, uint32_t *n_te
         volatile uint32_t *mailbox = nullptr;
         uint32_t mseq = 0;
         publish_with(dm, mailbox, mseq);
-#define LA3DM_D3_COMMIT(KB)                                                                                                                     \
-    hipLaunchKernelGGL((dm_commit_prune_d3<KB>), dim3(std::min(cdiv(cdiv(n_test, KB), 4), kCommitPruneWgs)), dim3(256),                         \
-                       4 * KB * prune_lds_stride(kD3Npb), st, (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off,              \
-                       (const uint32_t *)dm->leaf_node.ptr, own_emit ? (const uint32_t *)dm->leaf_key.ptr : (const uint32_t *)nullptr,           \
-                       (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B,   \
-                       dm->S, dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq)
-        if (d3 == 8)
-            LA3DM_D3_COMMIT(8);
-        else if (d3)
-            LA3DM_D3_COMMIT(4);
-#undef LA3DM_D3_COMMIT
+        if (d3)
+            launch_commit_prune_d3(d3, st, (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off, (const uint32_t *)dm->leaf_node.ptr,
+                                   own_emit ? (const uint32_t *)dm->leaf_key.ptr : (const uint32_t *)nullptr, (const float *)dm->leaf_alpha.ptr,
+                                   (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr, dm->A, dm->B, dm->S, dm->d_cnt,
+                                   dm->d_mm + kArriveBase, mailbox, mseq);
         else
-        hipLaunchKernelGGL(dm_commit_prune, dim3(std::min(cdiv(n_test, 4), kCommitPruneWgs)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
+            hipLaunchKernelGGL(dm_commit_prune, dim3(std::min(cdiv(n_test, 4), kCommitPruneWgs)), dim3(256), 4 * prune_lds_stride(dm->npb), st,
                            (const uint32_t *)dm->t_slot.ptr, n_test, (const uint32_t *)leaf_off, (const uint32_t *)dm->leaf_node.ptr,
                            own_emit ? (const uint32_t *)dm->leaf_key.ptr : (const uint32_t *)nullptr, (const float *)dm->leaf_alpha.ptr, (const float *)dm->leaf_beta.ptr, (const uint8_t *)dm->leaf_state.ptr,
                            dm->A, dm->B, dm->S, dm->npb, dm->depth, dm->d_cnt, dm->d_mm + kArriveBase, mailbox, mseq);
